@@ -1,0 +1,92 @@
+"""ctypes binding of libdoda_hip.so (include/doda_hip.h).
+
+There is no fallback: if the shared library is missing or lacks a symbol, importing the product
+path raises.  PyTorch is used only for device memory and streams; every signature below is
+plain pointers + sizes.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdoda_hip.so")
+
+c_i32, c_i64, c_f32, c_sz, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/doda_hip.h one to one
+_SIGNATURES = {
+    "doda_abi_version": (c_i32, []),
+    "doda_strerror": (C.c_char_p, [c_i32]),
+    "doda_voxelize_idx_h": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, C.POINTER(c_vp),
+                                    C.POINTER(c_i32), C.POINTER(c_i32)]),
+    "doda_voxelize_idx_fill_h": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
+    "doda_voxelize_idx_free_h": (None, [c_vp]),
+    "doda_voxelize_idx_workspace_bytes": (c_sz, [c_i32]),
+    "doda_voxelize_idx_assign": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "doda_voxelize_idx_fill": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                       c_sz, c_vp]),
+    "doda_voxelize_fp": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "doda_voxelize_bp": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "doda_point_recover_fp": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "doda_point_recover_bp": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "doda_rulebook_workspace_bytes": (c_sz, [c_i32]),
+    "doda_rulebook_subm": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_sz, c_vp]),
+    "doda_rulebook_down2_assign": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                           c_sz, c_vp]),
+    "doda_rulebook_down2_tables": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp]),
+    "doda_rulebook_pairs_workspace_bytes": (c_sz, [c_i32, c_i32]),
+    "doda_rulebook_pairs": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_sz,
+                                    c_vp]),
+    "doda_spconv_gather_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
+                                       c_i32, c_vp]),
+    "doda_spconv_wgrad_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "doda_spconv_wgrad_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
+                                      c_vp, c_sz, c_vp]),
+    "doda_spconv_gather_bf16_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
+    "doda_spconv_gather_bf16": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
+                                        c_i32, c_vp, c_sz, c_vp]),
+    "doda_spconv_wgrad_bf16": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
+                                       c_vp, c_sz, c_vp]),
+    "doda_maxpool_fwd_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "doda_maxpool_bwd_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "doda_knnquery": (c_i32, [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "doda_knn_batch": (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "doda_ballquery_workspace_bytes": (c_sz, [c_i32]),
+    "doda_ballquery_batch_p": (c_i32, [c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                       C.POINTER(c_i32), c_vp, c_sz, c_vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class DodaNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded C-ABI library; raises DodaNativeError if it is not built (no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DodaNativeError(
+                "libdoda_hip.so is not built (%s). Run `python -m doda_amd.build` "
+                "(hipcc, gfx950). doda_amd has no CPU fallback for its native ops." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise DodaNativeError("libdoda_hip.so lacks symbol %s (stale build?)" % name) from e
+            fn.restype = res
+            fn.argtypes = args
+        if handle.doda_abi_version() != 1:
+            raise DodaNativeError("libdoda_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().doda_strerror(status).decode()
+        raise DodaNativeError("%s failed: %s (%d)" % (what, msg, status))

@@ -1,0 +1,95 @@
+// Shared device/host helpers for libdoda_hip.so (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/doda_hip.h"
+
+#define DODA_WAVE 64
+
+static inline int doda_check_launch() {
+    return hipGetLastError() == hipSuccess ? DODA_OK : DODA_ERR_LAUNCH;
+}
+
+static inline hipStream_t as_stream(doda_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static inline uint32_t next_pow2(uint32_t x) {
+    uint32_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cell-id hash table.  One 64-bit word per slot: (cell id : 32 | value : 32).  A single
+// atomicCAS inserts; because the key sits in the high half, atomicMin on the whole word keeps
+// the smallest value among inserts of the same key (first-touch numbering needs exactly that).
+// Capacity is a power of two >= 2 * n (load factor <= 0.5), linear probing.
+// ---------------------------------------------------------------------------------------------
+#define DODA_HASH_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ uint32_t hash_mix(uint32_t k) {
+    k ^= k >> 16;
+    k *= 0x7feb352du;
+    k ^= k >> 15;
+    k *= 0x846ca68bu;
+    k ^= k >> 16;
+    return k;
+}
+
+// insert (key, val); duplicates of key keep the minimum val.
+__device__ __forceinline__ void hash_insert_min(unsigned long long *tab, uint32_t mask,
+                                                uint32_t key, uint32_t val) {
+    const unsigned long long mine = ((unsigned long long)key << 32) | val;
+    uint32_t slot = hash_mix(key) & mask;
+    for (;;) {
+        unsigned long long old = atomicCAS(&tab[slot], DODA_HASH_EMPTY, mine);
+        if (old == DODA_HASH_EMPTY) return;
+        if ((uint32_t)(old >> 32) == key) {
+            if (mine < old) atomicMin(&tab[slot], mine);
+            return;
+        }
+        slot = (slot + 1) & mask;
+    }
+}
+
+// returns the value stored for key, or -1.
+__device__ __forceinline__ int hash_find(const unsigned long long *__restrict__ tab,
+                                         uint32_t mask, uint32_t key) {
+    uint32_t slot = hash_mix(key) & mask;
+    for (;;) {
+        unsigned long long cur = tab[slot];
+        if (cur == DODA_HASH_EMPTY) return -1;
+        if ((uint32_t)(cur >> 32) == key) return (int)(uint32_t)cur;
+        slot = (slot + 1) & mask;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave / block primitives
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// number of set bits of a 64-bit ballot mask strictly below this lane
+__device__ __forceinline__ int mask_rank(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+}
+
+// inclusive wave scan (sum) over 64 lanes
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int n = __shfl_up(v, d, 64);
+        if (lane_id() >= d) v += n;
+    }
+    return v;
+}
+
+// Exclusive prefix sum over int32 arrays of any length: three launches, deterministic.
+// ws_ints: scratch of at least scan_ws_ints(n) ints.  Optionally writes the grand total.
+size_t scan_ws_ints(int n);
+int exclusive_scan_i32(const int32_t *in, int32_t *out, int n, int32_t *total_out, int32_t *ws,
+                       hipStream_t stream);

@@ -1,0 +1,150 @@
+"""SparseConv U-Net of DODA, as a caller of doda_amd.spconv.
+
+The reference's own model files (model/unet.py:15-69, model/unet_block.py:9-100) run unchanged on
+top of doda_amd.spconv; they cannot travel to the GPU box, so bench.py and
+smoke() drive this counterpart.  It has the same layer graph (7 levels, channels
+16*i, block_reps residual blocks per stage, BN(eps=1e-4, momentum=0.1) -> ReLU -> conv
+pre-activation order, k2s2 down / inverse up sharing `spconv{i}`, concatenation skip, BN weight 1 /
+bias 0 init) and the same module names, so state dicts are interchangeable with the reference's
+checkpoints (`input_conv.0.weight`, `unet.blocks.block0.conv_branch.2.weight`, `unet.conv.2.weight`,
+`unet.u...`, `unet.deconv.2.weight`, `unet.blocks_tail.block0.i_branch.0.weight`, `linear.weight`).
+tests/test_model_graph.py checks that equivalence against the reference files when they are
+present.
+"""
+import functools
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import pointgroup_ops, spconv
+from .spconv.modules import SparseModule
+
+
+def default_cfg(n_classes=20, in_channel=3, mid_channel=16, block_reps=2, block_residual=True,
+                use_xyz=False, voxel_mode=4):
+    """The keys SparseConvNet reads, with cfgs/scannet/spconv.yaml's values (:16-21)."""
+    backbone = SimpleNamespace(in_channel=in_channel, mid_channel=mid_channel, block_reps=block_reps,
+                               block_residual=block_residual, use_xyz=use_xyz)
+    return SimpleNamespace(MODEL=SimpleNamespace(BACKBONE=backbone),
+                           COMMON_CLASSES=SimpleNamespace(n_classes=n_classes),
+                           DATA_CONFIG=SimpleNamespace(
+                               DATA_PROCESSOR=SimpleNamespace(voxel_mode=voxel_mode),
+                               DATA_CLASS=SimpleNamespace(n_classes=n_classes, ignore_label=255)))
+
+
+def _shallow(t):
+    """A second SparseConvTensor header over the same features / rulebooks: SparseSequential
+    re-binds `.features` on the object it is given, so a branch that must keep the incoming
+    features takes its own header (reference unet_block.py:33,89)."""
+    c = spconv.SparseConvTensor(t.features, t.indices, t.spatial_shape, t.batch_size)
+    return c
+
+
+def _subm3(cin, cout, key):
+    return spconv.SubMConv3d(cin, cout, kernel_size=3, padding=1, bias=False, indice_key=key)
+
+
+class ResidualBlock(SparseModule):
+    """y = conv_branch(x) + i_branch(x); i_branch is Identity or a 1x1 SubM when Cin != Cout."""
+
+    def __init__(self, in_channels, out_channels, norm_fn, indice_key=None):
+        super().__init__()
+        skip = nn.Identity() if in_channels == out_channels else \
+            spconv.SubMConv3d(in_channels, out_channels, kernel_size=1, bias=False)
+        self.i_branch = spconv.SparseSequential(skip)
+        self.conv_branch = spconv.SparseSequential(
+            norm_fn(in_channels), nn.ReLU(), _subm3(in_channels, out_channels, indice_key),
+            norm_fn(out_channels), nn.ReLU(), _subm3(out_channels, out_channels, indice_key))
+
+    def forward(self, input):
+        skip = self.i_branch(_shallow(input))
+        out = self.conv_branch(input)
+        out.features += skip.features
+        return out
+
+
+class VGGBlock(SparseModule):
+    def __init__(self, in_channels, out_channels, norm_fn, indice_key=None):
+        super().__init__()
+        self.conv_layers = spconv.SparseSequential(
+            norm_fn(in_channels), nn.ReLU(), _subm3(in_channels, out_channels, indice_key))
+
+    def forward(self, input):
+        return self.conv_layers(input)
+
+
+class UBlock(nn.Module):
+    """One U-Net level: blocks -> [down -> UBlock(level+1) -> up -> cat -> blocks_tail]."""
+
+    def __init__(self, nPlanes, norm_fn, block_reps, block, indice_key_id=1):
+        super().__init__()
+        self.nPlanes = nPlanes
+        c = nPlanes[0]
+        subm_key, down_key = "subm%d" % indice_key_id, "spconv%d" % indice_key_id
+        self.blocks = spconv.SparseSequential(OrderedDict(
+            ("block%d" % r, block(c, c, norm_fn, indice_key=subm_key)) for r in range(block_reps)))
+        if len(nPlanes) > 1:
+            c_next = nPlanes[1]
+            self.conv = spconv.SparseSequential(
+                norm_fn(c), nn.ReLU(),
+                spconv.SparseConv3d(c, c_next, kernel_size=2, stride=2, bias=False, indice_key=down_key))
+            self.u = UBlock(nPlanes[1:], norm_fn, block_reps, block, indice_key_id=indice_key_id + 1)
+            self.deconv = spconv.SparseSequential(
+                norm_fn(c_next), nn.ReLU(),
+                spconv.SparseInverseConv3d(c_next, c, kernel_size=2, bias=False, indice_key=down_key))
+            self.blocks_tail = spconv.SparseSequential(OrderedDict(
+                ("block%d" % r, block(c * (2 - r) if r < 2 else c, c, norm_fn, indice_key=subm_key))
+                for r in range(block_reps)))
+
+    def forward(self, input):
+        out = self.blocks(input)
+        if len(self.nPlanes) > 1:
+            skip = _shallow(out)
+            dec = self.deconv(self.u(self.conv(out)))
+            out.features = torch.cat((skip.features, dec.features), dim=1)
+            out = self.blocks_tail(out)
+        return out
+
+
+class SparseConvNet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        bb = cfg.MODEL.BACKBONE
+        try:
+            n_classes = cfg.COMMON_CLASSES.n_classes
+        except AttributeError:
+            n_classes = cfg.DATA_CONFIG.DATA_CLASS.n_classes
+        m = bb.mid_channel
+        norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+        block = ResidualBlock if bb.block_residual else VGGBlock
+        self.input_conv = spconv.SparseSequential(_subm3(bb.in_channel, m, "subm1"))
+        self.unet = UBlock([m * i for i in range(1, 8)], norm_fn, bb.block_reps, block, indice_key_id=1)
+        self.output_layer = spconv.SparseSequential(norm_fn(m), nn.ReLU())
+        self.linear = nn.Linear(m, n_classes)
+        for mod in self.modules():  # reference set_bn_init (unet.py:51-56)
+            if "BatchNorm" in mod.__class__.__name__:
+                mod.weight.data.fill_(1.0)
+                mod.bias.data.fill_(0.0)
+
+    def forward(self, input, input_map, return_mid_feat=False):
+        out = self.output_layer(self.unet(self.input_conv(input)))
+        point_feats = out.features[input_map.long()]  # voxel -> point
+        scores = self.linear(point_feats.to(self.linear.weight.dtype))
+        return (point_feats, scores) if return_mid_feat else scores
+
+
+def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32):
+    """reference model/unet.py:72-99 (test_model_feat): H2D, voxel mean-pooling, network."""
+    voxel_coords = batch["voxel_locs"].to(device, non_blocking=True)
+    p2v = batch["p2v_map"].to(device, non_blocking=True)
+    v2p = batch["v2p_map"].to(device, non_blocking=True)
+    feats = batch["feats"].to(device, non_blocking=True)
+    if cfg.MODEL.BACKBONE.use_xyz:
+        feats = torch.cat((feats, batch["locs_float"].to(device, non_blocking=True)), 1)
+    voxel_feats = pointgroup_ops.voxelization(feats, v2p, cfg.DATA_CONFIG.DATA_PROCESSOR.voxel_mode)
+    batch_size = batch["offsets"].numel() - 1
+    inp = spconv.SparseConvTensor(voxel_feats.to(feature_dtype), voxel_coords.int(),
+                                  batch["spatial_shape"], batch_size)
+    return model(inp, p2v)

@@ -1,0 +1,284 @@
+"""Tensor-level entry points over the C ABI (include/doda_hip.h).
+
+Each function validates tensors, allocates outputs/workspaces from PyTorch's caching allocator,
+and makes exactly the native calls — no arithmetic happens in Python and there is no CPU fallback
+(device tensors are required wherever the ABI takes device pointers).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError("doda_amd native ops need device (ROCm) tensors; got a %s tensor — "
+                               "there is no CPU fallback" % t.device)
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------
+# voxelisation
+# ------------------------------------------------------------------------------------------
+def voxelize_idx_host(coords, batch_size, mode=4):
+    """CPU point->voxel maps; reference PG_OP.voxelize_idx (voxelize.cpp:10-31).
+
+    coords: int64 CPU [N, 3|4].  Returns (output_coords int64 [M,ncol], input_map int32 [N],
+    output_map int32 [M, 1+maxActive])."""
+    if coords.is_cuda or coords.dtype != torch.int64 or coords.dim() != 2:
+        raise RuntimeError("voxelize_idx_host: coords must be a CPU int64 [N,3|4] tensor")
+    coords = coords.contiguous()
+    n, ncol = coords.shape
+    input_map = torch.zeros(n, dtype=torch.int32)
+    handle = C.c_void_p()
+    n_active, max_active = C.c_int32(), C.c_int32()
+    check(lib().doda_voxelize_idx_h(_p(coords), n, ncol, int(batch_size), int(mode), _p(input_map),
+                                    C.byref(handle), C.byref(n_active), C.byref(max_active)),
+          "doda_voxelize_idx_h")
+    out_coords = torch.zeros((n_active.value, ncol), dtype=torch.int64)
+    out_map = torch.zeros((n_active.value, max_active.value + 1), dtype=torch.int32)
+    check(lib().doda_voxelize_idx_fill_h(handle, _p(coords), _p(out_coords), _p(out_map)),
+          "doda_voxelize_idx_fill_h")
+    return out_coords, input_map, out_map
+
+
+def voxelize_idx_device(coords, batch_size, mode=4):
+    """Device version of voxelize_idx (same results); coords int64 device [N,3|4]."""
+    _need_cuda(coords)
+    if coords.dtype != torch.int64 or coords.dim() != 2:
+        raise RuntimeError("voxelize_idx_device: coords must be int64 [N,3|4]")
+    coords = coords.contiguous()
+    n, ncol = coords.shape
+    dev = coords.device
+    input_map = torch.zeros(n, dtype=torch.int32, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    nbytes = lib().doda_voxelize_idx_workspace_bytes(n)
+    ws = _ws(nbytes, dev)
+    check(lib().doda_voxelize_idx_assign(_p(coords), n, ncol, int(mode), _p(input_map), _p(counts),
+                                         _p(ws), ws.numel(), _stream()), "doda_voxelize_idx_assign")
+    m, max_active = (int(v) for v in counts.tolist())  # one D2H sync: sizes of the outputs
+    max_active = max(max_active, 1)
+    out_coords = torch.zeros((m, ncol), dtype=torch.int64, device=dev)
+    out_map = torch.zeros((m, max_active + 1), dtype=torch.int32, device=dev)
+    check(lib().doda_voxelize_idx_fill(_p(coords), n, ncol, int(mode), m, max_active,
+                                       _p(out_coords), _p(out_map), _p(ws), ws.numel(), _stream()),
+          "doda_voxelize_idx_fill")
+    return out_coords, input_map, out_map
+
+
+def _pool_args(feats, out, rules):
+    _need_cuda(feats, out, rules)
+    if feats.dtype != torch.float32 or out.dtype != torch.float32 or rules.dtype != torch.int32:
+        raise RuntimeError("voxel pooling: feats/out must be float32 and rules int32")
+    if not (feats.is_contiguous() and out.is_contiguous() and rules.is_contiguous()):
+        raise RuntimeError("voxel pooling: tensors must be contiguous")
+
+
+def voxelize_fp(feats, out, rules, mode, n_active, max_active, n_plane):
+    _pool_args(feats, out, rules)
+    check(lib().doda_voxelize_fp(_p(feats), _p(out), _p(rules), int(mode), int(n_active),
+                                 int(max_active), int(n_plane), _stream()), "doda_voxelize_fp")
+
+
+def voxelize_bp(d_out, d_feats, rules, mode, n_active, max_active, n_plane):
+    _pool_args(d_out, d_feats, rules)
+    check(lib().doda_voxelize_bp(_p(d_out), _p(d_feats), _p(rules), int(mode), int(n_active),
+                                 int(max_active), int(n_plane), _stream()), "doda_voxelize_bp")
+
+
+def point_recover_fp(feats, out, rules, n_active, max_active, n_plane):
+    _pool_args(feats, out, rules)
+    check(lib().doda_point_recover_fp(_p(feats), _p(out), _p(rules), int(n_active),
+                                      int(max_active), int(n_plane), _stream()),
+          "doda_point_recover_fp")
+
+
+def point_recover_bp(d_out, d_feats, rules, n_active, max_active, n_plane):
+    _pool_args(d_out, d_feats, rules)
+    check(lib().doda_point_recover_bp(_p(d_out), _p(d_feats), _p(rules), int(n_active),
+                                      int(max_active), int(n_plane), _stream()),
+          "doda_point_recover_bp")
+
+
+# ------------------------------------------------------------------------------------------
+# rulebooks
+# ------------------------------------------------------------------------------------------
+def _shape3(spatial_shape):
+    s = [int(v) for v in np.asarray(spatial_shape).reshape(-1)]
+    if len(s) != 3:
+        raise RuntimeError("spatial_shape must have 3 entries")
+    return (C.c_int32 * 3)(*s), s
+
+
+def _check_indices(indices):
+    _need_cuda(indices)
+    if indices.dtype != torch.int32 or indices.dim() != 2 or indices.shape[1] != 4:
+        raise RuntimeError("indices must be int32 [M,4] (batch,x,y,z)")
+    return indices.contiguous()
+
+
+def rulebook_subm(indices, spatial_shape, batch_size, ksize=3):
+    """Gather table int32 [ksize^3, M] of a SubMConv3d (nbr[o][t] = input row or -1)."""
+    indices = _check_indices(indices)
+    m = indices.shape[0]
+    shape_c, _ = _shape3(spatial_shape)
+    K = ksize ** 3
+    nbr = torch.empty((K, m), dtype=torch.int32, device=indices.device)
+    ws = _ws(lib().doda_rulebook_workspace_bytes(m), indices.device)
+    check(lib().doda_rulebook_subm(_p(indices), m, shape_c, int(batch_size), int(ksize), _p(nbr), m,
+                                   _p(ws), ws.numel(), _stream()), "doda_rulebook_subm")
+    return nbr
+
+
+def rulebook_down2(indices, spatial_shape, batch_size):
+    """SparseConv3d(k=2,s=2) rulebook.  Returns (out_indices int32 [M_out,4], child int32
+    [8,M_out], par_off int32 [8,M], out_shape list[3]).  One D2H sync (M_out)."""
+    indices = _check_indices(indices)
+    m = indices.shape[0]
+    dev = indices.device
+    shape_c, s = _shape3(spatial_shape)
+    out_shape = [(v - 2) // 2 + 1 for v in s]
+    parent = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+    off = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+    out_idx_full = torch.empty((max(m, 1), 4), dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _ws(lib().doda_rulebook_workspace_bytes(m), dev)
+    check(lib().doda_rulebook_down2_assign(_p(indices), m, shape_c, int(batch_size), _p(parent),
+                                           _p(off), _p(out_idx_full), _p(count), _p(ws), ws.numel(),
+                                           _stream()), "doda_rulebook_down2_assign")
+    m_out = int(count.item())
+    child = torch.empty((8, m_out), dtype=torch.int32, device=dev)
+    par_off = torch.empty((8, m), dtype=torch.int32, device=dev)
+    check(lib().doda_rulebook_down2_tables(_p(parent), _p(off), m, m_out, _p(child), m_out,
+                                           _p(par_off), m, _stream()), "doda_rulebook_down2_tables")
+    return out_idx_full[:m_out].clone(), child, par_off, out_shape
+
+
+def rulebook_pairs(tbl, n_rows, flip):
+    """spconv-v1.2-format (pairs int32 [2,K,n_rows] -1 padded, pairNum int32 [K]) from a table."""
+    _need_cuda(tbl)
+    K, ld = tbl.shape
+    dev = tbl.device
+    pairs = torch.empty((2, K, max(n_rows, 1)), dtype=torch.int32, device=dev)
+    pair_num = torch.zeros(K, dtype=torch.int32, device=dev)
+    ws = _ws(lib().doda_rulebook_pairs_workspace_bytes(n_rows, K), dev)
+    if n_rows == 0:
+        return pairs[:, :, :0], pair_num
+    check(lib().doda_rulebook_pairs(_p(tbl), ld, K, n_rows, int(bool(flip)), _p(pairs), n_rows,
+                                    _p(pair_num), _p(ws), ws.numel(), _stream()),
+          "doda_rulebook_pairs")
+    return pairs, pair_num
+
+
+# ------------------------------------------------------------------------------------------
+# convolution arithmetic
+# ------------------------------------------------------------------------------------------
+def _feat_ok(x, name):
+    _need_cuda(x)
+    if x.dim() != 2 or not x.is_contiguous():
+        raise RuntimeError("%s must be a contiguous [rows, channels] tensor" % name)
+
+
+def spconv_gather(x, w, tbl, n_out, w_layout, nc):
+    """y[t] = sum_o x[tbl[o][t]] @ B_o (see doda_hip.h).  x: [*,kc] f32|bf16; w: fp32 weights
+    viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2).  Returns y [n_out, nc] in x.dtype."""
+    _feat_ok(x, "x")
+    _need_cuda(w, tbl)
+    K, ld = tbl.shape
+    kc = x.shape[1]
+    w = w.contiguous()
+    if w.dtype != torch.float32 or w.numel() != K * kc * nc:
+        raise RuntimeError("weight must be float32 with K*kc*nc = %d elements" % (K * kc * nc))
+    y = torch.empty((n_out, nc), dtype=x.dtype, device=x.device)
+    if x.dtype == torch.float32:
+        check(lib().doda_spconv_gather_f32(_p(x), kc, _p(w), nc, _p(tbl), ld, K, n_out, _p(y),
+                                           int(w_layout), _stream()), "doda_spconv_gather_f32")
+    elif x.dtype == torch.bfloat16:
+        ws = _ws(lib().doda_spconv_gather_bf16_workspace_bytes(K, kc, nc), x.device)
+        check(lib().doda_spconv_gather_bf16(_p(x), kc, _p(w), nc, _p(tbl), ld, K, n_out, _p(y),
+                                            int(w_layout), _p(ws), ws.numel(), _stream()),
+              "doda_spconv_gather_bf16")
+    else:
+        raise RuntimeError("spconv_gather: unsupported feature dtype %s" % x.dtype)
+    return y
+
+
+def spconv_wgrad(a, b, tbl, n_rows):
+    """dw[o] = sum_t a[tbl[o][t]]^T b[t]  ->  float32 [K, ca, cb]."""
+    _feat_ok(a, "a")
+    _feat_ok(b, "b")
+    _need_cuda(tbl)
+    if a.dtype != b.dtype:
+        raise RuntimeError("spconv_wgrad: a and b must share a dtype")
+    K, ld = tbl.shape
+    ca, cb = a.shape[1], b.shape[1]
+    dw = torch.empty((K, ca, cb), dtype=torch.float32, device=a.device)
+    ws = _ws(lib().doda_spconv_wgrad_workspace_bytes(K, ca, cb, n_rows), a.device)
+    if a.dtype == torch.float32:
+        fn, name = lib().doda_spconv_wgrad_f32, "doda_spconv_wgrad_f32"
+    elif a.dtype == torch.bfloat16:
+        fn, name = lib().doda_spconv_wgrad_bf16, "doda_spconv_wgrad_bf16"
+    else:
+        raise RuntimeError("spconv_wgrad: unsupported dtype %s" % a.dtype)
+    check(fn(_p(a), ca, _p(b), cb, _p(tbl), ld, K, n_rows, _p(dw), _p(ws), ws.numel(), _stream()),
+          name)
+    return dw
+
+
+def maxpool_fwd(x, tbl, n_out):
+    _feat_ok(x, "x")
+    K, ld = tbl.shape
+    y = torch.empty((n_out, x.shape[1]), dtype=torch.float32, device=x.device)
+    check(lib().doda_maxpool_fwd_f32(_p(x), x.shape[1], _p(tbl), ld, K, n_out, _p(y), _stream()),
+          "doda_maxpool_fwd_f32")
+    return y
+
+
+def maxpool_bwd(x, y, dy, tbl, n_out):
+    K, ld = tbl.shape
+    dx = torch.zeros_like(x)
+    check(lib().doda_maxpool_bwd_f32(_p(x), _p(y), _p(dy), x.shape[1], _p(tbl), ld, K, n_out,
+                                     _p(dx), _stream()), "doda_maxpool_bwd_f32")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------
+# neighbour queries
+# ------------------------------------------------------------------------------------------
+def knnquery(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):
+    """pointops2_cuda.knnquery_cuda signature (offset/new_offset are END offsets, int32)."""
+    _need_cuda(xyz, new_xyz, offset, new_offset, idx, dist2)
+    check(lib().doda_knnquery(int(m), int(nsample), _p(xyz), _p(new_xyz), _p(offset),
+                              _p(new_offset), int(offset.numel()), _p(idx), _p(dist2), _stream()),
+          "doda_knnquery")
+
+
+def knn_batch(xyz, query_xyz, batch_idxs, query_batch_offsets, idx, n, m, k):
+    _need_cuda(xyz, query_xyz, batch_idxs, query_batch_offsets, idx)
+    check(lib().doda_knn_batch(int(n), int(m), int(k), _p(xyz), _p(query_xyz), _p(batch_idxs),
+                               _p(query_batch_offsets), _p(idx), _stream()), "doda_knn_batch")
+
+
+def ballquery_batch_p(xyz, batch_idxs, batch_offsets, idx, start_len, n, mean_active, radius):
+    _need_cuda(xyz, batch_idxs, batch_offsets, idx, start_len)
+    ws = _ws(lib().doda_ballquery_workspace_bytes(int(n)), xyz.device)
+    total = C.c_int32(0)
+    check(lib().doda_ballquery_batch_p(int(n), int(mean_active), float(radius), _p(xyz),
+                                       _p(batch_idxs), _p(batch_offsets), _p(idx), _p(start_len),
+                                       C.byref(total), _p(ws), ws.numel(), _stream()),
+          "doda_ballquery_batch_p")
+    return int(total.value)

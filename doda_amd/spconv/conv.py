@@ -1,0 +1,129 @@
+"""SubMConv3d / SparseConv3d / SparseInverseConv3d (spconv v1.2 `spconv.conv`).
+
+Constructor arguments, the `[kD,kH,kW,Cin,Cout]` weight Parameter (state-dict compatible with
+DODA's model zoo), kaiming_uniform(a=sqrt(5)) initialisation, rulebook caching by
+`indice_key` in `input.indice_dict`, and the 1x1 shortcut (`features @ W.view(Cin,Cout)`) follow
+upstream; the arithmetic is libdoda_hip.so's."""
+import math
+
+import torch
+from torch import nn
+from torch.nn import init
+
+from . import functional as Fsp
+from . import ops
+from .core import SparseConvTensor
+from .modules import SparseModule
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0,
+                 dilation=1, groups=1, bias=True, subm=False, output_padding=0, transposed=False,
+                 inverse=False, indice_key=None, fused_bn=False, use_hash=False):
+        super().__init__()
+        if groups != 1:
+            raise NotImplementedError("groups != 1")
+        if ndim != 3:
+            raise NotImplementedError("doda_amd implements 3-D sparse convolution only")
+        self.ndim = ndim
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = ops._triple(kernel_size)
+        self.conv1x1 = all(k == 1 for k in self.kernel_size)
+        self.stride = ops._triple(stride)
+        self.padding = ops._triple(padding)
+        self.dilation = ops._triple(dilation)
+        self.output_padding = ops._triple(output_padding)
+        self.transposed = transposed
+        self.inverse = inverse
+        self.groups = groups
+        self.subm = subm
+        self.indice_key = indice_key
+        self.fused_bn = fused_bn
+        self.use_hash = use_hash
+        if inverse and indice_key is None:
+            raise ValueError("SparseInverseConv3d needs the indice_key of its strided convolution")
+        self.weight = nn.Parameter(torch.Tensor(*self.kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in)
+            init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return "{}, {}, kernel_size={}, stride={}, subm={}, inverse={}, indice_key={}".format(
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.subm,
+            self.inverse, self.indice_key)
+
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        features = input.features
+        indices = input.indices
+        spatial_shape = input.spatial_shape
+        batch_size = input.batch_size
+
+        if self.conv1x1:
+            w2 = self.weight.view(self.in_channels, self.out_channels)
+            out_features = torch.mm(features, w2.to(features.dtype))
+            if self.bias is not None:
+                out_features = out_features + self.bias.to(features.dtype)
+            out = SparseConvTensor(out_features, indices, spatial_shape, batch_size)
+            out.indice_dict = input.indice_dict
+            out.grid = input.grid
+            return out
+
+        data = input.find_indice_pair(self.indice_key)
+        if self.inverse:
+            if data is None or data.kind != "down2":
+                raise RuntimeError("SparseInverseConv3d: no strided rulebook under indice_key %r"
+                                   % (self.indice_key,))
+            outids, out_spatial_shape = data.indices, data.spatial_shape
+            out_features = Fsp.indice_inverse_conv(features, self.weight, data)
+        else:
+            if data is None:
+                if self.subm:
+                    data = ops.build_subm(indices, batch_size, spatial_shape, self.kernel_size)
+                else:
+                    data = ops.build_down2(indices, batch_size, spatial_shape, self.kernel_size,
+                                           self.stride, self.padding, self.dilation)
+                if self.indice_key is not None:
+                    input.indice_dict[self.indice_key] = data
+            outids, out_spatial_shape = data.outids, data.out_spatial_shape
+            if self.subm:
+                out_features = Fsp.indice_subm_conv(features, self.weight, data)
+            else:
+                out_features = Fsp.indice_conv(features, self.weight, data)
+
+        if self.bias is not None:
+            out_features = out_features + self.bias.to(out_features.dtype)
+        out = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
+        out.indice_dict = input.indice_dict
+        out.grid = input.grid
+        return out
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None, use_hash=False):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, bias, True, indice_key=indice_key, use_hash=use_hash)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None, use_hash=False):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, bias, indice_key=indice_key, use_hash=use_hash)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True,
+                         indice_key=indice_key)

@@ -1,0 +1,96 @@
+"""SparseConvTensor and the rulebook record kept in its indice_dict."""
+import numpy as np
+import torch
+
+from .. import ops as _ops
+
+
+class IndiceData:
+    """Rulebook of one indice_key.
+
+    Behaves like spconv v1.2's 5-tuple `(outids, indices, indice_pairs, indice_pair_num,
+    spatial_shape)` (unpacking and [i] indexing work), but the native record is the gather
+    table(s) of include/doda_hip.h; the spconv-format pairs are materialised on first access.
+
+    kind 'subm' : tbl = nbr int32 [27, M]
+    kind 'down2': tbl = child int32 [8, M_out]; tbl_rev = par_off int32 [8, M_in]
+    """
+
+    def __init__(self, kind, outids, indices, spatial_shape, out_spatial_shape, tbl, tbl_rev=None):
+        self.kind = kind
+        self.outids = outids
+        self.indices = indices
+        self.spatial_shape = spatial_shape
+        self.out_spatial_shape = out_spatial_shape
+        self.tbl = tbl
+        self.tbl_rev = tbl_rev
+        self._pairs = None
+
+    def _export(self):
+        if self._pairs is None:
+            n_in = self.indices.shape[0]
+            if self.kind == "subm":
+                self._pairs = _ops.rulebook_pairs(self.tbl, n_in, flip=True)
+            else:
+                self._pairs = _ops.rulebook_pairs(self.tbl_rev, n_in, flip=False)
+        return self._pairs
+
+    @property
+    def indice_pairs(self):
+        return self._export()[0]
+
+    @property
+    def indice_pair_num(self):
+        return self._export()[1]
+
+    def _as_tuple(self):
+        return (self.outids, self.indices, self.indice_pairs, self.indice_pair_num,
+                self.spatial_shape)
+
+    def __iter__(self):
+        return iter(self._as_tuple())
+
+    def __len__(self):
+        return 5
+
+    def __getitem__(self, i):
+        return self._as_tuple()[i]
+
+
+class SparseConvTensor:
+    """features [M,C] + indices int32 [M,4] (batch,x,y,z) + spatial_shape + batch_size.
+
+    Mirrors spconv v1.2 SparseConvTensor as used at reference model/unet.py:94 and
+    model/unet_block.py:33,89 (rw attributes features/indices/spatial_shape/batch_size,
+    indice_dict shared along the network, grid carried but unused by the hash builders)."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+        self.features = features
+        self.indices = indices
+        self.spatial_shape = [int(v) for v in np.asarray(spatial_shape).reshape(-1)]
+        self.batch_size = int(batch_size)
+        self.indice_dict = {}
+        self.grid = grid
+
+    @property
+    def spatial_size(self):
+        return int(np.prod(self.spatial_shape))
+
+    def find_indice_pair(self, key):
+        if key is None:
+            return None
+        return self.indice_dict.get(key)
+
+    def dense(self, channels_first=True):
+        idx = self.indices.long()
+        shape = [self.batch_size] + list(self.spatial_shape) + [self.features.shape[1]]
+        out = torch.zeros(shape, dtype=self.features.dtype, device=self.features.device)
+        out[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] = self.features
+        if not channels_first:
+            return out
+        ndim = len(self.spatial_shape)
+        return out.permute(0, ndim + 1, *range(1, ndim + 1)).contiguous()
+
+    @property
+    def sparity(self):
+        return self.indices.shape[0] / max(self.spatial_size * self.batch_size, 1)

@@ -1,0 +1,70 @@
+"""SparseModule marker base class and SparseSequential container (spconv v1.2 `spconv.modules`;
+reference imports at model/unet_block.py:3-4, uses at model/unet.py:35,42 and
+model/unet_block.py:10,41,62-85)."""
+from collections import OrderedDict
+
+from torch import nn
+
+from .core import SparseConvTensor
+
+
+class SparseModule(nn.Module):
+    """Modules deriving from this are called with the SparseConvTensor itself; anything else in
+    a SparseSequential is applied to `.features`."""
+    pass
+
+
+def is_spconv_module(module):
+    return isinstance(module, SparseModule)
+
+
+class SparseSequential(SparseModule):
+    """nn.Sequential for mixed sparse / dense-feature modules.
+
+    Accepts positional modules, a single OrderedDict, or keyword-named modules (upstream API).
+    Non-sparse modules (BatchNorm1d, ReLU, Identity, DSNorm...) act on `.features`, which is
+    re-bound on the same tensor object; they are skipped when the tensor has no active rows."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError("index {} is out of range".format(idx))
+        if idx < 0:
+            idx += len(self)
+        it = iter(self._modules.values())
+        for _ in range(idx):
+            next(it)
+        return next(it)
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def forward(self, input):
+        for module in self._modules.values():
+            if is_spconv_module(module):
+                input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    input.features = module(input.features)
+            else:
+                input = module(input)
+        return input

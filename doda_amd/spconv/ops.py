@@ -1,0 +1,55 @@
+"""Rulebook construction at the level of spconv v1.2 `spconv.ops` (get_conv_output_size,
+get_indice_pairs).  Supported geometries are the ones DODA instantiates: SubM with an odd cubic
+kernel (1 or 3) and strided kernel-2 / stride-2 / padding-0 convolution (model/unet.py:36,
+model/unet_block.py:18-29,48,70,78)."""
+import numpy as np
+
+from .. import ops as _ops
+from .core import IndiceData
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple, np.ndarray)):
+        out = [int(x) for x in v]
+        if len(out) != 3:
+            raise ValueError("expected 3 values, got %r" % (v,))
+        return out
+    return [int(v)] * 3
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    out = []
+    for i in range(len(input_size)):
+        size = (input_size[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) // stride[i] + 1
+        out.append(1 if kernel_size[i] == -1 else size)
+    return out
+
+
+def build_subm(indices, batch_size, spatial_shape, ksize):
+    k = _triple(ksize)
+    if not (k[0] == k[1] == k[2] and k[0] in (1, 3)):
+        raise NotImplementedError("doda_amd SubMConv3d supports cubic kernels 1 and 3, got %r" % (k,))
+    tbl = _ops.rulebook_subm(indices, spatial_shape, batch_size, k[0])
+    return IndiceData("subm", indices, indices, list(spatial_shape), list(spatial_shape), tbl)
+
+
+def build_down2(indices, batch_size, spatial_shape, ksize, stride, padding, dilation):
+    k, s, p, d = _triple(ksize), _triple(stride), _triple(padding), _triple(dilation)
+    if k != [2, 2, 2] or s != [2, 2, 2] or p != [0, 0, 0] or d != [1, 1, 1]:
+        raise NotImplementedError(
+            "doda_amd SparseConv3d supports kernel_size=2, stride=2, padding=0, dilation=1 "
+            "(the geometry DODA uses); got k=%r s=%r p=%r d=%r" % (k, s, p, d))
+    outids, child, par_off, out_shape = _ops.rulebook_down2(indices, spatial_shape, batch_size)
+    return IndiceData("down2", outids, indices, list(spatial_shape), out_shape, child, par_off)
+
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
+                     out_padding=0, subm=False, transpose=False, grid=None, use_hash=False):
+    """Upstream-shaped entry: returns (outids, indice_pairs [2,K,N], indice_pair_num [K])."""
+    if transpose:
+        raise NotImplementedError("transposed sparse convolution is not part of DODA's path")
+    if subm:
+        data = build_subm(indices, batch_size, spatial_shape, ksize)
+    else:
+        data = build_down2(indices, batch_size, spatial_shape, ksize, stride, padding, dilation)
+    return data.outids, data.indice_pairs, data.indice_pair_num

@@ -1,0 +1,213 @@
+/*
+ * doda_hip.h — C ABI of libdoda_hip.so: the MI355X (gfx950) native replacement for the
+ * native layer under DODA's sparse-conv U-Net hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers + sizes, an explicit HIP stream
+ * (passed as void*, i.e. a hipStream_t), and returns an int status (0 = DODA_OK, negative =
+ * error, see doda_strerror).  Nothing here exits the process, allocates device memory or
+ * synchronises the device unless the comment says so; all buffers are caller-owned (PyTorch's
+ * caching allocator on the Python side), workspaces are sized by the *_workspace_bytes queries.
+ * Pointers are DEVICE pointers unless the parameter name ends in `_h` (host).
+ *
+ * Each declaration cites the reference interface (file:line under the DODA checkout) it replaces.
+ * spconv v1.2 is an un-vendored third-party dependency of the reference (docs/INSTALL.md:8,26);
+ * for those entry points the citation is the reference CALL SITE plus the upstream op name.
+ */
+#ifndef DODA_HIP_H
+#define DODA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DODA_ABI_VERSION 1
+
+#define DODA_OK 0
+#define DODA_ERR_INVALID (-1)        /* bad argument (null pointer, negative size, bad mode) */
+#define DODA_ERR_LAUNCH (-2)         /* hipGetLastError() != hipSuccess after a launch          */
+#define DODA_ERR_GRID_TOO_LARGE (-3) /* batch*X*Y*Z >= 2^32-1: cell id does not fit the hash key */
+#define DODA_ERR_UNSUPPORTED (-4)    /* channel count / k outside the compiled range            */
+#define DODA_ERR_WORKSPACE (-5)      /* workspace smaller than the *_workspace_bytes answer     */
+#define DODA_ERR_NOMEM (-6)          /* host allocation failed (host entry points only)         */
+
+typedef void *doda_stream_t; /* hipStream_t */
+
+int doda_abi_version(void);
+const char *doda_strerror(int status);
+
+/* ------------------------------------------------------------------------------------------
+ * Voxelisation (pointgroup_ops)
+ * ---------------------------------------------------------------------------------------- */
+
+/* HOST, fork-safe, no GPU context.  Replaces PG_OP.voxelize_idx
+ * (lib/pointgroup_ops/src/pointgroup_ops_api.cpp:7 -> voxelize/voxelize.cpp:10-31).
+ * The reference resizes its output tensors; a C ABI cannot, so the call is split:
+ *   doda_voxelize_idx_h      : hashes the points, fills input_map[n], returns M and maxActive
+ *                              and an opaque handle holding the per-voxel point lists;
+ *   doda_voxelize_idx_fill_h : writes output_coords[M,ncol] and output_map[M,1+maxActive]
+ *                              and releases the handle (doda_voxelize_idx_free_h on error paths).
+ * coords_h: int64 [n, ncol], ncol = 3 (single batch) or 4 (column 0 = batch index).
+ * mode: 0 unique, 1 first point, 2 last point, 3 sum, 4 mean (reference numbering,
+ * voxelize.cpp:54,119-152; modes 1/2 follow the CODE, not its comment). */
+int doda_voxelize_idx_h(const int64_t *coords_h, int32_t n, int32_t ncol, int32_t batch_size,
+                        int32_t mode, int32_t *input_map_h, void **handle, int32_t *n_active,
+                        int32_t *max_active);
+int doda_voxelize_idx_fill_h(void *handle, const int64_t *coords_h, int64_t *output_coords_h,
+                             int32_t *output_map_h);
+void doda_voxelize_idx_free_h(void *handle);
+
+/* DEVICE version of the same map (same results as the host call).
+ * Stage 1 (assign): input_map[n] and counts_out[2] = {M, maxActive} (device ints the caller
+ * copies back before allocating the outputs of stage 2).  Stage 2 (fill): output_coords,
+ * output_map.  `ws` must hold doda_voxelize_idx_workspace_bytes(n) bytes and be passed
+ * unchanged to both stages. */
+size_t doda_voxelize_idx_workspace_bytes(int32_t n);
+int doda_voxelize_idx_assign(const int64_t *coords, int32_t n, int32_t ncol, int32_t mode,
+                             int32_t *input_map, int32_t *counts_out, void *ws, size_t ws_bytes,
+                             doda_stream_t stream);
+int doda_voxelize_idx_fill(const int64_t *coords, int32_t n, int32_t ncol, int32_t mode,
+                           int32_t n_active, int32_t max_active, int64_t *output_coords,
+                           int32_t *output_map, void *ws, size_t ws_bytes, doda_stream_t stream);
+
+/* Replaces PG_OP.voxelize_fp / voxelize_bp (pointgroup_ops_api.cpp:8-9 -> voxelize.cpp:159-181
+ * -> voxelize.cu:10-53).  out[r,:] += mult * feats[rule[r,i],:], i = 1..rule[r,0], products
+ * rounded before accumulation, in point order; mult = 1/cnt when mode == 4.  `out` must be
+ * zero-initialised by the caller as in the reference wrapper (pointgroup_ops.py:59). */
+int doda_voxelize_fp(const float *feats, float *out, const int32_t *rules, int32_t mode,
+                     int32_t n_active, int32_t max_active, int32_t n_plane, doda_stream_t stream);
+int doda_voxelize_bp(const float *d_out, float *d_feats, const int32_t *rules, int32_t mode,
+                     int32_t n_active, int32_t max_active, int32_t n_plane, doda_stream_t stream);
+/* PG_OP.point_recover_fp / _bp (pointgroup_ops_api.cpp:10-11 -> voxelize.cpp:184-205): the two
+ * kernels above with roles swapped and no averaging. */
+int doda_point_recover_fp(const float *feats, float *out, const int32_t *rules, int32_t n_active,
+                          int32_t max_active, int32_t n_plane, doda_stream_t stream);
+int doda_point_recover_bp(const float *d_out, float *d_feats, const int32_t *rules,
+                          int32_t n_active, int32_t max_active, int32_t n_plane,
+                          doda_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse-convolution rulebooks  (spconv v1.2 `ops.get_indice_pairs` ->
+ * torch.ops.spconv.get_indice_pairs; reference call sites model/unet.py:36,
+ * model/unet_block.py:26,29,48,70,78)
+ *
+ * Native rulebook format ("gather table"): int32 tbl[K][ld]; tbl[o][t] = row of the INPUT
+ * feature matrix that output row t reads for kernel offset o, or -1.  Offsets are numbered
+ * row-major over (k0,k1,k2) exactly as spconv numbers them.
+ * ---------------------------------------------------------------------------------------- */
+size_t doda_rulebook_workspace_bytes(int32_t m);
+
+/* SubMConv3d, odd cubic kernel `ksize` (1 or 3), stride 1, padding ksize/2, dilation 1.
+ * indices: int32 [m,4] = (batch, x, y, z).  nbr: int32 [ksize^3][ld], ld >= m.
+ * nbr[o][t] = id of the active voxel at p_t + k(o) - ksize/2, or -1 (out of shape / inactive). */
+int doda_rulebook_subm(const int32_t *indices, int32_t m, const int32_t *shape_h, int32_t batch,
+                       int32_t ksize, int32_t *nbr, int32_t ld, void *ws, size_t ws_bytes,
+                       doda_stream_t stream);
+
+/* SparseConv3d kernel 2 stride 2 padding 0 (unet_block.py:70), stage 1: parent[j] = output row
+ * of input j (or -1 when its cell lies outside the output shape (s-2)/2+1), off[j] = kernel
+ * offset ((x&1)*2+(y&1))*2+(z&1), out_indices[q] for q < M_out, counts_out[0] = M_out (device).
+ * Output rows are numbered in first-touch order over ascending input index, which is the order
+ * spconv's CPU path produces. */
+int doda_rulebook_down2_assign(const int32_t *indices, int32_t m, const int32_t *shape_h,
+                               int32_t batch, int32_t *parent, int32_t *off,
+                               int32_t *out_indices, int32_t *counts_out, void *ws,
+                               size_t ws_bytes, doda_stream_t stream);
+/* stage 2: child[8][ld_out] (child[o][q] = fine row with parent q and offset o, or -1) and
+ * par_off[8][ld_in] (par_off[o][j] = parent[j] if off[j]==o else -1). */
+int doda_rulebook_down2_tables(const int32_t *parent, const int32_t *off, int32_t m,
+                               int32_t m_out, int32_t *child, int32_t ld_out, int32_t *par_off,
+                               int32_t ld_in, doda_stream_t stream);
+
+/* Export a gather table as spconv-v1.2-format indice pairs: pairs int32 [2][K][ld_pairs]
+ * (-1 padded), pair_num int32 [K].  List o holds (in = j, out = tbl[src(o)][j]) for ascending j
+ * with tbl[src(o)][j] >= 0, src(o) = K-1-o when `flip` (SubM: in/out roles are mirrored) else o
+ * (down2: pass par_off).  Ascending-j order is the order of spconv's CPU path. */
+size_t doda_rulebook_pairs_workspace_bytes(int32_t n_rows, int32_t K);
+int doda_rulebook_pairs(const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, int32_t flip,
+                        int32_t *pairs, int32_t ld_pairs, int32_t *pair_num, void *ws,
+                        size_t ws_bytes, doda_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse-convolution arithmetic (spconv v1.2 torch.ops.spconv.indice_conv /
+ * indice_conv_backward behind Fsp.indice_subm_conv / indice_conv / indice_inverse_conv;
+ * reference call sites as above).  All output-stationary: every output row is written once,
+ * no atomics, deterministic.
+ *
+ *   y[t, :] = sum_o  x[tbl[o][t], :] . B_o          t < n_out,  x: [*, kc],  y: [n_out, nc]
+ *
+ * w_layout 0: B_o = W[o]        with w stored [K][kc][nc]           (forward)
+ * w_layout 1: B_o = W[o]^T      with w stored [K][nc][kc]           (data-grad of down2/inverse)
+ * w_layout 2: B_o = W[K-1-o]^T  with w stored [K][nc][kc]           (data-grad of SubM)
+ * ---------------------------------------------------------------------------------------- */
+int doda_spconv_gather_f32(const float *x, int32_t kc, const float *w, int32_t nc,
+                           const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, float *y,
+                           int32_t w_layout, doda_stream_t stream);
+
+/* dw[o][i][j] = sum_t a[tbl[o][t], i] * b[t, j],  a: [*, ca], b: [n_rows, cb], dw: [K][ca][cb].
+ * Two deterministic stages inside one call (partials in ws, then a fixed-order reduce). */
+size_t doda_spconv_wgrad_workspace_bytes(int32_t K, int32_t ca, int32_t cb, int32_t n_rows);
+int doda_spconv_wgrad_f32(const float *a, int32_t ca, const float *b, int32_t cb,
+                          const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, float *dw,
+                          void *ws, size_t ws_bytes, doda_stream_t stream);
+
+/* bf16-storage variants (BASELINE config 2): x/y/a/b are bf16 (uint16 bit patterns); weights
+ * arrive fp32 and are rounded to bf16 into `ws` in MFMA fragment order by a pre-pack kernel inside
+ * the call; fp32 accumulate; y rounded to bf16 (RNE); dw fp32.  wgrad_bf16 uses the same
+ * workspace size as doda_spconv_wgrad_workspace_bytes. */
+size_t doda_spconv_gather_bf16_workspace_bytes(int32_t K, int32_t kc, int32_t nc);
+int doda_spconv_gather_bf16(const uint16_t *x, int32_t kc, const float *w, int32_t nc,
+                            const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
+                            uint16_t *y, int32_t w_layout, void *ws, size_t ws_bytes,
+                            doda_stream_t stream);
+int doda_spconv_wgrad_bf16(const uint16_t *a, int32_t ca, const uint16_t *b, int32_t cb,
+                           const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, float *dw,
+                           void *ws, size_t ws_bytes, doda_stream_t stream);
+
+/* Indice-pair max pooling (spconv v1.2 indice_maxpool / indice_maxpool_backward; unused by
+ * DODA, named by north_star).  y[t,c] = max_o x[tbl[o][t],c] over present o (0 if none);
+ * dx[tbl[o][t],c] += dy[t,c] where x[tbl[o][t],c] == y[t,c]. */
+int doda_maxpool_fwd_f32(const float *x, int32_t c, const int32_t *tbl, int32_t ld, int32_t K,
+                         int32_t n_out, float *y, doda_stream_t stream);
+int doda_maxpool_bwd_f32(const float *x, const float *y, const float *dy, int32_t c,
+                         const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, float *dx,
+                         doda_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Neighbour queries
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces pointops2_cuda.knnquery_cuda (lib/pointops2/src/pointops_api.cpp:13 ->
+ * knnquery/knnquery_cuda.cpp:8-17 -> knnquery_cuda_kernel.cu:65-116).  offset/new_offset are
+ * the END offsets per batch item (length nbatch; the wrapper strips the leading 0,
+ * pointops2.py:66).  idx int32 [m,nsample], dist2 f32 [m,nsample] ascending, tie order = the
+ * reference's max-heap + heap-sort order.  nsample <= 100 (reference array bound). */
+int doda_knnquery(int32_t m, int32_t nsample, const float *xyz, const float *new_xyz,
+                  const int32_t *offset, const int32_t *new_offset, int32_t nbatch, int32_t *idx,
+                  float *dist2, doda_stream_t stream);
+
+/* Replaces PG_OP.knn_batch (pointgroup_ops_api.cpp:26 -> knn/knn.cpp:8-19 -> knn.cu:7-73):
+ * for each of the n points of `xyz`, its k nearest in query_xyz[offsets[b]:offsets[b+1]),
+ * insertion order, strict '<' (first seen wins ties).  k <= 40. */
+int doda_knn_batch(int32_t n, int32_t m, int32_t k, const float *xyz, const float *query_xyz,
+                   const int32_t *batch_idxs, const int32_t *query_batch_offsets, int32_t *idx,
+                   doda_stream_t stream);
+
+/* Replaces PG_OP.ballquery_batch_p (pointgroup_ops_api.cpp:13 -> bfs_cluster.cpp:15-25 ->
+ * bfs_cluster.cu:15-90).  Deterministic two-pass form: start_len[i] = (exclusive prefix of
+ * counts, count) in point order, neighbours ascending; at most 1000 neighbours per point and
+ * nothing written at or beyond n*mean_active, as in the reference.  *total_h receives the sum
+ * of counts; like the reference's blocking cudaMemcpy this call synchronises `stream`.
+ * ws: doda_ballquery_workspace_bytes(n). */
+size_t doda_ballquery_workspace_bytes(int32_t n);
+int doda_ballquery_batch_p(int32_t n, int32_t mean_active, float radius, const float *xyz,
+                           const int32_t *batch_idxs, const int32_t *batch_offsets, int32_t *idx,
+                           int32_t *start_len, int32_t *total_h, void *ws, size_t ws_bytes,
+                           doda_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DODA_HIP_H */

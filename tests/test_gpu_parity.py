@@ -1,0 +1,316 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (doda_amd.ops -> ctypes ->
+libdoda_hip.so), against the CPU oracle on the same seeded inputs.  Integer / index results are
+compared bit-exactly; fp32 features to 1e-4 relative (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import random_voxels, surface_voxels
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4  # north_star: within 1e-4 rel on fp32 features
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+# ------------------------------------------------------------------ voxelisation
+def _points(seed, n, batch, extent):
+    rng = np.random.default_rng(seed)
+    c = rng.integers(0, extent, size=(n, 3))
+    b = np.sort(rng.integers(0, batch, size=(n, 1)), axis=0)
+    return np.concatenate([b, c], 1).astype(np.int64)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("ncol", [3, 4])
+def test_voxelize_idx_host_and_device(native_lib, oracle, mode, ncol):
+    from doda_amd import ops
+    coords = _points(3 + mode, 5000, 3, 14)
+    if ncol == 3:
+        coords = coords[:, 1:].copy()
+    ref = oracle.voxelize_idx(coords, mode)
+    host = ops.voxelize_idx_host(torch.from_numpy(coords), 3, mode)
+    devr = ops.voxelize_idx_device(torch.from_numpy(coords).to(dev()), 3, mode)
+    for r, h, d in zip(ref, host, devr):
+        assert np.array_equal(r, h.numpy())
+        assert np.array_equal(r, d.cpu().numpy())
+
+
+def test_voxelize_idx_mode0_and_empty(native_lib, oracle):
+    from doda_amd import ops
+    coords = np.unique(_points(11, 800, 2, 30), axis=0)
+    np.random.default_rng(0).shuffle(coords)
+    ref = oracle.voxelize_idx(coords, 0)
+    got = ops.voxelize_idx_device(torch.from_numpy(coords).to(dev()), 2, 0)
+    for r, d in zip(ref, got):
+        assert np.array_equal(r, d.cpu().numpy())
+    empty = torch.zeros((0, 4), dtype=torch.int64)
+    oc, im, om = ops.voxelize_idx_host(empty, 1, 4)
+    assert oc.shape[0] == 0 and im.shape[0] == 0 and om.shape[0] == 0
+    oc, im, om = ops.voxelize_idx_device(empty.to(dev()), 1, 4)
+    assert oc.shape[0] == 0 and im.shape[0] == 0 and om.shape[0] == 0
+
+
+@pytest.mark.parametrize("c", [1, 3, 6, 32])
+@pytest.mark.parametrize("mode", [3, 4])
+def test_voxelize_fp_bp_bit_exact(native_lib, oracle, c, mode):
+    from doda_amd import pointgroup_ops as pg
+    coords = _points(21, 20000, 4, 20)
+    _, _, om = oracle.voxelize_idx(coords, mode)
+    rng = np.random.default_rng(5)
+    feats = rng.standard_normal((coords.shape[0], c)).astype(np.float32)
+    ref = oracle.voxelize_fp(feats, om, average=(mode == 4))
+    f = torch.from_numpy(feats).to(dev()).requires_grad_(True)
+    rules = torch.from_numpy(om).to(dev())
+    out = pg.voxelization(f, rules, mode)
+    assert np.array_equal(ref.view(np.uint32), out.detach().cpu().numpy().view(np.uint32))
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    out.backward(torch.from_numpy(g).to(dev()))
+    ref_g = oracle.voxelize_bp(g, om, coords.shape[0], average=(mode == 4))
+    assert np.array_equal(ref_g.view(np.uint32), f.grad.cpu().numpy().view(np.uint32))
+    # point_recover: voxel -> point broadcast and its backward
+    vf = torch.from_numpy(g).to(dev()).requires_grad_(True)
+    rec = pg.point_recover(vf, rules, coords.shape[0])
+    assert np.array_equal(oracle.voxelize_bp(g, om, coords.shape[0], average=False).view(np.uint32),
+                          rec.detach().cpu().numpy().view(np.uint32))
+
+
+# ------------------------------------------------------------------ rulebooks
+CASES = [(0, 700, 2, [16, 12, 20], random_voxels), (1, 3000, 3, [33, 31, 17], surface_voxels),
+         (2, 20000, 4, [128, 128, 128], surface_voxels), (3, 1, 1, [4, 4, 4], random_voxels),
+         (4, 64, 1, [4, 4, 4], random_voxels)]
+
+
+@pytest.mark.parametrize("seed,n,batch,shape,gen", CASES)
+def test_rulebook_subm_bit_exact(native_lib, oracle, seed, n, batch, shape, gen):
+    from doda_amd import spconv
+    idx = gen(seed, n, batch, shape)
+    ref_pairs, ref_num = oracle.indice_pairs_subm(idx, batch, shape, 3)
+    data = spconv.ops.build_subm(torch.from_numpy(idx).to(dev()), batch, shape, 3)
+    outids, _, pairs, pair_num, _ = data
+    assert np.array_equal(outids.cpu().numpy(), idx)
+    assert np.array_equal(pair_num.cpu().numpy(), ref_num)
+    assert np.array_equal(pairs.cpu().numpy(), ref_pairs)
+
+
+@pytest.mark.parametrize("seed,n,batch,shape,gen", CASES)
+def test_rulebook_down2_bit_exact(native_lib, oracle, seed, n, batch, shape, gen):
+    from doda_amd import spconv
+    idx = gen(seed, n, batch, shape)
+    ref_out, ref_pairs, ref_num, ref_shape = oracle.indice_pairs_conv(idx, batch, shape, 2, 2, 0, 1)
+    data = spconv.ops.build_down2(torch.from_numpy(idx).to(dev()), batch, shape, 2, 2, 0, 1)
+    outids, _, pairs, pair_num, _ = data
+    assert data.out_spatial_shape == ref_shape
+    assert np.array_equal(outids.cpu().numpy(), ref_out)
+    assert np.array_equal(pair_num.cpu().numpy(), ref_num)
+    assert np.array_equal(pairs.cpu().numpy(), ref_pairs)
+
+
+def test_rulebook_odd_shape_drops_border(native_lib, oracle):
+    """Odd spatial extents: inputs whose cell falls outside (s-2)//2+1 get no pair."""
+    from doda_amd import spconv
+    shape = [13, 11, 9]
+    idx = random_voxels(9, 600, 2, shape)
+    ref_out, ref_pairs, ref_num, _ = oracle.indice_pairs_conv(idx, 2, shape, 2, 2, 0, 1)
+    assert ref_num.sum() < idx.shape[0]
+    data = spconv.ops.build_down2(torch.from_numpy(idx).to(dev()), 2, shape, 2, 2, 0, 1)
+    assert np.array_equal(data.indice_pairs.cpu().numpy(), ref_pairs)
+    assert np.array_equal(data.outids.cpu().numpy(), ref_out)
+
+
+# ------------------------------------------------------------------ convolutions
+CHANNELS = [(3, 16), (16, 16), (32, 16), (16, 32), (48, 48), (64, 32), (112, 112), (5, 7), (20, 40)]
+
+
+def _conv_case(oracle, seed, cin, cout, n=1500, batch=2, shape=(24, 20, 22)):
+    shape = list(shape)
+    idx = surface_voxels(seed, n, batch, shape)
+    rng = np.random.default_rng(seed + 100)
+    x = rng.standard_normal((idx.shape[0], cin)).astype(np.float32)
+    return idx, shape, batch, x, rng
+
+
+@pytest.mark.parametrize("cin,cout", CHANNELS)
+def test_subm_conv_fwd_bwd(native_lib, oracle, cin, cout):
+    from doda_amd import spconv
+    idx, shape, batch, x, rng = _conv_case(oracle, cin * 7 + cout, cin, cout)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) * 0.2).astype(np.float32)
+    gy = rng.standard_normal((idx.shape[0], cout)).astype(np.float32)
+    pairs, pn = oracle.indice_pairs_subm(idx, batch, shape, 3)
+    x64, w64, g64 = (torch.from_numpy(a).double() for a in (x, w, gy))
+    ref_y = oracle.indice_conv(x64, w64, pairs, pn, idx.shape[0], False, True)
+    ref_dx, ref_dw = oracle.indice_conv_backward(x64, w64, g64, pairs, pn, False, True)
+
+    conv = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="k").to(dev())
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(w))
+    xt = torch.from_numpy(x).to(dev()).requires_grad_(True)
+    st = spconv.SparseConvTensor(xt, torch.from_numpy(idx).to(dev()), shape, batch)
+    out = conv(st)
+    out.features.backward(torch.from_numpy(gy).to(dev()))
+    assert rel_err(out.features.detach().cpu(), ref_y) < RTOL
+    assert rel_err(xt.grad.cpu(), ref_dx) < RTOL
+    assert rel_err(conv.weight.grad.cpu(), ref_dw) < RTOL
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 48), (96, 112), (6, 10)])
+def test_down2_and_inverse_conv_fwd_bwd(native_lib, oracle, cin, cout):
+    from doda_amd import spconv
+    idx, shape, batch, x, rng = _conv_case(oracle, cin + cout, cin, cout, shape=(25, 20, 23))
+    w = (rng.standard_normal((2, 2, 2, cin, cout)) * 0.3).astype(np.float32)
+    wi = (rng.standard_normal((2, 2, 2, cout, cin)) * 0.3).astype(np.float32)
+    oi, pairs, pn, oshape = oracle.indice_pairs_conv(idx, batch, shape, 2, 2, 0, 1)
+    gy = rng.standard_normal((idx.shape[0], cin)).astype(np.float32)
+    x64, w64, wi64, g64 = (torch.from_numpy(a).double() for a in (x, w, wi, gy))
+    ref_mid = oracle.indice_conv(x64, w64, pairs, pn, oi.shape[0], False, False)
+    ref_y = oracle.indice_conv(ref_mid, wi64, pairs, pn, idx.shape[0], True, False)
+    ref_dmid, ref_dwi = oracle.indice_conv_backward(ref_mid, wi64, g64, pairs, pn, True, False)
+    ref_dx, ref_dw = oracle.indice_conv_backward(x64, w64, ref_dmid, pairs, pn, False, False)
+
+    down = spconv.SparseConv3d(cin, cout, kernel_size=2, stride=2, bias=False, indice_key="d").to(dev())
+    up = spconv.SparseInverseConv3d(cout, cin, kernel_size=2, bias=False, indice_key="d").to(dev())
+    with torch.no_grad():
+        down.weight.copy_(torch.from_numpy(w))
+        up.weight.copy_(torch.from_numpy(wi))
+    xt = torch.from_numpy(x).to(dev()).requires_grad_(True)
+    st = spconv.SparseConvTensor(xt, torch.from_numpy(idx).to(dev()), shape, batch)
+    mid = down(st)
+    assert mid.spatial_shape == oshape
+    assert np.array_equal(mid.indices.cpu().numpy(), oi)
+    out = up(mid)
+    assert np.array_equal(out.indices.cpu().numpy(), idx) and out.spatial_shape == shape
+    out.features.backward(torch.from_numpy(gy).to(dev()))
+    assert rel_err(mid.features.detach().cpu(), ref_mid) < RTOL
+    assert rel_err(out.features.detach().cpu(), ref_y) < RTOL
+    assert rel_err(xt.grad.cpu(), ref_dx) < RTOL
+    assert rel_err(down.weight.grad.cpu(), ref_dw) < RTOL
+    assert rel_err(up.weight.grad.cpu(), ref_dwi) < RTOL
+
+
+def test_subm_conv_matches_dense_definition(native_lib):
+    """The HIP path against the definitional dense conv3d (fp64), independent of the rulebook
+    restatement."""
+    from doda_amd import spconv
+    from oracle import dense_ref
+    shape, batch = [14, 12, 10], 2
+    idx = random_voxels(4, 500, batch, shape)
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((idx.shape[0], 16)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 16, 32)) * 0.2).astype(np.float32)
+    ref = dense_ref.subm_conv(torch.from_numpy(x).double(), idx, shape, batch, torch.from_numpy(w).double())
+    conv = spconv.SubMConv3d(16, 32, 3, padding=1, bias=False).to(dev())
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(w))
+    st = spconv.SparseConvTensor(torch.from_numpy(x).to(dev()), torch.from_numpy(idx).to(dev()), shape, batch)
+    assert rel_err(conv(st).features.detach().cpu(), ref) < RTOL
+
+
+def test_conv1x1_and_empty(native_lib):
+    from doda_amd import spconv
+    conv = spconv.SubMConv3d(32, 16, kernel_size=1, bias=False).to(dev())
+    x = torch.randn(100, 32, device=dev())
+    idx = torch.from_numpy(random_voxels(1, 100, 1, [8, 8, 8])).to(dev())
+    out = conv(spconv.SparseConvTensor(x, idx, [8, 8, 8], 1))
+    assert torch.allclose(out.features, x @ conv.weight.view(32, 16), rtol=1e-5, atol=1e-5)
+    conv3 = spconv.SubMConv3d(16, 16, 3, padding=1, bias=False, indice_key="e").to(dev())
+    e = spconv.SparseConvTensor(torch.zeros(0, 16, device=dev()),
+                                torch.zeros((0, 4), dtype=torch.int32, device=dev()), [8, 8, 8], 1)
+    assert conv3(e).features.shape == (0, 16)
+
+
+def test_maxpool_fwd_bwd(native_lib, oracle):
+    from doda_amd import spconv
+    shape, batch = [10, 12, 8], 2
+    idx = random_voxels(6, 400, batch, shape)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((idx.shape[0], 8)).astype(np.float32)
+    oi, pairs, pn, _ = oracle.indice_pairs_conv(idx, batch, shape, 2, 2, 0, 1)
+    ref = oracle.indice_maxpool(torch.from_numpy(x), pairs, pn, oi.shape[0])
+    pool = spconv.SparseMaxPool3d(2, 2)
+    xt = torch.from_numpy(x).to(dev()).requires_grad_(True)
+    out = pool(spconv.SparseConvTensor(xt, torch.from_numpy(idx).to(dev()), shape, batch))
+    assert np.array_equal(out.features.detach().cpu().numpy(), ref.numpy())
+    out.features.sum().backward()
+    # each output channel routes its unit gradient to the arg-max input(s)
+    g = xt.grad.cpu().numpy()
+    assert g.min() >= 0 and abs(g.sum() - (ref.numpy() > 0).sum()) < 1e-3
+
+
+# ------------------------------------------------------------------ neighbour queries
+def _clouds(seed, sizes, lattice=False):
+    rng = np.random.default_rng(seed)
+    pts = []
+    for n in sizes:
+        if lattice:
+            pts.append(rng.integers(0, 4, size=(n, 3)).astype(np.float32))  # many exact ties
+        else:
+            pts.append(rng.standard_normal((n, 3)).astype(np.float32))
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    return np.concatenate(pts, 0), off
+
+
+@pytest.mark.parametrize("k", [1, 3, 16, 100])
+@pytest.mark.parametrize("lattice", [False, True])
+def test_knnquery_bit_exact(native_lib, oracle, k, lattice):
+    from doda_amd import pointops2
+    xyz, off = _clouds(1, [700, 300, 1200], lattice)
+    new_xyz, noff = _clouds(2, [900, 100, 500], lattice)
+    ref_idx, ref_d2 = oracle.knnquery(k, xyz, new_xyz, off[1:], noff[1:])
+    d = dev()
+    idx, dist = pointops2.knnquery(k, torch.from_numpy(xyz).to(d), torch.from_numpy(new_xyz).to(d),
+                                   torch.from_numpy(off).to(d), torch.from_numpy(noff).to(d))
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    assert np.array_equal(dist.cpu().numpy(), np.sqrt(ref_d2))
+
+
+def test_knnquery_survey_known_answer(native_lib):
+    """recorded from the reference kernel body (heap order on a 3-way tie)."""
+    from doda_amd import pointops2
+    d = dev()
+    xyz = torch.tensor([[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [5, 5, 5]], dtype=torch.float32, device=d)
+    q = torch.tensor([[0, 0, 0], [0.5, 0, 0]], dtype=torch.float32, device=d)
+    idx, dist = pointops2.knnquery(3, xyz, q, torch.tensor([0, 5], dtype=torch.int32, device=d),
+                                   torch.tensor([0, 2], dtype=torch.int32, device=d))
+    assert idx.cpu().tolist() == [[0, 2, 1], [1, 0, 3]]
+    assert torch.allclose(dist.cpu() ** 2, torch.tensor([[0, 1, 1], [0.25, 0.25, 1.25]]))
+
+
+@pytest.mark.parametrize("k", [1, 8, 40])
+def test_knn_batch_bit_exact(native_lib, oracle, k):
+    from doda_amd import pointgroup_ops as pg
+    xyz, off = _clouds(3, [400, 600], True)
+    qxyz, qoff = _clouds(4, [500, 300], True)
+    bi = np.repeat(np.arange(2), np.diff(off)).astype(np.int32)
+    ref = oracle.knn_batch(xyz, qxyz, bi, qoff, k)
+    d = dev()
+    got = pg.knn(torch.from_numpy(xyz).to(d), torch.from_numpy(qxyz).to(d), torch.from_numpy(bi).to(d),
+                 torch.from_numpy(qoff).to(d), k)
+    assert np.array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("mean_active", [2, 50])
+def test_ballquery_bit_exact(native_lib, oracle, mean_active):
+    from doda_amd import pointgroup_ops as pg
+    xyz, off = _clouds(5, [800, 500])
+    bi = np.repeat(np.arange(2), np.diff(off)).astype(np.int32)
+    d = dev()
+    idx, start_len = pg.ballquery_batch_p(torch.from_numpy(xyz).to(d), torch.from_numpy(bi).to(d),
+                                          torch.from_numpy(off).to(d), 0.6, mean_active)
+    # replay the wrapper's grow-and-retry loop on the oracle
+    ma = mean_active
+    while True:
+        ref_idx, ref_sl, total = oracle.ballquery(xyz, bi, off, 0.6, ma)
+        if total <= xyz.shape[0] * ma:
+            break
+        ma = int(total // xyz.shape[0] + 1)
+    assert np.array_equal(start_len.cpu().numpy(), ref_sl)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx[:total])

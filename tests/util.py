@@ -1,0 +1,34 @@
+"""Shared helpers for the tests: seeded synthetic voxel sets."""
+import numpy as np
+
+
+def random_voxels(seed, n, batch, shape):
+    """n unique (b,x,y,z) int32 rows in random order."""
+    rng = np.random.default_rng(seed)
+    cells = batch * shape[0] * shape[1] * shape[2]
+    n = min(n, cells)
+    lin = rng.choice(cells, size=n, replace=False)
+    z = lin % shape[2]
+    y = (lin // shape[2]) % shape[1]
+    x = (lin // (shape[2] * shape[1])) % shape[0]
+    b = lin // (shape[2] * shape[1] * shape[0])
+    return np.stack([b, x, y, z], 1).astype(np.int32)
+
+
+def surface_voxels(seed, n, batch, shape):
+    """Voxels concentrated on a few planes (ScanNet-like neighbourhood statistics)."""
+    rng = np.random.default_rng(seed)
+    pts = set()
+    while len(pts) < n:
+        b = int(rng.integers(batch))
+        axis = int(rng.integers(3))
+        level = int(rng.integers(shape[axis]))
+        for _ in range(64):
+            p = [int(rng.integers(shape[0])), int(rng.integers(shape[1])), int(rng.integers(shape[2]))]
+            p[axis] = min(shape[axis] - 1, level + int(rng.integers(2)))
+            pts.add((b, p[0], p[1], p[2]))
+            if len(pts) >= n:
+                break
+    arr = np.array(list(pts), dtype=np.int32)
+    rng.shuffle(arr)
+    return arr
