@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py — headline metric of BASELINE.json on synthetic ScanNet-shaped scenes.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one training pass of the SparseConv U-Net over one resident batch on each GPU:
+voxel mean-pooling (pointgroup_ops.voxelization) -> SparseConvTensor -> 7-level U-Net forward
+(all 13 rulebooks rebuilt, as every real batch differs) -> cross-entropy -> backward (weight + data
+gradients of all 71 sparse convs; DDP gradient all-reduce over RCCL when N > 1) -> SGD step.
+Inputs are already in HBM when the timed region starts.  value = (sum over ranks of level-1 active
+voxels) * K / max-over-ranks time.  Weak scaling: every rank holds its own batch of
+`--scenes` scenes (cfgs/scannet BATCH_SIZE_PER_GPU = 4) of ~`--voxels` active voxels.
+
+The JSON line also carries
+  roofline     : the dominant kernel (SubM 16->16 gather at level-1 size), timed live with HIP
+                 events on the launch stream, against the HBM roofline with ALGORITHMIC bytes
+                 (DESIGN.md §4);
+  cpu_baseline : the CPU oracle's U-Net (oracle/unet_cpu.py — a port: spconv's CPU path cannot be
+                 built here) fwd+bwd on a bounded sample, on this box's host cores (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    p.add_argument("--scenes", type=int, default=4, help="scenes per GPU (BATCH_SIZE_PER_GPU)")
+    p.add_argument("--voxels", type=int, default=150000, help="target active voxels per scene")
+    p.add_argument("--voxel-scale", type=int, default=50)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-voxels", type=int, default=150000, help="size of the CPU-baseline sample scene")
+    p.add_argument("--kernel-reps", type=int, default=50)
+    return p.parse_args()
+
+
+def kernel_roofline(batch_dev, dtype, reps):
+    """Time the dominant kernel live: SubMConv3d 16->16 forward gather on the batch's level-1
+    rulebook.  Algorithmic bytes per launch: s*(M*Cin + M*Cout) + s*K*Cin*Cout + 8*P."""
+    from doda_amd import ops, spconv
+    dev = batch_dev["voxel_locs"].device
+    idx = batch_dev["voxel_locs"].int()
+    m = idx.shape[0]
+    nb = int(batch_dev["offsets"].numel() - 1)
+    data = spconv.ops.build_subm(idx, nb, batch_dev["spatial_shape"], 3)
+    pairs_total = int((data.tbl >= 0).sum().item())
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    x = torch.randn(m, 16, device=dev).to(tdt)
+    gy = torch.randn(m, 16, device=dev).to(tdt)
+    w = torch.randn(27, 16, 16, device=dev) * 0.1
+    s = 4 if dtype == "f32" else 2
+    out = {}
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()  # current stream == the stream ops.* launches on
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    b_f = s * (m * 16 + m * 16) + 4 * 27 * 16 * 16 + 8 * pairs_total
+    b_w = s * (m * 16 + m * 16) + 4 * 27 * 16 * 16 + 8 * pairs_total
+    t_f = timed(lambda: ops.spconv_gather(x, w, data.tbl, m, 0, 16))
+    t_d = timed(lambda: ops.spconv_gather(gy, w, data.tbl, m, 2, 16))
+    t_w = timed(lambda: ops.spconv_wgrad(x, gy, data.tbl, m))
+    out["subm16_fwd"] = {"us": t_f * 1e6, "GBs": b_f / t_f / 1e9}
+    out["subm16_dgrad"] = {"us": t_d * 1e6, "GBs": b_f / t_d / 1e9}
+    out["subm16_wgrad"] = {"us": t_w * 1e6, "GBs": b_w / t_w / 1e9}
+    # north-star gate: whole SubMConv3d fwd+bwd vs (B_f + B_b)
+    b_b = s * (2 * m * 16 + m * 16) + 2 * 4 * 27 * 16 * 16 + 8 * pairs_total
+    t_all = t_f + t_d + t_w
+    out["subm16_fwd_bwd"] = {"us": t_all * 1e6, "GBs": (b_f + b_b) / t_all / 1e9,
+                             "frac_of_hbm_peak": (b_f + b_b) / t_all / 1e9 / HBM_PEAK_GBS}
+    dom = "subm16_fwd"
+    roof = {"kernel": "conv_gather_%s<NB=1,S=4> (SubMConv3d 16->16 fwd, M=%d, P=%d)" % (dtype, m, pairs_total),
+            "bound": "hbm", "achieved": out[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": out[dom]["GBs"] / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": b_f, "avg_launch_us": out[dom]["us"], "detail": out}
+    return roof, pairs_total / max(m, 1)
+
+
+def cpu_baseline(args):
+    """Oracle U-Net fwd+bwd (fp32, torch-CPU threads = all host cores) on ONE scene."""
+    from doda_amd.scene import make_batch
+    from oracle.unet_cpu import OracleUNet, forward_backward
+    batch = make_batch(1, args.cpu_voxels, 1000, args.voxel_scale)
+    torch.manual_seed(0)
+    net = OracleUNet().train()
+    t0 = time.time()
+    forward_backward(net, batch)
+    dt = time.time() - t0
+    m = batch["voxel_locs"].shape[0]
+    return {"value": m / dt, "unit": "voxels/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 scene (%d active voxels), 1 U-Net fwd+bwd incl. serial rulebook build, fp32, "
+                      "oracle/unet_cpu.py (spconv CPU path cannot be built: restatement stands in)" % m,
+            "seconds": dt}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from doda_amd.build import build_native
+    from doda_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH) and rank == 0:
+        build_native(verbose=False)
+    if world > 1:
+        dist.barrier()
+    _lib.lib()
+    from doda_amd.model import SparseConvNet, default_cfg, voxelize_and_run
+    from doda_amd.scene import make_batch
+
+    batch = make_batch(args.scenes, args.voxels, 1000 + 100 * rank, args.voxel_scale)
+    batch_dev = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    m_local = batch["voxel_locs"].shape[0]
+    n_local = batch["locs"].shape[0]
+
+    cfg = default_cfg()
+    torch.manual_seed(0)
+    net = SparseConvNet(cfg).to(dev).train()
+    model = net
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(
+            net, device_ids=[local_rank], broadcast_buffers=False, gradient_as_bucket_view=True)
+    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    fdt = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    labels = batch_dev["labels"]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        scores = voxelize_and_run(cfg, model, batch_dev, dev, feature_dtype=fdt)
+        loss = torch.nn.functional.cross_entropy(scores.float(), labels, ignore_index=255)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    stats = torch.tensor([elapsed, float(m_local), float(n_local)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = stats[1:].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed, m_total, n_total = float(tmax[0]), float(tot[0]), float(tot[1])
+    else:
+        m_total, n_total = float(m_local), float(n_local)
+    final_loss = float(loss)
+
+    if rank == 0:
+        roof, ppv = kernel_roofline(batch_dev, args.dtype, args.kernel_reps)
+        line = {
+            "metric": "active-voxels/sec fwd+bwd SparseConv U-Net, ScanNet 2cm",
+            "value": m_total * args.steps / elapsed, "unit": "voxels/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "cfgs/scannet SparseConv U-Net training step (voxel pooling + fwd "
+                                   "+ CE + bwd + SGD), 2 cm voxels, %d scenes/GPU x ~%d active voxels, "
+                                   "random-init weights" % (args.scenes, args.voxels),
+                       "global_batch": args.scenes * world, "voxels_per_gpu": m_local,
+                       "points_per_gpu": n_local, "pairs_per_voxel_subm1": round(ppv, 2),
+                       "parallelism": "dp%d" % world, "n_classes": 20, "final_loss": final_loss},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

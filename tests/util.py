@@ -32,3 +32,28 @@ def surface_voxels(seed, n, batch, shape):
     arr = np.array(list(pts), dtype=np.int32)
     rng.shuffle(arr)
     return arr
+
+
+def deterministic_init(model, seed=0):
+    """Re-initialise every parameter / BN buffer from one CPU generator, visiting state-dict keys in
+    sorted order, so two structurally equivalent models (the reference's SparseConvNet and
+    doda_amd.model.SparseConvNet) get identical weights regardless of construction order."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for key in sorted(sd.keys()):
+            t = sd[key]
+            if key.endswith("num_batches_tracked"):
+                t.zero_()
+            elif key.endswith("running_mean"):
+                t.copy_(0.1 * torch.randn(t.shape, generator=g))
+            elif key.endswith("running_var"):
+                t.copy_(1.0 + 0.2 * torch.rand(t.shape, generator=g))
+            elif t.dim() == 1:  # BN affine / biases
+                base = 1.0 if key.endswith("weight") else 0.0
+                t.copy_(base + 0.1 * torch.randn(t.shape, generator=g))
+            else:
+                fan_in = t.shape[-2] * (t.numel() // (t.shape[-1] * t.shape[-2])) if t.dim() == 5 else t.shape[1]
+                t.copy_(torch.randn(t.shape, generator=g) * (1.5 / max(fan_in, 1)) ** 0.5)
+    return model
