@@ -36,18 +36,23 @@ _SIGNATURES = {
     "doda_rulebook_pairs_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "doda_rulebook_pairs": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_sz,
                                     c_vp]),
-    "doda_spconv_gather_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
-                                       c_i32, c_vp]),
+    "doda_spconv_gather_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "doda_spconv_gather_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
+                                       c_i32, c_vp, c_sz, c_vp]),
     "doda_spconv_wgrad_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "doda_spconv_wgrad_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
                                       c_vp, c_sz, c_vp]),
-    "doda_spconv_gather_bf16_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
-    "doda_spconv_gather_bf16": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
+    "doda_spconv_gather_bf16": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
                                         c_i32, c_vp, c_sz, c_vp]),
     "doda_spconv_wgrad_bf16": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
                                        c_vp, c_sz, c_vp]),
     "doda_maxpool_fwd_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "doda_maxpool_bwd_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "doda_bn_workspace_bytes": (c_sz, [c_i32, c_i32]),
+    "doda_bn_relu_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                 c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "doda_bn_relu_bwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
+                                 c_vp, c_vp, c_vp, c_sz, c_vp]),
     "doda_knnquery": (c_i32, [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "doda_knn_batch": (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "doda_ballquery_workspace_bytes": (c_sz, [c_i32]),

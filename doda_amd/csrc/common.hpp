@@ -88,6 +88,16 @@ __device__ __forceinline__ int wave_inclusive_sum(int v) {
     return v;
 }
 
+// XCD-aware work mapping (guide T1).  Blocks are dealt round-robin to the 8 XCDs (block b runs on
+// XCD b % 8, each with a private 4 MB L2); give every XCD one CONTIGUOUS range of work items so
+// that the rows its blocks gather stay in its own L2.  Bijective for any grid size; a different
+// hardware placement only costs speed.
+__device__ __forceinline__ int xcd_work_item(int bid, int n_items) {
+    const int q = n_items >> 3, r = n_items & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
 // Exclusive prefix sum over int32 arrays of any length: three launches, deterministic.
 // ws_ints: scratch of at least scan_ws_ints(n) ints.  Optionally writes the grand total.
 size_t scan_ws_ints(int n);

@@ -1,0 +1,558 @@
+// Sparse-convolution arithmetic: gather -> MFMA -> single wide store per output row.
+// fp32 and bf16 feature storage from one template.
+//
+// Replaces spconv v1.2's indice_conv / indice_conv_backward data path (per offset: sparse_gather
+// kernel, cuBLAS mm, sparse_scatter_add kernel; reference call sites model/unet_block.py:26,29,
+// 48,70,78).  MI355X-first design:
+//   * OUTPUT-STATIONARY.  A wave owns S subtiles of 16 consecutive output rows x NBW blocks of 16
+//     output channels.  Per kernel offset o it gathers rows tbl[o][t] of x straight into MFMA
+//     operand layout (lane (row, g) loads the 4-channel quad g of its row: 16 B fp32 / 8 B bf16,
+//     a whole 64 B / 32 B row per 4 lanes), multiplies by W[o] and accumulates in registers.
+//     Every output row is written once: no gather/scatter buffers in HBM, no atomics, deterministic.
+//   * The block's slice of the gather table is staged once into LDS with coalesced reads; each
+//     wave then derives the set of offsets that have at least one present row (27-bit mask in an
+//     SGPR) and walks only those — absent offsets cost nothing.
+//   * All global loads of the next (offset, 16-channel chunk) unit are issued before the MFMAs of
+//     the current one (two register buffer sets, no copies), so the in-order vmcnt wait of unit u
+//     never covers unit u+1: gather latency overlaps MFMA + the other waves.
+//   * Weights are pre-packed (tiny kernel, L2-resident result) into MFMA fragment order, rounded
+//     to bf16 for the bf16 path, with the transposition / offset mirroring of the data-grad
+//     layouts folded in, so a B fragment is one 16 B / 8 B load per lane.
+//   * MFMA operands are swapped (W fragment first, x fragment second) so that each lane ends up
+//     with 4 consecutive output channels of ONE row: a single 16 B / 8 B store per fragment.
+//   * fp32: v_mfma_f32_16x16x4_f32 (exact fmaf chain); bf16: v_mfma_f32_16x16x16_bf16, fp32
+//     accumulate, one RNE rounding at the store.
+// Bound: HBM for table + feature bytes; MFMA only for the dense contraction.
+#include "common.hpp"
+#include <stdlib.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+struct F32 {
+    typedef float elem;
+    typedef f32x4 frag;  // 4 channels of one row / 4 k-slots of a weight column
+    static __device__ __forceinline__ frag zero() { return (frag){0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ elem from_float(float f) { return f; }
+    static __device__ __forceinline__ void mma(f32x4 &acc, const frag &w, const frag &x) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q], x[q], acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void store4(elem *p, const f32x4 &v) {
+        *reinterpret_cast<f32x4 *>(p) = v;
+    }
+};
+
+struct BF16 {
+    typedef unsigned short elem;
+    typedef s16x4 frag;
+    static __device__ __forceinline__ frag zero() { return (frag){0, 0, 0, 0}; }
+    static __device__ __forceinline__ elem from_float(float f) { return f2bf(f); }
+    static __device__ __forceinline__ void mma(f32x4 &acc, const frag &w, const frag &x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w, x, acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void store4(elem *p, const f32x4 &v) {
+        s16x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (short)f2bf(v[q]);
+        *reinterpret_cast<s16x4 *>(p) = o;
+    }
+};
+
+// packed[o][cc][nb][lane] = frag{ B_o[cc*16 + 4g + q][nb*16 + i] : q = 0..3 }, lane = 16g + i
+// B_o = W[o] (layout 0, w: [K][kc][nc]), W[o]^T (1, w: [K][nc][kc]), W[K-1-o]^T (2).
+template <class T>
+__global__ __launch_bounds__(256) void pack_weights(const float *__restrict__ w, int K, int kc,
+                                                    int nc, int n_chunk, int NB, int wl,
+                                                    typename T::frag *__restrict__ packed) {
+    const long long total = (long long)K * n_chunk * NB * 64;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int lane = (int)(e & 63);
+    long long r = e >> 6;
+    const int nb = (int)(r % NB); r /= NB;
+    const int cc = (int)(r % n_chunk);
+    const int o = (int)(r / n_chunk);
+    const int i = lane & 15, g = lane >> 4;
+    const int col = nb * 16 + i;
+    typename T::frag v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = cc * 16 + 4 * g + q;
+        float f = 0.f;
+        if (c < kc && col < nc) {
+            if (wl == 0) f = w[((long long)o * kc + c) * nc + col];
+            else f = w[((long long)(wl == 2 ? K - 1 - o : o) * nc + col) * kc + c];
+        }
+        v[q] = T::from_float(f);
+    }
+    packed[e] = v;
+}
+
+constexpr int MAX_K = 27;
+
+template <class T, int NBW, int S>
+__global__ __launch_bounds__(256) void conv_gather(const typename T::elem *__restrict__ x, int kc,
+                                                   const typename T::frag *__restrict__ wp, int nc,
+                                                   int NB, const int32_t *__restrict__ tbl, int ld,
+                                                   int K, int n_out,
+                                                   typename T::elem *__restrict__ y, int vec_ok) {
+    typedef typename T::frag frag;
+    typedef typename T::elem elem;
+    constexpr int TM = 4 * 16 * S;  // rows per block
+    __shared__ int32_t idx_tile[MAX_K * TM];
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    // work item = (row tile, channel-block group), group fastest; contiguous items per XCD
+    const int n_nbg = (NB + NBW - 1) / NBW;
+    const int item = xcd_work_item(blockIdx.x, gridDim.x);
+    const long long r0 = (long long)(item / n_nbg) * TM;
+    const int nb0 = (item % n_nbg) * NBW;
+
+    // ---- stage the block's table slice (coalesced) ----
+    for (int e = threadIdx.x; e < K * TM; e += 256) {
+        const int o = e / TM, r = e - o * TM;
+        idx_tile[e] = (r0 + r < n_out) ? tbl[(long long)o * ld + r0 + r] : -1;
+    }
+    __syncthreads();
+
+    const int wrow = wid * 16 * S;  // this wave's first row inside the tile
+    if (r0 + wrow >= n_out) return;
+
+    // ---- offsets with at least one present row among this wave's rows ----
+    unsigned int active = 0;
+    for (int o = 0; o < K; ++o) {
+        bool any = false;
+#pragma unroll
+        for (int s = 0; s < S; ++s) any |= idx_tile[o * TM + wrow + s * 16 + i] >= 0;
+        if (__ballot(any) != 0ull) active |= 1u << o;
+    }
+    active = __builtin_amdgcn_readfirstlane(active);
+
+    f32x4 acc[S][NBW];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) acc[s][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int n_chunk = (kc + 15) / 16;
+
+    auto load_unit = [&](int o, int cc, frag (&xa)[S], frag (&wb)[NBW]) {
+        const int c0 = cc * 16 + 4 * g;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int idx = idx_tile[o * TM + wrow + s * 16 + i];
+            xa[s] = T::zero();
+            if (idx >= 0 && c0 < kc) {
+                const elem *row = x + (long long)idx * kc + c0;
+                if (vec_ok) {
+                    xa[s] = *reinterpret_cast<const frag *>(row);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + q < kc) xa[s][q] = row[q];
+                }
+            }
+        }
+        const frag *wrow_p = wp + (((long long)o * n_chunk + cc) * NB + nb0) * 64 + lane;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+            if (nb0 + nb < NB) wb[nb] = wrow_p[nb * 64];
+    };
+    auto mma_unit = [&](const frag (&xa)[S], const frag (&wb)[NBW]) {
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int s = 0; s < S; ++s) T::mma(acc[s][nb], wb[nb], xa[s]);
+    };
+    // advance (o, cc) to the next unit; returns false when exhausted (wave-uniform)
+    auto advance = [&](int &o, int &cc) -> bool {
+        if (++cc < n_chunk) return true;
+        cc = 0;
+        if (active == 0) return false;
+        o = __builtin_ctz(active);
+        active &= active - 1;
+        return true;
+    };
+
+    if (active != 0) {
+        frag xa0[S], xa1[S], wb0[NBW], wb1[NBW];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) { wb0[nb] = T::zero(); wb1[nb] = T::zero(); }
+        int o = __builtin_ctz(active), cc = 0;
+        active &= active - 1;
+        load_unit(o, cc, xa0, wb0);
+        for (;;) {
+            const bool m1 = advance(o, cc);
+            if (m1) load_unit(o, cc, xa1, wb1);
+            mma_unit(xa0, wb0);
+            if (!m1) break;
+            const bool m0 = advance(o, cc);
+            if (m0) load_unit(o, cc, xa0, wb0);
+            mma_unit(xa1, wb1);
+            if (!m0) break;
+        }
+    }
+
+    // D[i = channel 4g+r][j = row]: lane (row = lane&15, g) holds 4 consecutive channels
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const long long t = r0 + wrow + s * 16 + i;
+        if (t < n_out) {
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                const int col = (nb0 + nb) * 16 + 4 * g;
+                if (nb0 + nb < NB) {
+                    elem *p = y + t * nc + col;
+                    if (vec_ok && col + 3 < nc) {
+                        T::store4(p, acc[s][nb]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col + r < nc) p[r] = T::from_float(acc[s][nb][r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Fast path (kc % 16 == 0, nc % 16 == 0, 16-byte aligned, buffers < 2 GB): the same algorithm with
+// the instruction stream and the memory pipeline under explicit control.  Measured on MI355X the
+// generic kernel is instruction-issue bound at 16..32 channels (~4000 instructions per 64-row
+// wave) and, once that is fixed, latency bound: hipcc waits vmcnt(0) before every MFMA group of a
+// software-pipelined loop, so nothing is ever in flight (guide §5.7 / T3+T4).  Hence:
+//   * every global access is a raw BUFFER op: 32-bit offsets (one VALU add per gather) and
+//     hardware range checking — an absent neighbour is an out-of-range offset that returns
+//     zeros, a row past n_out is a dropped store: no exec-mask branches in the loop;
+//   * phase 0 turns the wave's slice of the gather table into BYTE OFFSETS once (one multiply
+//     per table entry, not per gather) in a wave-private LDS strip and derives the active-offset
+//     mask from the same registers (ballot); weight fragments are addressed on the scalar side;
+//   * the (offset, chunk) units run through a ring of D register sets filled by INLINE-ASM
+//     buffer loads that hipcc does not count, with hand-placed `s_waitcnt vmcnt((D-1)*L)`:
+//     D-1 units (L = S + NBW loads each) stay in flight across every MFMA group.  When the real
+//     units run out the ring is topped up with an all-out-of-range dummy unit (returns zeros),
+//     which keeps L constant and the loop branch-free.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ u32x4 make_rsrc(const void *p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    u32x4 r;
+    r[0] = (unsigned)a;
+    r[1] = (unsigned)(a >> 32) & 0xffffu;  // stride 0: raw buffer, byte offsets
+    r[2] = bytes;                          // num_records
+    r[3] = 0x00020000u;
+    return r;
+}
+
+template <class T> struct RawIO;
+template <> struct RawIO<F32> {
+    typedef u32x4 raw;
+    static __device__ __forceinline__ void load(raw &dst, unsigned voff, const u32x4 &rs, unsigned soff) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff));
+    }
+    static __device__ __forceinline__ void store(const f32x4 &v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 as_frag(const raw &r) { return __builtin_bit_cast(f32x4, r); }
+};
+template <> struct RawIO<BF16> {
+    typedef u32x2 raw;
+    static __device__ __forceinline__ void load(raw &dst, unsigned voff, const u32x4 &rs, unsigned soff) {
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff));
+    }
+    static __device__ __forceinline__ void store(const f32x4 &v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+        s16x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (short)f2bf(v[q]);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), r, voff, 0, 0);
+    }
+    static __device__ __forceinline__ s16x4 as_frag(const raw &r) { return __builtin_bit_cast(s16x4, r); }
+};
+
+// wait until at most N of the asm-issued loads are outstanding; `first` (and every register passed
+// to touch() right after) is marked as written here so no consumer can be scheduled above it
+template <int N, class R>
+__device__ __forceinline__ void wait_vm(R &first) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(first) : "n"(N));
+}
+template <class R>
+__device__ __forceinline__ void touch(R &r) {
+    asm volatile("" : "+v"(r));
+}
+
+template <class T, int NBW, int S, int D>
+__global__ __launch_bounds__(256) void conv_fast(const typename T::elem *__restrict__ x,
+                                                 unsigned x_bytes, int kc,
+                                                 const typename T::frag *__restrict__ wp,
+                                                 unsigned wp_bytes, int nc, int NB,
+                                                 const int32_t *__restrict__ tbl,
+                                                 unsigned tbl_bytes, int ld, int K, int n_out,
+                                                 typename T::elem *__restrict__ y,
+                                                 unsigned y_bytes) {
+    typedef typename T::frag frag;
+    typedef typename T::elem elem;
+    typedef typename RawIO<T>::raw raw;
+    constexpr int RW = 16 * S;                 // rows per wave
+    constexpr int OPI = 64 / RW;               // table offsets fetched per load instruction
+    constexpr int NLD = (MAX_K + 1 + OPI - 1) / OPI;  // strips 0..MAX_K; strip MAX_K is all-OOB
+    constexpr int L = S + NBW;                 // asm loads per unit
+    constexpr unsigned ESZ = sizeof(elem), FSZ = sizeof(frag);
+    static_assert((D - 1) * L <= 63, "vmcnt field");
+    __shared__ unsigned off_tile[4][NLD * 64];
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int n_nbg = (NB + NBW - 1) / NBW;
+    const int item = xcd_work_item(blockIdx.x, gridDim.x);
+    const int nb0 = (item % n_nbg) * NBW;
+    const int row0 = ((item / n_nbg) * 4 + wid) * RW;   // this wave's first output row
+
+    const u32x4 rs_x = make_rsrc(x, x_bytes), rs_w = make_rsrc(wp, wp_bytes);
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void *)tbl, 0, tbl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, y_bytes, 0x00020000);
+
+    // ---- phase 0: table slice -> byte offsets in LDS, active-offset mask ----
+    const unsigned row_bytes = (unsigned)kc * ESZ;
+    unsigned active = 0;
+    {
+        const int r = lane & (RW - 1), oq = lane / RW;
+        const bool row_ok = row0 + r < n_out;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int o = j * OPI + oq;
+            const bool ok = row_ok && o < K;
+            const unsigned voff = ok ? ((unsigned)o * (unsigned)ld + (unsigned)(row0 + r)) * 4u : OOB;
+            const int idx = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_t, voff, 0, 0);
+            const bool present = ok && idx >= 0;
+            off_tile[wid][j * 64 + lane] = present ? (unsigned)idx * row_bytes : OOB;
+            const unsigned long long b = __ballot(present);
+#pragma unroll
+            for (int q = 0; q < OPI; ++q) {
+                const unsigned long long part = (RW == 64) ? b : ((b >> (q * RW)) & ((1ull << (RW & 63)) - 1ull));
+                if (part != 0ull && j * OPI + q < 32) active |= 1u << (j * OPI + q);
+            }
+        }
+    }
+    active = __builtin_amdgcn_readfirstlane(active);
+    __syncthreads();
+
+    f32x4 acc[S][NBW];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) acc[s][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int n_chunk = kc >> 4;
+    const unsigned lane_x = (unsigned)g * FSZ;       // this lane's channel quad inside a 16-ch chunk
+    const unsigned lane_w = (unsigned)lane * FSZ;    // this lane's slot inside a packed W fragment
+    const unsigned *my_off = &off_tile[wid][i];
+
+    int units_left = __builtin_popcount(active) * n_chunk;
+    if (units_left > 0) {
+        raw xa[D][S], wb[D][NBW];
+        // (o, cc, have): the next unit to issue
+        int o = __builtin_ctz(active), cc = 0;
+        active &= active - 1;
+        bool have = true;
+
+        auto issue = [&](raw (&xr)[S], raw (&wr)[NBW]) {
+            const int o_eff = have ? o : MAX_K;                // strip MAX_K holds only OOB
+            const unsigned *p = my_off + o_eff * RW;
+            const unsigned soff_x = (unsigned)cc * 16u * ESZ;
+#pragma unroll
+            for (int s = 0; s < S; ++s) RawIO<T>::load(xr[s], p[s * 16] + lane_x, rs_x, soff_x);
+            const unsigned soff_w = (unsigned)((o * n_chunk + cc) * NB + nb0) * 64u * FSZ;
+            const unsigned voff_w = have ? lane_w : OOB;
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) RawIO<T>::load(wr[nb], voff_w, rs_w, soff_w + nb * 64u * FSZ);
+            if (have && ++cc == n_chunk) {
+                cc = 0;
+                if (active == 0) have = false;
+                else { o = __builtin_ctz(active); active &= active - 1; }
+            }
+        };
+
+#pragma unroll
+        for (int k = 0; k < D; ++k) issue(xa[k], wb[k]);
+        while (units_left > 0) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                wait_vm<(D - 1) * L>(xa[k][0]);
+#pragma unroll
+                for (int s = 1; s < S; ++s) touch(xa[k][s]);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) touch(wb[k][nb]);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+                        T::mma(acc[s][nb], RawIO<T>::as_frag(wb[k][nb]), RawIO<T>::as_frag(xa[k][s]));
+                issue(xa[k], wb[k]);
+            }
+            units_left -= D;
+        }
+        // retire the loads still in flight (dummy units) before their registers are reused
+        wait_vm<0>(xa[0][0]);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) touch(xa[k][s]);
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) touch(wb[k][nb]);
+        }
+    }
+
+    // lane (row = lane&15, g) holds channels 4g..4g+3 of each 16-channel block: one wide store
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const unsigned t = (unsigned)(row0 + s * 16 + i);
+        const unsigned base = (t < (unsigned)n_out) ? t * (unsigned)nc * ESZ + (unsigned)(nb0 * 16 + 4 * g) * ESZ : OOB;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+            if (nb0 + nb < NB) RawIO<T>::store(acc[s][nb], rs_y, base + nb * 16u * ESZ);
+    }
+}
+
+template <class T, int NBW, int S>
+int launch_fast(const typename T::elem *x, int kc, const typename T::frag *wp, size_t wp_bytes,
+                int nc, int NB, const int32_t *tbl, int ld, int K, int n_out, long long n_in,
+                typename T::elem *y, hipStream_t s) {
+    const dim3 grid(div_up(n_out, 4 * 16 * S) * div_up(NB, NBW)), block(256);
+    constexpr int D = (S + NBW <= 3) ? 8 : ((S + NBW <= 5) ? 6 : ((S + NBW <= 6) ? 4 : 3));
+    hipLaunchKernelGGL((conv_fast<T, NBW, S, D>), grid, block, 0, s, x,
+                       (unsigned)((size_t)n_in * kc * sizeof(typename T::elem)), kc, wp,
+                       (unsigned)wp_bytes, nc, NB, tbl, (unsigned)((size_t)K * ld * 4), ld, K, n_out, y,
+                       (unsigned)((size_t)n_out * nc * sizeof(typename T::elem)));
+    return doda_check_launch();
+}
+
+template <class T, int NBW, int S>
+int launch(const typename T::elem *x, int kc, const typename T::frag *wp, int nc, int NB,
+           const int32_t *tbl, int ld, int K, int n_out, typename T::elem *y, int vec_ok,
+           hipStream_t s) {
+    const dim3 grid(div_up(n_out, 4 * 16 * S) * div_up(NB, NBW)), block(256);
+    hipLaunchKernelGGL((conv_gather<T, NBW, S>), grid, block, 0, s, x, kc, wp, nc, NB, tbl, ld, K,
+                       n_out, y, vec_ok);
+    return doda_check_launch();
+}
+
+template <class T>
+int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tbl, int ld, int K,
+               int n_out, void *y_, int wl, void *ws, size_t ws_bytes, long long n_in,
+               hipStream_t s) {
+    typedef typename T::elem elem;
+    typedef typename T::frag frag;
+    const elem *x = (const elem *)x_;
+    elem *y = (elem *)y_;
+    const int n_chunk = (kc + 15) / 16, NB = (nc + 15) / 16;
+    const size_t need = (size_t)K * n_chunk * NB * 64 * sizeof(frag);
+    if (ws_bytes < need) return DODA_ERR_WORKSPACE;
+    frag *wp = (frag *)ws;
+    const long long total = (long long)K * n_chunk * NB * 64;
+    hipLaunchKernelGGL((pack_weights<T>), dim3(div_up(total, 256)), dim3(256), 0, s, w, K, kc, nc,
+                       n_chunk, NB, wl, wp);
+    // all rows the table may reference must sit inside the 2 GB buffer window of the fast path
+    const bool x_rows_bytes_ok = n_in > 0 && (size_t)n_in * kc * sizeof(elem) < 0x7ffffff0ull;
+    const size_t va = 4 * sizeof(elem);  // vector access granule
+    const int vec_ok = (kc % 4 == 0) && (nc % 4 == 0) && ((uintptr_t)x % va == 0) &&
+                       ((uintptr_t)y % va == 0);
+    // Tile choice: many rows -> more subtiles per wave and all channel blocks in one wave (x is
+    // gathered once); few rows -> one subtile, channel blocks spread over blockIdx.y so the chip
+    // still sees thousands of waves.
+    const long long waves_full = ((long long)n_out + 15) / 16;
+    // x_bytes: the table only references rows that exist, so the buffer bound just has to keep a
+    // present row in range and an absent one (offset 2^31) out: use the 2 GB window.
+    const bool fast = (kc % 16 == 0) && (nc % 16 == 0) && ((uintptr_t)x % 16 == 0) &&
+                      ((uintptr_t)y % 16 == 0) && ((size_t)n_out * nc * sizeof(elem) < 0x7fffffffull) &&
+                      ((size_t)K * ld * 4 < 0xffffffffull) && x_rows_bytes_ok;
+#define GO(NBW, S)                                                                                 \
+    do {                                                                                           \
+        if (fast) return launch_fast<T, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y, s); \
+        return launch<T, NBW, S>(x, kc, wp, nc, NB, tbl, ld, K, n_out, y, vec_ok, s);              \
+    } while (0)
+    static const int force_s = getenv("DODA_S") ? atoi(getenv("DODA_S")) : 0;
+    if (NB == 1 && force_s == 4) GO(1, 4);
+    if (NB == 1 && force_s == 2) GO(1, 2);
+    if (NB == 1 && force_s == 1) GO(1, 1);
+    if (NB == 2 && force_s == 2) GO(2, 2);
+    if (NB == 2 && force_s == 1) GO(2, 1);
+    if (NB == 1) {
+        if (waves_full >= 16384) GO(1, 4);
+        if (waves_full >= 4096) GO(1, 2);
+        GO(1, 1);
+    }
+    if (NB == 2) {
+        if (waves_full >= 8192) GO(2, 2);
+        if (waves_full >= 2048) GO(2, 1);
+        GO(1, 1);
+    }
+    if (NB <= 4) {
+        if (waves_full >= 8192) GO(4, 2);
+        if (waves_full >= 2048) GO(4, 1);
+        if (waves_full >= 512) GO(2, 1);
+        GO(1, 1);
+    }
+    if (waves_full >= 4096) GO(8, 1);
+    if (waves_full >= 1024) GO(4, 1);
+    if (waves_full >= 256) GO(2, 1);
+    GO(1, 1);
+#undef GO
+}
+
+bool bad_args(const void *x, int kc, const float *w, int nc, const int32_t *tbl, int ld, int K,
+              int n_out, const void *y, int wl, int *status) {
+    if (kc <= 0 || nc <= 0 || K <= 0 || n_out < 0 || ld < n_out || wl < 0 || wl > 2) {
+        *status = DODA_ERR_INVALID;
+        return true;
+    }
+    if (n_out == 0) { *status = DODA_OK; return true; }
+    if (!x || !w || !tbl || !y) { *status = DODA_ERR_INVALID; return true; }
+    if (K > MAX_K || nc > 4096 || kc > 4096) { *status = DODA_ERR_UNSUPPORTED; return true; }
+    return false;
+}
+}  // namespace
+
+extern "C" size_t doda_spconv_gather_workspace_bytes(int32_t K, int32_t kc, int32_t nc,
+                                                     int32_t elem_bytes) {
+    if (K <= 0 || kc <= 0 || nc <= 0) return 0;
+    return align_up((size_t)K * ((kc + 15) / 16) * ((nc + 15) / 16) * 64 * 4 * (size_t)elem_bytes, 256);
+}
+
+extern "C" int doda_spconv_gather_f32(const float *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
+                                      const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
+                                      float *y, int32_t w_layout, void *ws, size_t ws_bytes,
+                                      doda_stream_t stream) {
+    int st;
+    if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
+    if (!ws) return DODA_ERR_INVALID;
+    return run_gather<F32>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in,
+                           as_stream(stream));
+}
+
+extern "C" int doda_spconv_gather_bf16(const uint16_t *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
+                                       const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
+                                       uint16_t *y, int32_t w_layout, void *ws, size_t ws_bytes,
+                                       doda_stream_t stream) {
+    int st;
+    if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
+    if (!ws) return DODA_ERR_INVALID;
+    return run_gather<BF16>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in,
+                            as_stream(stream));
+}

@@ -1,0 +1,306 @@
+// Sparse-convolution weight gradient:  dw[o][ci][co] = sum_t a[tbl[o][t]][ci] * b[t][co].
+// (spconv v1.2 indice_conv_backward's per-offset `Xg^T . dYg` GEMMs; reference call sites
+// model/unet_block.py:26,29,48,70,78.)  fp32 and bf16 feature storage from one template.
+//
+// The contraction runs over ROWS, so both MFMA operands need the row index as their k dimension
+// while memory holds channels contiguously: rows go through LDS.  Per block and per step of 64
+// rows:  the dY tile [64][TB*16] is loaded once (coalesced) into a shared LDS tile and each wave
+// lifts its B fragments into registers; then every wave walks ITS OWN subset of kernel offsets
+// (o = wave, wave+4, ...): coalesced read of tbl[o][rows], one contiguous row-slice gather per
+// lane into a wave-private LDS tile, transposed fragment reads, MFMAs into that offset's
+// accumulators.  Gathers for the next offset are issued before the MFMAs of the current one.
+// Offsets with no present row in the step are skipped wave-uniformly.  Accumulators (<= 7 offsets
+// x TA x TB 16x16 tiles) live in registers for the whole row chunk; per-chunk partials are reduced
+// by a second kernel in fixed order: deterministic, no float atomics.
+#include "common.hpp"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int RT = 64;    // rows per step
+constexpr int OGW = 7;    // offsets per wave (4 waves x 7 >= 27)
+constexpr int PAD = 4;    // LDS row padding in elements (bank spread, keeps 8/16-byte alignment)
+
+struct F32 {
+    typedef float elem;
+    typedef f32x4 frag;
+    static constexpr int KSTEPS = RT / 4;   // v_mfma_f32_16x16x4_f32: 4 rows per MFMA
+    typedef float kfrag;                    // one MFMA operand
+    static __device__ __forceinline__ kfrag lds_frag(const elem *tile, int stride, int ks, int g, int col) {
+        return tile[(ks * 4 + g) * stride + col];
+    }
+    static __device__ __forceinline__ f32x4 mma(kfrag a, kfrag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+struct BF16 {
+    typedef unsigned short elem;
+    typedef s16x4 frag;
+    static constexpr int KSTEPS = RT / 16;  // v_mfma_f32_16x16x16_bf16: 16 rows per MFMA
+    typedef s16x4 kfrag;
+    static __device__ __forceinline__ kfrag lds_frag(const elem *tile, int stride, int ks, int g, int col) {
+        kfrag v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (short)tile[(ks * 16 + 4 * g + q) * stride + col];
+        return v;
+    }
+    static __device__ __forceinline__ f32x4 mma(kfrag a, kfrag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+    }
+};
+
+template <class T, int TA, int TB>
+__global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__restrict__ a, int ca,
+                                                    const typename T::elem *__restrict__ b, int cb,
+                                                    const int32_t *__restrict__ tbl, int ld, int K,
+                                                    int n_rows, int rows_per_chunk, int n_tag,
+                                                    int n_grp, float *__restrict__ partial,
+                                                    int vec_ok) {
+    typedef typename T::elem elem;
+    typedef typename T::frag frag;
+    typedef typename T::kfrag kfrag;
+    constexpr int SA = TA * 16 + PAD, SB = TB * 16 + PAD;  // LDS row strides (elements)
+    __shared__ __attribute__((aligned(16))) elem b_tile[RT * SB];
+    __shared__ __attribute__((aligned(16))) elem a_tile[4][RT * SA];
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    // work item = (row chunk, channel-tile group), group fastest; contiguous items per XCD
+    const int item = xcd_work_item(blockIdx.x, gridDim.x);
+    const int chunk = item / n_grp, grp = item % n_grp;
+    const int tag = grp % n_tag, tbg = grp / n_tag;
+    const int ca0 = tag * TA * 16, cb0 = tbg * TB * 16;  // channel slices of this block
+
+    f32x4 acc[OGW][TA][TB];
+#pragma unroll
+    for (int oo = 0; oo < OGW; ++oo)
+#pragma unroll
+        for (int x_ = 0; x_ < TA; ++x_)
+#pragma unroll
+            for (int y_ = 0; y_ < TB; ++y_) acc[oo][x_][y_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const long long r_begin = (long long)chunk * rows_per_chunk;
+    long long r_end = r_begin + rows_per_chunk;
+    if (r_end > n_rows) r_end = n_rows;
+
+    elem *my_a = a_tile[wid];
+
+    // one lane's row slice: TA*4 fragments of 4 channels
+    auto gather_row = [&](int idx, frag (&dst)[TA * 4]) {
+#pragma unroll
+        for (int f = 0; f < TA * 4; ++f) {
+            frag v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = 0;
+            const int c = ca0 + f * 4;
+            if (idx >= 0 && c < ca) {
+                const elem *p = a + (long long)idx * ca + c;
+                if (vec_ok) v = *reinterpret_cast<const frag *>(p);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c + q < ca) v[q] = p[q];
+                }
+            }
+            dst[f] = v;
+        }
+    };
+
+    for (long long r0 = r_begin; r0 < r_end; r0 += RT) {
+        // ---- dY tile -> shared LDS ----
+        __syncthreads();
+        for (int e = threadIdx.x; e < RT * TB * 4; e += 256) {
+            const int r = e / (TB * 4), f = e - r * (TB * 4);
+            const long long row = r0 + r;
+            const int c = cb0 + f * 4;
+            frag v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = 0;
+            if (row < r_end && c < cb) {
+                const elem *p = b + row * cb + c;
+                if (vec_ok) v = *reinterpret_cast<const frag *>(p);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c + q < cb) v[q] = p[q];
+                }
+            }
+            *reinterpret_cast<frag *>(&b_tile[r * SB + f * 4]) = v;
+        }
+        __syncthreads();
+        kfrag bf[T::KSTEPS][TB];
+#pragma unroll
+        for (int ks = 0; ks < T::KSTEPS; ++ks)
+#pragma unroll
+            for (int y_ = 0; y_ < TB; ++y_) bf[ks][y_] = T::lds_frag(b_tile, SB, ks, g, y_ * 16 + i);
+
+        // ---- this wave's offsets ----
+        int idx[OGW];
+#pragma unroll
+        for (int oo = 0; oo < OGW; ++oo) {
+            const int o = wid + 4 * oo;
+            const long long row = r0 + lane;
+            idx[oo] = (o < K && row < r_end) ? tbl[(long long)o * ld + row] : -1;
+        }
+        frag rows_cur[TA * 4], rows_nxt[TA * 4];
+        gather_row(idx[0], rows_cur);
+#pragma unroll
+        for (int oo = 0; oo < OGW; ++oo) {
+            if (oo + 1 < OGW) gather_row(idx[oo + 1], rows_nxt);  // issued ahead of this offset's MFMAs
+            if (__ballot(idx[oo] >= 0) != 0ull) {
+#pragma unroll
+                for (int f = 0; f < TA * 4; ++f)
+                    *reinterpret_cast<frag *>(&my_a[lane * SA + f * 4]) = rows_cur[f];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int ks = 0; ks < T::KSTEPS; ++ks)
+#pragma unroll
+                    for (int x_ = 0; x_ < TA; ++x_) {
+                        const kfrag af = T::lds_frag(my_a, SA, ks, g, x_ * 16 + i);
+#pragma unroll
+                        for (int y_ = 0; y_ < TB; ++y_)
+                            acc[oo][x_][y_] = T::mma(af, bf[ks][y_], acc[oo][x_][y_]);
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+#pragma unroll
+            for (int f = 0; f < TA * 4; ++f) rows_cur[f] = rows_nxt[f];
+        }
+    }
+
+    // D[i = ci][j = co]: lane (co = lane&15, g) holds ci = 4g + r
+    float *out = partial + (long long)chunk * K * ca * cb;
+#pragma unroll
+    for (int oo = 0; oo < OGW; ++oo) {
+        const int o = wid + 4 * oo;
+        if (o < K) {
+#pragma unroll
+            for (int x_ = 0; x_ < TA; ++x_)
+#pragma unroll
+                for (int y_ = 0; y_ < TB; ++y_)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ci = ca0 + x_ * 16 + 4 * g + r, co = cb0 + y_ * 16 + i;
+                        if (ci < ca && co < cb)
+                            out[((long long)o * ca + ci) * cb + co] = acc[oo][x_][y_][r];
+                    }
+        }
+    }
+}
+
+// Fixed-order reduction of the per-chunk partials: 16 element lanes x 16 chunk lanes per block;
+// lane r sums chunks r, r+16, ... and the 16 lane sums are added in ascending r (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce(const float *__restrict__ partial, int R,
+                                                    long long n_elem, float *__restrict__ dw) {
+    __shared__ float part[16][17];
+    const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const long long e = (long long)blockIdx.x * 16 + el;
+    float s = 0.f;
+    if (e < n_elem)
+        for (int r = rl; r < R; r += 16) s += partial[(long long)r * n_elem + e];
+    part[rl][el] = s;
+    __syncthreads();
+    if (rl == 0 && e < n_elem) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += part[r][el];
+        dw[e] = t;
+    }
+}
+
+struct Plan {
+    int TA, TB, n_tag, n_tbg, R, rows_per_chunk;
+};
+
+Plan make_plan(int K, int ca, int cb, int n_rows) {
+    Plan p;
+    const int ta = (ca + 15) / 16, tb = (cb + 15) / 16;
+    p.TA = (ta % 2 == 0) ? 2 : 1;
+    p.TB = (tb % 2 == 0) ? 2 : 1;
+    p.n_tag = ta / p.TA;
+    p.n_tbg = tb / p.TB;
+    const int gy = p.n_tag * p.n_tbg;
+    const int rows = n_rows > 0 ? n_rows : 1;
+    int R = div_up(512, gy);            // aim at >= 2 blocks per CU over the whole grid
+    const int max_r = div_up(rows, RT);
+    if (R > max_r) R = max_r;
+    if (R < 1) R = 1;
+    p.rows_per_chunk = div_up(div_up(rows, R), RT) * RT;
+    p.R = div_up(rows, p.rows_per_chunk);
+    (void)K;
+    return p;
+}
+
+template <class T>
+int run_wgrad(const void *a_, int ca, const void *b_, int cb, const int32_t *tbl, int ld, int K,
+              int n_rows, float *dw, void *ws, size_t ws_bytes, hipStream_t s) {
+    typedef typename T::elem elem;
+    const elem *a = (const elem *)a_, *b = (const elem *)b_;
+    const long long n_elem = (long long)K * ca * cb;
+    const Plan p = make_plan(K, ca, cb, n_rows);
+    if (ws_bytes < (size_t)p.R * n_elem * 4) return DODA_ERR_WORKSPACE;
+    float *partial = (float *)ws;
+    const size_t va = 4 * sizeof(elem);
+    const int vec_ok = (ca % 4 == 0) && (cb % 4 == 0) && ((uintptr_t)a % va == 0) && ((uintptr_t)b % va == 0);
+    const dim3 grid(p.R * p.n_tag * p.n_tbg), block(256);
+#define GO(TA, TB)                                                                                 \
+    hipLaunchKernelGGL((wgrad_kernel<T, TA, TB>), grid, block, 0, s, a, ca, b, cb, tbl, ld, K,    \
+                       n_rows, p.rows_per_chunk, p.n_tag, p.n_tag * p.n_tbg, partial, vec_ok)
+    if (p.TA == 1 && p.TB == 1) GO(1, 1);
+    else if (p.TA == 2 && p.TB == 1) GO(2, 1);
+    else if (p.TA == 1 && p.TB == 2) GO(1, 2);
+    else GO(2, 2);
+#undef GO
+    int st = doda_check_launch();
+    if (st != DODA_OK) return st;
+    hipLaunchKernelGGL(wgrad_reduce, dim3(div_up(n_elem, 16)), dim3(256), 0, s, partial, p.R,
+                       n_elem, dw);
+    return doda_check_launch();
+}
+
+int check_args(const void *a, int ca, const void *b, int cb, const int32_t *tbl, int ld, int K,
+               int n_rows, float *dw, void *ws, hipStream_t s, bool *done) {
+    *done = true;
+    if (ca <= 0 || cb <= 0 || K <= 0 || n_rows < 0 || ld < n_rows || !dw) return DODA_ERR_INVALID;
+    if (K > 4 * OGW) return DODA_ERR_UNSUPPORTED;
+    if (n_rows == 0) {
+        hipMemsetAsync(dw, 0, (size_t)K * ca * cb * 4, s);
+        return DODA_OK;
+    }
+    if (!a || !b || !tbl || !ws) return DODA_ERR_INVALID;
+    *done = false;
+    return DODA_OK;
+}
+}  // namespace
+
+extern "C" size_t doda_spconv_wgrad_workspace_bytes(int32_t K, int32_t ca, int32_t cb,
+                                                    int32_t n_rows) {
+    if (K <= 0 || ca <= 0 || cb <= 0) return 0;
+    const Plan p = make_plan(K, ca, cb, n_rows);
+    return align_up((size_t)p.R * K * ca * cb * 4, 256);
+}
+
+extern "C" int doda_spconv_wgrad_f32(const float *a, int32_t ca, const float *b, int32_t cb,
+                                     const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows,
+                                     float *dw, void *ws, size_t ws_bytes, doda_stream_t stream) {
+    bool done;
+    const int st = check_args(a, ca, b, cb, tbl, ld, K, n_rows, dw, ws, as_stream(stream), &done);
+    if (done) return st;
+    return run_wgrad<F32>(a, ca, b, cb, tbl, ld, K, n_rows, dw, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int doda_spconv_wgrad_bf16(const uint16_t *a, int32_t ca, const uint16_t *b, int32_t cb,
+                                      const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows,
+                                      float *dw, void *ws, size_t ws_bytes, doda_stream_t stream) {
+    bool done;
+    const int st = check_args(a, ca, b, cb, tbl, ld, K, n_rows, dw, ws, as_stream(stream), &done);
+    if (done) return st;
+    return run_wgrad<BF16>(a, ca, b, cb, tbl, ld, K, n_rows, dw, ws, ws_bytes, as_stream(stream));
+}

@@ -1,0 +1,60 @@
+"""Fused BatchNorm1d(+ReLU) for [M, C] sparse-tensor features, backed by libdoda_hip.so.
+
+spconv's SparseSequential applies non-sparse modules to `.features`; DODA's network does that with
+`BatchNorm1d(eps=1e-4, momentum=0.1)` followed by `ReLU` in front of every convolution (reference
+model/unet.py:28,42-45; model/unet_block.py:23-30,46-49,67-79).  doda_amd.spconv.SparseSequential
+recognises that pair (exact torch types only — DSNorm and friends keep their own forward) and routes
+it here; semantics are torch.nn.BatchNorm1d's: batch statistics + running-stat update in training,
+running statistics in eval, same gradients.
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from . import ops as _ops
+
+
+class _BNReLU(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+        x = x.contiguous()
+        y, mean, invstd = _ops.bn_relu_fwd(x, weight, bias, running_mean, running_var, training,
+                                           momentum, eps, relu)
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.cfg = (bool(training), bool(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, mean, invstd = ctx.saved_tensors
+        training, relu = ctx.cfg
+        dy = dy.contiguous()
+        if training:
+            dx, dg, db = _ops.bn_relu_bwd(x, dy, mean, invstd, weight, bias, relu)
+        else:  # statistics are constants
+            xh = (x.float() - mean) * invstd
+            dz = dy.float()
+            if relu:
+                dz = dz * ((xh * weight + bias) > 0)
+            dx = (dz * (weight * invstd)).to(x.dtype)
+            dg, db = (dz * xh).sum(0), dz.sum(0)
+        return dx, dg.to(weight.dtype), db.to(bias.dtype), None, None, None, None, None, None
+
+
+def fusable(bn, features):
+    """Exactly torch's BatchNorm1d with affine fp32 parameters, running stats and a numeric momentum,
+    on a device [M, C] fp32/bf16 matrix with C % 4 == 0."""
+    return (type(bn) is nn.BatchNorm1d and bn.affine and bn.track_running_stats
+            and bn.momentum is not None and features.is_cuda and features.dim() == 2
+            and features.dtype in (torch.float32, torch.bfloat16) and features.shape[1] % 4 == 0
+            and bn.weight.dtype == torch.float32
+            and not (bn.training and features.shape[0] < 2))
+
+
+def batch_norm_relu(features, bn, relu):
+    """BatchNorm1d `bn` (+ReLU when `relu`) on features through the fused HIP kernels."""
+    training = bn.training
+    if training:
+        bn.num_batches_tracked.add_(1)
+    return _BNReLU.apply(features, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                         bn.momentum, bn.eps, relu)

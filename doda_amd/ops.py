@@ -205,15 +205,14 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc):
         raise RuntimeError("weight must be float32 with K*kc*nc = %d elements" % (K * kc * nc))
     y = torch.empty((n_out, nc), dtype=x.dtype, device=x.device)
     if x.dtype == torch.float32:
-        check(lib().doda_spconv_gather_f32(_p(x), kc, _p(w), nc, _p(tbl), ld, K, n_out, _p(y),
-                                           int(w_layout), _stream()), "doda_spconv_gather_f32")
+        fn, name, esz = lib().doda_spconv_gather_f32, "doda_spconv_gather_f32", 4
     elif x.dtype == torch.bfloat16:
-        ws = _ws(lib().doda_spconv_gather_bf16_workspace_bytes(K, kc, nc), x.device)
-        check(lib().doda_spconv_gather_bf16(_p(x), kc, _p(w), nc, _p(tbl), ld, K, n_out, _p(y),
-                                            int(w_layout), _p(ws), ws.numel(), _stream()),
-              "doda_spconv_gather_bf16")
+        fn, name, esz = lib().doda_spconv_gather_bf16, "doda_spconv_gather_bf16", 2
     else:
         raise RuntimeError("spconv_gather: unsupported feature dtype %s" % x.dtype)
+    ws = _ws(lib().doda_spconv_gather_workspace_bytes(K, kc, nc, esz), x.device)
+    check(fn(_p(x), x.shape[0], kc, _p(w), nc, _p(tbl), ld, K, n_out, _p(y), int(w_layout), _p(ws), ws.numel(),
+             _stream()), name)
     return y
 
 
@@ -254,6 +253,52 @@ def maxpool_bwd(x, y, dy, tbl, n_out):
     check(lib().doda_maxpool_bwd_f32(_p(x), _p(y), _p(dy), x.shape[1], _p(tbl), ld, K, n_out,
                                      _p(dx), _stream()), "doda_maxpool_bwd_f32")
     return dx
+
+
+# ------------------------------------------------------------------------------------------
+# fused BatchNorm(+ReLU)
+# ------------------------------------------------------------------------------------------
+def _esz(t):
+    if t.dtype == torch.float32:
+        return 4
+    if t.dtype == torch.bfloat16:
+        return 2
+    raise RuntimeError("unsupported feature dtype %s" % t.dtype)
+
+
+def bn_relu_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+    """-> (y, save_mean, save_invstd).  x: contiguous [m, c] fp32|bf16 on device, c % 4 == 0."""
+    _feat_ok(x, "x")
+    m, c = x.shape
+    y = torch.empty_like(x)
+    if training:
+        save_mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    else:
+        save_mean = running_mean.float().contiguous()
+        save_invstd = torch.rsqrt(running_var.float() + eps).contiguous()
+    ws = _ws(lib().doda_bn_workspace_bytes(m, c), x.device)
+    rm = _p(running_mean) if (training and running_mean is not None) else None
+    rv = _p(running_var) if (training and running_var is not None) else None
+    check(lib().doda_bn_relu_fwd(_p(x), m, c, _esz(x), float(eps), float(momentum), _p(gamma), _p(beta),
+                                 rm, rv, int(bool(training)), int(bool(relu)), _p(y), _p(save_mean),
+                                 _p(save_invstd), _p(ws), ws.numel(), _stream()), "doda_bn_relu_fwd")
+    return y, save_mean, save_invstd
+
+
+def bn_relu_bwd(x, dy, save_mean, save_invstd, gamma, beta, relu):
+    """-> (dx, dgamma, dbeta) for the training-mode forward above."""
+    _feat_ok(x, "x")
+    _feat_ok(dy, "dy")
+    m, c = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    ws = _ws(lib().doda_bn_workspace_bytes(m, c), x.device)
+    check(lib().doda_bn_relu_bwd(_p(x), _p(dy), m, c, _esz(x), _p(save_mean), _p(save_invstd),
+                                 _p(gamma), _p(beta), int(bool(relu)), _p(dx), _p(dgamma), _p(dbeta),
+                                 _p(ws), ws.numel(), _stream()), "doda_bn_relu_bwd")
+    return dx, dgamma, dbeta
 
 
 # ------------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@ from collections import OrderedDict
 
 from torch import nn
 
+from .. import nn as _dnn
 from .core import SparseConvTensor
 
 
@@ -59,12 +60,22 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for module in self._modules.values():
+        mods = list(self._modules.values())
+        k = 0
+        while k < len(mods):
+            module = mods[k]
+            k += 1
             if is_spconv_module(module):
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
-                    input.features = module(input.features)
+                    if _dnn.fusable(module, input.features):
+                        # BatchNorm1d [-> ReLU] on .features: one fused HIP path (doda_amd.nn)
+                        relu = k < len(mods) and type(mods[k]) is nn.ReLU
+                        input.features = _dnn.batch_norm_relu(input.features, module, relu)
+                        k += int(relu)
+                    else:
+                        input.features = module(input.features)
             else:
                 input = module(input)
         return input

@@ -136,32 +136,33 @@ int doda_rulebook_pairs(const int32_t *tbl, int32_t ld, int32_t K, int32_t n_row
  * reference call sites as above).  All output-stationary: every output row is written once,
  * no atomics, deterministic.
  *
- *   y[t, :] = sum_o  x[tbl[o][t], :] . B_o          t < n_out,  x: [*, kc],  y: [n_out, nc]
+ *   y[t, :] = sum_o  x[tbl[o][t], :] . B_o          t < n_out,  x: [n_in, kc],  y: [n_out, nc]
  *
  * w_layout 0: B_o = W[o]        with w stored [K][kc][nc]           (forward)
  * w_layout 1: B_o = W[o]^T      with w stored [K][nc][kc]           (data-grad of down2/inverse)
  * w_layout 2: B_o = W[K-1-o]^T  with w stored [K][nc][kc]           (data-grad of SubM)
+ *
+ * `ws` (doda_spconv_gather_workspace_bytes(K,kc,nc, sizeof element)) receives the weights
+ * re-laid-out in MFMA fragment order by a pre-pack kernel inside the call.  K <= 27.
  * ---------------------------------------------------------------------------------------- */
-int doda_spconv_gather_f32(const float *x, int32_t kc, const float *w, int32_t nc,
+size_t doda_spconv_gather_workspace_bytes(int32_t K, int32_t kc, int32_t nc, int32_t elem_bytes);
+int doda_spconv_gather_f32(const float *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
                            const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, float *y,
-                           int32_t w_layout, doda_stream_t stream);
+                           int32_t w_layout, void *ws, size_t ws_bytes, doda_stream_t stream);
+/* bf16 feature storage (BASELINE config 2): x / y are bf16 bit patterns; weights arrive fp32 and
+ * are rounded to bf16 by the pre-pack; fp32 accumulate; y rounded to bf16 (RNE) once. */
+int doda_spconv_gather_bf16(const uint16_t *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
+                            const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
+                            uint16_t *y, int32_t w_layout, void *ws, size_t ws_bytes,
+                            doda_stream_t stream);
 
-/* dw[o][i][j] = sum_t a[tbl[o][t], i] * b[t, j],  a: [*, ca], b: [n_rows, cb], dw: [K][ca][cb].
- * Two deterministic stages inside one call (partials in ws, then a fixed-order reduce). */
+/* dw[o][i][j] = sum_t a[tbl[o][t], i] * b[t, j],  a: [*, ca], b: [n_rows, cb], dw: fp32
+ * [K][ca][cb].  Two deterministic stages inside one call (per-row-chunk partials in ws, then a
+ * fixed-order reduce); K <= 28. */
 size_t doda_spconv_wgrad_workspace_bytes(int32_t K, int32_t ca, int32_t cb, int32_t n_rows);
 int doda_spconv_wgrad_f32(const float *a, int32_t ca, const float *b, int32_t cb,
                           const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, float *dw,
                           void *ws, size_t ws_bytes, doda_stream_t stream);
-
-/* bf16-storage variants (BASELINE config 2): x/y/a/b are bf16 (uint16 bit patterns); weights
- * arrive fp32 and are rounded to bf16 into `ws` in MFMA fragment order by a pre-pack kernel inside
- * the call; fp32 accumulate; y rounded to bf16 (RNE); dw fp32.  wgrad_bf16 uses the same
- * workspace size as doda_spconv_wgrad_workspace_bytes. */
-size_t doda_spconv_gather_bf16_workspace_bytes(int32_t K, int32_t kc, int32_t nc);
-int doda_spconv_gather_bf16(const uint16_t *x, int32_t kc, const float *w, int32_t nc,
-                            const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
-                            uint16_t *y, int32_t w_layout, void *ws, size_t ws_bytes,
-                            doda_stream_t stream);
 int doda_spconv_wgrad_bf16(const uint16_t *a, int32_t ca, const uint16_t *b, int32_t cb,
                            const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, float *dw,
                            void *ws, size_t ws_bytes, doda_stream_t stream);
@@ -174,6 +175,26 @@ int doda_maxpool_fwd_f32(const float *x, int32_t c, const int32_t *tbl, int32_t 
 int doda_maxpool_bwd_f32(const float *x, const float *y, const float *dy, int32_t c,
                          const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, float *dx,
                          doda_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused BatchNorm1d(+ReLU) on [m, c] features (the BN -> ReLU pairs that
+ * precede every conv, reference model/unet.py:28,42-45, model/unet_block.py:23-30,46-49,67-79;
+ * upstream these are torch.nn.BatchNorm1d + ReLU applied to `.features` by SparseSequential).
+ * x / y / dy / dx: fp32 (elem_bytes 4) or bf16 (2); statistics and parameters fp32; c % 4 == 0.
+ * training != 0: batch statistics (biased variance, eps inside the sqrt) are computed, written to
+ * save_mean / save_invstd and folded into running_mean / running_var (momentum, unbiased variance)
+ * when those are non-null; training == 0: save_mean / save_invstd must already hold the running
+ * mean and 1/sqrt(running_var + eps).  Backward recomputes the ReLU mask from x.
+ * ---------------------------------------------------------------------------------------- */
+size_t doda_bn_workspace_bytes(int32_t m, int32_t c);
+int doda_bn_relu_fwd(const void *x, int32_t m, int32_t c, int32_t elem_bytes, float eps,
+                     float momentum, const float *gamma, const float *beta, float *running_mean,
+                     float *running_var, int32_t training, int32_t relu, void *y, float *save_mean,
+                     float *save_invstd, void *ws, size_t ws_bytes, doda_stream_t stream);
+int doda_bn_relu_bwd(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
+                     const float *save_mean, const float *save_invstd, const float *gamma,
+                     const float *beta, int32_t relu, void *dx, float *dgamma, float *dbeta,
+                     void *ws, size_t ws_bytes, doda_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Neighbour queries

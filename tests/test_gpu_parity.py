@@ -314,3 +314,42 @@ def test_ballquery_bit_exact(native_lib, oracle, mean_active):
         ma = int(total // xyz.shape[0] + 1)
     assert np.array_equal(start_len.cpu().numpy(), ref_sl)
     assert np.array_equal(idx.cpu().numpy(), ref_idx[:total])
+
+
+# ------------------------------------------------------------------ fused BatchNorm(+ReLU)
+@pytest.mark.parametrize("c", [16, 48, 112, 192])
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_relu_matches_torch(native_lib, c, relu, dtype):
+    """doda_amd.nn against torch.nn.BatchNorm1d(+ReLU) evaluated in fp64 (training and eval)."""
+    from doda_amd import nn as dnn
+    torch.manual_seed(c)
+    m = 5000 + c
+    d = dev()
+    x = (torch.randn(m, c, device=d) * 1.7 + 3.0).to(dtype)       # non-zero mean: exercises the shift
+    gy = torch.randn(m, c, device=d).to(dtype)
+    ref = torch.nn.BatchNorm1d(c, eps=1e-4, momentum=0.1).to(d).double()
+    mine = torch.nn.BatchNorm1d(c, eps=1e-4, momentum=0.1).to(d)
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(c) + 0.5); ref.bias.copy_(torch.randn(c) * 0.3)
+        mine.weight.copy_(ref.weight.float()); mine.bias.copy_(ref.bias.float())
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    for training in (True, False):
+        ref.train(training); mine.train(training)
+        xr = x.double().requires_grad_(True)
+        yr = ref(xr)
+        if relu:
+            yr = torch.relu(yr)
+        yr.backward(gy.double())
+        xm = x.clone().requires_grad_(True)
+        assert dnn.fusable(mine, xm)
+        ym = dnn.batch_norm_relu(xm, mine, relu)
+        ym.backward(gy)
+        assert rel_err(ym.detach().float().cpu(), yr.detach().cpu()) < tol
+        assert rel_err(xm.grad.float().cpu(), xr.grad.cpu()) < tol
+        assert rel_err(mine.weight.grad.cpu(), ref.weight.grad.cpu()) < tol
+        assert rel_err(mine.bias.grad.cpu(), ref.bias.grad.cpu()) < tol
+        mine.weight.grad = None; mine.bias.grad = None; ref.weight.grad = None; ref.bias.grad = None
+    assert rel_err(mine.running_mean.cpu(), ref.running_mean.cpu()) < 1e-4
+    assert rel_err(mine.running_var.cpu(), ref.running_var.cpu()) < 1e-3 if dtype == torch.bfloat16 else 1e-4
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 1

@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""One kernel under the profiler: SubM 16->16 gather forward (level-1 size), N launches."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from doda_amd import ops, spconv
+from doda_amd.scene import make_batch
+dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+which = sys.argv[2] if len(sys.argv) > 2 else "fwd"
+c = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+dev = torch.device("cuda:0")
+cache = "/tmp/k1_batch.pt"
+if os.path.exists(cache):
+    batch = torch.load(cache, weights_only=False)
+else:
+    batch = make_batch(4, 150000, 1000)
+    torch.save(batch, cache)
+idx = batch["voxel_locs"].int().to(dev)
+shape = [int(s) for s in batch["spatial_shape"]]
+sub = spconv.ops.build_subm(idx, 4, shape, 3)
+m = idx.shape[0]
+tdt = torch.float32 if dt == "f32" else torch.bfloat16
+x = torch.randn(m, c, device=dev).to(tdt); gy = torch.randn(m, c, device=dev).to(tdt)
+w = torch.randn(27, c, c, device=dev) * 0.05
+for _ in range(reps):
+    if which == "fwd": ops.spconv_gather(x, w, sub.tbl, m, 0, c)
+    elif which == "dgrad": ops.spconv_gather(gy, w, sub.tbl, m, 2, c)
+    else: ops.spconv_wgrad(x, gy, sub.tbl, m)
+torch.cuda.synchronize()
+print("done", m)
