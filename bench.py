@@ -136,7 +136,7 @@ def main():
     if world > 1:
         dist.barrier()
     _lib.lib()
-    from doda_amd.model import SparseConvNet, default_cfg, voxelize_and_run
+    from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
     from doda_amd.scene import make_batch
 
     batch = make_batch(args.scenes, args.voxels, 1000 + 100 * rank, args.voxel_scale)
@@ -158,7 +158,7 @@ def main():
     def step():
         opt.zero_grad(set_to_none=True)
         scores = voxelize_and_run(cfg, model, batch_dev, dev, feature_dtype=fdt)
-        loss = torch.nn.functional.cross_entropy(scores.float(), labels, ignore_index=255)
+        loss = cross_entropy(scores, labels, ignore_index=255)
         loss.backward()
         opt.step()
         return loss

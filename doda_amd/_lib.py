@@ -43,7 +43,7 @@ _SIGNATURES = {
     "doda_spconv_wgrad_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
                                       c_vp, c_sz, c_vp]),
     "doda_spconv_gather_bf16": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
-                                        c_i32, c_vp, c_sz, c_vp]),
+                                        c_i32, c_i32, c_vp, c_sz, c_vp]),
     "doda_spconv_wgrad_bf16": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
                                        c_vp, c_sz, c_vp]),
     "doda_maxpool_fwd_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -297,18 +297,18 @@ __device__ __forceinline__ void touch(R &r) {
     asm volatile("" : "+v"(r));
 }
 
-template <class T, int NBW, int S, int D>
+template <class T, int NBW, int S, int D, bool OUT32>
 __global__ __launch_bounds__(256) void conv_fast(const typename T::elem *__restrict__ x,
                                                  unsigned x_bytes, int kc,
                                                  const typename T::frag *__restrict__ wp,
                                                  unsigned wp_bytes, int nc, int NB,
                                                  const int32_t *__restrict__ tbl,
                                                  unsigned tbl_bytes, int ld, int K, int n_out,
-                                                 typename T::elem *__restrict__ y,
-                                                 unsigned y_bytes) {
+                                                 void *__restrict__ y, unsigned y_bytes) {
     typedef typename T::frag frag;
     typedef typename T::elem elem;
     typedef typename RawIO<T>::raw raw;
+    constexpr unsigned OSZ = OUT32 ? 4u : (unsigned)sizeof(elem);   // output element size
     constexpr int RW = 16 * S;                 // rows per wave
     constexpr int OPI = 64 / RW;               // table offsets fetched per load instruction
     constexpr int NLD = (MAX_K + 1 + OPI - 1) / OPI;  // strips 0..MAX_K; strip MAX_K is all-OOB
@@ -359,7 +359,8 @@ __global__ __launch_bounds__(256) void conv_fast(const typename T::elem *__restr
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) acc[s][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int n_chunk = kc >> 4;
+    const int n_chunk = (kc + 15) >> 4;   // a partial last chunk reads past the row end: those
+                                          // channels meet zero weights (pack_weights guards c < kc)
     const unsigned lane_x = (unsigned)g * FSZ;       // this lane's channel quad inside a 16-ch chunk
     const unsigned lane_w = (unsigned)lane * FSZ;    // this lane's slot inside a packed W fragment
     const unsigned *my_off = &off_tile[wid][i];
@@ -423,23 +424,33 @@ __global__ __launch_bounds__(256) void conv_fast(const typename T::elem *__restr
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const unsigned t = (unsigned)(row0 + s * 16 + i);
-        const unsigned base = (t < (unsigned)n_out) ? t * (unsigned)nc * ESZ + (unsigned)(nb0 * 16 + 4 * g) * ESZ : OOB;
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
-            if (nb0 + nb < NB) RawIO<T>::store(acc[s][nb], rs_y, base + nb * 16u * ESZ);
+        for (int nb = 0; nb < NBW; ++nb) {
+            const unsigned col = (unsigned)((nb0 + nb) * 16 + 4 * g);
+            const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * (unsigned)nc + col) * OSZ : OOB;
+            if (OUT32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[s][nb]), rs_y, voff, 0, 0);
+            else RawIO<T>::store(acc[s][nb], rs_y, voff);
+        }
     }
 }
 
 template <class T, int NBW, int S>
 int launch_fast(const typename T::elem *x, int kc, const typename T::frag *wp, size_t wp_bytes,
                 int nc, int NB, const int32_t *tbl, int ld, int K, int n_out, long long n_in,
-                typename T::elem *y, hipStream_t s) {
+                void *y, bool out32, hipStream_t s) {
     const dim3 grid(div_up(n_out, 4 * 16 * S) * div_up(NB, NBW)), block(256);
     constexpr int D = (S + NBW <= 3) ? 8 : ((S + NBW <= 5) ? 6 : ((S + NBW <= 6) ? 4 : 3));
-    hipLaunchKernelGGL((conv_fast<T, NBW, S, D>), grid, block, 0, s, x,
-                       (unsigned)((size_t)n_in * kc * sizeof(typename T::elem)), kc, wp,
-                       (unsigned)wp_bytes, nc, NB, tbl, (unsigned)((size_t)K * ld * 4), ld, K, n_out, y,
-                       (unsigned)((size_t)n_out * nc * sizeof(typename T::elem)));
+    const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(typename T::elem));
+    const unsigned tb = (unsigned)((size_t)K * ld * 4);
+    if (out32 && sizeof(typename T::elem) != 4) {
+        const unsigned yb = (unsigned)((size_t)n_out * nc * 4);
+        hipLaunchKernelGGL((conv_fast<T, NBW, S, D, true>), grid, block, 0, s, x, xb, kc, wp,
+                           (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb);
+    } else {
+        const unsigned yb = (unsigned)((size_t)n_out * nc * sizeof(typename T::elem));
+        hipLaunchKernelGGL((conv_fast<T, NBW, S, D, false>), grid, block, 0, s, x, xb, kc, wp,
+                           (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb);
+    }
     return doda_check_launch();
 }
 
@@ -455,7 +466,7 @@ int launch(const typename T::elem *x, int kc, const typename T::frag *wp, int nc
 
 template <class T>
 int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tbl, int ld, int K,
-               int n_out, void *y_, int wl, void *ws, size_t ws_bytes, long long n_in,
+               int n_out, void *y_, int wl, void *ws, size_t ws_bytes, long long n_in, bool out32,
                hipStream_t s) {
     typedef typename T::elem elem;
     typedef typename T::frag frag;
@@ -479,12 +490,13 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     const long long waves_full = ((long long)n_out + 15) / 16;
     // x_bytes: the table only references rows that exist, so the buffer bound just has to keep a
     // present row in range and an absent one (offset 2^31) out: use the 2 GB window.
-    const bool fast = (kc % 16 == 0) && (nc % 16 == 0) && ((uintptr_t)x % 16 == 0) &&
-                      ((uintptr_t)y % 16 == 0) && ((size_t)n_out * nc * sizeof(elem) < 0x7fffffffull) &&
+    const bool fast = (kc % 4 == 0) && (nc % 4 == 0) && ((uintptr_t)x % 16 == 0) &&
+                      ((uintptr_t)y % 16 == 0) && ((size_t)n_out * nc * 4 < 0x7fffffffull) &&
                       ((size_t)K * ld * 4 < 0xffffffffull) && x_rows_bytes_ok;
+    if (out32 && sizeof(elem) != 4 && !fast) return DODA_ERR_UNSUPPORTED;
 #define GO(NBW, S)                                                                                 \
     do {                                                                                           \
-        if (fast) return launch_fast<T, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y, s); \
+        if (fast) return launch_fast<T, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
         return launch<T, NBW, S>(x, kc, wp, nc, NB, tbl, ld, K, n_out, y, vec_ok, s);              \
     } while (0)
     static const int force_s = getenv("DODA_S") ? atoi(getenv("DODA_S")) : 0;
@@ -542,17 +554,17 @@ extern "C" int doda_spconv_gather_f32(const float *x, int32_t n_in, int32_t kc, 
     int st;
     if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
     if (!ws) return DODA_ERR_INVALID;
-    return run_gather<F32>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in,
+    return run_gather<F32>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, false,
                            as_stream(stream));
 }
 
 extern "C" int doda_spconv_gather_bf16(const uint16_t *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
                                        const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
-                                       uint16_t *y, int32_t w_layout, void *ws, size_t ws_bytes,
-                                       doda_stream_t stream) {
+                                       void *y, int32_t y_is_f32, int32_t w_layout, void *ws,
+                                       size_t ws_bytes, doda_stream_t stream) {
     int st;
     if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
     if (!ws) return DODA_ERR_INVALID;
-    return run_gather<BF16>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in,
+    return run_gather<BF16>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, y_is_f32 != 0,
                             as_stream(stream));
 }

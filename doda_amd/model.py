@@ -17,7 +17,9 @@ from types import SimpleNamespace
 
 import torch
 from torch import nn
+from torch.autograd import Function
 
+from . import ops as _ops
 from . import pointgroup_ops, spconv
 from .spconv.modules import SparseModule
 
@@ -108,6 +110,50 @@ class UBlock(nn.Module):
         return out
 
 
+class _PointLinear(Function):
+    """scores[n] = feats[p2v[n]] @ W^T + b: the voxel->point gather and the Linear head of reference
+    model/unet.py:62-64 as ONE gather-GEMM (K = 1 table = p2v).  Backward re-uses the same native
+    kernels: d_feats[v] = sum over the voxel's points (table = transposed v2p map) of d_scores @ W,
+    dW = wgrad over the p2v table."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, bias, p2v, v2p_t):
+        n = p2v.shape[0]
+        scores = _ops.spconv_gather(feats.contiguous(), weight.view(1, *weight.shape), p2v.view(1, n),
+                                    n, 1, weight.shape[0], out_f32=True)
+        if bias is not None:
+            scores += bias
+        ctx.save_for_backward(feats, weight, p2v, v2p_t)
+        ctx.has_bias = bias is not None
+        return scores
+
+    @staticmethod
+    def backward(ctx, d_scores):
+        feats, weight, p2v, v2p_t = ctx.saved_tensors
+        n = p2v.shape[0]
+        dy = d_scores.contiguous().to(feats.dtype)
+        d_feats = d_w = d_b = None
+        if ctx.needs_input_grad[0]:
+            k = v2p_t.shape[0]
+            w_rep = weight.unsqueeze(0).expand(k, *weight.shape).contiguous()
+            d_feats = _ops.spconv_gather(dy, w_rep, v2p_t, feats.shape[0], 0, weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            d_w = _ops.spconv_wgrad(feats.contiguous(), dy, p2v.view(1, n), n)[0].t().to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            d_b = d_scores.sum(0)
+        return d_feats, d_w, d_b, None, None
+
+
+def cross_entropy(scores, labels, ignore_index=255):
+    """nn.CrossEntropyLoss(ignore_index) (reference model/unet.py:108,196) written as
+    log_softmax + gather: torch's fused nll_loss reduction kernels take ~1.6 ms per step at 800k
+    points x 20 classes on MI355X, this formulation ~0.2 ms; same value and gradient."""
+    valid = labels != ignore_index
+    logp = torch.log_softmax(scores.float(), dim=1)
+    picked = logp.gather(1, labels.clamp(0, scores.shape[1] - 1).unsqueeze(1)).squeeze(1)
+    return -(picked * valid).sum() / valid.sum().clamp(min=1)
+
+
 class SparseConvNet(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -128,14 +174,21 @@ class SparseConvNet(nn.Module):
                 mod.weight.data.fill_(1.0)
                 mod.bias.data.fill_(0.0)
 
-    def forward(self, input, input_map, return_mid_feat=False):
+    def forward(self, input, input_map, return_mid_feat=False, v2p_map=None):
         out = self.output_layer(self.unet(self.input_conv(input)))
-        point_feats = out.features[input_map.long()]  # voxel -> point
+        feats = out.features
+        fused = (v2p_map is not None and not return_mid_feat and feats.is_cuda
+                 and input_map.dtype == torch.int32 and 0 < v2p_map.shape[1] - 1 <= 27
+                 and feats.shape[1] % 4 == 0 and self.linear.out_features % 4 == 0)
+        if fused:  # voxel->point gather + Linear as one gather-GEMM over the p2v table
+            v2p_t = v2p_map[:, 1:].t().contiguous()
+            return _PointLinear.apply(feats, self.linear.weight, self.linear.bias, input_map, v2p_t)
+        point_feats = feats[input_map.long()]  # voxel -> point
         scores = self.linear(point_feats.to(self.linear.weight.dtype))
         return (point_feats, scores) if return_mid_feat else scores
 
 
-def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32):
+def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fused_head=True):
     """reference model/unet.py:72-99 (test_model_feat): H2D, voxel mean-pooling, network."""
     voxel_coords = batch["voxel_locs"].to(device, non_blocking=True)
     p2v = batch["p2v_map"].to(device, non_blocking=True)
@@ -147,4 +200,6 @@ def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32):
     batch_size = batch["offsets"].numel() - 1
     inp = spconv.SparseConvTensor(voxel_feats.to(feature_dtype), voxel_coords.int(),
                                   batch["spatial_shape"], batch_size)
+    if fused_head:
+        return model(inp, p2v, v2p_map=v2p)
     return model(inp, p2v)

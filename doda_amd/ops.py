@@ -193,9 +193,10 @@ def _feat_ok(x, name):
         raise RuntimeError("%s must be a contiguous [rows, channels] tensor" % name)
 
 
-def spconv_gather(x, w, tbl, n_out, w_layout, nc):
-    """y[t] = sum_o x[tbl[o][t]] @ B_o (see doda_hip.h).  x: [*,kc] f32|bf16; w: fp32 weights
-    viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2).  Returns y [n_out, nc] in x.dtype."""
+def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False):
+    """y[t] = sum_o x[tbl[o][t]] @ B_o (see doda_hip.h).  x: [n_in,kc] f32|bf16; w: fp32 weights
+    viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2).  Returns y [n_out, nc] in x.dtype
+    (or float32 when out_f32)."""
     _feat_ok(x, "x")
     _need_cuda(w, tbl)
     K, ld = tbl.shape
@@ -203,16 +204,20 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc):
     w = w.contiguous()
     if w.dtype != torch.float32 or w.numel() != K * kc * nc:
         raise RuntimeError("weight must be float32 with K*kc*nc = %d elements" % (K * kc * nc))
-    y = torch.empty((n_out, nc), dtype=x.dtype, device=x.device)
+    ws_esz = 4 if x.dtype == torch.float32 else 2
+    ws = _ws(lib().doda_spconv_gather_workspace_bytes(K, kc, nc, ws_esz), x.device)
     if x.dtype == torch.float32:
-        fn, name, esz = lib().doda_spconv_gather_f32, "doda_spconv_gather_f32", 4
+        y = torch.empty((n_out, nc), dtype=torch.float32, device=x.device)
+        check(lib().doda_spconv_gather_f32(_p(x), x.shape[0], kc, _p(w), nc, _p(tbl), ld, K, n_out,
+                                           _p(y), int(w_layout), _p(ws), ws.numel(), _stream()),
+              "doda_spconv_gather_f32")
     elif x.dtype == torch.bfloat16:
-        fn, name, esz = lib().doda_spconv_gather_bf16, "doda_spconv_gather_bf16", 2
+        y = torch.empty((n_out, nc), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+        check(lib().doda_spconv_gather_bf16(_p(x), x.shape[0], kc, _p(w), nc, _p(tbl), ld, K, n_out,
+                                            _p(y), int(bool(out_f32)), int(w_layout), _p(ws), ws.numel(),
+                                            _stream()), "doda_spconv_gather_bf16")
     else:
         raise RuntimeError("spconv_gather: unsupported feature dtype %s" % x.dtype)
-    ws = _ws(lib().doda_spconv_gather_workspace_bytes(K, kc, nc, esz), x.device)
-    check(fn(_p(x), x.shape[0], kc, _p(w), nc, _p(tbl), ld, K, n_out, _p(y), int(w_layout), _p(ws), ws.numel(),
-             _stream()), name)
     return y
 
 

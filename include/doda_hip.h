@@ -150,10 +150,11 @@ int doda_spconv_gather_f32(const float *x, int32_t n_in, int32_t kc, const float
                            const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, float *y,
                            int32_t w_layout, void *ws, size_t ws_bytes, doda_stream_t stream);
 /* bf16 feature storage (BASELINE config 2): x / y are bf16 bit patterns; weights arrive fp32 and
- * are rounded to bf16 by the pre-pack; fp32 accumulate; y rounded to bf16 (RNE) once. */
+ * are rounded to bf16 by the pre-pack; fp32 accumulate; y rounded to bf16 (RNE) once, or kept
+ * fp32 when y_is_f32 (y then points to float [n_out, nc]; used by the point head's logits). */
 int doda_spconv_gather_bf16(const uint16_t *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
-                            const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
-                            uint16_t *y, int32_t w_layout, void *ws, size_t ws_bytes,
+                            const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, void *y,
+                            int32_t y_is_f32, int32_t w_layout, void *ws, size_t ws_bytes,
                             doda_stream_t stream);
 
 /* dw[o][i][j] = sum_t a[tbl[o][t], i] * b[t, j],  a: [*, ca], b: [n_rows, cb], dw: fp32
