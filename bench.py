@@ -40,7 +40,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    p.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
+                   help="feature storage dtype; bf16 = BASELINE config 2 (fp32 accumulate, fp32 weights)")
     p.add_argument("--scenes", type=int, default=4, help="scenes per GPU (BATCH_SIZE_PER_GPU)")
     p.add_argument("--voxels", type=int, default=150000, help="target active voxels per scene")
     p.add_argument("--voxel-scale", type=int, default=50)
@@ -93,7 +94,7 @@ def kernel_roofline(batch_dev, dtype, reps):
     out["subm16_fwd_bwd"] = {"us": t_all * 1e6, "GBs": (b_f + b_b) / t_all / 1e9,
                              "frac_of_hbm_peak": (b_f + b_b) / t_all / 1e9 / HBM_PEAK_GBS}
     dom = "subm16_fwd"
-    roof = {"kernel": "conv_gather_%s<NB=1,S=4> (SubMConv3d 16->16 fwd, M=%d, P=%d)" % (dtype, m, pairs_total),
+    roof = {"kernel": "conv_fast<%s,NBW=1,S=4> (SubMConv3d 16->16 fwd gather, M=%d, P=%d)" % (dtype, m, pairs_total),
             "bound": "hbm", "achieved": out[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": out[dom]["GBs"] / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_launch": b_f, "avg_launch_us": out[dom]["us"], "detail": out}
@@ -119,12 +120,8 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")
+    from doda_amd import dist as ddist
+    world, rank, local_rank = ddist.setup()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -133,13 +130,12 @@ def main():
     from doda_amd import _lib
     if not os.path.exists(_lib.LIB_PATH) and rank == 0:
         build_native(verbose=False)
-    if world > 1:
-        dist.barrier()
+    ddist.barrier()
     _lib.lib()
     from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
     from doda_amd.scene import make_batch
 
-    batch = make_batch(args.scenes, args.voxels, 1000 + 100 * rank, args.voxel_scale)
+    batch = make_batch(args.scenes, args.voxels, ddist.seed_for_rank(1000, rank), args.voxel_scale)
     batch_dev = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
     m_local = batch["voxel_locs"].shape[0]
     n_local = batch["locs"].shape[0]
@@ -147,10 +143,7 @@ def main():
     cfg = default_cfg()
     torch.manual_seed(0)
     net = SparseConvNet(cfg).to(dev).train()
-    model = net
-    if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(
-            net, device_ids=[local_rank], broadcast_buffers=False, gradient_as_bucket_view=True)
+    model = ddist.wrap_ddp(net, local_rank)
     opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     fdt = torch.float32 if args.dtype == "f32" else torch.bfloat16
     labels = batch_dev["labels"]
@@ -165,26 +158,16 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
+    ddist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    ddist.barrier()
     elapsed = time.perf_counter() - t0
-    stats = torch.tensor([elapsed, float(m_local), float(n_local)], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = stats[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tot = stats[1:].clone()
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed, m_total, n_total = float(tmax[0]), float(tot[0]), float(tot[1])
-    else:
-        m_total, n_total = float(m_local), float(n_local)
-    final_loss = float(loss)
+    elapsed, (m_total, n_total) = ddist.reduce_step_stats(elapsed, [m_local, n_local], dev)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         roof, ppv = kernel_roofline(batch_dev, args.dtype, args.kernel_reps)
@@ -205,8 +188,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
+    ddist.barrier()
     if world > 1:
-        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -20,7 +20,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int RT = 64;    // rows per step
-constexpr int OGW = 7;    // offsets per wave (4 waves x 7 >= 27)
+constexpr int MAX_OGW = 7;  // offsets per wave (4 waves x 7 >= 27)
 constexpr int PAD = 4;    // LDS row padding in elements (bank spread, keeps 8/16-byte alignment)
 
 struct F32 {
@@ -52,12 +52,12 @@ struct BF16 {
     }
 };
 
-template <class T, int TA, int TB>
+template <class T, int TA, int TB, int OGW>
 __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__restrict__ a, int ca,
                                                     const typename T::elem *__restrict__ b, int cb,
                                                     const int32_t *__restrict__ tbl, int ld, int K,
                                                     int n_rows, int rows_per_chunk, int n_tag,
-                                                    int n_grp, float *__restrict__ partial,
+                                                    int n_tbg, int n_og, float *__restrict__ partial,
                                                     int vec_ok) {
     typedef typename T::elem elem;
     typedef typename T::frag frag;
@@ -70,8 +70,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__re
     const int i = lane & 15, g = lane >> 4;
     // work item = (row chunk, channel-tile group), group fastest; contiguous items per XCD
     const int item = xcd_work_item(blockIdx.x, gridDim.x);
-    const int chunk = item / n_grp, grp = item % n_grp;
-    const int tag = grp % n_tag, tbg = grp / n_tag;
+    const int n_grp = n_tag * n_tbg * n_og;
+    const int chunk = item / n_grp;
+    int grp = item % n_grp;
+    const int tag = grp % n_tag; grp /= n_tag;
+    const int tbg = grp % n_tbg;
+    const int o_base = (grp / n_tbg) * (4 * OGW);   // this block's group of 4*OGW offsets
     const int ca0 = tag * TA * 16, cb0 = tbg * TB * 16;  // channel slices of this block
 
     f32x4 acc[OGW][TA][TB];
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__re
         int idx[OGW];
 #pragma unroll
         for (int oo = 0; oo < OGW; ++oo) {
-            const int o = wid + 4 * oo;
+            const int o = o_base + wid + 4 * oo;
             const long long row = r0 + lane;
             idx[oo] = (o < K && row < r_end) ? tbl[(long long)o * ld + row] : -1;
         }
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__re
     float *out = partial + (long long)chunk * K * ca * cb;
 #pragma unroll
     for (int oo = 0; oo < OGW; ++oo) {
-        const int o = wid + 4 * oo;
+        const int o = o_base + wid + 4 * oo;
         if (o < K) {
 #pragma unroll
             for (int x_ = 0; x_ < TA; ++x_)
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float *__restrict__ pa
 }
 
 struct Plan {
-    int TA, TB, n_tag, n_tbg, R, rows_per_chunk;
+    int TA, TB, OGW, n_og, n_tag, n_tbg, R, rows_per_chunk;
 };
 
 Plan make_plan(int K, int ca, int cb, int n_rows) {
@@ -226,7 +230,12 @@ Plan make_plan(int K, int ca, int cb, int n_rows) {
     p.TB = (tb % 2 == 0) ? 2 : 1;
     p.n_tag = ta / p.TA;
     p.n_tbg = tb / p.TB;
-    const int gy = p.n_tag * p.n_tbg;
+    // 2x2 accumulator tiles x 7 offsets would need 112 accumulator registers (1 wave/SIMD): give
+    // such blocks 4 offsets per wave and spread the offsets over several block groups instead
+    p.OGW = (p.TA * p.TB == 4) ? 4 : MAX_OGW;
+    if (K <= 8) p.OGW = (p.TA * p.TB == 4) ? 2 : 2;
+    p.n_og = div_up(K, 4 * p.OGW);
+    const int gy = p.n_tag * p.n_tbg * p.n_og;
     const int rows = n_rows > 0 ? n_rows : 1;
     int R = div_up(512, gy);            // aim at >= 2 blocks per CU over the whole grid
     const int max_r = div_up(rows, RT);
@@ -249,14 +258,19 @@ int run_wgrad(const void *a_, int ca, const void *b_, int cb, const int32_t *tbl
     float *partial = (float *)ws;
     const size_t va = 4 * sizeof(elem);
     const int vec_ok = (ca % 4 == 0) && (cb % 4 == 0) && ((uintptr_t)a % va == 0) && ((uintptr_t)b % va == 0);
-    const dim3 grid(p.R * p.n_tag * p.n_tbg), block(256);
-#define GO(TA, TB)                                                                                 \
-    hipLaunchKernelGGL((wgrad_kernel<T, TA, TB>), grid, block, 0, s, a, ca, b, cb, tbl, ld, K,    \
-                       n_rows, p.rows_per_chunk, p.n_tag, p.n_tag * p.n_tbg, partial, vec_ok)
-    if (p.TA == 1 && p.TB == 1) GO(1, 1);
-    else if (p.TA == 2 && p.TB == 1) GO(2, 1);
-    else if (p.TA == 1 && p.TB == 2) GO(1, 2);
-    else GO(2, 2);
+    const dim3 grid(p.R * p.n_tag * p.n_tbg * p.n_og), block(256);
+#define GO(TA, TB, OG)                                                                             \
+    hipLaunchKernelGGL((wgrad_kernel<T, TA, TB, OG>), grid, block, 0, s, a, ca, b, cb, tbl, ld, K, \
+                       n_rows, p.rows_per_chunk, p.n_tag, p.n_tbg, p.n_og, partial, vec_ok)
+    if (p.OGW == 2) {
+        if (p.TA == 1 && p.TB == 1) GO(1, 1, 2);
+        else if (p.TA == 2 && p.TB == 1) GO(2, 1, 2);
+        else if (p.TA == 1 && p.TB == 2) GO(1, 2, 2);
+        else GO(2, 2, 2);
+    } else if (p.TA == 1 && p.TB == 1) GO(1, 1, 7);
+    else if (p.TA == 2 && p.TB == 1) GO(2, 1, 7);
+    else if (p.TA == 1 && p.TB == 2) GO(1, 2, 7);
+    else GO(2, 2, 4);
 #undef GO
     int st = doda_check_launch();
     if (st != DODA_OK) return st;
@@ -269,7 +283,7 @@ int check_args(const void *a, int ca, const void *b, int cb, const int32_t *tbl,
                int n_rows, float *dw, void *ws, hipStream_t s, bool *done) {
     *done = true;
     if (ca <= 0 || cb <= 0 || K <= 0 || n_rows < 0 || ld < n_rows || !dw) return DODA_ERR_INVALID;
-    if (K > 4 * OGW) return DODA_ERR_UNSUPPORTED;
+    if (K > 4 * MAX_OGW) return DODA_ERR_UNSUPPORTED;
     if (n_rows == 0) {
         hipMemsetAsync(dw, 0, (size_t)K * ca * cb * 4, s);
         return DODA_OK;

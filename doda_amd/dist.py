@@ -1,0 +1,56 @@
+"""Data-parallel plumbing for the U-Net step: one process per GPU, torch.distributed over RCCL
+(backend "nccl" on ROCm) on GPUs, gloo on CPU (tests).  Scenes are independent units, so ranks share
+nothing but the gradient all-reduce (reference tool/train.py:360-361: DDP) and the bench bookkeeping
+below (max-over-ranks time, sum-over-ranks work)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return (int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def setup(backend=None):
+    """Initialise the default process group from the launcher's environment (idempotent).
+    Returns (world, rank, local_rank)."""
+    world, rank, local_rank = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend)
+    return world, rank, local_rank
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def seed_for_rank(base_seed, rank):
+    """Every rank draws its own scenes (weak scaling): disjoint seed ranges per rank."""
+    return base_seed + 100 * rank
+
+
+def reduce_step_stats(elapsed, units, device):
+    """elapsed -> MAX over ranks, every entry of `units` -> SUM over ranks (whole-job aggregate)."""
+    t = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
+    u = torch.tensor([float(v) for v in units], dtype=torch.float64, device=device)
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t[0]), [float(v) for v in u]
+
+
+def wrap_ddp(module, local_rank=None):
+    """DistributedDataParallel as tool/train.py:360-361 wraps the model; BN buffers are rank-local
+    (no per-forward broadcast), gradients live in bucket views."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return module
+    kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True)
+    if local_rank is not None and torch.cuda.is_available():
+        kw["device_ids"] = [local_rank]
+    return torch.nn.parallel.DistributedDataParallel(module, **kw)

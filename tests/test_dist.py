@@ -1,0 +1,69 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the same helpers bench.py uses on RCCL
+(process-group setup from the launcher environment, max-over-ranks timing, sum-over-ranks work,
+per-rank scene seeds, DDP gradient averaging)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+                      RANK=str(rank), LOCAL_RANK=str(rank))
+    from doda_amd import dist as ddist
+    import torch.distributed as dist
+    w, r, lr = ddist.setup("gloo")
+    assert (w, r, lr) == (world, rank, rank) and dist.get_backend() == "gloo"
+    # bench bookkeeping: slowest rank defines the time, work adds up
+    t, units = ddist.reduce_step_stats(1.0 + rank, [100.0 * (rank + 1), 7.0], torch.device("cpu"))
+    assert t == float(world) and units == [100.0 * world * (world + 1) / 2, 7.0 * world]
+    assert ddist.seed_for_rank(1000, rank) == 1000 + 100 * rank
+    # DDP averages gradients of rank-local batches (scenes are independent units)
+    torch.manual_seed(0)
+    net = torch.nn.Linear(4, 3)
+    ddp = ddist.wrap_ddp(net)
+    x = torch.full((5, 4), float(rank + 1))
+    ddp(x).sum().backward()
+    expect = torch.full((3, 4), 5.0 * (1 + world) / 2)   # mean over ranks of 5*(rank+1)
+    assert torch.allclose(net.weight.grad, expect)
+    ddist.barrier()
+    out.put((rank, t))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_bookkeeping_and_ddp():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, 2.0), (1, 2.0)]
+
+
+def test_single_process_is_a_noop():
+    from doda_amd import dist as ddist
+    saved = {k: os.environ.pop(k, None) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        assert ddist.setup() == (1, 0, 0)
+        t, units = ddist.reduce_step_stats(0.5, [3.0], torch.device("cpu"))
+        assert t == 0.5 and units == [3.0]
+        m = torch.nn.Linear(2, 2)
+        assert ddist.wrap_ddp(m) is m
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
