@@ -365,17 +365,20 @@ __global__ __launch_bounds__(256) void conv_fast(const typename T::elem *__restr
     const unsigned lane_w = (unsigned)lane * FSZ;    // this lane's slot inside a packed W fragment
     const unsigned *my_off = &off_tile[wid][i];
 
-    int units_left = __builtin_popcount(active) * n_chunk;
-    if (units_left > 0) {
+    const int n_units = __builtin_popcount(active) * n_chunk;
+    if (n_units > 0) {
         raw xa[D][S], wb[D][NBW];
-        // (o, cc, have): the next unit to issue
+        // (o, cc, have): the next unit to issue.  Every asm load below is UNCONDITIONAL (a slot with
+        // nothing left to fetch gets the all-out-of-range dummy unit, strip MAX_K): conditional
+        // definitions of ring registers make the register allocator resolve phis with moves of
+        // registers whose loads are still in flight (observed as a nondeterministic race).
         int o = __builtin_ctz(active), cc = 0;
         active &= active - 1;
         bool have = true;
+        int to_issue = n_units;
 
         auto issue = [&](raw (&xr)[S], raw (&wr)[NBW]) {
-            const int o_eff = have ? o : MAX_K;                // strip MAX_K holds only OOB
-            const unsigned *p = my_off + o_eff * RW;
+            const unsigned *p = my_off + (have ? o : MAX_K) * RW;
             const unsigned soff_x = (unsigned)cc * 16u * ESZ;
 #pragma unroll
             for (int s = 0; s < S; ++s) RawIO<T>::load(xr[s], p[s * 16] + lane_x, rs_x, soff_x);
@@ -383,40 +386,52 @@ __global__ __launch_bounds__(256) void conv_fast(const typename T::elem *__restr
             const unsigned voff_w = have ? lane_w : OOB;
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) RawIO<T>::load(wr[nb], voff_w, rs_w, soff_w + nb * 64u * FSZ);
-            if (have && ++cc == n_chunk) {
-                cc = 0;
-                if (active == 0) have = false;
-                else { o = __builtin_ctz(active); active &= active - 1; }
+            if (have) {
+                --to_issue;
+                if (++cc == n_chunk) {
+                    cc = 0;
+                    if (active == 0) have = false;
+                    else { o = __builtin_ctz(active); active &= active - 1; }
+                }
             }
+        };
+        auto consume = [&](raw (&xr)[S], raw (&wr)[NBW]) {
+#pragma unroll
+            for (int s = 1; s < S; ++s) touch(xr[s]);
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) touch(wr[nb]);
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    T::mma(acc[s][nb], RawIO<T>::as_frag(wr[nb]), RawIO<T>::as_frag(xr[s]));
         };
 
 #pragma unroll
         for (int k = 0; k < D; ++k) issue(xa[k], wb[k]);
-        while (units_left > 0) {
+        int consumed = 0;
+        // steady state: D-1 units (L loads each) stay in flight behind the one being consumed
+        while (to_issue > 0) {
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 wait_vm<(D - 1) * L>(xa[k][0]);
+                consume(xa[k], wb[k]);
+                issue(xa[k], wb[k]);
+            }
+            consumed += D;
+        }
+        // tail: everything is issued; drain once, then use the slots that still hold real units
+        wait_vm<0>(xa[0][0]);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            if (k > 0) touch(xa[k][0]);
+            if (consumed + k < n_units) consume(xa[k], wb[k]);
+            else {
 #pragma unroll
                 for (int s = 1; s < S; ++s) touch(xa[k][s]);
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb) touch(wb[k][nb]);
-#pragma unroll
-                for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-                    for (int s = 0; s < S; ++s)
-                        T::mma(acc[s][nb], RawIO<T>::as_frag(wb[k][nb]), RawIO<T>::as_frag(xa[k][s]));
-                issue(xa[k], wb[k]);
             }
-            units_left -= D;
-        }
-        // retire the loads still in flight (dummy units) before their registers are reused
-        wait_vm<0>(xa[0][0]);
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-#pragma unroll
-            for (int s = 0; s < S; ++s) touch(xa[k][s]);
-#pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) touch(wb[k][nb]);
         }
     }
 
