@@ -49,8 +49,8 @@ _SIGNATURES = {
     "doda_maxpool_fwd_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "doda_maxpool_bwd_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "doda_bn_workspace_bytes": (c_sz, [c_i32, c_i32]),
-    "doda_bn_relu_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i32,
-                                 c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "doda_bn_relu_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                 c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "doda_bn_relu_bwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                  c_vp, c_vp, c_vp, c_sz, c_vp]),
     "doda_knnquery": (c_i32, [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(64) void bn_stats_final(const typename T::elem *__r
                                                      int m, int c, float eps, float momentum,
                                                      float *__restrict__ mean, float *__restrict__ invstd,
                                                      float *__restrict__ running_mean,
-                                                     float *__restrict__ running_var) {
+                                                     float *__restrict__ running_var,
+                                                     long long *__restrict__ num_batches_tracked) {
     const int ch = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 64) {
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(64) void bn_stats_final(const typename T::elem *__r
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
     if (threadIdx.x != 0) return;
+    if (ch == 0 && num_batches_tracked) *num_batches_tracked += 1;
     const f32x4 k4 = T::load4(x + (ch & ~3));
     const double k = (double)k4[ch & 3];
     const double d = s1 / m;
@@ -264,8 +266,8 @@ int n_blocks_for(int m, const Geo &g) {
 
 template <class T>
 int run_fwd(const void *x_, int m, int c, float eps, float momentum, const float *gamma,
-            const float *beta, float *running_mean, float *running_var, int training, int relu,
-            void *y_, float *mean, float *invstd, void *ws, size_t ws_bytes, hipStream_t s) {
+            const float *beta, float *running_mean, float *running_var, long long *nbt, int training,
+            int relu, void *y_, float *mean, float *invstd, void *ws, size_t ws_bytes, hipStream_t s) {
     typedef typename T::elem elem;
     const elem *x = (const elem *)x_;
     elem *y = (elem *)y_;
@@ -277,7 +279,7 @@ int run_fwd(const void *x_, int m, int c, float eps, float momentum, const float
         hipLaunchKernelGGL((bn_stats_partial<T>), dim3(nb), dim3(BN_BLOCK), (size_t)g.rpb * 2 * c * 4, s,
                            x, m, c, g, partial);
         hipLaunchKernelGGL((bn_stats_final<T>), dim3(c), dim3(64), 0, s, x, partial, nb, m,
-                           c, eps, momentum, mean, invstd, running_mean, running_var);
+                           c, eps, momentum, mean, invstd, running_mean, running_var, nbt);
     }
     const long long n_frag = (long long)m * g.nf;
     const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
@@ -322,17 +324,20 @@ extern "C" size_t doda_bn_workspace_bytes(int32_t m, int32_t c) {
 
 extern "C" int doda_bn_relu_fwd(const void *x, int32_t m, int32_t c, int32_t elem_bytes, float eps,
                                 float momentum, const float *gamma, const float *beta,
-                                float *running_mean, float *running_var, int32_t training,
-                                int32_t relu, void *y, float *save_mean, float *save_invstd,
-                                void *ws, size_t ws_bytes, doda_stream_t stream) {
+                                float *running_mean, float *running_var,
+                                int64_t *num_batches_tracked, int32_t training, int32_t relu,
+                                void *y, float *save_mean, float *save_invstd, void *ws,
+                                size_t ws_bytes, doda_stream_t stream) {
     if (m == 0) return DODA_OK;
     if (bn_args_bad(m, c, elem_bytes)) return DODA_ERR_UNSUPPORTED;
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !ws) return DODA_ERR_INVALID;
     if (elem_bytes == 4)
-        return run_fwd<F32>(x, m, c, eps, momentum, gamma, beta, running_mean, running_var, training,
-                            relu, y, save_mean, save_invstd, ws, ws_bytes, as_stream(stream));
-    return run_fwd<BF16>(x, m, c, eps, momentum, gamma, beta, running_mean, running_var, training, relu,
-                         y, save_mean, save_invstd, ws, ws_bytes, as_stream(stream));
+        return run_fwd<F32>(x, m, c, eps, momentum, gamma, beta, running_mean, running_var,
+                            (long long *)num_batches_tracked, training, relu, y, save_mean, save_invstd,
+                            ws, ws_bytes, as_stream(stream));
+    return run_fwd<BF16>(x, m, c, eps, momentum, gamma, beta, running_mean, running_var,
+                         (long long *)num_batches_tracked, training, relu, y, save_mean, save_invstd, ws,
+                         ws_bytes, as_stream(stream));
 }
 
 extern "C" int doda_bn_relu_bwd(const void *x, const void *dy, int32_t m, int32_t c,

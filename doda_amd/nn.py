@@ -16,10 +16,10 @@ from . import ops as _ops
 
 class _BNReLU(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, relu):
         x = x.contiguous()
         y, mean, invstd = _ops.bn_relu_fwd(x, weight, bias, running_mean, running_var, training,
-                                           momentum, eps, relu)
+                                           momentum, eps, relu, nbt)
         ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.cfg = (bool(training), bool(relu))
         return y
@@ -38,7 +38,7 @@ class _BNReLU(Function):
                 dz = dz * ((xh * weight + bias) > 0)
             dx = (dz * (weight * invstd)).to(x.dtype)
             dg, db = (dz * xh).sum(0), dz.sum(0)
-        return dx, dg.to(weight.dtype), db.to(bias.dtype), None, None, None, None, None, None
+        return dx, dg.to(weight.dtype), db.to(bias.dtype), None, None, None, None, None, None, None
 
 
 def fusable(bn, features):
@@ -53,8 +53,7 @@ def fusable(bn, features):
 
 def batch_norm_relu(features, bn, relu):
     """BatchNorm1d `bn` (+ReLU when `relu`) on features through the fused HIP kernels."""
-    training = bn.training
-    if training:
-        bn.num_batches_tracked.add_(1)
-    return _BNReLU.apply(features, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                         bn.momentum, bn.eps, relu)
+    # num_batches_tracked += 1 happens inside the stats kernel (65 one-element add kernels per step
+    # otherwise)
+    return _BNReLU.apply(features, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                         bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, relu)

@@ -271,7 +271,8 @@ def _esz(t):
     raise RuntimeError("unsupported feature dtype %s" % t.dtype)
 
 
-def bn_relu_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+def bn_relu_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu,
+                num_batches_tracked=None):
     """-> (y, save_mean, save_invstd).  x: contiguous [m, c] fp32|bf16 on device, c % 4 == 0."""
     _feat_ok(x, "x")
     m, c = x.shape
@@ -285,8 +286,9 @@ def bn_relu_fwd(x, gamma, beta, running_mean, running_var, training, momentum, e
     ws = _ws(lib().doda_bn_workspace_bytes(m, c), x.device)
     rm = _p(running_mean) if (training and running_mean is not None) else None
     rv = _p(running_var) if (training and running_var is not None) else None
+    nbt = _p(num_batches_tracked) if (training and num_batches_tracked is not None) else None
     check(lib().doda_bn_relu_fwd(_p(x), m, c, _esz(x), float(eps), float(momentum), _p(gamma), _p(beta),
-                                 rm, rv, int(bool(training)), int(bool(relu)), _p(y), _p(save_mean),
+                                 rm, rv, nbt, int(bool(training)), int(bool(relu)), _p(y), _p(save_mean),
                                  _p(save_invstd), _p(ws), ws.numel(), _stream()), "doda_bn_relu_fwd")
     return y, save_mean, save_invstd
 

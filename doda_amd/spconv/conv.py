@@ -70,8 +70,20 @@ class SparseConvolution(SparseModule):
         batch_size = input.batch_size
 
         if self.conv1x1:
-            w2 = self.weight.view(self.in_channels, self.out_channels)
-            out_features = torch.mm(features, w2.to(features.dtype))
+            native = (features.is_cuda and features.dtype in (torch.float32, torch.bfloat16)
+                      and self.in_channels % 4 == 0 and self.out_channels % 4 == 0
+                      and self.weight.dtype == torch.float32 and features.shape[0] > 0)
+            if native:
+                key = ("__identity__", features.shape[0])
+                ident = input.indice_dict.get(key)
+                if ident is None:
+                    ident = torch.arange(features.shape[0], dtype=torch.int32,
+                                         device=features.device).view(1, -1)
+                    input.indice_dict[key] = ident
+                out_features = Fsp.conv1x1(features, self.weight, ident)
+            else:
+                w2 = self.weight.view(self.in_channels, self.out_channels)
+                out_features = torch.mm(features, w2.to(features.dtype))
             if self.bias is not None:
                 out_features = out_features + self.bias.to(features.dtype)
             out = SparseConvTensor(out_features, indices, spatial_shape, batch_size)

@@ -184,14 +184,15 @@ int doda_maxpool_bwd_f32(const float *x, const float *y, const float *dy, int32_
  * x / y / dy / dx: fp32 (elem_bytes 4) or bf16 (2); statistics and parameters fp32; c % 4 == 0.
  * training != 0: batch statistics (biased variance, eps inside the sqrt) are computed, written to
  * save_mean / save_invstd and folded into running_mean / running_var (momentum, unbiased variance)
- * when those are non-null; training == 0: save_mean / save_invstd must already hold the running
+ * when those are non-null, and *num_batches_tracked (int64, nullable) is incremented; training == 0: save_mean / save_invstd must already hold the running
  * mean and 1/sqrt(running_var + eps).  Backward recomputes the ReLU mask from x.
  * ---------------------------------------------------------------------------------------- */
 size_t doda_bn_workspace_bytes(int32_t m, int32_t c);
 int doda_bn_relu_fwd(const void *x, int32_t m, int32_t c, int32_t elem_bytes, float eps,
                      float momentum, const float *gamma, const float *beta, float *running_mean,
-                     float *running_var, int32_t training, int32_t relu, void *y, float *save_mean,
-                     float *save_invstd, void *ws, size_t ws_bytes, doda_stream_t stream);
+                     float *running_var, int64_t *num_batches_tracked, int32_t training,
+                     int32_t relu, void *y, float *save_mean, float *save_invstd, void *ws,
+                     size_t ws_bytes, doda_stream_t stream);
 int doda_bn_relu_bwd(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
                      const float *save_mean, const float *save_invstd, const float *gamma,
                      const float *beta, int32_t relu, void *dx, float *dgamma, float *dbeta,
