@@ -144,7 +144,7 @@ def main():
     torch.manual_seed(0)
     net = SparseConvNet(cfg).to(dev).train()
     model = ddist.wrap_ddp(net, local_rank)
-    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)
     fdt = torch.float32 if args.dtype == "f32" else torch.bfloat16
     labels = batch_dev["labels"]
 

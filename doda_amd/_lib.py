@@ -37,6 +37,9 @@ _SIGNATURES = {
     "doda_rulebook_pairs": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_sz,
                                     c_vp]),
     "doda_spconv_gather_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "doda_spconv_pack_desc_bytes": (c_sz, []),
+    "doda_spconv_pack_plan_h": (c_i32, [c_vp, c_i32, c_vp, C.POINTER(c_i32)]),
+    "doda_spconv_pack_multi": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "doda_spconv_gather_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
                                        c_i32, c_vp, c_sz, c_vp]),
     "doda_spconv_wgrad_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),

@@ -98,6 +98,52 @@ __global__ __launch_bounds__(256) void pack_weights(const float *__restrict__ w,
     packed[e] = v;
 }
 
+// One launch for many weight tensors (all layers of a network, both layouts): block b looks up its
+// descriptor through the inclusive block prefix `blk_end`.
+struct PackDesc {
+    const float *w;
+    void *out;
+    int K, kc, nc, layout, elem_bytes, n_chunk, NB, pad;
+};
+
+template <class T>
+__device__ __forceinline__ void pack_one(const PackDesc &d, long long e) {
+    const int lane = (int)(e & 63);
+    long long r = e >> 6;
+    const int nb = (int)(r % d.NB); r /= d.NB;
+    const int cc = (int)(r % d.n_chunk);
+    const int o = (int)(r / d.n_chunk);
+    const int i = lane & 15, g = lane >> 4;
+    const int col = nb * 16 + i;
+    typename T::frag v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = cc * 16 + 4 * g + q;
+        float f = 0.f;
+        if (c < d.kc && col < d.nc) {
+            if (d.layout == 0) f = d.w[((long long)o * d.kc + c) * d.nc + col];
+            else f = d.w[((long long)(d.layout == 2 ? d.K - 1 - o : o) * d.nc + col) * d.kc + c];
+        }
+        v[q] = T::from_float(f);
+    }
+    reinterpret_cast<typename T::frag *>(d.out)[e] = v;
+}
+
+__global__ __launch_bounds__(256) void pack_weights_multi(const PackDesc *__restrict__ descs,
+                                                          const int *__restrict__ blk_end, int n_desc) {
+    int lo = 0, hi = n_desc - 1;
+    while (lo < hi) {  // first descriptor whose inclusive end exceeds this block
+        const int mid = (lo + hi) >> 1;
+        if ((int)blockIdx.x < blk_end[mid]) hi = mid; else lo = mid + 1;
+    }
+    const PackDesc d = descs[lo];
+    const int first = lo == 0 ? 0 : blk_end[lo - 1];
+    const long long e = (long long)(blockIdx.x - first) * 256 + threadIdx.x;
+    const long long total = (long long)d.K * d.n_chunk * d.NB * 64;
+    if (e >= total) return;
+    if (d.elem_bytes == 4) pack_one<F32>(d, e); else pack_one<BF16>(d, e);
+}
+
 constexpr int MAX_K = 27;
 
 template <class T, int NBW, int S>
@@ -489,11 +535,16 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     elem *y = (elem *)y_;
     const int n_chunk = (kc + 15) / 16, NB = (nc + 15) / 16;
     const size_t need = (size_t)K * n_chunk * NB * 64 * sizeof(frag);
-    if (ws_bytes < need) return DODA_ERR_WORKSPACE;
-    frag *wp = (frag *)ws;
-    const long long total = (long long)K * n_chunk * NB * 64;
-    hipLaunchKernelGGL((pack_weights<T>), dim3(div_up(total, 256)), dim3(256), 0, s, w, K, kc, nc,
-                       n_chunk, NB, wl, wp);
+    frag *wp;
+    if (wl & 0x100) {  // `w` already holds the fragment-packed weights (doda_spconv_pack_multi)
+        wp = (frag *)(const void *)w;
+    } else {
+        if (!ws || ws_bytes < need) return DODA_ERR_WORKSPACE;
+        wp = (frag *)ws;
+        const long long total = (long long)K * n_chunk * NB * 64;
+        hipLaunchKernelGGL((pack_weights<T>), dim3(div_up(total, 256)), dim3(256), 0, s, w, K, kc, nc,
+                           n_chunk, NB, wl, wp);
+    }
     // all rows the table may reference must sit inside the 2 GB buffer window of the fast path
     const bool x_rows_bytes_ok = n_in > 0 && (size_t)n_in * kc * sizeof(elem) < 0x7ffffff0ull;
     const size_t va = 4 * sizeof(elem);  // vector access granule
@@ -545,7 +596,7 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
 
 bool bad_args(const void *x, int kc, const float *w, int nc, const int32_t *tbl, int ld, int K,
               int n_out, const void *y, int wl, int *status) {
-    if (kc <= 0 || nc <= 0 || K <= 0 || n_out < 0 || ld < n_out || wl < 0 || wl > 2) {
+    if (kc <= 0 || nc <= 0 || K <= 0 || n_out < 0 || ld < n_out || (wl & 0xff) > 2 || (wl & ~0x1ff)) {
         *status = DODA_ERR_INVALID;
         return true;
     }
@@ -562,13 +613,43 @@ extern "C" size_t doda_spconv_gather_workspace_bytes(int32_t K, int32_t kc, int3
     return align_up((size_t)K * ((kc + 15) / 16) * ((nc + 15) / 16) * 64 * 4 * (size_t)elem_bytes, 256);
 }
 
+extern "C" size_t doda_spconv_pack_desc_bytes(void) { return sizeof(PackDesc); }
+
+// descs_h: n_desc host descriptors {w, out, K, kc, nc, layout, elem_bytes}; fills the derived
+// fields and the block prefix, both written to the caller's host arrays for upload.
+extern "C" int doda_spconv_pack_plan_h(void *descs_h, int32_t n_desc, int32_t *blk_end_h,
+                                       int32_t *total_blocks) {
+    if (!descs_h || !blk_end_h || !total_blocks || n_desc <= 0) return DODA_ERR_INVALID;
+    PackDesc *d = (PackDesc *)descs_h;
+    long long acc = 0;
+    for (int k = 0; k < n_desc; ++k) {
+        if (d[k].K <= 0 || d[k].K > MAX_K || d[k].kc <= 0 || d[k].nc <= 0 || d[k].layout < 0 ||
+            d[k].layout > 2 || (d[k].elem_bytes != 2 && d[k].elem_bytes != 4))
+            return DODA_ERR_INVALID;
+        d[k].n_chunk = (d[k].kc + 15) / 16;
+        d[k].NB = (d[k].nc + 15) / 16;
+        acc += div_up((long long)d[k].K * d[k].n_chunk * d[k].NB * 64, 256);
+        if (acc > 0x7fffffff) return DODA_ERR_UNSUPPORTED;
+        blk_end_h[k] = (int32_t)acc;
+    }
+    *total_blocks = (int32_t)acc;
+    return DODA_OK;
+}
+
+extern "C" int doda_spconv_pack_multi(const void *descs_dev, const int32_t *blk_end_dev,
+                                      int32_t n_desc, int32_t total_blocks, doda_stream_t stream) {
+    if (!descs_dev || !blk_end_dev || n_desc <= 0 || total_blocks <= 0) return DODA_ERR_INVALID;
+    hipLaunchKernelGGL(pack_weights_multi, dim3(total_blocks), dim3(256), 0, as_stream(stream),
+                       (const PackDesc *)descs_dev, blk_end_dev, n_desc);
+    return doda_check_launch();
+}
+
 extern "C" int doda_spconv_gather_f32(const float *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
                                       const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
                                       float *y, int32_t w_layout, void *ws, size_t ws_bytes,
                                       doda_stream_t stream) {
     int st;
     if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
-    if (!ws) return DODA_ERR_INVALID;
     return run_gather<F32>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, false,
                            as_stream(stream));
 }
@@ -579,7 +660,6 @@ extern "C" int doda_spconv_gather_bf16(const uint16_t *x, int32_t n_in, int32_t 
                                        size_t ws_bytes, doda_stream_t stream) {
     int st;
     if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
-    if (!ws) return DODA_ERR_INVALID;
     return run_gather<BF16>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, y_is_f32 != 0,
                             as_stream(stream));
 }

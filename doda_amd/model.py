@@ -175,6 +175,8 @@ class SparseConvNet(nn.Module):
                 mod.bias.data.fill_(0.0)
 
     def forward(self, input, input_map, return_mid_feat=False, v2p_map=None):
+        if input.features.is_cuda and input.indices.shape[0] > 0:
+            spconv.ops.build_pyramid(input, len(self.unet.nPlanes))   # all 13 rulebooks up front
         out = self.output_layer(self.unet(self.input_conv(input)))
         feats = out.features
         fused = (v2p_map is not None and not return_mid_feat and feats.is_cuda

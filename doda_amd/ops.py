@@ -12,7 +12,14 @@ import torch
 from ._lib import check, lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (the raw getter is ~30x cheaper
+    than torch.cuda.current_stream(), which dominated the host time of a U-Net step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -27,8 +34,19 @@ def _need_cuda(*ts):
                                "there is no CPU fallback" % t.device)
 
 
+_WS = {}
+
+
 def _ws(nbytes, device):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    """Scratch for ONE native call.  Calls on a stream execute in order, so a single grow-only
+    buffer per (device, stream) is reused instead of allocating per call."""
+    nbytes = max(int(nbytes), 256)
+    key = (device, _stream())
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
 
 
 # ------------------------------------------------------------------------------------------
@@ -193,32 +211,80 @@ def _feat_ok(x, name):
         raise RuntimeError("%s must be a contiguous [rows, channels] tensor" % name)
 
 
-def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False):
+def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None):
     """y[t] = sum_o x[tbl[o][t]] @ B_o (see doda_hip.h).  x: [n_in,kc] f32|bf16; w: fp32 weights
-    viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2).  Returns y [n_out, nc] in x.dtype
-    (or float32 when out_f32)."""
+    viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2), or `packed`: the fragment-packed buffer
+    produced by PackPlan for this (weight, layout, dtype).  Returns y [n_out, nc] in x.dtype (or
+    float32 when out_f32)."""
     _feat_ok(x, "x")
-    _need_cuda(w, tbl)
+    _need_cuda(tbl)
     K, ld = tbl.shape
     kc = x.shape[1]
-    w = w.contiguous()
-    if w.dtype != torch.float32 or w.numel() != K * kc * nc:
-        raise RuntimeError("weight must be float32 with K*kc*nc = %d elements" % (K * kc * nc))
-    ws_esz = 4 if x.dtype == torch.float32 else 2
-    ws = _ws(lib().doda_spconv_gather_workspace_bytes(K, kc, nc, ws_esz), x.device)
+    esz = 4 if x.dtype == torch.float32 else 2
+    if packed is not None:
+        need = lib().doda_spconv_gather_workspace_bytes(K, kc, nc, esz)
+        if packed.numel() * packed.element_size() < need - 255:
+            raise RuntimeError("packed weight buffer too small")
+        w_ptr, ws_ptr, ws_n, layout = _p(packed), None, 0, int(w_layout) | 0x100
+    else:
+        _need_cuda(w)
+        w = w.contiguous()
+        if w.dtype != torch.float32 or w.numel() != K * kc * nc:
+            raise RuntimeError("weight must be float32 with K*kc*nc = %d elements" % (K * kc * nc))
+        ws = _ws(lib().doda_spconv_gather_workspace_bytes(K, kc, nc, esz), x.device)
+        w_ptr, ws_ptr, ws_n, layout = _p(w), _p(ws), ws.numel(), int(w_layout)
     if x.dtype == torch.float32:
         y = torch.empty((n_out, nc), dtype=torch.float32, device=x.device)
-        check(lib().doda_spconv_gather_f32(_p(x), x.shape[0], kc, _p(w), nc, _p(tbl), ld, K, n_out,
-                                           _p(y), int(w_layout), _p(ws), ws.numel(), _stream()),
+        check(lib().doda_spconv_gather_f32(_p(x), x.shape[0], kc, w_ptr, nc, _p(tbl), ld, K, n_out,
+                                           _p(y), layout, ws_ptr, ws_n, _stream()),
               "doda_spconv_gather_f32")
     elif x.dtype == torch.bfloat16:
         y = torch.empty((n_out, nc), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
-        check(lib().doda_spconv_gather_bf16(_p(x), x.shape[0], kc, _p(w), nc, _p(tbl), ld, K, n_out,
-                                            _p(y), int(bool(out_f32)), int(w_layout), _p(ws), ws.numel(),
-                                            _stream()), "doda_spconv_gather_bf16")
+        check(lib().doda_spconv_gather_bf16(_p(x), x.shape[0], kc, w_ptr, nc, _p(tbl), ld, K, n_out,
+                                            _p(y), int(bool(out_f32)), layout, ws_ptr, ws_n, _stream()),
+              "doda_spconv_gather_bf16")
     else:
         raise RuntimeError("spconv_gather: unsupported feature dtype %s" % x.dtype)
     return y
+
+
+class PackPlan:
+    """One-launch pre-pack of many weight tensors (doda_spconv_pack_multi).
+
+    entries: list of (w fp32 device tensor viewed [K,*,*], K, kc, nc, layout, elem_bytes).  Output
+    buffers and the device descriptor table are created once; run() re-packs everything in a single
+    kernel launch (call it whenever the weights changed)."""
+
+    def __init__(self, entries, device):
+        import numpy as np
+        l = lib()
+        n = len(entries)
+        dsz = l.doda_spconv_pack_desc_bytes()
+        assert dsz == 48
+        desc = np.zeros(n, dtype=np.dtype([("w", "<u8"), ("out", "<u8"), ("K", "<i4"), ("kc", "<i4"),
+                                           ("nc", "<i4"), ("layout", "<i4"), ("esz", "<i4"),
+                                           ("n_chunk", "<i4"), ("NB", "<i4"), ("pad", "<i4")]))
+        self.outputs = []
+        self._keep = []
+        for k, (w, K, kc, nc, layout, esz) in enumerate(entries):
+            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.numel() == K * kc * nc):
+                raise RuntimeError("PackPlan: weights must be contiguous fp32 device tensors")
+            out = torch.empty(l.doda_spconv_gather_workspace_bytes(K, kc, nc, esz), dtype=torch.uint8,
+                              device=device)
+            self.outputs.append(out)
+            self._keep.append(w)
+            desc[k] = (w.data_ptr(), out.data_ptr(), K, kc, nc, layout, esz, 0, 0, 0)
+        blk_end = np.zeros(n, dtype=np.int32)
+        total = C.c_int32()
+        check(l.doda_spconv_pack_plan_h(desc.ctypes.data, n, blk_end.ctypes.data, C.byref(total)),
+              "doda_spconv_pack_plan_h")
+        self.n, self.total = n, int(total.value)
+        self.desc_dev = torch.from_numpy(desc.view(np.uint8).copy()).to(device)
+        self.blk_dev = torch.from_numpy(blk_end).to(device)
+
+    def run(self):
+        check(lib().doda_spconv_pack_multi(_p(self.desc_dev), _p(self.blk_dev), self.n, self.total,
+                                           _stream()), "doda_spconv_pack_multi")
 
 
 def spconv_wgrad(a, b, tbl, n_rows):

@@ -5,15 +5,62 @@ DODA's model zoo), kaiming_uniform(a=sqrt(5)) initialisation, rule
 `indice_key` in `input.indice_dict`, and the 1x1 shortcut (`features @ W.view(Cin,Cout)`) follow
 upstream; the arithmetic is libdoda_hip.so's."""
 import math
+import weakref
 
 import torch
 from torch import nn
 from torch.nn import init
 
+from .. import ops as _nops
 from . import functional as Fsp
 from . import ops
 from .core import SparseConvTensor
 from .modules import SparseModule
+
+# ---------------------------------------------------------------------------------------------
+# Weight pre-packing.  The native conv kernels read weights in MFMA-fragment order (bf16-rounded for
+# bf16 features; transposed / offset-mirrored for the data-grad).  Weights change once per optimizer
+# step, so instead of packing inside every conv call (2 x 71 launches per U-Net step) all live
+# convolution modules of a device are re-packed by ONE multi-tensor launch the first time any of
+# them sees a new `weight._version`.  (In-place edits through `.data` do not bump the version; call
+# doda_amd.spconv.conv.invalidate_packed() after such edits.)
+# ---------------------------------------------------------------------------------------------
+import os as _os
+
+_MODULES = weakref.WeakSet()
+_PLANS = {}   # (device, elem_bytes) -> (signature, PackPlan, [modules])
+_PREPACK = _os.environ.get("DODA_NO_PREPACK", "0") != "1"
+
+
+def invalidate_packed():
+    _PLANS.clear()
+    for m in list(_MODULES):
+        m._doda_packed = {}
+
+
+def _bwd_layout(m):
+    return 2 if (m.subm and not m.conv1x1) else 1
+
+
+def _repack_all(device, esz):
+    mods = [m for m in _MODULES if m.weight.device == device and m.weight.dtype == torch.float32]
+    mods.sort(key=id)
+    sig = tuple((id(m), m.weight.data_ptr()) for m in mods)
+    cached = _PLANS.get((device, esz))
+    if cached is None or cached[0] != sig:
+        entries = []
+        for m in mods:
+            K = m.weight.shape[0] * m.weight.shape[1] * m.weight.shape[2]
+            w = m.weight.detach().view(K, m.in_channels, m.out_channels)
+            entries.append((w, K, m.in_channels, m.out_channels, 0, esz))          # forward: [K][kc][nc]
+            entries.append((w, K, m.out_channels, m.in_channels, _bwd_layout(m), esz))  # data-grad
+        plan = _nops.PackPlan(entries, device)
+        cached = (sig, plan, mods)
+        _PLANS[(device, esz)] = cached
+    _, plan, mods = cached
+    plan.run()
+    for k, m in enumerate(mods):
+        m._doda_packed[esz] = (m.weight._version, m.weight.data_ptr(), plan.outputs[2 * k], plan.outputs[2 * k + 1])
 
 
 class SparseConvolution(SparseModule):
@@ -44,6 +91,8 @@ class SparseConvolution(SparseModule):
         if inverse and indice_key is None:
             raise ValueError("SparseInverseConv3d needs the indice_key of its strided convolution")
         self.weight = nn.Parameter(torch.Tensor(*self.kernel_size, in_channels, out_channels))
+        self._doda_packed = {}
+        _MODULES.add(self)
         if bias:
             self.bias = nn.Parameter(torch.Tensor(out_channels))
         else:
@@ -61,6 +110,22 @@ class SparseConvolution(SparseModule):
         return "{}, {}, kernel_size={}, stride={}, subm={}, inverse={}, indice_key={}".format(
             self.in_channels, self.out_channels, self.kernel_size, self.stride, self.subm,
             self.inverse, self.indice_key)
+
+    def _packed(self, features):
+        """(forward, data-grad) fragment-packed weights for this feature dtype, or None when the
+        native fast path does not apply."""
+        if not (_PREPACK and features.is_cuda and self.weight.is_cuda and self.weight.dtype == torch.float32
+                and features.dtype in (torch.float32, torch.bfloat16) and self.weight.is_contiguous()):
+            return None
+        if self.weight.shape[0] * self.weight.shape[1] * self.weight.shape[2] > 27:
+            return None
+        esz = 4 if features.dtype == torch.float32 else 2
+        st = self._doda_packed.get(esz)
+        if st is None or st[0] != self.weight._version or st[1] != self.weight.data_ptr():
+            _MODULES.add(self)   # e.g. a deep-copied module never ran __init__
+            _repack_all(self.weight.device, esz)
+            st = self._doda_packed[esz]
+        return st[2], st[3]
 
     def forward(self, input):
         assert isinstance(input, SparseConvTensor)
@@ -80,7 +145,7 @@ class SparseConvolution(SparseModule):
                     ident = torch.arange(features.shape[0], dtype=torch.int32,
                                          device=features.device).view(1, -1)
                     input.indice_dict[key] = ident
-                out_features = Fsp.conv1x1(features, self.weight, ident)
+                out_features = Fsp.conv1x1(features, self.weight, ident, self._packed(features))
             else:
                 w2 = self.weight.view(self.in_channels, self.out_channels)
                 out_features = torch.mm(features, w2.to(features.dtype))
@@ -97,7 +162,7 @@ class SparseConvolution(SparseModule):
                 raise RuntimeError("SparseInverseConv3d: no strided rulebook under indice_key %r"
                                    % (self.indice_key,))
             outids, out_spatial_shape = data.indices, data.spatial_shape
-            out_features = Fsp.indice_inverse_conv(features, self.weight, data)
+            out_features = Fsp.indice_inverse_conv(features, self.weight, data, self._packed(features))
         else:
             if data is None:
                 if self.subm:
@@ -109,9 +174,9 @@ class SparseConvolution(SparseModule):
                     input.indice_dict[self.indice_key] = data
             outids, out_spatial_shape = data.outids, data.out_spatial_shape
             if self.subm:
-                out_features = Fsp.indice_subm_conv(features, self.weight, data)
+                out_features = Fsp.indice_subm_conv(features, self.weight, data, self._packed(features))
             else:
-                out_features = Fsp.indice_conv(features, self.weight, data)
+                out_features = Fsp.indice_conv(features, self.weight, data, self._packed(features))
 
         if self.bias is not None:
             out_features = out_features + self.bias.to(out_features.dtype)

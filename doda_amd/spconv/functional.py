@@ -50,28 +50,29 @@ def _backward_pair(need_dx, need_dw, dgrad_fn, wgrad_fn, device):
 
 class _IndiceConv(Function):
     @staticmethod
-    def forward(ctx, features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout):
+    def forward(ctx, features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed):
         K = fwd_tbl.shape[0]
         cin, cout = weight.shape[-2], weight.shape[-1]
         w = weight.reshape(K, cin, cout)
         ctx.save_for_backward(features, weight)
-        ctx.tables = (fwd_tbl, bwd_tbl, n_out, bwd_layout)
-        return _ops.spconv_gather(features.contiguous(), w, fwd_tbl, n_out, 0, cout)
+        pk_fwd, pk_bwd = packed if packed is not None else (None, None)
+        ctx.tables = (fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_bwd)
+        return _ops.spconv_gather(features.contiguous(), w, fwd_tbl, n_out, 0, cout, packed=pk_fwd)
 
     @staticmethod
     def backward(ctx, grad_output):
         features, weight = ctx.saved_tensors
-        fwd_tbl, bwd_tbl, n_out, bwd_layout = ctx.tables
+        fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_bwd = ctx.tables
         K = fwd_tbl.shape[0]
         cin, cout = weight.shape[-2], weight.shape[-1]
         dy = grad_output.contiguous()  # reference fork patch llijiang/spconv@740a5b7
         w = weight.reshape(K, cin, cout)
         d_feat, d_w = _backward_pair(
             ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-            lambda: _ops.spconv_gather(dy, w, bwd_tbl, features.shape[0], bwd_layout, cin),
+            lambda: _ops.spconv_gather(dy, w, bwd_tbl, features.shape[0], bwd_layout, cin, packed=pk_bwd),
             lambda: _ops.spconv_wgrad(features.contiguous(), dy, fwd_tbl, n_out).reshape(weight.shape).to(weight.dtype),
             dy.device)
-        return d_feat, d_w, None, None, None, None
+        return d_feat, d_w, None, None, None, None, None
 
 
 class _Conv1x1(Function):
@@ -80,11 +81,12 @@ class _Conv1x1(Function):
     5-10x slower than the gather kernel on MI355X."""
 
     @staticmethod
-    def forward(ctx, features, weight, ident):
+    def forward(ctx, features, weight, ident, packed):
         cin, cout = weight.shape[-2], weight.shape[-1]
         ctx.save_for_backward(features, weight, ident)
+        pk_fwd, ctx.pk_bwd = packed if packed is not None else (None, None)
         return _ops.spconv_gather(features.contiguous(), weight.reshape(1, cin, cout), ident,
-                                  features.shape[0], 0, cout)
+                                  features.shape[0], 0, cout, packed=pk_fwd)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -93,27 +95,28 @@ class _Conv1x1(Function):
         dy = grad_output.contiguous()
         d_feat, d_w = _backward_pair(
             ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-            lambda: _ops.spconv_gather(dy, weight.reshape(1, cin, cout), ident, features.shape[0], 1, cin),
+            lambda: _ops.spconv_gather(dy, weight.reshape(1, cin, cout), ident, features.shape[0], 1, cin,
+                                       packed=ctx.pk_bwd),
             lambda: _ops.spconv_wgrad(features.contiguous(), dy, ident, features.shape[0]).reshape(weight.shape).to(weight.dtype),
             dy.device)
-        return d_feat, d_w, None
+        return d_feat, d_w, None, None
 
 
-def conv1x1(features, weight, ident):
-    return _Conv1x1.apply(features, weight, ident)
+def conv1x1(features, weight, ident, packed=None):
+    return _Conv1x1.apply(features, weight, ident, packed)
 
 
-def indice_subm_conv(features, weight, data):
-    return _IndiceConv.apply(features, weight, data.tbl, data.tbl, data.outids.shape[0], 2)
+def indice_subm_conv(features, weight, data, packed=None):
+    return _IndiceConv.apply(features, weight, data.tbl, data.tbl, data.outids.shape[0], 2, packed)
 
 
-def indice_conv(features, weight, data):
-    return _IndiceConv.apply(features, weight, data.tbl, data.tbl_rev, data.outids.shape[0], 1)
+def indice_conv(features, weight, data, packed=None):
+    return _IndiceConv.apply(features, weight, data.tbl, data.tbl_rev, data.outids.shape[0], 1, packed)
 
 
-def indice_inverse_conv(features, weight, data):
+def indice_inverse_conv(features, weight, data, packed=None):
     # roles swapped: outputs live on the saved (fine) input indices of the strided conv
-    return _IndiceConv.apply(features, weight, data.tbl_rev, data.tbl, data.indices.shape[0], 1)
+    return _IndiceConv.apply(features, weight, data.tbl_rev, data.tbl, data.indices.shape[0], 1, packed)
 
 
 class _IndiceMaxPool(Function):

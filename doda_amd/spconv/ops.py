@@ -53,3 +53,25 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     else:
         data = build_down2(indices, batch_size, spatial_shape, ksize, stride, padding, dilation)
     return data.outids, data.indice_pairs, data.indice_pair_num
+
+
+def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", first_level=1):
+    """Build every rulebook of an n-level U-Net up front and store it in `tensor.indice_dict`
+    (SubM k3 under subm_key % i, k2s2 under down_key % i), so the convolutions find them cached.
+    Rulebooks depend only on the voxel indices; building them before any feature kernel is queued
+    means the size read-backs of the strided levels wait on an almost empty stream instead of
+    stalling the host in the middle of the forward pass."""
+    indices, shape = tensor.indices, tensor.spatial_shape
+    for lvl in range(first_level, first_level + n_levels):
+        key = subm_key % lvl
+        if key not in tensor.indice_dict:
+            tensor.indice_dict[key] = build_subm(indices, tensor.batch_size, shape, 3)
+        if lvl == first_level + n_levels - 1:
+            break
+        key = down_key % lvl
+        data = tensor.indice_dict.get(key)
+        if data is None:
+            data = build_down2(indices, tensor.batch_size, shape, 2, 2, 0, 1)
+            tensor.indice_dict[key] = data
+        indices, shape = data.outids, data.out_spatial_shape
+    return tensor.indice_dict

@@ -146,6 +146,18 @@ int doda_rulebook_pairs(const int32_t *tbl, int32_t ld, int32_t K, int32_t n_row
  * re-laid-out in MFMA fragment order by a pre-pack kernel inside the call.  K <= 27.
  * ---------------------------------------------------------------------------------------- */
 size_t doda_spconv_gather_workspace_bytes(int32_t K, int32_t kc, int32_t nc, int32_t elem_bytes);
+
+/* Pre-packing many weight tensors in ONE launch (weights change once per optimizer step; a U-Net
+ * step otherwise issues 2 x 71 pack launches).  A descriptor is 8 bytes `w` (device, fp32),
+ * 8 bytes `out` (device, doda_spconv_gather_workspace_bytes each), then int32 K, kc, nc, layout
+ * (0..2), elem_bytes (2|4) and three int32 the planner fills (doda_spconv_pack_desc_bytes() bytes
+ * in all).  doda_spconv_pack_plan_h completes the host descriptors and the inclusive block prefix;
+ * the caller uploads both and calls doda_spconv_pack_multi.  A gather call then passes the packed
+ * buffer as `w` with w_layout | 0x100 (and may pass ws = NULL). */
+size_t doda_spconv_pack_desc_bytes(void);
+int doda_spconv_pack_plan_h(void *descs_h, int32_t n_desc, int32_t *blk_end_h, int32_t *total_blocks);
+int doda_spconv_pack_multi(const void *descs_dev, const int32_t *blk_end_dev, int32_t n_desc,
+                           int32_t total_blocks, doda_stream_t stream);
 int doda_spconv_gather_f32(const float *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
                            const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, float *y,
                            int32_t w_layout, void *ws, size_t ws_bytes, doda_stream_t stream);
