@@ -308,10 +308,25 @@ __device__ __forceinline__ u32x4 make_rsrc(const void *p, unsigned bytes) {
 }
 
 template <class T> struct RawIO;
+// Gathers: lanes whose row is absent (offset >= 2^31) are masked out of EXEC so the texture
+// addresser does not spend a cycle per absent 4-lane quad (PMC: the TA, not HBM, paces this kernel
+// and ~64 % of the lanes are absent); their destination is pre-zeroed.  Lane 0 always stays active:
+// a VMEM instruction whose EXEC is all-zero may not count in vmcnt, which would break the counted
+// waits of the ring.
 template <> struct RawIO<F32> {
     typedef u32x4 raw;
     static __device__ __forceinline__ void load(raw &dst, unsigned voff, const u32x4 &rs, unsigned soff) {
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff));
+    }
+    static __device__ __forceinline__ void gather(raw &dst, unsigned voff, const u32x4 &rs, unsigned soff) {
+        unsigned long long keep;
+        dst = (raw){0u, 0u, 0u, 0u};
+        asm volatile("v_cmp_lt_i32 vcc, -1, %2\n\t"
+                     "s_or_b64 vcc, vcc, 1\n\t"
+                     "s_and_saveexec_b64 %1, vcc\n\t"
+                     "buffer_load_dwordx4 %0, %2, %3, %4 offen\n\t"
+                     "s_mov_b64 exec, %1"
+                     : "+v"(dst), "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff) : "vcc");
     }
     static __device__ __forceinline__ void store(const f32x4 &v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
@@ -322,6 +337,16 @@ template <> struct RawIO<BF16> {
     typedef u32x2 raw;
     static __device__ __forceinline__ void load(raw &dst, unsigned voff, const u32x4 &rs, unsigned soff) {
         asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff));
+    }
+    static __device__ __forceinline__ void gather(raw &dst, unsigned voff, const u32x4 &rs, unsigned soff) {
+        unsigned long long keep;
+        dst = (raw){0u, 0u};
+        asm volatile("v_cmp_lt_i32 vcc, -1, %2\n\t"
+                     "s_or_b64 vcc, vcc, 1\n\t"
+                     "s_and_saveexec_b64 %1, vcc\n\t"
+                     "buffer_load_dwordx2 %0, %2, %3, %4 offen\n\t"
+                     "s_mov_b64 exec, %1"
+                     : "+v"(dst), "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff) : "vcc");
     }
     static __device__ __forceinline__ void store(const f32x4 &v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
         s16x4 o;
@@ -427,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_fast(const typename T::elem *__restr
             const unsigned *p = my_off + (have ? o : MAX_K) * RW;
             const unsigned soff_x = (unsigned)cc * 16u * ESZ;
 #pragma unroll
-            for (int s = 0; s < S; ++s) RawIO<T>::load(xr[s], p[s * 16] + lane_x, rs_x, soff_x);
+            for (int s = 0; s < S; ++s) RawIO<T>::gather(xr[s], p[s * 16] + lane_x, rs_x, soff_x);
             const unsigned soff_w = (unsigned)((o * n_chunk + cc) * NB + nb0) * 64u * FSZ;
             const unsigned voff_w = have ? lane_w : OOB;
 #pragma unroll
@@ -571,8 +596,7 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     if (NB == 1 && force_s == 1) GO(1, 1);
     if (NB == 2 && force_s == 2) GO(2, 2);
     if (NB == 2 && force_s == 1) GO(2, 1);
-    if (NB == 1) {
-        if (waves_full >= 16384) GO(1, 4);
+    if (NB == 1) {  // measured at M = 600k, 16 ch: S=2 51 us, S=4 56 us, S=1 56 us
         if (waves_full >= 4096) GO(1, 2);
         GO(1, 1);
     }
