@@ -249,6 +249,133 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply(const typename T::elem 
     }
 }
 
+// ---- small-M variants: ONE launch per direction --------------------------------------------------
+// Deep U-Net levels have a few hundred to ~10k rows; three launches per BN pass are then pure
+// launch-floor time.  Here a block owns one 4-channel fragment column over ALL rows, so the
+// statistics need no cross-block step: sweep 1 reduces, sweep 2 applies (rows stay in L2).
+constexpr int BN_SMALL_ROWS = 16384;
+
+__device__ __forceinline__ f32x4 block_sum4(f32x4 v, float (*lds)[4]) {  // 256 threads, fixed order
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += __shfl_xor(v[q], d, 64);
+    }
+    const int wid = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lds[wid][q] = v[q];
+    }
+    __syncthreads();
+    f32x4 t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = (lds[0][q] + lds[1][q]) + (lds[2][q] + lds[3][q]);
+    return t;
+}
+
+template <class T>
+__global__ __launch_bounds__(BN_BLOCK) void bn_small_fwd(const typename T::elem *__restrict__ x, int m,
+                                                         int c, float eps, float momentum,
+                                                         const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta,
+                                                         float *__restrict__ running_mean,
+                                                         float *__restrict__ running_var,
+                                                         long long *__restrict__ nbt, int relu,
+                                                         typename T::elem *__restrict__ y,
+                                                         float *__restrict__ mean,
+                                                         float *__restrict__ invstd) {
+    __shared__ float lds[4][4];
+    const int f = blockIdx.x;
+    const f32x4 k = T::load4(x + f * 4);
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    for (int r = threadIdx.x; r < m; r += BN_BLOCK) {
+        const f32x4 v = T::load4(x + (long long)r * c + f * 4) - k;
+        s1 += v;
+        s2 += v * v;
+    }
+    s1 = block_sum4(s1, lds);
+    s2 = block_sum4(s2, lds);
+    f32x4 mu, is;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double d = (double)s1[q] / m;
+        double var = (double)s2[q] / m - d * d;
+        if (var < 0.0) var = 0.0;
+        mu[q] = (float)((double)k[q] + d);
+        is[q] = (float)(1.0 / sqrt(var + (double)eps));
+        if (threadIdx.x == 0) {
+            mean[f * 4 + q] = mu[q];
+            invstd[f * 4 + q] = is[q];
+            if (running_mean) {
+                const double unbiased = m > 1 ? var * (double)m / (double)(m - 1) : var;
+                running_mean[f * 4 + q] = (float)((1.0 - momentum) * (double)running_mean[f * 4 + q] + momentum * ((double)k[q] + d));
+                running_var[f * 4 + q] = (float)((1.0 - momentum) * (double)running_var[f * 4 + q] + momentum * unbiased);
+            }
+        }
+    }
+    if (threadIdx.x == 0 && f == 0 && nbt) *nbt += 1;
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
+    const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + f * 4);
+    for (int r = threadIdx.x; r < m; r += BN_BLOCK) {
+        const f32x4 v = T::load4(x + (long long)r * c + f * 4);
+        f32x4 o = (v - mu) * is * ga + be;
+        if (relu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = o[q] > 0.f ? o[q] : 0.f;
+        }
+        T::store4(y + (long long)r * c + f * 4, o);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd(const typename T::elem *__restrict__ x,
+                                                         const typename T::elem *__restrict__ dy,
+                                                         int m, int c, const float *__restrict__ mean,
+                                                         const float *__restrict__ invstd,
+                                                         const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, int relu,
+                                                         typename T::elem *__restrict__ dx,
+                                                         float *__restrict__ dgamma,
+                                                         float *__restrict__ dbeta) {
+    __shared__ float lds[4][4];
+    const int f = blockIdx.x;
+    const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + f * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + f * 4);
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
+    const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + f * 4);
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    for (int r = threadIdx.x; r < m; r += BN_BLOCK) {
+        const f32x4 xh = (T::load4(x + (long long)r * c + f * 4) - mu) * is;
+        f32x4 dz = T::load4(dy + (long long)r * c + f * 4);
+        if (relu) {
+            const f32x4 yv = xh * ga + be;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dz[q] = yv[q] > 0.f ? dz[q] : 0.f;
+        }
+        s1 += dz;
+        s2 += dz * xh;
+    }
+    s1 = block_sum4(s1, lds);
+    s2 = block_sum4(s2, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { dbeta[f * 4 + q] = s1[q]; dgamma[f * 4 + q] = s2[q]; }
+    }
+    const float inv_m = 1.f / (float)m;
+    const f32x4 a = ga * is, b = s1 * inv_m, d = s2 * inv_m;
+    for (int r = threadIdx.x; r < m; r += BN_BLOCK) {
+        const f32x4 xh = (T::load4(x + (long long)r * c + f * 4) - mu) * is;
+        f32x4 dz = T::load4(dy + (long long)r * c + f * 4);
+        if (relu) {
+            const f32x4 yv = xh * ga + be;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dz[q] = yv[q] > 0.f ? dz[q] : 0.f;
+        }
+        T::store4(dx + (long long)r * c + f * 4, a * (dz - b - xh * d));
+    }
+}
+
 Geo make_geo(int c) {
     Geo g;
     g.nf = c / 4;
@@ -272,6 +399,11 @@ int run_fwd(const void *x_, int m, int c, float eps, float momentum, const float
     const elem *x = (const elem *)x_;
     elem *y = (elem *)y_;
     const Geo g = make_geo(c);
+    if (training && m <= BN_SMALL_ROWS) {
+        hipLaunchKernelGGL((bn_small_fwd<T>), dim3(c / 4), dim3(BN_BLOCK), 0, s, x, m, c, eps, momentum,
+                           gamma, beta, running_mean, running_var, nbt, relu, y, mean, invstd);
+        return doda_check_launch();
+    }
     if (training) {
         const int nb = n_blocks_for(m, g);
         if (ws_bytes < (size_t)nb * 2 * c * 4) return DODA_ERR_WORKSPACE;
@@ -296,6 +428,11 @@ int run_bwd(const void *x_, const void *dy_, int m, int c, const float *mean, co
     const elem *x = (const elem *)x_, *dy = (const elem *)dy_;
     elem *dx = (elem *)dx_;
     const Geo g = make_geo(c);
+    if (m <= BN_SMALL_ROWS) {
+        hipLaunchKernelGGL((bn_small_bwd<T>), dim3(c / 4), dim3(BN_BLOCK), 0, s, x, dy, m, c, mean, invstd,
+                           gamma, beta, relu, dx, dgamma, dbeta);
+        return doda_check_launch();
+    }
     const int nb = n_blocks_for(m, g);
     if (ws_bytes < (size_t)nb * 2 * c * 4 + (size_t)3 * c * 4) return DODA_ERR_WORKSPACE;
     float *partial = (float *)ws;

@@ -324,8 +324,12 @@ def test_bn_relu_matches_torch(native_lib, c, relu, dtype):
     """doda_amd.nn against torch.nn.BatchNorm1d(+ReLU) evaluated in fp64 (training and eval)."""
     from doda_amd import nn as dnn
     torch.manual_seed(c)
-    m = 5000 + c
     d = dev()
+    for m in (5000 + c, 40000 + c):   # single-launch small-M kernels and the multi-block path
+        _check_bn(dnn, m, c, relu, dtype, d)
+
+
+def _check_bn(dnn, m, c, relu, dtype, d):
     x = (torch.randn(m, c, device=d) * 1.7 + 3.0).to(dtype)       # non-zero mean: exercises the shift
     gy = torch.randn(m, c, device=d).to(dtype)
     ref = torch.nn.BatchNorm1d(c, eps=1e-4, momentum=0.1).to(d).double()
@@ -336,16 +340,19 @@ def test_bn_relu_matches_torch(native_lib, c, relu, dtype):
     tol = 1e-4 if dtype == torch.float32 else 2e-2
     for training in (True, False):
         ref.train(training); mine.train(training)
-        xr = x.double().requires_grad_(True)
-        yr = ref(xr)
-        if relu:
-            yr = torch.relu(yr)
-        yr.backward(gy.double())
         xm = x.clone().requires_grad_(True)
         assert dnn.fusable(mine, xm)
         ym = dnn.batch_norm_relu(xm, mine, relu)
         ym.backward(gy)
-        assert rel_err(ym.detach().float().cpu(), yr.detach().cpu()) < tol
+        xr = x.double().requires_grad_(True)
+        yr = ref(xr)
+        assert rel_err(ym.detach().float().cpu(), (torch.relu(yr) if relu else yr).detach().cpu()) < tol
+        if relu:
+            # backward reference uses the kernel's own activation pattern: the mask is recomputed in
+            # fp32, so a pre-activation within rounding of 0 may legitimately fall on the other side
+            # than in fp64 (a few of 4.5 M elements), which would otherwise dominate max-norm errors
+            yr = yr * (ym.detach() > 0).double()
+        yr.backward(gy.double())
         assert rel_err(xm.grad.float().cpu(), xr.grad.cpu()) < tol
         assert rel_err(mine.weight.grad.cpu(), ref.weight.grad.cpu()) < tol
         assert rel_err(mine.bias.grad.cpu(), ref.bias.grad.cpu()) < tol
