@@ -28,6 +28,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -98,6 +99,42 @@ __global__ __launch_bounds__(256) void pack_weights(const float *__restrict__ w,
     packed[e] = v;
 }
 
+// wide bf16 packing (PBF16W): packed[o][cc32][nb][lane] = 8 bf16 { B_o[cc*32 + 8g + q][nb*16 + i] }
+__device__ __forceinline__ u32x4_t pack_wide_frag(const float *__restrict__ w, int K, int kc, int nc,
+                                                  int wl, int o, int cc, int nb, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int col = nb * 16 + i;
+    unsigned short h[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = cc * 32 + 8 * g + q;
+        float f = 0.f;
+        if (c < kc && col < nc) {
+            if (wl == 0) f = w[((long long)o * kc + c) * nc + col];
+            else f = w[((long long)(wl == 2 ? K - 1 - o : o) * nc + col) * kc + c];
+        }
+        h[q] = f2bf(f);
+    }
+    u32x4_t r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = (unsigned)h[2 * q] | ((unsigned)h[2 * q + 1] << 16);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void pack_weights_wide(const float *__restrict__ w, int K, int kc,
+                                                         int nc, int n_chunk, int NB, int wl,
+                                                         u32x4_t *__restrict__ packed) {
+    const long long total = (long long)K * n_chunk * NB * 64;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int lane = (int)(e & 63);
+    long long r = e >> 6;
+    const int nb = (int)(r % NB); r /= NB;
+    const int cc = (int)(r % n_chunk);
+    const int o = (int)(r / n_chunk);
+    packed[e] = pack_wide_frag(w, K, kc, nc, wl, o, cc, nb, lane);
+}
+
 // One launch for many weight tensors (all layers of a network, both layouts): block b looks up its
 // descriptor through the inclusive block prefix `blk_end`.
 struct PackDesc {
@@ -121,8 +158,8 @@ __device__ __forceinline__ void pack_one(const PackDesc &d, long long e) {
         const int c = cc * 16 + 4 * g + q;
         float f = 0.f;
         if (c < d.kc && col < d.nc) {
-            if (d.layout == 0) f = d.w[((long long)o * d.kc + c) * d.nc + col];
-            else f = d.w[((long long)(d.layout == 2 ? d.K - 1 - o : o) * d.nc + col) * d.kc + c];
+            if ((d.layout & 3) == 0) f = d.w[((long long)o * d.kc + c) * d.nc + col];
+            else f = d.w[((long long)((d.layout & 3) == 2 ? d.K - 1 - o : o) * d.nc + col) * d.kc + c];
         }
         v[q] = T::from_float(f);
     }
@@ -141,7 +178,14 @@ __global__ __launch_bounds__(256) void pack_weights_multi(const PackDesc *__rest
     const long long e = (long long)(blockIdx.x - first) * 256 + threadIdx.x;
     const long long total = (long long)d.K * d.n_chunk * d.NB * 64;
     if (e >= total) return;
-    if (d.elem_bytes == 4) pack_one<F32>(d, e); else pack_one<BF16>(d, e);
+    if (d.layout & 0x10) {  // wide bf16 fragments
+        long long r = e >> 6;
+        const int nb = (int)(r % d.NB); r /= d.NB;
+        const int cc = (int)(r % d.n_chunk);
+        reinterpret_cast<u32x4_t *>(d.out)[e] =
+            pack_wide_frag(d.w, d.K, d.kc, d.nc, d.layout & 3, (int)(r / d.n_chunk), cc, nb, (int)(e & 63));
+    } else if (d.elem_bytes == 4) pack_one<F32>(d, e);
+    else pack_one<BF16>(d, e);
 }
 
 constexpr int MAX_K = 27;
@@ -307,55 +351,78 @@ __device__ __forceinline__ u32x4 make_rsrc(const void *p, unsigned bytes) {
     return r;
 }
 
-template <class T> struct RawIO;
+// Per-mode policy of the fast kernel.  CH = input channels per (offset, chunk) unit; every lane
+// owns a quarter of the unit's bytes (FSZ = sizeof(raw)).
+//   PF32 : fp32 features, 16 channels per unit, 4 x v_mfma_f32_16x16x4_f32
+//   PBF16: bf16 features, 16 channels per unit, v_mfma_f32_16x16x16_bf16  (8-byte lane loads)
+//   PBF16W: bf16 features, 32 channels per unit, v_mfma_f32_16x16x32_bf16 (16-byte lane loads):
+//          half the gathers, weight loads and MFMAs per channel — these kernels are paced by
+//          the NUMBER of 64-lane memory instructions through the per-CU texture path.
 // Gathers: lanes whose row is absent (offset >= 2^31) are masked out of EXEC so the texture
-// addresser does not spend a cycle per absent 4-lane quad (PMC: the TA, not HBM, paces this kernel
-// and ~64 % of the lanes are absent); their destination is pre-zeroed.  Lane 0 always stays active:
-// a VMEM instruction whose EXEC is all-zero may not count in vmcnt, which would break the counted
-// waits of the ring.
-template <> struct RawIO<F32> {
+// addresser does not spend a cycle per absent 4-lane quad; their destination is pre-zeroed.
+// Lane 0 always stays active: a VMEM instruction whose EXEC is all-zero may not count in vmcnt,
+// which would break the counted waits of the ring.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define DODA_ASM_LOAD(INSTR)                                                                       \
+    static __device__ __forceinline__ void load(raw &dst, unsigned voff, const u32x4 &rs, unsigned soff) { \
+        asm volatile(INSTR " %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff));   \
+    }                                                                                              \
+    static __device__ __forceinline__ void gather(raw &dst, unsigned voff, const u32x4 &rs, unsigned soff) { \
+        unsigned long long keep;                                                                   \
+        dst = raw{};                                                                               \
+        asm volatile("v_cmp_lt_i32 vcc, -1, %2\n\t"                                                \
+                     "s_or_b64 vcc, vcc, 1\n\t"                                                    \
+                     "s_and_saveexec_b64 %1, vcc\n\t" INSTR " %0, %2, %3, %4 offen\n\t"            \
+                     "s_mov_b64 exec, %1"                                                          \
+                     : "+v"(dst), "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff) : "vcc");            \
+    }
+
+struct PF32 {
+    typedef float elem;
     typedef u32x4 raw;
-    static __device__ __forceinline__ void load(raw &dst, unsigned voff, const u32x4 &rs, unsigned soff) {
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff));
+    typedef F32 pack;  // weight pre-pack flavour
+    static constexpr int CH = 16;
+    DODA_ASM_LOAD("buffer_load_dwordx4")
+    static __device__ __forceinline__ void mma(f32x4 &acc, const raw &w, const raw &x) {
+        const f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q], xf[q], acc, 0, 0, 0);
     }
-    static __device__ __forceinline__ void gather(raw &dst, unsigned voff, const u32x4 &rs, unsigned soff) {
-        unsigned long long keep;
-        dst = (raw){0u, 0u, 0u, 0u};
-        asm volatile("v_cmp_lt_i32 vcc, -1, %2\n\t"
-                     "s_or_b64 vcc, vcc, 1\n\t"
-                     "s_and_saveexec_b64 %1, vcc\n\t"
-                     "buffer_load_dwordx4 %0, %2, %3, %4 offen\n\t"
-                     "s_mov_b64 exec, %1"
-                     : "+v"(dst), "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff) : "vcc");
-    }
-    static __device__ __forceinline__ void store(const f32x4 &v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
-    }
-    static __device__ __forceinline__ f32x4 as_frag(const raw &r) { return __builtin_bit_cast(f32x4, r); }
 };
-template <> struct RawIO<BF16> {
+struct PBF16 {
+    typedef unsigned short elem;
     typedef u32x2 raw;
-    static __device__ __forceinline__ void load(raw &dst, unsigned voff, const u32x4 &rs, unsigned soff) {
-        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff));
+    typedef BF16 pack;
+    static constexpr int CH = 16;
+    DODA_ASM_LOAD("buffer_load_dwordx2")
+    static __device__ __forceinline__ void mma(f32x4 &acc, const raw &w, const raw &x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, w), __builtin_bit_cast(s16x4, x), acc, 0, 0, 0);
     }
-    static __device__ __forceinline__ void gather(raw &dst, unsigned voff, const u32x4 &rs, unsigned soff) {
-        unsigned long long keep;
-        dst = (raw){0u, 0u};
-        asm volatile("v_cmp_lt_i32 vcc, -1, %2\n\t"
-                     "s_or_b64 vcc, vcc, 1\n\t"
-                     "s_and_saveexec_b64 %1, vcc\n\t"
-                     "buffer_load_dwordx2 %0, %2, %3, %4 offen\n\t"
-                     "s_mov_b64 exec, %1"
-                     : "+v"(dst), "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff) : "vcc");
+};
+struct PBF16W {
+    typedef unsigned short elem;
+    typedef u32x4 raw;
+    typedef BF16 pack;
+    static constexpr int CH = 32;
+    DODA_ASM_LOAD("buffer_load_dwordx4")
+    static __device__ __forceinline__ void mma(f32x4 &acc, const raw &w, const raw &x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
     }
-    static __device__ __forceinline__ void store(const f32x4 &v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+};
+
+// one wide output store: lane holds 4 consecutive channels of one row
+template <class P, bool OUT32>
+__device__ __forceinline__ void store_frag(const f32x4 &v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+    if (OUT32 || sizeof(typename P::elem) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+    } else {
         s16x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = (short)f2bf(v[q]);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), r, voff, 0, 0);
     }
-    static __device__ __forceinline__ s16x4 as_frag(const raw &r) { return __builtin_bit_cast(s16x4, r); }
-};
+}
 
 // wait until at most N of the asm-issued loads are outstanding; `first` (and every register passed
 // to touch() right after) is marked as written here so no consumer can be scheduled above it
@@ -368,23 +435,23 @@ __device__ __forceinline__ void touch(R &r) {
     asm volatile("" : "+v"(r));
 }
 
-template <class T, int NBW, int S, int D, bool OUT32>
-__global__ __launch_bounds__(256) void conv_fast(const typename T::elem *__restrict__ x,
+template <class P, int NBW, int S, int D, bool OUT32>
+__global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restrict__ x,
                                                  unsigned x_bytes, int kc,
-                                                 const typename T::frag *__restrict__ wp,
+                                                 const void *__restrict__ wp,
                                                  unsigned wp_bytes, int nc, int NB,
                                                  const int32_t *__restrict__ tbl,
                                                  unsigned tbl_bytes, int ld, int K, int n_out,
                                                  void *__restrict__ y, unsigned y_bytes) {
-    typedef typename T::frag frag;
-    typedef typename T::elem elem;
-    typedef typename RawIO<T>::raw raw;
+    typedef typename P::elem elem;
+    typedef typename P::raw raw;
     constexpr unsigned OSZ = OUT32 ? 4u : (unsigned)sizeof(elem);   // output element size
     constexpr int RW = 16 * S;                 // rows per wave
     constexpr int OPI = 64 / RW;               // table offsets fetched per load instruction
     constexpr int NLD = (MAX_K + 1 + OPI - 1) / OPI;  // strips 0..MAX_K; strip MAX_K is all-OOB
     constexpr int L = S + NBW;                 // asm loads per unit
-    constexpr unsigned ESZ = sizeof(elem), FSZ = sizeof(frag);
+    constexpr unsigned ESZ = sizeof(elem), FSZ = sizeof(raw);
+    constexpr int CH = P::CH;
     static_assert((D - 1) * L <= 63, "vmcnt field");
     __shared__ unsigned off_tile[4][NLD * 64];
 
@@ -430,9 +497,9 @@ __global__ __launch_bounds__(256) void conv_fast(const typename T::elem *__restr
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) acc[s][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int n_chunk = (kc + 15) >> 4;   // a partial last chunk reads past the row end: those
-                                          // channels meet zero weights (pack_weights guards c < kc)
-    const unsigned lane_x = (unsigned)g * FSZ;       // this lane's channel quad inside a 16-ch chunk
+    const int n_chunk = (kc + CH - 1) / CH;
+    const unsigned lane_x = (unsigned)g * FSZ;       // this lane's quarter of a unit's channels
+    const int lane_c = g * (CH / 4);                 // its first channel inside the unit
     const unsigned lane_w = (unsigned)lane * FSZ;    // this lane's slot inside a packed W fragment
     const unsigned *my_off = &off_tile[wid][i];
 
@@ -449,14 +516,16 @@ __global__ __launch_bounds__(256) void conv_fast(const typename T::elem *__restr
         int to_issue = n_units;
 
         auto issue = [&](raw (&xr)[S], raw (&wr)[NBW]) {
-            const unsigned *p = my_off + (have ? o : MAX_K) * RW;
-            const unsigned soff_x = (unsigned)cc * 16u * ESZ;
+            // a lane whose channels lie past kc (partial last chunk) fetches the all-absent strip
+            const bool lane_ok = have && (cc * CH + lane_c < kc);
+            const unsigned *p = my_off + (lane_ok ? o : MAX_K) * RW;
+            const unsigned soff_x = (unsigned)cc * (unsigned)CH * ESZ;
 #pragma unroll
-            for (int s = 0; s < S; ++s) RawIO<T>::gather(xr[s], p[s * 16] + lane_x, rs_x, soff_x);
+            for (int s = 0; s < S; ++s) P::gather(xr[s], p[s * 16] + lane_x, rs_x, soff_x);
             const unsigned soff_w = (unsigned)((o * n_chunk + cc) * NB + nb0) * 64u * FSZ;
             const unsigned voff_w = have ? lane_w : OOB;
 #pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) RawIO<T>::load(wr[nb], voff_w, rs_w, soff_w + nb * 64u * FSZ);
+            for (int nb = 0; nb < NBW; ++nb) P::load(wr[nb], voff_w, rs_w, soff_w + nb * 64u * FSZ);
             if (have) {
                 --to_issue;
                 if (++cc == n_chunk) {
@@ -475,7 +544,7 @@ __global__ __launch_bounds__(256) void conv_fast(const typename T::elem *__restr
             for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
                 for (int s = 0; s < S; ++s)
-                    T::mma(acc[s][nb], RawIO<T>::as_frag(wr[nb]), RawIO<T>::as_frag(xr[s]));
+                    P::mma(acc[s][nb], wr[nb], xr[s]);
         };
 
 #pragma unroll
@@ -514,27 +583,26 @@ __global__ __launch_bounds__(256) void conv_fast(const typename T::elem *__restr
         for (int nb = 0; nb < NBW; ++nb) {
             const unsigned col = (unsigned)((nb0 + nb) * 16 + 4 * g);
             const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * (unsigned)nc + col) * OSZ : OOB;
-            if (OUT32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[s][nb]), rs_y, voff, 0, 0);
-            else RawIO<T>::store(acc[s][nb], rs_y, voff);
+            store_frag<P, OUT32>(acc[s][nb], rs_y, voff);
         }
     }
 }
 
-template <class T, int NBW, int S>
-int launch_fast(const typename T::elem *x, int kc, const typename T::frag *wp, size_t wp_bytes,
-                int nc, int NB, const int32_t *tbl, int ld, int K, int n_out, long long n_in,
-                void *y, bool out32, hipStream_t s) {
+template <class P, int NBW, int S>
+int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_bytes, int nc, int NB,
+                const int32_t *tbl, int ld, int K, int n_out, long long n_in, void *y, bool out32,
+                hipStream_t s) {
     const dim3 grid(div_up(n_out, 4 * 16 * S) * div_up(NB, NBW)), block(256);
     constexpr int D = (S + NBW <= 3) ? 8 : ((S + NBW <= 5) ? 6 : ((S + NBW <= 6) ? 4 : 3));
-    const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(typename T::elem));
+    const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(typename P::elem));
     const unsigned tb = (unsigned)((size_t)K * ld * 4);
-    if (out32 && sizeof(typename T::elem) != 4) {
+    if (out32 && sizeof(typename P::elem) != 4) {
         const unsigned yb = (unsigned)((size_t)n_out * nc * 4);
-        hipLaunchKernelGGL((conv_fast<T, NBW, S, D, true>), grid, block, 0, s, x, xb, kc, wp,
+        hipLaunchKernelGGL((conv_fast<P, NBW, S, D, true>), grid, block, 0, s, x, xb, kc, wp,
                            (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb);
     } else {
-        const unsigned yb = (unsigned)((size_t)n_out * nc * sizeof(typename T::elem));
-        hipLaunchKernelGGL((conv_fast<T, NBW, S, D, false>), grid, block, 0, s, x, xb, kc, wp,
+        const unsigned yb = (unsigned)((size_t)n_out * nc * sizeof(typename P::elem));
+        hipLaunchKernelGGL((conv_fast<P, NBW, S, D, false>), grid, block, 0, s, x, xb, kc, wp,
                            (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb);
     }
     return doda_check_launch();
@@ -550,6 +618,10 @@ int launch(const typename T::elem *x, int kc, const typename T::frag *wp, int nc
     return doda_check_launch();
 }
 
+template <class T> struct FastPolicy;
+template <> struct FastPolicy<F32> { typedef PF32 narrow; typedef PF32 wide; };
+template <> struct FastPolicy<BF16> { typedef PBF16 narrow; typedef PBF16W wide; };
+
 template <class T>
 int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tbl, int ld, int K,
                int n_out, void *y_, int wl, void *ws, size_t ws_bytes, long long n_in, bool out32,
@@ -558,37 +630,46 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     typedef typename T::frag frag;
     const elem *x = (const elem *)x_;
     elem *y = (elem *)y_;
-    const int n_chunk = (kc + 15) / 16, NB = (nc + 15) / 16;
-    const size_t need = (size_t)K * n_chunk * NB * 64 * sizeof(frag);
-    frag *wp;
-    if (wl & 0x100) {  // `w` already holds the fragment-packed weights (doda_spconv_pack_multi)
-        wp = (frag *)(const void *)w;
-    } else {
-        if (!ws || ws_bytes < need) return DODA_ERR_WORKSPACE;
-        wp = (frag *)ws;
-        const long long total = (long long)K * n_chunk * NB * 64;
-        hipLaunchKernelGGL((pack_weights<T>), dim3(div_up(total, 256)), dim3(256), 0, s, w, K, kc, nc,
-                           n_chunk, NB, wl, wp);
-    }
+    const int NB = (nc + 15) / 16;
     // all rows the table may reference must sit inside the 2 GB buffer window of the fast path
     const bool x_rows_bytes_ok = n_in > 0 && (size_t)n_in * kc * sizeof(elem) < 0x7ffffff0ull;
     const size_t va = 4 * sizeof(elem);  // vector access granule
     const int vec_ok = (kc % 4 == 0) && (nc % 4 == 0) && ((uintptr_t)x % va == 0) &&
                        ((uintptr_t)y % va == 0);
-    // Tile choice: many rows -> more subtiles per wave and all channel blocks in one wave (x is
-    // gathered once); few rows -> one subtile, channel blocks spread over blockIdx.y so the chip
-    // still sees thousands of waves.
-    const long long waves_full = ((long long)n_out + 15) / 16;
-    // x_bytes: the table only references rows that exist, so the buffer bound just has to keep a
-    // present row in range and an absent one (offset 2^31) out: use the 2 GB window.
     const bool fast = (kc % 4 == 0) && (nc % 4 == 0) && ((uintptr_t)x % 16 == 0) &&
                       ((uintptr_t)y % 16 == 0) && ((size_t)n_out * nc * 4 < 0x7fffffffull) &&
                       ((size_t)K * ld * 4 < 0xffffffffull) && x_rows_bytes_ok;
     if (out32 && sizeof(elem) != 4 && !fast) return DODA_ERR_UNSUPPORTED;
+    // bf16 with >= 32 input channels: 32-channel units (16-byte lane loads, 16x16x32 MFMA)
+    const bool wide = fast && sizeof(elem) == 2 && (kc % 8 == 0) && kc >= 32;
+    const int n_chunk = wide ? (kc + 31) / 32 : (kc + 15) / 16;
+    const size_t need = (size_t)K * n_chunk * NB * 64 * (wide ? 16 : sizeof(frag));
+    const void *wp;
+    if (wl & 0x100) {  // `w` already holds fragment-packed weights (doda_spconv_pack_multi)
+        if (((wl & 0x10) != 0) != wide) return DODA_ERR_UNSUPPORTED;  // packed for the other mode
+        wp = (const void *)w;
+    } else {
+        if (!ws || ws_bytes < need) return DODA_ERR_WORKSPACE;
+        wp = ws;
+        const long long total = (long long)K * n_chunk * NB * 64;
+        if (wide)
+            hipLaunchKernelGGL(pack_weights_wide, dim3(div_up(total, 256)), dim3(256), 0, s, w, K, kc, nc,
+                               n_chunk, NB, wl & 3, (u32x4_t *)ws);
+        else
+            hipLaunchKernelGGL((pack_weights<T>), dim3(div_up(total, 256)), dim3(256), 0, s, w, K, kc,
+                               nc, n_chunk, NB, wl & 3, (frag *)ws);
+    }
+    // Tile choice: many rows -> more subtiles per wave and all channel blocks in one wave (x is
+    // gathered once); few rows -> one subtile, channel blocks spread over the grid so the chip
+    // still sees thousands of waves.
+    const long long waves_full = ((long long)n_out + 15) / 16;
+    typedef typename FastPolicy<T>::narrow PN;
+    typedef typename FastPolicy<T>::wide PW;
 #define GO(NBW, S)                                                                                 \
     do {                                                                                           \
-        if (fast) return launch_fast<T, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
-        return launch<T, NBW, S>(x, kc, wp, nc, NB, tbl, ld, K, n_out, y, vec_ok, s);              \
+        if (wide) return launch_fast<PW, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
+        if (fast) return launch_fast<PN, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
+        return launch<T, NBW, S>(x, kc, (const frag *)wp, nc, NB, tbl, ld, K, n_out, y, vec_ok, s); \
     } while (0)
     static const int force_s = getenv("DODA_S") ? atoi(getenv("DODA_S")) : 0;
     if (NB == 1 && force_s == 4) GO(1, 4);
@@ -620,7 +701,7 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
 
 bool bad_args(const void *x, int kc, const float *w, int nc, const int32_t *tbl, int ld, int K,
               int n_out, const void *y, int wl, int *status) {
-    if (kc <= 0 || nc <= 0 || K <= 0 || n_out < 0 || ld < n_out || (wl & 0xff) > 2 || (wl & ~0x1ff)) {
+    if (kc <= 0 || nc <= 0 || K <= 0 || n_out < 0 || ld < n_out || (wl & 3) > 2 || (wl & ~0x113)) {
         *status = DODA_ERR_INVALID;
         return true;
     }
@@ -634,6 +715,8 @@ bool bad_args(const void *x, int kc, const float *w, int nc, const int32_t *tbl,
 extern "C" size_t doda_spconv_gather_workspace_bytes(int32_t K, int32_t kc, int32_t nc,
                                                      int32_t elem_bytes) {
     if (K <= 0 || kc <= 0 || nc <= 0) return 0;
+    if (elem_bytes == 2)  // covers both the 16-channel (8 B) and the 32-channel (16 B) fragment packing
+        return align_up((size_t)K * ((kc + 31) / 32) * ((nc + 15) / 16) * 64 * 16, 256);
     return align_up((size_t)K * ((kc + 15) / 16) * ((nc + 15) / 16) * 64 * 4 * (size_t)elem_bytes, 256);
 }
 
@@ -647,10 +730,11 @@ extern "C" int doda_spconv_pack_plan_h(void *descs_h, int32_t n_desc, int32_t *b
     PackDesc *d = (PackDesc *)descs_h;
     long long acc = 0;
     for (int k = 0; k < n_desc; ++k) {
-        if (d[k].K <= 0 || d[k].K > MAX_K || d[k].kc <= 0 || d[k].nc <= 0 || d[k].layout < 0 ||
-            d[k].layout > 2 || (d[k].elem_bytes != 2 && d[k].elem_bytes != 4))
+        if (d[k].K <= 0 || d[k].K > MAX_K || d[k].kc <= 0 || d[k].nc <= 0 || (d[k].layout & ~0x13) ||
+            (d[k].layout & 3) > 2 || (d[k].elem_bytes != 2 && d[k].elem_bytes != 4) ||
+            ((d[k].layout & 0x10) && d[k].elem_bytes != 2))
             return DODA_ERR_INVALID;
-        d[k].n_chunk = (d[k].kc + 15) / 16;
+        d[k].n_chunk = (d[k].layout & 0x10) ? (d[k].kc + 31) / 32 : (d[k].kc + 15) / 16;
         d[k].NB = (d[k].nc + 15) / 16;
         acc += div_up((long long)d[k].K * d[k].n_chunk * d[k].NB * 64, 256);
         if (acc > 0x7fffffff) return DODA_ERR_UNSUPPORTED;

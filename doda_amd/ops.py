@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import check, lib
+from ._lib import DodaNativeError, check, lib  # noqa: F401
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -225,7 +225,8 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None):
         need = lib().doda_spconv_gather_workspace_bytes(K, kc, nc, esz)
         if packed.numel() * packed.element_size() < need - 255:
             raise RuntimeError("packed weight buffer too small")
-        w_ptr, ws_ptr, ws_n, layout = _p(packed), None, 0, int(w_layout) | 0x100
+        w_ptr, ws_ptr, ws_n = _p(packed), None, 0
+        layout = int(w_layout) | 0x100 | (0x10 if wide_packing(esz, kc) else 0)
     else:
         _need_cuda(w)
         w = w.contiguous()
@@ -246,6 +247,12 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None):
     else:
         raise RuntimeError("spconv_gather: unsupported feature dtype %s" % x.dtype)
     return y
+
+
+def wide_packing(elem_bytes, kc):
+    """True when the fast conv kernel uses 32-channel units (bf16, >= 32 input channels, kc % 8 == 0)
+    and therefore expects the wide fragment packing."""
+    return elem_bytes == 2 and kc >= 32 and kc % 8 == 0
 
 
 class PackPlan:
@@ -273,7 +280,8 @@ class PackPlan:
                               device=device)
             self.outputs.append(out)
             self._keep.append(w)
-            desc[k] = (w.data_ptr(), out.data_ptr(), K, kc, nc, layout, esz, 0, 0, 0)
+            desc[k] = (w.data_ptr(), out.data_ptr(), K, kc, nc,
+                       layout | (0x10 if wide_packing(esz, kc) else 0), esz, 0, 0, 0)
         blk_end = np.zeros(n, dtype=np.int32)
         total = C.c_int32()
         check(l.doda_spconv_pack_plan_h(desc.ctypes.data, n, blk_end.ctypes.data, C.byref(total)),

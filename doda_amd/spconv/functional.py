@@ -26,6 +26,17 @@ _SIDE = {}
 _SERIAL = os.environ.get("DODA_OVERLAP_BWD", "0") != "1"
 
 
+def _gather(x, w, tbl, n_out, layout, nc, packed):
+    """spconv_gather through the pre-packed weights; falls back to packing inside the call when the
+    native fast path refuses them (unaligned or > 2 GB feature matrices use the generic kernel)."""
+    if packed is not None:
+        try:
+            return _ops.spconv_gather(x, w, tbl, n_out, layout, nc, packed=packed)
+        except _ops.DodaNativeError:
+            pass
+    return _ops.spconv_gather(x, w, tbl, n_out, layout, nc)
+
+
 def _side_stream(device):
     s = _SIDE.get(device)
     if s is None:
@@ -57,7 +68,7 @@ class _IndiceConv(Function):
         ctx.save_for_backward(features, weight)
         pk_fwd, pk_bwd = packed if packed is not None else (None, None)
         ctx.tables = (fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_bwd)
-        return _ops.spconv_gather(features.contiguous(), w, fwd_tbl, n_out, 0, cout, packed=pk_fwd)
+        return _gather(features.contiguous(), w, fwd_tbl, n_out, 0, cout, pk_fwd)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -69,7 +80,7 @@ class _IndiceConv(Function):
         w = weight.reshape(K, cin, cout)
         d_feat, d_w = _backward_pair(
             ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-            lambda: _ops.spconv_gather(dy, w, bwd_tbl, features.shape[0], bwd_layout, cin, packed=pk_bwd),
+            lambda: _gather(dy, w, bwd_tbl, features.shape[0], bwd_layout, cin, pk_bwd),
             lambda: _ops.spconv_wgrad(features.contiguous(), dy, fwd_tbl, n_out).reshape(weight.shape).to(weight.dtype),
             dy.device)
         return d_feat, d_w, None, None, None, None, None
@@ -85,8 +96,8 @@ class _Conv1x1(Function):
         cin, cout = weight.shape[-2], weight.shape[-1]
         ctx.save_for_backward(features, weight, ident)
         pk_fwd, ctx.pk_bwd = packed if packed is not None else (None, None)
-        return _ops.spconv_gather(features.contiguous(), weight.reshape(1, cin, cout), ident,
-                                  features.shape[0], 0, cout, packed=pk_fwd)
+        return _gather(features.contiguous(), weight.reshape(1, cin, cout), ident, features.shape[0], 0,
+                       cout, pk_fwd)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -95,8 +106,7 @@ class _Conv1x1(Function):
         dy = grad_output.contiguous()
         d_feat, d_w = _backward_pair(
             ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-            lambda: _ops.spconv_gather(dy, weight.reshape(1, cin, cout), ident, features.shape[0], 1, cin,
-                                       packed=ctx.pk_bwd),
+            lambda: _gather(dy, weight.reshape(1, cin, cout), ident, features.shape[0], 1, cin, ctx.pk_bwd),
             lambda: _ops.spconv_wgrad(features.contiguous(), dy, ident, features.shape[0]).reshape(weight.shape).to(weight.dtype),
             dy.device)
         return d_feat, d_w, None, None
