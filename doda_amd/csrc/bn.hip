@@ -253,7 +253,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply(const typename T::elem 
 // Deep U-Net levels have a few hundred to ~10k rows; three launches per BN pass are then pure
 // launch-floor time.  Here a block owns one 4-channel fragment column over ALL rows, so the
 // statistics need no cross-block step: sweep 1 reduces, sweep 2 applies (rows stay in L2).
-constexpr int BN_SMALL_ROWS = 16384;
+constexpr int BN_SMALL_ROWS = 4096;   // measured: at ~11k rows the C/4 blocks of this form take up to 80 us
 
 __device__ __forceinline__ f32x4 block_sum4(f32x4 v, float (*lds)[4]) {  // 256 threads, fixed order
 #pragma unroll
