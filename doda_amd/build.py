@@ -72,5 +72,49 @@ def build_native(force=False, verbose=True):
     return LIB
 
 
+EXT_SRC = os.path.join(HERE, "csrc_ext", "doda_torch.cpp")
+EXT_LIB = os.path.join(HERE, "_doda_torch.so")
+
+
+def build_torch_ext(force=False, verbose=True):
+    """g++ the thin PyTorch-ROCm glue (host-only C++) against torch + libdoda_hip.so, in-tree."""
+    import sysconfig
+    import torch
+    if not os.path.exists(LIB):
+        build_native(verbose=verbose)
+    stamp_file = EXT_LIB + ".sha1"
+    h = hashlib.sha1()
+    for p in (EXT_SRC, os.path.join(HERE, "..", "include", "doda_hip.h")):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(torch.__version__.encode())
+    stamp = h.hexdigest()
+    if (not force and os.path.exists(EXT_LIB) and os.path.exists(stamp_file)
+            and open(stamp_file).read() == stamp):
+        if verbose:
+            print("[doda_amd.build] up to date:", EXT_LIB)
+        return EXT_LIB
+    ti = os.path.dirname(torch.__file__)
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_doda_torch",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % abi,
+           "-I" + os.path.join(ti, "include"), "-I" + os.path.join(ti, "include", "torch", "csrc", "api", "include"),
+           "-I/opt/rocm/include", "-I" + sysconfig.get_paths()["include"],
+           EXT_SRC, "-o", EXT_LIB,
+           "-L" + os.path.join(ti, "lib"), "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip",
+           "-ltorch_python", "-L" + HERE, "-l:libdoda_hip.so",
+           "-Wl,-rpath," + os.path.join(ti, "lib"), "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("torch extension build failed:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-6000:]))
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    if verbose:
+        print("[doda_amd.build] linked", EXT_LIB)
+    return EXT_LIB
+
+
 if __name__ == "__main__":
     build_native(force="--force" in sys.argv)
+    build_torch_ext(force="--force" in sys.argv)

@@ -1,0 +1,219 @@
+// Thin PyTorch-ROCm extension over the C ABI of libdoda_hip.so.
+//
+// The arithmetic lives behind include/doda_hip.h; this file is host-side glue only (no device code):
+// C++ autograd functions for the sparse convolutions and the fused BatchNorm(+ReLU), so that a U-Net
+// step does not pay Python + ctypes overhead on each of its ~800 native launches (measured: the
+// Python glue alone needs ~11.5 ms per step, as much as all GPU kernels together).
+// doda_amd/spconv/functional.py and doda_amd/nn.py use it when it is built and fall back to the
+// equivalent ctypes glue (same kernels) otherwise.
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+
+#include "../../include/doda_hip.h"
+
+namespace {
+
+using torch::autograd::AutogradContext;
+using torch::autograd::tensor_list;
+
+inline void *stream_of(const at::Tensor &t) {
+    return (void *)c10::hip::getCurrentHIPStream(t.device().index()).stream();
+}
+
+inline void check(int status, const char *what) {
+    TORCH_CHECK(status == 0, what, " failed: ", doda_strerror(status), " (", status, ")");
+}
+
+inline int elem_bytes(const at::Tensor &t) {
+    if (t.scalar_type() == at::kFloat) return 4;
+    TORCH_CHECK(t.scalar_type() == at::kBFloat16, "doda: features must be float32 or bfloat16");
+    return 2;
+}
+
+inline bool wide_packing(int esz, int64_t kc) { return esz == 2 && kc >= 32 && kc % 8 == 0; }
+
+// y[t] = sum_o x[tbl[o][t]] . B_o   (include/doda_hip.h: doda_spconv_gather_*)
+at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
+                  const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32) {
+    const at::Tensor x = x_in.contiguous();
+    TORCH_CHECK(x.is_cuda() && x.dim() == 2 && tbl.is_cuda() && tbl.dim() == 2, "doda gather: bad inputs");
+    const int esz = elem_bytes(x);
+    const int64_t K = tbl.size(0), ld = tbl.size(1), kc = x.size(1);
+    void *st = stream_of(x);
+    const bool f32_out = esz == 4 || out_f32;
+    at::Tensor y = at::empty({n_out, nc}, x.options().dtype(f32_out ? at::kFloat : at::kBFloat16));
+    const void *wptr;
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    at::Tensor ws_t, wc;
+    int lay = (int)layout;
+    bool use_packed = packed.has_value() && packed->defined();
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (use_packed) {
+            wptr = packed->data_ptr();
+            lay = (int)layout | 0x100 | (wide_packing(esz, kc) ? 0x10 : 0);
+        } else {
+            wc = w.contiguous();
+            TORCH_CHECK(wc.scalar_type() == at::kFloat && wc.numel() == K * kc * nc, "doda gather: weight shape");
+            wptr = wc.data_ptr();
+            ws_bytes = doda_spconv_gather_workspace_bytes((int)K, (int)kc, (int)nc, esz);
+            ws_t = at::empty({(int64_t)ws_bytes}, x.options().dtype(at::kByte));
+            ws = ws_t.data_ptr();
+            lay = (int)layout;
+        }
+        int status;
+        if (esz == 4)
+            status = doda_spconv_gather_f32((const float *)x.data_ptr(), (int)x.size(0), (int)kc, (const float *)wptr,
+                                            (int)nc, (const int32_t *)tbl.data_ptr(), (int)ld, (int)K, (int)n_out,
+                                            (float *)y.data_ptr(), lay, ws, ws_bytes, st);
+        else
+            status = doda_spconv_gather_bf16((const uint16_t *)x.data_ptr(), (int)x.size(0), (int)kc,
+                                             (const float *)wptr, (int)nc, (const int32_t *)tbl.data_ptr(), (int)ld,
+                                             (int)K, (int)n_out, y.data_ptr(), out_f32 ? 1 : 0, lay, ws, ws_bytes, st);
+        if (status == DODA_ERR_UNSUPPORTED && use_packed) {  // fast path refused the pre-packed weights
+            use_packed = false;
+            continue;
+        }
+        check(status, "doda_spconv_gather");
+        break;
+    }
+    return y;
+}
+
+at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tensor &tbl, int64_t n_rows) {
+    const at::Tensor a = a_in.contiguous(), b = b_in.contiguous();
+    TORCH_CHECK(a.scalar_type() == b.scalar_type(), "doda wgrad: dtype mismatch");
+    const int esz = elem_bytes(a);
+    const int64_t K = tbl.size(0), ld = tbl.size(1), ca = a.size(1), cb = b.size(1);
+    at::Tensor dw = at::empty({K, ca, cb}, a.options().dtype(at::kFloat));
+    const size_t wsb = doda_spconv_wgrad_workspace_bytes((int)K, (int)ca, (int)cb, (int)n_rows);
+    at::Tensor ws = at::empty({(int64_t)(wsb > 256 ? wsb : 256)}, a.options().dtype(at::kByte));
+    int status;
+    if (esz == 4)
+        status = doda_spconv_wgrad_f32((const float *)a.data_ptr(), (int)ca, (const float *)b.data_ptr(), (int)cb,
+                                       (const int32_t *)tbl.data_ptr(), (int)ld, (int)K, (int)n_rows,
+                                       (float *)dw.data_ptr(), ws.data_ptr(), (size_t)ws.numel(), stream_of(a));
+    else
+        status = doda_spconv_wgrad_bf16((const uint16_t *)a.data_ptr(), (int)ca, (const uint16_t *)b.data_ptr(),
+                                        (int)cb, (const int32_t *)tbl.data_ptr(), (int)ld, (int)K, (int)n_rows,
+                                        (float *)dw.data_ptr(), ws.data_ptr(), (size_t)ws.numel(), stream_of(a));
+    check(status, "doda_spconv_wgrad");
+    return dw;
+}
+
+// features, weight [k,k,k,Cin,Cout], fwd_tbl, bwd_tbl, n_out, bwd_layout, packed fwd / data-grad
+struct IndiceConvFn : public torch::autograd::Function<IndiceConvFn> {
+    static at::Tensor forward(AutogradContext *ctx, const at::Tensor &features, const at::Tensor &weight,
+                              const at::Tensor &fwd_tbl, const at::Tensor &bwd_tbl, int64_t n_out,
+                              int64_t bwd_layout, const c10::optional<at::Tensor> &pk_fwd,
+                              const c10::optional<at::Tensor> &pk_bwd) {
+        const int64_t cin = weight.size(-2), cout = weight.size(-1), K = fwd_tbl.size(0);
+        ctx->save_for_backward({features, weight, fwd_tbl, bwd_tbl,
+                                pk_bwd.has_value() && pk_bwd->defined() ? *pk_bwd : at::Tensor()});
+        ctx->saved_data["n_out"] = n_out;
+        ctx->saved_data["bwd_layout"] = bwd_layout;
+        return gather(features, weight.reshape({K, cin, cout}), pk_fwd, fwd_tbl, n_out, 0, cout, false);
+    }
+    static tensor_list backward(AutogradContext *ctx, tensor_list grads) {
+        const auto saved = ctx->get_saved_variables();
+        const at::Tensor &features = saved[0], &weight = saved[1], &fwd_tbl = saved[2], &bwd_tbl = saved[3];
+        const at::Tensor &pk_bwd = saved[4];
+        const int64_t n_out = ctx->saved_data["n_out"].toInt(), bwd_layout = ctx->saved_data["bwd_layout"].toInt();
+        const int64_t cin = weight.size(-2), cout = weight.size(-1), K = fwd_tbl.size(0);
+        const at::Tensor dy = grads[0].contiguous();  // reference fork patch llijiang/spconv@740a5b7
+        at::Tensor d_feat, d_w;
+        if (ctx->needs_input_grad(0))
+            d_feat = gather(dy, weight.reshape({K, cin, cout}),
+                            pk_bwd.defined() ? c10::optional<at::Tensor>(pk_bwd) : c10::nullopt, bwd_tbl,
+                            features.size(0), bwd_layout, cin, false);
+        if (ctx->needs_input_grad(1)) d_w = wgrad(features, dy, fwd_tbl, n_out).reshape(weight.sizes()).to(weight.scalar_type());
+        return {d_feat, d_w, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor indice_conv(const at::Tensor &features, const at::Tensor &weight, const at::Tensor &fwd_tbl,
+                       const at::Tensor &bwd_tbl, int64_t n_out, int64_t bwd_layout,
+                       const c10::optional<at::Tensor> &pk_fwd, const c10::optional<at::Tensor> &pk_bwd) {
+    return IndiceConvFn::apply(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd);
+}
+
+// ---- fused BatchNorm1d(+ReLU) ----------------------------------------------------------------
+struct BNReLUFn : public torch::autograd::Function<BNReLUFn> {
+    static at::Tensor forward(AutogradContext *ctx, const at::Tensor &x_in, const at::Tensor &weight,
+                              const at::Tensor &bias, const at::Tensor &running_mean,
+                              const at::Tensor &running_var, const at::Tensor &nbt, bool training,
+                              double momentum, double eps, bool relu) {
+        const at::Tensor x = x_in.contiguous();
+        const int esz = elem_bytes(x);
+        const int64_t m = x.size(0), c = x.size(1);
+        at::Tensor y = at::empty_like(x);
+        at::Tensor mean, invstd;
+        if (training) {
+            mean = at::empty({c}, x.options().dtype(at::kFloat));
+            invstd = at::empty({c}, x.options().dtype(at::kFloat));
+        } else {
+            mean = running_mean.to(at::kFloat).contiguous();
+            invstd = at::rsqrt(running_var.to(at::kFloat) + eps).contiguous();
+        }
+        const size_t wsb = doda_bn_workspace_bytes((int)m, (int)c);
+        at::Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
+        check(doda_bn_relu_fwd(x.data_ptr(), (int)m, (int)c, esz, (float)eps, (float)momentum,
+                               (const float *)weight.data_ptr(), (const float *)bias.data_ptr(),
+                               training ? (float *)running_mean.data_ptr() : nullptr,
+                               training ? (float *)running_var.data_ptr() : nullptr,
+                               training && nbt.defined() ? (int64_t *)nbt.data_ptr() : nullptr, training ? 1 : 0,
+                               relu ? 1 : 0, y.data_ptr(), (float *)mean.data_ptr(), (float *)invstd.data_ptr(),
+                               ws.data_ptr(), wsb, stream_of(x)),
+              "doda_bn_relu_fwd");
+        ctx->save_for_backward({x, weight, bias, mean, invstd});
+        ctx->saved_data["training"] = training;
+        ctx->saved_data["relu"] = relu;
+        return y;
+    }
+    static tensor_list backward(AutogradContext *ctx, tensor_list grads) {
+        const auto saved = ctx->get_saved_variables();
+        const at::Tensor &x = saved[0], &weight = saved[1], &bias = saved[2], &mean = saved[3], &invstd = saved[4];
+        const bool training = ctx->saved_data["training"].toBool(), relu = ctx->saved_data["relu"].toBool();
+        const at::Tensor dy = grads[0].contiguous();
+        at::Tensor dx, dg, db;
+        if (training) {
+            const int64_t m = x.size(0), c = x.size(1);
+            dx = at::empty_like(x);
+            dg = at::empty({c}, x.options().dtype(at::kFloat));
+            db = at::empty({c}, x.options().dtype(at::kFloat));
+            const size_t wsb = doda_bn_workspace_bytes((int)m, (int)c);
+            at::Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
+            check(doda_bn_relu_bwd(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
+                                   (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(),
+                                   (const float *)weight.data_ptr(), (const float *)bias.data_ptr(), relu ? 1 : 0,
+                                   dx.data_ptr(), (float *)dg.data_ptr(), (float *)db.data_ptr(), ws.data_ptr(), wsb,
+                                   stream_of(x)),
+                  "doda_bn_relu_bwd");
+        } else {  // running statistics are constants
+            at::Tensor xh = (x.to(at::kFloat) - mean) * invstd;
+            at::Tensor dz = dy.to(at::kFloat);
+            if (relu) dz = dz * ((xh * weight + bias) > 0);
+            dx = (dz * (weight * invstd)).to(x.scalar_type());
+            dg = (dz * xh).sum(0);
+            db = dz.sum(0);
+        }
+        return {dx, dg.to(weight.scalar_type()), db.to(bias.scalar_type()), at::Tensor(), at::Tensor(),
+                at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor bn_relu(const at::Tensor &x, const at::Tensor &weight, const at::Tensor &bias,
+                   const at::Tensor &running_mean, const at::Tensor &running_var, const at::Tensor &nbt,
+                   bool training, double momentum, double eps, bool relu) {
+    return BNReLUFn::apply(x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, relu);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.def("indice_conv", &indice_conv, "sparse conv (gather table) with autograd");
+    m.def("bn_relu", &bn_relu, "fused BatchNorm1d(+ReLU) with autograd");
+    m.def("gather", &gather, "raw gather-GEMM");
+    m.def("wgrad", &wgrad, "raw weight gradient");
+    m.def("abi_version", []() { return doda_abi_version(); });
+}

@@ -12,6 +12,7 @@ from torch import nn
 from torch.autograd import Function
 
 from . import ops as _ops
+from ._ext import ext as _ext
 
 
 class _BNReLU(Function):
@@ -55,5 +56,8 @@ def batch_norm_relu(features, bn, relu):
     """BatchNorm1d `bn` (+ReLU when `relu`) on features through the fused HIP kernels."""
     # num_batches_tracked += 1 happens inside the stats kernel (65 one-element add kernels per step
     # otherwise)
+    if _ext is not None:
+        return _ext.bn_relu(features, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                            bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, relu)
     return _BNReLU.apply(features, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                          bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, relu)

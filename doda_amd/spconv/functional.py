@@ -15,6 +15,7 @@ import torch
 from torch.autograd import Function
 
 from .. import ops as _ops
+from .._ext import ext as _ext
 
 # Backward of a sparse conv = two independent native ops on the same inputs: the data-grad gather
 # (on the critical path of the chain rule) and the weight-grad reduction.  With DODA_OVERLAP_BWD=1
@@ -112,21 +113,30 @@ class _Conv1x1(Function):
         return d_feat, d_w, None, None
 
 
+def _conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed):
+    if _ext is not None and _SERIAL:   # compiled autograd glue (no Python per launch)
+        pk_fwd, pk_bwd = packed if packed is not None else (None, None)
+        return _ext.indice_conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd)
+    return _IndiceConv.apply(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed)
+
+
 def conv1x1(features, weight, ident, packed=None):
+    if _ext is not None and _SERIAL:
+        return _conv(features, weight, ident, ident, features.shape[0], 1, packed)
     return _Conv1x1.apply(features, weight, ident, packed)
 
 
 def indice_subm_conv(features, weight, data, packed=None):
-    return _IndiceConv.apply(features, weight, data.tbl, data.tbl, data.outids.shape[0], 2, packed)
+    return _conv(features, weight, data.tbl, data.tbl, data.outids.shape[0], 2, packed)
 
 
 def indice_conv(features, weight, data, packed=None):
-    return _IndiceConv.apply(features, weight, data.tbl, data.tbl_rev, data.outids.shape[0], 1, packed)
+    return _conv(features, weight, data.tbl, data.tbl_rev, data.outids.shape[0], 1, packed)
 
 
 def indice_inverse_conv(features, weight, data, packed=None):
     # roles swapped: outputs live on the saved (fine) input indices of the strided conv
-    return _IndiceConv.apply(features, weight, data.tbl_rev, data.tbl, data.indices.shape[0], 1, packed)
+    return _conv(features, weight, data.tbl_rev, data.tbl, data.indices.shape[0], 1, packed)
 
 
 class _IndiceMaxPool(Function):
