@@ -28,8 +28,11 @@ struct F32 {
     typedef f32x4 frag;
     static constexpr int KSTEPS = RT / 4;   // v_mfma_f32_16x16x4_f32: 4 rows per MFMA
     typedef float kfrag;                    // one MFMA operand
-    static __device__ __forceinline__ kfrag lds_frag(const elem *tile, int stride, int ks, int g, int col) {
-        return tile[(ks * 4 + g) * stride + col];
+    // fragments of all KSTEPS k-steps for the 16 channels starting at col0 (lane = (i, g))
+    template <int STRIDE>
+    static __device__ __forceinline__ void frags(const elem *tile, int g, int i, int col0, kfrag (&out)[KSTEPS]) {
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) out[ks] = tile[(ks * 4 + g) * STRIDE + col0 + i];
     }
     static __device__ __forceinline__ f32x4 mma(kfrag a, kfrag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -41,11 +44,23 @@ struct BF16 {
     typedef s16x4 frag;
     static constexpr int KSTEPS = RT / 16;  // v_mfma_f32_16x16x16_bf16: 16 rows per MFMA
     typedef s16x4 kfrag;
-    static __device__ __forceinline__ kfrag lds_frag(const elem *tile, int stride, int ks, int g, int col) {
-        kfrag v;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = (short)tile[(ks * 16 + 4 * g + q) * stride + col];
-        return v;
+    // Rows are the MFMA k dimension but LDS holds [row][channel]: ds_read_b64_tr_b16 does the 4x16
+    // transpose in the LDS crossbar.  Probed on gfx950 (tools/probe/trread.hip): when lane t of a
+    // 16-lane group g points at &tile[4g + t/4][4*(t&3)] it receives {tile[4g+q][t] : q = 0..3} —
+    // exactly the 16x16x16 fragment of channel t.  The four k-steps are 16 rows apart (immediate
+    // offsets).  The asm ends with lgkmcnt(0): hipcc does not count LDS ops issued inside asm.
+    template <int STRIDE>
+    static __device__ __forceinline__ void frags(const elem *tile, int g, int i, int col0, kfrag (&out)[KSTEPS]) {
+        static_assert(KSTEPS == 4, "four k-steps of 16 rows");
+        const unsigned addr = (unsigned)(uintptr_t)(tile + (4 * g + (i >> 2)) * STRIDE + col0 + 4 * (i & 3));
+        asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                     "ds_read_b64_tr_b16 %1, %4 offset:%5\n\t"
+                     "ds_read_b64_tr_b16 %2, %4 offset:%6\n\t"
+                     "ds_read_b64_tr_b16 %3, %4 offset:%7\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+                     : "v"(addr), "n"(16 * STRIDE * 2), "n"(32 * STRIDE * 2), "n"(48 * STRIDE * 2)
+                     : "memory");
     }
     static __device__ __forceinline__ f32x4 mma(kfrag a, kfrag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
@@ -135,11 +150,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__re
             *reinterpret_cast<frag *>(&b_tile[r * SB + f * 4]) = v;
         }
         __syncthreads();
-        kfrag bf[T::KSTEPS][TB];
+        kfrag bf[TB][T::KSTEPS];
 #pragma unroll
-        for (int ks = 0; ks < T::KSTEPS; ++ks)
-#pragma unroll
-            for (int y_ = 0; y_ < TB; ++y_) bf[ks][y_] = T::lds_frag(b_tile, SB, ks, g, y_ * 16 + i);
+        for (int y_ = 0; y_ < TB; ++y_) T::template frags<SB>(b_tile, g, i, y_ * 16, bf[y_]);
 
         // ---- this wave's offsets ----
         int idx[OGW];
@@ -162,14 +175,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__re
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                for (int ks = 0; ks < T::KSTEPS; ++ks)
+                for (int x_ = 0; x_ < TA; ++x_) {
+                    kfrag af[T::KSTEPS];
+                    T::template frags<SA>(my_a, g, i, x_ * 16, af);
 #pragma unroll
-                    for (int x_ = 0; x_ < TA; ++x_) {
-                        const kfrag af = T::lds_frag(my_a, SA, ks, g, x_ * 16 + i);
+                    for (int ks = 0; ks < T::KSTEPS; ++ks)
 #pragma unroll
                         for (int y_ = 0; y_ < TB; ++y_)
-                            acc[oo][x_][y_] = T::mma(af, bf[ks][y_], acc[oo][x_][y_]);
-                    }
+                            acc[oo][x_][y_] = T::mma(af[ks], bf[y_][ks], acc[oo][x_][y_]);
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
