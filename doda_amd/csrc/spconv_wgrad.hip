@@ -13,6 +13,7 @@
 // x TA x TB 16x16 tiles) live in registers for the whole row chunk; per-chunk partials are reduced
 // by a second kernel in fixed order: deterministic, no float atomics.
 #include "common.hpp"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -251,7 +252,11 @@ Plan make_plan(int K, int ca, int cb, int n_rows) {
     p.n_og = div_up(K, 4 * p.OGW);
     const int gy = p.n_tag * p.n_tbg * p.n_og;
     const int rows = n_rows > 0 ? n_rows : 1;
-    int R = div_up(512, gy);            // aim at >= 2 blocks per CU over the whole grid
+    // measured at M = 600k / 183k (rocprofv3): 1x1 and 2x1 tiles 68 -> 50 us going from 512 to 1024
+    // blocks (+5 us of partial reduce); 2x2 tiles are fastest at 512
+    static const int forced = getenv("DODA_WGRAD_BLOCKS") ? atoi(getenv("DODA_WGRAD_BLOCKS")) : 0;
+    const int target = forced ? forced : ((p.TA * p.TB == 4) ? 512 : 1024);
+    int R = div_up(target, gy);         // blocks over the whole grid
     const int max_r = div_up(rows, RT);
     if (R > max_r) R = max_r;
     if (R < 1) R = 1;
