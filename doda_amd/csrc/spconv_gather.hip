@@ -123,9 +123,15 @@ __device__ __forceinline__ u32x4_t pack_wide_frag(const float *__restrict__ w, i
 
 __global__ __launch_bounds__(256) void pack_weights_wide(const float *__restrict__ w, int K, int kc,
                                                          int nc, int n_chunk, int NB, int wl,
-                                                         u32x4_t *__restrict__ packed) {
-    const long long total = (long long)K * n_chunk * NB * 64;
+                                                         u32x4_t *__restrict__ packed, int pair) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair) {
+        if (e >= (long long)K * NB * 32) return;
+        const long long r = e >> 5;
+        packed[e] = pack_wide_frag(w, K, kc, nc, wl, (int)(r / NB), 0, (int)(r % NB), (int)(e & 31));
+        return;
+    }
+    const long long total = (long long)K * n_chunk * NB * 64;
     if (e >= total) return;
     const int lane = (int)(e & 63);
     long long r = e >> 6;
@@ -176,6 +182,13 @@ __global__ __launch_bounds__(256) void pack_weights_multi(const PackDesc *__rest
     const PackDesc d = descs[lo];
     const int first = lo == 0 ? 0 : blk_end[lo - 1];
     const long long e = (long long)(blockIdx.x - first) * 256 + threadIdx.x;
+    if (d.layout & 0x20) {  // pair packing (kc == 16): [o][nb][32 slots] = lanes 0..31 of a wide fragment
+        if (e >= (long long)d.K * d.NB * 32) return;
+        const long long r = e >> 5;
+        reinterpret_cast<u32x4_t *>(d.out)[e] =
+            pack_wide_frag(d.w, d.K, d.kc, d.nc, d.layout & 3, (int)(r / d.NB), 0, (int)(r % d.NB), (int)(e & 31));
+        return;
+    }
     const long long total = (long long)d.K * d.n_chunk * d.NB * 64;
     if (e >= total) return;
     if (d.layout & 0x10) {  // wide bf16 fragments
@@ -358,10 +371,12 @@ __device__ __forceinline__ u32x4 make_rsrc(const void *p, unsigned bytes) {
 //   PBF16W: bf16 features, 32 channels per unit, v_mfma_f32_16x16x32_bf16 (16-byte lane loads):
 //          half the gathers, weight loads and MFMAs per channel — these kernels are paced by
 //          the NUMBER of 64-lane memory instructions through the per-CU texture path.
+//   PBF16P: bf16 features, kc == 16: two offsets x 16 channels per unit (see the struct).
 // Gathers: lanes whose row is absent (offset >= 2^31) are masked out of EXEC so the texture
 // addresser does not spend a cycle per absent 4-lane quad; their destination is pre-zeroed.
 // Lane 0 always stays active: a VMEM instruction whose EXEC is all-zero may not count in vmcnt,
-// which would break the counted waits of the ring.
+// which would break the counted waits of the ring.  The mask arithmetic writes SCC, so "scc" is in
+// the clobber list (without it the compiler kept an s_cmp result live across the block).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define DODA_ASM_LOAD(INSTR)                                                                       \
@@ -375,7 +390,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
                      "s_or_b64 vcc, vcc, 1\n\t"                                                    \
                      "s_and_saveexec_b64 %1, vcc\n\t" INSTR " %0, %2, %3, %4 offen\n\t"            \
                      "s_mov_b64 exec, %1"                                                          \
-                     : "+v"(dst), "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff) : "vcc");            \
+                     : "+v"(dst), "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff) : "vcc", "scc");     \
     }
 
 struct PF32 {
@@ -383,6 +398,7 @@ struct PF32 {
     typedef u32x4 raw;
     typedef F32 pack;  // weight pre-pack flavour
     static constexpr int CH = 16;
+    static constexpr bool PAIR = false;
     DODA_ASM_LOAD("buffer_load_dwordx4")
     static __device__ __forceinline__ void mma(f32x4 &acc, const raw &w, const raw &x) {
         const f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
@@ -395,6 +411,7 @@ struct PBF16 {
     typedef u32x2 raw;
     typedef BF16 pack;
     static constexpr int CH = 16;
+    static constexpr bool PAIR = false;
     DODA_ASM_LOAD("buffer_load_dwordx2")
     static __device__ __forceinline__ void mma(f32x4 &acc, const raw &w, const raw &x) {
         acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, w), __builtin_bit_cast(s16x4, x), acc, 0, 0, 0);
@@ -405,10 +422,20 @@ struct PBF16W {
     typedef u32x4 raw;
     typedef BF16 pack;
     static constexpr int CH = 32;
+    static constexpr bool PAIR = false;
     DODA_ASM_LOAD("buffer_load_dwordx4")
     static __device__ __forceinline__ void mma(f32x4 &acc, const raw &w, const raw &x) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
     }
+};
+// PBF16P: bf16 features with exactly 16 input channels.  A unit is a PAIR of kernel offsets: the
+// k = 32 of one v_mfma_f32_16x16x32_bf16 is (offset a | offset b) x 16 channels.  Lane groups
+// g = 0,1 gather the two 16-byte halves of the row under offset a, g = 2,3 under offset b, and read
+// the matching halves of W[a] / W[b] — half the gathers, weight loads and MFMAs of PBF16 for the
+// layers that dominate the step (level-1 SubM 16 -> 16).
+struct PBF16P : PBF16W {
+    static constexpr int CH = 16;
+    static constexpr bool PAIR = true;
 };
 
 // one wide output store: lane holds 4 consecutive channels of one row
@@ -497,25 +524,52 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) acc[s][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int n_chunk = (kc + CH - 1) / CH;
-    const unsigned lane_x = (unsigned)g * FSZ;       // this lane's quarter of a unit's channels
-    const int lane_c = g * (CH / 4);                 // its first channel inside the unit
-    const unsigned lane_w = (unsigned)lane * FSZ;    // this lane's slot inside a packed W fragment
+    constexpr bool PAIR = P::PAIR;
+    const int n_chunk = PAIR ? 1 : (kc + CH - 1) / CH;
+    // this lane's share of a unit's bytes / its first channel inside the unit / its slot inside a
+    // packed W fragment.  PAIR: groups g = 2,3 belong to the unit's second offset.
+    const unsigned lane_x = (unsigned)(PAIR ? (g & 1) : g) * FSZ;
+    const int lane_c = g * (CH / 4);
+    const unsigned lane_w = (unsigned)(PAIR ? ((g & 1) * 16 + i) : lane) * FSZ;
+    const bool second = PAIR && g >= 2;
     const unsigned *my_off = &off_tile[wid][i];
 
-    const int n_units = __builtin_popcount(active) * n_chunk;
+    const int n_units = PAIR ? (__builtin_popcount(active) + 1) / 2 : __builtin_popcount(active) * n_chunk;
     if (n_units > 0) {
         raw xa[D][S], wb[D][NBW];
         // (o, cc, have): the next unit to issue.  Every asm load below is UNCONDITIONAL (a slot with
         // nothing left to fetch gets the all-out-of-range dummy unit, strip MAX_K): conditional
         // definitions of ring registers make the register allocator resolve phis with moves of
         // registers whose loads are still in flight (observed as a nondeterministic race).
-        int o = __builtin_ctz(active), cc = 0;
+        int o = __builtin_ctz(active), cc = 0, o2 = MAX_K;
         active &= active - 1;
+        if (PAIR && active != 0) { o2 = __builtin_ctz(active); active &= active - 1; }
         bool have = true;
         int to_issue = n_units;
 
         auto issue = [&](raw (&xr)[S], raw (&wr)[NBW]) {
+            if constexpr (PAIR) {
+                // offset of this lane's half of the unit; strip MAX_K / a W offset past the packed
+                // buffer are the all-zero dummies (odd offset count, ring top-up)
+                const int osel = have ? (second ? o2 : o) : MAX_K;
+                const unsigned *p = my_off + osel * RW;
+#pragma unroll
+                for (int s = 0; s < S; ++s) P::gather(xr[s], p[s * 16] + lane_x, rs_x, 0u);
+                const unsigned voff_w = (unsigned)osel * ((unsigned)NB * 32u * FSZ) + lane_w;
+                const unsigned soff_w = (unsigned)nb0 * 32u * FSZ;
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) P::load(wr[nb], voff_w, rs_w, soff_w + nb * 32u * FSZ);
+                if (have) {
+                    --to_issue;
+                    if (active == 0) have = false;
+                    else {
+                        o = __builtin_ctz(active); active &= active - 1;
+                        o2 = MAX_K;
+                        if (active != 0) { o2 = __builtin_ctz(active); active &= active - 1; }
+                    }
+                }
+                return;
+            }
             // a lane whose channels lie past kc (partial last chunk) fetches the all-absent strip
             const bool lane_ok = have && (cc * CH + lane_c < kc);
             const unsigned *p = my_off + (lane_ok ? o : MAX_K) * RW;
@@ -619,8 +673,16 @@ int launch(const typename T::elem *x, int kc, const typename T::frag *wp, int nc
 }
 
 template <class T> struct FastPolicy;
-template <> struct FastPolicy<F32> { typedef PF32 narrow; typedef PF32 wide; };
-template <> struct FastPolicy<BF16> { typedef PBF16 narrow; typedef PBF16W wide; };
+template <> struct FastPolicy<F32> { typedef PF32 narrow; typedef PF32 wide; typedef PF32 pair; };
+template <> struct FastPolicy<BF16> { typedef PBF16 narrow; typedef PBF16W wide; typedef PBF16P pair; };
+
+// Fragment packing the fast kernel uses for a layer: 0x10 wide (bf16, >= 32 input channels),
+// 0x20 pair (bf16, exactly 16 input channels, more than one offset), 0 narrow.
+inline int pack_mode(int K, int kc, int elem_bytes) {
+    if (elem_bytes == 2 && kc >= 32 && kc % 8 == 0) return 0x10;
+    if (elem_bytes == 2 && kc == 16 && K >= 2) return 0x20;
+    return 0;
+}
 
 template <class T>
 int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tbl, int ld, int K,
@@ -640,21 +702,21 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
                       ((uintptr_t)y % 16 == 0) && ((size_t)n_out * nc * 4 < 0x7fffffffull) &&
                       ((size_t)K * ld * 4 < 0xffffffffull) && x_rows_bytes_ok;
     if (out32 && sizeof(elem) != 4 && !fast) return DODA_ERR_UNSUPPORTED;
-    // bf16 with >= 32 input channels: 32-channel units (16-byte lane loads, 16x16x32 MFMA)
-    const bool wide = fast && sizeof(elem) == 2 && (kc % 8 == 0) && kc >= 32;
+    const int mode = pack_mode(K, kc, (int)sizeof(elem));
+    const bool wide = fast && mode == 0x10, pair = fast && mode == 0x20;
     const int n_chunk = wide ? (kc + 31) / 32 : (kc + 15) / 16;
-    const size_t need = (size_t)K * n_chunk * NB * 64 * (wide ? 16 : sizeof(frag));
+    const size_t need = pair ? (size_t)K * NB * 32 * 16 : (size_t)K * n_chunk * NB * 64 * (wide ? 16 : sizeof(frag));
     const void *wp;
     if (wl & 0x100) {  // `w` already holds fragment-packed weights (doda_spconv_pack_multi)
-        if (((wl & 0x10) != 0) != wide) return DODA_ERR_UNSUPPORTED;  // packed for the other mode
+        if (mode != 0 && !fast) return DODA_ERR_UNSUPPORTED;  // packed for a mode this call cannot take
         wp = (const void *)w;
     } else {
         if (!ws || ws_bytes < need) return DODA_ERR_WORKSPACE;
         wp = ws;
-        const long long total = (long long)K * n_chunk * NB * 64;
-        if (wide)
+        const long long total = pair ? (long long)K * NB * 32 : (long long)K * n_chunk * NB * 64;
+        if (wide || pair)
             hipLaunchKernelGGL(pack_weights_wide, dim3(div_up(total, 256)), dim3(256), 0, s, w, K, kc, nc,
-                               n_chunk, NB, wl & 3, (u32x4_t *)ws);
+                               n_chunk, NB, wl & 3, (u32x4_t *)ws, pair ? 1 : 0);
         else
             hipLaunchKernelGGL((pack_weights<T>), dim3(div_up(total, 256)), dim3(256), 0, s, w, K, kc,
                                nc, n_chunk, NB, wl & 3, (frag *)ws);
@@ -665,9 +727,11 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     const long long waves_full = ((long long)n_out + 15) / 16;
     typedef typename FastPolicy<T>::narrow PN;
     typedef typename FastPolicy<T>::wide PW;
+    typedef typename FastPolicy<T>::pair PP;
 #define GO(NBW, S)                                                                                 \
     do {                                                                                           \
         if (wide) return launch_fast<PW, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
+        if (pair) return launch_fast<PP, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
         if (fast) return launch_fast<PN, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
         return launch<T, NBW, S>(x, kc, (const frag *)wp, nc, NB, tbl, ld, K, n_out, y, vec_ok, s); \
     } while (0)
@@ -701,7 +765,7 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
 
 bool bad_args(const void *x, int kc, const float *w, int nc, const int32_t *tbl, int ld, int K,
               int n_out, const void *y, int wl, int *status) {
-    if (kc <= 0 || nc <= 0 || K <= 0 || n_out < 0 || ld < n_out || (wl & 3) > 2 || (wl & ~0x113)) {
+    if (kc <= 0 || nc <= 0 || K <= 0 || n_out < 0 || ld < n_out || (wl & 3) > 2 || (wl & ~0x103)) {
         *status = DODA_ERR_INVALID;
         return true;
     }
@@ -730,13 +794,14 @@ extern "C" int doda_spconv_pack_plan_h(void *descs_h, int32_t n_desc, int32_t *b
     PackDesc *d = (PackDesc *)descs_h;
     long long acc = 0;
     for (int k = 0; k < n_desc; ++k) {
-        if (d[k].K <= 0 || d[k].K > MAX_K || d[k].kc <= 0 || d[k].nc <= 0 || (d[k].layout & ~0x13) ||
-            (d[k].layout & 3) > 2 || (d[k].elem_bytes != 2 && d[k].elem_bytes != 4) ||
-            ((d[k].layout & 0x10) && d[k].elem_bytes != 2))
+        if (d[k].K <= 0 || d[k].K > MAX_K || d[k].kc <= 0 || d[k].nc <= 0 || (d[k].layout & ~3) ||
+            (d[k].layout & 3) > 2 || (d[k].elem_bytes != 2 && d[k].elem_bytes != 4))
             return DODA_ERR_INVALID;
+        d[k].layout |= pack_mode(d[k].K, d[k].kc, d[k].elem_bytes);   // the mode the gather will expect
         d[k].n_chunk = (d[k].layout & 0x10) ? (d[k].kc + 31) / 32 : (d[k].kc + 15) / 16;
         d[k].NB = (d[k].nc + 15) / 16;
-        acc += div_up((long long)d[k].K * d[k].n_chunk * d[k].NB * 64, 256);
+        acc += div_up((d[k].layout & 0x20) ? (long long)d[k].K * d[k].NB * 32
+                                           : (long long)d[k].K * d[k].n_chunk * d[k].NB * 64, 256);
         if (acc > 0x7fffffff) return DODA_ERR_UNSUPPORTED;
         blk_end_h[k] = (int32_t)acc;
     }

@@ -30,8 +30,6 @@ inline int elem_bytes(const at::Tensor &t) {
     return 2;
 }
 
-inline bool wide_packing(int esz, int64_t kc) { return esz == 2 && kc >= 32 && kc % 8 == 0; }
-
 // y[t] = sum_o x[tbl[o][t]] . B_o   (include/doda_hip.h: doda_spconv_gather_*)
 at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
                   const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32) {
@@ -51,7 +49,7 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (use_packed) {
             wptr = packed->data_ptr();
-            lay = (int)layout | 0x100 | (wide_packing(esz, kc) ? 0x10 : 0);
+            lay = (int)layout | 0x100;
         } else {
             wc = w.contiguous();
             TORCH_CHECK(wc.scalar_type() == at::kFloat && wc.numel() == K * kc * nc, "doda gather: weight shape");

@@ -226,7 +226,7 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None):
         if packed.numel() * packed.element_size() < need - 255:
             raise RuntimeError("packed weight buffer too small")
         w_ptr, ws_ptr, ws_n = _p(packed), None, 0
-        layout = int(w_layout) | 0x100 | (0x10 if wide_packing(esz, kc) else 0)
+        layout = int(w_layout) | 0x100
     else:
         _need_cuda(w)
         w = w.contiguous()
@@ -247,12 +247,6 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None):
     else:
         raise RuntimeError("spconv_gather: unsupported feature dtype %s" % x.dtype)
     return y
-
-
-def wide_packing(elem_bytes, kc):
-    """True when the fast conv kernel uses 32-channel units (bf16, >= 32 input channels, kc % 8 == 0)
-    and therefore expects the wide fragment packing."""
-    return elem_bytes == 2 and kc >= 32 and kc % 8 == 0
 
 
 class PackPlan:
@@ -280,8 +274,7 @@ class PackPlan:
                               device=device)
             self.outputs.append(out)
             self._keep.append(w)
-            desc[k] = (w.data_ptr(), out.data_ptr(), K, kc, nc,
-                       layout | (0x10 if wide_packing(esz, kc) else 0), esz, 0, 0, 0)
+            desc[k] = (w.data_ptr(), out.data_ptr(), K, kc, nc, layout, esz, 0, 0, 0)
         blk_end = np.zeros(n, dtype=np.int32)
         total = C.c_int32()
         check(l.doda_spconv_pack_plan_h(desc.ctypes.data, n, blk_end.ctypes.data, C.byref(total)),

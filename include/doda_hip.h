@@ -153,7 +153,11 @@ size_t doda_spconv_gather_workspace_bytes(int32_t K, int32_t kc, int32_t nc, int
  * (0..2), elem_bytes (2|4) and three int32 the planner fills (doda_spconv_pack_desc_bytes() bytes
  * in all).  doda_spconv_pack_plan_h completes the host descriptors and the inclusive block prefix;
  * the caller uploads both and calls doda_spconv_pack_multi.  A gather call then passes the packed
- * buffer as `w` with w_layout | 0x100 (and may pass ws = NULL). */
+ * buffer as `w` with w_layout | 0x100 (and may pass ws = NULL).  The fragment order (16-channel,
+ * 32-channel "wide", or offset-"pair" for 16-channel bf16 layers) is chosen by the library from
+ * (K, kc, elem_bytes) alone, identically in the planner and in the gather; a gather call that
+ * cannot use the order its buffer was packed in (unaligned / > 2 GB features, which take the
+ * generic kernel) returns DODA_ERR_UNSUPPORTED and the caller passes the fp32 weights instead. */
 size_t doda_spconv_pack_desc_bytes(void);
 int doda_spconv_pack_plan_h(void *descs_h, int32_t n_desc, int32_t *blk_end_h, int32_t *total_blocks);
 int doda_spconv_pack_multi(const void *descs_dev, const int32_t *blk_end_dev, int32_t n_desc,
