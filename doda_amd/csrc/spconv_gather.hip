@@ -462,7 +462,11 @@ __device__ __forceinline__ void touch(R &r) {
     asm volatile("" : "+v"(r));
 }
 
-template <class P, int NBW, int S, int D, bool OUT32>
+// SPLIT (few rows, S = NBW = 1): the block's four waves share ONE 16-row tile and one channel
+// block; each takes every fourth active offset and the four partial accumulators are summed in a
+// fixed order through LDS.  At the coarse U-Net levels a wave otherwise walks 80-190 units in
+// series (27 offsets x 3..7 chunks, ~70 ns each) while the chip is nearly empty.
+template <class P, int NBW, int S, int D, bool OUT32, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restrict__ x,
                                                  unsigned x_bytes, int kc,
                                                  const void *__restrict__ wp,
@@ -482,12 +486,13 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
     static_assert((D - 1) * L <= 63, "vmcnt field");
     __shared__ unsigned off_tile[4][NLD * 64];
 
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int n_nbg = (NB + NBW - 1) / NBW;
     const int item = xcd_work_item(blockIdx.x, gridDim.x);
     const int nb0 = (item % n_nbg) * NBW;
-    const int row0 = ((item / n_nbg) * 4 + wid) * RW;   // this wave's first output row
+    static_assert(!SPLIT || (S == 1 && NBW == 1), "SPLIT: one subtile, one channel block");
+    const int row0 = SPLIT ? (item / n_nbg) * RW : ((item / n_nbg) * 4 + wid) * RW;   // wave's first output row
 
     const u32x4 rs_x = make_rsrc(x, x_bytes), rs_w = make_rsrc(wp, wp_bytes);
     const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void *)tbl, 0, tbl_bytes, 0x00020000);
@@ -516,6 +521,13 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
         }
     }
     active = __builtin_amdgcn_readfirstlane(active);
+    if (SPLIT) {  // keep the offsets whose rank among the active ones is wid (mod 4)
+        unsigned mine = 0;
+        int rank = 0;
+        for (unsigned m = active; m != 0; m &= m - 1, ++rank)
+            if ((rank & 3) == wid) mine |= m & (0u - m);
+        active = __builtin_amdgcn_readfirstlane(mine);
+    }
     __syncthreads();
 
     f32x4 acc[S][NBW];
@@ -629,6 +641,18 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
         }
     }
 
+    if constexpr (SPLIT) {
+        __shared__ f32x4 part[3][64];
+        if (wid > 0) part[wid - 1][lane] = acc[0][0];
+        __syncthreads();
+        if (wid > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const f32x4 p = part[w][lane];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[0][0][q] += p[q];
+        }
+    }
     // lane (row = lane&15, g) holds channels 4g..4g+3 of each 16-channel block: one wide store
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -642,21 +666,21 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
     }
 }
 
-template <class P, int NBW, int S>
+template <class P, int NBW, int S, bool SPLIT = false>
 int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_bytes, int nc, int NB,
                 const int32_t *tbl, int ld, int K, int n_out, long long n_in, void *y, bool out32,
                 hipStream_t s) {
-    const dim3 grid(div_up(n_out, 4 * 16 * S) * div_up(NB, NBW)), block(256);
+    const dim3 grid(div_up(n_out, (SPLIT ? 1 : 4) * 16 * S) * div_up(NB, NBW)), block(256);
     constexpr int D = (S + NBW <= 3) ? 8 : ((S + NBW <= 5) ? 6 : ((S + NBW <= 6) ? 4 : 3));
     const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(typename P::elem));
     const unsigned tb = (unsigned)((size_t)K * ld * 4);
     if (out32 && sizeof(typename P::elem) != 4) {
         const unsigned yb = (unsigned)((size_t)n_out * nc * 4);
-        hipLaunchKernelGGL((conv_fast<P, NBW, S, D, true>), grid, block, 0, s, x, xb, kc, wp,
+        hipLaunchKernelGGL((conv_fast<P, NBW, S, D, true, SPLIT>), grid, block, 0, s, x, xb, kc, wp,
                            (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb);
     } else {
         const unsigned yb = (unsigned)((size_t)n_out * nc * sizeof(typename P::elem));
-        hipLaunchKernelGGL((conv_fast<P, NBW, S, D, false>), grid, block, 0, s, x, xb, kc, wp,
+        hipLaunchKernelGGL((conv_fast<P, NBW, S, D, false, SPLIT>), grid, block, 0, s, x, xb, kc, wp,
                            (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb);
     }
     return doda_check_launch();
@@ -735,12 +759,15 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
         if (fast) return launch_fast<PN, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
         return launch<T, NBW, S>(x, kc, (const frag *)wp, nc, NB, tbl, ld, K, n_out, y, vec_ok, s); \
     } while (0)
-    static const int force_s = getenv("DODA_S") ? atoi(getenv("DODA_S")) : 0;
-    if (NB == 1 && force_s == 4) GO(1, 4);
-    if (NB == 1 && force_s == 2) GO(1, 2);
-    if (NB == 1 && force_s == 1) GO(1, 1);
-    if (NB == 2 && force_s == 2) GO(2, 2);
-    if (NB == 2 && force_s == 1) GO(2, 1);
+    {   // few rows, long unit chains: split the offsets of a 16-row tile over the block's waves
+        // measured (rocprofv3, per dispatch): 795 / 210 / 49 blocks 12.7 -> 9.5, 12.2 -> 6.1,
+        // 16.0 -> 6.3 us; 2808 blocks (level 4) 18.0 -> 24.7 us, so only below ~1k blocks
+        if (fast && (long long)K * n_chunk >= 12 && waves_full * NB <= 1024) {
+            if (wide) return launch_fast<PW, 1, 1, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s);
+            if (pair) return launch_fast<PP, 1, 1, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s);
+            return launch_fast<PN, 1, 1, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s);
+        }
+    }
     if (NB == 1) {  // measured at M = 600k, 16 ch: S=2 51 us, S=4 56 us, S=1 56 us
         if (waves_full >= 4096) GO(1, 2);
         GO(1, 1);

@@ -234,6 +234,40 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float *__restrict__ pa
     }
 }
 
+// float4 flavour for n_elem % 4 == 0: LANES chunk lanes per element quad (1 = a thread walks all R
+// chunks itself).  The launcher picks LANES from (n_elem, R) only, so the summation order of a given
+// layer shape is fixed.  Coarse levels have few chunks and many elements (27 x 112 x 112): the
+// 16-lane kernel above spends its time on 20k nearly idle blocks there.
+template <int LANES>
+__global__ __launch_bounds__(256) void wgrad_reduce4(const float4 *__restrict__ partial, int R,
+                                                     long long n_quad, float4 *__restrict__ dw) {
+    constexpr int EPB = 256 / LANES;
+    __shared__ float4 part[LANES][EPB];
+    const int el = threadIdx.x % EPB, rl = threadIdx.x / EPB;
+    const long long q = (long long)blockIdx.x * EPB + el;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < n_quad)
+        for (int r = rl; r < R; r += LANES) {
+            const float4 v = partial[(long long)r * n_quad + q];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    if (LANES == 1) {
+        if (q < n_quad) dw[q] = s;
+        return;
+    }
+    part[rl][el] = s;
+    __syncthreads();
+    if (rl == 0 && q < n_quad) {
+        float4 t = part[0][el];
+#pragma unroll 4
+        for (int r = 1; r < LANES; ++r) {
+            const float4 v = part[r][el];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        dw[q] = t;
+    }
+}
+
 struct Plan {
     int TA, TB, OGW, n_og, n_tag, n_tbg, R, rows_per_chunk;
 };
@@ -274,7 +308,8 @@ int run_wgrad(const void *a_, int ca, const void *b_, int cb, const int32_t *tbl
     const long long n_elem = (long long)K * ca * cb;
     const Plan p = make_plan(K, ca, cb, n_rows);
     if (ws_bytes < (size_t)p.R * n_elem * 4) return DODA_ERR_WORKSPACE;
-    float *partial = (float *)ws;
+    // a single row chunk needs no reduction: the kernel writes dw itself
+    float *partial = p.R == 1 ? dw : (float *)ws;
     const size_t va = 4 * sizeof(elem);
     const int vec_ok = (ca % 4 == 0) && (cb % 4 == 0) && ((uintptr_t)a % va == 0) && ((uintptr_t)b % va == 0);
     const dim3 grid(p.R * p.n_tag * p.n_tbg * p.n_og), block(256);
@@ -293,6 +328,21 @@ int run_wgrad(const void *a_, int ca, const void *b_, int cb, const int32_t *tbl
 #undef GO
     int st = doda_check_launch();
     if (st != DODA_OK) return st;
+    if (p.R == 1) return DODA_OK;
+    if (n_elem % 4 == 0 && (uintptr_t)dw % 16 == 0) {
+        const long long n_quad = n_elem / 4;
+        // fewest chunk lanes that still give >= 512 blocks, never more lanes than chunks need
+        int lanes = 1;
+        while (lanes < 64 && lanes < p.R && n_quad * lanes / 256 < 512) lanes *= 4;
+        const dim3 grid(div_up(n_quad, 256 / lanes));
+        const float4 *src = (const float4 *)partial;
+        float4 *dst = (float4 *)dw;
+        if (lanes == 1) hipLaunchKernelGGL(wgrad_reduce4<1>, grid, dim3(256), 0, s, src, p.R, n_quad, dst);
+        else if (lanes == 4) hipLaunchKernelGGL(wgrad_reduce4<4>, grid, dim3(256), 0, s, src, p.R, n_quad, dst);
+        else if (lanes == 16) hipLaunchKernelGGL(wgrad_reduce4<16>, grid, dim3(256), 0, s, src, p.R, n_quad, dst);
+        else hipLaunchKernelGGL(wgrad_reduce4<64>, grid, dim3(256), 0, s, src, p.R, n_quad, dst);
+        return doda_check_launch();
+    }
     hipLaunchKernelGGL(wgrad_reduce, dim3(div_up(n_elem, 16)), dim3(256), 0, s, partial, p.R,
                        n_elem, dw);
     return doda_check_launch();
