@@ -491,7 +491,6 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
     const int n_nbg = (NB + NBW - 1) / NBW;
     const int item = xcd_work_item(blockIdx.x, gridDim.x);
     const int nb0 = (item % n_nbg) * NBW;
-    static_assert(!SPLIT || (S == 1 && NBW == 1), "SPLIT: one subtile, one channel block");
     const int row0 = SPLIT ? (item / n_nbg) * RW : ((item / n_nbg) * 4 + wid) * RW;   // wave's first output row
 
     const u32x4 rs_x = make_rsrc(x, x_bytes), rs_w = make_rsrc(wp, wp_bytes);
@@ -642,16 +641,25 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
     }
 
     if constexpr (SPLIT) {
-        __shared__ f32x4 part[3][64];
-        if (wid > 0) part[wid - 1][lane] = acc[0][0];
+        __shared__ f32x4 part[3][S][NBW][64];
+        if (wid > 0) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) part[wid - 1][s][nb][lane] = acc[s][nb];
+        }
         __syncthreads();
         if (wid > 0) return;
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
-            const f32x4 p = part[w][lane];
+        for (int w = 0; w < 3; ++w)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[0][0][q] += p[q];
-        }
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    const f32x4 p = part[w][s][nb][lane];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[s][nb][q] += p[q];
+                }
     }
     // lane (row = lane&15, g) holds channels 4g..4g+3 of each 16-channel block: one wide store
 #pragma unroll
@@ -762,11 +770,16 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     {   // few rows, long unit chains: split the offsets of a 16-row tile over the block's waves
         // measured (rocprofv3, per dispatch): 795 / 210 / 49 blocks 12.7 -> 9.5, 12.2 -> 6.1,
         // 16.0 -> 6.3 us; 2808 blocks (level 4) 18.0 -> 24.7 us, so only below ~1k blocks
-        if (fast && (long long)K * n_chunk >= 12 && waves_full * NB <= 1024) {
-            if (wide) return launch_fast<PW, 1, 1, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s);
-            if (pair) return launch_fast<PP, 1, 1, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s);
-            return launch_fast<PN, 1, 1, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s);
-        }
+#define GS(NBW, S)                                                                                 \
+    do {                                                                                           \
+        if (wide) return launch_fast<PW, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
+        if (pair) return launch_fast<PP, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
+        return launch_fast<PN, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
+    } while (0)
+        // (two channel blocks / 32-row tiles per split block were tried at level 4: 14.2 us against
+        // 13.0 us for the unsplit <4,1> tile, so the split stays at one block, 16 rows)
+        if (fast && (long long)K * n_chunk >= 12 && waves_full * NB <= 1024) GS(1, 1);
+#undef GS
     }
     if (NB == 1) {  // measured at M = 600k, 16 ch: S=2 51 us, S=4 56 us, S=1 56 us
         if (waves_full >= 4096) GO(1, 2);
@@ -779,8 +792,7 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     }
     if (NB <= 4) {
         if (waves_full >= 8192) GO(4, 2);
-        if (waves_full >= 2048) GO(4, 1);
-        if (waves_full >= 512) GO(2, 1);
+        if (waves_full >= 512) GO(4, 1);   // level 4 (11k rows, 64 ch): <4,1> 13.0 us, <2,1> 17.3, <2,2> 14.9
         GO(1, 1);
     }
     if (waves_full >= 4096) GO(8, 1);

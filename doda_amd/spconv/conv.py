@@ -156,13 +156,25 @@ class SparseConvolution(SparseModule):
             out.grid = input.grid
             return out
 
+        weight, packed = self.weight, None
+        if features.is_cuda and self.in_channels % 4 != 0:
+            # e.g. the xyz input layer (3 channels): rows of 6 / 12 bytes miss the aligned vector
+            # path of the native kernels (measured 107 us against ~30 us at 600k voxels).  Zero
+            # channels appended to the features and zero rows to the weight leave the result
+            # unchanged; autograd slices the weight gradient back.
+            extra = (-self.in_channels) % 4
+            features = nn.functional.pad(features, (0, extra))
+            weight = nn.functional.pad(self.weight, (0, 0, 0, extra))
+        else:
+            packed = self._packed(features)
+
         data = input.find_indice_pair(self.indice_key)
         if self.inverse:
             if data is None or data.kind != "down2":
                 raise RuntimeError("SparseInverseConv3d: no strided rulebook under indice_key %r"
                                    % (self.indice_key,))
             outids, out_spatial_shape = data.indices, data.spatial_shape
-            out_features = Fsp.indice_inverse_conv(features, self.weight, data, self._packed(features))
+            out_features = Fsp.indice_inverse_conv(features, weight, data, packed)
         else:
             if data is None:
                 if self.subm:
@@ -174,9 +186,9 @@ class SparseConvolution(SparseModule):
                     input.indice_dict[self.indice_key] = data
             outids, out_spatial_shape = data.outids, data.out_spatial_shape
             if self.subm:
-                out_features = Fsp.indice_subm_conv(features, self.weight, data, self._packed(features))
+                out_features = Fsp.indice_subm_conv(features, weight, data, packed)
             else:
-                out_features = Fsp.indice_conv(features, self.weight, data, self._packed(features))
+                out_features = Fsp.indice_conv(features, weight, data, packed)
 
         if self.bias is not None:
             out_features = out_features + self.bias.to(out_features.dtype)
