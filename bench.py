@@ -100,11 +100,31 @@ def kernel_roofline(batch_dev, dtype, reps):
                              "frac_of_hbm_peak": (b_f + b_b) / t_all / 1e9 / HBM_PEAK_GBS}
     dom = "subm16_fwd"
     kname = "conv_fast<PF32,1,2,8>" if dtype == "f32" else "conv_fast<PBF16P,1,2,8>"
+    traffic, traffic_src = pmc_traffic(dtype)
     roof = {"kernel": "%s (SubMConv3d 16->16 fwd gather, M=%d, P=%d)" % (kname, m, pairs_total),
             "bound": "hbm", "achieved": out[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": out[dom]["GBs"] / HBM_PEAK_GBS, "traffic": None,
+            "frac": out[dom]["GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": b_f, "avg_launch_us": out[dom]["us"], "detail": out}
     return roof, pairs_total / max(m, 1)
+
+
+def pmc_traffic(dtype):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
+    (tools/profile_round.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of the same kernel
+    on the same 4 x 150k-voxel batch).  Counters are in KiB; FETCH_SIZE is doubled as
+    MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950 (check: the doubled value,
+    86.5 MB, sits 2.5 % above the compulsory x + table bytes, 84.4 MB; WRITE_SIZE equals the output
+    bytes exactly).  A counter pass cannot run inside this process, hence the file."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_raw.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)[dtype]
+        fetch, write = d["FETCH_SIZE_KB_mean"], d["WRITE_SIZE_KB_mean"]
+        if fetch is None or write is None:
+            return None, None
+        return (2.0 * fetch + write) * 1024.0, "profiles/r01_pmc_traffic_raw.json (2 x FETCH_SIZE + WRITE_SIZE, KiB)"
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def cpu_baseline(args):
