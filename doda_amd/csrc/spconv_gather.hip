@@ -679,7 +679,11 @@ int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_byt
                 const int32_t *tbl, int ld, int K, int n_out, long long n_in, void *y, bool out32,
                 hipStream_t s) {
     const dim3 grid(div_up(n_out, (SPLIT ? 1 : 4) * 16 * S) * div_up(NB, NBW)), block(256);
-    constexpr int D = (S + NBW <= 3) ? 8 : ((S + NBW <= 5) ? 6 : ((S + NBW <= 6) ? 4 : 3));
+    // Ring depth.  Re-measured after the EXEC-masked gathers and the wide / pair units went in: with
+    // every load hitting L1 (ablation) the kernel time did not move, i.e. the unit loop is paced by
+    // instruction issue and by how many waves a SIMD can interleave, not by memory latency.  Depth 8
+    // cost 124 VGPRs (4 waves per SIMD); depth 3: level-1 16->16 52 -> 38 us, level-2 32->32 37 -> 32 us.
+    constexpr int D = 3;
     const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(typename P::elem));
     const unsigned tb = (unsigned)((size_t)K * ld * 4);
     if (out32 && sizeof(typename P::elem) != 4) {

@@ -34,11 +34,26 @@ def main():
     ap.add_argument("--dtypes", default="bf16,f32")
     ap.add_argument("--levels", default="1,2,3,4,5,6,7")
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--order", default="scene", help="voxel order: scene | morton | random | zyx")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     batch = make_batch(a.scenes, a.voxels, 1000)
     idx = batch["voxel_locs"].int().to(dev)
     shape = [int(s) for s in batch["spatial_shape"]]
+    if a.order != "scene":
+        b, x, y, z = [idx[:, k].long() for k in range(4)]
+        if a.order == "random":
+            perm = torch.randperm(idx.shape[0], device=dev)
+        elif a.order == "zyx":
+            perm = torch.argsort(((b * 4096 + x) * 4096 + y) * 4096 + z)
+        else:
+            def spread(v):
+                r = torch.zeros_like(v)
+                for bit in range(12):
+                    r |= ((v >> bit) & 1) << (3 * bit)
+                return r
+            perm = torch.argsort((b << 40) | (spread(x) << 2) | (spread(y) << 1) | spread(z))
+        idx = idx[perm].contiguous()
     levels = [int(v) for v in a.levels.split(",")]
     for lvl in range(1, 8):
         m = idx.shape[0]
