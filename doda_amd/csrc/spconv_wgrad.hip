@@ -17,16 +17,20 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int RT = 64;    // rows per step
 constexpr int MAX_OGW = 7;  // offsets per wave (4 waves x 7 >= 27)
-constexpr int PAD = 4;    // LDS row padding in elements (bank spread, keeps 8/16-byte alignment)
+constexpr int PAD = 8;    // LDS row padding in elements (bank spread, keeps rows 16-byte aligned)
 
 struct F32 {
     typedef float elem;
     typedef f32x4 frag;
+    typedef f32x4 vec;                      // 16-byte global / LDS access unit
+    static constexpr int VEC = 4;
     static constexpr int KSTEPS = RT / 4;   // v_mfma_f32_16x16x4_f32: 4 rows per MFMA
     typedef float kfrag;                    // one MFMA operand
     // fragments of all KSTEPS k-steps for the 16 channels starting at col0 (lane = (i, g))
@@ -43,38 +47,50 @@ struct F32 {
 struct BF16 {
     typedef unsigned short elem;
     typedef s16x4 frag;
-    static constexpr int KSTEPS = RT / 16;  // v_mfma_f32_16x16x16_bf16: 16 rows per MFMA
-    typedef s16x4 kfrag;
+    typedef u32x4 vec;
+    static constexpr int VEC = 8;
+    static constexpr int KSTEPS = RT / 32;  // v_mfma_f32_16x16x32_bf16: 32 rows per MFMA
+    typedef bf16x8 kfrag;
     // Rows are the MFMA k dimension but LDS holds [row][channel]: ds_read_b64_tr_b16 does the 4x16
     // transpose in the LDS crossbar.  Probed on gfx950 (tools/probe/trread.hip): when lane t of a
-    // 16-lane group g points at &tile[4g + t/4][4*(t&3)] it receives {tile[4g+q][t] : q = 0..3} —
-    // exactly the 16x16x16 fragment of channel t.  The four k-steps are 16 rows apart (immediate
-    // offsets).  The asm ends with lgkmcnt(0): hipcc does not count LDS ops issued inside asm.
+    // 16-lane group g points at &tile[R + t/4][4*(t&3)] it receives {tile[R+q][t] : q = 0..3}.
+    // A 16x16x32 operand wants k = 8g..8g+7 per lane: two reads with R = 8g and R = 8g + 4; the two
+    // k-steps are 32 rows apart (immediate offsets).  The asm ends with lgkmcnt(0): hipcc does not
+    // count LDS ops issued inside asm.
     template <int STRIDE>
     static __device__ __forceinline__ void frags(const elem *tile, int g, int i, int col0, kfrag (&out)[KSTEPS]) {
-        static_assert(KSTEPS == 4, "four k-steps of 16 rows");
-        const unsigned addr = (unsigned)(uintptr_t)(tile + (4 * g + (i >> 2)) * STRIDE + col0 + 4 * (i & 3));
+        static_assert(KSTEPS == 2, "two k-steps of 32 rows");
+        const unsigned addr = (unsigned)(uintptr_t)(tile + (8 * g + (i >> 2)) * STRIDE + col0 + 4 * (i & 3));
+        s16x4 lo0, hi0, lo1, hi1;
         asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
                      "ds_read_b64_tr_b16 %1, %4 offset:%5\n\t"
                      "ds_read_b64_tr_b16 %2, %4 offset:%6\n\t"
                      "ds_read_b64_tr_b16 %3, %4 offset:%7\n\t"
                      "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
-                     : "v"(addr), "n"(16 * STRIDE * 2), "n"(32 * STRIDE * 2), "n"(48 * STRIDE * 2)
+                     : "=&v"(lo0), "=&v"(hi0), "=&v"(lo1), "=&v"(hi1)
+                     : "v"(addr), "n"(4 * STRIDE * 2), "n"(32 * STRIDE * 2), "n"(36 * STRIDE * 2)
                      : "memory");
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 k0 = __builtin_shufflevector(lo0, hi0, 0, 1, 2, 3, 4, 5, 6, 7);
+        const s16x8 k1 = __builtin_shufflevector(lo1, hi1, 0, 1, 2, 3, 4, 5, 6, 7);
+        out[0] = __builtin_bit_cast(bf16x8, k0);
+        out[1] = __builtin_bit_cast(bf16x8, k1);
     }
     static __device__ __forceinline__ f32x4 mma(kfrag a, kfrag b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
 };
 
-template <class T, int TA, int TB, int OGW>
+// VOK: rows of both operands are 16-byte aligned multiples of 16 bytes.  Then every global access is
+// an UNCONDITIONAL 16-byte load from an always-valid address (absent rows read row 0) whose value is
+// zeroed by a select: no divergent branch around a load, so hipcc can keep many loads in flight
+// (with branches it emitted `s_waitcnt vmcnt(0)` after every single load).
+template <class T, int TA, int TB, int OGW, bool VOK>
 __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__restrict__ a, int ca,
                                                     const typename T::elem *__restrict__ b, int cb,
                                                     const int32_t *__restrict__ tbl, int ld, int K,
                                                     int n_rows, int rows_per_chunk, int n_tag,
-                                                    int n_tbg, int n_og, float *__restrict__ partial,
-                                                    int vec_ok) {
+                                                    int n_tbg, int n_og, float *__restrict__ partial) {
     typedef typename T::elem elem;
     typedef typename T::frag frag;
     typedef typename T::kfrag kfrag;
@@ -108,47 +124,86 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__re
 
     elem *my_a = a_tile[wid];
 
-    // one lane's row slice: TA*4 fragments of 4 channels
-    auto gather_row = [&](int idx, frag (&dst)[TA * 4]) {
+    // one lane's row slice: NVA 16-byte vectors (TA*16 channels)
+    typedef typename T::vec vec;
+    constexpr int VEC = T::VEC, NVA = TA * 16 / VEC, NVB = TB * 16 / VEC;
+    auto load_vec = [&](const elem *p, const elem *safe, int c, int cmax, bool ok) -> vec {
+        const bool live = ok && c < cmax;
+        if constexpr (VOK) {
+            // raw value; the CONSUMER zeroes dead lanes (a select here would make the compiler wait
+            // for the load on the spot)
+            return *reinterpret_cast<const vec *>(live ? p : safe);
+        } else {
+            vec v = vec{};
+            if (live) {
+                elem tmp[VEC];
 #pragma unroll
-        for (int f = 0; f < TA * 4; ++f) {
-            frag v;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = 0;
-            const int c = ca0 + f * 4;
-            if (idx >= 0 && c < ca) {
-                const elem *p = a + (long long)idx * ca + c;
-                if (vec_ok) v = *reinterpret_cast<const frag *>(p);
-                else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (c + q < ca) v[q] = p[q];
-                }
+                for (int q = 0; q < VEC; ++q) tmp[q] = (c + q < cmax) ? p[q] : (elem)0;
+                v = *reinterpret_cast<const vec *>(tmp);
             }
-            dst[f] = v;
+            return v;
+        }
+    };
+    auto gather_row = [&](int idx, vec (&dst)[NVA]) {
+#pragma unroll
+        for (int f = 0; f < NVA; ++f) {
+            const int c = ca0 + f * VEC;
+            dst[f] = load_vec(a + (long long)(idx >= 0 ? idx : 0) * ca + c, a, c, ca, idx >= 0);
         }
     };
 
-    for (long long r0 = r_begin; r0 < r_end; r0 += RT) {
-        // ---- dY tile -> shared LDS ----
-        __syncthreads();
-        for (int e = threadIdx.x; e < RT * TB * 4; e += 256) {
-            const int r = e / (TB * 4), f = e - r * (TB * 4);
+    // Software pipeline over the 64-row steps: the dY vectors and the table entries of step n+1 are
+    // requested at the start of step n and the gather of its first offset during step n's last one,
+    // so a step no longer begins with three dependent memory latencies (dY tile, table, first gather)
+    // — measured as the bound of this kernel (20 steps x ~3 us per block at level 1).
+    constexpr int NDY = (RT * NVB + 255) / 256;   // dY vectors per thread and step
+    vec dy_reg[NDY];
+    int idx_n[OGW];
+    auto load_dy = [&](long long r0) {
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) {
+            const int e = threadIdx.x + k * 256;
+            const int r = e / NVB, f = e - r * NVB;
             const long long row = r0 + r;
-            const int c = cb0 + f * 4;
-            frag v;
+            const int c = cb0 + f * VEC;
+            dy_reg[k] = load_vec(b + (row < r_end ? row : 0) * cb + c, b, c, cb, e < RT * NVB && row < r_end);
+        }
+    };
+    auto load_idx = [&](long long r0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = 0;
-            if (row < r_end && c < cb) {
-                const elem *p = b + row * cb + c;
-                if (vec_ok) v = *reinterpret_cast<const frag *>(p);
-                else {
+        for (int oo = 0; oo < OGW; ++oo) {
+            const int o = o_base + wid + 4 * oo;
+            const long long row = r0 + lane;
+            idx_n[oo] = tbl[(o < K && row < r_end) ? (long long)o * ld + row : 0];   // raw; masked when consumed
+        }
+    };
+
+    vec rows_cur[NVA], rows_nxt[NVA];
+    if (r_begin < r_end) {
+        load_dy(r_begin);
+        load_idx(r_begin);
+        gather_row((o_base + wid < K && r_begin + lane < r_end) ? idx_n[0] : -1, rows_cur);
+    }
+    for (long long r0 = r_begin; r0 < r_end; r0 += RT) {
+        // ---- dY tile (already in registers) -> shared LDS ----
+        __syncthreads();
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (c + q < cb) v[q] = p[q];
-                }
+        for (int k = 0; k < NDY; ++k) {
+            const int e = threadIdx.x + k * 256;
+            if (e < RT * NVB) {
+                const int r = e / NVB, f = e - r * NVB;
+                const bool live = r0 + r < r_end && cb0 + f * VEC < cb;
+                *reinterpret_cast<vec *>(&b_tile[r * SB + f * VEC]) = (VOK && !live) ? vec{} : dy_reg[k];
             }
-            *reinterpret_cast<frag *>(&b_tile[r * SB + f * 4]) = v;
+        }
+        int idx[OGW];
+#pragma unroll
+        for (int oo = 0; oo < OGW; ++oo)
+            idx[oo] = (o_base + wid + 4 * oo < K && r0 + lane < r_end) ? idx_n[oo] : -1;
+        const bool more = r0 + RT < r_end;
+        if (more) {  // in flight for the whole step
+            load_dy(r0 + RT);
+            load_idx(r0 + RT);
         }
         __syncthreads();
         kfrag bf[TB][T::KSTEPS];
@@ -156,22 +211,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__re
         for (int y_ = 0; y_ < TB; ++y_) T::template frags<SB>(b_tile, g, i, y_ * 16, bf[y_]);
 
         // ---- this wave's offsets ----
-        int idx[OGW];
 #pragma unroll
         for (int oo = 0; oo < OGW; ++oo) {
-            const int o = o_base + wid + 4 * oo;
-            const long long row = r0 + lane;
-            idx[oo] = (o < K && row < r_end) ? tbl[(long long)o * ld + row] : -1;
-        }
-        frag rows_cur[TA * 4], rows_nxt[TA * 4];
-        gather_row(idx[0], rows_cur);
-#pragma unroll
-        for (int oo = 0; oo < OGW; ++oo) {
-            if (oo + 1 < OGW) gather_row(idx[oo + 1], rows_nxt);  // issued ahead of this offset's MFMAs
+            // gather for the next offset (or for the first offset of the next step) ahead of the MFMAs
+            if (oo + 1 < OGW) gather_row(idx[oo + 1], rows_nxt);
+            else if (more) gather_row((o_base + wid < K && r0 + RT + lane < r_end) ? idx_n[0] : -1, rows_nxt);
             if (__ballot(idx[oo] >= 0) != 0ull) {
 #pragma unroll
-                for (int f = 0; f < TA * 4; ++f)
-                    *reinterpret_cast<frag *>(&my_a[lane * SA + f * 4]) = rows_cur[f];
+                for (int f = 0; f < NVA; ++f) {
+                    const bool live = idx[oo] >= 0 && ca0 + f * VEC < ca;
+                    *reinterpret_cast<vec *>(&my_a[lane * SA + f * VEC]) = (VOK && !live) ? vec{} : rows_cur[f];
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -190,7 +240,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__re
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
 #pragma unroll
-            for (int f = 0; f < TA * 4; ++f) rows_cur[f] = rows_nxt[f];
+            for (int f = 0; f < NVA; ++f) rows_cur[f] = rows_nxt[f];
         }
     }
 
@@ -272,7 +322,7 @@ struct Plan {
     int TA, TB, OGW, n_og, n_tag, n_tbg, R, rows_per_chunk;
 };
 
-Plan make_plan(int K, int ca, int cb, int n_rows) {
+Plan make_plan(int K, int ca, int cb, int n_rows, int elem_bytes) {
     Plan p;
     const int ta = (ca + 15) / 16, tb = (cb + 15) / 16;
     p.TA = (ta % 2 == 0) ? 2 : 1;
@@ -281,15 +331,17 @@ Plan make_plan(int K, int ca, int cb, int n_rows) {
     p.n_tbg = tb / p.TB;
     // 2x2 accumulator tiles x 7 offsets would need 112 accumulator registers (1 wave/SIMD): give
     // such blocks 4 offsets per wave and spread the offsets over several block groups instead
-    p.OGW = (p.TA * p.TB == 4) ? 4 : MAX_OGW;
+    // offsets per wave for 1- and 2-tile blocks (rocprofv3, levels 1 / 3 / 5): bf16 7 -> 4 offsets
+    // 54.8 -> 52.2, 39.6 -> 35.3, 19.0 -> 14.3 us (fewer registers, half the partials); fp32 the other
+    // way round (91 vs 106 us at level 3): its 16 dY fragment reads per step amortise over more offsets
+    p.OGW = (p.TA * p.TB == 4 || elem_bytes == 2) ? 4 : MAX_OGW;
     if (K <= 8) p.OGW = (p.TA * p.TB == 4) ? 2 : 2;
     p.n_og = div_up(K, 4 * p.OGW);
     const int gy = p.n_tag * p.n_tbg * p.n_og;
     const int rows = n_rows > 0 ? n_rows : 1;
     // measured at M = 600k / 183k (rocprofv3): 1x1 and 2x1 tiles 68 -> 50 us going from 512 to 1024
     // blocks (+5 us of partial reduce); 2x2 tiles are fastest at 512
-    static const int forced = getenv("DODA_WGRAD_BLOCKS") ? atoi(getenv("DODA_WGRAD_BLOCKS")) : 0;
-    const int target = forced ? forced : ((p.TA * p.TB == 4) ? 512 : 1024);
+    const int target = (p.TA * p.TB == 4) ? 512 : 1024;
     int R = div_up(target, gy);         // blocks over the whole grid
     const int max_r = div_up(rows, RT);
     if (R > max_r) R = max_r;
@@ -306,22 +358,32 @@ int run_wgrad(const void *a_, int ca, const void *b_, int cb, const int32_t *tbl
     typedef typename T::elem elem;
     const elem *a = (const elem *)a_, *b = (const elem *)b_;
     const long long n_elem = (long long)K * ca * cb;
-    const Plan p = make_plan(K, ca, cb, n_rows);
+    const Plan p = make_plan(K, ca, cb, n_rows, (int)sizeof(elem));
     if (ws_bytes < (size_t)p.R * n_elem * 4) return DODA_ERR_WORKSPACE;
     // a single row chunk needs no reduction: the kernel writes dw itself
     float *partial = p.R == 1 ? dw : (float *)ws;
-    const size_t va = 4 * sizeof(elem);
-    const int vec_ok = (ca % 4 == 0) && (cb % 4 == 0) && ((uintptr_t)a % va == 0) && ((uintptr_t)b % va == 0);
+    // 16-byte row vectors need 16-byte aligned rows in both operands
+    const int vec_ok = ((size_t)ca * sizeof(elem) % 16 == 0) && ((size_t)cb * sizeof(elem) % 16 == 0) &&
+                       ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0);
     const dim3 grid(p.R * p.n_tag * p.n_tbg * p.n_og), block(256);
 #define GO(TA, TB, OG)                                                                             \
-    hipLaunchKernelGGL((wgrad_kernel<T, TA, TB, OG>), grid, block, 0, s, a, ca, b, cb, tbl, ld, K, \
-                       n_rows, p.rows_per_chunk, p.n_tag, p.n_tbg, p.n_og, partial, vec_ok)
+    do {                                                                                           \
+        if (vec_ok)                                                                                \
+            hipLaunchKernelGGL((wgrad_kernel<T, TA, TB, OG, true>), grid, block, 0, s, a, ca, b, cb, tbl, \
+                               ld, K, n_rows, p.rows_per_chunk, p.n_tag, p.n_tbg, p.n_og, partial); \
+        else                                                                                       \
+            hipLaunchKernelGGL((wgrad_kernel<T, TA, TB, OG, false>), grid, block, 0, s, a, ca, b, cb, tbl, \
+                               ld, K, n_rows, p.rows_per_chunk, p.n_tag, p.n_tbg, p.n_og, partial); \
+    } while (0)
     if (p.OGW == 2) {
         if (p.TA == 1 && p.TB == 1) GO(1, 1, 2);
         else if (p.TA == 2 && p.TB == 1) GO(2, 1, 2);
         else if (p.TA == 1 && p.TB == 2) GO(1, 2, 2);
         else GO(2, 2, 2);
-    } else if (p.TA == 1 && p.TB == 1) GO(1, 1, 7);
+    } else if (p.OGW == 4 && p.TA == 1 && p.TB == 1) GO(1, 1, 4);
+    else if (p.OGW == 4 && p.TA == 2 && p.TB == 1) GO(2, 1, 4);
+    else if (p.OGW == 4 && p.TA == 1 && p.TB == 2) GO(1, 2, 4);
+    else if (p.TA == 1 && p.TB == 1) GO(1, 1, 7);
     else if (p.TA == 2 && p.TB == 1) GO(2, 1, 7);
     else if (p.TA == 1 && p.TB == 2) GO(1, 2, 7);
     else GO(2, 2, 4);
@@ -366,8 +428,8 @@ int check_args(const void *a, int ca, const void *b, int cb, const int32_t *tbl,
 extern "C" size_t doda_spconv_wgrad_workspace_bytes(int32_t K, int32_t ca, int32_t cb,
                                                     int32_t n_rows) {
     if (K <= 0 || ca <= 0 || cb <= 0) return 0;
-    const Plan p = make_plan(K, ca, cb, n_rows);
-    return align_up((size_t)p.R * K * ca * cb * 4, 256);
+    const Plan p2 = make_plan(K, ca, cb, n_rows, 2), p4 = make_plan(K, ca, cb, n_rows, 4);
+    return align_up((size_t)(p2.R > p4.R ? p2.R : p4.R) * K * ca * cb * 4, 256);
 }
 
 extern "C" int doda_spconv_wgrad_f32(const float *a, int32_t ca, const float *b, int32_t cb,
