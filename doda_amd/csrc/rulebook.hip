@@ -34,6 +34,13 @@ __global__ __launch_bounds__(256) void subm_insert(const int4 *__restrict__ indi
     hash_insert_min(tab, mask, cell_id(c.x, c.y, c.z, c.w, g), (uint32_t)t);
 }
 
+// One thread per voxel.  A SubM table is its own transpose under offset mirroring (nbr[o][t] = j  <=>
+// nbr[K3-1-o][j] = t), so only the first half of the offsets is probed: a hit writes both entries
+// (the mirrored one is a scattered 4-byte store into a half that the launcher pre-fills with -1).
+// The kernel is bound by the rate of random 8-byte table reads (16 M of them at 600k voxels), not
+// by their latency — issuing all first-slot reads before inspecting any changed nothing — so
+// halving the reads is what pays.  The first-slot reads are still issued together; only a
+// neighbour whose first slot holds a different key walks the probe chain.
 template <int KS>
 __global__ __launch_bounds__(256) void subm_probe(const int4 *__restrict__ indices, int m,
                                                   GridDesc g,
@@ -43,22 +50,41 @@ __global__ __launch_bounds__(256) void subm_probe(const int4 *__restrict__ indic
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const int4 c = indices[t];  // (b, x, y, z)
-    constexpr int R = KS / 2;
+    constexpr int R = KS / 2, K3 = KS * KS * KS, NP = K3 / 2;   // offsets 0..NP-1 are probed
+    const uint32_t own = cell_id(c.x, c.y, c.z, c.w, g);
+    nbr[(long long)NP * ld + t] = t;   // centre
+    if (NP == 0) return;
+    uint32_t key[NP > 0 ? NP : 1];
+    unsigned long long first[NP > 0 ? NP : 1];
 #pragma unroll
-    for (int k0 = 0; k0 < KS; ++k0)
+    for (int o = 0; o < NP; ++o) {
+        const int k0 = o / (KS * KS), k1 = (o / KS) % KS, k2 = o % KS;
+        const int x = c.y + k0 - R, y = c.z + k1 - R, z = c.w + k2 - R;
+        const bool inb = x >= 0 && x < g.X && y >= 0 && y < g.Y && z >= 0 && z < g.Z;
+        // out-of-grid neighbours read the voxel's own slot chain head (a valid address) and are
+        // discarded below through key == own
+        key[o] = inb ? cell_id(c.x, x, y, z, g) : own;
+        first[o] = tab[hash_mix(key[o]) & mask];
+    }
 #pragma unroll
-        for (int k1 = 0; k1 < KS; ++k1)
-#pragma unroll
-            for (int k2 = 0; k2 < KS; ++k2) {
-                const int o = (k0 * KS + k1) * KS + k2;
-                const int x = c.y + k0 - R, y = c.z + k1 - R, z = c.w + k2 - R;
-                int v = -1;
-                if (k0 == R && k1 == R && k2 == R)
-                    v = t;
-                else if (x >= 0 && x < g.X && y >= 0 && y < g.Y && z >= 0 && z < g.Z)
-                    v = hash_find(tab, mask, cell_id(c.x, x, y, z, g));
-                nbr[(long long)o * ld + t] = v;
+    for (int o = 0; o < NP; ++o) {
+        int v = -1;
+        if (key[o] != own) {
+            const unsigned long long cur = first[o];
+            if ((uint32_t)(cur >> 32) == key[o]) v = (int)(uint32_t)cur;
+            else if (cur != DODA_HASH_EMPTY) {   // collision: continue along the chain
+                uint32_t slot = (hash_mix(key[o]) + 1) & mask;
+                for (;;) {
+                    const unsigned long long nx = tab[slot];
+                    if (nx == DODA_HASH_EMPTY) break;
+                    if ((uint32_t)(nx >> 32) == key[o]) { v = (int)(uint32_t)nx; break; }
+                    slot = (slot + 1) & mask;
+                }
             }
+        }
+        nbr[(long long)o * ld + t] = v;
+        if (v >= 0) nbr[(long long)(K3 - 1 - o) * ld + v] = t;
+    }
 }
 
 // ---- Down2 (kernel 2, stride 2, pad 0) ------------------------------------------------------
@@ -243,6 +269,7 @@ extern "C" int doda_rulebook_subm(const int32_t *indices, int32_t m, const int32
         return doda_check_launch();
     }
     hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
+    hipMemsetAsync(nbr + (size_t)14 * ld, 0xFF, (size_t)13 * ld * 4, s);   // mirrored half: -1 unless hit
     hipLaunchKernelGGL(subm_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g,
                        w.tab, w.cap - 1);
     hipLaunchKernelGGL((subm_probe<3>), dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g,
