@@ -794,6 +794,10 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
         if (waves_full >= 2048) GO(2, 1);
         GO(1, 1);
     }
+    if (NB == 3) {   // 48 channels: three channel blocks exactly (a <4,*> tile would load and multiply a zero block)
+        if (waves_full >= 512) GO(3, 1);   // level 3 (46k rows): <3,1> 23.2 us, <4,1> 27.8, <3,2> 22.8 (fp32 74.6)
+        GO(1, 1);
+    }
     if (NB <= 4) {
         if (waves_full >= 8192) GO(4, 2);
         if (waves_full >= 512) GO(4, 1);   // level 4 (11k rows, 64 ch): <4,1> 13.0 us, <2,1> 17.3, <2,2> 14.9
