@@ -15,7 +15,11 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdoda_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -amdgpu-mfma-vgpr-form: MFMA accumulators stay in ordinary VGPRs.  With the default (AGPR) form
+# hipcc rotated the accumulators through 8 v_accvgpr_mov per unit of the conv ring (ISA check); the
+# kernels use 40-150 VGPRs, so the unified register file has room.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 

@@ -478,13 +478,13 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
     typedef typename P::raw raw;
     constexpr unsigned OSZ = OUT32 ? 4u : (unsigned)sizeof(elem);   // output element size
     constexpr int RW = 16 * S;                 // rows per wave
-    constexpr int OPI = 64 / RW;               // table offsets fetched per load instruction
+    constexpr int OPI = 256 / RW;              // table offsets fetched per (16-byte) load instruction
     constexpr int NLD = (MAX_K + 1 + OPI - 1) / OPI;  // strips 0..MAX_K; strip MAX_K is all-OOB
     constexpr int L = S + NBW;                 // asm loads per unit
     constexpr unsigned ESZ = sizeof(elem), FSZ = sizeof(raw);
     constexpr int CH = P::CH;
     static_assert((D - 1) * L <= 63, "vmcnt field");
-    __shared__ unsigned off_tile[4][NLD * 64];
+    __shared__ __attribute__((aligned(16))) unsigned off_tile[4][(MAX_K + 1) * RW];
 
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, g = lane >> 4;
@@ -498,23 +498,33 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, y_bytes, 0x00020000);
 
     // ---- phase 0: table slice -> byte offsets in LDS, active-offset mask ----
+    // 16-byte table loads: a lane takes 4 consecutive rows of one offset, so one instruction covers
+    // OPI = 256 / RW offsets (the kernel is paced by the NUMBER of vector-memory instructions; this
+    // is 4 instead of 14 per 32-row wave).  Strip MAX_K stays all-out-of-range (the dummy unit).
     const unsigned row_bytes = (unsigned)kc * ESZ;
     unsigned active = 0;
     {
-        const int r = lane & (RW - 1), oq = lane / RW;
-        const bool row_ok = row0 + r < n_out;
+        constexpr int LPO = RW / 4;            // lanes per offset
+        const int rq = (lane % LPO) * 4, oq = lane / LPO;
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int o = j * OPI + oq;
-            const bool ok = row_ok && o < K;
-            const unsigned voff = ok ? ((unsigned)o * (unsigned)ld + (unsigned)(row0 + r)) * 4u : OOB;
-            const int idx = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_t, voff, 0, 0);
-            const bool present = ok && idx >= 0;
-            off_tile[wid][j * 64 + lane] = present ? (unsigned)idx * row_bytes : OOB;
-            const unsigned long long b = __ballot(present);
+            const bool ok = o < K && row0 + rq < n_out;
+            const unsigned voff = ok ? ((unsigned)o * (unsigned)ld + (unsigned)(row0 + rq)) * 4u : OOB;
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_t, voff, 0, 0);
+            u32x4 off;
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool present = ok && row0 + rq + k < n_out && (int)t[k] >= 0;
+                off[k] = present ? t[k] * row_bytes : OOB;
+                any |= present;
+            }
+            if (o <= MAX_K) *reinterpret_cast<u32x4 *>(&off_tile[wid][o * RW + rq]) = off;
+            const unsigned long long b = __ballot(any);
 #pragma unroll
             for (int q = 0; q < OPI; ++q) {
-                const unsigned long long part = (RW == 64) ? b : ((b >> (q * RW)) & ((1ull << (RW & 63)) - 1ull));
+                const unsigned long long part = (b >> (q * LPO)) & ((1ull << LPO) - 1ull);
                 if (part != 0ull && j * OPI + q < 32) active |= 1u << (j * OPI + q);
             }
         }
@@ -564,9 +574,12 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                 // buffer are the all-zero dummies (odd offset count, ring top-up)
                 const int osel = have ? (second ? o2 : o) : MAX_K;
                 const unsigned *p = my_off + osel * RW;
+                unsigned off[S];   // all LDS reads first (one ds_read2 / one wait), then the gathers
 #pragma unroll
-                for (int s = 0; s < S; ++s) P::gather(xr[s], p[s * 16] + lane_x, rs_x, 0u);
-                const unsigned voff_w = (unsigned)osel * ((unsigned)NB * 32u * FSZ) + lane_w;
+                for (int s = 0; s < S; ++s) off[s] = p[s * 16];
+#pragma unroll
+                for (int s = 0; s < S; ++s) P::gather(xr[s], off[s] + lane_x, rs_x, 0u);
+                const unsigned voff_w = __umul24((unsigned)osel, (unsigned)NB * 32u * FSZ) + lane_w;
                 const unsigned soff_w = (unsigned)nb0 * 32u * FSZ;
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb) P::load(wr[nb], voff_w, rs_w, soff_w + nb * 32u * FSZ);
@@ -585,8 +598,11 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
             const bool lane_ok = have && (cc * CH + lane_c < kc);
             const unsigned *p = my_off + (lane_ok ? o : MAX_K) * RW;
             const unsigned soff_x = (unsigned)cc * (unsigned)CH * ESZ;
+            unsigned off[S];
 #pragma unroll
-            for (int s = 0; s < S; ++s) P::gather(xr[s], p[s * 16] + lane_x, rs_x, soff_x);
+            for (int s = 0; s < S; ++s) off[s] = p[s * 16];
+#pragma unroll
+            for (int s = 0; s < S; ++s) P::gather(xr[s], off[s] + lane_x, rs_x, soff_x);
             const unsigned soff_w = (unsigned)((o * n_chunk + cc) * NB + nb0) * 64u * FSZ;
             const unsigned voff_w = have ? lane_w : OOB;
 #pragma unroll
