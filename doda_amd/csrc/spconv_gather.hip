@@ -799,6 +799,13 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
         // (two channel blocks / 32-row tiles per split block were tried at level 4: 14.2 us against
         // 13.0 us for the unsplit <4,1> tile, so the split stays at one block, 16 rows)
         if (fast && (long long)K * n_chunk >= 12 && waves_full * NB <= 1024) GS(1, 1);
+        // mid levels, 3-4 channel blocks: 32-row split blocks load each weight fragment once per 32
+        // rows instead of once per 16 (level 3, 46k rows x 48 ch: 22.0 -> 19.6 us; level 4, 11k x 64:
+        // 13.9 -> 11.9 us); 64-row split blocks and 2-block layers lose (23.2 / 36.3 us)
+        if (fast && (long long)K * n_chunk >= 12) {
+            if (NB == 3 && waves_full >= 512 && waves_full < 8192) GS(3, 2);
+            if (NB == 4 && waves_full >= 512 && waves_full < 2048) GS(4, 2);
+        }
 #undef GS
     }
     if (NB == 1) {  // measured at M = 600k, 16 ch: S=2 51 us, S=4 56 us, S=1 56 us
