@@ -222,9 +222,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__re
                     const bool live = idx[oo] >= 0 && ca0 + f * VEC < ca;
                     *reinterpret_cast<vec *>(&my_a[lane * SA + f * VEC]) = (VOK && !live) ? vec{} : rows_cur[f];
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                // LDS operations of one wave are processed in issue order, so the transposed reads
+                // below see the stores above (and the next offset's stores cannot overtake these
+                // reads) without a counter wait; only the compiler has to be kept from reordering
                 __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                 for (int x_ = 0; x_ < TA; ++x_) {
                     kfrag af[T::KSTEPS];
@@ -235,9 +236,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__re
                         for (int y_ = 0; y_ < TB; ++y_)
                             acc[oo][x_][y_] = T::mma(af[ks], bf[y_][ks], acc[oo][x_][y_]);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
 #pragma unroll
             for (int f = 0; f < NVA; ++f) rows_cur[f] = rows_nxt[f];
