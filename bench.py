@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, MI355X_MICROARCH.md
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
                    help="feature storage dtype; bf16 = BASELINE config 2 (fp32 accumulate, fp32 weights)")
     p.add_argument("--scenes", type=int, default=4, help="scenes per GPU (BATCH_SIZE_PER_GPU)")
@@ -99,7 +99,7 @@ def kernel_roofline(batch_dev, dtype, reps):
     out["subm16_fwd_bwd"] = {"us": t_all * 1e6, "GBs": (b_f + b_b) / t_all / 1e9,
                              "frac_of_hbm_peak": (b_f + b_b) / t_all / 1e9 / HBM_PEAK_GBS}
     dom = "subm16_fwd"
-    kname = "conv_fast<PF32,1,2,8>" if dtype == "f32" else "conv_fast<PBF16P,1,2,8>"
+    kname = "conv_fast<PF32,1,2,3>" if dtype == "f32" else "conv_fast<PBF16P,1,2,3>"
     traffic, traffic_src = pmc_traffic(dtype)
     roof = {"kernel": "%s (SubMConv3d 16->16 fwd gather, M=%d, P=%d)" % (kname, m, pairs_total),
             "bound": "hbm", "achieved": out[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
