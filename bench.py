@@ -176,7 +176,7 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        scores = voxelize_and_run(cfg, model, batch_dev, dev, feature_dtype=fdt)
+        scores = voxelize_and_run(cfg, model, batch_dev, dev, feature_dtype=fdt, inputs_ready=True)
         loss = cross_entropy(scores, labels, ignore_index=255)
         loss.backward()
         opt.step()

@@ -42,6 +42,10 @@ _SIGNATURES = {
     "doda_spconv_pack_multi": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "doda_spconv_gather_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
                                        c_i32, c_vp, c_sz, c_vp]),
+    "doda_spconv_gather_add_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp,
+                                           c_i32, c_vp, c_sz, c_vp]),
+    "doda_spconv_gather_add_bf16": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp,
+                                            c_i32, c_i32, c_vp, c_sz, c_vp]),
     "doda_spconv_wgrad_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "doda_spconv_wgrad_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
                                       c_vp, c_sz, c_vp]),

@@ -44,6 +44,7 @@ struct F32 {
     typedef f32x4 frag;  // 4 channels of one row / 4 k-slots of a weight column
     static __device__ __forceinline__ frag zero() { return (frag){0.f, 0.f, 0.f, 0.f}; }
     static __device__ __forceinline__ elem from_float(float f) { return f; }
+    static __device__ __forceinline__ float to_float(elem e) { return e; }
     static __device__ __forceinline__ void mma(f32x4 &acc, const frag &w, const frag &x) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q], x[q], acc, 0, 0, 0);
@@ -58,6 +59,7 @@ struct BF16 {
     typedef s16x4 frag;
     static __device__ __forceinline__ frag zero() { return (frag){0, 0, 0, 0}; }
     static __device__ __forceinline__ elem from_float(float f) { return f2bf(f); }
+    static __device__ __forceinline__ float to_float(elem e) { return __uint_as_float((unsigned)e << 16); }
     static __device__ __forceinline__ void mma(f32x4 &acc, const frag &w, const frag &x) {
         acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w, x, acc, 0, 0, 0);
     }
@@ -208,7 +210,8 @@ __global__ __launch_bounds__(256) void conv_gather(const typename T::elem *__res
                                                    const typename T::frag *__restrict__ wp, int nc,
                                                    int NB, const int32_t *__restrict__ tbl, int ld,
                                                    int K, int n_out,
-                                                   typename T::elem *__restrict__ y, int vec_ok) {
+                                                   typename T::elem *__restrict__ y, int vec_ok,
+                                                   const typename T::elem *__restrict__ res) {
     typedef typename T::frag frag;
     typedef typename T::elem elem;
     constexpr int TM = 4 * 16 * S;  // rows per block
@@ -317,6 +320,11 @@ __global__ __launch_bounds__(256) void conv_gather(const typename T::elem *__res
                 const int col = (nb0 + nb) * 16 + 4 * g;
                 if (nb0 + nb < NB) {
                     elem *p = y + t * nc + col;
+                    if (res) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col + r < nc) acc[s][nb][r] += T::to_float(res[t * nc + col + r]);
+                    }
                     if (vec_ok && col + 3 < nc) {
                         T::store4(p, acc[s][nb]);
                     } else {
@@ -473,7 +481,8 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                                                  unsigned wp_bytes, int nc, int NB,
                                                  const int32_t *__restrict__ tbl,
                                                  unsigned tbl_bytes, int ld, int K, int n_out,
-                                                 void *__restrict__ y, unsigned y_bytes) {
+                                                 void *__restrict__ y, unsigned y_bytes,
+                                                 const void *__restrict__ res) {
     typedef typename P::elem elem;
     typedef typename P::raw raw;
     constexpr unsigned OSZ = OUT32 ? 4u : (unsigned)sizeof(elem);   // output element size
@@ -685,6 +694,20 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
         for (int nb = 0; nb < NBW; ++nb) {
             const unsigned col = (unsigned)((nb0 + nb) * 16 + 4 * g);
             const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * (unsigned)nc + col) * OSZ : OOB;
+            if (res) {   // y = conv + res (residual add of the block fused into the store; res has y's dtype)
+                const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, y_bytes, 0x00020000);
+                if (OUT32 || sizeof(elem) == 4) {
+                    const f32x4 r4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, voff, 0, 0));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[s][nb][q] += r4[q];
+                } else {
+                    const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rs_r, voff, 0, 0);
+                    acc[s][nb][0] += __uint_as_float(r2[0] << 16);
+                    acc[s][nb][1] += __uint_as_float(r2[0] & 0xffff0000u);
+                    acc[s][nb][2] += __uint_as_float(r2[1] << 16);
+                    acc[s][nb][3] += __uint_as_float(r2[1] & 0xffff0000u);
+                }
+            }
             store_frag<P, OUT32>(acc[s][nb], rs_y, voff);
         }
     }
@@ -693,7 +716,7 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
 template <class P, int NBW, int S, bool SPLIT = false>
 int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_bytes, int nc, int NB,
                 const int32_t *tbl, int ld, int K, int n_out, long long n_in, void *y, bool out32,
-                hipStream_t s) {
+                const void *res, hipStream_t s) {
     const dim3 grid(div_up(n_out, (SPLIT ? 1 : 4) * 16 * S) * div_up(NB, NBW)), block(256);
     // Ring depth.  Re-measured after the EXEC-masked gathers and the wide / pair units went in: with
     // every load hitting L1 (ablation) the kernel time did not move, i.e. the unit loop is paced by
@@ -705,11 +728,11 @@ int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_byt
     if (out32 && sizeof(typename P::elem) != 4) {
         const unsigned yb = (unsigned)((size_t)n_out * nc * 4);
         hipLaunchKernelGGL((conv_fast<P, NBW, S, D, true, SPLIT>), grid, block, 0, s, x, xb, kc, wp,
-                           (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb);
+                           (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res);
     } else {
         const unsigned yb = (unsigned)((size_t)n_out * nc * sizeof(typename P::elem));
         hipLaunchKernelGGL((conv_fast<P, NBW, S, D, false, SPLIT>), grid, block, 0, s, x, xb, kc, wp,
-                           (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb);
+                           (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res);
     }
     return doda_check_launch();
 }
@@ -717,10 +740,10 @@ int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_byt
 template <class T, int NBW, int S>
 int launch(const typename T::elem *x, int kc, const typename T::frag *wp, int nc, int NB,
            const int32_t *tbl, int ld, int K, int n_out, typename T::elem *y, int vec_ok,
-           hipStream_t s) {
+           const typename T::elem *res, hipStream_t s) {
     const dim3 grid(div_up(n_out, 4 * 16 * S) * div_up(NB, NBW)), block(256);
     hipLaunchKernelGGL((conv_gather<T, NBW, S>), grid, block, 0, s, x, kc, wp, nc, NB, tbl, ld, K,
-                       n_out, y, vec_ok);
+                       n_out, y, vec_ok, res);
     return doda_check_launch();
 }
 
@@ -739,7 +762,7 @@ inline int pack_mode(int K, int kc, int elem_bytes) {
 template <class T>
 int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tbl, int ld, int K,
                int n_out, void *y_, int wl, void *ws, size_t ws_bytes, long long n_in, bool out32,
-               hipStream_t s) {
+               const void *res, hipStream_t s) {
     typedef typename T::elem elem;
     typedef typename T::frag frag;
     const elem *x = (const elem *)x_;
@@ -782,19 +805,19 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     typedef typename FastPolicy<T>::pair PP;
 #define GO(NBW, S)                                                                                 \
     do {                                                                                           \
-        if (wide) return launch_fast<PW, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
-        if (pair) return launch_fast<PP, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
-        if (fast) return launch_fast<PN, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
-        return launch<T, NBW, S>(x, kc, (const frag *)wp, nc, NB, tbl, ld, K, n_out, y, vec_ok, s); \
+        if (wide) return launch_fast<PW, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, s); \
+        if (pair) return launch_fast<PP, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, s); \
+        if (fast) return launch_fast<PN, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, s); \
+        return launch<T, NBW, S>(x, kc, (const frag *)wp, nc, NB, tbl, ld, K, n_out, y, vec_ok, (const elem *)res, s); \
     } while (0)
     {   // few rows, long unit chains: split the offsets of a 16-row tile over the block's waves
         // measured (rocprofv3, per dispatch): 795 / 210 / 49 blocks 12.7 -> 9.5, 12.2 -> 6.1,
         // 16.0 -> 6.3 us; 2808 blocks (level 4) 18.0 -> 24.7 us, so only below ~1k blocks
 #define GS(NBW, S)                                                                                 \
     do {                                                                                           \
-        if (wide) return launch_fast<PW, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
-        if (pair) return launch_fast<PP, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
-        return launch_fast<PN, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, s); \
+        if (wide) return launch_fast<PW, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, s); \
+        if (pair) return launch_fast<PP, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, s); \
+        return launch_fast<PN, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, s); \
     } while (0)
         // (two channel blocks / 32-row tiles per split block were tried at level 4: 14.2 us against
         // 13.0 us for the unsplit <4,1> tile, so the split stays at one block, 16 rows)
@@ -893,7 +916,18 @@ extern "C" int doda_spconv_gather_f32(const float *x, int32_t n_in, int32_t kc, 
                                       doda_stream_t stream) {
     int st;
     if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
-    return run_gather<F32>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, false,
+    return run_gather<F32>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, false, nullptr,
+                           as_stream(stream));
+}
+
+extern "C" int doda_spconv_gather_add_f32(const float *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
+                                          const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
+                                          const float *res, float *y, int32_t w_layout, void *ws,
+                                          size_t ws_bytes, doda_stream_t stream) {
+    int st;
+    if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
+    if (!res) return DODA_ERR_INVALID;
+    return run_gather<F32>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, false, res,
                            as_stream(stream));
 }
 
@@ -904,5 +938,17 @@ extern "C" int doda_spconv_gather_bf16(const uint16_t *x, int32_t n_in, int32_t 
     int st;
     if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
     return run_gather<BF16>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, y_is_f32 != 0,
-                            as_stream(stream));
+                            nullptr, as_stream(stream));
+}
+
+extern "C" int doda_spconv_gather_add_bf16(const uint16_t *x, int32_t n_in, int32_t kc, const float *w,
+                                           int32_t nc, const int32_t *tbl, int32_t ld, int32_t K,
+                                           int32_t n_out, const void *res, void *y, int32_t y_is_f32,
+                                           int32_t w_layout, void *ws, size_t ws_bytes,
+                                           doda_stream_t stream) {
+    int st;
+    if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
+    if (!res) return DODA_ERR_INVALID;
+    return run_gather<BF16>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, y_is_f32 != 0,
+                            res, as_stream(stream));
 }

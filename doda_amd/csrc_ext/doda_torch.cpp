@@ -32,7 +32,8 @@ inline int elem_bytes(const at::Tensor &t) {
 
 // y[t] = sum_o x[tbl[o][t]] . B_o   (include/doda_hip.h: doda_spconv_gather_*)
 at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
-                  const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32) {
+                  const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32,
+                  const c10::optional<at::Tensor> &residual = c10::nullopt) {
     const at::Tensor x = x_in.contiguous();
     TORCH_CHECK(x.is_cuda() && x.dim() == 2 && tbl.is_cuda() && tbl.dim() == 2, "doda gather: bad inputs");
     const int esz = elem_bytes(x);
@@ -40,6 +41,12 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
     void *st = stream_of(x);
     const bool f32_out = esz == 4 || out_f32;
     at::Tensor y = at::empty({n_out, nc}, x.options().dtype(f32_out ? at::kFloat : at::kBFloat16));
+    at::Tensor res;   // y = conv + res (doda_spconv_gather_add_*)
+    if (residual.has_value() && residual->defined()) {
+        res = residual->contiguous();
+        TORCH_CHECK(res.is_cuda() && res.scalar_type() == y.scalar_type() && res.dim() == 2 &&
+                    res.size(0) == n_out && res.size(1) == nc, "doda gather: residual must be [n_out, nc] in the output dtype");
+    }
     const void *wptr;
     void *ws = nullptr;
     size_t ws_bytes = 0;
@@ -60,14 +67,24 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
             lay = (int)layout;
         }
         int status;
-        if (esz == 4)
+        if (esz == 4 && !res.defined())
             status = doda_spconv_gather_f32((const float *)x.data_ptr(), (int)x.size(0), (int)kc, (const float *)wptr,
                                             (int)nc, (const int32_t *)tbl.data_ptr(), (int)ld, (int)K, (int)n_out,
                                             (float *)y.data_ptr(), lay, ws, ws_bytes, st);
-        else
+        else if (esz == 4)
+            status = doda_spconv_gather_add_f32((const float *)x.data_ptr(), (int)x.size(0), (int)kc,
+                                                (const float *)wptr, (int)nc, (const int32_t *)tbl.data_ptr(), (int)ld,
+                                                (int)K, (int)n_out, (const float *)res.data_ptr(),
+                                                (float *)y.data_ptr(), lay, ws, ws_bytes, st);
+        else if (!res.defined())
             status = doda_spconv_gather_bf16((const uint16_t *)x.data_ptr(), (int)x.size(0), (int)kc,
                                              (const float *)wptr, (int)nc, (const int32_t *)tbl.data_ptr(), (int)ld,
                                              (int)K, (int)n_out, y.data_ptr(), out_f32 ? 1 : 0, lay, ws, ws_bytes, st);
+        else
+            status = doda_spconv_gather_add_bf16((const uint16_t *)x.data_ptr(), (int)x.size(0), (int)kc,
+                                                 (const float *)wptr, (int)nc, (const int32_t *)tbl.data_ptr(), (int)ld,
+                                                 (int)K, (int)n_out, res.data_ptr(), y.data_ptr(), out_f32 ? 1 : 0,
+                                                 lay, ws, ws_bytes, st);
         if (status == DODA_ERR_UNSUPPORTED && use_packed) {  // fast path refused the pre-packed weights
             use_packed = false;
             continue;
@@ -99,18 +116,21 @@ at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tenso
     return dw;
 }
 
-// features, weight [k,k,k,Cin,Cout], fwd_tbl, bwd_tbl, n_out, bwd_layout, packed fwd / data-grad
+// features, weight [k,k,k,Cin,Cout], fwd_tbl, bwd_tbl, n_out, bwd_layout, packed fwd / data-grad,
+// optional residual (y = conv + residual; its gradient is the incoming gradient itself)
 struct IndiceConvFn : public torch::autograd::Function<IndiceConvFn> {
     static at::Tensor forward(AutogradContext *ctx, const at::Tensor &features, const at::Tensor &weight,
                               const at::Tensor &fwd_tbl, const at::Tensor &bwd_tbl, int64_t n_out,
                               int64_t bwd_layout, const c10::optional<at::Tensor> &pk_fwd,
-                              const c10::optional<at::Tensor> &pk_bwd) {
+                              const c10::optional<at::Tensor> &pk_bwd,
+                              const c10::optional<at::Tensor> &residual) {
         const int64_t cin = weight.size(-2), cout = weight.size(-1), K = fwd_tbl.size(0);
         ctx->save_for_backward({features, weight, fwd_tbl, bwd_tbl,
                                 pk_bwd.has_value() && pk_bwd->defined() ? *pk_bwd : at::Tensor()});
         ctx->saved_data["n_out"] = n_out;
         ctx->saved_data["bwd_layout"] = bwd_layout;
-        return gather(features, weight.reshape({K, cin, cout}), pk_fwd, fwd_tbl, n_out, 0, cout, false);
+        ctx->saved_data["res_grad"] = residual.has_value() && residual->defined() && residual->requires_grad();
+        return gather(features, weight.reshape({K, cin, cout}), pk_fwd, fwd_tbl, n_out, 0, cout, false, residual);
     }
     static tensor_list backward(AutogradContext *ctx, tensor_list grads) {
         const auto saved = ctx->get_saved_variables();
@@ -125,14 +145,17 @@ struct IndiceConvFn : public torch::autograd::Function<IndiceConvFn> {
                             pk_bwd.defined() ? c10::optional<at::Tensor>(pk_bwd) : c10::nullopt, bwd_tbl,
                             features.size(0), bwd_layout, cin, false);
         if (ctx->needs_input_grad(1)) d_w = wgrad(features, dy, fwd_tbl, n_out).reshape(weight.sizes()).to(weight.scalar_type());
-        return {d_feat, d_w, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+        at::Tensor d_res;
+        if (ctx->saved_data["res_grad"].toBool()) d_res = grads[0];
+        return {d_feat, d_w, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), d_res};
     }
 };
 
 at::Tensor indice_conv(const at::Tensor &features, const at::Tensor &weight, const at::Tensor &fwd_tbl,
                        const at::Tensor &bwd_tbl, int64_t n_out, int64_t bwd_layout,
-                       const c10::optional<at::Tensor> &pk_fwd, const c10::optional<at::Tensor> &pk_bwd) {
-    return IndiceConvFn::apply(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd);
+                       const c10::optional<at::Tensor> &pk_fwd, const c10::optional<at::Tensor> &pk_bwd,
+                       const c10::optional<at::Tensor> &residual) {
+    return IndiceConvFn::apply(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd, residual);
 }
 
 // ---- fused BatchNorm1d(+ReLU) ----------------------------------------------------------------
@@ -211,7 +234,10 @@ at::Tensor bn_relu(const at::Tensor &x, const at::Tensor &weight, const at::Tens
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("indice_conv", &indice_conv, "sparse conv (gather table) with autograd");
     m.def("bn_relu", &bn_relu, "fused BatchNorm1d(+ReLU) with autograd");
-    m.def("gather", &gather, "raw gather-GEMM");
+    m.def("gather", [](const at::Tensor &x, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
+                       const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32) {
+        return gather(x, w, packed, tbl, n_out, layout, nc, out_f32);
+    }, "raw gather-GEMM");
     m.def("wgrad", &wgrad, "raw weight gradient");
     m.def("abi_version", []() { return doda_abi_version(); });
 }

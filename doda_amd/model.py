@@ -62,9 +62,9 @@ class ResidualBlock(SparseModule):
 
     def forward(self, input):
         skip = self.i_branch(_shallow(input))
-        out = self.conv_branch(input)
-        out.features += skip.features
-        return out
+        # reference: output = conv_branch(input); output.features += i_branch(identity).features
+        # (model/unet_block.py:33-37).  Here the add rides in the last convolution's store.
+        return self.conv_branch(input, residual=skip.features)
 
 
 class VGGBlock(SparseModule):
@@ -190,8 +190,39 @@ class SparseConvNet(nn.Module):
         return (point_feats, scores) if return_mid_feat else scores
 
 
-def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fused_head=True):
-    """reference model/unet.py:72-99 (test_model_feat): H2D, voxel mean-pooling, network."""
+_PYR_STREAMS = {}
+
+
+def _prebuild_pyramid(voxel_coords, spatial_shape, batch_size, n_levels, device):
+    """Build the int32 indices and all rulebooks on a side stream that does NOT wait for the main
+    stream.  Rulebooks depend only on the voxel coordinates; built at the head of the forward pass on
+    the main stream, each of their six size read-backs blocks the host until the previous step's
+    whole backward has drained, and the GPU then idles while the host catches up (measured: 1.1 ms of
+    wall time per step for 0.55 ms of kernels).  Only valid when `voxel_coords` has no producer work
+    pending on any stream (a resident batch) — the caller opts in.
+    Returns (indices int32, indice_dict); every tensor is handed over to the main stream."""
+    main = torch.cuda.current_stream(device)
+    side = _PYR_STREAMS.get(device)
+    if side is None:
+        side = _PYR_STREAMS[device] = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(side):
+        idx32 = voxel_coords.int()
+        probe = spconv.SparseConvTensor(None, idx32, spatial_shape, batch_size)
+        spconv.ops.build_pyramid(probe, n_levels)
+    main.wait_stream(side)
+    idx32.record_stream(main)
+    for data in probe.indice_dict.values():
+        for t in vars(data).values():
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(main)
+    return idx32, probe.indice_dict
+
+
+def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fused_head=True,
+                     inputs_ready=False):
+    """reference model/unet.py:72-99 (test_model_feat): H2D, voxel mean-pooling, network.
+    inputs_ready: the batch is resident on `device` with no copy or kernel still producing it, so the
+    rulebooks may be built on a side stream ahead of the main stream's queue (_prebuild_pyramid)."""
     voxel_coords = batch["voxel_locs"].to(device, non_blocking=True)
     p2v = batch["p2v_map"].to(device, non_blocking=True)
     v2p = batch["v2p_map"].to(device, non_blocking=True)
@@ -200,8 +231,16 @@ def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fus
         feats = torch.cat((feats, batch["locs_float"].to(device, non_blocking=True)), 1)
     voxel_feats = pointgroup_ops.voxelization(feats, v2p, cfg.DATA_CONFIG.DATA_PROCESSOR.voxel_mode)
     batch_size = batch["offsets"].numel() - 1
-    inp = spconv.SparseConvTensor(voxel_feats.to(feature_dtype), voxel_coords.int(),
-                                  batch["spatial_shape"], batch_size)
+    net = model.module if hasattr(model, "module") else model
+    if (inputs_ready and batch["voxel_locs"].is_cuda and voxel_coords.shape[0] > 0
+            and hasattr(net, "unet") and device.type == "cuda"):
+        idx32, pyramid = _prebuild_pyramid(voxel_coords, batch["spatial_shape"], batch_size,
+                                           len(net.unet.nPlanes), device)
+        inp = spconv.SparseConvTensor(voxel_feats.to(feature_dtype), idx32, batch["spatial_shape"], batch_size)
+        inp.indice_dict.update(pyramid)
+    else:
+        inp = spconv.SparseConvTensor(voxel_feats.to(feature_dtype), voxel_coords.int(),
+                                      batch["spatial_shape"], batch_size)
     if fused_head:
         return model(inp, p2v, v2p_map=v2p)
     return model(inp, p2v)

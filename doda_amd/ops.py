@@ -211,11 +211,11 @@ def _feat_ok(x, name):
         raise RuntimeError("%s must be a contiguous [rows, channels] tensor" % name)
 
 
-def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None):
+def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, residual=None):
     """y[t] = sum_o x[tbl[o][t]] @ B_o (see doda_hip.h).  x: [n_in,kc] f32|bf16; w: fp32 weights
     viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2), or `packed`: the fragment-packed buffer
     produced by PackPlan for this (weight, layout, dtype).  Returns y [n_out, nc] in x.dtype (or
-    float32 when out_f32)."""
+    float32 when out_f32); with `residual` ([n_out, nc], dtype of y) returns conv + residual."""
     _feat_ok(x, "x")
     _need_cuda(tbl)
     K, ld = tbl.shape
@@ -234,16 +234,31 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None):
             raise RuntimeError("weight must be float32 with K*kc*nc = %d elements" % (K * kc * nc))
         ws = _ws(lib().doda_spconv_gather_workspace_bytes(K, kc, nc, esz), x.device)
         w_ptr, ws_ptr, ws_n, layout = _p(w), _p(ws), ws.numel(), int(w_layout)
+    ydt = torch.float32 if (x.dtype == torch.float32 or out_f32) else torch.bfloat16
+    if residual is not None:
+        _need_cuda(residual)
+        if residual.dtype != ydt or tuple(residual.shape) != (n_out, nc) or not residual.is_contiguous():
+            raise RuntimeError("residual must be a contiguous [n_out, nc] tensor in the output dtype")
     if x.dtype == torch.float32:
         y = torch.empty((n_out, nc), dtype=torch.float32, device=x.device)
-        check(lib().doda_spconv_gather_f32(_p(x), x.shape[0], kc, w_ptr, nc, _p(tbl), ld, K, n_out,
-                                           _p(y), layout, ws_ptr, ws_n, _stream()),
-              "doda_spconv_gather_f32")
+        if residual is None:
+            check(lib().doda_spconv_gather_f32(_p(x), x.shape[0], kc, w_ptr, nc, _p(tbl), ld, K, n_out,
+                                               _p(y), layout, ws_ptr, ws_n, _stream()),
+                  "doda_spconv_gather_f32")
+        else:
+            check(lib().doda_spconv_gather_add_f32(_p(x), x.shape[0], kc, w_ptr, nc, _p(tbl), ld, K, n_out,
+                                                   _p(residual), _p(y), layout, ws_ptr, ws_n, _stream()),
+                  "doda_spconv_gather_add_f32")
     elif x.dtype == torch.bfloat16:
-        y = torch.empty((n_out, nc), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
-        check(lib().doda_spconv_gather_bf16(_p(x), x.shape[0], kc, w_ptr, nc, _p(tbl), ld, K, n_out,
-                                            _p(y), int(bool(out_f32)), layout, ws_ptr, ws_n, _stream()),
-              "doda_spconv_gather_bf16")
+        y = torch.empty((n_out, nc), dtype=ydt, device=x.device)
+        if residual is None:
+            check(lib().doda_spconv_gather_bf16(_p(x), x.shape[0], kc, w_ptr, nc, _p(tbl), ld, K, n_out,
+                                                _p(y), int(bool(out_f32)), layout, ws_ptr, ws_n, _stream()),
+                  "doda_spconv_gather_bf16")
+        else:
+            check(lib().doda_spconv_gather_add_bf16(_p(x), x.shape[0], kc, w_ptr, nc, _p(tbl), ld, K, n_out,
+                                                    _p(residual), _p(y), int(bool(out_f32)), layout, ws_ptr,
+                                                    ws_n, _stream()), "doda_spconv_gather_add_bf16")
     else:
         raise RuntimeError("spconv_gather: unsupported feature dtype %s" % x.dtype)
     return y

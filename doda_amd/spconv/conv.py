@@ -64,6 +64,8 @@ def _repack_all(device, esz):
 
 
 class SparseConvolution(SparseModule):
+    supports_residual = True   # forward(input, residual=...) adds a feature matrix to the output
+
     def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0,
                  dilation=1, groups=1, bias=True, subm=False, output_padding=0, transposed=False,
                  inverse=False, indice_key=None, fused_bn=False, use_hash=False):
@@ -127,7 +129,9 @@ class SparseConvolution(SparseModule):
             st = self._doda_packed[esz]
         return st[2], st[3]
 
-    def forward(self, input):
+    def forward(self, input, residual=None):
+        """residual (extension over spconv): optional feature matrix added to the output, fused into the
+        native kernel's store for 3x3x3 SubM convolutions (`y = conv(x) + residual`)."""
         assert isinstance(input, SparseConvTensor)
         features = input.features
         indices = input.indices
@@ -151,6 +155,8 @@ class SparseConvolution(SparseModule):
                 out_features = torch.mm(features, w2.to(features.dtype))
             if self.bias is not None:
                 out_features = out_features + self.bias.to(features.dtype)
+            if residual is not None:
+                out_features = out_features + residual
             out = SparseConvTensor(out_features, indices, spatial_shape, batch_size)
             out.indice_dict = input.indice_dict
             out.grid = input.grid
@@ -186,10 +192,16 @@ class SparseConvolution(SparseModule):
                     input.indice_dict[self.indice_key] = data
             outids, out_spatial_shape = data.outids, data.out_spatial_shape
             if self.subm:
-                out_features = Fsp.indice_subm_conv(features, weight, data, packed)
+                fuse = (residual is not None and features.is_cuda and residual.dtype == features.dtype
+                        and tuple(residual.shape) == (outids.shape[0], self.out_channels))
+                out_features = Fsp.indice_subm_conv(features, weight, data, packed, residual if fuse else None)
+                if fuse:
+                    residual = None
             else:
                 out_features = Fsp.indice_conv(features, weight, data, packed)
 
+        if residual is not None:
+            out_features = out_features + residual
         if self.bias is not None:
             out_features = out_features + self.bias.to(out_features.dtype)
         out = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)

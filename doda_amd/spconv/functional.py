@@ -27,15 +27,15 @@ _SIDE = {}
 _SERIAL = os.environ.get("DODA_OVERLAP_BWD", "0") != "1"
 
 
-def _gather(x, w, tbl, n_out, layout, nc, packed):
+def _gather(x, w, tbl, n_out, layout, nc, packed, residual=None):
     """spconv_gather through the pre-packed weights; falls back to packing inside the call when the
     native fast path refuses them (unaligned or > 2 GB feature matrices use the generic kernel)."""
     if packed is not None:
         try:
-            return _ops.spconv_gather(x, w, tbl, n_out, layout, nc, packed=packed)
+            return _ops.spconv_gather(x, w, tbl, n_out, layout, nc, packed=packed, residual=residual)
         except _ops.DodaNativeError:
             pass
-    return _ops.spconv_gather(x, w, tbl, n_out, layout, nc)
+    return _ops.spconv_gather(x, w, tbl, n_out, layout, nc, residual=residual)
 
 
 def _side_stream(device):
@@ -62,14 +62,15 @@ def _backward_pair(need_dx, need_dw, dgrad_fn, wgrad_fn, device):
 
 class _IndiceConv(Function):
     @staticmethod
-    def forward(ctx, features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed):
+    def forward(ctx, features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual=None):
         K = fwd_tbl.shape[0]
         cin, cout = weight.shape[-2], weight.shape[-1]
         w = weight.reshape(K, cin, cout)
         ctx.save_for_backward(features, weight)
         pk_fwd, pk_bwd = packed if packed is not None else (None, None)
         ctx.tables = (fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_bwd)
-        return _gather(features.contiguous(), w, fwd_tbl, n_out, 0, cout, pk_fwd)
+        return _gather(features.contiguous(), w, fwd_tbl, n_out, 0, cout, pk_fwd,
+                       None if residual is None else residual.contiguous())
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -84,7 +85,7 @@ class _IndiceConv(Function):
             lambda: _gather(dy, w, bwd_tbl, features.shape[0], bwd_layout, cin, pk_bwd),
             lambda: _ops.spconv_wgrad(features.contiguous(), dy, fwd_tbl, n_out).reshape(weight.shape).to(weight.dtype),
             dy.device)
-        return d_feat, d_w, None, None, None, None, None
+        return d_feat, d_w, None, None, None, None, None, (grad_output if ctx.needs_input_grad[7] else None)
 
 
 class _Conv1x1(Function):
@@ -113,11 +114,13 @@ class _Conv1x1(Function):
         return d_feat, d_w, None, None
 
 
-def _conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed):
+def _conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual=None):
+    """residual: optional [n_out, Cout] tensor in the output dtype; returns conv + residual with the
+    add fused into the kernel's store (the residual's gradient is the incoming gradient)."""
     if _ext is not None and _SERIAL:   # compiled autograd glue (no Python per launch)
         pk_fwd, pk_bwd = packed if packed is not None else (None, None)
-        return _ext.indice_conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd)
-    return _IndiceConv.apply(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed)
+        return _ext.indice_conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd, residual)
+    return _IndiceConv.apply(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual)
 
 
 def conv1x1(features, weight, ident, packed=None):
@@ -126,8 +129,8 @@ def conv1x1(features, weight, ident, packed=None):
     return _Conv1x1.apply(features, weight, ident, packed)
 
 
-def indice_subm_conv(features, weight, data, packed=None):
-    return _conv(features, weight, data.tbl, data.tbl, data.outids.shape[0], 2, packed)
+def indice_subm_conv(features, weight, data, packed=None, residual=None):
+    return _conv(features, weight, data.tbl, data.tbl, data.outids.shape[0], 2, packed, residual)
 
 
 def indice_conv(features, weight, data, packed=None):

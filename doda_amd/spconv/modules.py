@@ -59,14 +59,20 @@ class SparseSequential(SparseModule):
                 raise KeyError("name exists")
         self.add_module(name, module)
 
-    def forward(self, input):
+    def forward(self, input, residual=None):
+        """residual (extension over spconv): feature matrix added to the output of the sequence; when
+        the last module is a sparse convolution the add is fused into its kernel."""
         mods = list(self._modules.values())
         k = 0
         while k < len(mods):
             module = mods[k]
             k += 1
             if is_spconv_module(module):
-                input = module(input)
+                if residual is not None and k == len(mods) and getattr(module, "supports_residual", False):
+                    input = module(input, residual=residual)
+                    residual = None
+                else:
+                    input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
                     if _dnn.fusable(module, input.features):
@@ -78,4 +84,6 @@ class SparseSequential(SparseModule):
                         input.features = module(input.features)
             else:
                 input = module(input)
+        if residual is not None:
+            input.features = input.features + residual
         return input

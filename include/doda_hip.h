@@ -173,6 +173,19 @@ int doda_spconv_gather_bf16(const uint16_t *x, int32_t n_in, int32_t kc, const f
                             int32_t y_is_f32, int32_t w_layout, void *ws, size_t ws_bytes,
                             doda_stream_t stream);
 
+/* Same with the block's residual add fused into the store:  y = (sum_o x[tbl[o][t]] . B_o) + res,
+ * res: [n_out, nc] in the dtype of y (fp32 when y_is_f32).  Replaces the `output.features +=
+ * identity.features` of the reference's ResidualBlock (model/unet_block.py:36) when the caller
+ * owns the block; the sum is taken in fp32 before the single rounding of y. */
+int doda_spconv_gather_add_f32(const float *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
+                               const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
+                               const float *res, float *y, int32_t w_layout, void *ws,
+                               size_t ws_bytes, doda_stream_t stream);
+int doda_spconv_gather_add_bf16(const uint16_t *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
+                                const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
+                                const void *res, void *y, int32_t y_is_f32, int32_t w_layout,
+                                void *ws, size_t ws_bytes, doda_stream_t stream);
+
 /* dw[o][i][j] = sum_t a[tbl[o][t], i] * b[t, j],  a: [*, ca], b: [n_rows, cb], dw: fp32
  * [K][ca][cb].  Two deterministic stages inside one call (per-row-chunk partials in ws, then a
  * fixed-order reduce); K <= 28. */

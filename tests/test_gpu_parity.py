@@ -392,3 +392,42 @@ def test_conv_kernels_bitwise_repeatable(native_lib, dtype):
                 junk = torch.randn(1 << (14 + rep % 6), device=d).sum()  # perturb timing / occupancy
                 assert torch.equal(fn(), first)
             del junk
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("m,c_in,c_out", [(60000, 16, 16), (5000, 32, 48), (300, 96, 112), (2000, 6, 10)])
+def test_conv_residual_epilogue(native_lib, dtype, m, c_in, c_out):
+    """doda_spconv_gather_add_*: y = conv + res with the add fused into the store, against the
+    unfused sequence, through the raw op and through the module + autograd (the residual's gradient
+    is the incoming gradient; feature / weight gradients are unchanged)."""
+    from doda_amd import ops, spconv
+    d = dev()
+    shape = [64, 64, 48]
+    idx = surface_voxels(5, m, 2, shape)
+    n = idx.shape[0]
+    ind = torch.from_numpy(idx).to(d)
+    sub = spconv.ops.build_subm(ind, 2, shape, 3)
+    x = torch.randn(n, c_in, device=d).to(dtype)
+    res = torch.randn(n, c_out, device=d).to(dtype)
+    w = torch.randn(27, c_in, c_out, device=d) * 0.1
+    plain = ops.spconv_gather(x, w, sub.tbl, n, 0, c_out)
+    fused = ops.spconv_gather(x, w, sub.tbl, n, 0, c_out, residual=res)
+    if dtype == torch.float32:
+        assert torch.equal(fused, plain + res)          # same fp32 add, same order
+    else:                                               # one rounding instead of two
+        ref = plain.float() + res.float()
+        assert float((fused.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+    conv = spconv.SubMConv3d(c_in, c_out, 3, bias=False, indice_key="s").to(d)
+    grads = []
+    for use_res in (False, True):
+        xin = x.clone().requires_grad_(True)
+        rin = res.clone().requires_grad_(True)
+        conv.zero_grad(set_to_none=True)
+        t = spconv.SparseConvTensor(xin, ind, shape, 2)
+        y = conv(t, residual=rin).features if use_res else conv(t).features + rin
+        (y.float() * torch.linspace(-1, 1, c_out, device=d)).sum().backward()
+        grads.append((y.detach().float(), xin.grad.float(), rin.grad.float(), conv.weight.grad.float().clone()))
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    for a, b in zip(grads[0], grads[1]):
+        assert float((a - b).abs().max()) <= tol * max(float(a.abs().max()), 1e-6)
