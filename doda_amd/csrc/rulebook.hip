@@ -25,13 +25,17 @@ __device__ __forceinline__ uint32_t cell_id(int b, int x, int y, int z, const Gr
 }
 
 // ---- SubM ---------------------------------------------------------------------------------
+// Also pre-fills column t of the table's mirrored half (offsets first_fill .. K3-1) with -1: the
+// probe kernel only writes hits there (saves a memset launch per rulebook).
 __global__ __launch_bounds__(256) void subm_insert(const int4 *__restrict__ indices, int m,
                                                    GridDesc g, unsigned long long *tab,
-                                                   uint32_t mask) {
+                                                   uint32_t mask, int32_t *__restrict__ nbr, int ld,
+                                                   int first_fill, int k3) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const int4 c = indices[t];
     hash_insert_min(tab, mask, cell_id(c.x, c.y, c.z, c.w, g), (uint32_t)t);
+    for (int o = first_fill; o < k3; ++o) nbr[(long long)o * ld + t] = -1;
 }
 
 // One thread per voxel.  A SubM table is its own transpose under offset mirroring (nbr[o][t] = j  <=>
@@ -269,9 +273,8 @@ extern "C" int doda_rulebook_subm(const int32_t *indices, int32_t m, const int32
         return doda_check_launch();
     }
     hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
-    hipMemsetAsync(nbr + (size_t)14 * ld, 0xFF, (size_t)13 * ld * 4, s);   // mirrored half: -1 unless hit
     hipLaunchKernelGGL(subm_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g,
-                       w.tab, w.cap - 1);
+                       w.tab, w.cap - 1, nbr, ld, 14, 27);   // + mirrored half := -1
     hipLaunchKernelGGL((subm_probe<3>), dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g,
                        w.tab, w.cap - 1, nbr, ld);
     return doda_check_launch();

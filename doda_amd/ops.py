@@ -173,7 +173,7 @@ def rulebook_down2(indices, spatial_shape, batch_size):
     parent = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
     off = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
     out_idx_full = torch.empty((max(m, 1), 4), dtype=torch.int32, device=dev)
-    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)   # always written by the scan
     ws = _ws(lib().doda_rulebook_workspace_bytes(m), dev)
     check(lib().doda_rulebook_down2_assign(_p(indices), m, shape_c, int(batch_size), _p(parent),
                                            _p(off), _p(out_idx_full), _p(count), _p(ws), ws.numel(),
@@ -183,7 +183,7 @@ def rulebook_down2(indices, spatial_shape, batch_size):
     par_off = torch.empty((8, m), dtype=torch.int32, device=dev)
     check(lib().doda_rulebook_down2_tables(_p(parent), _p(off), m, m_out, _p(child), m_out,
                                            _p(par_off), m, _stream()), "doda_rulebook_down2_tables")
-    return out_idx_full[:m_out].clone(), child, par_off, out_shape
+    return out_idx_full[:m_out], child, par_off, out_shape   # a view: no copy launch
 
 
 def rulebook_pairs(tbl, n_rows, flip):

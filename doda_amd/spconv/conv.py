@@ -32,6 +32,18 @@ _PLANS = {}   # (device, elem_bytes) -> (signature, PackPlan, [modules])
 _PREPACK = _os.environ.get("DODA_NO_PREPACK", "0") != "1"
 
 
+_IDENT = {}
+
+
+def _identity_table(n, device):
+    """[1, n] int32 table 0..n-1 for the K = 1 gather-GEMM of 1x1 convolutions: a prefix view of one
+    grow-only arange per device (no launch per call)."""
+    buf = _IDENT.get(device)
+    if buf is None or buf.numel() < n:
+        buf = _IDENT[device] = torch.arange(max(n, 1 << 20), dtype=torch.int32, device=device)
+    return buf[:n].view(1, n)
+
+
 def invalidate_packed():
     _PLANS.clear()
     for m in list(_MODULES):
@@ -143,12 +155,7 @@ class SparseConvolution(SparseModule):
                       and self.in_channels % 4 == 0 and self.out_channels % 4 == 0
                       and self.weight.dtype == torch.float32 and features.shape[0] > 0)
             if native:
-                key = ("__identity__", features.shape[0])
-                ident = input.indice_dict.get(key)
-                if ident is None:
-                    ident = torch.arange(features.shape[0], dtype=torch.int32,
-                                         device=features.device).view(1, -1)
-                    input.indice_dict[key] = ident
+                ident = _identity_table(features.shape[0], features.device)
                 out_features = Fsp.conv1x1(features, self.weight, ident, self._packed(features))
             else:
                 w2 = self.weight.view(self.in_channels, self.out_channels)

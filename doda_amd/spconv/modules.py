@@ -4,6 +4,7 @@ model/unet_block.py:10,41,62-85)."""
 from collections import OrderedDict
 
 from torch import nn
+from torch.nn.modules import module as _mod
 
 from .. import nn as _dnn
 from .core import SparseConvTensor
@@ -17,6 +18,16 @@ class SparseModule(nn.Module):
 
 def is_spconv_module(module):
     return isinstance(module, SparseModule)
+
+
+def _run(module, *args, **kwargs):
+    """module(*args) without nn.Module.__call__'s hook machinery when the module has no hooks: a
+    U-Net step makes ~200 child calls and the step is issue-bound on the host."""
+    if (module._forward_hooks or module._forward_pre_hooks or module._backward_hooks
+            or module._backward_pre_hooks or _mod._global_forward_hooks or _mod._global_forward_pre_hooks
+            or _mod._global_backward_hooks or _mod._global_backward_pre_hooks):
+        return module(*args, **kwargs)
+    return module.forward(*args, **kwargs)
 
 
 class SparseSequential(SparseModule):
@@ -69,10 +80,10 @@ class SparseSequential(SparseModule):
             k += 1
             if is_spconv_module(module):
                 if residual is not None and k == len(mods) and getattr(module, "supports_residual", False):
-                    input = module(input, residual=residual)
+                    input = _run(module, input, residual=residual)
                     residual = None
                 else:
-                    input = module(input)
+                    input = _run(module, input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
                     if _dnn.fusable(module, input.features):
@@ -81,9 +92,9 @@ class SparseSequential(SparseModule):
                         input.features = _dnn.batch_norm_relu(input.features, module, relu)
                         k += int(relu)
                     else:
-                        input.features = module(input.features)
+                        input.features = _run(module, input.features)
             else:
-                input = module(input)
+                input = _run(module, input)
         if residual is not None:
             input.features = input.features + residual
         return input

@@ -11,7 +11,7 @@ net = SparseConvNet(cfg).to(dev).train()
 opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)
 def fwd():
     opt.zero_grad(set_to_none=True)
-    s = voxelize_and_run(cfg, net, bd, dev, feature_dtype=torch.bfloat16)
+    s = voxelize_and_run(cfg, net, bd, dev, feature_dtype=torch.bfloat16, inputs_ready=True)
     return cross_entropy(s, bd["labels"])
 for _ in range(5):
     l = fwd(); l.backward(); opt.step()
@@ -27,4 +27,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(5):
     l = fwd(); l.backward(); opt.step()
 torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45); print(s.getvalue()[:9000])
