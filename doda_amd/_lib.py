@@ -49,6 +49,9 @@ _SIGNATURES = {
     "doda_spconv_wgrad_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "doda_spconv_wgrad_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
                                       c_vp, c_sz, c_vp]),
+    "doda_spconv_wgrad_multi_workspace_bytes": (c_sz, [c_vp, c_i32]),
+    "doda_spconv_wgrad_multi_desc_bytes": (c_sz, [c_i32]),
+    "doda_spconv_wgrad_multi": (c_i32, [c_vp, c_i32, c_vp, c_sz, c_vp, c_sz, c_vp]),
     "doda_spconv_gather_bf16": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
                                         c_i32, c_i32, c_vp, c_sz, c_vp]),
     "doda_spconv_wgrad_bf16": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,

@@ -14,6 +14,9 @@
 // by a second kernel in fixed order: deterministic, no float atomics.
 #include "common.hpp"
 #include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -86,11 +89,11 @@ struct BF16 {
 // zeroed by a select: no divergent branch around a load, so hipcc can keep many loads in flight
 // (with branches it emitted `s_waitcnt vmcnt(0)` after every single load).
 template <class T, int TA, int TB, int OGW, bool VOK>
-__global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__restrict__ a, int ca,
-                                                    const typename T::elem *__restrict__ b, int cb,
-                                                    const int32_t *__restrict__ tbl, int ld, int K,
-                                                    int n_rows, int rows_per_chunk, int n_tag,
-                                                    int n_tbg, int n_og, float *__restrict__ partial) {
+__device__ __forceinline__ void wgrad_body(const typename T::elem *__restrict__ a, int ca,
+                                           const typename T::elem *__restrict__ b, int cb,
+                                           const int32_t *__restrict__ tbl, int ld, int K,
+                                           int n_rows, int rows_per_chunk, int n_tag,
+                                           int n_tbg, int n_og, float *__restrict__ partial, int item) {
     typedef typename T::elem elem;
     typedef typename T::frag frag;
     typedef typename T::kfrag kfrag;
@@ -100,8 +103,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__re
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
-    // work item = (row chunk, channel-tile group), group fastest; contiguous items per XCD
-    const int item = xcd_work_item(blockIdx.x, gridDim.x);
+    // work item = (row chunk, channel-tile group), group fastest
     const int n_grp = n_tag * n_tbg * n_og;
     const int chunk = item / n_grp;
     int grp = item % n_grp;
@@ -260,6 +262,81 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__re
                             out[((long long)o * ca + ci) * cb + co] = acc[oo][x_][y_][r];
                     }
         }
+    }
+}
+
+template <class T, int TA, int TB, int OGW, bool VOK>
+__global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__restrict__ a, int ca,
+                                                    const typename T::elem *__restrict__ b, int cb,
+                                                    const int32_t *__restrict__ tbl, int ld, int K,
+                                                    int n_rows, int rows_per_chunk, int n_tag,
+                                                    int n_tbg, int n_og, float *__restrict__ partial) {
+    // contiguous items per XCD
+    wgrad_body<T, TA, TB, OGW, VOK>(a, ca, b, cb, tbl, ld, K, n_rows, rows_per_chunk, n_tag, n_tbg, n_og,
+                                    partial, xcd_work_item(blockIdx.x, gridDim.x));
+}
+
+// ---- many layers in one launch --------------------------------------------------------------
+// The weight gradients of a network are independent of the rest of the backward pass.  Queued and
+// launched together (one launch per kernel variant, one reduce launch), the 71 x 2 launches of a U-Net
+// step become ~8, and the coarse levels' small grids run side by side instead of one after another.
+struct WJob {            // device descriptor of one layer inside a variant group
+    const void *a, *b;
+    const int32_t *tbl;
+    float *out;          // partials of the job (or dw itself when it has a single row chunk)
+    int ca, cb, ld, K, n_rows, rows_per_chunk, n_tag, n_tbg, n_og, blk_end;   // blk_end: inclusive prefix
+};
+struct RJob {            // one reduction: dw[q] = sum_r partial[r][q]
+    const float4 *partial;
+    float4 *dw;
+    long long n_quad;
+    int R, blk_end;
+};
+
+template <class J>
+__device__ __forceinline__ int find_job(const J *jobs, int n_jobs, int blk) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (blk < jobs[mid].blk_end) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+template <class T, int TA, int TB, int OGW, bool VOK>
+__global__ __launch_bounds__(256) void wgrad_multi_kernel(const WJob *__restrict__ jobs, int n_jobs) {
+    const int j = find_job(jobs, n_jobs, (int)blockIdx.x);
+    const WJob d = jobs[j];
+    const int first = j == 0 ? 0 : jobs[j - 1].blk_end;
+    wgrad_body<T, TA, TB, OGW, VOK>((const typename T::elem *)d.a, d.ca, (const typename T::elem *)d.b, d.cb,
+                                    d.tbl, d.ld, d.K, d.n_rows, d.rows_per_chunk, d.n_tag, d.n_tbg, d.n_og,
+                                    d.out, (int)blockIdx.x - first);
+}
+
+// 16 element quads x 16 chunk lanes per block, fixed order (as wgrad_reduce4<16>)
+__global__ __launch_bounds__(256) void wgrad_reduce_multi(const RJob *__restrict__ jobs, int n_jobs) {
+    __shared__ float4 part[16][16];
+    const int j = find_job(jobs, n_jobs, (int)blockIdx.x);
+    const RJob d = jobs[j];
+    const int first = j == 0 ? 0 : jobs[j - 1].blk_end;
+    const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const long long q = (long long)((int)blockIdx.x - first) * 16 + el;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < d.n_quad)
+        for (int r = rl; r < d.R; r += 16) {
+            const float4 v = d.partial[(long long)r * d.n_quad + q];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    part[rl][el] = s;
+    __syncthreads();
+    if (rl == 0 && q < d.n_quad) {
+        float4 t = part[0][el];
+#pragma unroll 4
+        for (int r = 1; r < 16; ++r) {
+            const float4 v = part[r][el];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        d.dw[q] = t;
     }
 }
 
@@ -422,7 +499,178 @@ int check_args(const void *a, int ca, const void *b, int cb, const int32_t *tbl,
     *done = false;
     return DODA_OK;
 }
+// ---- host side of the many-layer launch -------------------------------------------------------
+struct JobPlan {
+    Plan p;
+    int esz, vok, key;
+    size_t ws_off;     // partials of this job inside the workspace (unused when R == 1)
+    long long n_elem;
+};
+
+bool plan_job(const doda_wgrad_job &j, JobPlan *out) {
+    if (j.ca <= 0 || j.cb <= 0 || j.K <= 0 || j.K > 4 * MAX_OGW || j.n_rows <= 0 || j.ld < j.n_rows || !j.a ||
+        !j.b || !j.tbl || !j.dw || (j.elem_bytes != 2 && j.elem_bytes != 4))
+        return false;
+    out->esz = j.elem_bytes;
+    out->p = make_plan(j.K, j.ca, j.cb, j.n_rows, j.elem_bytes);
+    out->vok = ((size_t)j.ca * j.elem_bytes % 16 == 0) && ((size_t)j.cb * j.elem_bytes % 16 == 0) &&
+               ((uintptr_t)j.a % 16 == 0) && ((uintptr_t)j.b % 16 == 0);
+    out->key = (((j.elem_bytes * 4 + out->p.TA) * 4 + out->p.TB) * 8 + out->p.OGW) * 2 + out->vok;
+    out->n_elem = (long long)j.K * j.ca * j.cb;
+    return true;
+}
+
+template <class T>
+void launch_multi_variant(const Plan &p, int vok, int total_blocks, const WJob *jobs_dev, int n, hipStream_t s) {
+    const dim3 grid(total_blocks), block(256);
+#define GO(TA, TB, OG)                                                                             \
+    do {                                                                                           \
+        if (vok) hipLaunchKernelGGL((wgrad_multi_kernel<T, TA, TB, OG, true>), grid, block, 0, s, jobs_dev, n); \
+        else hipLaunchKernelGGL((wgrad_multi_kernel<T, TA, TB, OG, false>), grid, block, 0, s, jobs_dev, n); \
+    } while (0)
+    if (p.OGW == 2) {
+        if (p.TA == 1 && p.TB == 1) GO(1, 1, 2);
+        else if (p.TA == 2 && p.TB == 1) GO(2, 1, 2);
+        else if (p.TA == 1 && p.TB == 2) GO(1, 2, 2);
+        else GO(2, 2, 2);
+    } else if (p.OGW == 4 && p.TA == 1 && p.TB == 1) GO(1, 1, 4);
+    else if (p.OGW == 4 && p.TA == 2 && p.TB == 1) GO(2, 1, 4);
+    else if (p.OGW == 4 && p.TA == 1 && p.TB == 2) GO(1, 2, 4);
+    else if (p.TA == 1 && p.TB == 1) GO(1, 1, 7);
+    else if (p.TA == 2 && p.TB == 1) GO(2, 1, 7);
+    else if (p.TA == 1 && p.TB == 2) GO(1, 2, 7);
+    else GO(2, 2, 4);
+#undef GO
+}
+
+// pinned staging for the descriptor upload (one per process, grow-only, reuse guarded by an event)
+struct Staging {
+    std::mutex mu;
+    void *host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+};
+Staging g_staging;
 }  // namespace
+
+extern "C" size_t doda_spconv_wgrad_multi_workspace_bytes(const doda_wgrad_job *jobs_h, int32_t n_jobs) {
+    if (!jobs_h || n_jobs <= 0) return 0;
+    size_t total = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        JobPlan jp;
+        if (!plan_job(jobs_h[k], &jp)) continue;
+        if (jp.p.R > 1) total += align_up((size_t)jp.p.R * jp.n_elem * 4, 256);
+    }
+    return total < 256 ? 256 : total;
+}
+
+extern "C" size_t doda_spconv_wgrad_multi_desc_bytes(int32_t n_jobs) {
+    return n_jobs <= 0 ? 0 : align_up((size_t)n_jobs * (sizeof(WJob) + sizeof(RJob)), 256);
+}
+
+extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_jobs, void *ws, size_t ws_bytes,
+                                       void *desc_dev, size_t desc_bytes, doda_stream_t stream) {
+    if (!jobs_h || n_jobs <= 0 || !ws || !desc_dev) return DODA_ERR_INVALID;
+    if (desc_bytes < doda_spconv_wgrad_multi_desc_bytes(n_jobs)) return DODA_ERR_WORKSPACE;
+    hipStream_t s = as_stream(stream);
+    std::vector<JobPlan> plans(n_jobs);
+    std::vector<int> keys;
+    size_t off = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        if (jobs_h[k].n_rows == 0 && jobs_h[k].dw && jobs_h[k].K > 0 && jobs_h[k].ca > 0 && jobs_h[k].cb > 0) {
+            hipMemsetAsync(jobs_h[k].dw, 0, (size_t)jobs_h[k].K * jobs_h[k].ca * jobs_h[k].cb * 4, s);
+            plans[k].key = -1;
+            continue;
+        }
+        if (!plan_job(jobs_h[k], &plans[k])) return DODA_ERR_INVALID;
+        plans[k].ws_off = off;
+        if (plans[k].p.R > 1) off += align_up((size_t)plans[k].p.R * plans[k].n_elem * 4, 256);
+        bool seen = false;
+        for (int key : keys) seen |= key == plans[k].key;
+        if (!seen) keys.push_back(plans[k].key);
+    }
+    if (ws_bytes < off) return DODA_ERR_WORKSPACE;
+
+    // descriptors grouped by kernel variant, then the reductions
+    std::vector<WJob> wj;
+    std::vector<RJob> rj;
+    struct Group { int first, count, blocks, rep; };
+    std::vector<Group> groups;
+    for (int key : keys) {
+        Group g{(int)wj.size(), 0, 0, -1};
+        for (int k = 0; k < n_jobs; ++k) {
+            if (plans[k].key != key) continue;
+            const doda_wgrad_job &j = jobs_h[k];
+            const Plan &p = plans[k].p;
+            if (g.rep < 0) g.rep = k;
+            WJob d;
+            d.a = j.a; d.b = j.b; d.tbl = j.tbl;
+            d.out = p.R == 1 ? j.dw : (float *)((char *)ws + plans[k].ws_off);
+            d.ca = j.ca; d.cb = j.cb; d.ld = j.ld; d.K = j.K; d.n_rows = j.n_rows;
+            d.rows_per_chunk = p.rows_per_chunk; d.n_tag = p.n_tag; d.n_tbg = p.n_tbg; d.n_og = p.n_og;
+            g.blocks += p.R * p.n_tag * p.n_tbg * p.n_og;
+            d.blk_end = g.blocks;
+            wj.push_back(d);
+            ++g.count;
+        }
+        groups.push_back(g);
+    }
+    int r_blocks = 0;
+    bool scalar_reduce = false;
+    for (int k = 0; k < n_jobs; ++k) {
+        if (plans[k].key < 0 || plans[k].p.R <= 1) continue;
+        if (plans[k].n_elem % 4 != 0 || (uintptr_t)jobs_h[k].dw % 16 != 0) { scalar_reduce = true; continue; }
+        RJob d;
+        d.partial = (const float4 *)((char *)ws + plans[k].ws_off);
+        d.dw = (float4 *)jobs_h[k].dw;
+        d.n_quad = plans[k].n_elem / 4;
+        d.R = plans[k].p.R;
+        r_blocks += (int)div_up(d.n_quad, 16);
+        d.blk_end = r_blocks;
+        rj.push_back(d);
+    }
+    const size_t wbytes = wj.size() * sizeof(WJob), rbytes = rj.size() * sizeof(RJob);
+    {
+        std::lock_guard<std::mutex> lock(g_staging.mu);
+        Staging &st = g_staging;
+        if (st.pending) { hipEventSynchronize(st.ev); st.pending = false; }
+        if (st.cap < wbytes + rbytes) {
+            if (st.host) hipHostFree(st.host);
+            st.cap = align_up(wbytes + rbytes, 4096) * 2;
+            if (hipHostMalloc(&st.host, st.cap, hipHostMallocDefault) != hipSuccess) { st.host = nullptr; st.cap = 0; return DODA_ERR_NOMEM; }
+        }
+        if (!st.ev && hipEventCreateWithFlags(&st.ev, hipEventDisableTiming) != hipSuccess) return DODA_ERR_LAUNCH;
+        memcpy(st.host, wj.data(), wbytes);
+        if (rbytes) memcpy((char *)st.host + wbytes, rj.data(), rbytes);
+        if (hipMemcpyAsync(desc_dev, st.host, wbytes + rbytes, hipMemcpyHostToDevice, s) != hipSuccess) return DODA_ERR_LAUNCH;
+        hipEventRecord(st.ev, s);
+        st.pending = true;
+    }
+    const WJob *wj_dev = (const WJob *)desc_dev;
+    for (const Group &g : groups) {
+        const JobPlan &jp = plans[g.rep];
+        if (jp.esz == 4) launch_multi_variant<F32>(jp.p, jp.vok, g.blocks, wj_dev + g.first, g.count, s);
+        else launch_multi_variant<BF16>(jp.p, jp.vok, g.blocks, wj_dev + g.first, g.count, s);
+    }
+    int st = doda_check_launch();
+    if (st != DODA_OK) return st;
+    if (!rj.empty()) {
+        hipLaunchKernelGGL(wgrad_reduce_multi, dim3(r_blocks), dim3(256), 0, s,
+                           (const RJob *)((const char *)desc_dev + wbytes), (int)rj.size());
+        st = doda_check_launch();
+        if (st != DODA_OK) return st;
+    }
+    if (scalar_reduce)   // odd element counts: the per-layer scalar reduce
+        for (int k = 0; k < n_jobs; ++k) {
+            if (plans[k].key < 0 || plans[k].p.R <= 1) continue;
+            if (plans[k].n_elem % 4 == 0 && (uintptr_t)jobs_h[k].dw % 16 == 0) continue;
+            hipLaunchKernelGGL(wgrad_reduce, dim3(div_up(plans[k].n_elem, 16)), dim3(256), 0, s,
+                               (const float *)((char *)ws + plans[k].ws_off), plans[k].p.R, plans[k].n_elem,
+                               jobs_h[k].dw);
+        }
+    return doda_check_launch();
+}
 
 extern "C" size_t doda_spconv_wgrad_workspace_bytes(int32_t K, int32_t ca, int32_t cb,
                                                     int32_t n_rows) {

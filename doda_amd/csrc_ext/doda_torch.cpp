@@ -7,7 +7,12 @@
 // doda_amd/spconv/functional.py and doda_amd/nn.py use it when it is built and fall back to the
 // equivalent ctypes glue (same kernels) otherwise.
 #include <torch/extension.h>
+#include <torch/csrc/autograd/engine.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
+
+#include <mutex>
+#include <vector>
 
 #include "../../include/doda_hip.h"
 
@@ -116,6 +121,68 @@ at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tenso
     return dw;
 }
 
+// ---- deferred weight gradients ---------------------------------------------------------------
+// The weight gradient of a layer feeds nothing else in the backward pass.  With deferral switched on
+// (set_defer_wgrad) the conv backward only queues (features, dy, table) and binds an uninitialised
+// fp32 tensor as the parameter's .grad; an engine callback that runs when the backward pass is
+// complete issues ALL queued jobs through doda_spconv_wgrad_multi (~8 launches instead of 2 per
+// layer).  Preconditions checked per layer: fp32 leaf weight without an existing .grad (otherwise
+// the layer computes its gradient on the spot).  AccumulateGrad hooks do not see these gradients, so
+// torch DDP must not be combined with deferral (doda_amd.dist reduces gradients itself).
+struct PendingWgrad {
+    at::Tensor a, b, tbl, dw;
+    int64_t n_rows;
+};
+std::mutex g_wq_mu;
+std::vector<PendingWgrad> g_wq;
+bool g_wq_callback = false, g_defer_wgrad = false;
+c10::optional<c10::hip::HIPStream> g_wq_stream;
+
+void flush_wgrads() {
+    std::vector<PendingWgrad> q;
+    c10::optional<c10::hip::HIPStream> st;
+    {
+        std::lock_guard<std::mutex> lock(g_wq_mu);
+        q.swap(g_wq);
+        st = g_wq_stream;
+        g_wq_callback = false;
+    }
+    if (q.empty()) return;
+    c10::hip::HIPStreamGuard guard(*st);
+    std::vector<doda_wgrad_job> jobs(q.size());
+    for (size_t k = 0; k < q.size(); ++k) {
+        const PendingWgrad &p = q[k];
+        jobs[k] = doda_wgrad_job{p.a.data_ptr(), p.b.data_ptr(), (const int32_t *)p.tbl.data_ptr(),
+                                 (float *)p.dw.data_ptr(), (int32_t)p.a.size(1), (int32_t)p.b.size(1),
+                                 (int32_t)p.tbl.size(1), (int32_t)p.tbl.size(0), (int32_t)p.n_rows,
+                                 (int32_t)elem_bytes(p.a)};
+    }
+    const auto opt = q[0].a.options().dtype(at::kByte);
+    const size_t wsb = doda_spconv_wgrad_multi_workspace_bytes(jobs.data(), (int32_t)jobs.size());
+    const size_t dsb = doda_spconv_wgrad_multi_desc_bytes((int32_t)jobs.size());
+    at::Tensor ws = at::empty({(int64_t)wsb}, opt), desc = at::empty({(int64_t)dsb}, opt);
+    check(doda_spconv_wgrad_multi(jobs.data(), (int32_t)jobs.size(), ws.data_ptr(), wsb, desc.data_ptr(), dsb,
+                                  (void *)st->stream()), "doda_spconv_wgrad_multi");
+}
+
+// true when the job was queued (the caller then returns no gradient for the weight)
+bool try_defer_wgrad(const at::Tensor &features, const at::Tensor &dy, const at::Tensor &tbl, int64_t n_rows,
+                     const at::Tensor &weight) {
+    if (!g_defer_wgrad || !weight.is_leaf() || weight.scalar_type() != at::kFloat || weight.grad().defined() ||
+        !weight.is_contiguous() || n_rows <= 0)
+        return false;
+    at::Tensor dw = at::empty(weight.sizes(), weight.options());
+    weight.mutable_grad() = dw;
+    std::lock_guard<std::mutex> lock(g_wq_mu);
+    g_wq.push_back(PendingWgrad{features.contiguous(), dy, tbl, dw, n_rows});
+    g_wq_stream = c10::hip::getCurrentHIPStream(dy.device().index());
+    if (!g_wq_callback) {
+        g_wq_callback = true;
+        torch::autograd::Engine::get_default_engine().queue_callback([]() { flush_wgrads(); });
+    }
+    return true;
+}
+
 // features, weight [k,k,k,Cin,Cout], fwd_tbl, bwd_tbl, n_out, bwd_layout, packed fwd / data-grad,
 // optional residual (y = conv + residual; its gradient is the incoming gradient itself)
 struct IndiceConvFn : public torch::autograd::Function<IndiceConvFn> {
@@ -144,7 +211,8 @@ struct IndiceConvFn : public torch::autograd::Function<IndiceConvFn> {
             d_feat = gather(dy, weight.reshape({K, cin, cout}),
                             pk_bwd.defined() ? c10::optional<at::Tensor>(pk_bwd) : c10::nullopt, bwd_tbl,
                             features.size(0), bwd_layout, cin, false);
-        if (ctx->needs_input_grad(1)) d_w = wgrad(features, dy, fwd_tbl, n_out).reshape(weight.sizes()).to(weight.scalar_type());
+        if (ctx->needs_input_grad(1) && !try_defer_wgrad(features, dy, fwd_tbl, n_out, weight))
+            d_w = wgrad(features, dy, fwd_tbl, n_out).reshape(weight.sizes()).to(weight.scalar_type());
         at::Tensor d_res;
         if (ctx->saved_data["res_grad"].toBool()) d_res = grads[0];
         return {d_feat, d_w, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), d_res};
@@ -239,5 +307,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         return gather(x, w, packed, tbl, n_out, layout, nc, out_f32);
     }, "raw gather-GEMM");
     m.def("wgrad", &wgrad, "raw weight gradient");
+    m.def("set_defer_wgrad", [](bool on) { g_defer_wgrad = on; },
+          "queue conv weight gradients during backward and issue them in one multi-layer call at its end");
+    m.def("get_defer_wgrad", []() { return g_defer_wgrad; });
+    m.def("flush_wgrads", &flush_wgrads);
     m.def("abi_version", []() { return doda_abi_version(); });
 }

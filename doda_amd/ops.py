@@ -303,6 +303,42 @@ class PackPlan:
                                            _stream()), "doda_spconv_pack_multi")
 
 
+class _WgradJob(C.Structure):   # doda_wgrad_job (include/doda_hip.h)
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("tbl", C.c_void_p), ("dw", C.c_void_p),
+                ("ca", C.c_int32), ("cb", C.c_int32), ("ld", C.c_int32), ("K", C.c_int32),
+                ("n_rows", C.c_int32), ("elem_bytes", C.c_int32)]
+
+
+def spconv_wgrad_multi(jobs):
+    """Weight gradients of many layers in one native call (doda_spconv_wgrad_multi).
+    jobs: list of (a [*,ca], b [n_rows,cb], tbl int32 [K,ld], n_rows); returns the list of dw tensors
+    (float32 [K, ca, cb]), equal to spconv_wgrad per job up to the summation order of the partials."""
+    if not jobs:
+        return []
+    arr = (_WgradJob * len(jobs))()
+    outs, keep = [], []
+    for k, (a, b, tbl, n_rows) in enumerate(jobs):
+        _feat_ok(a, "a")
+        _feat_ok(b, "b")
+        _need_cuda(tbl)
+        a, b = a.contiguous(), b.contiguous()
+        if a.dtype != b.dtype:
+            raise RuntimeError("wgrad_multi: a and b must share a dtype")
+        K, ld = tbl.shape
+        dw = torch.empty((K, a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
+        arr[k] = _WgradJob(_p(a), _p(b), _p(tbl), _p(dw), a.shape[1], b.shape[1], ld, K, int(n_rows),
+                           4 if a.dtype == torch.float32 else 2)
+        outs.append(dw)
+        keep.append((a, b))
+    dev = outs[0].device
+    l = lib()
+    ws = _ws(l.doda_spconv_wgrad_multi_workspace_bytes(C.addressof(arr), len(jobs)), dev)
+    desc = torch.empty(l.doda_spconv_wgrad_multi_desc_bytes(len(jobs)), dtype=torch.uint8, device=dev)
+    check(l.doda_spconv_wgrad_multi(C.addressof(arr), len(jobs), _p(ws), ws.numel(), _p(desc), desc.numel(),
+                                    _stream()), "doda_spconv_wgrad_multi")
+    return outs
+
+
 def spconv_wgrad(a, b, tbl, n_rows):
     """dw[o] = sum_t a[tbl[o][t]]^T b[t]  ->  float32 [K, ca, cb]."""
     _feat_ok(a, "a")

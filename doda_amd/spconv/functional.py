@@ -27,6 +27,19 @@ _SIDE = {}
 _SERIAL = os.environ.get("DODA_OVERLAP_BWD", "0") != "1"
 
 
+def set_deferred_wgrad(on):
+    """Queue the weight gradients of all sparse convolutions during backward and issue them in one
+    multi-layer native call when the backward pass completes (doda_spconv_wgrad_multi: ~8 launches
+    instead of two per layer).  Needs the compiled extension; parameters must be fp32 leaves whose
+    .grad is None when backward starts (zero_grad(set_to_none=True)), otherwise a layer computes its
+    gradient on the spot.  The gradients do not pass through AccumulateGrad hooks: use
+    doda_amd.dist.GradAllReduce, not DistributedDataParallel.  Returns whether deferral is active."""
+    if _ext is None or not _SERIAL:
+        return False
+    _ext.set_defer_wgrad(bool(on))
+    return bool(on)
+
+
 def _gather(x, w, tbl, n_out, layout, nc, packed, residual=None):
     """spconv_gather through the pre-packed weights; falls back to packing inside the call when the
     native fast path refuses them (unaligned or > 2 GB feature matrices use the generic kernel)."""

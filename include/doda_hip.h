@@ -197,6 +197,25 @@ int doda_spconv_wgrad_bf16(const uint16_t *a, int32_t ca, const uint16_t *b, int
                            const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, float *dw,
                            void *ws, size_t ws_bytes, doda_stream_t stream);
 
+/* Weight gradients of MANY layers in one call (one launch per kernel variant + one reduce launch
+ * instead of two launches per layer; the coarse levels' small grids run concurrently).  The weight
+ * gradient of a layer does not feed the rest of the backward pass, so a caller can queue the jobs
+ * while back-propagating and issue them together before the optimizer step.  `jobs_h` is a host
+ * array; `ws` (doda_spconv_wgrad_multi_workspace_bytes) holds the partials, `desc_dev`
+ * (doda_spconv_wgrad_multi_desc_bytes) receives the device descriptors.  Results equal the per-layer
+ * calls up to the summation order of the partial reduce (both deterministic). */
+typedef struct doda_wgrad_job {
+    const void *a;        /* [*, ca]      features gathered through tbl (fp32 or bf16) */
+    const void *b;        /* [n_rows, cb] output gradient, same dtype */
+    const int32_t *tbl;   /* [K][ld] */
+    float *dw;            /* [K][ca][cb] fp32, overwritten */
+    int32_t ca, cb, ld, K, n_rows, elem_bytes;
+} doda_wgrad_job;
+size_t doda_spconv_wgrad_multi_workspace_bytes(const doda_wgrad_job *jobs_h, int32_t n_jobs);
+size_t doda_spconv_wgrad_multi_desc_bytes(int32_t n_jobs);
+int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_jobs, void *ws, size_t ws_bytes,
+                            void *desc_dev, size_t desc_bytes, doda_stream_t stream);
+
 /* Indice-pair max pooling (spconv v1.2 indice_maxpool / indice_maxpool_backward; unused by
  * DODA, named by north_star).  y[t,c] = max_o x[tbl[o][t],c] over present o (0 if none);
  * dx[tbl[o][t],c] += dy[t,c] where x[tbl[o][t],c] == y[t,c]. */

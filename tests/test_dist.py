@@ -67,3 +67,44 @@ def test_single_process_is_a_noop():
         for k, v in saved.items():
             if v is not None:
                 os.environ[k] = v
+
+
+def _grad_allreduce_worker(rank, world, port, q):
+    import os
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch
+    from doda_amd import dist as ddist
+    ddist.setup("gloo")
+    torch.manual_seed(rank)                       # different initial weights per rank
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    red = ddist.GradAllReduce(net)                # broadcast from rank 0
+    w0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    torch.manual_seed(100 + rank)
+    x = torch.randn(4, 6)
+    net(x).square().sum().backward()
+    local = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+    red.reduce()
+    avg = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    q.put((rank, w0.tolist(), local.tolist(), avg.tolist()))
+    ddist.barrier()
+
+
+def test_grad_allreduce_world2_gloo():
+    """GradAllReduce: same parameters on every rank after construction, gradients averaged."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_grad_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, w_a, g_a, avg_a), (_, w_b, g_b, avg_b) = res
+    assert w_a == w_b
+    want = [(a + b) / 2 for a, b in zip(g_a, g_b)]
+    assert max(abs(x - y) for x, y in zip(avg_a, want)) < 1e-6
+    assert avg_a == avg_b

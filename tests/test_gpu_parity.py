@@ -431,3 +431,33 @@ def test_conv_residual_epilogue(native_lib, dtype, m, c_in, c_out):
     tol = 1e-6 if dtype == torch.float32 else 2e-2
     for a, b in zip(grads[0], grads[1]):
         assert float((a - b).abs().max()) <= tol * max(float(a.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wgrad_multi_matches_per_layer(native_lib, dtype):
+    """doda_spconv_wgrad_multi: many layers (mixed sizes, channel counts, SubM and k2s2 tables, several
+    kernel variants, single- and multi-chunk jobs) in one call against the per-layer entry point."""
+    from doda_amd import ops, spconv
+    d = dev()
+    jobs, refs = [], []
+    for m, c_in, c_out, seed in ((50000, 16, 16, 0), (9000, 32, 32, 1), (9000, 32, 48, 2), (700, 96, 112, 3),
+                                 (150, 48, 16, 4), (50000, 16, 32, 5), (40, 64, 64, 6)):
+        shape = [64, 64, 48]
+        idx = surface_voxels(seed, m, 2, shape)
+        n = idx.shape[0]
+        ind = torch.from_numpy(idx).to(d)
+        sub = spconv.ops.build_subm(ind, 2, shape, 3)
+        dn = spconv.ops.build_down2(ind, 2, shape, 2, 2, 0, 1)
+        x = torch.randn(n, c_in, device=d).to(dtype)
+        gy = torch.randn(n, c_out, device=d).to(dtype)
+        gmid = torch.randn(dn.outids.shape[0], c_out, device=d).to(dtype)
+        jobs += [(x, gy, sub.tbl, n), (x, gmid, dn.tbl, dn.outids.shape[0])]
+        refs += [ops.spconv_wgrad(x, gy, sub.tbl, n), ops.spconv_wgrad(x, gmid, dn.tbl, dn.outids.shape[0])]
+    outs = ops.spconv_wgrad_multi(jobs)
+    assert len(outs) == len(refs)
+    for o, r in zip(outs, refs):
+        assert o.shape == r.shape
+        assert rel_err(o.cpu(), r.cpu()) < 2e-6        # same products, different partial-sum order
+    again = ops.spconv_wgrad_multi(jobs)
+    for o, r in zip(outs, again):
+        assert torch.equal(o, r)                       # deterministic

@@ -9,6 +9,8 @@ bd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
 cfg = default_cfg(); torch.manual_seed(0)
 net = SparseConvNet(cfg).to(dev).train()
 opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)
+from doda_amd.spconv import functional as Fsp
+print('deferred wgrad:', Fsp.set_deferred_wgrad(os.environ.get('DEFER', '1') == '1'))
 def fwd():
     opt.zero_grad(set_to_none=True)
     s = voxelize_and_run(cfg, net, bd, dev, feature_dtype=torch.bfloat16, inputs_ready=True)

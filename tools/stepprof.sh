@@ -9,7 +9,7 @@ import csv, json, collections
 rows = list(csv.DictReader(open("$out/k_kernel_stats.csv")))
 fam = collections.OrderedDict()
 def family(n):
-    for key in ("conv_fast", "conv_gather", "wgrad_kernel", "wgrad_reduce", "bn_small", "bn_", "subm_", "down2", "pack_w", "voxel", "scan", "maxpool", "elementwise", "multi_tensor", "reduce", "fill", "copy", "softmax", "nll"):
+    for key in ("conv_fast", "conv_gather", "wgrad_multi", "wgrad_kernel", "wgrad_reduce", "bn_small", "bn_", "subm_", "down2", "pack_w", "voxel", "scan", "maxpool", "elementwise", "multi_tensor", "reduce", "fill", "copy", "softmax", "nll"):
         if key in n: return key
     return "other"
 tot = 0
