@@ -149,6 +149,7 @@ def main():
     from doda_amd import dist as ddist
     world, rank, local_rank = ddist.setup()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    local_rank %= torch.cuda.device_count()   # (several ranks on one GPU only happens in gloo smoke tests)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
