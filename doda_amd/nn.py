@@ -3,7 +3,7 @@
 spconv's SparseSequential applies non-sparse modules to `.features`; DODA's network does that with
 `BatchNorm1d(eps=1e-4, momentum=0.1)` followed by `ReLU` in front of every convolution (reference
 model/unet.py:28,42-45; model/unet_block.py:23-30,46-49,67-79).  doda_amd.spconv.SparseSequential
-recognises that pair (exact torch types only — DSNorm and friends keep their own forward) and routes
+recognises that pair (exact torch BatchNorm1d, or DSNorm: reference model/dsnorm.py) and routes
 it here; semantics are torch.nn.BatchNorm1d's: batch statistics + running-stat update in training,
 running statistics in eval, same gradients.
 """
@@ -42,10 +42,24 @@ class _BNReLU(Function):
         return dx, dg.to(weight.dtype), db.to(bias.dtype), None, None, None, None, None, None, None
 
 
+def _is_dsnorm(m):
+    """doda_amd.dsnorm.DSNorm1d or the reference's model/dsnorm.py class (recognised by its buffers)."""
+    return (type(m).__name__ in ("DSNorm1d", "DSNorm") and hasattr(m, "running_mean_source")
+            and hasattr(m, "running_var_target") and hasattr(m, "domain_label"))
+
+
+def _running_stats(bn):
+    if _is_dsnorm(bn):
+        if bn.domain_label:
+            return bn.running_mean_target, bn.running_var_target
+        return bn.running_mean_source, bn.running_var_source
+    return bn.running_mean, bn.running_var
+
+
 def fusable(bn, features):
-    """Exactly torch's BatchNorm1d with affine fp32 parameters, running stats and a numeric momentum,
-    on a device [M, C] fp32/bf16 matrix with C % 4 == 0."""
-    return (type(bn) is nn.BatchNorm1d and bn.affine and bn.track_running_stats
+    """torch's BatchNorm1d (exact type) or a DSNorm with affine fp32 parameters, running stats and a
+    numeric momentum, on a device [M, C] fp32/bf16 matrix with C % 4 == 0."""
+    return ((type(bn) is nn.BatchNorm1d or _is_dsnorm(bn)) and bn.affine and bn.track_running_stats
             and bn.momentum is not None and features.is_cuda and features.dim() == 2
             and features.dtype in (torch.float32, torch.bfloat16) and features.shape[1] % 4 == 0
             and bn.weight.dtype == torch.float32
@@ -56,8 +70,9 @@ def batch_norm_relu(features, bn, relu):
     """BatchNorm1d `bn` (+ReLU when `relu`) on features through the fused HIP kernels."""
     # num_batches_tracked += 1 happens inside the stats kernel (65 one-element add kernels per step
     # otherwise)
+    running_mean, running_var = _running_stats(bn)   # DSNorm: the current domain's pair
     if _ext is not None:
-        return _ext.bn_relu(features, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+        return _ext.bn_relu(features, bn.weight, bn.bias, running_mean, running_var,
                             bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, relu)
-    return _BNReLU.apply(features, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+    return _BNReLU.apply(features, bn.weight, bn.bias, running_mean, running_var,
                          bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, relu)

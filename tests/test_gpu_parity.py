@@ -461,3 +461,37 @@ def test_wgrad_multi_matches_per_layer(native_lib, dtype):
     again = ops.spconv_wgrad_multi(jobs)
     for o, r in zip(outs, again):
         assert torch.equal(o, r)                       # deterministic
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dsnorm_fused_path(native_lib, dtype):
+    """DSNorm (reference model/dsnorm.py): the fused BN+ReLU path picks the running statistics of the
+    current domain and leaves the other domain's untouched; values and gradients as torch's."""
+    from doda_amd import spconv
+    from doda_amd.dsnorm import DSNorm1d
+    from doda_amd.nn import fusable
+    d = dev()
+    c, m = 32, 5000
+    torch.manual_seed(3)
+    mine, ref = DSNorm1d(c, eps=1e-4, momentum=0.1).to(d), DSNorm1d(c, eps=1e-4, momentum=0.1).to(d)
+    with torch.no_grad():
+        mine.weight.uniform_(0.5, 1.5); mine.bias.uniform_(-0.5, 0.5)
+        ref.load_state_dict(mine.state_dict())
+    seq = spconv.SparseSequential(mine, torch.nn.ReLU())
+    idx = torch.from_numpy(surface_voxels(1, m, 1, [64, 64, 48])).to(d)
+    n = idx.shape[0]
+    for label in (1, 0, 1):
+        mine.set_domain_label(label); ref.set_domain_label(label)
+        x = (torch.randn(n, c, device=d) * 2 + 1).to(dtype)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        assert fusable(mine, xa)
+        ya = seq(spconv.SparseConvTensor(xa, idx, [64, 64, 48], 1)).features
+        yb = torch.relu(ref(xb.float()))
+        g = torch.randn_like(yb)
+        (ya.float() * g).sum().backward(); (yb * g).sum().backward()
+        tol = 1e-4 if dtype == torch.float32 else 3e-2
+        assert rel_err(ya.detach().float().cpu(), yb.detach().cpu()) < tol
+        assert rel_err(xa.grad.float().cpu(), xb.grad.float().cpu()) < (1e-3 if dtype == torch.float32 else 5e-2)
+    for name in ("running_mean_source", "running_var_source", "running_mean_target", "running_var_target"):
+        assert rel_err(getattr(mine, name).cpu(), getattr(ref, name).cpu()) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 3
