@@ -33,6 +33,12 @@ _SIGNATURES = {
     "doda_rulebook_down2_assign": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            c_sz, c_vp]),
     "doda_rulebook_down2_tables": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp]),
+    "doda_rulebook_conv_workspace_bytes": (c_sz, [c_i32, c_i32]),
+    "doda_rulebook_conv_assign": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                          c_sz, c_vp]),
+    "doda_rulebook_conv_tables": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp,
+                                          c_i32, c_vp, c_i32, c_vp, c_sz, c_vp]),
+    "doda_rulebook_subm_generic": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "doda_rulebook_pairs_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "doda_rulebook_pairs": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_sz,
                                     c_vp]),

@@ -216,6 +216,135 @@ __global__ __launch_bounds__(PAIR_TILE) void pairs_fill(const int32_t *__restric
     }
 }
 
+// ---- generic geometry (any kernel_size / stride / padding / dilation with K <= 27) -----------
+// spconv's getIndicePairsConv numbers the outputs in first-touch order of a serial scan: inputs
+// ascending, each input's valid output positions in getValidOutPos order (last axis fastest, from
+// the upper bound downwards).  Here every (input j, enumeration rank i) candidate carries the touch
+// key j*K + i; a hash of the OUTPUT cells keeps the minimum key per cell (atomicMin on the packed
+// word), the entries that hold their cell's minimum are flagged and a prefix sum over the flags in
+// key order is the serial numbering.  No atomic cursor anywhere: deterministic and equal to the
+// serial order.
+struct ConvGeo {
+    int k[3], s[3], p[3], d[3];   // kernel, stride, padding, dilation
+    int K;
+    GridDesc out;                 // output spatial shape
+};
+
+// enumeration of getValidOutPos; calls f(rank, ox, oy, oz, offset) for the VALID positions
+template <class F>
+__device__ __forceinline__ void for_valid_out(const int4 c, const ConvGeo &g, F f) {
+    const int pos[3] = {c.y, c.z, c.w};
+    int lo[3], up[3], cs[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = (pos[a] - (g.k[a] - 1) * g.d[a] - 1 + g.s[a] + g.p[a]) / g.s[a];
+        up[a] = (pos[a] + g.p[a]) / g.s[a];
+        cs[a] = (up[a] - lo[a]) / g.d[a] + 1;
+    }
+    const int shape[3] = {g.out.X, g.out.Y, g.out.Z};
+    int rank = 0;
+    for (int c0 = 0; c0 < cs[0]; ++c0)
+        for (int c1 = 0; c1 < cs[1]; ++c1)
+            for (int c2 = 0; c2 < cs[2]; ++c2) {
+                const int cnt[3] = {c0, c1, c2};
+                int v[3], off = 0, mul = 1;
+                bool valid = true;
+#pragma unroll
+                for (int a = 2; a >= 0; --a) {
+                    v[a] = up[a] - cnt[a] * g.d[a];
+                    valid &= v[a] >= 0 && v[a] <= shape[a] - 1;
+                    off += mul * (pos[a] - v[a] * g.s[a] + g.p[a]) / g.d[a];
+                    mul *= g.k[a];
+                }
+                if (valid) {
+                    f(rank, v[0], v[1], v[2], off);
+                    ++rank;
+                }
+            }
+}
+
+__global__ __launch_bounds__(256) void conv_touch(const int4 *__restrict__ indices, int m, ConvGeo g,
+                                                  unsigned long long *tab, uint32_t mask) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int4 c = indices[j];
+    for_valid_out(c, g, [&](int rank, int ox, int oy, int oz, int) {
+        hash_insert_min(tab, mask, cell_id(c.x, ox, oy, oz, g.out), (uint32_t)j * (uint32_t)g.K + (uint32_t)rank);
+    });
+}
+
+// flag[j*K + rank] = 1 where that candidate is the first touch of its output cell
+__global__ __launch_bounds__(256) void conv_first(const int4 *__restrict__ indices, int m, ConvGeo g,
+                                                  const unsigned long long *__restrict__ tab,
+                                                  uint32_t mask, int32_t *__restrict__ flag) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int4 c = indices[j];
+    for (int r = 0; r < g.K; ++r) flag[(long long)j * g.K + r] = 0;
+    for_valid_out(c, g, [&](int rank, int ox, int oy, int oz, int) {
+        const uint32_t mine = (uint32_t)j * (uint32_t)g.K + (uint32_t)rank;
+        if ((uint32_t)hash_find(tab, mask, cell_id(c.x, ox, oy, oz, g.out)) == mine) flag[mine] = 1;
+    });
+}
+
+// the first-touch candidates write their output's coordinates and replace the table value (touch
+// key) of their cell by the output id
+__global__ __launch_bounds__(256) void conv_number(const int4 *__restrict__ indices, int m, ConvGeo g,
+                                                   unsigned long long *tab, uint32_t mask,
+                                                   const int32_t *__restrict__ flag,
+                                                   const int32_t *__restrict__ rank_of,
+                                                   int4 *__restrict__ out_indices) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int4 c = indices[j];
+    for_valid_out(c, g, [&](int rank, int ox, int oy, int oz, int) {
+        const long long e = (long long)j * g.K + rank;
+        if (!flag[e]) return;
+        const int id = rank_of[e];
+        out_indices[id] = make_int4(c.x, ox, oy, oz);
+        const uint32_t key = cell_id(c.x, ox, oy, oz, g.out);
+        uint32_t slot = hash_mix(key) & mask;
+        while ((uint32_t)(tab[slot] >> 32) != key) slot = (slot + 1) & mask;   // present by construction
+        tab[slot] = ((unsigned long long)key << 32) | (uint32_t)id;
+    });
+}
+
+// tbl[off][out] = j and tbl_rev[off][j] = out for every (input, output, offset) triple
+__global__ __launch_bounds__(256) void conv_tables(const int4 *__restrict__ indices, int m, ConvGeo g,
+                                                   const unsigned long long *__restrict__ tab,
+                                                   uint32_t mask, int32_t *__restrict__ tbl, int ld_out,
+                                                   int32_t *__restrict__ tbl_rev, int ld_in) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int4 c = indices[j];
+    for (int o = 0; o < g.K; ++o) tbl_rev[(long long)o * ld_in + j] = -1;
+    for_valid_out(c, g, [&](int, int ox, int oy, int oz, int off) {
+        const int out = hash_find(tab, mask, cell_id(c.x, ox, oy, oz, g.out));
+        tbl_rev[(long long)off * ld_in + j] = out;
+        tbl[(long long)off * ld_out + out] = j;
+    });
+}
+
+// SubM with a non-cubic odd kernel: plain per-offset lookups (offset = row-major kernel index)
+__global__ __launch_bounds__(256) void subm_probe_generic(const int4 *__restrict__ indices, int m,
+                                                          GridDesc g, int k0, int k1, int k2,
+                                                          const unsigned long long *__restrict__ tab,
+                                                          uint32_t mask, int32_t *__restrict__ nbr, int ld) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const int4 c = indices[t];
+    int o = 0;
+    for (int a = 0; a < k0; ++a)
+        for (int b = 0; b < k1; ++b)
+            for (int d = 0; d < k2; ++d, ++o) {
+                const int x = c.y + a - k0 / 2, y = c.z + b - k1 / 2, z = c.w + d - k2 / 2;
+                int v = -1;
+                if (x >= 0 && x < g.X && y >= 0 && y < g.Y && z >= 0 && z < g.Z)
+                    v = hash_find(tab, mask, cell_id(c.x, x, y, z, g));
+                nbr[(long long)o * ld + t] = v;
+            }
+}
+
 struct RbWs {
     unsigned long long *tab;
     uint32_t cap;
@@ -352,5 +481,126 @@ extern "C" int doda_rulebook_pairs(const int32_t *tbl, int32_t ld, int32_t K, in
     hipLaunchKernelGGL(pairs_scan, dim3(K), dim3(256), 0, s, counts, nt, pair_num);
     hipLaunchKernelGGL(pairs_fill, dim3(nt, K), dim3(PAIR_TILE), 0, s, tbl, ld, K, n_rows, flip,
                        counts, nt, pairs, ld_pairs);
+    return doda_check_launch();
+}
+
+
+// ---- generic geometry: host entry points ------------------------------------------------------
+namespace {
+struct ConvWs {
+    unsigned long long *tab;
+    uint32_t cap;
+    int32_t *flag, *rank, *scan;
+    size_t total;
+};
+ConvWs carve_conv(void *ws, int m, int K) {
+    ConvWs r;
+    const long long cand = (long long)(m > 0 ? m : 1) * K;
+    const uint32_t cap = next_pow2((uint32_t)(2 * cand < 1024 ? 1024 : 2 * cand));
+    size_t off = 0;
+    char *p = (char *)ws;
+    r.cap = cap;
+    r.tab = (unsigned long long *)(p + off);
+    off += (size_t)cap * 8;
+    const size_t ci = align_up((size_t)cand * 4, 256);
+    r.flag = (int32_t *)(p + off); off += ci;
+    r.rank = (int32_t *)(p + off); off += ci;
+    r.scan = (int32_t *)(p + off); off += align_up(scan_ws_ints((int)cand) * 4, 256);
+    r.total = off;
+    return r;
+}
+bool make_geo(const int32_t *shape, const int32_t *k, const int32_t *s, const int32_t *p, const int32_t *d,
+              ConvGeo *g) {
+    g->K = 1;
+    int o[3];
+    for (int a = 0; a < 3; ++a) {
+        if (k[a] < 1 || s[a] < 1 || p[a] < 0 || d[a] < 1 || shape[a] < 1) return false;
+        g->k[a] = k[a]; g->s[a] = s[a]; g->p[a] = p[a]; g->d[a] = d[a];
+        g->K *= k[a];
+        o[a] = (shape[a] + 2 * p[a] - d[a] * (k[a] - 1) - 1) / s[a] + 1;   // spconv get_conv_output_size
+        if (o[a] < 1) return false;
+    }
+    g->out = GridDesc{o[0], o[1], o[2]};
+    return true;
+}
+}  // namespace
+
+extern "C" size_t doda_rulebook_conv_workspace_bytes(int32_t m, int32_t K) {
+    if (m < 0 || K < 1 || K > 27 || (long long)m * K > 0x3fffffffll) return 0;
+    return carve_conv(nullptr, m, K).total;
+}
+
+extern "C" int doda_rulebook_conv_assign(const int32_t *indices, int32_t m, const int32_t *shape_h,
+                                         int32_t batch, const int32_t *ksize_h, const int32_t *stride_h,
+                                         const int32_t *pad_h, const int32_t *dil_h, int32_t *out_shape_h,
+                                         int32_t *count_out, void *ws, size_t ws_bytes, doda_stream_t stream) {
+    if (m < 0 || !shape_h || !ksize_h || !stride_h || !pad_h || !dil_h || !out_shape_h || !count_out)
+        return DODA_ERR_INVALID;
+    ConvGeo g;
+    if (!make_geo(shape_h, ksize_h, stride_h, pad_h, dil_h, &g)) return DODA_ERR_INVALID;
+    if (g.K > 27 || (long long)m * g.K > 0x3fffffffll) return DODA_ERR_UNSUPPORTED;
+    out_shape_h[0] = g.out.X; out_shape_h[1] = g.out.Y; out_shape_h[2] = g.out.Z;
+    hipStream_t s = as_stream(stream);
+    if (m == 0) { hipMemsetAsync(count_out, 0, sizeof(int32_t), s); return DODA_OK; }
+    if (!indices || !ws) return DODA_ERR_INVALID;
+    if (!grid_fits(batch, g.out.X, g.out.Y, g.out.Z)) return DODA_ERR_GRID_TOO_LARGE;
+    const ConvWs w = carve_conv(ws, m, g.K);
+    if (ws_bytes < w.total) return DODA_ERR_WORKSPACE;
+    const int grid = div_up(m, 256);
+    hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
+    hipLaunchKernelGGL(conv_touch, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1);
+    hipLaunchKernelGGL(conv_first, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1,
+                       w.flag);
+    return exclusive_scan_i32(w.flag, w.rank, m * g.K, count_out, w.scan, s);
+}
+
+extern "C" int doda_rulebook_conv_tables(const int32_t *indices, int32_t m, const int32_t *shape_h,
+                                         int32_t batch, const int32_t *ksize_h, const int32_t *stride_h,
+                                         const int32_t *pad_h, const int32_t *dil_h, int32_t m_out,
+                                         int32_t *out_indices, int32_t *tbl, int32_t ld_out,
+                                         int32_t *tbl_rev, int32_t ld_in, void *ws, size_t ws_bytes,
+                                         doda_stream_t stream) {
+    if (m < 0 || m_out < 0 || ld_out < m_out || ld_in < m || !shape_h || !ksize_h || !stride_h || !pad_h || !dil_h)
+        return DODA_ERR_INVALID;
+    if (m == 0) return DODA_OK;
+    ConvGeo g;
+    if (!make_geo(shape_h, ksize_h, stride_h, pad_h, dil_h, &g)) return DODA_ERR_INVALID;
+    if (g.K > 27) return DODA_ERR_UNSUPPORTED;
+    if (!indices || !out_indices || !tbl || !tbl_rev || !ws) return DODA_ERR_INVALID;
+    (void)batch;
+    const ConvWs w = carve_conv(ws, m, g.K);
+    if (ws_bytes < w.total) return DODA_ERR_WORKSPACE;
+    hipStream_t s = as_stream(stream);
+    const int grid = div_up(m, 256);
+    if (m_out > 0) hipMemsetAsync(tbl, 0xFF, (size_t)g.K * ld_out * 4, s);
+    hipLaunchKernelGGL(conv_number, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1,
+                       w.flag, w.rank, (int4 *)out_indices);
+    hipLaunchKernelGGL(conv_tables, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1,
+                       tbl, ld_out, tbl_rev, ld_in);
+    return doda_check_launch();
+}
+
+// SubM with per-axis odd kernel sizes (K <= 27); the cubic 1 / 3 cases keep doda_rulebook_subm
+extern "C" int doda_rulebook_subm_generic(const int32_t *indices, int32_t m, const int32_t *shape_h,
+                                          int32_t batch, const int32_t *ksize_h, int32_t *nbr, int32_t ld,
+                                          void *ws, size_t ws_bytes, doda_stream_t stream) {
+    if (m < 0 || ld < m || !shape_h || !ksize_h) return DODA_ERR_INVALID;
+    for (int a = 0; a < 3; ++a)
+        if (ksize_h[a] < 1 || ksize_h[a] % 2 == 0) return DODA_ERR_INVALID;
+    const int K = ksize_h[0] * ksize_h[1] * ksize_h[2];
+    if (K > 27) return DODA_ERR_UNSUPPORTED;
+    if (m == 0) return DODA_OK;
+    if (!indices || !nbr || !ws) return DODA_ERR_INVALID;
+    if (!grid_fits(batch, shape_h[0], shape_h[1], shape_h[2])) return DODA_ERR_GRID_TOO_LARGE;
+    const RbWs w = carve(ws, m);
+    if (ws_bytes < w.total) return DODA_ERR_WORKSPACE;
+    hipStream_t s = as_stream(stream);
+    const GridDesc g{shape_h[0], shape_h[1], shape_h[2]};
+    const int grid = div_up(m, 256);
+    hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
+    hipLaunchKernelGGL(subm_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1,
+                       nbr, ld, K, K);   // no prefill
+    hipLaunchKernelGGL(subm_probe_generic, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g,
+                       ksize_h[0], ksize_h[1], ksize_h[2], w.tab, w.cap - 1, nbr, ld);
     return doda_check_launch();
 }

@@ -186,6 +186,52 @@ def rulebook_down2(indices, spatial_shape, batch_size):
     return out_idx_full[:m_out], child, par_off, out_shape   # a view: no copy launch
 
 
+def _i3(v):
+    arr = (C.c_int32 * 3)(*[int(x) for x in v])
+    return arr
+
+
+def rulebook_conv(indices, spatial_shape, batch_size, ksize, stride, padding, dilation):
+    """Generic SparseConv3d rulebook (K <= 27).  Returns (out_indices int32 [M_out,4], tbl int32
+    [K,M_out], tbl_rev int32 [K,M], out_shape list[3]).  One D2H sync (M_out)."""
+    indices = _check_indices(indices)
+    m = indices.shape[0]
+    dev = indices.device
+    shape_c, _ = _shape3(spatial_shape)
+    k, s, p, d = _i3(ksize), _i3(stride), _i3(padding), _i3(dilation)
+    K = k[0] * k[1] * k[2]
+    out_shape_c = (C.c_int32 * 3)()
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    nbytes = lib().doda_rulebook_conv_workspace_bytes(m, K)
+    if nbytes == 0:
+        raise DodaNativeError("doda_rulebook_conv: kernel volume %d or size not supported" % K)
+    ws = _ws(nbytes, dev)
+    check(lib().doda_rulebook_conv_assign(_p(indices), m, shape_c, int(batch_size), k, s, p, d, out_shape_c,
+                                          _p(count), _p(ws), ws.numel(), _stream()), "doda_rulebook_conv_assign")
+    m_out = int(count.item())
+    out_idx = torch.empty((m_out, 4), dtype=torch.int32, device=dev)
+    tbl = torch.empty((K, m_out), dtype=torch.int32, device=dev)
+    tbl_rev = torch.empty((K, m), dtype=torch.int32, device=dev)
+    check(lib().doda_rulebook_conv_tables(_p(indices), m, shape_c, int(batch_size), k, s, p, d, m_out,
+                                          _p(out_idx), _p(tbl), m_out, _p(tbl_rev), m, _p(ws), ws.numel(),
+                                          _stream()), "doda_rulebook_conv_tables")
+    return out_idx, tbl, tbl_rev, [int(v) for v in out_shape_c]
+
+
+def rulebook_subm_generic(indices, spatial_shape, batch_size, ksize):
+    """SubM neighbour table for per-axis odd kernel sizes (K <= 27): int32 [K, M]."""
+    indices = _check_indices(indices)
+    m = indices.shape[0]
+    shape_c, _ = _shape3(spatial_shape)
+    k = _i3(ksize)
+    K = k[0] * k[1] * k[2]
+    nbr = torch.empty((K, m), dtype=torch.int32, device=indices.device)
+    ws = _ws(lib().doda_rulebook_workspace_bytes(m), indices.device)
+    check(lib().doda_rulebook_subm_generic(_p(indices), m, shape_c, int(batch_size), k, _p(nbr), m, _p(ws),
+                                           ws.numel(), _stream()), "doda_rulebook_subm_generic")
+    return nbr
+
+
 def rulebook_pairs(tbl, n_rows, flip):
     """spconv-v1.2-format (pairs int32 [2,K,n_rows] -1 padded, pairNum int32 [K]) from a table."""
     _need_cuda(tbl)

@@ -1,7 +1,8 @@
 """Rulebook construction at the level of spconv v1.2 `spconv.ops` (get_conv_output_size,
-get_indice_pairs).  Supported geometries are the ones DODA instantiates: SubM with an odd cubic
-kernel (1 or 3) and strided kernel-2 / stride-2 / padding-0 convolution (model/unet.py:36,
-model/unet_block.py:18-29,48,70,78)."""
+get_indice_pairs).  The geometries DODA instantiates — SubM with a cubic kernel of 1 or 3 and the
+kernel-2 / stride-2 / padding-0 convolution (model/unet.py:36, model/unet_block.py:18-29,48,70,78) —
+have dedicated native builders; any other kernel_size / stride / padding / dilation with a kernel
+volume of at most 27 goes through the generic one (doda_rulebook_conv_*, doda_rulebook_subm_generic)."""
 import numpy as np
 
 from .. import ops as _ops
@@ -27,18 +28,22 @@ def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
 
 def build_subm(indices, batch_size, spatial_shape, ksize):
     k = _triple(ksize)
-    if not (k[0] == k[1] == k[2] and k[0] in (1, 3)):
-        raise NotImplementedError("doda_amd SubMConv3d supports cubic kernels 1 and 3, got %r" % (k,))
-    tbl = _ops.rulebook_subm(indices, spatial_shape, batch_size, k[0])
+    if any(v % 2 == 0 or v < 1 for v in k) or k[0] * k[1] * k[2] > 27:
+        raise NotImplementedError("doda_amd SubMConv3d supports odd kernel sizes with volume <= 27, got %r" % (k,))
+    if k[0] == k[1] == k[2]:
+        tbl = _ops.rulebook_subm(indices, spatial_shape, batch_size, k[0])
+    else:
+        tbl = _ops.rulebook_subm_generic(indices, spatial_shape, batch_size, k)
     return IndiceData("subm", indices, indices, list(spatial_shape), list(spatial_shape), tbl)
 
 
 def build_down2(indices, batch_size, spatial_shape, ksize, stride, padding, dilation):
     k, s, p, d = _triple(ksize), _triple(stride), _triple(padding), _triple(dilation)
     if k != [2, 2, 2] or s != [2, 2, 2] or p != [0, 0, 0] or d != [1, 1, 1]:
-        raise NotImplementedError(
-            "doda_amd SparseConv3d supports kernel_size=2, stride=2, padding=0, dilation=1 "
-            "(the geometry DODA uses); got k=%r s=%r p=%r d=%r" % (k, s, p, d))
+        if k[0] * k[1] * k[2] > 27:
+            raise NotImplementedError("doda_amd SparseConv3d supports kernel volumes <= 27, got k=%r" % (k,))
+        outids, tbl, tbl_rev, out_shape = _ops.rulebook_conv(indices, spatial_shape, batch_size, k, s, p, d)
+        return IndiceData("down2", outids, indices, list(spatial_shape), out_shape, tbl, tbl_rev)
     outids, child, par_off, out_shape = _ops.rulebook_down2(indices, spatial_shape, batch_size)
     return IndiceData("down2", outids, indices, list(spatial_shape), out_shape, child, par_off)
 

@@ -121,6 +121,31 @@ int doda_rulebook_down2_tables(const int32_t *parent, const int32_t *off, int32_
                                int32_t m_out, int32_t *child, int32_t ld_out, int32_t *par_off,
                                int32_t ld_in, doda_stream_t stream);
 
+/* Generic geometry (spconv get_indice_pairs for any kernel_size / stride / padding / dilation with
+ * K = k0*k1*k2 <= 27; SURVEY §8f rank 4 — DODA itself only instantiates SubM k1/k3 and k2 s2).
+ * Outputs are numbered in the first-touch order of spconv's serial scan (inputs ascending, each
+ * input's valid output positions in getValidOutPos order).  Two stages around one size read-back,
+ * sharing `ws` (doda_rulebook_conv_workspace_bytes(m, K)), which must not be touched in between:
+ *   assign: out_shape_h (host, 3 ints) and *count_out (device) = number of outputs;
+ *   tables: out_indices [m_out][4], tbl[K][ld_out] (tbl[o][t] = input row feeding output t through
+ *           kernel offset o, row-major offset index) and tbl_rev[K][ld_in] (the output that input j
+ *           feeds through offset o) — the same pair of tables as child / par_off above, so forward,
+ *           inverse and gradients run through the same doda_spconv_* calls.
+ * doda_rulebook_subm_generic: SubM with per-axis odd kernel sizes (nbr[o][t], row-major offsets). */
+size_t doda_rulebook_conv_workspace_bytes(int32_t m, int32_t K);
+int doda_rulebook_conv_assign(const int32_t *indices, int32_t m, const int32_t *shape_h, int32_t batch,
+                              const int32_t *ksize_h, const int32_t *stride_h, const int32_t *pad_h,
+                              const int32_t *dil_h, int32_t *out_shape_h, int32_t *count_out, void *ws,
+                              size_t ws_bytes, doda_stream_t stream);
+int doda_rulebook_conv_tables(const int32_t *indices, int32_t m, const int32_t *shape_h, int32_t batch,
+                              const int32_t *ksize_h, const int32_t *stride_h, const int32_t *pad_h,
+                              const int32_t *dil_h, int32_t m_out, int32_t *out_indices, int32_t *tbl,
+                              int32_t ld_out, int32_t *tbl_rev, int32_t ld_in, void *ws, size_t ws_bytes,
+                              doda_stream_t stream);
+int doda_rulebook_subm_generic(const int32_t *indices, int32_t m, const int32_t *shape_h, int32_t batch,
+                               const int32_t *ksize_h, int32_t *nbr, int32_t ld, void *ws,
+                               size_t ws_bytes, doda_stream_t stream);
+
 /* Export a gather table as spconv-v1.2-format indice pairs: pairs int32 [2][K][ld_pairs]
  * (-1 padded), pair_num int32 [K].  List o holds (in = j, out = tbl[src(o)][j]) for ascending j
  * with tbl[src(o)][j] >= 0, src(o) = K-1-o when `flip` (SubM: in/out roles are mirrored) else o

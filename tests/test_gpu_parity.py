@@ -495,3 +495,70 @@ def test_dsnorm_fused_path(native_lib, dtype):
     for name in ("running_mean_source", "running_var_source", "running_mean_target", "running_var_target"):
         assert rel_err(getattr(mine, name).cpu(), getattr(ref, name).cpu()) < (1e-4 if dtype == torch.float32 else 2e-2)
     assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 3
+
+
+# ------------------------------------------------------------------ generic geometry
+GEOMS = [((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)),
+         ((3, 3, 3), (1, 1, 1), (0, 0, 0), (1, 1, 1)), ((2, 2, 2), (2, 2, 2), (0, 0, 0), (1, 1, 1)),
+         ((3, 1, 2), (1, 1, 2), (1, 0, 0), (1, 1, 1)), ((3, 3, 3), (1, 1, 1), (2, 2, 2), (2, 2, 2)),
+         ((2, 3, 1), (2, 1, 1), (0, 1, 0), (1, 1, 1))]
+
+
+@pytest.mark.parametrize("k,s,p,d", GEOMS)
+@pytest.mark.parametrize("seed,n,batch,shape,gen", CASES[:3])
+def test_rulebook_generic_conv_bit_exact(native_lib, oracle, seed, n, batch, shape, gen, k, s, p, d):
+    """doda_rulebook_conv_*: output numbering, pair lists and pair counts equal to the serial spconv
+    algorithm (oracle getIndicePairsConv) for strided, padded, dilated and non-cubic kernels."""
+    from doda_amd import spconv
+    idx = gen(seed, n, batch, shape)
+    ref_out, ref_pairs, ref_num, ref_shape = oracle.indice_pairs_conv(idx, batch, shape, list(k), list(s), list(p), list(d))
+    outids, pairs, pair_num = spconv.ops.get_indice_pairs(torch.from_numpy(idx).to(dev()), batch, shape, list(k),
+                                                          list(s), list(p), list(d))
+    assert np.array_equal(outids.cpu().numpy(), ref_out)
+    assert np.array_equal(pair_num.cpu().numpy(), ref_num)
+    assert np.array_equal(pairs.cpu().numpy()[:, :, :idx.shape[0]], ref_pairs)
+
+
+@pytest.mark.parametrize("k", [(3, 1, 3), (1, 3, 1), (3, 3, 1)])
+def test_rulebook_generic_subm_bit_exact(native_lib, oracle, k):
+    from doda_amd import spconv
+    shape, batch = [33, 31, 17], 3
+    idx = surface_voxels(1, 3000, batch, shape)
+    ref_pairs, ref_num = oracle.indice_pairs_subm(idx, batch, shape, list(k))
+    data = spconv.ops.build_subm(torch.from_numpy(idx).to(dev()), batch, shape, list(k))
+    assert np.array_equal(data.indice_pair_num.cpu().numpy(), ref_num)
+    assert np.array_equal(data.indice_pairs.cpu().numpy(), ref_pairs)
+
+
+@pytest.mark.parametrize("k,s,p,d", [GEOMS[0], GEOMS[1], GEOMS[4], GEOMS[5]])
+def test_generic_conv_fwd_bwd_and_inverse(native_lib, oracle, k, s, p, d):
+    """SparseConv3d / SparseInverseConv3d with a generic geometry through the same native conv kernels."""
+    from doda_amd import spconv
+    cin, cout = 16, 32
+    idx, shape, batch, x, rng = _conv_case(oracle, 77, cin, cout, n=1200, shape=(21, 18, 20))
+    w = (rng.standard_normal((*k, cin, cout)) * 0.3).astype(np.float32)
+    wi = (rng.standard_normal((*k, cout, cin)) * 0.3).astype(np.float32)
+    oi, pairs, pn, oshape = oracle.indice_pairs_conv(idx, batch, shape, list(k), list(s), list(p), list(d))
+    gy = rng.standard_normal((idx.shape[0], cin)).astype(np.float32)
+    x64, w64, wi64, g64 = (torch.from_numpy(a).double() for a in (x, w, wi, gy))
+    ref_mid = oracle.indice_conv(x64, w64, pairs, pn, oi.shape[0], False, False)
+    ref_y = oracle.indice_conv(ref_mid, wi64, pairs, pn, idx.shape[0], True, False)
+    ref_dmid, ref_dwi = oracle.indice_conv_backward(ref_mid, wi64, g64, pairs, pn, True, False)
+    ref_dx, ref_dw = oracle.indice_conv_backward(x64, w64, ref_dmid, pairs, pn, False, False)
+    down = spconv.SparseConv3d(cin, cout, kernel_size=list(k), stride=list(s), padding=list(p), dilation=list(d),
+                               bias=False, indice_key="g").to(dev())
+    up = spconv.SparseInverseConv3d(cout, cin, kernel_size=list(k), bias=False, indice_key="g").to(dev())
+    with torch.no_grad():
+        down.weight.copy_(torch.from_numpy(w))
+        up.weight.copy_(torch.from_numpy(wi))
+    xt = torch.from_numpy(x).to(dev()).requires_grad_(True)
+    mid = down(spconv.SparseConvTensor(xt, torch.from_numpy(idx).to(dev()), shape, batch))
+    assert mid.spatial_shape == oshape and np.array_equal(mid.indices.cpu().numpy(), oi)
+    out = up(mid)
+    assert np.array_equal(out.indices.cpu().numpy(), idx)
+    out.features.backward(torch.from_numpy(gy).to(dev()))
+    assert rel_err(mid.features.detach().cpu(), ref_mid) < RTOL
+    assert rel_err(out.features.detach().cpu(), ref_y) < RTOL
+    assert rel_err(xt.grad.cpu(), ref_dx) < RTOL
+    assert rel_err(down.weight.grad.cpu(), ref_dw) < RTOL
+    assert rel_err(up.weight.grad.cpu(), ref_dwi) < RTOL

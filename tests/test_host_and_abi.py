@@ -120,7 +120,10 @@ def test_spconv_surface_and_state_dict_layout():
     assert net.input_conv[0].weight.shape == (3, 3, 3, 3, 16)
     assert isinstance(net.unet.blocks, spconv.SparseSequential) and issubclass(model.ResidualBlock, SparseModule)
     assert all("BatchNorm" not in type(m).__name__ for m in net.modules() if isinstance(m, spconv.SparseConvolution))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):   # kernel volume > 27 has no native path
+        spconv.SparseConv3d(4, 4, kernel_size=4, stride=2)(spconv.SparseConvTensor(
+            torch.zeros(1, 4), torch.zeros((1, 4), dtype=torch.int32), [8, 8, 8], 1))
+    with pytest.raises(RuntimeError):          # and there is no CPU fallback for the supported ones
         spconv.SparseConv3d(4, 4, kernel_size=3, stride=2)(spconv.SparseConvTensor(
             torch.zeros(1, 4), torch.zeros((1, 4), dtype=torch.int32), [8, 8, 8], 1))
 
