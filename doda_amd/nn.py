@@ -56,13 +56,23 @@ def _running_stats(bn):
     return bn.running_mean, bn.running_var
 
 
+def _module_ok(bn):
+    """Static half of the test, cached on the module (per step this is asked 65 times)."""
+    ok = bn.__dict__.get("_doda_bn_ok")
+    if ok is None:
+        ok = bool((type(bn) is nn.BatchNorm1d or _is_dsnorm(bn)) and bn.affine and bn.track_running_stats
+                  and bn.momentum is not None and bn.weight.dtype == torch.float32)
+        bn.__dict__["_doda_bn_ok"] = ok
+    return ok
+
+
 def fusable(bn, features):
     """torch's BatchNorm1d (exact type) or a DSNorm with affine fp32 parameters, running stats and a
     numeric momentum, on a device [M, C] fp32/bf16 matrix with C % 4 == 0."""
-    return ((type(bn) is nn.BatchNorm1d or _is_dsnorm(bn)) and bn.affine and bn.track_running_stats
-            and bn.momentum is not None and features.is_cuda and features.dim() == 2
+    if type(bn) is nn.ReLU or type(bn) is nn.Identity:
+        return False
+    return (_module_ok(bn) and features.is_cuda and features.dim() == 2
             and features.dtype in (torch.float32, torch.bfloat16) and features.shape[1] % 4 == 0
-            and bn.weight.dtype == torch.float32
             and not (bn.training and features.shape[0] < 2))
 
 
@@ -70,9 +80,14 @@ def batch_norm_relu(features, bn, relu):
     """BatchNorm1d `bn` (+ReLU when `relu`) on features through the fused HIP kernels."""
     # num_batches_tracked += 1 happens inside the stats kernel (65 one-element add kernels per step
     # otherwise)
-    running_mean, running_var = _running_stats(bn)   # DSNorm: the current domain's pair
+    if type(bn) is nn.BatchNorm1d:
+        buf = bn._buffers
+        running_mean, running_var = buf["running_mean"], buf["running_var"]
+    else:
+        running_mean, running_var = _running_stats(bn)   # DSNorm: the current domain's pair
     if _ext is not None:
-        return _ext.bn_relu(features, bn.weight, bn.bias, running_mean, running_var,
-                            bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, relu)
+        par = bn._parameters
+        return _ext.bn_relu(features, par["weight"], par["bias"], running_mean, running_var,
+                            bn._buffers["num_batches_tracked"], bn.training, bn.momentum, bn.eps, relu)
     return _BNReLU.apply(features, bn.weight, bn.bias, running_mean, running_var,
                          bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, relu)
