@@ -121,6 +121,52 @@ at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tenso
     return dw;
 }
 
+// ---- rulebook pyramid -----------------------------------------------------------------------------
+// The 13 rulebooks of a 7-level U-Net (SubM k3 per level, k2 s2 p0 between levels) in one call: the
+// same native entry points doda_amd.ops drives through ctypes, without ~0.4 ms of Python per step.
+// Returns per level (nbr [27, M]) and, except for the last, (outids [M_out, 4], child [8, M_out],
+// par_off [8, M], out_shape).
+std::vector<std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, std::vector<int64_t>>>
+build_pyramid(const at::Tensor &indices_in, std::vector<int64_t> shape, int64_t batch, int64_t n_levels) {
+    TORCH_CHECK(indices_in.is_cuda() && indices_in.scalar_type() == at::kInt && indices_in.dim() == 2 &&
+                indices_in.size(1) == 4 && shape.size() == 3, "doda build_pyramid: indices must be int32 [M,4] on the GPU");
+    std::vector<std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, std::vector<int64_t>>> out;
+    at::Tensor indices = indices_in.contiguous();
+    const auto iopt = indices.options();
+    void *st = stream_of(indices);
+    for (int64_t lvl = 0; lvl < n_levels; ++lvl) {
+        const int32_t m = (int32_t)indices.size(0);
+        int32_t shp[3] = {(int32_t)shape[0], (int32_t)shape[1], (int32_t)shape[2]};
+        const size_t wsb = doda_rulebook_workspace_bytes(m);
+        at::Tensor ws = at::empty({(int64_t)(wsb > 256 ? wsb : 256)}, iopt.dtype(at::kByte));
+        at::Tensor nbr = at::empty({27, m}, iopt);
+        check(doda_rulebook_subm((const int32_t *)indices.data_ptr(), m, shp, (int32_t)batch, 3,
+                                 (int32_t *)nbr.data_ptr(), m, ws.data_ptr(), (size_t)ws.numel(), st),
+              "doda_rulebook_subm");
+        if (lvl == n_levels - 1) {
+            out.emplace_back(nbr, at::Tensor(), at::Tensor(), at::Tensor(), std::vector<int64_t>());
+            break;
+        }
+        at::Tensor parent = at::empty({m > 0 ? m : 1}, iopt), off = at::empty({m > 0 ? m : 1}, iopt);
+        at::Tensor out_idx = at::empty({m > 0 ? m : 1, 4}, iopt), count = at::empty({1}, iopt);
+        check(doda_rulebook_down2_assign((const int32_t *)indices.data_ptr(), m, shp, (int32_t)batch,
+                                         (int32_t *)parent.data_ptr(), (int32_t *)off.data_ptr(),
+                                         (int32_t *)out_idx.data_ptr(), (int32_t *)count.data_ptr(), ws.data_ptr(),
+                                         (size_t)ws.numel(), st), "doda_rulebook_down2_assign");
+        const int32_t m_out = count.item<int32_t>();   // the level's one size read-back
+        at::Tensor child = at::empty({8, m_out}, iopt), par_off = at::empty({8, m}, iopt);
+        check(doda_rulebook_down2_tables((const int32_t *)parent.data_ptr(), (const int32_t *)off.data_ptr(), m, m_out,
+                                         (int32_t *)child.data_ptr(), m_out, (int32_t *)par_off.data_ptr(), m, st),
+              "doda_rulebook_down2_tables");
+        std::vector<int64_t> oshape = {(shape[0] - 2) / 2 + 1, (shape[1] - 2) / 2 + 1, (shape[2] - 2) / 2 + 1};
+        at::Tensor outids = out_idx.narrow(0, 0, m_out);
+        out.emplace_back(nbr, outids, child, par_off, oshape);
+        indices = outids;
+        shape = oshape;
+    }
+    return out;
+}
+
 // ---- deferred weight gradients ---------------------------------------------------------------
 // The weight gradient of a layer feeds nothing else in the backward pass.  With deferral switched on
 // (set_defer_wgrad) the conv backward only queues (features, dy, table) and binds an uninitialised
@@ -307,6 +353,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         return gather(x, w, packed, tbl, n_out, layout, nc, out_f32);
     }, "raw gather-GEMM");
     m.def("wgrad", &wgrad, "raw weight gradient");
+    m.def("build_pyramid", &build_pyramid,
+          "all SubM k3 and k2s2 rulebooks of an n-level U-Net in one call (13 native builds, 6 size read-backs)");
     m.def("set_defer_wgrad", [](bool on) { g_defer_wgrad = on; },
           "queue conv weight gradients during backward and issue them in one multi-layer call at its end");
     m.def("get_defer_wgrad", []() { return g_defer_wgrad; });

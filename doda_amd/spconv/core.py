@@ -67,7 +67,9 @@ class SparseConvTensor:
     def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
         self.features = features
         self.indices = indices
-        self.spatial_shape = [int(v) for v in np.asarray(spatial_shape).reshape(-1)]
+        # (a plain list of ints — what the conv modules pass along — skips the numpy round trip)
+        self.spatial_shape = list(spatial_shape) if type(spatial_shape) is list else \
+            [int(v) for v in np.asarray(spatial_shape).reshape(-1)]
         self.batch_size = int(batch_size)
         self.indice_dict = {}
         self.grid = grid

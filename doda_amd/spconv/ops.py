@@ -5,7 +5,10 @@ have dedicated native builders; any other kernel_size / stride / padding / dilat
 volume of at most 27 goes through the generic one (doda_rulebook_conv_*, doda_rulebook_subm_generic)."""
 import numpy as np
 
+import torch
+
 from .. import ops as _ops
+from .._ext import ext as _ext
 from .core import IndiceData
 
 
@@ -67,6 +70,18 @@ def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", firs
     means the size read-backs of the strided levels wait on an almost empty stream instead of
     stalling the host in the middle of the forward pass."""
     indices, shape = tensor.indices, tensor.spatial_shape
+    if (_ext is not None and not tensor.indice_dict and indices.is_cuda and indices.dtype == torch.int32
+            and indices.shape[0] > 0 and all(int(v) >= 2 for v in shape)):
+        levels = _ext.build_pyramid(indices, [int(v) for v in shape], int(tensor.batch_size), int(n_levels))
+        for k, (nbr, outids, child, par_off, oshape) in enumerate(levels):
+            lvl = first_level + k
+            tensor.indice_dict[subm_key % lvl] = IndiceData("subm", indices, indices, list(shape), list(shape), nbr)
+            if k == len(levels) - 1:
+                break
+            tensor.indice_dict[down_key % lvl] = IndiceData("down2", outids, indices, list(shape), list(oshape),
+                                                            child, par_off)
+            indices, shape = outids, list(oshape)
+        return tensor.indice_dict
     for lvl in range(first_level, first_level + n_levels):
         key = subm_key % lvl
         if key not in tensor.indice_dict:
