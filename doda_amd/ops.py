@@ -498,3 +498,30 @@ def ballquery_batch_p(xyz, batch_idxs, batch_offsets, idx, start_len, n, mean_ac
                                        C.byref(total), _p(ws), ws.numel(), _stream()),
           "doda_ballquery_batch_p")
     return int(total.value)
+
+
+# ------------------------------------------------------------------------------------------
+# loss
+# ------------------------------------------------------------------------------------------
+def cross_entropy_fwd(logits, labels, ignore_index):
+    """-> (out float32 [2] = {mean loss over valid points, n_valid}, lse float32 [N])."""
+    _need_cuda(logits)
+    _need_cuda(labels)
+    if logits.dtype != torch.float32 or labels.dtype != torch.int64 or logits.dim() != 2:
+        raise RuntimeError("cross_entropy: logits float32 [N,C], labels int64 [N]")
+    logits, labels = logits.contiguous(), labels.contiguous()
+    n, c = logits.shape
+    lse = torch.empty(n, dtype=torch.float32, device=logits.device)
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    ws = _ws(lib().doda_cross_entropy_workspace_bytes(n), logits.device)
+    check(lib().doda_cross_entropy_fwd(_p(logits), _p(labels), n, c, int(ignore_index), _p(lse), _p(out), _p(ws),
+                                       ws.numel(), _stream()), "doda_cross_entropy_fwd")
+    return out, lse
+
+
+def cross_entropy_bwd(logits, labels, lse, out, grad, ignore_index):
+    n, c = logits.shape
+    d = torch.empty_like(logits)
+    check(lib().doda_cross_entropy_bwd(_p(logits), _p(labels), _p(lse), _p(out), _p(grad), n, c, int(ignore_index),
+                                       _p(d), _stream()), "doda_cross_entropy_bwd")
+    return d

@@ -303,6 +303,20 @@ int doda_ballquery_batch_p(int32_t n, int32_t mean_active, float radius, const f
                            int32_t *start_len, int32_t *total_h, void *ws, size_t ws_bytes,
                            doda_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Cross-entropy with ignore_index on the point logits (reference model/unet.py:107-108,196:
+ * nn.CrossEntropyLoss(ignore_index) after the Linear head): mean over the non-ignored points.
+ * fwd: lse float [n] (saved for bwd), out float [2] = {mean loss, number of valid points};
+ * bwd: dlogits = (softmax - onehot) * grad[0] / n_valid, zero rows for ignored points.  c <= 64.
+ * ---------------------------------------------------------------------------------------- */
+size_t doda_cross_entropy_workspace_bytes(int32_t n);
+int doda_cross_entropy_fwd(const float *logits, const int64_t *labels, int32_t n, int32_t c,
+                           int64_t ignore_index, float *lse, float *out, void *ws, size_t ws_bytes,
+                           doda_stream_t stream);
+int doda_cross_entropy_bwd(const float *logits, const int64_t *labels, const float *lse, const float *out,
+                           const float *grad, int32_t n, int32_t c, int64_t ignore_index, float *dlogits,
+                           doda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

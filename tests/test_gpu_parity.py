@@ -562,3 +562,25 @@ def test_generic_conv_fwd_bwd_and_inverse(native_lib, oracle, k, s, p, d):
     assert rel_err(xt.grad.cpu(), ref_dx) < RTOL
     assert rel_err(down.weight.grad.cpu(), ref_dw) < RTOL
     assert rel_err(up.weight.grad.cpu(), ref_dwi) < RTOL
+
+
+@pytest.mark.parametrize("c", [20, 13, 64])
+def test_fused_cross_entropy(native_lib, c):
+    """doda_cross_entropy_fwd/_bwd == nn.CrossEntropyLoss(ignore_index=255): value, gradient, all-ignored case."""
+    from doda_amd.model import cross_entropy
+    d = dev()
+    torch.manual_seed(c)
+    n = 70001
+    logits = (torch.randn(n, c, device=d) * 3).requires_grad_(True)
+    labels = torch.randint(0, c, (n,), device=d)
+    labels[torch.rand(n, device=d) < 0.2] = 255
+    ref_in = logits.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_in, labels, ignore_index=255)
+    got = cross_entropy(logits, labels, ignore_index=255)
+    (got * 1.7).backward(); (ref * 1.7).backward()
+    assert abs(float(got) - float(ref)) < 2e-6 * max(abs(float(ref)), 1.0)
+    assert rel_err(logits.grad.cpu(), ref_in.grad.cpu()) < 2e-6
+    again = cross_entropy(logits.detach(), labels, ignore_index=255)
+    assert float(again) == float(got)                       # deterministic
+    none = cross_entropy(logits.detach(), torch.full_like(labels, 255), ignore_index=255)
+    assert float(none) == 0.0
