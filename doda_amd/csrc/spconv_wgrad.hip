@@ -398,7 +398,9 @@ struct Plan {
     int TA, TB, OGW, n_og, n_tag, n_tbg, R, rows_per_chunk;
 };
 
-Plan make_plan(int K, int ca, int cb, int n_rows, int elem_bytes) {
+// multi: the job is one of many in a doda_spconv_wgrad_multi launch — the other layers fill the chip,
+// so a layer needs far fewer row chunks (each chunk costs K*ca*cb*4 bytes of partials to write and reduce)
+Plan make_plan(int K, int ca, int cb, int n_rows, int elem_bytes, bool multi = false) {
     Plan p;
     const int ta = (ca + 15) / 16, tb = (cb + 15) / 16;
     p.TA = (ta % 2 == 0) ? 2 : 1;
@@ -417,7 +419,8 @@ Plan make_plan(int K, int ca, int cb, int n_rows, int elem_bytes) {
     const int rows = n_rows > 0 ? n_rows : 1;
     // measured at M = 600k / 183k (rocprofv3): 1x1 and 2x1 tiles 68 -> 50 us going from 512 to 1024
     // blocks (+5 us of partial reduce); 2x2 tiles are fastest at 512
-    const int target = (p.TA * p.TB == 4) ? 512 : 1024;
+    // multi (whole U-Net step, wgrad + reduce): 1024 -> 1.86 ms, 512 -> 1.67, 256 -> 1.67, 128 -> 1.99
+    const int target = multi ? 512 : ((p.TA * p.TB == 4) ? 512 : 1024);
     int R = div_up(target, gy);         // blocks over the whole grid
     const int max_r = div_up(rows, RT);
     if (R > max_r) R = max_r;
@@ -512,7 +515,7 @@ bool plan_job(const doda_wgrad_job &j, JobPlan *out) {
         !j.b || !j.tbl || !j.dw || (j.elem_bytes != 2 && j.elem_bytes != 4))
         return false;
     out->esz = j.elem_bytes;
-    out->p = make_plan(j.K, j.ca, j.cb, j.n_rows, j.elem_bytes);
+    out->p = make_plan(j.K, j.ca, j.cb, j.n_rows, j.elem_bytes, true);
     out->vok = ((size_t)j.ca * j.elem_bytes % 16 == 0) && ((size_t)j.cb * j.elem_bytes % 16 == 0) &&
                ((uintptr_t)j.a % 16 == 0) && ((uintptr_t)j.b % 16 == 0);
     out->key = (((j.elem_bytes * 4 + out->p.TA) * 4 + out->p.TB) * 8 + out->p.OGW) * 2 + out->vok;
