@@ -227,7 +227,8 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply(const typename T::elem 
                                                          const float *__restrict__ gamma,
                                                          const float *__restrict__ beta, int relu,
                                                          const float *__restrict__ coef,
-                                                         typename T::elem *__restrict__ dx) {
+                                                         typename T::elem *__restrict__ dx,
+                                                         const typename T::elem *__restrict__ add) {
     for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < n_frag;
          e += (long long)gridDim.x * BN_BLOCK) {
         const int f = (int)(e % nf);
@@ -245,7 +246,9 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply(const typename T::elem 
         const f32x4 a = *reinterpret_cast<const f32x4 *>(coef + f * 4);
         const f32x4 b = *reinterpret_cast<const f32x4 *>(coef + c + f * 4);
         const f32x4 d = *reinterpret_cast<const f32x4 *>(coef + 2 * c + f * 4);
-        T::store4(dx + e * 4, a * (dz - b - xh * d));
+        f32x4 o = a * (dz - b - xh * d);
+        if (add) o += T::load4(add + e * 4);   // a second gradient of x (residual path) summed here
+        T::store4(dx + e * 4, o);
     }
 }
 
@@ -337,7 +340,8 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd(const typename T::elem 
                                                          const float *__restrict__ beta, int relu,
                                                          typename T::elem *__restrict__ dx,
                                                          float *__restrict__ dgamma,
-                                                         float *__restrict__ dbeta) {
+                                                         float *__restrict__ dbeta,
+                                                         const typename T::elem *__restrict__ add) {
     __shared__ float lds[4][4];
     const int f = blockIdx.x;
     const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + f * 4);
@@ -372,7 +376,9 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd(const typename T::elem 
 #pragma unroll
             for (int q = 0; q < 4; ++q) dz[q] = yv[q] > 0.f ? dz[q] : 0.f;
         }
-        T::store4(dx + (long long)r * c + f * 4, a * (dz - b - xh * d));
+        f32x4 o = a * (dz - b - xh * d);
+        if (add) o += T::load4(add + (long long)r * c + f * 4);
+        T::store4(dx + (long long)r * c + f * 4, o);
     }
 }
 
@@ -423,14 +429,14 @@ int run_fwd(const void *x_, int m, int c, float eps, float momentum, const float
 template <class T>
 int run_bwd(const void *x_, const void *dy_, int m, int c, const float *mean, const float *invstd,
             const float *gamma, const float *beta, int relu, void *dx_, float *dgamma, float *dbeta,
-            void *ws, size_t ws_bytes, hipStream_t s) {
+            void *ws, size_t ws_bytes, const void *add_, hipStream_t s) {
     typedef typename T::elem elem;
-    const elem *x = (const elem *)x_, *dy = (const elem *)dy_;
+    const elem *x = (const elem *)x_, *dy = (const elem *)dy_, *add = (const elem *)add_;
     elem *dx = (elem *)dx_;
     const Geo g = make_geo(c);
     if (m <= BN_SMALL_ROWS) {
         hipLaunchKernelGGL((bn_small_bwd<T>), dim3(c / 4), dim3(BN_BLOCK), 0, s, x, dy, m, c, mean, invstd,
-                           gamma, beta, relu, dx, dgamma, dbeta);
+                           gamma, beta, relu, dx, dgamma, dbeta, add);
         return doda_check_launch();
     }
     const int nb = n_blocks_for(m, g);
@@ -444,7 +450,7 @@ int run_bwd(const void *x_, const void *dy_, int m, int c, const float *mean, co
     const long long n_frag = (long long)m * g.nf;
     const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
     hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(grid), dim3(BN_BLOCK), 0, s, x, dy, n_frag, g.nf, c, mean,
-                       invstd, gamma, beta, relu, coef, dx);
+                       invstd, gamma, beta, relu, coef, dx, add);
     return doda_check_launch();
 }
 
@@ -488,7 +494,26 @@ extern "C" int doda_bn_relu_bwd(const void *x, const void *dy, int32_t m, int32_
         return DODA_ERR_INVALID;
     if (elem_bytes == 4)
         return run_bwd<F32>(x, dy, m, c, save_mean, save_invstd, gamma, beta, relu, dx, dgamma, dbeta, ws,
-                            ws_bytes, as_stream(stream));
+                            ws_bytes, nullptr, as_stream(stream));
     return run_bwd<BF16>(x, dy, m, c, save_mean, save_invstd, gamma, beta, relu, dx, dgamma, dbeta, ws,
-                         ws_bytes, as_stream(stream));
+                         ws_bytes, nullptr, as_stream(stream));
+}
+
+// dx = BN backward + add: `add` ([m, c], dtype of x) is a second gradient of the same x — in a
+// pre-activation residual block x feeds both the BatchNorm and the skip connection — so the
+// gradient accumulation rides in the apply pass instead of a separate elementwise kernel.
+extern "C" int doda_bn_relu_bwd_add(const void *x, const void *dy, int32_t m, int32_t c,
+                                    int32_t elem_bytes, const float *save_mean,
+                                    const float *save_invstd, const float *gamma, const float *beta,
+                                    int32_t relu, const void *add, void *dx, float *dgamma, float *dbeta,
+                                    void *ws, size_t ws_bytes, doda_stream_t stream) {
+    if (m == 0) return DODA_OK;
+    if (bn_args_bad(m, c, elem_bytes)) return DODA_ERR_UNSUPPORTED;
+    if (!x || !dy || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !ws || !add)
+        return DODA_ERR_INVALID;
+    if (elem_bytes == 4)
+        return run_bwd<F32>(x, dy, m, c, save_mean, save_invstd, gamma, beta, relu, dx, dgamma, dbeta, ws,
+                            ws_bytes, add, as_stream(stream));
+    return run_bwd<BF16>(x, dy, m, c, save_mean, save_invstd, gamma, beta, relu, dx, dgamma, dbeta, ws,
+                         ws_bytes, add, as_stream(stream));
 }

@@ -302,6 +302,9 @@ at::Tensor indice_conv(const at::Tensor &features, const at::Tensor &weight, con
 }
 
 // ---- fused BatchNorm1d(+ReLU).  Gradient edges: 0 x, 1 weight, 2 bias. ----------------------------
+// With `passthrough` the op has a second output: an alias of x whose gradient (the skip connection of a
+// pre-activation residual block) is summed into dx by the apply pass (doda_bn_relu_bwd_add) instead of
+// by a separate accumulation kernel.
 struct BNNode : public torch::autograd::Node {
     SavedVariable x_, weight_, bias_;
     at::Tensor mean, invstd;
@@ -310,10 +313,30 @@ struct BNNode : public torch::autograd::Node {
     variable_list apply(variable_list &&grads) override {
         const at::Tensor x = x_.unpack(), weight = weight_.unpack(), bias = bias_.unpack();
         variable_list out(3);
-        if (!grads[0].defined()) return out;
+        at::Tensor extra;   // gradient of the pass-through alias
+        if (grads.size() > 1 && grads[1].defined()) extra = grads[1];
+        if (!grads[0].defined()) {
+            if (extra.defined() && task_should_compute_output(0)) out[0] = extra;
+            return out;
+        }
         const at::Tensor dy = grads[0].contiguous();
         at::Tensor dx, dg, db;
-        if (training) {
+        if (training && extra.defined() && extra.scalar_type() == x.scalar_type()) {
+            const at::Tensor add = extra.contiguous();
+            const int64_t m = x.size(0), c = x.size(1);
+            dx = at::empty_like(x);
+            dg = at::empty({c}, x.options().dtype(at::kFloat));
+            db = at::empty({c}, x.options().dtype(at::kFloat));
+            const size_t wsb = doda_bn_workspace_bytes((int)m, (int)c);
+            at::Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
+            check(doda_bn_relu_bwd_add(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
+                                       (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(),
+                                       (const float *)weight.data_ptr(), (const float *)bias.data_ptr(),
+                                       relu ? 1 : 0, add.data_ptr(), dx.data_ptr(), (float *)dg.data_ptr(),
+                                       (float *)db.data_ptr(), ws.data_ptr(), wsb, stream_of(x)),
+                  "doda_bn_relu_bwd_add");
+            extra = at::Tensor();
+        } else if (training) {
             const int64_t m = x.size(0), c = x.size(1);
             dx = at::empty_like(x);
             dg = at::empty({c}, x.options().dtype(at::kFloat));
@@ -334,6 +357,7 @@ struct BNNode : public torch::autograd::Node {
             dg = (dz * xh).sum(0);
             db = dz.sum(0);
         }
+        if (extra.defined()) dx = dx + extra;
         if (task_should_compute_output(0)) out[0] = dx;
         if (task_should_compute_output(1)) out[1] = dg.scalar_type() == weight.scalar_type() ? dg : dg.to(weight.scalar_type());
         if (task_should_compute_output(2)) out[2] = db.scalar_type() == bias.scalar_type() ? db : db.to(bias.scalar_type());
@@ -349,15 +373,17 @@ struct BNNode : public torch::autograd::Node {
     std::string name() const override { return "DodaBNReLUBackward"; }
 };
 
-at::Tensor bn_relu(const at::Tensor &x_in, const at::Tensor &weight, const at::Tensor &bias,
-                   const at::Tensor &running_mean, const at::Tensor &running_var, const at::Tensor &nbt,
-                   bool training, double momentum, double eps, bool relu) {
+std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &weight, const at::Tensor &bias,
+                                     const at::Tensor &running_mean, const at::Tensor &running_var,
+                                     const at::Tensor &nbt, bool training, double momentum, double eps,
+                                     bool relu, bool passthrough) {
     const bool need_grad = at::GradMode::is_enabled() &&
                            (x_in.requires_grad() || weight.requires_grad() || bias.requires_grad());
-    at::Tensor x, y, mean, invstd;
+    at::Tensor x, y, mean, invstd, xp;
     {
         at::AutoDispatchBelowADInplaceOrView guard;
         x = x_in.contiguous();
+        if (passthrough) xp = x.alias();
         const int esz = elem_bytes(x);
         const int64_t m = x.size(0), c = x.size(1);
         y = at::empty_like(x);
@@ -390,8 +416,23 @@ at::Tensor bn_relu(const at::Tensor &x_in, const at::Tensor &weight, const at::T
         node->training = training;
         node->relu = relu;
         torch::autograd::set_history(y, node);
+        if (passthrough) torch::autograd::set_history(xp, node);   // output 1
     }
-    return y;
+    if (passthrough) return {y, xp};
+    return {y};
+}
+
+at::Tensor bn_relu(const at::Tensor &x, const at::Tensor &weight, const at::Tensor &bias,
+                   const at::Tensor &running_mean, const at::Tensor &running_var, const at::Tensor &nbt,
+                   bool training, double momentum, double eps, bool relu) {
+    return bn_relu_impl(x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, relu, false)[0];
+}
+
+// (y, x_alias): use x_alias wherever the block needs x again (its gradient is summed inside this op's backward)
+std::vector<at::Tensor> bn_relu_pass(const at::Tensor &x, const at::Tensor &weight, const at::Tensor &bias,
+                                     const at::Tensor &running_mean, const at::Tensor &running_var,
+                                     const at::Tensor &nbt, bool training, double momentum, double eps, bool relu) {
+    return bn_relu_impl(x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, relu, true);
 }
 
 }  // namespace
@@ -399,6 +440,7 @@ at::Tensor bn_relu(const at::Tensor &x_in, const at::Tensor &weight, const at::T
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("indice_conv", &indice_conv, "sparse conv (gather table) with autograd");
     m.def("bn_relu", &bn_relu, "fused BatchNorm1d(+ReLU) with autograd");
+    m.def("bn_relu_pass", &bn_relu_pass, "fused BatchNorm1d(+ReLU) returning (y, alias of x) for residual blocks");
     m.def("gather", [](const at::Tensor &x, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
                        const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32) {
         return gather(x, w, packed, tbl, n_out, layout, nc, out_f32);

@@ -61,9 +61,12 @@ class ResidualBlock(SparseModule):
             norm_fn(out_channels), nn.ReLU(), _subm3(out_channels, out_channels, indice_key))
 
     def forward(self, input):
-        skip = self.i_branch(_shallow(input))
         # reference: output = conv_branch(input); output.features += i_branch(identity).features
-        # (model/unet_block.py:33-37).  Here the add rides in the last convolution's store.
+        # (model/unet_block.py:33-37).  Here the add rides in the last convolution's store and, for an
+        # identity skip, the skip's gradient in the first BatchNorm's backward kernel.
+        if type(self.i_branch[0]) is nn.Identity and len(self.i_branch) == 1:
+            return self.conv_branch(input, residual="input")
+        skip = self.i_branch(_shallow(input))
         return self.conv_branch(input, residual=skip.features)
 
 

@@ -76,8 +76,10 @@ def fusable(bn, features):
             and not (bn.training and features.shape[0] < 2))
 
 
-def batch_norm_relu(features, bn, relu):
-    """BatchNorm1d `bn` (+ReLU when `relu`) on features through the fused HIP kernels."""
+def batch_norm_relu(features, bn, relu, passthrough=False):
+    """BatchNorm1d `bn` (+ReLU when `relu`) on features through the fused HIP kernels.
+    passthrough: return (y, x_alias) — x_alias is `features` again, for a skip connection; its gradient
+    is summed inside this op's backward kernel instead of by an autograd accumulation pass."""
     # num_batches_tracked += 1 happens inside the stats kernel (65 one-element add kernels per step
     # otherwise)
     if type(bn) is nn.BatchNorm1d:
@@ -87,7 +89,13 @@ def batch_norm_relu(features, bn, relu):
         running_mean, running_var = _running_stats(bn)   # DSNorm: the current domain's pair
     if _ext is not None:
         par = bn._parameters
+        if passthrough:
+            return _ext.bn_relu_pass(features, par["weight"], par["bias"], running_mean, running_var,
+                                     bn._buffers["num_batches_tracked"], bn.training, bn.momentum, bn.eps, relu)
         return _ext.bn_relu(features, par["weight"], par["bias"], running_mean, running_var,
                             bn._buffers["num_batches_tracked"], bn.training, bn.momentum, bn.eps, relu)
+    if passthrough:
+        return _BNReLU.apply(features, bn.weight, bn.bias, running_mean, running_var,
+                             bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, relu), features
     return _BNReLU.apply(features, bn.weight, bn.bias, running_mean, running_var,
                          bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, relu)

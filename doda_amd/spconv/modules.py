@@ -72,9 +72,15 @@ class SparseSequential(SparseModule):
 
     def forward(self, input, residual=None):
         """residual (extension over spconv): feature matrix added to the output of the sequence; when
-        the last module is a sparse convolution the add is fused into its kernel."""
+        the last module is a sparse convolution the add is fused into its kernel.  residual="input" adds
+        the sequence's own input features (identity skip of a residual block): if the sequence starts
+        with a fused BatchNorm the skip's gradient is summed inside that BatchNorm's backward kernel."""
         mods = list(self._modules.values())
         k = 0
+        take_input = isinstance(residual, str)
+        if take_input:
+            assert residual == "input"
+            residual = input.features
         while k < len(mods):
             module = mods[k]
             k += 1
@@ -89,7 +95,10 @@ class SparseSequential(SparseModule):
                     if _dnn.fusable(module, input.features):
                         # BatchNorm1d [-> ReLU] on .features: one fused HIP path (doda_amd.nn)
                         relu = k < len(mods) and type(mods[k]) is nn.ReLU
-                        input.features = _dnn.batch_norm_relu(input.features, module, relu)
+                        if take_input and k == 1 and module.training:
+                            input.features, residual = _dnn.batch_norm_relu(input.features, module, relu, True)
+                        else:
+                            input.features = _dnn.batch_norm_relu(input.features, module, relu)
                         k += int(relu)
                     else:
                         input.features = _run(module, input.features)

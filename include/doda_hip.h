@@ -270,6 +270,13 @@ int doda_bn_relu_bwd(const void *x, const void *dy, int32_t m, int32_t c, int32_
                      const float *save_mean, const float *save_invstd, const float *gamma,
                      const float *beta, int32_t relu, void *dx, float *dgamma, float *dbeta,
                      void *ws, size_t ws_bytes, doda_stream_t stream);
+/* Same, plus a second gradient of x summed into dx: dx = BN-backward(dy) + add (add: [m, c], dtype of x).
+ * In a pre-activation residual block (model/unet_block.py:23-37) x feeds both the first BatchNorm and
+ * the skip connection; autograd would add the two gradients with an extra elementwise pass. */
+int doda_bn_relu_bwd_add(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
+                         const float *save_mean, const float *save_invstd, const float *gamma,
+                         const float *beta, int32_t relu, const void *add, void *dx, float *dgamma,
+                         float *dbeta, void *ws, size_t ws_bytes, doda_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Neighbour queries

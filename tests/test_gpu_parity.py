@@ -584,3 +584,38 @@ def test_fused_cross_entropy(native_lib, c):
     assert float(again) == float(got)                       # deterministic
     none = cross_entropy(logits.detach(), torch.full_like(labels, 255), ignore_index=255)
     assert float(none) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("m", [300, 30000])
+def test_residual_block_identity_skip_fusions(native_lib, dtype, m):
+    """SparseSequential(..., residual="input"): skip add in the last conv's store and the skip's gradient in
+    the first BatchNorm's backward (doda_bn_relu_bwd_add), against the unfused formulation."""
+    from doda_amd import spconv
+    d = dev()
+    c, shape = 32, [64, 64, 48]
+    idx = torch.from_numpy(surface_voxels(2, m, 2, shape)).to(d)
+    n = idx.shape[0]
+    torch.manual_seed(1)
+    seq = spconv.SparseSequential(
+        torch.nn.BatchNorm1d(c, eps=1e-4, momentum=0.1), torch.nn.ReLU(), spconv.SubMConv3d(c, c, 3, bias=False, indice_key="k"),
+        torch.nn.BatchNorm1d(c, eps=1e-4, momentum=0.1), torch.nn.ReLU(), spconv.SubMConv3d(c, c, 3, bias=False, indice_key="k")).to(d)
+    x0 = (torch.randn(n, c, device=d) * 2).to(dtype)
+    g = torch.randn(n, c, device=d)
+    res = []
+    for fused in (True, False):
+        for mod in seq.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.reset_running_stats()
+        seq.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        t = spconv.SparseConvTensor(x, idx, shape, 2)
+        if fused:
+            y = seq(t, residual="input").features
+        else:
+            y = seq(t).features + x
+        (y.float() * g).sum().backward()
+        res.append([y.detach().float(), x.grad.float()] + [p.grad.float().clone() for p in seq.parameters()])
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6)
