@@ -212,8 +212,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "cfgs/scannet SparseConv U-Net training step (voxel pooling + fwd "
-                                   "+ CE + bwd + SGD), 2 cm voxels, %d scenes/GPU x ~%d active voxels, "
-                                   "random-init weights" % (args.scenes, args.voxels),
+                                   "+ CE + bwd + SGD), %g cm voxels, %d scenes/GPU x ~%d active voxels, "
+                                   "random-init weights" % (100.0 / args.voxel_scale, args.scenes, args.voxels),
                        "global_batch": args.scenes * world, "voxels_per_gpu": m_local,
                        "points_per_gpu": n_local, "pairs_per_voxel_subm1": round(ppv, 2),
                        "parallelism": "dp%d" % world, "n_classes": 20, "final_loss": final_loss,
