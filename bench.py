@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, MI355X_MICROARCH.md
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=30)
-    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=30)
     p.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
                    help="feature storage dtype; bf16 = BASELINE config 2 (fp32 accumulate, fp32 weights)")
     p.add_argument("--scenes", type=int, default=4, help="scenes per GPU (BATCH_SIZE_PER_GPU)")
