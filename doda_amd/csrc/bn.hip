@@ -290,12 +290,35 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_fwd(const typename T::elem 
                                                          float *__restrict__ invstd) {
     __shared__ float lds[4][4];
     const int f = blockIdx.x;
+    // Every global read of the kernel is issued up front and independently (rows past m re-read row
+    // m-1 and are masked): a dependent round trip to L2/HBM costs 2-3 us here and the old form had
+    // four of them in series (shift row, stats sweep, affine parameters, apply sweep).
+    constexpr int RPT = BN_SMALL_ROWS / BN_BLOCK;
     const f32x4 k = T::load4(x + f * 4);
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
+    const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + f * 4);
+    // (the running statistics and the batch counter too: updating them element by element at the end
+    // cost thread 0 five more dependent round trips)
+    f32x4 rm = {0, 0, 0, 0}, rv = {0, 0, 0, 0};
+    long long n_tracked = 0;
+    if (threadIdx.x == 0 && running_mean) {
+        rm = *reinterpret_cast<const f32x4 *>(running_mean + f * 4);
+        rv = *reinterpret_cast<const f32x4 *>(running_var + f * 4);
+    }
+    if (threadIdx.x == 0 && f == 0 && nbt) n_tracked = *nbt;
+    f32x4 xv[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = threadIdx.x + i * BN_BLOCK;
+        xv[i] = T::load4(x + (long long)(r < m ? r : m - 1) * c + f * 4);
+    }
     f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-    for (int r = threadIdx.x; r < m; r += BN_BLOCK) {
-        const f32x4 v = T::load4(x + (long long)r * c + f * 4) - k;
-        s1 += v;
-        s2 += v * v;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const f32x4 v = xv[i] - k;
+        const float w = threadIdx.x + i * BN_BLOCK < m ? 1.f : 0.f;
+        s1 += v * w;
+        s2 += v * v * w;
     }
     s1 = block_sum4(s1, lds);
     s2 = block_sum4(s2, lds);
@@ -307,27 +330,30 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_fwd(const typename T::elem 
         if (var < 0.0) var = 0.0;
         mu[q] = (float)((double)k[q] + d);
         is[q] = (float)(1.0 / sqrt(var + (double)eps));
-        if (threadIdx.x == 0) {
-            mean[f * 4 + q] = mu[q];
-            invstd[f * 4 + q] = is[q];
-            if (running_mean) {
-                const double unbiased = m > 1 ? var * (double)m / (double)(m - 1) : var;
-                running_mean[f * 4 + q] = (float)((1.0 - momentum) * (double)running_mean[f * 4 + q] + momentum * ((double)k[q] + d));
-                running_var[f * 4 + q] = (float)((1.0 - momentum) * (double)running_var[f * 4 + q] + momentum * unbiased);
-            }
-        }
+        const double unbiased = m > 1 ? var * (double)m / (double)(m - 1) : var;
+        rm[q] = (float)((1.0 - momentum) * (double)rm[q] + momentum * ((double)k[q] + d));
+        rv[q] = (float)((1.0 - momentum) * (double)rv[q] + momentum * unbiased);
     }
-    if (threadIdx.x == 0 && f == 0 && nbt) *nbt += 1;
-    const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
-    const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + f * 4);
-    for (int r = threadIdx.x; r < m; r += BN_BLOCK) {
-        const f32x4 v = T::load4(x + (long long)r * c + f * 4);
-        f32x4 o = (v - mu) * is * ga + be;
-        if (relu) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = o[q] > 0.f ? o[q] : 0.f;
+    if (threadIdx.x == 0) {
+        *reinterpret_cast<f32x4 *>(mean + f * 4) = mu;
+        *reinterpret_cast<f32x4 *>(invstd + f * 4) = is;
+        if (running_mean) {
+            *reinterpret_cast<f32x4 *>(running_mean + f * 4) = rm;
+            *reinterpret_cast<f32x4 *>(running_var + f * 4) = rv;
         }
-        T::store4(y + (long long)r * c + f * 4, o);
+        if (f == 0 && nbt) *nbt = n_tracked + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = threadIdx.x + i * BN_BLOCK;
+        if (r < m) {
+            f32x4 o = (xv[i] - mu) * is * ga + be;
+            if (relu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = o[q] > 0.f ? o[q] : 0.f;
+            }
+            T::store4(y + (long long)r * c + f * 4, o);
+        }
     }
 }
 
@@ -348,17 +374,28 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd(const typename T::elem 
     const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + f * 4);
     const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
     const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + f * 4);
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-    for (int r = threadIdx.x; r < m; r += BN_BLOCK) {
-        const f32x4 xh = (T::load4(x + (long long)r * c + f * 4) - mu) * is;
-        f32x4 dz = T::load4(dy + (long long)r * c + f * 4);
-        if (relu) {
-            const f32x4 yv = xh * ga + be;
+    constexpr int RPT = BN_SMALL_ROWS / BN_BLOCK;
+    f32x4 xh[RPT], dz[RPT], ad[RPT];   // all reads up front, kept for the apply pass (see bn_small_fwd)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dz[q] = yv[q] > 0.f ? dz[q] : 0.f;
+    for (int i = 0; i < RPT; ++i) {
+        const int r = threadIdx.x + i * BN_BLOCK;
+        const long long off = (long long)(r < m ? r : m - 1) * c + f * 4;
+        xh[i] = T::load4(x + off);
+        dz[i] = T::load4(dy + off);
+        ad[i] = add ? T::load4(add + off) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        xh[i] = (xh[i] - mu) * is;
+        if (relu) {
+            const f32x4 yv = xh[i] * ga + be;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dz[i][q] = yv[q] > 0.f ? dz[i][q] : 0.f;
         }
-        s1 += dz;
-        s2 += dz * xh;
+        const float w = threadIdx.x + i * BN_BLOCK < m ? 1.f : 0.f;
+        s1 += dz[i] * w;
+        s2 += dz[i] * xh[i] * w;
     }
     s1 = block_sum4(s1, lds);
     s2 = block_sum4(s2, lds);
@@ -368,17 +405,10 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd(const typename T::elem 
     }
     const float inv_m = 1.f / (float)m;
     const f32x4 a = ga * is, b = s1 * inv_m, d = s2 * inv_m;
-    for (int r = threadIdx.x; r < m; r += BN_BLOCK) {
-        const f32x4 xh = (T::load4(x + (long long)r * c + f * 4) - mu) * is;
-        f32x4 dz = T::load4(dy + (long long)r * c + f * 4);
-        if (relu) {
-            const f32x4 yv = xh * ga + be;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dz[q] = yv[q] > 0.f ? dz[q] : 0.f;
-        }
-        f32x4 o = a * (dz - b - xh * d);
-        if (add) o += T::load4(add + (long long)r * c + f * 4);
-        T::store4(dx + (long long)r * c + f * 4, o);
+    for (int i = 0; i < RPT; ++i) {
+        const int r = threadIdx.x + i * BN_BLOCK;
+        if (r < m) T::store4(dx + (long long)r * c + f * 4, a * (dz[i] - b - xh[i] * d) + ad[i]);
     }
 }
 
