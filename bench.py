@@ -108,6 +108,45 @@ def kernel_roofline(batch_dev, dtype, reps):
     return roof, pairs_total / max(m, 1)
 
 
+def step_algorithmic_bytes(net, batch_dev, dtype):
+    """Algorithmic bytes of one training step over the 71 sparse convolutions: per layer
+    B_f + B_b = s(3 M_in Cin + 2 M_out Cout) + 3 s K Cin Cout + 16 P, with the layer's own row counts and
+    pair count P (SubM: non-empty table entries; k2 s2 and its inverse: one pair per fine voxel; 1x1: M).
+    BN / ReLU / loss traffic is not counted (fusable).  Returns (bytes, number of layers)."""
+    from doda_amd import spconv
+    s = 4 if dtype == "f32" else 2
+    idx = batch_dev["voxel_locs"].int()
+    probe = spconv.SparseConvTensor(None, idx, batch_dev["spatial_shape"], int(batch_dev["offsets"].numel() - 1))
+    book = spconv.ops.build_pyramid(probe, len(net.unet.nPlanes))
+    total, layers = 0, 0
+    first_rows = idx.shape[0]
+    for mod in net.modules():
+        if not isinstance(mod, spconv.SparseConvolution):
+            continue
+        K = mod.weight.shape[0] * mod.weight.shape[1] * mod.weight.shape[2]
+        cin, cout = mod.in_channels, mod.out_channels
+        data = book.get(mod.indice_key)
+        if mod.conv1x1:
+            # the 1x1 shortcuts carry no indice_key: find the level by the channel count (c = 16 * level)
+            lvl = max(1, cout // 16)
+            rows = book["subm%d" % lvl].outids.shape[0]
+            m_in = m_out = pairs = rows
+        elif data is None:       # input conv: level-1 SubM rulebook under its own key
+            data = book["subm1"]
+            m_in = m_out = first_rows
+            pairs = int((data.tbl >= 0).sum())
+        elif data.kind == "subm":
+            m_in = m_out = data.outids.shape[0]
+            pairs = int((data.tbl >= 0).sum())
+        else:
+            fine, coarse = data.indices.shape[0], data.outids.shape[0]
+            m_in, m_out = (coarse, fine) if mod.inverse else (fine, coarse)
+            pairs = fine
+        total += s * (3 * m_in * cin + 2 * m_out * cout) + 3 * s * K * cin * cout + 16 * pairs
+        layers += 1
+    return total, layers
+
+
 def pmc_traffic(dtype):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
     (tools/profile_round.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of the same kernel
@@ -205,6 +244,12 @@ def main():
 
     if rank == 0:
         roof, ppv = kernel_roofline(batch_dev, args.dtype, args.kernel_reps)
+        step_bytes, n_layers = step_algorithmic_bytes(net, batch_dev, args.dtype)
+        step_gbs = step_bytes / (elapsed / args.steps) / 1e9
+        roof["step"] = {"algorithmic_bytes": step_bytes, "conv_layers": n_layers, "GBs": step_gbs,
+                        "frac_of_hbm_peak": step_gbs / HBM_PEAK_GBS,
+                        "note": "all 71 sparse convs fwd+bwd (SURVEY 8d formula) over the whole step time, which "
+                                "also contains BN, rulebooks, loss and optimizer"}
         line = {
             "metric": "active-voxels/sec fwd+bwd SparseConv U-Net, ScanNet 2cm",
             "value": m_total * args.steps / elapsed, "unit": "voxels/s", "n_gpus": world,
