@@ -10,7 +10,7 @@ if os.environ.get("DODA_NO_EXT", "0") != "1":
         from . import _lib
         _lib.lib()     # loads libdoda_hip.so (fails loudly if missing)
         from . import _doda_torch as ext  # type: ignore
-        if ext.abi_version() != 1:
+        if ext.abi_version() != _lib.ABI_VERSION or getattr(ext, "built_for_abi", lambda: -1)() != _lib.ABI_VERSION:
             ext = None
     except ImportError:
         ext = None

@@ -55,6 +55,9 @@ _SIGNATURES = {
     "doda_spconv_wgrad_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "doda_spconv_wgrad_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
                                       c_vp, c_sz, c_vp]),
+    "doda_spconv_wgrad_pairs_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "doda_spconv_wgrad_pairs_bf16": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32,
+                                             c_vp, c_i32, c_vp, c_sz, c_vp]),
     "doda_spconv_wgrad_multi_workspace_bytes": (c_sz, [c_vp, c_i32]),
     "doda_spconv_wgrad_multi_desc_bytes": (c_sz, [c_i32]),
     "doda_spconv_wgrad_multi": (c_i32, [c_vp, c_i32, c_vp, c_sz, c_vp, c_sz, c_vp]),
@@ -82,6 +85,7 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+ABI_VERSION = 2   # include/doda_hip.h DODA_ABI_VERSION
 
 _lib = None
 
@@ -106,7 +110,7 @@ def lib():
                 raise DodaNativeError("libdoda_hip.so lacks symbol %s (stale build?)" % name) from e
             fn.restype = res
             fn.argtypes = args
-        if handle.doda_abi_version() != 1:
+        if handle.doda_abi_version() != ABI_VERSION:
             raise DodaNativeError("libdoda_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -475,11 +475,12 @@ extern "C" int doda_rulebook_pairs(const int32_t *tbl, int32_t ld, int32_t K, in
     if (ws_bytes < doda_rulebook_pairs_workspace_bytes(n_rows, K)) return DODA_ERR_WORKSPACE;
     const int nt = div_up(n_rows, PAIR_TILE);
     int32_t *counts = (int32_t *)ws;
-    hipMemsetAsync(pairs, 0xFF, (size_t)2 * K * ld_pairs * 4, s);
-    hipLaunchKernelGGL(pairs_count, dim3(nt, K), dim3(PAIR_TILE), 0, s, tbl, ld, K, n_rows, flip,
+    const int flip_tbl = flip & 1;
+    if (!(flip & 2)) hipMemsetAsync(pairs, 0xFF, (size_t)2 * K * ld_pairs * 4, s);   // -1 padding (spconv format)
+    hipLaunchKernelGGL(pairs_count, dim3(nt, K), dim3(PAIR_TILE), 0, s, tbl, ld, K, n_rows, flip_tbl,
                        counts, nt);
     hipLaunchKernelGGL(pairs_scan, dim3(K), dim3(256), 0, s, counts, nt, pair_num);
-    hipLaunchKernelGGL(pairs_fill, dim3(nt, K), dim3(PAIR_TILE), 0, s, tbl, ld, K, n_rows, flip,
+    hipLaunchKernelGGL(pairs_fill, dim3(nt, K), dim3(PAIR_TILE), 0, s, tbl, ld, K, n_rows, flip_tbl,
                        counts, nt, pairs, ld_pairs);
     return doda_check_launch();
 }

@@ -12,7 +12,7 @@
 // Offsets with no present row in the step are skipped wave-uniformly.  Accumulators (<= 7 offsets
 // x TA x TB 16x16 tiles) live in registers for the whole row chunk; per-chunk partials are reduced
 // by a second kernel in fixed order: deterministic, no float atomics.
-#include "common.hpp"
+#include "wgrad_pairs.hpp"
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
@@ -286,11 +286,11 @@ struct WJob {            // device descriptor of one layer inside a variant grou
     float *out;          // partials of the job (or dw itself when it has a single row chunk)
     int ca, cb, ld, K, n_rows, rows_per_chunk, n_tag, n_tbg, n_og, blk_end;   // blk_end: inclusive prefix
 };
-struct RJob {            // one reduction: dw[q] = sum_r partial[r][q]
+struct RJob {            // one reduction: dw[q] (+)= sum_r partial[r][q]
     const float4 *partial;
     float4 *dw;
     long long n_quad;
-    int R, blk_end;
+    int R, blk_end, accumulate, pad;
 };
 
 template <class J>
@@ -336,6 +336,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi(const RJob *__restrict
             const float4 v = part[r][el];
             t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
         }
+        if (d.accumulate) {
+            const float4 old = d.dw[q];
+            t.x += old.x; t.y += old.y; t.z += old.z; t.w += old.w;
+        }
         d.dw[q] = t;
     }
 }
@@ -343,7 +347,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi(const RJob *__restrict
 // Fixed-order reduction of the per-chunk partials: 16 element lanes x 16 chunk lanes per block;
 // lane r sums chunks r, r+16, ... and the 16 lane sums are added in ascending r (deterministic).
 __global__ __launch_bounds__(256) void wgrad_reduce(const float *__restrict__ partial, int R,
-                                                    long long n_elem, float *__restrict__ dw) {
+                                                    long long n_elem, float *__restrict__ dw,
+                                                    int accumulate = 0) {
     __shared__ float part[16][17];
     const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const long long e = (long long)blockIdx.x * 16 + el;
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float *__restrict__ pa
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += part[r][el];
-        dw[e] = t;
+        dw[e] = accumulate ? dw[e] + t : t;
     }
 }
 
@@ -557,19 +562,38 @@ struct Staging {
 Staging g_staging;
 }  // namespace
 
+// job classes of a multi call
+enum { J_SKIP = 0, J_ZERO = 1, J_DENSE = 2, J_PAIRS = 3 };
+
+static int classify(const doda_wgrad_job &j) {
+    if (j.n_rows == 0 && j.dw && j.K > 0 && j.ca > 0 && j.cb > 0)
+        return (j.flags & DODA_WGRAD_ACCUMULATE) ? J_SKIP : J_ZERO;
+    if (doda_pairs::eligible(j)) return J_PAIRS;
+    return J_DENSE;
+}
+
+static bool dense_needs_partial(const JobPlan &jp, const doda_wgrad_job &j) {
+    return jp.p.R > 1 || (j.flags & DODA_WGRAD_ACCUMULATE);
+}
+
 extern "C" size_t doda_spconv_wgrad_multi_workspace_bytes(const doda_wgrad_job *jobs_h, int32_t n_jobs) {
     if (!jobs_h || n_jobs <= 0) return 0;
     size_t total = 0;
     for (int k = 0; k < n_jobs; ++k) {
+        const int cls = classify(jobs_h[k]);
+        if (cls == J_PAIRS) { total += doda_pairs::partial_bytes(jobs_h[k]); continue; }
+        if (cls != J_DENSE) continue;
         JobPlan jp;
         if (!plan_job(jobs_h[k], &jp)) continue;
-        if (jp.p.R > 1) total += align_up((size_t)jp.p.R * jp.n_elem * 4, 256);
+        if (dense_needs_partial(jp, jobs_h[k])) total += align_up((size_t)jp.p.R * jp.n_elem * 4, 256);
     }
     return total < 256 ? 256 : total;
 }
 
 extern "C" size_t doda_spconv_wgrad_multi_desc_bytes(int32_t n_jobs) {
-    return n_jobs <= 0 ? 0 : align_up((size_t)n_jobs * (sizeof(WJob) + sizeof(RJob)), 256);
+    const size_t per = sizeof(WJob) + sizeof(RJob) > doda_pairs::desc_bytes_per_job()
+                           ? sizeof(WJob) + sizeof(RJob) : doda_pairs::desc_bytes_per_job();
+    return n_jobs <= 0 ? 0 : align_up((size_t)n_jobs * per + 256, 256);
 }
 
 extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_jobs, void *ws, size_t ws_bytes,
@@ -578,24 +602,32 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
     if (desc_bytes < doda_spconv_wgrad_multi_desc_bytes(n_jobs)) return DODA_ERR_WORKSPACE;
     hipStream_t s = as_stream(stream);
     std::vector<JobPlan> plans(n_jobs);
-    std::vector<int> keys;
+    std::vector<int> keys, cls(n_jobs), pair_jobs;
     size_t off = 0;
     for (int k = 0; k < n_jobs; ++k) {
-        if (jobs_h[k].n_rows == 0 && jobs_h[k].dw && jobs_h[k].K > 0 && jobs_h[k].ca > 0 && jobs_h[k].cb > 0) {
+        plans[k].key = -1;
+        cls[k] = classify(jobs_h[k]);
+        if (cls[k] == J_ZERO) {
             hipMemsetAsync(jobs_h[k].dw, 0, (size_t)jobs_h[k].K * jobs_h[k].ca * jobs_h[k].cb * 4, s);
-            plans[k].key = -1;
             continue;
         }
+        if (cls[k] == J_SKIP) continue;
+        if (cls[k] == J_PAIRS) { pair_jobs.push_back(k); continue; }
         if (!plan_job(jobs_h[k], &plans[k])) return DODA_ERR_INVALID;
         plans[k].ws_off = off;
-        if (plans[k].p.R > 1) off += align_up((size_t)plans[k].p.R * plans[k].n_elem * 4, 256);
+        if (dense_needs_partial(plans[k], jobs_h[k])) off += align_up((size_t)plans[k].p.R * plans[k].n_elem * 4, 256);
         bool seen = false;
         for (int key : keys) seen |= key == plans[k].key;
         if (!seen) keys.push_back(plans[k].key);
     }
+    doda_pairs::Prepared prep;
+    if (!pair_jobs.empty()) {
+        const int st = doda_pairs::prepare(jobs_h, pair_jobs.data(), (int)pair_jobs.size(), (char *)ws, &off, &prep);
+        if (st != DODA_OK) return st;
+    }
     if (ws_bytes < off) return DODA_ERR_WORKSPACE;
 
-    // descriptors grouped by kernel variant, then the reductions
+    // dense descriptors grouped by kernel variant, then the reductions
     std::vector<WJob> wj;
     std::vector<RJob> rj;
     struct Group { int first, count, blocks, rep; };
@@ -603,13 +635,13 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
     for (int key : keys) {
         Group g{(int)wj.size(), 0, 0, -1};
         for (int k = 0; k < n_jobs; ++k) {
-            if (plans[k].key != key) continue;
+            if (cls[k] != J_DENSE || plans[k].key != key) continue;
             const doda_wgrad_job &j = jobs_h[k];
             const Plan &p = plans[k].p;
             if (g.rep < 0) g.rep = k;
             WJob d;
             d.a = j.a; d.b = j.b; d.tbl = j.tbl;
-            d.out = p.R == 1 ? j.dw : (float *)((char *)ws + plans[k].ws_off);
+            d.out = dense_needs_partial(plans[k], j) ? (float *)((char *)ws + plans[k].ws_off) : j.dw;
             d.ca = j.ca; d.cb = j.cb; d.ld = j.ld; d.K = j.K; d.n_rows = j.n_rows;
             d.rows_per_chunk = p.rows_per_chunk; d.n_tag = p.n_tag; d.n_tbg = p.n_tbg; d.n_og = p.n_og;
             g.blocks += p.R * p.n_tag * p.n_tbg * p.n_og;
@@ -622,31 +654,37 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
     int r_blocks = 0;
     bool scalar_reduce = false;
     for (int k = 0; k < n_jobs; ++k) {
-        if (plans[k].key < 0 || plans[k].p.R <= 1) continue;
+        if (cls[k] != J_DENSE || !dense_needs_partial(plans[k], jobs_h[k])) continue;
         if (plans[k].n_elem % 4 != 0 || (uintptr_t)jobs_h[k].dw % 16 != 0) { scalar_reduce = true; continue; }
         RJob d;
         d.partial = (const float4 *)((char *)ws + plans[k].ws_off);
         d.dw = (float4 *)jobs_h[k].dw;
         d.n_quad = plans[k].n_elem / 4;
         d.R = plans[k].p.R;
+        d.accumulate = (jobs_h[k].flags & DODA_WGRAD_ACCUMULATE) ? 1 : 0;
+        d.pad = 0;
         r_blocks += (int)div_up(d.n_quad, 16);
         d.blk_end = r_blocks;
         rj.push_back(d);
     }
     const size_t wbytes = wj.size() * sizeof(WJob), rbytes = rj.size() * sizeof(RJob);
-    {
+    const size_t pair_off = align_up(wbytes + rbytes, 16), pbytes = prep.desc.size();
+    const size_t total_desc = pair_off + pbytes;
+    if (total_desc > desc_bytes) return DODA_ERR_WORKSPACE;
+    if (total_desc > 0) {
         std::lock_guard<std::mutex> lock(g_staging.mu);
         Staging &st = g_staging;
         if (st.pending) { hipEventSynchronize(st.ev); st.pending = false; }
-        if (st.cap < wbytes + rbytes) {
+        if (st.cap < total_desc) {
             if (st.host) hipHostFree(st.host);
-            st.cap = align_up(wbytes + rbytes, 4096) * 2;
+            st.cap = align_up(total_desc, 4096) * 2;
             if (hipHostMalloc(&st.host, st.cap, hipHostMallocDefault) != hipSuccess) { st.host = nullptr; st.cap = 0; return DODA_ERR_NOMEM; }
         }
         if (!st.ev && hipEventCreateWithFlags(&st.ev, hipEventDisableTiming) != hipSuccess) return DODA_ERR_LAUNCH;
-        memcpy(st.host, wj.data(), wbytes);
+        if (wbytes) memcpy(st.host, wj.data(), wbytes);
         if (rbytes) memcpy((char *)st.host + wbytes, rj.data(), rbytes);
-        if (hipMemcpyAsync(desc_dev, st.host, wbytes + rbytes, hipMemcpyHostToDevice, s) != hipSuccess) return DODA_ERR_LAUNCH;
+        if (pbytes) memcpy((char *)st.host + pair_off, prep.desc.data(), pbytes);
+        if (hipMemcpyAsync(desc_dev, st.host, total_desc, hipMemcpyHostToDevice, s) != hipSuccess) return DODA_ERR_LAUNCH;
         hipEventRecord(st.ev, s);
         st.pending = true;
     }
@@ -658,6 +696,10 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
     }
     int st = doda_check_launch();
     if (st != DODA_OK) return st;
+    if (!pair_jobs.empty()) {
+        st = doda_pairs::launch(prep, (const char *)desc_dev + pair_off, s);
+        if (st != DODA_OK) return st;
+    }
     if (!rj.empty()) {
         hipLaunchKernelGGL(wgrad_reduce_multi, dim3(r_blocks), dim3(256), 0, s,
                            (const RJob *)((const char *)desc_dev + wbytes), (int)rj.size());
@@ -666,13 +708,52 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
     }
     if (scalar_reduce)   // odd element counts: the per-layer scalar reduce
         for (int k = 0; k < n_jobs; ++k) {
-            if (plans[k].key < 0 || plans[k].p.R <= 1) continue;
+            if (cls[k] != J_DENSE || !dense_needs_partial(plans[k], jobs_h[k])) continue;
             if (plans[k].n_elem % 4 == 0 && (uintptr_t)jobs_h[k].dw % 16 == 0) continue;
             hipLaunchKernelGGL(wgrad_reduce, dim3(div_up(plans[k].n_elem, 16)), dim3(256), 0, s,
                                (const float *)((char *)ws + plans[k].ws_off), plans[k].p.R, plans[k].n_elem,
-                               jobs_h[k].dw);
+                               jobs_h[k].dw, (jobs_h[k].flags & DODA_WGRAD_ACCUMULATE) ? 1 : 0);
         }
     return doda_check_launch();
+}
+
+// ---- pair-list kernel, single layer ------------------------------------------------------------
+static doda_wgrad_job pairs_job(const uint16_t *a, int32_t n_a, int32_t ca, const uint16_t *b, int32_t n_b,
+                                int32_t cb, const int32_t *pin, const int32_t *pout, const int32_t *pnum,
+                                int32_t ld, int32_t K, float *dw, int32_t accumulate) {
+    doda_wgrad_job j;
+    memset(&j, 0, sizeof(j));
+    j.a = a; j.b = b; j.dw = dw;
+    j.ca = ca; j.cb = cb; j.ld = ld; j.K = K; j.n_rows = n_b; j.elem_bytes = 2;
+    j.pair_in = pin; j.pair_out = pout; j.pair_num = pnum; j.pair_ld = ld; j.n_a = n_a;
+    j.flags = accumulate ? DODA_WGRAD_ACCUMULATE : 0;
+    return j;
+}
+
+extern "C" size_t doda_spconv_wgrad_pairs_workspace_bytes(int32_t K, int32_t ca, int32_t cb, int32_t ld) {
+    if (K <= 0 || ca <= 0 || cb <= 0 || ld <= 0) return 256;
+    doda_wgrad_job j = pairs_job(nullptr, ld, ca, nullptr, ld, cb, nullptr, nullptr, nullptr, ld, K, nullptr, 0);
+    return doda_pairs::partial_bytes(j) + doda_spconv_wgrad_multi_desc_bytes(1);
+}
+
+extern "C" int doda_spconv_wgrad_pairs_bf16(const uint16_t *a, int32_t n_a, int32_t ca, const uint16_t *b,
+                                            int32_t n_b, int32_t cb, const int32_t *pair_in,
+                                            const int32_t *pair_out, const int32_t *pair_num, int32_t ld,
+                                            int32_t K, float *dw, int32_t accumulate, void *ws, size_t ws_bytes,
+                                            doda_stream_t stream) {
+    if (!a || !b || !dw || !ws || K <= 0 || ca <= 0 || cb <= 0 || n_b < 0 || ld < 0) return DODA_ERR_INVALID;
+    hipStream_t s = as_stream(stream);
+    if (n_b == 0 || ld == 0) {
+        if (!accumulate) hipMemsetAsync(dw, 0, (size_t)K * ca * cb * 4, s);
+        return DODA_OK;
+    }
+    const doda_wgrad_job j = pairs_job(a, n_a, ca, b, n_b, cb, pair_in, pair_out, pair_num, ld, K, dw, accumulate);
+    if (!doda_pairs::eligible(j)) return DODA_ERR_UNSUPPORTED;
+    const size_t pbytes = doda_pairs::partial_bytes(j);
+    const size_t dbytes = doda_spconv_wgrad_multi_desc_bytes(1);
+    if (ws_bytes < pbytes + dbytes) return DODA_ERR_WORKSPACE;
+    // the tail of the workspace receives the device descriptors
+    return doda_spconv_wgrad_multi(&j, 1, ws, pbytes, (char *)ws + pbytes, dbytes, stream);
 }
 
 extern "C" size_t doda_spconv_wgrad_workspace_bytes(int32_t K, int32_t ca, int32_t cb,

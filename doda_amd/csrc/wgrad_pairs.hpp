@@ -1,0 +1,33 @@
+// Internal interface between spconv_wgrad.hip (job planning, descriptor upload) and
+// spconv_wgrad_pairs.hip (the pair-list weight-gradient kernels).  Not part of the C ABI.
+#pragma once
+#include "common.hpp"
+#include <vector>
+
+namespace doda_pairs {
+
+// true when the job can run on the pair kernel (bf16, 16-channel multiples, pair lists given or
+// identity, operands inside the 4 GB hardware range check)
+bool eligible(const doda_wgrad_job &j);
+
+// bytes of per-chunk partials the job needs in the caller's workspace (multiple of 256)
+size_t partial_bytes(const doda_wgrad_job &j);
+
+struct Prepared {
+    std::vector<unsigned char> desc;   // device descriptors, laid out [kernel groups][reduce jobs]
+    struct Group { int ta, tb, first, count, blocks; };
+    std::vector<Group> groups;         // one launch each; `first` = index of the group's first PJob
+    size_t reduce_off = 0;             // byte offset of the reduce descriptors inside desc
+    int n_reduce = 0, reduce_blocks = 0;
+};
+
+// Plans the eligible jobs (partials carved from ws_base + offsets starting at *ws_off, which is
+// advanced).  Returns DODA_OK or an error.
+int prepare(const doda_wgrad_job *jobs, const int *which, int n, char *ws_base, size_t *ws_off, Prepared *out);
+
+// desc_dev: device copy of out.desc (already enqueued on `s`)
+int launch(const Prepared &p, const void *desc_dev, hipStream_t s);
+
+size_t desc_bytes_per_job();
+
+}  // namespace doda_pairs

@@ -10,10 +10,12 @@
 #include <torch/csrc/autograd/engine.h>
 #include <torch/csrc/autograd/function.h>
 #include <torch/csrc/autograd/functions/utils.h>
+#include <torch/csrc/autograd/graph_task.h>
 #include <torch/csrc/autograd/saved_variable.h>
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -103,12 +105,38 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
     return y;
 }
 
-at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tensor &tbl, int64_t n_rows) {
+// pair lists of a rulebook for the pair-list weight-gradient kernel (all optional)
+struct PairLists {
+    at::Tensor in, out, num;   // int32 [K, ld] (unit inner stride), int32 [K] or undefined (full lists)
+    bool defined() const { return in.defined() && out.defined(); }
+    int64_t ld() const { return in.size(0) > 1 ? in.stride(0) : in.size(1); }
+};
+
+inline bool pairs_usable(const at::Tensor &a, const at::Tensor &b, const PairLists &pl) {
+    return pl.defined() && a.scalar_type() == at::kBFloat16 && b.scalar_type() == at::kBFloat16 &&
+           a.size(1) % 16 == 0 && b.size(1) % 16 == 0;
+}
+
+at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tensor &tbl, int64_t n_rows,
+                 const PairLists &pl = PairLists()) {
     const at::Tensor a = a_in.contiguous(), b = b_in.contiguous();
     TORCH_CHECK(a.scalar_type() == b.scalar_type(), "doda wgrad: dtype mismatch");
     const int esz = elem_bytes(a);
     const int64_t K = tbl.size(0), ld = tbl.size(1), ca = a.size(1), cb = b.size(1);
     at::Tensor dw = at::empty({K, ca, cb}, a.options().dtype(at::kFloat));
+    if (pairs_usable(a, b, pl)) {
+        const size_t wsb = doda_spconv_wgrad_pairs_workspace_bytes((int)K, (int)ca, (int)cb, (int)pl.ld());
+        at::Tensor ws = at::empty({(int64_t)wsb}, a.options().dtype(at::kByte));
+        const int status = doda_spconv_wgrad_pairs_bf16(
+            (const uint16_t *)a.data_ptr(), (int)a.size(0), (int)ca, (const uint16_t *)b.data_ptr(), (int)b.size(0),
+            (int)cb, (const int32_t *)pl.in.data_ptr(), (const int32_t *)pl.out.data_ptr(),
+            pl.num.defined() ? (const int32_t *)pl.num.data_ptr() : nullptr, (int)pl.ld(), (int)K,
+            (float *)dw.data_ptr(), 0, ws.data_ptr(), wsb, stream_of(a));
+        if (status != DODA_ERR_UNSUPPORTED) {
+            check(status, "doda_spconv_wgrad_pairs");
+            return dw;
+        }
+    }
     const size_t wsb = doda_spconv_wgrad_workspace_bytes((int)K, (int)ca, (int)cb, (int)n_rows);
     at::Tensor ws = at::empty({(int64_t)(wsb > 256 ? wsb : 256)}, a.options().dtype(at::kByte));
     int status;
@@ -124,16 +152,34 @@ at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tenso
     return dw;
 }
 
+// spconv-format pair lists of a gather table without the -1 fill (doda_rulebook_pairs, flip | 2)
+std::pair<at::Tensor, at::Tensor> export_pairs(const at::Tensor &tbl, int64_t n_rows, bool flip, void *st) {
+    const int64_t K = tbl.size(0);
+    const auto iopt = tbl.options();
+    at::Tensor pairs = at::empty({2, K, n_rows > 0 ? n_rows : 1}, iopt), num = at::empty({K}, iopt);
+    const size_t wsb = doda_rulebook_pairs_workspace_bytes((int32_t)n_rows, (int32_t)K);
+    at::Tensor ws = at::empty({(int64_t)(wsb > 256 ? wsb : 256)}, iopt.dtype(at::kByte));
+    check(doda_rulebook_pairs((const int32_t *)tbl.data_ptr(), (int32_t)tbl.size(1), (int32_t)K, (int32_t)n_rows,
+                              (flip ? 1 : 0) | 2, (int32_t *)pairs.data_ptr(), (int32_t)pairs.size(2),
+                              (int32_t *)num.data_ptr(), ws.data_ptr(), (size_t)ws.numel(), st),
+          "doda_rulebook_pairs");
+    return {pairs, num};
+}
+
 // ---- rulebook pyramid -----------------------------------------------------------------------------
 // The 13 rulebooks of a 7-level U-Net (SubM k3 per level, k2 s2 p0 between levels) in one call: the
 // same native entry points doda_amd.ops drives through ctypes, without ~0.4 ms of Python per step.
 // Returns per level (nbr [27, M]) and, except for the last, (outids [M_out, 4], child [8, M_out],
 // par_off [8, M], out_shape).
-std::vector<std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, std::vector<int64_t>>>
-build_pyramid(const at::Tensor &indices_in, std::vector<int64_t> shape, int64_t batch, int64_t n_levels) {
+// with_pairs: also export every rulebook's pair lists (SubM: [2,27,M] from nbr; k2s2: [2,8,M] from par_off)
+// for the pair-list weight gradient — on the same (side) stream, off the critical path.
+typedef std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, std::vector<int64_t>, at::Tensor, at::Tensor,
+                   at::Tensor, at::Tensor> PyramidLevel;
+std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vector<int64_t> shape, int64_t batch,
+                                        int64_t n_levels, bool with_pairs) {
     TORCH_CHECK(indices_in.is_cuda() && indices_in.scalar_type() == at::kInt && indices_in.dim() == 2 &&
                 indices_in.size(1) == 4 && shape.size() == 3, "doda build_pyramid: indices must be int32 [M,4] on the GPU");
-    std::vector<std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, std::vector<int64_t>>> out;
+    std::vector<PyramidLevel> out;
     at::Tensor indices = indices_in.contiguous();
     const auto iopt = indices.options();
     void *st = stream_of(indices);
@@ -146,8 +192,10 @@ build_pyramid(const at::Tensor &indices_in, std::vector<int64_t> shape, int64_t 
         check(doda_rulebook_subm((const int32_t *)indices.data_ptr(), m, shp, (int32_t)batch, 3,
                                  (int32_t *)nbr.data_ptr(), m, ws.data_ptr(), (size_t)ws.numel(), st),
               "doda_rulebook_subm");
+        at::Tensor sp, sn, dp, dn;
+        if (with_pairs) std::tie(sp, sn) = export_pairs(nbr, m, true, st);
         if (lvl == n_levels - 1) {
-            out.emplace_back(nbr, at::Tensor(), at::Tensor(), at::Tensor(), std::vector<int64_t>());
+            out.emplace_back(nbr, at::Tensor(), at::Tensor(), at::Tensor(), std::vector<int64_t>(), sp, sn, dp, dn);
             break;
         }
         at::Tensor parent = at::empty({m > 0 ? m : 1}, iopt), off = at::empty({m > 0 ? m : 1}, iopt);
@@ -161,9 +209,10 @@ build_pyramid(const at::Tensor &indices_in, std::vector<int64_t> shape, int64_t 
         check(doda_rulebook_down2_tables((const int32_t *)parent.data_ptr(), (const int32_t *)off.data_ptr(), m, m_out,
                                          (int32_t *)child.data_ptr(), m_out, (int32_t *)par_off.data_ptr(), m, st),
               "doda_rulebook_down2_tables");
+        if (with_pairs) std::tie(dp, dn) = export_pairs(par_off, m, false, st);
         std::vector<int64_t> oshape = {(shape[0] - 2) / 2 + 1, (shape[1] - 2) / 2 + 1, (shape[2] - 2) / 2 + 1};
         at::Tensor outids = out_idx.narrow(0, 0, m_out);
-        out.emplace_back(nbr, outids, child, par_off, oshape);
+        out.emplace_back(nbr, outids, child, par_off, oshape, sp, sn, dp, dn);
         indices = outids;
         shape = oshape;
     }
@@ -172,20 +221,73 @@ build_pyramid(const at::Tensor &indices_in, std::vector<int64_t> shape, int64_t 
 
 // ---- deferred weight gradients ---------------------------------------------------------------
 // The weight gradient of a layer feeds nothing else in the backward pass.  With deferral switched on
-// (set_defer_wgrad) the conv backward only queues (features, dy, table) and binds an uninitialised
-// fp32 tensor as the parameter's .grad; an engine callback that runs when the backward pass is
-// complete issues ALL queued jobs through doda_spconv_wgrad_multi (~8 launches instead of 2 per
-// layer).  Preconditions checked per layer: fp32 leaf weight without an existing .grad (otherwise
-// the layer computes its gradient on the spot).  AccumulateGrad hooks do not see these gradients, so
-// torch DDP must not be combined with deferral (doda_amd.dist reduces gradients itself).
+// (set_defer_wgrad) the conv backward only queues (features, dy, table / pair lists, weight); an engine
+// callback that runs when the backward pass is complete issues ALL queued jobs through
+// doda_spconv_wgrad_multi (~8 launches instead of 2 per layer) and only THEN binds the results:
+//   * weight.grad undefined at flush time -> a fresh tensor is written and bound as .grad;
+//   * weight.grad defined (an earlier backward pass of the same optimizer step — the two passes of
+//     tool/st.py:136-198 —, zero_grad(set_to_none=False), or another consumer of the weight whose
+//     gradient went through AccumulateGrad during this pass) -> the job ACCUMULATES into it.
+// Nothing uninitialised is ever visible as .grad.  A weight that is queued twice in one pass (shared
+// module, two forward passes summed into one loss) gets its second job in a follow-up call, after the
+// first has written.  Preconditions per layer: fp32 contiguous leaf weight (otherwise the layer computes
+// its gradient on the spot).  AccumulateGrad hooks do not see these gradients, so torch DDP must not be
+// combined with deferral (doda_amd.dist reduces gradients itself).  If a backward pass aborts, its
+// queued jobs are dropped when the next pass starts (different graph-task id).
 struct PendingWgrad {
-    at::Tensor a, b, tbl, dw;
+    at::Tensor a, b, tbl, weight;
+    PairLists pl;
     int64_t n_rows;
 };
 std::mutex g_wq_mu;
 std::vector<PendingWgrad> g_wq;
 bool g_wq_callback = false, g_defer_wgrad = false;
+int g_wq_task = -2;
 c10::optional<c10::hip::HIPStream> g_wq_stream;
+
+void issue_wgrads(std::vector<PendingWgrad> &q, const c10::hip::HIPStream &st) {
+    if (q.empty()) return;
+    c10::hip::HIPStreamGuard guard(st);
+    std::vector<doda_wgrad_job> jobs(q.size());
+    std::vector<at::Tensor> fresh(q.size());
+    for (size_t k = 0; k < q.size(); ++k) {
+        const PendingWgrad &p = q[k];
+        at::Tensor target = p.weight.grad();
+        int flags = 0;
+        if (target.defined() && target.scalar_type() == at::kFloat && target.is_contiguous() &&
+            target.sizes() == p.weight.sizes() && target.device() == p.weight.device()) {
+            flags = DODA_WGRAD_ACCUMULATE;
+        } else {
+            TORCH_CHECK(!target.defined(), "doda deferred wgrad: existing .grad of a conv weight is not a contiguous fp32 tensor");
+            target = fresh[k] = at::empty(p.weight.sizes(), p.weight.options());
+        }
+        doda_wgrad_job j;
+        memset(&j, 0, sizeof(j));
+        j.a = p.a.data_ptr(); j.b = p.b.data_ptr();
+        j.tbl = (const int32_t *)p.tbl.data_ptr();
+        j.dw = (float *)target.data_ptr();
+        j.ca = (int32_t)p.a.size(1); j.cb = (int32_t)p.b.size(1);
+        j.ld = (int32_t)p.tbl.size(1); j.K = (int32_t)p.tbl.size(0);
+        j.n_rows = (int32_t)p.n_rows; j.elem_bytes = (int32_t)elem_bytes(p.a);
+        j.n_a = (int32_t)p.a.size(0);
+        j.flags = flags;
+        if (pairs_usable(p.a, p.b, p.pl)) {
+            j.pair_in = (const int32_t *)p.pl.in.data_ptr();
+            j.pair_out = (const int32_t *)p.pl.out.data_ptr();
+            j.pair_num = p.pl.num.defined() ? (const int32_t *)p.pl.num.data_ptr() : nullptr;
+            j.pair_ld = (int32_t)p.pl.ld();
+        }
+        jobs[k] = j;
+    }
+    const auto opt = q[0].a.options().dtype(at::kByte);
+    const size_t wsb = doda_spconv_wgrad_multi_workspace_bytes(jobs.data(), (int32_t)jobs.size());
+    const size_t dsb = doda_spconv_wgrad_multi_desc_bytes((int32_t)jobs.size());
+    at::Tensor ws = at::empty({(int64_t)wsb}, opt), desc = at::empty({(int64_t)dsb}, opt);
+    check(doda_spconv_wgrad_multi(jobs.data(), (int32_t)jobs.size(), ws.data_ptr(), wsb, desc.data_ptr(), dsb,
+                                  (void *)st.stream()), "doda_spconv_wgrad_multi");
+    for (size_t k = 0; k < q.size(); ++k)
+        if (fresh[k].defined()) q[k].weight.mutable_grad() = fresh[k];
+}
 
 void flush_wgrads() {
     std::vector<PendingWgrad> q;
@@ -195,35 +297,36 @@ void flush_wgrads() {
         q.swap(g_wq);
         st = g_wq_stream;
         g_wq_callback = false;
+        g_wq_task = -2;
     }
-    if (q.empty()) return;
-    c10::hip::HIPStreamGuard guard(*st);
-    std::vector<doda_wgrad_job> jobs(q.size());
-    for (size_t k = 0; k < q.size(); ++k) {
-        const PendingWgrad &p = q[k];
-        jobs[k] = doda_wgrad_job{p.a.data_ptr(), p.b.data_ptr(), (const int32_t *)p.tbl.data_ptr(),
-                                 (float *)p.dw.data_ptr(), (int32_t)p.a.size(1), (int32_t)p.b.size(1),
-                                 (int32_t)p.tbl.size(1), (int32_t)p.tbl.size(0), (int32_t)p.n_rows,
-                                 (int32_t)elem_bytes(p.a)};
+    // jobs whose weight already appeared earlier in the queue wait for a follow-up call
+    while (!q.empty()) {
+        std::vector<PendingWgrad> now, later;
+        for (PendingWgrad &p : q) {
+            bool dup = false;
+            for (const PendingWgrad &e : now) dup |= e.weight.unsafeGetTensorImpl() == p.weight.unsafeGetTensorImpl();
+            (dup ? later : now).push_back(std::move(p));
+        }
+        issue_wgrads(now, *st);
+        q.swap(later);
     }
-    const auto opt = q[0].a.options().dtype(at::kByte);
-    const size_t wsb = doda_spconv_wgrad_multi_workspace_bytes(jobs.data(), (int32_t)jobs.size());
-    const size_t dsb = doda_spconv_wgrad_multi_desc_bytes((int32_t)jobs.size());
-    at::Tensor ws = at::empty({(int64_t)wsb}, opt), desc = at::empty({(int64_t)dsb}, opt);
-    check(doda_spconv_wgrad_multi(jobs.data(), (int32_t)jobs.size(), ws.data_ptr(), wsb, desc.data_ptr(), dsb,
-                                  (void *)st->stream()), "doda_spconv_wgrad_multi");
 }
 
 // true when the job was queued (the caller then returns no gradient for the weight)
 bool try_defer_wgrad(const at::Tensor &features, const at::Tensor &dy, const at::Tensor &tbl, int64_t n_rows,
-                     const at::Tensor &weight) {
-    if (!g_defer_wgrad || !weight.is_leaf() || weight.scalar_type() != at::kFloat || weight.grad().defined() ||
-        !weight.is_contiguous() || n_rows <= 0)
+                     const at::Tensor &weight, const PairLists &pl) {
+    if (!g_defer_wgrad || !weight.is_leaf() || weight.scalar_type() != at::kFloat || !weight.is_contiguous() ||
+        n_rows <= 0)
         return false;
-    at::Tensor dw = at::empty(weight.sizes(), weight.options());
-    weight.mutable_grad() = dw;
+    const int task = torch::autograd::get_current_graph_task_id();
+    if (task < 0) return false;   // not inside an engine run (e.g. a functional call of the node)
     std::lock_guard<std::mutex> lock(g_wq_mu);
-    g_wq.push_back(PendingWgrad{features.contiguous(), dy, tbl, dw, n_rows});
+    if (g_wq_task != task) {      // leftovers of a backward pass that never completed
+        g_wq.clear();
+        g_wq_callback = false;
+        g_wq_task = task;
+    }
+    g_wq.push_back(PendingWgrad{features.contiguous(), dy, tbl, weight, pl, n_rows});
     g_wq_stream = c10::hip::getCurrentHIPStream(dy.device().index());
     if (!g_wq_callback) {
         g_wq_callback = true;
@@ -246,6 +349,7 @@ using torch::autograd::variable_list;
 struct ConvNode : public torch::autograd::Node {
     SavedVariable features_, weight_;
     at::Tensor fwd_tbl, bwd_tbl, pk_bwd;
+    PairLists pl;
     int64_t n_out = 0, bwd_layout = 0;
 
     variable_list apply(variable_list &&grads) override {
@@ -258,8 +362,8 @@ struct ConvNode : public torch::autograd::Node {
             out[0] = gather(dy, weight.reshape({K, cin, cout}),
                             pk_bwd.defined() ? c10::optional<at::Tensor>(pk_bwd) : c10::nullopt, bwd_tbl,
                             features.size(0), bwd_layout, cin, false);
-        if (task_should_compute_output(1) && !try_defer_wgrad(features, dy, fwd_tbl, n_out, weight))
-            out[1] = wgrad(features, dy, fwd_tbl, n_out).reshape(weight.sizes()).to(weight.scalar_type());
+        if (task_should_compute_output(1) && !try_defer_wgrad(features, dy, fwd_tbl, n_out, weight, pl))
+            out[1] = wgrad(features, dy, fwd_tbl, n_out, pl).reshape(weight.sizes()).to(weight.scalar_type());
         if (task_should_compute_output(2)) out[2] = grads[0];
         return out;
     }
@@ -269,6 +373,7 @@ struct ConvNode : public torch::autograd::Node {
         fwd_tbl.reset();
         bwd_tbl.reset();
         pk_bwd.reset();
+        pl = PairLists();
     }
     std::string name() const override { return "DodaIndiceConvBackward"; }
 };
@@ -276,7 +381,8 @@ struct ConvNode : public torch::autograd::Node {
 at::Tensor indice_conv(const at::Tensor &features, const at::Tensor &weight, const at::Tensor &fwd_tbl,
                        const at::Tensor &bwd_tbl, int64_t n_out, int64_t bwd_layout,
                        const c10::optional<at::Tensor> &pk_fwd, const c10::optional<at::Tensor> &pk_bwd,
-                       const c10::optional<at::Tensor> &residual) {
+                       const c10::optional<at::Tensor> &residual, const c10::optional<at::Tensor> &pair_in,
+                       const c10::optional<at::Tensor> &pair_out, const c10::optional<at::Tensor> &pair_num) {
     const at::Tensor res = residual.has_value() ? *residual : at::Tensor();
     const bool need_grad = at::GradMode::is_enabled() &&
                            (features.requires_grad() || weight.requires_grad() || (res.defined() && res.requires_grad()));
@@ -296,6 +402,15 @@ at::Tensor indice_conv(const at::Tensor &features, const at::Tensor &weight, con
         if (pk_bwd.has_value() && pk_bwd->defined()) node->pk_bwd = *pk_bwd;
         node->n_out = n_out;
         node->bwd_layout = bwd_layout;
+        if (pair_in.has_value() && pair_in->defined() && pair_out.has_value() && pair_out->defined()) {
+            TORCH_CHECK(pair_in->scalar_type() == at::kInt && pair_in->dim() == 2 && pair_in->stride(1) == 1 &&
+                        pair_out->scalar_type() == at::kInt && pair_out->sizes() == pair_in->sizes() &&
+                        pair_out->stride(1) == 1 && pair_out->stride(0) == pair_in->stride(0) &&
+                        pair_in->size(0) == fwd_tbl.size(0), "doda indice_conv: pair lists must be int32 [K, ld]");
+            node->pl.in = *pair_in;
+            node->pl.out = *pair_out;
+            if (pair_num.has_value() && pair_num->defined()) node->pl.num = *pair_num;
+        }
         torch::autograd::set_history(y, node);
     }
     return y;
@@ -438,19 +553,27 @@ std::vector<at::Tensor> bn_relu_pass(const at::Tensor &x, const at::Tensor &weig
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
-    m.def("indice_conv", &indice_conv, "sparse conv (gather table) with autograd");
+    m.def("indice_conv", &indice_conv, "sparse conv (gather table) with autograd",
+          py::arg("features"), py::arg("weight"), py::arg("fwd_tbl"), py::arg("bwd_tbl"), py::arg("n_out"),
+          py::arg("bwd_layout"), py::arg("pk_fwd"), py::arg("pk_bwd"), py::arg("residual"),
+          py::arg("pair_in") = py::none(), py::arg("pair_out") = py::none(), py::arg("pair_num") = py::none());
     m.def("bn_relu", &bn_relu, "fused BatchNorm1d(+ReLU) with autograd");
     m.def("bn_relu_pass", &bn_relu_pass, "fused BatchNorm1d(+ReLU) returning (y, alias of x) for residual blocks");
     m.def("gather", [](const at::Tensor &x, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
                        const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32) {
         return gather(x, w, packed, tbl, n_out, layout, nc, out_f32);
     }, "raw gather-GEMM");
-    m.def("wgrad", &wgrad, "raw weight gradient");
+    m.def("wgrad", [](const at::Tensor &a, const at::Tensor &b, const at::Tensor &tbl, int64_t n_rows) {
+        return wgrad(a, b, tbl, n_rows);
+    }, "raw weight gradient");
     m.def("build_pyramid", &build_pyramid,
-          "all SubM k3 and k2s2 rulebooks of an n-level U-Net in one call (13 native builds, 6 size read-backs)");
+          "all SubM k3 and k2s2 rulebooks of an n-level U-Net in one call (13 native builds, 6 size read-backs)",
+          py::arg("indices"), py::arg("shape"), py::arg("batch"), py::arg("n_levels"), py::arg("with_pairs") = false);
+    m.def("pending_wgrads", []() { std::lock_guard<std::mutex> lock(g_wq_mu); return (int64_t)g_wq.size(); });
     m.def("set_defer_wgrad", [](bool on) { g_defer_wgrad = on; },
           "queue conv weight gradients during backward and issue them in one multi-layer call at its end");
     m.def("get_defer_wgrad", []() { return g_defer_wgrad; });
     m.def("flush_wgrads", &flush_wgrads);
     m.def("abi_version", []() { return doda_abi_version(); });
+    m.def("built_for_abi", []() { return (int)DODA_ABI_VERSION; });
 }

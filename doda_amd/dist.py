@@ -45,45 +45,89 @@ def reduce_step_stats(elapsed, units, device):
     return float(t[0]), [float(v) for v in u]
 
 
-def wrap_ddp(module, local_rank=None):
-    """DistributedDataParallel as tool/train.py:360-361 wraps the model; BN buffers are rank-local
-    (no per-forward broadcast), gradients live in bucket views."""
+def wrap_ddp(module, local_rank=None, broadcast_buffers=True):
+    """DistributedDataParallel as tool/train.py:360-361 wraps the model (defaults: buffers broadcast
+    from rank 0 on every forward); gradients live in bucket views."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return module
-    kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True)
+    kw = dict(broadcast_buffers=bool(broadcast_buffers), gradient_as_bucket_view=True)
     if local_rank is not None and torch.cuda.is_available():
         kw["device_ids"] = [local_rank]
     return torch.nn.parallel.DistributedDataParallel(module, **kw)
 
 
+def _flat_broadcast(tensors, src=0):
+    """Broadcast a list of tensors from `src` as one flat message per dtype."""
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    with torch.no_grad():
+        for group in by_dtype.values():
+            flat = torch.cat([t.detach().reshape(-1) for t in group])
+            dist.broadcast(flat, src)
+            off = 0
+            for t in group:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+
+
 class GradAllReduce:
-    """Gradient averaging after the backward pass: parameters broadcast from rank 0 once, then per
-    step ONE all-reduce of a flat copy of all gradients (7.5 M fp32 = 30 MB for the U-Net, a single
-    bucket sized for xGMI rings) and a multi-tensor copy back.  Replaces DistributedDataParallel
+    """Gradient averaging after the backward pass.  Replaces DistributedDataParallel
     (tool/train.py:360-361) when weight gradients are deferred to the end of backward
     (doda_amd.spconv.functional.set_deferred_wgrad): those never pass through the AccumulateGrad hooks
-    DDP listens on.  With world size 1 everything is a no-op."""
+    DDP listens on.
 
-    def __init__(self, module):
+    * construction: parameters AND buffers (BatchNorm / DSNorm running statistics) are broadcast from
+      rank 0, as DDP does at wrap time; `sync_buffers()` repeats the buffer broadcast on demand (DDP's
+      broadcast_buffers=True does it every forward; call it before evaluation / checkpointing — the
+      running statistics of rank-local batches otherwise drift apart, which only matters there);
+    * reduce(): the FIXED parameter list (a missing gradient counts as zeros, so every rank sends the
+      same message sizes whatever its batch touched) is cut into buckets of ~`bucket_mb` MB; bucket k's
+      all-reduce (RCCL ring over xGMI, per-link bound) is asynchronous and overlaps the flattening copy
+      of bucket k+1 and the copy-back of bucket k-1.  With world size 1 everything is a no-op."""
+
+    def __init__(self, module, bucket_mb=8.0, broadcast_buffers=True):
+        self.module = module
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.buckets = []
+        cur, cur_bytes, limit = [], 0, int(bucket_mb * (1 << 20))
+        for p in self.params:
+            cur.append(p)
+            cur_bytes += p.numel() * p.element_size()
+            if cur_bytes >= limit:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            self.buckets.append(cur)
         if self.world > 1:
-            with torch.no_grad():
-                flat = torch.cat([p.detach().reshape(-1) for p in self.params])
-                dist.broadcast(flat, 0)
-                off = 0
-                for p in self.params:
-                    p.copy_(flat[off:off + p.numel()].view_as(p))
-                    off += p.numel()
+            _flat_broadcast(self.params)
+            if broadcast_buffers:
+                self.sync_buffers()
+
+    def sync_buffers(self):
+        """Rank 0's buffers (running statistics, batch counters) to every rank."""
+        if self.world > 1:
+            bufs = [b for b in self.module.buffers() if b is not None and b.numel() > 0]
+            if bufs:
+                _flat_broadcast(bufs)
 
     def reduce(self):
         """Call between loss.backward() and optimizer.step()."""
         if self.world == 1:
             return
-        grads = [p.grad for p in self.params if p.grad is not None]
-        if not grads:
-            return
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat)
-        flat.div_(self.world)
-        torch._foreach_copy_(grads, [t.view_as(g) for t, g in zip(flat.split([g.numel() for g in grads]), grads)])
+        pending = []
+        for bucket in self.buckets:
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+            pending.append((bucket, flat, dist.all_reduce(flat, async_op=True)))
+        inv = 1.0 / self.world
+        for bucket, flat, work in pending:
+            work.wait()
+            flat.mul_(inv)
+            views = [t.view_as(p) for t, p in zip(flat.split([p.numel() for p in bucket]), bucket)]
+            have = [(p.grad, v) for p, v in zip(bucket, views) if p.grad is not None]
+            if have:
+                torch._foreach_copy_([g for g, _ in have], [v for _, v in have])
+            for p, v in zip(bucket, views):
+                if p.grad is None:
+                    p.grad = v.clone()

@@ -1,4 +1,5 @@
-"""Domain-specific BatchNorm (reference model/dsnorm.py:12-214, DSNorm / DSNorm1d): one affine pair
+"""Domain-specific BatchNorm (reference model/dsnorm.py:12-315, DSNorm / DSNorm1d, convert_dsnorm,
+set_ds_source / set_ds_target, BatchNorm-checkpoint loading): one affine pair
 shared by both domains, separate running statistics for the source (domain_label 0) and the target
 (domain_label 1) domain.  State-dict keys are the reference's (`weight`, `bias`,
 `running_mean_source|target`, `running_var_source|target`, `num_batches_tracked`).
@@ -36,6 +37,63 @@ class DSNorm1d(nn.Module):
     def set_domain_label(self, domain_label):
         self.domain_label = domain_label
 
+    def reset_running_stats(self):
+        if self.track_running_stats:
+            self.running_mean_source.zero_()
+            self.running_var_source.fill_(1)
+            self.running_mean_target.zero_()
+            self.running_var_target.fill_(1)
+            self.num_batches_tracked.zero_()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys,
+                              unexpected_keys, error_msgs):
+        """Reference model/dsnorm.py:87-170: a key `running_*_source|target` that the checkpoint lacks is
+        read from the plain BatchNorm key (`running_mean` / `running_var`), so a source-only
+        nn.BatchNorm1d checkpoint initialises BOTH domains; a missing `num_batches_tracked` counts as 0.
+        Keys the module does not know are not reported as unexpected (the reference's check is
+        commented out, :164-170)."""
+        if self.track_running_stats and prefix + "num_batches_tracked" not in state_dict:
+            state_dict[prefix + "num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+        local = {k: v for k, v in list(self._parameters.items()) + list(self._buffers.items()) if v is not None}
+        with torch.no_grad():
+            for name, param in local.items():
+                key = prefix + name
+                if name.endswith(("_source", "_target")) and key not in state_dict:
+                    key = key[:-7]
+                if key not in state_dict:
+                    if strict:
+                        missing_keys.append(key)
+                    continue
+                value = state_dict[key]
+                if param.dim() == 0 and value.dim() == 1:
+                    value = value[0]
+                if value.shape != param.shape:
+                    error_msgs.append("size mismatch for {}: copying a param with shape {} from checkpoint, "
+                                      "the shape in current model is {}.".format(key, value.shape, param.shape))
+                    continue
+                param.copy_(value)
+
+    @classmethod
+    def convert_dsnorm(cls, module):
+        """Reference model/dsnorm.py:172-210 (called at tool/train.py:332, tool/st.py:476,
+        tool/test.py:290): every torch BatchNorm layer of `module` becomes a DSNorm carrying the same
+        affine parameters; as in the reference both domains start out SHARING the BatchNorm's
+        running-statistics tensors (and its batch counter)."""
+        out = module
+        if isinstance(module, nn.modules.batchnorm._BatchNorm):
+            out = cls(module.num_features, module.eps, module.momentum, module.affine, module.track_running_stats)
+            if module.affine:
+                out.weight.data = module.weight.data.clone().detach()
+                out.bias.data = module.bias.data.clone().detach()
+                out.weight.requires_grad = module.weight.requires_grad
+                out.bias.requires_grad = module.bias.requires_grad
+            out.running_mean_target = out.running_mean_source = module.running_mean
+            out.running_var_target = out.running_var_source = module.running_var
+            out.num_batches_tracked = module.num_batches_tracked
+        for name, child in module.named_children():
+            out.add_module(name, cls.convert_dsnorm(child))
+        return out
+
     def running_stats(self):
         dom = "target" if self.domain_label else "source"
         return getattr(self, "running_mean_" + dom), getattr(self, "running_var_" + dom)
@@ -58,3 +116,15 @@ class DSNorm1d(nn.Module):
 
 
 DSNorm = DSNorm1d
+
+
+def set_ds_source(m):
+    """`model.apply(set_ds_source)`: reference model/dsnorm.py:306-309."""
+    if m.__class__.__name__.find("DSNorm") != -1:
+        m.set_domain_label(0)
+
+
+def set_ds_target(m):
+    """`model.apply(set_ds_target)`: reference model/dsnorm.py:312-315."""
+    if m.__class__.__name__.find("DSNorm") != -1:
+        m.set_domain_label(1)

@@ -199,7 +199,9 @@ class SparseConvNet(nn.Module):
 
     def forward(self, input, input_map, return_mid_feat=False, v2p_map=None):
         if input.features.is_cuda and input.indices.shape[0] > 0:
-            spconv.ops.build_pyramid(input, len(self.unet.nPlanes))   # all 13 rulebooks up front
+            # all 13 rulebooks up front (+ their pair lists when a bf16 backward pass will follow)
+            spconv.ops.build_pyramid(input, len(self.unet.nPlanes), with_pairs=(
+                torch.is_grad_enabled() and self.training and input.features.dtype == torch.bfloat16))
         out = self.output_layer(self.unet(self.input_conv(input)))
         feats = out.features
         fused = (v2p_map is not None and not return_mid_feat and feats.is_cuda
@@ -216,7 +218,7 @@ class SparseConvNet(nn.Module):
 _PYR_STREAMS = {}
 
 
-def _prebuild_pyramid(voxel_coords, spatial_shape, batch_size, n_levels, device):
+def _prebuild_pyramid(voxel_coords, spatial_shape, batch_size, n_levels, device, with_pairs=False):
     """Build the int32 indices and all rulebooks on a side stream that does NOT wait for the main
     stream.  Rulebooks depend only on the voxel coordinates; built at the head of the forward pass on
     the main stream, each of their six size read-backs blocks the host until the previous step's
@@ -231,13 +233,14 @@ def _prebuild_pyramid(voxel_coords, spatial_shape, batch_size, n_levels, device)
     with torch.cuda.stream(side):
         idx32 = voxel_coords.int()
         probe = spconv.SparseConvTensor(None, idx32, spatial_shape, batch_size)
-        spconv.ops.build_pyramid(probe, n_levels)
+        spconv.ops.build_pyramid(probe, n_levels, with_pairs=with_pairs)
     main.wait_stream(side)
     idx32.record_stream(main)
     for data in probe.indice_dict.values():
         for t in vars(data).values():
-            if torch.is_tensor(t) and t.is_cuda:
-                t.record_stream(main)
+            for u in (t if isinstance(t, tuple) else (t,)):
+                if torch.is_tensor(u) and u.is_cuda:
+                    u.record_stream(main)
     return idx32, probe.indice_dict
 
 
@@ -258,7 +261,9 @@ def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fus
     if (inputs_ready and batch["voxel_locs"].is_cuda and voxel_coords.shape[0] > 0
             and hasattr(net, "unet") and device.type == "cuda"):
         idx32, pyramid = _prebuild_pyramid(voxel_coords, batch["spatial_shape"], batch_size,
-                                           len(net.unet.nPlanes), device)
+                                           len(net.unet.nPlanes), device,
+                                           with_pairs=(torch.is_grad_enabled() and net.training
+                                                       and feature_dtype == torch.bfloat16))
         inp = spconv.SparseConvTensor(voxel_feats.to(feature_dtype), idx32, batch["spatial_shape"], batch_size)
         inp.indice_dict.update(pyramid)
     else:

@@ -57,13 +57,15 @@ def _running_stats(bn):
 
 
 def _module_ok(bn):
-    """Static half of the test, cached on the module (per step this is asked 65 times)."""
+    """Structural half of the test, cached on the module (per step this is asked 65 times); the
+    parameter dtype is NOT cached — `model.bfloat16()` / `.half()` may change it later —
+    and is compared on every call (one attribute read)."""
     ok = bn.__dict__.get("_doda_bn_ok")
     if ok is None:
         ok = bool((type(bn) is nn.BatchNorm1d or _is_dsnorm(bn)) and bn.affine and bn.track_running_stats
-                  and bn.momentum is not None and bn.weight.dtype == torch.float32)
+                  and bn.momentum is not None)
         bn.__dict__["_doda_bn_ok"] = ok
-    return ok
+    return ok and bn._parameters["weight"].dtype == torch.float32
 
 
 def fusable(bn, features):

@@ -232,8 +232,9 @@ def rulebook_subm_generic(indices, spatial_shape, batch_size, ksize):
     return nbr
 
 
-def rulebook_pairs(tbl, n_rows, flip):
-    """spconv-v1.2-format (pairs int32 [2,K,n_rows] -1 padded, pairNum int32 [K]) from a table."""
+def rulebook_pairs(tbl, n_rows, flip, pad=True):
+    """spconv-v1.2-format (pairs int32 [2,K,n_rows] -1 padded, pairNum int32 [K]) from a table.
+    pad=False leaves the entries past pairNum[o] unwritten (lists for the pair-list weight gradient)."""
     _need_cuda(tbl)
     K, ld = tbl.shape
     dev = tbl.device
@@ -242,7 +243,7 @@ def rulebook_pairs(tbl, n_rows, flip):
     ws = _ws(lib().doda_rulebook_pairs_workspace_bytes(n_rows, K), dev)
     if n_rows == 0:
         return pairs[:, :, :0], pair_num
-    check(lib().doda_rulebook_pairs(_p(tbl), ld, K, n_rows, int(bool(flip)), _p(pairs), n_rows,
+    check(lib().doda_rulebook_pairs(_p(tbl), ld, K, n_rows, int(bool(flip)) | (0 if pad else 2), _p(pairs), n_rows,
                                     _p(pair_num), _p(ws), ws.numel(), _stream()),
           "doda_rulebook_pairs")
     return pairs, pair_num
@@ -327,14 +328,12 @@ class PackPlan:
                                            ("nc", "<i4"), ("layout", "<i4"), ("esz", "<i4"),
                                            ("n_chunk", "<i4"), ("NB", "<i4"), ("pad", "<i4")]))
         self.outputs = []
-        self._keep = []
         for k, (w, K, kc, nc, layout, esz) in enumerate(entries):
             if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.numel() == K * kc * nc):
                 raise RuntimeError("PackPlan: weights must be contiguous fp32 device tensors")
             out = torch.empty(l.doda_spconv_gather_workspace_bytes(K, kc, nc, esz), dtype=torch.uint8,
                               device=device)
-            self.outputs.append(out)
-            self._keep.append(w)
+            self.outputs.append(out)   # (the weights are NOT kept alive: the owner re-plans when they die)
             desc[k] = (w.data_ptr(), out.data_ptr(), K, kc, nc, layout, esz, 0, 0, 0)
         blk_end = np.zeros(n, dtype=np.int32)
         total = C.c_int32()
@@ -349,31 +348,60 @@ class PackPlan:
                                            _stream()), "doda_spconv_pack_multi")
 
 
-class _WgradJob(C.Structure):   # doda_wgrad_job (include/doda_hip.h)
+class _WgradJob(C.Structure):   # doda_wgrad_job (include/doda_hip.h, ABI 2)
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("tbl", C.c_void_p), ("dw", C.c_void_p),
                 ("ca", C.c_int32), ("cb", C.c_int32), ("ld", C.c_int32), ("K", C.c_int32),
-                ("n_rows", C.c_int32), ("elem_bytes", C.c_int32)]
+                ("n_rows", C.c_int32), ("elem_bytes", C.c_int32),
+                ("pair_in", C.c_void_p), ("pair_out", C.c_void_p), ("pair_num", C.c_void_p),
+                ("pair_ld", C.c_int32), ("n_a", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+WGRAD_ACCUMULATE = 1
 
 
 def spconv_wgrad_multi(jobs):
     """Weight gradients of many layers in one native call (doda_spconv_wgrad_multi).
-    jobs: list of (a [*,ca], b [n_rows,cb], tbl int32 [K,ld], n_rows); returns the list of dw tensors
-    (float32 [K, ca, cb]), equal to spconv_wgrad per job up to the summation order of the partials."""
+    jobs: list of (a [*,ca], b [n_rows,cb], tbl int32 [K,ld], n_rows[, pairs[, dw]]); `pairs` = None or
+    (pair_in int32 [K,ld_p], pair_out int32 [K,ld_p], pair_num int32 [K] | None): bf16 jobs with
+    16-multiple channel counts then take the pair-list kernel; `dw` = an existing float32 [K,ca,cb] tensor
+    to ACCUMULATE into.  Returns the list of dw tensors (float32 [K, ca, cb]), equal to spconv_wgrad per
+    job up to the summation order of the partials."""
     if not jobs:
         return []
     arr = (_WgradJob * len(jobs))()
     outs, keep = [], []
-    for k, (a, b, tbl, n_rows) in enumerate(jobs):
+    for k, job in enumerate(jobs):
+        a, b, tbl, n_rows = job[:4]
+        pairs = job[4] if len(job) > 4 else None
+        acc_into = job[5] if len(job) > 5 else None
         _feat_ok(a, "a")
         _feat_ok(b, "b")
-        _need_cuda(tbl)
         a, b = a.contiguous(), b.contiguous()
         if a.dtype != b.dtype:
             raise RuntimeError("wgrad_multi: a and b must share a dtype")
-        K, ld = tbl.shape
-        dw = torch.empty((K, a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
+        if tbl is not None:
+            _need_cuda(tbl)
+            K, ld = tbl.shape
+        else:
+            K, ld = pairs[0].shape[0], int(n_rows)
+        if acc_into is not None:
+            dw = acc_into
+            if dw.dtype != torch.float32 or not dw.is_contiguous() or dw.numel() != K * a.shape[1] * b.shape[1]:
+                raise RuntimeError("wgrad_multi: the tensor to accumulate into must be contiguous float32 [K,ca,cb]")
+        else:
+            dw = torch.empty((K, a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
         arr[k] = _WgradJob(_p(a), _p(b), _p(tbl), _p(dw), a.shape[1], b.shape[1], ld, K, int(n_rows),
-                           4 if a.dtype == torch.float32 else 2)
+                           4 if a.dtype == torch.float32 else 2,
+                           None, None, None, 0, a.shape[0], WGRAD_ACCUMULATE if acc_into is not None else 0, 0)
+        if pairs is not None:
+            pin, pout, pnum = pairs
+            if pin.dtype != torch.int32 or pout.dtype != torch.int32 or pin.stride(-1) != 1 or pout.stride(-1) != 1 \
+                    or pin.shape != pout.shape or pin.dim() != 2 or pin.stride(0) != pout.stride(0):
+                raise RuntimeError("wgrad_multi: pair lists must be int32 [K, ld] with a unit inner stride")
+            arr[k].pair_in, arr[k].pair_out = _p(pin), _p(pout)
+            arr[k].pair_num = _p(pnum)
+            arr[k].pair_ld = pin.stride(0) if pin.shape[0] > 1 else pin.shape[1]
+            keep.append((pin, pout, pnum))
         outs.append(dw)
         keep.append((a, b))
     dev = outs[0].device
@@ -404,6 +432,27 @@ def spconv_wgrad(a, b, tbl, n_rows):
         raise RuntimeError("spconv_wgrad: unsupported dtype %s" % a.dtype)
     check(fn(_p(a), ca, _p(b), cb, _p(tbl), ld, K, n_rows, _p(dw), _p(ws), ws.numel(), _stream()),
           name)
+    return dw
+
+
+def spconv_wgrad_pairs(a, b, pair_in, pair_out, pair_num, accumulate_into=None):
+    """dw[o] (+)= sum_{p < pair_num[o]} a[pair_in[o,p]]^T b[pair_out[o,p]] -> float32 [K, ca, cb]
+    (doda_spconv_wgrad_pairs_bf16: bf16 operands, channel counts multiples of 16).  pair_num None: every
+    list is full (the identity list of a 1x1 convolution)."""
+    _feat_ok(a, "a")
+    _feat_ok(b, "b")
+    _need_cuda(pair_in, pair_out)
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+        raise RuntimeError("spconv_wgrad_pairs: bf16 operands only")
+    K, ld = pair_in.shape
+    ldp = pair_in.stride(0) if K > 1 else ld
+    ca, cb = a.shape[1], b.shape[1]
+    dw = accumulate_into if accumulate_into is not None else \
+        torch.empty((K, ca, cb), dtype=torch.float32, device=a.device)
+    ws = _ws(lib().doda_spconv_wgrad_pairs_workspace_bytes(K, ca, cb, ldp), a.device)
+    check(lib().doda_spconv_wgrad_pairs_bf16(_p(a), a.shape[0], ca, _p(b), b.shape[0], cb, _p(pair_in), _p(pair_out),
+                                             _p(pair_num), ldp, K, _p(dw), int(accumulate_into is not None),
+                                             _p(ws), ws.numel(), _stream()), "doda_spconv_wgrad_pairs_bf16")
     return dw
 
 

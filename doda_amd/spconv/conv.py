@@ -14,22 +14,79 @@ from torch.nn import init
 from .. import ops as _nops
 from . import functional as Fsp
 from . import ops
-from .core import SparseConvTensor
+from .core import IndiceDict, SparseConvTensor
 from .modules import SparseModule
 
 # ---------------------------------------------------------------------------------------------
 # Weight pre-packing.  The native conv kernels read weights in MFMA-fragment order (bf16-rounded for
-# bf16 features; transposed / offset-mirrored for the data-grad).  Weights change once per optimizer
-# step, so instead of packing inside every conv call (2 x 71 launches per U-Net step) all live
-# convolution modules of a device are re-packed by ONE multi-tensor launch the first time any of
-# them sees a new `weight._version`.  (In-place edits through `.data` do not bump the version; call
-# doda_amd.spconv.conv.invalidate_packed() after such edits.)
+# bf16 features; transposed / offset-mirrored for the data-grad).  Instead of packing inside every
+# conv call (2 x 71 launches per U-Net step) all live convolution modules of a device are re-packed
+# by ONE multi-tensor launch (~20 us) whenever the weights may have changed.
+#
+# "May have changed" must not depend on something an optimizer can bypass: `weight._version` is NOT
+# bumped by fused optimizers (torch 2.10: SGD/Adam(fused=True) leave it untouched) nor by edits through
+# `.data`.  The packed copies therefore belong to a GENERATION, and a new generation starts
+#   * with every new forward pass: the first convolution that sees a SparseConvTensor whose
+#     `indice_dict` carries no generation token starts one (a network input is a fresh tensor each
+#     step, and every tensor derived from it shares its indice_dict);
+#   * after every `optimizer.step()` of any torch optimizer (global step post-hook);
+#   * on `invalidate_packed()`, `load_state_dict`, `.to()/.float()/...` (Module._apply).
+# Within a generation `_version` and `data_ptr()` are still compared, which catches ordinary in-place
+# edits between two calls on the SAME input tensor; only a `.data` edit between two such calls needs
+# an explicit invalidate_packed().
+# The cache holds weak references only: a deleted model drops out of the plan.
 # ---------------------------------------------------------------------------------------------
 import os as _os
 
 _MODULES = weakref.WeakSet()
-_PLANS = {}   # (device, elem_bytes) -> (signature, PackPlan, [modules])
+_PLANS = {}   # (device, elem_bytes) -> _Plan
 _PREPACK = _os.environ.get("DODA_NO_PREPACK", "0") != "1"
+_GEN = [1]    # current weight generation
+
+
+def set_prepack(on):
+    """Switch the one-launch pre-pack on or off at run time (off: every conv call packs its own
+    weights inside the call — the reference behaviour for the parity tests)."""
+    global _PREPACK
+    _PREPACK = bool(on)
+    invalidate_packed()
+    return _PREPACK
+
+
+def new_generation():
+    """Declare every packed weight copy stale (cheap: the re-pack happens lazily, once, at the next
+    convolution call)."""
+    _GEN[0] += 1
+    return _GEN[0]
+
+
+def invalidate_packed():
+    new_generation()
+    _PLANS.clear()
+    for m in list(_MODULES):
+        m._doda_packed = {}
+
+
+def _after_optimizer_step(optimizer, args, kwargs):
+    new_generation()
+
+
+try:   # any torch optimizer, fused or not (reference tool/train.py:100-104 plain optimizer.step())
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
+    _reg_post(_after_optimizer_step)
+except ImportError:   # pragma: no cover  (torch < 2.0)
+    pass
+
+
+def _enter_forward_pass(indice_dict):
+    """Start a new generation the first time a convolution meets the rulebook dictionary of a forward
+    pass.  A foreign dictionary (user code assigned a plain dict) has no slot for the token: every call
+    then starts a generation — slower, never stale."""
+    if type(indice_dict) is IndiceDict:
+        if indice_dict.pack_gen is None:
+            indice_dict.pack_gen = new_generation()
+    else:
+        new_generation()
 
 
 _IDENT = {}
@@ -44,35 +101,42 @@ def _identity_table(n, device):
     return buf[:n].view(1, n)
 
 
-def invalidate_packed():
-    _PLANS.clear()
-    for m in list(_MODULES):
-        m._doda_packed = {}
-
-
 def _bwd_layout(m):
     return 2 if (m.subm and not m.conv1x1) else 1
 
 
+class _Plan:
+    """One pack launch for all convolution modules of (device, elem_bytes)."""
+    __slots__ = ("sig", "plan", "refs", "gen", "versions")
+
+    def __init__(self, sig, plan, mods):
+        self.sig, self.plan = sig, plan
+        self.refs = [weakref.ref(m) for m in mods]
+        self.gen = -1
+        self.versions = ()
+
+
 def _repack_all(device, esz):
-    mods = [m for m in _MODULES if m.weight.device == device and m.weight.dtype == torch.float32]
+    mods = [m for m in _MODULES if m.weight.device == device and m.weight.dtype == torch.float32
+            and m.weight.is_contiguous()
+            and m.weight.shape[0] * m.weight.shape[1] * m.weight.shape[2] <= 27]
     mods.sort(key=id)
     sig = tuple((id(m), m.weight.data_ptr()) for m in mods)
     cached = _PLANS.get((device, esz))
-    if cached is None or cached[0] != sig:
+    if cached is None or cached.sig != sig:
         entries = []
         for m in mods:
             K = m.weight.shape[0] * m.weight.shape[1] * m.weight.shape[2]
             w = m.weight.detach().view(K, m.in_channels, m.out_channels)
             entries.append((w, K, m.in_channels, m.out_channels, 0, esz))          # forward: [K][kc][nc]
             entries.append((w, K, m.out_channels, m.in_channels, _bwd_layout(m), esz))  # data-grad
-        plan = _nops.PackPlan(entries, device)
-        cached = (sig, plan, mods)
-        _PLANS[(device, esz)] = cached
-    _, plan, mods = cached
-    plan.run()
-    for k, m in enumerate(mods):
-        m._doda_packed[esz] = (m.weight._version, m.weight.data_ptr(), plan.outputs[2 * k], plan.outputs[2 * k + 1])
+        cached = _PLANS[(device, esz)] = _Plan(sig, _nops.PackPlan(entries, device), mods)
+        for k, m in enumerate(mods):
+            m._doda_packed[esz] = (cached, k, m._parameters["weight"], m.weight.data_ptr())
+    cached.plan.run()
+    cached.gen = _GEN[0]
+    cached.versions = tuple(m.weight._version for m in mods)
+    return cached
 
 
 class SparseConvolution(SparseModule):
@@ -125,29 +189,55 @@ class SparseConvolution(SparseModule):
             self.in_channels, self.out_channels, self.kernel_size, self.stride, self.subm,
             self.inverse, self.indice_key)
 
-    def _packed(self, features):
+    def _packed(self, features, indice_dict=None):
         """(forward, data-grad) fragment-packed weights for this feature dtype, or None when the
-        native fast path does not apply."""
+        native fast path does not apply.  indice_dict: the input tensor's rulebook dictionary, which
+        carries the generation token of the forward pass (see the comment at the top of this file)."""
+        if indice_dict is not None and getattr(indice_dict, "pack_gen", None) is None:
+            _enter_forward_pass(indice_dict)
         # hot path first (called for every conv of every step; the step is issue-bound on the host):
-        # same Parameter object, same version, same storage -> the cached pair
+        # current generation, same Parameter object, same version, same storage -> the cached pair
         w = self._parameters["weight"]
-        dt = features.dtype
-        st = self._doda_packed.get(dt)
-        if st is not None and st[4] is w and st[0] == w._version and st[1] == w.data_ptr():
-            return st[2], st[3]
+        esz = 4 if features.dtype == torch.float32 else 2
+        st = self._doda_packed.get(esz)
+        if st is not None:
+            plan, k = st[0], st[1]
+            if (plan.gen == _GEN[0] and st[2] is w and st[3] == w.data_ptr()
+                    and plan.versions[k] == w._version):
+                out = plan.plan.outputs
+                return out[2 * k], out[2 * k + 1]
         if not (_PREPACK and features.is_cuda and w.is_cuda and w.dtype == torch.float32
-                and dt in (torch.float32, torch.bfloat16) and w.is_contiguous()):
+                and features.dtype in (torch.float32, torch.bfloat16) and w.is_contiguous()):
             return None
         if w.shape[0] * w.shape[1] * w.shape[2] > 27:
             return None
-        esz = 4 if dt == torch.float32 else 2
-        st = self._doda_packed.get(esz)   # written for ALL modules by whichever one noticed the new version
-        if st is None or st[0] != w._version or st[1] != w.data_ptr():
-            _MODULES.add(self)   # e.g. a deep-copied module never ran __init__
-            _repack_all(w.device, esz)
-            st = self._doda_packed[esz]
-        self._doda_packed[dt] = st + (w,)
-        return st[2], st[3]
+        _MODULES.add(self)   # e.g. a deep-copied module never ran __init__
+        plan = _repack_all(w.device, esz)   # rewrites every module's copies, under the current generation
+        st = self._doda_packed.get(esz)
+        if st is None or st[0] is not plan or st[2] is not w:
+            return None
+        out = plan.plan.outputs
+        return out[2 * st[1]], out[2 * st[1] + 1]
+
+    def _apply(self, fn, recurse=True):
+        # .to() / .cuda() / .float() / .bfloat16(): storage (and maybe dtype) of the weight changes
+        self._doda_packed = {}
+        new_generation()
+        return super()._apply(fn, recurse)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        new_generation()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k == "_doda_packed" else copy.deepcopy(v, memo)
+        _MODULES.add(new)
+        return new
 
     def forward(self, input, residual=None):
         """residual (extension over spconv): optional feature matrix added to the output, fused into the
@@ -164,7 +254,7 @@ class SparseConvolution(SparseModule):
                       and self.weight.dtype == torch.float32 and features.shape[0] > 0)
             if native:
                 ident = _identity_table(features.shape[0], features.device)
-                out_features = Fsp.conv1x1(features, self.weight, ident, self._packed(features))
+                out_features = Fsp.conv1x1(features, self.weight, ident, self._packed(features, input.indice_dict))
             else:
                 w2 = self.weight.view(self.in_channels, self.out_channels)
                 out_features = torch.mm(features, w2.to(features.dtype))
@@ -187,7 +277,7 @@ class SparseConvolution(SparseModule):
             features = nn.functional.pad(features, (0, extra))
             weight = nn.functional.pad(self.weight, (0, 0, 0, extra))
         else:
-            packed = self._packed(features)
+            packed = self._packed(features, input.indice_dict)
 
         data = input.find_indice_pair(self.indice_key)
         if self.inverse:

@@ -25,6 +25,7 @@ class IndiceData:
         self.tbl = tbl
         self.tbl_rev = tbl_rev
         self._pairs = None
+        self._wpairs = None   # (pairs int32 [2,K,n_in] without the -1 fill, pair_num) for the weight gradient
 
     def _export(self):
         if self._pairs is None:
@@ -34,6 +35,20 @@ class IndiceData:
             else:
                 self._pairs = _ops.rulebook_pairs(self.tbl_rev, n_in, flip=False)
         return self._pairs
+
+    def wgrad_lists(self, inverse=False):
+        """(pair_in [K,ld], pair_out [K,ld], pair_num [K]) of the pair-list weight gradient
+        (doda_spconv_wgrad_pairs_bf16): list o pairs the row of the conv INPUT with the row of the conv
+        OUTPUT under offset o.  The strided rulebook serves its inverse convolution with the roles
+        swapped.  Exported once per rulebook (doda_rulebook_pairs without the -1 fill)."""
+        if self._wpairs is None:
+            n_in = self.indices.shape[0]
+            if self.kind == "subm":
+                self._wpairs = _ops.rulebook_pairs(self.tbl, n_in, flip=True, pad=False)
+            else:
+                self._wpairs = _ops.rulebook_pairs(self.tbl_rev, n_in, flip=False, pad=False)
+        pairs, num = self._wpairs
+        return (pairs[1], pairs[0], num) if inverse else (pairs[0], pairs[1], num)
 
     @property
     def indice_pairs(self):
@@ -57,6 +72,18 @@ class IndiceData:
         return self._as_tuple()[i]
 
 
+class IndiceDict(dict):
+    """`SparseConvTensor.indice_dict`: indice_key -> IndiceData, shared by every tensor derived from one
+    network input.  `pack_gen` is the weight-pack generation of the forward pass that owns the dictionary
+    (doda_amd.spconv.conv: packed weight copies are refreshed once per forward pass); it lives in a slot,
+    not under a key, so code that walks the rulebooks never meets it."""
+    __slots__ = ("pack_gen",)
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.pack_gen = None
+
+
 class SparseConvTensor:
     """features [M,C] + indices int32 [M,4] (batch,x,y,z) + spatial_shape + batch_size.
 
@@ -71,7 +98,7 @@ class SparseConvTensor:
         self.spatial_shape = list(spatial_shape) if type(spatial_shape) is list else \
             [int(v) for v in np.asarray(spatial_shape).reshape(-1)]
         self.batch_size = int(batch_size)
-        self.indice_dict = {}
+        self.indice_dict = IndiceDict()
         self.grid = grid
 
     @property

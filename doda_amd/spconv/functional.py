@@ -73,22 +73,34 @@ def _backward_pair(need_dx, need_dw, dgrad_fn, wgrad_fn, device):
     return dx, dw
 
 
+def _wgrad(features, dy, fwd_tbl, n_out, pairs):
+    """Weight gradient of one layer: the pair-list kernel for bf16 operands with 16-multiple channel
+    counts when the rulebook's lists are at hand, else the gather-table kernel."""
+    if (pairs is not None and features.dtype == torch.bfloat16 and features.shape[1] % 16 == 0
+            and dy.shape[1] % 16 == 0):
+        try:
+            return _ops.spconv_wgrad_pairs(features, dy, *pairs)
+        except _ops.DodaNativeError:
+            pass
+    return _ops.spconv_wgrad(features, dy, fwd_tbl, n_out)
+
+
 class _IndiceConv(Function):
     @staticmethod
-    def forward(ctx, features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual=None):
+    def forward(ctx, features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual=None, pairs=None):
         K = fwd_tbl.shape[0]
         cin, cout = weight.shape[-2], weight.shape[-1]
         w = weight.reshape(K, cin, cout)
         ctx.save_for_backward(features, weight)
         pk_fwd, pk_bwd = packed if packed is not None else (None, None)
-        ctx.tables = (fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_bwd)
+        ctx.tables = (fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_bwd, pairs)
         return _gather(features.contiguous(), w, fwd_tbl, n_out, 0, cout, pk_fwd,
                        None if residual is None else residual.contiguous())
 
     @staticmethod
     def backward(ctx, grad_output):
         features, weight = ctx.saved_tensors
-        fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_bwd = ctx.tables
+        fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_bwd, pairs = ctx.tables
         K = fwd_tbl.shape[0]
         cin, cout = weight.shape[-2], weight.shape[-1]
         dy = grad_output.contiguous()  # reference fork patch llijiang/spconv@740a5b7
@@ -96,63 +108,53 @@ class _IndiceConv(Function):
         d_feat, d_w = _backward_pair(
             ctx.needs_input_grad[0], ctx.needs_input_grad[1],
             lambda: _gather(dy, w, bwd_tbl, features.shape[0], bwd_layout, cin, pk_bwd),
-            lambda: _ops.spconv_wgrad(features.contiguous(), dy, fwd_tbl, n_out).reshape(weight.shape).to(weight.dtype),
+            lambda: _wgrad(features.contiguous(), dy, fwd_tbl, n_out, pairs).reshape(weight.shape).to(weight.dtype),
             dy.device)
-        return d_feat, d_w, None, None, None, None, None, (grad_output if ctx.needs_input_grad[7] else None)
+        return d_feat, d_w, None, None, None, None, None, (grad_output if ctx.needs_input_grad[7] else None), None
 
 
-class _Conv1x1(Function):
-    """SubMConv3d(kernel_size=1) (upstream: features @ W.view(Cin,Cout)) as a K = 1 gather-GEMM over
-    an identity table: the library GEMM picked for these skinny shapes ([600k,32] @ [32,16]) runs
-    5-10x slower than the gather kernel on MI355X."""
-
-    @staticmethod
-    def forward(ctx, features, weight, ident, packed):
-        cin, cout = weight.shape[-2], weight.shape[-1]
-        ctx.save_for_backward(features, weight, ident)
-        pk_fwd, ctx.pk_bwd = packed if packed is not None else (None, None)
-        return _gather(features.contiguous(), weight.reshape(1, cin, cout), ident, features.shape[0], 0,
-                       cout, pk_fwd)
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        features, weight, ident = ctx.saved_tensors
-        cin, cout = weight.shape[-2], weight.shape[-1]
-        dy = grad_output.contiguous()
-        d_feat, d_w = _backward_pair(
-            ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-            lambda: _gather(dy, weight.reshape(1, cin, cout), ident, features.shape[0], 1, cin, ctx.pk_bwd),
-            lambda: _ops.spconv_wgrad(features.contiguous(), dy, ident, features.shape[0]).reshape(weight.shape).to(weight.dtype),
-            dy.device)
-        return d_feat, d_w, None, None
-
-
-def _conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual=None):
+def _conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual=None, pairs=None):
     """residual: optional [n_out, Cout] tensor in the output dtype; returns conv + residual with the
-    add fused into the kernel's store (the residual's gradient is the incoming gradient)."""
+    add fused into the kernel's store (the residual's gradient is the incoming gradient).
+    pairs: (pair_in [K,ld], pair_out [K,ld], pair_num [K] | None) of the rulebook, for the weight gradient."""
     if _ext is not None and _SERIAL:   # compiled autograd glue (no Python per launch)
         pk_fwd, pk_bwd = packed if packed is not None else (None, None)
-        return _ext.indice_conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd, residual)
-    return _IndiceConv.apply(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual)
+        if pairs is None:
+            return _ext.indice_conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd, residual)
+        return _ext.indice_conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd, residual,
+                                pairs[0], pairs[1], pairs[2])
+    return _IndiceConv.apply(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual, pairs)
+
+
+def _want_pairs(features, weight):
+    """The pair lists pay off for the weight gradient only: bf16 operands, 16-multiple channel counts,
+    gradient recording on and a weight that wants one."""
+    return (features.dtype == torch.bfloat16 and weight.requires_grad and torch.is_grad_enabled()
+            and weight.shape[-2] % 16 == 0 and weight.shape[-1] % 16 == 0)
 
 
 def conv1x1(features, weight, ident, packed=None):
-    if _ext is not None and _SERIAL:
-        return _conv(features, weight, ident, ident, features.shape[0], 1, packed)
-    return _Conv1x1.apply(features, weight, ident, packed)
+    """SubMConv3d(kernel_size=1) (upstream: features @ W.view(Cin,Cout)) as a K = 1 gather-GEMM over an
+    identity table: the library GEMM picked for these skinny shapes ([600k,32] @ [32,16]) runs 5-10x
+    slower than the gather kernel on MI355X.  The identity table doubles as both pair lists."""
+    pairs = (ident, ident, None) if _want_pairs(features, weight) else None
+    return _conv(features, weight, ident, ident, features.shape[0], 1, packed, None, pairs)
 
 
 def indice_subm_conv(features, weight, data, packed=None, residual=None):
-    return _conv(features, weight, data.tbl, data.tbl, data.outids.shape[0], 2, packed, residual)
+    pairs = data.wgrad_lists() if _want_pairs(features, weight) else None
+    return _conv(features, weight, data.tbl, data.tbl, data.outids.shape[0], 2, packed, residual, pairs)
 
 
 def indice_conv(features, weight, data, packed=None):
-    return _conv(features, weight, data.tbl, data.tbl_rev, data.outids.shape[0], 1, packed)
+    pairs = data.wgrad_lists() if _want_pairs(features, weight) else None
+    return _conv(features, weight, data.tbl, data.tbl_rev, data.outids.shape[0], 1, packed, None, pairs)
 
 
 def indice_inverse_conv(features, weight, data, packed=None):
     # roles swapped: outputs live on the saved (fine) input indices of the strided conv
-    return _conv(features, weight, data.tbl_rev, data.tbl, data.indices.shape[0], 1, packed)
+    pairs = data.wgrad_lists(inverse=True) if _want_pairs(features, weight) else None
+    return _conv(features, weight, data.tbl_rev, data.tbl, data.indices.shape[0], 1, packed, None, pairs)
 
 
 class _IndiceMaxPool(Function):

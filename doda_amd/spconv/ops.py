@@ -63,29 +63,38 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     return data.outids, data.indice_pairs, data.indice_pair_num
 
 
-def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", first_level=1):
+def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", first_level=1, with_pairs=False):
     """Build every rulebook of an n-level U-Net up front and store it in `tensor.indice_dict`
     (SubM k3 under subm_key % i, k2s2 under down_key % i), so the convolutions find them cached.
     Rulebooks depend only on the voxel indices; building them before any feature kernel is queued
     means the size read-backs of the strided levels wait on an almost empty stream instead of
-    stalling the host in the middle of the forward pass."""
+    stalling the host in the middle of the forward pass.  with_pairs: also export every rulebook's pair
+    lists for the pair-list weight gradient (training with bf16 features)."""
     indices, shape = tensor.indices, tensor.spatial_shape
     if (_ext is not None and not tensor.indice_dict and indices.is_cuda and indices.dtype == torch.int32
             and indices.shape[0] > 0 and all(int(v) >= 2 for v in shape)):
-        levels = _ext.build_pyramid(indices, [int(v) for v in shape], int(tensor.batch_size), int(n_levels))
-        for k, (nbr, outids, child, par_off, oshape) in enumerate(levels):
+        levels = _ext.build_pyramid(indices, [int(v) for v in shape], int(tensor.batch_size), int(n_levels),
+                                    bool(with_pairs))
+        for k, (nbr, outids, child, par_off, oshape, sp, sn, dp, dn) in enumerate(levels):
             lvl = first_level + k
-            tensor.indice_dict[subm_key % lvl] = IndiceData("subm", indices, indices, list(shape), list(shape), nbr)
+            data = tensor.indice_dict[subm_key % lvl] = IndiceData("subm", indices, indices, list(shape),
+                                                                   list(shape), nbr)
+            if sp is not None:
+                data._wpairs = (sp, sn)
             if k == len(levels) - 1:
                 break
-            tensor.indice_dict[down_key % lvl] = IndiceData("down2", outids, indices, list(shape), list(oshape),
-                                                            child, par_off)
+            data = tensor.indice_dict[down_key % lvl] = IndiceData("down2", outids, indices, list(shape),
+                                                                   list(oshape), child, par_off)
+            if dp is not None:
+                data._wpairs = (dp, dn)
             indices, shape = outids, list(oshape)
         return tensor.indice_dict
     for lvl in range(first_level, first_level + n_levels):
         key = subm_key % lvl
         if key not in tensor.indice_dict:
             tensor.indice_dict[key] = build_subm(indices, tensor.batch_size, shape, 3)
+        if with_pairs:
+            tensor.indice_dict[key].wgrad_lists()
         if lvl == first_level + n_levels - 1:
             break
         key = down_key % lvl
@@ -93,5 +102,7 @@ def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", firs
         if data is None:
             data = build_down2(indices, tensor.batch_size, shape, 2, 2, 0, 1)
             tensor.indice_dict[key] = data
+        if with_pairs:
+            data.wgrad_lists()
         indices, shape = data.outids, data.out_spatial_shape
     return tensor.indice_dict

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DODA_ABI_VERSION 1
+#define DODA_ABI_VERSION 2
 
 #define DODA_OK 0
 #define DODA_ERR_INVALID (-1)        /* bad argument (null pointer, negative size, bad mode) */
@@ -148,8 +148,10 @@ int doda_rulebook_subm_generic(const int32_t *indices, int32_t m, const int32_t 
 
 /* Export a gather table as spconv-v1.2-format indice pairs: pairs int32 [2][K][ld_pairs]
  * (-1 padded), pair_num int32 [K].  List o holds (in = j, out = tbl[src(o)][j]) for ascending j
- * with tbl[src(o)][j] >= 0, src(o) = K-1-o when `flip` (SubM: in/out roles are mirrored) else o
- * (down2: pass par_off).  Ascending-j order is the order of spconv's CPU path. */
+ * with tbl[src(o)][j] >= 0, src(o) = K-1-o when `flip & 1` (SubM: in/out roles are mirrored) else o
+ * (down2: pass par_off).  Ascending-j order is the order of spconv's CPU path.  `flip & 2`: entries
+ * past pair_num[o] are left unwritten instead of -1 (lists for doda_spconv_wgrad_pairs_bf16, which
+ * is bounded by pair_num: saves the 8*K*ld-byte fill). */
 size_t doda_rulebook_pairs_workspace_bytes(int32_t n_rows, int32_t K);
 int doda_rulebook_pairs(const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, int32_t flip,
                         int32_t *pairs, int32_t ld_pairs, int32_t *pair_num, void *ws,
@@ -222,6 +224,19 @@ int doda_spconv_wgrad_bf16(const uint16_t *a, int32_t ca, const uint16_t *b, int
                            const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, float *dw,
                            void *ws, size_t ws_bytes, doda_stream_t stream);
 
+/* The same contraction over spconv-format PAIR LISTS (offset-major lists of present pairs only):
+ *   dw[o][i][j] (+)= sum_{p < pair_num[o]} a[pair_in[o*ld + p], i] * b[pair_out[o*ld + p], j]
+ * pair_num is a DEVICE array (no size read-back); pair_num == NULL means every list holds exactly ld
+ * pairs (the 1x1 convolution: K = 1, both lists = 0..n-1).  bf16, ca % 16 == 0, cb % 16 == 0.
+ * Rows are brought into MFMA k-order by a one-hot MFMA instead of an LDS round trip;
+ * per-chunk partials in ws, fixed-order reduce: deterministic. */
+size_t doda_spconv_wgrad_pairs_workspace_bytes(int32_t K, int32_t ca, int32_t cb, int32_t ld);
+int doda_spconv_wgrad_pairs_bf16(const uint16_t *a, int32_t n_a, int32_t ca, const uint16_t *b,
+                                 int32_t n_b, int32_t cb, const int32_t *pair_in,
+                                 const int32_t *pair_out, const int32_t *pair_num, int32_t ld,
+                                 int32_t K, float *dw, int32_t accumulate, void *ws, size_t ws_bytes,
+                                 doda_stream_t stream);
+
 /* Weight gradients of MANY layers in one call (one launch per kernel variant + one reduce launch
  * instead of two launches per layer; the coarse levels' small grids run concurrently).  The weight
  * gradient of a layer does not feed the rest of the backward pass, so a caller can queue the jobs
@@ -230,12 +245,22 @@ int doda_spconv_wgrad_bf16(const uint16_t *a, int32_t ca, const uint16_t *b, int
  * (doda_spconv_wgrad_multi_desc_bytes) receives the device descriptors.  Results equal the per-layer
  * calls up to the summation order of the partial reduce (both deterministic). */
 typedef struct doda_wgrad_job {
-    const void *a;        /* [*, ca]      features gathered through tbl (fp32 or bf16) */
+    const void *a;        /* [n_a, ca]    features gathered through tbl / pair_in (fp32 or bf16) */
     const void *b;        /* [n_rows, cb] output gradient, same dtype */
-    const int32_t *tbl;   /* [K][ld] */
-    float *dw;            /* [K][ca][cb] fp32, overwritten */
+    const int32_t *tbl;   /* [K][ld] gather table (may be NULL when the pair lists are given and usable) */
+    float *dw;            /* [K][ca][cb] fp32, overwritten (or accumulated into: DODA_WGRAD_ACCUMULATE) */
     int32_t ca, cb, ld, K, n_rows, elem_bytes;
+    /* ABI 2.  Optional spconv-format pair lists of the same rulebook (doda_rulebook_pairs):
+     * list o = pairs p < pair_num[o] of (a row pair_in[o*pair_ld+p], b row pair_out[o*pair_ld+p]).
+     * bf16 jobs with ca % 16 == 0 and cb % 16 == 0 then run the pair kernel (only PRESENT pairs are
+     * walked; see doda_spconv_wgrad_pairs_bf16); other jobs use tbl. */
+    const int32_t *pair_in, *pair_out, *pair_num;   /* pair_num NULL: every list holds pair_ld pairs */
+    int32_t pair_ld;      /* leading dimension of pair_in / pair_out */
+    int32_t n_a;          /* rows of a (bounds the hardware range check of the pair kernel) */
+    int32_t flags;        /* DODA_WGRAD_* */
+    int32_t reserved;
 } doda_wgrad_job;
+#define DODA_WGRAD_ACCUMULATE 1   /* dw += result (second backward pass into an existing .grad) */
 size_t doda_spconv_wgrad_multi_workspace_bytes(const doda_wgrad_job *jobs_h, int32_t n_jobs);
 size_t doda_spconv_wgrad_multi_desc_bytes(int32_t n_jobs);
 int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_jobs, void *ws, size_t ws_bytes,
