@@ -56,8 +56,9 @@ _SIGNATURES = {
     "doda_spconv_wgrad_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
                                       c_vp, c_sz, c_vp]),
     "doda_spconv_wgrad_pairs_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
-    "doda_spconv_wgrad_pairs_bf16": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32,
-                                             c_vp, c_i32, c_vp, c_sz, c_vp]),
+    "doda_spconv_wgrad_pairs_bf16": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
+                                             c_i32, c_vp, c_i32, c_vp, c_sz, c_vp]),
+    "doda_rulebook_pairs_tile": (c_i32, []),
     "doda_spconv_wgrad_multi_workspace_bytes": (c_sz, [c_vp, c_i32]),
     "doda_spconv_wgrad_multi_desc_bytes": (c_sz, [c_i32]),
     "doda_spconv_wgrad_multi": (c_i32, [c_vp, c_i32, c_vp, c_sz, c_vp, c_sz, c_vp]),

@@ -455,6 +455,8 @@ extern "C" int doda_rulebook_down2_tables(const int32_t *parent, const int32_t *
     return doda_check_launch();
 }
 
+extern "C" int32_t doda_rulebook_pairs_tile(void) { return PAIR_TILE; }
+
 extern "C" size_t doda_rulebook_pairs_workspace_bytes(int32_t n_rows, int32_t K) {
     const int nt = div_up(n_rows > 0 ? n_rows : 1, PAIR_TILE);
     return align_up((size_t)K * nt * 4, 256);

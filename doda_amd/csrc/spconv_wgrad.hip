@@ -520,9 +520,9 @@ bool plan_job(const doda_wgrad_job &j, JobPlan *out) {
         !j.b || !j.tbl || !j.dw || (j.elem_bytes != 2 && j.elem_bytes != 4))
         return false;
     out->esz = j.elem_bytes;
-    out->p = make_plan(j.K, j.ca, j.cb, j.n_rows, j.elem_bytes, true);
     out->vok = ((size_t)j.ca * j.elem_bytes % 16 == 0) && ((size_t)j.cb * j.elem_bytes % 16 == 0) &&
                ((uintptr_t)j.a % 16 == 0) && ((uintptr_t)j.b % 16 == 0);
+    out->p = make_plan(j.K, j.ca, j.cb, j.n_rows, j.elem_bytes, true);
     out->key = (((j.elem_bytes * 4 + out->p.TA) * 4 + out->p.TB) * 8 + out->p.OGW) * 2 + out->vok;
     out->n_elem = (long long)j.K * j.ca * j.cb;
     return true;
@@ -568,7 +568,9 @@ enum { J_SKIP = 0, J_ZERO = 1, J_DENSE = 2, J_PAIRS = 3 };
 static int classify(const doda_wgrad_job &j) {
     if (j.n_rows == 0 && j.dw && j.K > 0 && j.ca > 0 && j.cb > 0)
         return (j.flags & DODA_WGRAD_ACCUMULATE) ? J_SKIP : J_ZERO;
-    if (doda_pairs::eligible(j)) return J_PAIRS;
+    // DODA_WGRAD_NO_PAIRS=1 keeps every job on the gather-table kernel (A/B measurements)
+    static const bool no_pairs = getenv("DODA_WGRAD_NO_PAIRS") && getenv("DODA_WGRAD_NO_PAIRS")[0] == '1';
+    if (doda_pairs::eligible(j) && (!no_pairs || !j.tbl)) return J_PAIRS;
     return J_DENSE;
 }
 
@@ -720,26 +722,30 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
 // ---- pair-list kernel, single layer ------------------------------------------------------------
 static doda_wgrad_job pairs_job(const uint16_t *a, int32_t n_a, int32_t ca, const uint16_t *b, int32_t n_b,
                                 int32_t cb, const int32_t *pin, const int32_t *pout, const int32_t *pnum,
-                                int32_t ld, int32_t K, float *dw, int32_t accumulate) {
+                                int32_t ld, int32_t K, float *dw, int32_t accumulate,
+                                const int32_t *seg = nullptr, int32_t seg_nt = 0) {
     doda_wgrad_job j;
     memset(&j, 0, sizeof(j));
     j.a = a; j.b = b; j.dw = dw;
     j.ca = ca; j.cb = cb; j.ld = ld; j.K = K; j.n_rows = n_b; j.elem_bytes = 2;
     j.pair_in = pin; j.pair_out = pout; j.pair_num = pnum; j.pair_ld = ld; j.n_a = n_a;
     j.flags = accumulate ? DODA_WGRAD_ACCUMULATE : 0;
+    j.pair_seg = seg;
+    j.pair_seg_nt = seg_nt;
     return j;
 }
 
 extern "C" size_t doda_spconv_wgrad_pairs_workspace_bytes(int32_t K, int32_t ca, int32_t cb, int32_t ld) {
     if (K <= 0 || ca <= 0 || cb <= 0 || ld <= 0) return 256;
-    doda_wgrad_job j = pairs_job(nullptr, ld, ca, nullptr, ld, cb, nullptr, nullptr, nullptr, ld, K, nullptr, 0);
+    doda_wgrad_job j = pairs_job(nullptr, ld, ca, nullptr, ld, cb, nullptr, nullptr, nullptr, ld, K, nullptr, 1);
     return doda_pairs::partial_bytes(j) + doda_spconv_wgrad_multi_desc_bytes(1);
 }
 
 extern "C" int doda_spconv_wgrad_pairs_bf16(const uint16_t *a, int32_t n_a, int32_t ca, const uint16_t *b,
                                             int32_t n_b, int32_t cb, const int32_t *pair_in,
-                                            const int32_t *pair_out, const int32_t *pair_num, int32_t ld,
-                                            int32_t K, float *dw, int32_t accumulate, void *ws, size_t ws_bytes,
+                                            const int32_t *pair_out, const int32_t *pair_num,
+                                            const int32_t *pair_seg, int32_t seg_nt, int32_t ld, int32_t K,
+                                            float *dw, int32_t accumulate, void *ws, size_t ws_bytes,
                                             doda_stream_t stream) {
     if (!a || !b || !dw || !ws || K <= 0 || ca <= 0 || cb <= 0 || n_b < 0 || ld < 0) return DODA_ERR_INVALID;
     hipStream_t s = as_stream(stream);
@@ -747,7 +753,8 @@ extern "C" int doda_spconv_wgrad_pairs_bf16(const uint16_t *a, int32_t n_a, int3
         if (!accumulate) hipMemsetAsync(dw, 0, (size_t)K * ca * cb * 4, s);
         return DODA_OK;
     }
-    const doda_wgrad_job j = pairs_job(a, n_a, ca, b, n_b, cb, pair_in, pair_out, pair_num, ld, K, dw, accumulate);
+    const doda_wgrad_job j = pairs_job(a, n_a, ca, b, n_b, cb, pair_in, pair_out, pair_num, ld, K, dw, accumulate,
+                                       pair_seg, seg_nt);
     if (!doda_pairs::eligible(j)) return DODA_ERR_UNSUPPORTED;
     const size_t pbytes = doda_pairs::partial_bytes(j);
     const size_t dbytes = doda_spconv_wgrad_multi_desc_bytes(1);

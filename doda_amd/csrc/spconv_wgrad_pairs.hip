@@ -28,24 +28,44 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int WAVE_PAIRS = 512;            // pairs per wave: 8 double-steps of 64
-constexpr int BLK_PAIRS = 4 * WAVE_PAIRS;  // pairs per block (one offset, one chunk)
+constexpr int SEG_TILE = 256;              // rows per tile of the export's segment prefix (rulebook.hip PAIR_TILE)
+constexpr int RANGE_TILES = 8;             // a block's row range: 2048 rows of the lists' `in` side
+constexpr int RANGE_ROWS = SEG_TILE * RANGE_TILES;
 constexpr unsigned OOB = 0x80000000u;      // absent pair: beyond any buffer (operands are < 1 GB)
 constexpr unsigned CH_OOB = 0x40000000u;   // channel block past the channel count (OOB + CH_OOB does not wrap)
+constexpr int MAX_K = 28;
 
-struct PJob {            // one layer inside a kernel-variant group
+// One layer inside a kernel-variant group.  Work item = (row range of the lists' `in` side, group of 4
+// offsets, channel tile); the block's four waves take one offset each and walk that offset's pairs
+// whose `in` row lies in the range: the segment [seg[o][t0], seg[o][t0 + RANGE_TILES]) of list o, read
+// from the per-256-row-tile prefix the list export leaves behind.  All offsets of a row range touch the
+// same neighbourhood of rows, and consecutive work items run on one XCD (xcd_work_item), so the rows
+// are fetched from HBM once and served from L2 to the other offsets.  (Blocks split by OFFSET instead
+// re-fetched every row into every XCD's L2: measured 63 us per level-1 layer at ~6 TB/s of fabric reads.)
+struct PJob {
     const void *a, *b;
-    const int32_t *pin, *pout, *pnum;
-    float *partial;      // [K][n_chunk][ca][cb]
+    const int32_t *pin, *pout, *pnum, *seg;   // seg: [K][seg_nt] exclusive prefix per tile, or NULL (identity lists)
+    float *partial;      // [n_range][K][ca][cb]
     unsigned a_bytes, b_bytes;
-    int ca, cb, ld, K, n_rows, n_chunk, n_tag, n_tbg, blk_end, pad;
+    int ca, cb, ld, K, n_rows, n_range, n_og, n_tag, n_tbg, seg_nt, blk_end, pad;
 };
-struct RJob {            // dw[o][q] (+)= sum_{c < chunks(o)} partial[o][c][q]
+struct RJob {            // dw[q] (+)= sum_r partial[r][q], q over K*ca*cb/4
     const float4 *partial;
     float4 *dw;
-    const int32_t *pnum;
-    int n_quad, n_chunk, K, ld, accumulate, blk_end;
+    long long n_quad;
+    int R, accumulate, blk_end, pad;
 };
+// block -> job: the inclusive block prefixes travel in the kernel arguments (scalar cache), not in a
+// dependent chain of global loads
+constexpr int MAX_GROUP = 48;
+struct Ends { int n; int end[MAX_GROUP]; };
+
+__device__ __forceinline__ int find_end(const Ends &e, int blk) {
+    int j = 0;
+#pragma unroll 1
+    for (int k = 0; k < e.n - 1; ++k) j += blk >= e.end[k] ? 1 : 0;
+    return j;
+}
 
 template <class J>
 __device__ __forceinline__ int find_job(const J *jobs, int n_jobs, int blk) {
@@ -67,27 +87,36 @@ __device__ __forceinline__ bf16x8 pack_hi16(const f32x4 &d0, const f32x4 &d1) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-// TA x TB 16-channel blocks of (a, b) per wave.  Block = (offset o, chunk of BLK_PAIRS pairs,
-// channel tile); its four waves take WAVE_PAIRS pairs each and add up through LDS at the end.
+// TA x TB 16-channel blocks of (a, b) per wave.
 template <int TA, int TB>
-__global__ __launch_bounds__(256) void wgrad_pairs_kernel(const PJob *__restrict__ jobs, int n_jobs) {
-    const int jn = find_job(jobs, n_jobs, (int)blockIdx.x);
-    const PJob d = jobs[jn];
-    int lb = (int)blockIdx.x - (jn == 0 ? 0 : jobs[jn - 1].blk_end);
+__global__ __launch_bounds__(256) void wgrad_pairs_kernel(const PJob *__restrict__ jobs, const Ends ends) {
+    const int jn = find_end(ends, (int)blockIdx.x);
+    const PJob &d = jobs[jn];
+    const int first = jn == 0 ? 0 : ends.end[jn - 1], n_items = ends.end[jn] - first;
+    int lb = xcd_work_item((int)blockIdx.x - first, n_items);   // contiguous items per XCD
     const int tbg = lb % d.n_tbg; lb /= d.n_tbg;
     const int tag = lb % d.n_tag; lb /= d.n_tag;
-    const int chunk = lb % d.n_chunk;
-    const int o = lb / d.n_chunk;
-    // no counts: every list is full (identity list of a 1x1 conv).  readfirstlane: the value sizes a
-    // buffer descriptor, which must be provably wave-uniform (else hipcc wraps each load in a waterfall loop)
-    const int n_o = __builtin_amdgcn_readfirstlane(d.pnum ? d.pnum[o] : d.ld);
-    const int c0 = chunk * BLK_PAIRS;
-    if (c0 >= n_o) return;   // block-uniform: the list of this offset ends before the chunk
+    const int og = lb % d.n_og;
+    const int range = lb / d.n_og;
 
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int p_begin = c0 + wid * WAVE_PAIRS;
-    const int p_end = (p_begin + WAVE_PAIRS < n_o) ? p_begin + WAVE_PAIRS : n_o;
+    const int o = og * 4 + wid;
+    if (o >= d.K) return;     // (no barrier in this kernel)
+    // the wave's segment of list o.  readfirstlane: the values size buffer descriptors, which must be
+    // provably wave-uniform (else hipcc wraps each load in a waterfall loop)
+    int p_begin, p_end;
+    if (d.seg) {
+        const int t0 = range * RANGE_TILES, t1 = t0 + RANGE_TILES;
+        const int n_o = d.pnum[o];
+        p_begin = d.seg[(long long)o * d.seg_nt + t0];
+        p_end = t1 < d.seg_nt ? d.seg[(long long)o * d.seg_nt + t1] : n_o;
+    } else {                  // identity lists (1x1 convolution): pair p = (p, p)
+        p_begin = range * RANGE_ROWS;
+        p_end = p_begin + RANGE_ROWS < d.ld ? p_begin + RANGE_ROWS : d.ld;
+    }
+    p_begin = __builtin_amdgcn_readfirstlane(p_begin);
+    p_end = __builtin_amdgcn_readfirstlane(p_end);
 
     // one-hot B operands: P[G][k = (g, q)][j = i] = 1 iff the lane group carries pair group G
     // (g >> 1 == G), the half-row of channel j (g & 1 == j >> 3) and q == j & 7
@@ -127,12 +156,12 @@ __global__ __launch_bounds__(256) void wgrad_pairs_kernel(const PJob *__restrict
 #pragma unroll
         for (int yb = 0; yb < TB; ++yb) acc[xa][yb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // index registers of one double-step: lane l holds the pair p + l.  Raw buffer loads over this
-    // offset's lists (num_records = n_o entries): a lane past the end reads 0 and is masked when the
-    // rows are requested.  No branch anywhere in the loop: with control flow inside it hipcc falls
-    // back to s_waitcnt vmcnt(0) in front of every MFMA group and nothing stays in flight.
-    const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void *)pi, 0, (unsigned)n_o * 4u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void *)po, 0, (unsigned)n_o * 4u, 0x00020000);
+    // index registers of one double-step: lane l holds the pair p + l.  Raw buffer loads over the list
+    // up to p_end: a lane past the end reads 0 and is masked when the rows are requested.  No branch
+    // anywhere in the loop: with control flow inside it hipcc falls back to s_waitcnt vmcnt(0) in front
+    // of every MFMA group and nothing stays in flight.
+    const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void *)pi, 0, (unsigned)p_end * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void *)po, 0, (unsigned)p_end * 4u, 0x00020000);
     auto load_idx = [&](int p, int &in_l, int &out_l) {
         const unsigned voff = (unsigned)(p + lane) * 4u;
         in_l = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_i, voff, 0, 0);
@@ -208,55 +237,35 @@ __global__ __launch_bounds__(256) void wgrad_pairs_kernel(const PJob *__restrict
         }
     }
 
-    // ---- the block's four waves add up (fixed order), wave 0 writes the chunk's partial ----
-    __shared__ f32x4 part[3][TA][TB][64];
-    if (wid > 0) {
-#pragma unroll
-        for (int xa = 0; xa < TA; ++xa)
-#pragma unroll
-            for (int yb = 0; yb < TB; ++yb) part[wid - 1][xa][yb][lane] = acc[xa][yb];
-    }
-    __syncthreads();
-    if (wid > 0) return;
-    float *out = d.partial + ((long long)o * d.n_chunk + chunk) * d.ca * d.cb;
+    // ---- the wave owns (range, offset): it writes that partial itself (zeros for an empty segment) ----
+    float *out = d.partial + ((long long)range * d.K + o) * d.ca * d.cb;
 #pragma unroll
     for (int xa = 0; xa < TA; ++xa)
 #pragma unroll
         for (int yb = 0; yb < TB; ++yb) {
-            f32x4 t = acc[xa][yb];
-#pragma unroll
-            for (int w = 0; w < 3; ++w) {
-                const f32x4 v = part[w][xa][yb][lane];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t[r] += v[r];
-            }
             // D[i = ci][j = co]: lane (co = lane & 15, g) holds ci = 4g + r
             const int co = (tbg * TB + yb) * 16 + i;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = (tag * TA + xa) * 16 + 4 * g + r;
-                if (ci < d.ca && co < d.cb) out[(long long)ci * d.cb + co] = t[r];
+                if (ci < d.ca && co < d.cb) out[(long long)ci * d.cb + co] = acc[xa][yb][r];
             }
         }
 }
 
-// dw[o][q] (+)= sum over the chunks the offset's list reaches.  16 quads x 16 chunk lanes per block,
-// lane r sums chunks r, r+16, ... and the lane sums are added in ascending r: fixed order.
+// dw[q] (+)= sum_r partial[r][q]: 16 quads x 16 range lanes per block, lane r sums ranges r, r+16, ...
+// and the lane sums are added in ascending r: fixed order.
 __global__ __launch_bounds__(256) void wgrad_pairs_reduce(const RJob *__restrict__ jobs, int n_jobs) {
     __shared__ float4 part[16][16];
     const int jn = find_job(jobs, n_jobs, (int)blockIdx.x);
     const RJob d = jobs[jn];
-    int lb = (int)blockIdx.x - (jn == 0 ? 0 : jobs[jn - 1].blk_end);
-    const int qb = (d.n_quad + 15) / 16;
-    const int o = lb / qb;
+    const int first = jn == 0 ? 0 : jobs[jn - 1].blk_end;
     const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int q = (lb - o * qb) * 16 + el;
-    const int n_o = d.pnum ? d.pnum[o] : d.ld;
-    const int nch = (n_o + BLK_PAIRS - 1) / BLK_PAIRS;
+    const long long q = (long long)((int)blockIdx.x - first) * 16 + el;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < d.n_quad)
-        for (int c = rl; c < nch; c += 16) {
-            const float4 v = d.partial[((long long)o * d.n_chunk + c) * d.n_quad + q];
+        for (int r = rl; r < d.R; r += 16) {
+            const float4 v = d.partial[(long long)r * d.n_quad + q];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     part[rl][el] = s;
@@ -268,16 +277,18 @@ __global__ __launch_bounds__(256) void wgrad_pairs_reduce(const RJob *__restrict
             const float4 v = part[r][el];
             t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
         }
-        float4 *dst = d.dw + (long long)o * d.n_quad + q;
         if (d.accumulate) {
-            const float4 old = *dst;
+            const float4 old = d.dw[q];
             t.x += old.x; t.y += old.y; t.z += old.z; t.w += old.w;
         }
-        *dst = t;
+        d.dw[q] = t;
     }
 }
 
-struct Geo { int ta, tb, n_tag, n_tbg, n_chunk; };
+struct Geo {
+    int ta, tb, n_tag, n_tbg, n_og, n_range;
+    bool direct;   // one range and no accumulation: the waves write dw themselves
+};
 
 Geo make_geo(const doda_wgrad_job &j) {
     Geo g;
@@ -286,13 +297,17 @@ Geo make_geo(const doda_wgrad_job &j) {
     g.tb = nb >= 2 ? 2 : 1;
     g.n_tag = div_up(na, g.ta);
     g.n_tbg = div_up(nb, g.tb);
-    g.n_chunk = div_up(j.pair_ld > 0 ? j.pair_ld : 1, BLK_PAIRS);
+    g.n_og = div_up(j.K, 4);
+    // rows of the lists' `in` side: the segment prefix covers pair_seg_nt tiles; identity lists: pair_ld pairs
+    const long long rows = j.pair_seg ? (long long)j.pair_seg_nt * SEG_TILE : (long long)j.pair_ld;
+    g.n_range = div_up(rows > 0 ? rows : 1, RANGE_ROWS);
+    g.direct = g.n_range == 1 && !(j.flags & DODA_WGRAD_ACCUMULATE);
     return g;
 }
 
 template <int TA, int TB>
-void launch_variant(int blocks, const PJob *jobs_dev, int n, hipStream_t s) {
-    hipLaunchKernelGGL((wgrad_pairs_kernel<TA, TB>), dim3(blocks), dim3(256), 0, s, jobs_dev, n);
+void launch_variant(int blocks, const PJob *jobs_dev, const Ends &ends, hipStream_t s) {
+    hipLaunchKernelGGL((wgrad_pairs_kernel<TA, TB>), dim3(blocks), dim3(256), 0, s, jobs_dev, ends);
 }
 
 }  // namespace
@@ -302,20 +317,22 @@ namespace doda_pairs {
 bool eligible(const doda_wgrad_job &j) {
     if (j.elem_bytes != 2 || j.ca <= 0 || j.cb <= 0 || (j.ca % 16) || (j.cb % 16) || j.K <= 0 || j.n_rows <= 0)
         return false;
-    if (!j.a || !j.b || !j.dw) return false;
+    if (!j.a || !j.b || !j.dw || j.K > MAX_K) return false;
     if (!j.pair_in || !j.pair_out || j.pair_ld <= 0 || j.n_a <= 0) return false;
-    const long long n_a = j.n_a;
-    if ((unsigned long long)n_a * j.ca * 2ull >= 0x3fffffffull) return false;
+    // real lists come with their counts and segment prefix; the identity lists of a 1x1 conv with neither
+    if (j.pair_num ? (!j.pair_seg || j.pair_seg_nt <= 0) : (j.pair_seg != nullptr || j.K != 1)) return false;
+    if ((unsigned long long)j.n_a * j.ca * 2ull >= 0x3fffffffull) return false;
     if ((unsigned long long)j.n_rows * j.cb * 2ull >= 0x3fffffffull) return false;
     if (((uintptr_t)j.a % 16) || ((uintptr_t)j.b % 16) || ((uintptr_t)j.dw % 16)) return false;
     const Geo g = make_geo(j);
-    if ((long long)j.K * g.n_chunk * g.n_tag * g.n_tbg > 0x3fffffff) return false;
+    if ((long long)g.n_range * g.n_og * g.n_tag * g.n_tbg > 0x3fffffff) return false;
     return true;
 }
 
 size_t partial_bytes(const doda_wgrad_job &j) {
     const Geo g = make_geo(j);
-    return align_up((size_t)j.K * g.n_chunk * j.ca * j.cb * 4, 256);
+    if (g.direct) return 0;
+    return align_up((size_t)g.n_range * j.K * j.ca * j.cb * 4, 256);
 }
 
 size_t desc_bytes_per_job() { return sizeof(PJob) + sizeof(RJob); }
@@ -333,39 +350,45 @@ int prepare(const doda_wgrad_job *jobs, const int *which, int n, char *ws_base, 
     for (int ta = 1; ta <= 2; ++ta)
         for (int tb = 1; tb <= 2; ++tb) {
             Prepared::Group grp{ta, tb, (int)pj.size(), 0, 0};
+            auto flush = [&]() {
+                if (grp.count) out->groups.push_back(grp);
+                grp = Prepared::Group{ta, tb, (int)pj.size(), 0, 0};
+            };
             for (int k = 0; k < n; ++k) {
                 const doda_wgrad_job &j = jobs[which[k]];
                 const Geo g = make_geo(j);
                 if (g.ta != ta || g.tb != tb) continue;
+                if (grp.count == MAX_GROUP) flush();
                 PJob d;
                 memset(&d, 0, sizeof(d));
                 d.a = j.a; d.b = j.b;
-                d.pin = j.pair_in; d.pout = j.pair_out; d.pnum = j.pair_num;
-                d.partial = (float *)(ws_base + offs[k]);
+                d.pin = j.pair_in; d.pout = j.pair_out; d.pnum = j.pair_num; d.seg = j.pair_seg;
+                d.partial = g.direct ? j.dw : (float *)(ws_base + offs[k]);
                 d.a_bytes = (unsigned)((size_t)j.n_a * j.ca * 2);
                 d.b_bytes = (unsigned)((size_t)j.n_rows * j.cb * 2);
                 d.ca = j.ca; d.cb = j.cb; d.ld = j.pair_ld; d.K = j.K; d.n_rows = j.n_rows;
-                d.n_chunk = g.n_chunk; d.n_tag = g.n_tag; d.n_tbg = g.n_tbg;
-                grp.blocks += j.K * g.n_chunk * g.n_tag * g.n_tbg;
+                d.n_range = g.n_range; d.n_og = g.n_og; d.n_tag = g.n_tag; d.n_tbg = g.n_tbg;
+                d.seg_nt = j.pair_seg_nt;
+                grp.blocks += g.n_range * g.n_og * g.n_tag * g.n_tbg;
                 d.blk_end = grp.blocks;
                 pj.push_back(d);
                 ++grp.count;
             }
-            if (grp.count) out->groups.push_back(grp);
+            flush();
         }
     int r_blocks = 0;
     for (int k = 0; k < n; ++k) {
         const doda_wgrad_job &j = jobs[which[k]];
         const Geo g = make_geo(j);
+        if (g.direct) continue;
         RJob d;
         memset(&d, 0, sizeof(d));
         d.partial = (const float4 *)(ws_base + offs[k]);
         d.dw = (float4 *)j.dw;
-        d.pnum = j.pair_num;
-        d.n_quad = j.ca * j.cb / 4;
-        d.n_chunk = g.n_chunk; d.K = j.K; d.ld = j.pair_ld;
+        d.n_quad = (long long)j.K * j.ca * j.cb / 4;
+        d.R = g.n_range;
         d.accumulate = (j.flags & DODA_WGRAD_ACCUMULATE) ? 1 : 0;
-        r_blocks += j.K * div_up(d.n_quad, 16);
+        r_blocks += div_up(d.n_quad, 16);
         d.blk_end = r_blocks;
         rj.push_back(d);
     }
@@ -380,11 +403,16 @@ int prepare(const doda_wgrad_job *jobs, const int *which, int n, char *ws_base, 
 
 int launch(const Prepared &p, const void *desc_dev, hipStream_t s) {
     const PJob *pj = (const PJob *)desc_dev;
+    const PJob *pj_h = (const PJob *)p.desc.data();
     for (const Prepared::Group &g : p.groups) {
-        if (g.ta == 1 && g.tb == 1) launch_variant<1, 1>(g.blocks, pj + g.first, g.count, s);
-        else if (g.ta == 2 && g.tb == 1) launch_variant<2, 1>(g.blocks, pj + g.first, g.count, s);
-        else if (g.ta == 1 && g.tb == 2) launch_variant<1, 2>(g.blocks, pj + g.first, g.count, s);
-        else launch_variant<2, 2>(g.blocks, pj + g.first, g.count, s);
+        Ends ends;
+        memset(&ends, 0, sizeof(ends));
+        ends.n = g.count;
+        for (int k = 0; k < g.count; ++k) ends.end[k] = pj_h[g.first + k].blk_end;
+        if (g.ta == 1 && g.tb == 1) launch_variant<1, 1>(g.blocks, pj + g.first, ends, s);
+        else if (g.ta == 2 && g.tb == 1) launch_variant<2, 1>(g.blocks, pj + g.first, ends, s);
+        else if (g.ta == 1 && g.tb == 2) launch_variant<1, 2>(g.blocks, pj + g.first, ends, s);
+        else launch_variant<2, 2>(g.blocks, pj + g.first, ends, s);
     }
     int st = doda_check_launch();
     if (st != DODA_OK) return st;

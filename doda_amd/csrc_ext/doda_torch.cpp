@@ -108,6 +108,7 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
 // pair lists of a rulebook for the pair-list weight-gradient kernel (all optional)
 struct PairLists {
     at::Tensor in, out, num;   // int32 [K, ld] (unit inner stride), int32 [K] or undefined (full lists)
+    at::Tensor seg;            // int32 [K, nt] segment prefix of the lists (with num)
     bool defined() const { return in.defined() && out.defined(); }
     int64_t ld() const { return in.size(0) > 1 ? in.stride(0) : in.size(1); }
 };
@@ -130,12 +131,28 @@ at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tenso
         const int status = doda_spconv_wgrad_pairs_bf16(
             (const uint16_t *)a.data_ptr(), (int)a.size(0), (int)ca, (const uint16_t *)b.data_ptr(), (int)b.size(0),
             (int)cb, (const int32_t *)pl.in.data_ptr(), (const int32_t *)pl.out.data_ptr(),
-            pl.num.defined() ? (const int32_t *)pl.num.data_ptr() : nullptr, (int)pl.ld(), (int)K,
+            pl.num.defined() ? (const int32_t *)pl.num.data_ptr() : nullptr,
+            pl.seg.defined() ? (const int32_t *)pl.seg.data_ptr() : nullptr,
+            pl.seg.defined() ? (int)pl.seg.size(1) : 0, (int)pl.ld(), (int)K,
             (float *)dw.data_ptr(), 0, ws.data_ptr(), wsb, stream_of(a));
         if (status != DODA_ERR_UNSUPPORTED) {
             check(status, "doda_spconv_wgrad_pairs");
             return dw;
         }
+    }
+    if (esz == 2 && ca % 16 == 0 && cb % 16 == 0 && n_rows > 0) {
+        // job form: carries the row count of `a` (range check of the MFMA-transpose kernel)
+        doda_wgrad_job j;
+        memset(&j, 0, sizeof(j));
+        j.a = a.data_ptr(); j.b = b.data_ptr(); j.tbl = (const int32_t *)tbl.data_ptr(); j.dw = (float *)dw.data_ptr();
+        j.ca = (int32_t)ca; j.cb = (int32_t)cb; j.ld = (int32_t)ld; j.K = (int32_t)K; j.n_rows = (int32_t)n_rows;
+        j.elem_bytes = 2; j.n_a = (int32_t)a.size(0);
+        const size_t wsb = doda_spconv_wgrad_multi_workspace_bytes(&j, 1), dsb = doda_spconv_wgrad_multi_desc_bytes(1);
+        at::Tensor ws = at::empty({(int64_t)wsb}, a.options().dtype(at::kByte));
+        at::Tensor desc = at::empty({(int64_t)dsb}, a.options().dtype(at::kByte));
+        check(doda_spconv_wgrad_multi(&j, 1, ws.data_ptr(), wsb, desc.data_ptr(), dsb, stream_of(a)),
+              "doda_spconv_wgrad_multi");
+        return dw;
     }
     const size_t wsb = doda_spconv_wgrad_workspace_bytes((int)K, (int)ca, (int)cb, (int)n_rows);
     at::Tensor ws = at::empty({(int64_t)(wsb > 256 ? wsb : 256)}, a.options().dtype(at::kByte));
@@ -152,29 +169,28 @@ at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tenso
     return dw;
 }
 
-// spconv-format pair lists of a gather table without the -1 fill (doda_rulebook_pairs, flip | 2)
-std::pair<at::Tensor, at::Tensor> export_pairs(const at::Tensor &tbl, int64_t n_rows, bool flip, void *st) {
+// spconv-format pair lists of a gather table without the -1 fill (doda_rulebook_pairs, flip | 2), their
+// counts and their segment prefix [K, nt] (the head of the export's workspace)
+std::tuple<at::Tensor, at::Tensor, at::Tensor> export_pairs(const at::Tensor &tbl, int64_t n_rows, bool flip, void *st) {
     const int64_t K = tbl.size(0);
     const auto iopt = tbl.options();
     at::Tensor pairs = at::empty({2, K, n_rows > 0 ? n_rows : 1}, iopt), num = at::empty({K}, iopt);
+    // the workspace is an ordinary int32 tensor: its head IS the segment prefix handed on to the weight
+    // gradient, and a view of it takes part in record_stream like any other allocation
     const size_t wsb = doda_rulebook_pairs_workspace_bytes((int32_t)n_rows, (int32_t)K);
-    at::Tensor ws = at::empty({(int64_t)(wsb > 256 ? wsb : 256)}, iopt.dtype(at::kByte));
+    at::Tensor ws = at::empty({(int64_t)((wsb > 256 ? wsb : 256) / 4)}, iopt);
     check(doda_rulebook_pairs((const int32_t *)tbl.data_ptr(), (int32_t)tbl.size(1), (int32_t)K, (int32_t)n_rows,
                               (flip ? 1 : 0) | 2, (int32_t *)pairs.data_ptr(), (int32_t)pairs.size(2),
-                              (int32_t *)num.data_ptr(), ws.data_ptr(), (size_t)ws.numel(), st),
+                              (int32_t *)num.data_ptr(), ws.data_ptr(), (size_t)ws.numel() * 4, st),
           "doda_rulebook_pairs");
-    return {pairs, num};
+    const int64_t tile = doda_rulebook_pairs_tile(), nt = n_rows > 0 ? (n_rows + tile - 1) / tile : 1;
+    return {pairs, num, ws.narrow(0, 0, K * nt).view({K, nt})};
 }
 
-// ---- rulebook pyramid -----------------------------------------------------------------------------
-// The 13 rulebooks of a 7-level U-Net (SubM k3 per level, k2 s2 p0 between levels) in one call: the
-// same native entry points doda_amd.ops drives through ctypes, without ~0.4 ms of Python per step.
-// Returns per level (nbr [27, M]) and, except for the last, (outids [M_out, 4], child [8, M_out],
-// par_off [8, M], out_shape).
 // with_pairs: also export every rulebook's pair lists (SubM: [2,27,M] from nbr; k2s2: [2,8,M] from par_off)
 // for the pair-list weight gradient — on the same (side) stream, off the critical path.
 typedef std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, std::vector<int64_t>, at::Tensor, at::Tensor,
-                   at::Tensor, at::Tensor> PyramidLevel;
+                   at::Tensor, at::Tensor, at::Tensor, at::Tensor> PyramidLevel;
 std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vector<int64_t> shape, int64_t batch,
                                         int64_t n_levels, bool with_pairs) {
     TORCH_CHECK(indices_in.is_cuda() && indices_in.scalar_type() == at::kInt && indices_in.dim() == 2 &&
@@ -192,10 +208,10 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
         check(doda_rulebook_subm((const int32_t *)indices.data_ptr(), m, shp, (int32_t)batch, 3,
                                  (int32_t *)nbr.data_ptr(), m, ws.data_ptr(), (size_t)ws.numel(), st),
               "doda_rulebook_subm");
-        at::Tensor sp, sn, dp, dn;
-        if (with_pairs) std::tie(sp, sn) = export_pairs(nbr, m, true, st);
+        at::Tensor sp, sn, sh, dp, dn, dh;
+        if (with_pairs) std::tie(sp, sn, sh) = export_pairs(nbr, m, true, st);
         if (lvl == n_levels - 1) {
-            out.emplace_back(nbr, at::Tensor(), at::Tensor(), at::Tensor(), std::vector<int64_t>(), sp, sn, dp, dn);
+            out.emplace_back(nbr, at::Tensor(), at::Tensor(), at::Tensor(), std::vector<int64_t>(), sp, sn, sh, dp, dn, dh);
             break;
         }
         at::Tensor parent = at::empty({m > 0 ? m : 1}, iopt), off = at::empty({m > 0 ? m : 1}, iopt);
@@ -209,10 +225,10 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
         check(doda_rulebook_down2_tables((const int32_t *)parent.data_ptr(), (const int32_t *)off.data_ptr(), m, m_out,
                                          (int32_t *)child.data_ptr(), m_out, (int32_t *)par_off.data_ptr(), m, st),
               "doda_rulebook_down2_tables");
-        if (with_pairs) std::tie(dp, dn) = export_pairs(par_off, m, false, st);
+        if (with_pairs) std::tie(dp, dn, dh) = export_pairs(par_off, m, false, st);
         std::vector<int64_t> oshape = {(shape[0] - 2) / 2 + 1, (shape[1] - 2) / 2 + 1, (shape[2] - 2) / 2 + 1};
         at::Tensor outids = out_idx.narrow(0, 0, m_out);
-        out.emplace_back(nbr, outids, child, par_off, oshape, sp, sn, dp, dn);
+        out.emplace_back(nbr, outids, child, par_off, oshape, sp, sn, sh, dp, dn, dh);
         indices = outids;
         shape = oshape;
     }
@@ -275,6 +291,8 @@ void issue_wgrads(std::vector<PendingWgrad> &q, const c10::hip::HIPStream &st) {
             j.pair_in = (const int32_t *)p.pl.in.data_ptr();
             j.pair_out = (const int32_t *)p.pl.out.data_ptr();
             j.pair_num = p.pl.num.defined() ? (const int32_t *)p.pl.num.data_ptr() : nullptr;
+            j.pair_seg = p.pl.seg.defined() ? (const int32_t *)p.pl.seg.data_ptr() : nullptr;
+            j.pair_seg_nt = p.pl.seg.defined() ? (int32_t)p.pl.seg.size(1) : 0;
             j.pair_ld = (int32_t)p.pl.ld();
         }
         jobs[k] = j;
@@ -382,7 +400,8 @@ at::Tensor indice_conv(const at::Tensor &features, const at::Tensor &weight, con
                        const at::Tensor &bwd_tbl, int64_t n_out, int64_t bwd_layout,
                        const c10::optional<at::Tensor> &pk_fwd, const c10::optional<at::Tensor> &pk_bwd,
                        const c10::optional<at::Tensor> &residual, const c10::optional<at::Tensor> &pair_in,
-                       const c10::optional<at::Tensor> &pair_out, const c10::optional<at::Tensor> &pair_num) {
+                       const c10::optional<at::Tensor> &pair_out, const c10::optional<at::Tensor> &pair_num,
+                       const c10::optional<at::Tensor> &pair_seg) {
     const at::Tensor res = residual.has_value() ? *residual : at::Tensor();
     const bool need_grad = at::GradMode::is_enabled() &&
                            (features.requires_grad() || weight.requires_grad() || (res.defined() && res.requires_grad()));
@@ -410,6 +429,12 @@ at::Tensor indice_conv(const at::Tensor &features, const at::Tensor &weight, con
             node->pl.in = *pair_in;
             node->pl.out = *pair_out;
             if (pair_num.has_value() && pair_num->defined()) node->pl.num = *pair_num;
+            if (pair_seg.has_value() && pair_seg->defined()) {
+                TORCH_CHECK(pair_seg->is_cuda() && pair_seg->scalar_type() == at::kInt && pair_seg->is_contiguous() &&
+                            pair_seg->dim() == 2 && pair_seg->size(0) == fwd_tbl.size(0),
+                            "doda indice_conv: the segment prefix must be device int32 [K, nt]");
+                node->pl.seg = *pair_seg;
+            }
         }
         torch::autograd::set_history(y, node);
     }
@@ -556,7 +581,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("indice_conv", &indice_conv, "sparse conv (gather table) with autograd",
           py::arg("features"), py::arg("weight"), py::arg("fwd_tbl"), py::arg("bwd_tbl"), py::arg("n_out"),
           py::arg("bwd_layout"), py::arg("pk_fwd"), py::arg("pk_bwd"), py::arg("residual"),
-          py::arg("pair_in") = py::none(), py::arg("pair_out") = py::none(), py::arg("pair_num") = py::none());
+          py::arg("pair_in") = py::none(), py::arg("pair_out") = py::none(), py::arg("pair_num") = py::none(),
+          py::arg("pair_seg") = py::none());
     m.def("bn_relu", &bn_relu, "fused BatchNorm1d(+ReLU) with autograd");
     m.def("bn_relu_pass", &bn_relu_pass, "fused BatchNorm1d(+ReLU) returning (y, alias of x) for residual blocks");
     m.def("gather", [](const at::Tensor &x, const at::Tensor &w, const c10::optional<at::Tensor> &packed,

@@ -41,6 +41,7 @@ def _shallow(t):
     re-binds `.features` on the object it is given, so a branch that must keep the incoming
     features takes its own header (reference unet_block.py:33,89)."""
     c = spconv.SparseConvTensor(t.features, t.indices, t.spatial_shape, t.batch_size)
+    c.indice_dict = t.indice_dict   # same forward pass: rulebooks and weight-pack generation are shared
     return c
 
 
@@ -201,7 +202,8 @@ class SparseConvNet(nn.Module):
         if input.features.is_cuda and input.indices.shape[0] > 0:
             # all 13 rulebooks up front (+ their pair lists when a bf16 backward pass will follow)
             spconv.ops.build_pyramid(input, len(self.unet.nPlanes), with_pairs=(
-                torch.is_grad_enabled() and self.training and input.features.dtype == torch.bfloat16))
+                spconv.functional.WGRAD_PAIRS and torch.is_grad_enabled() and self.training
+                and input.features.dtype == torch.bfloat16))
         out = self.output_layer(self.unet(self.input_conv(input)))
         feats = out.features
         fused = (v2p_map is not None and not return_mid_feat and feats.is_cuda
@@ -262,8 +264,8 @@ def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fus
             and hasattr(net, "unet") and device.type == "cuda"):
         idx32, pyramid = _prebuild_pyramid(voxel_coords, batch["spatial_shape"], batch_size,
                                            len(net.unet.nPlanes), device,
-                                           with_pairs=(torch.is_grad_enabled() and net.training
-                                                       and feature_dtype == torch.bfloat16))
+                                           with_pairs=(spconv.functional.WGRAD_PAIRS and torch.is_grad_enabled()
+                                                       and net.training and feature_dtype == torch.bfloat16))
         inp = spconv.SparseConvTensor(voxel_feats.to(feature_dtype), idx32, batch["spatial_shape"], batch_size)
         inp.indice_dict.update(pyramid)
     else:

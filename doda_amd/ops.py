@@ -232,20 +232,27 @@ def rulebook_subm_generic(indices, spatial_shape, batch_size, ksize):
     return nbr
 
 
-def rulebook_pairs(tbl, n_rows, flip, pad=True):
+def rulebook_pairs(tbl, n_rows, flip, pad=True, with_seg=False):
     """spconv-v1.2-format (pairs int32 [2,K,n_rows] -1 padded, pairNum int32 [K]) from a table.
-    pad=False leaves the entries past pairNum[o] unwritten (lists for the pair-list weight gradient)."""
+    pad=False leaves the entries past pairNum[o] unwritten (lists for the pair-list weight gradient).
+    with_seg: also return the lists' segment prefix int32 [K, ceil(n_rows / 256)] (see doda_hip.h)."""
     _need_cuda(tbl)
     K, ld = tbl.shape
     dev = tbl.device
     pairs = torch.empty((2, K, max(n_rows, 1)), dtype=torch.int32, device=dev)
     pair_num = torch.zeros(K, dtype=torch.int32, device=dev)
-    ws = _ws(lib().doda_rulebook_pairs_workspace_bytes(n_rows, K), dev)
+    nbytes = lib().doda_rulebook_pairs_workspace_bytes(n_rows, K)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev) if with_seg else _ws(nbytes, dev)
     if n_rows == 0:
+        if with_seg:
+            return pairs[:, :, :0], pair_num, torch.zeros((K, 1), dtype=torch.int32, device=dev)
         return pairs[:, :, :0], pair_num
     check(lib().doda_rulebook_pairs(_p(tbl), ld, K, n_rows, int(bool(flip)) | (0 if pad else 2), _p(pairs), n_rows,
                                     _p(pair_num), _p(ws), ws.numel(), _stream()),
           "doda_rulebook_pairs")
+    if with_seg:
+        nt = -(-n_rows // lib().doda_rulebook_pairs_tile())
+        return pairs, pair_num, ws[:K * nt * 4].view(torch.int32).view(K, nt)
     return pairs, pair_num
 
 
@@ -353,7 +360,8 @@ class _WgradJob(C.Structure):   # doda_wgrad_job (include/doda_hip.h, ABI 2)
                 ("ca", C.c_int32), ("cb", C.c_int32), ("ld", C.c_int32), ("K", C.c_int32),
                 ("n_rows", C.c_int32), ("elem_bytes", C.c_int32),
                 ("pair_in", C.c_void_p), ("pair_out", C.c_void_p), ("pair_num", C.c_void_p),
-                ("pair_ld", C.c_int32), ("n_a", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
+                ("pair_ld", C.c_int32), ("n_a", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32),
+                ("pair_seg", C.c_void_p), ("pair_seg_nt", C.c_int32), ("reserved2", C.c_int32)]
 
 
 WGRAD_ACCUMULATE = 1
@@ -362,7 +370,7 @@ WGRAD_ACCUMULATE = 1
 def spconv_wgrad_multi(jobs):
     """Weight gradients of many layers in one native call (doda_spconv_wgrad_multi).
     jobs: list of (a [*,ca], b [n_rows,cb], tbl int32 [K,ld], n_rows[, pairs[, dw]]); `pairs` = None or
-    (pair_in int32 [K,ld_p], pair_out int32 [K,ld_p], pair_num int32 [K] | None): bf16 jobs with
+    (pair_in int32 [K,ld_p], pair_out int32 [K,ld_p], pair_num int32 [K] | None, seg int32 [K,nt] | None): bf16 jobs with
     16-multiple channel counts then take the pair-list kernel; `dw` = an existing float32 [K,ca,cb] tensor
     to ACCUMULATE into.  Returns the list of dw tensors (float32 [K, ca, cb]), equal to spconv_wgrad per
     job up to the summation order of the partials."""
@@ -392,16 +400,23 @@ def spconv_wgrad_multi(jobs):
             dw = torch.empty((K, a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
         arr[k] = _WgradJob(_p(a), _p(b), _p(tbl), _p(dw), a.shape[1], b.shape[1], ld, K, int(n_rows),
                            4 if a.dtype == torch.float32 else 2,
-                           None, None, None, 0, a.shape[0], WGRAD_ACCUMULATE if acc_into is not None else 0, 0)
+                           None, None, None, 0, a.shape[0], WGRAD_ACCUMULATE if acc_into is not None else 0, 0,
+                           None, 0, 0)
         if pairs is not None:
-            pin, pout, pnum = pairs
+            pin, pout, pnum = pairs[:3]
+            seg = pairs[3] if len(pairs) > 3 else None
             if pin.dtype != torch.int32 or pout.dtype != torch.int32 or pin.stride(-1) != 1 or pout.stride(-1) != 1 \
                     or pin.shape != pout.shape or pin.dim() != 2 or pin.stride(0) != pout.stride(0):
                 raise RuntimeError("wgrad_multi: pair lists must be int32 [K, ld] with a unit inner stride")
             arr[k].pair_in, arr[k].pair_out = _p(pin), _p(pout)
             arr[k].pair_num = _p(pnum)
             arr[k].pair_ld = pin.stride(0) if pin.shape[0] > 1 else pin.shape[1]
-            keep.append((pin, pout, pnum))
+            if seg is not None:
+                if not seg.is_cuda or seg.dtype != torch.int32 or seg.dim() != 2 or seg.shape[0] != K \
+                        or not seg.is_contiguous():
+                    raise RuntimeError("wgrad_multi: the segment prefix must be a device int32 [K, nt] tensor")
+                arr[k].pair_seg, arr[k].pair_seg_nt = _p(seg), seg.shape[1]
+            keep.append((pin, pout, pnum, seg))
         outs.append(dw)
         keep.append((a, b))
     dev = outs[0].device
@@ -422,6 +437,9 @@ def spconv_wgrad(a, b, tbl, n_rows):
         raise RuntimeError("spconv_wgrad: a and b must share a dtype")
     K, ld = tbl.shape
     ca, cb = a.shape[1], b.shape[1]
+    if a.dtype == torch.bfloat16 and ca % 16 == 0 and cb % 16 == 0 and n_rows > 0:
+        # the job form carries the row count of `a`, which the MFMA-transpose kernel's range check needs
+        return spconv_wgrad_multi([(a, b, tbl, n_rows)])[0]
     dw = torch.empty((K, ca, cb), dtype=torch.float32, device=a.device)
     ws = _ws(lib().doda_spconv_wgrad_workspace_bytes(K, ca, cb, n_rows), a.device)
     if a.dtype == torch.float32:
@@ -435,10 +453,11 @@ def spconv_wgrad(a, b, tbl, n_rows):
     return dw
 
 
-def spconv_wgrad_pairs(a, b, pair_in, pair_out, pair_num, accumulate_into=None):
+def spconv_wgrad_pairs(a, b, pair_in, pair_out, pair_num, pair_seg=None, accumulate_into=None):
     """dw[o] (+)= sum_{p < pair_num[o]} a[pair_in[o,p]]^T b[pair_out[o,p]] -> float32 [K, ca, cb]
     (doda_spconv_wgrad_pairs_bf16: bf16 operands, channel counts multiples of 16).  pair_num None: every
-    list is full (the identity list of a 1x1 convolution)."""
+    list is full (the identity list of a 1x1 convolution).  pair_seg: the lists' segment prefix int32
+    [K, nt] (third result of rulebook_pairs; required whenever pair_num is given)."""
     _feat_ok(a, "a")
     _feat_ok(b, "b")
     _need_cuda(pair_in, pair_out)
@@ -451,7 +470,9 @@ def spconv_wgrad_pairs(a, b, pair_in, pair_out, pair_num, accumulate_into=None):
         torch.empty((K, ca, cb), dtype=torch.float32, device=a.device)
     ws = _ws(lib().doda_spconv_wgrad_pairs_workspace_bytes(K, ca, cb, ldp), a.device)
     check(lib().doda_spconv_wgrad_pairs_bf16(_p(a), a.shape[0], ca, _p(b), b.shape[0], cb, _p(pair_in), _p(pair_out),
-                                             _p(pair_num), ldp, K, _p(dw), int(accumulate_into is not None),
+                                             _p(pair_num), _p(pair_seg),
+                                             0 if pair_seg is None else pair_seg.shape[1], ldp, K, _p(dw),
+                                             int(accumulate_into is not None),
                                              _p(ws), ws.numel(), _stream()), "doda_spconv_wgrad_pairs_bf16")
     return dw
 

@@ -254,7 +254,10 @@ class SparseConvolution(SparseModule):
                       and self.weight.dtype == torch.float32 and features.shape[0] > 0)
             if native:
                 ident = _identity_table(features.shape[0], features.device)
-                out_features = Fsp.conv1x1(features, self.weight, ident, self._packed(features, input.indice_dict))
+                # (no rulebook is involved, and the reference hands its 1x1 skip convolution a FRESH tensor
+                # header, model/unet_block.py:33: an empty dictionary here is not the start of a forward pass)
+                out_features = Fsp.conv1x1(features, self.weight, ident, self._packed(
+                    features, input.indice_dict if len(input.indice_dict) else None))
             else:
                 w2 = self.weight.view(self.in_channels, self.out_channels)
                 out_features = torch.mm(features, w2.to(features.dtype))

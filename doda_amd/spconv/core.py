@@ -37,18 +37,20 @@ class IndiceData:
         return self._pairs
 
     def wgrad_lists(self, inverse=False):
-        """(pair_in [K,ld], pair_out [K,ld], pair_num [K]) of the pair-list weight gradient
+        """(pair_in [K,ld], pair_out [K,ld], pair_num [K], seg [K,nt]) of the pair-list weight gradient
         (doda_spconv_wgrad_pairs_bf16): list o pairs the row of the conv INPUT with the row of the conv
-        OUTPUT under offset o.  The strided rulebook serves its inverse convolution with the roles
-        swapped.  Exported once per rulebook (doda_rulebook_pairs without the -1 fill)."""
+        OUTPUT under offset o, in ascending input row; seg is the lists' per-256-row prefix.  Exported
+        once per rulebook (doda_rulebook_pairs without the -1 fill)."""
         if self._wpairs is None:
             n_in = self.indices.shape[0]
             if self.kind == "subm":
-                self._wpairs = _ops.rulebook_pairs(self.tbl, n_in, flip=True, pad=False)
+                self._wpairs = _ops.rulebook_pairs(self.tbl, n_in, flip=True, pad=False, with_seg=True)
             else:
-                self._wpairs = _ops.rulebook_pairs(self.tbl_rev, n_in, flip=False, pad=False)
-        pairs, num = self._wpairs
-        return (pairs[1], pairs[0], num) if inverse else (pairs[0], pairs[1], num)
+                self._wpairs = _ops.rulebook_pairs(self.tbl_rev, n_in, flip=False, pad=False, with_seg=True)
+        pairs, num, seg = self._wpairs
+        # (the inverse convolution reads the same lists with the operand roles swapped; the segment prefix
+        # belongs to the ascending list, whichever operand it indexes)
+        return (pairs[1], pairs[0], num, seg) if inverse else (pairs[0], pairs[1], num, seg)
 
     @property
     def indice_pairs(self):

@@ -122,14 +122,18 @@ def _conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residua
         if pairs is None:
             return _ext.indice_conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd, residual)
         return _ext.indice_conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd, residual,
-                                pairs[0], pairs[1], pairs[2])
+                                pairs[0], pairs[1], pairs[2], pairs[3] if len(pairs) > 3 else None)
     return _IndiceConv.apply(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual, pairs)
 
 
+# The pair-list weight gradient (doda_spconv_wgrad_pairs_bf16) needs the rulebook's pair lists (exported
+# once per rulebook on the rulebook stream); DODA_WGRAD_PAIRS=0 keeps every layer on the gather-table kernel.
+WGRAD_PAIRS = os.environ.get("DODA_WGRAD_PAIRS", "1") == "1"
+
+
 def _want_pairs(features, weight):
-    """The pair lists pay off for the weight gradient only: bf16 operands, 16-multiple channel counts,
-    gradient recording on and a weight that wants one."""
-    return (features.dtype == torch.bfloat16 and weight.requires_grad and torch.is_grad_enabled()
+    """bf16 operands, 16-multiple channel counts, gradient recording on and a weight that wants one."""
+    return (WGRAD_PAIRS and features.dtype == torch.bfloat16 and weight.requires_grad and torch.is_grad_enabled()
             and weight.shape[-2] % 16 == 0 and weight.shape[-1] % 16 == 0)
 
 

@@ -75,18 +75,18 @@ def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", firs
             and indices.shape[0] > 0 and all(int(v) >= 2 for v in shape)):
         levels = _ext.build_pyramid(indices, [int(v) for v in shape], int(tensor.batch_size), int(n_levels),
                                     bool(with_pairs))
-        for k, (nbr, outids, child, par_off, oshape, sp, sn, dp, dn) in enumerate(levels):
+        for k, (nbr, outids, child, par_off, oshape, sp, sn, sh, dp, dn, dh) in enumerate(levels):   # s*/d*: lists, counts, segments
             lvl = first_level + k
             data = tensor.indice_dict[subm_key % lvl] = IndiceData("subm", indices, indices, list(shape),
                                                                    list(shape), nbr)
             if sp is not None:
-                data._wpairs = (sp, sn)
+                data._wpairs = (sp, sn, sh)
             if k == len(levels) - 1:
                 break
             data = tensor.indice_dict[down_key % lvl] = IndiceData("down2", outids, indices, list(shape),
                                                                    list(oshape), child, par_off)
             if dp is not None:
-                data._wpairs = (dp, dn)
+                data._wpairs = (dp, dn, dh)
             indices, shape = outids, list(oshape)
         return tensor.indice_dict
     for lvl in range(first_level, first_level + n_levels):

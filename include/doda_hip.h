@@ -151,7 +151,11 @@ int doda_rulebook_subm_generic(const int32_t *indices, int32_t m, const int32_t 
  * with tbl[src(o)][j] >= 0, src(o) = K-1-o when `flip & 1` (SubM: in/out roles are mirrored) else o
  * (down2: pass par_off).  Ascending-j order is the order of spconv's CPU path.  `flip & 2`: entries
  * past pair_num[o] are left unwritten instead of -1 (lists for doda_spconv_wgrad_pairs_bf16, which
- * is bounded by pair_num: saves the 8*K*ld-byte fill). */
+ * is bounded by pair_num: saves the 8*K*ld-byte fill).
+ * On return `ws` starts with the SEGMENT PREFIX of the lists, int32 [K][nt] with
+ * nt = ceil(n_rows / doda_rulebook_pairs_tile()): entry [o][t] = number of pairs of list o with
+ * j < t * tile (the stable compaction's own tile prefix); doda_spconv_wgrad_pairs_bf16 reads it. */
+int32_t doda_rulebook_pairs_tile(void);
 size_t doda_rulebook_pairs_workspace_bytes(int32_t n_rows, int32_t K);
 int doda_rulebook_pairs(const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, int32_t flip,
                         int32_t *pairs, int32_t ld_pairs, int32_t *pair_num, void *ws,
@@ -226,16 +230,20 @@ int doda_spconv_wgrad_bf16(const uint16_t *a, int32_t ca, const uint16_t *b, int
 
 /* The same contraction over spconv-format PAIR LISTS (offset-major lists of present pairs only):
  *   dw[o][i][j] (+)= sum_{p < pair_num[o]} a[pair_in[o*ld + p], i] * b[pair_out[o*ld + p], j]
- * pair_num is a DEVICE array (no size read-back); pair_num == NULL means every list holds exactly ld
- * pairs (the 1x1 convolution: K = 1, both lists = 0..n-1).  bf16, ca % 16 == 0, cb % 16 == 0.
+ * pair_num (device) and pair_seg [K][seg_nt] come from doda_rulebook_pairs: pair_seg[o][t] = number of
+ * pairs of list o whose `in` row lies below tile t (256 rows per tile).  A workgroup takes one range of
+ * `in` rows and walks, one offset per wave, the matching segment of every list: all offsets of a row
+ * range touch the same neighbourhood of rows, so a and b stream from HBM once.  pair_num == NULL and
+ * pair_seg == NULL with K == 1: the list holds exactly ld pairs in row order (the 1x1 convolution, both
+ * lists = 0..n-1).  bf16, ca % 16 == 0, cb % 16 == 0.
  * Rows are brought into MFMA k-order by a one-hot MFMA instead of an LDS round trip;
  * per-chunk partials in ws, fixed-order reduce: deterministic. */
 size_t doda_spconv_wgrad_pairs_workspace_bytes(int32_t K, int32_t ca, int32_t cb, int32_t ld);
 int doda_spconv_wgrad_pairs_bf16(const uint16_t *a, int32_t n_a, int32_t ca, const uint16_t *b,
                                  int32_t n_b, int32_t cb, const int32_t *pair_in,
-                                 const int32_t *pair_out, const int32_t *pair_num, int32_t ld,
-                                 int32_t K, float *dw, int32_t accumulate, void *ws, size_t ws_bytes,
-                                 doda_stream_t stream);
+                                 const int32_t *pair_out, const int32_t *pair_num,
+                                 const int32_t *pair_seg, int32_t seg_nt, int32_t ld, int32_t K, float *dw,
+                                 int32_t accumulate, void *ws, size_t ws_bytes, doda_stream_t stream);
 
 /* Weight gradients of MANY layers in one call (one launch per kernel variant + one reduce launch
  * instead of two launches per layer; the coarse levels' small grids run concurrently).  The weight
@@ -254,11 +262,14 @@ typedef struct doda_wgrad_job {
      * list o = pairs p < pair_num[o] of (a row pair_in[o*pair_ld+p], b row pair_out[o*pair_ld+p]).
      * bf16 jobs with ca % 16 == 0 and cb % 16 == 0 then run the pair kernel (only PRESENT pairs are
      * walked; see doda_spconv_wgrad_pairs_bf16); other jobs use tbl. */
-    const int32_t *pair_in, *pair_out, *pair_num;   /* pair_num NULL: every list holds pair_ld pairs */
+    const int32_t *pair_in, *pair_out, *pair_num;   /* pair_num NULL (K == 1): the list holds pair_ld pairs */
     int32_t pair_ld;      /* leading dimension of pair_in / pair_out */
     int32_t n_a;          /* rows of a (bounds the hardware range check of the pair kernel) */
     int32_t flags;        /* DODA_WGRAD_* */
     int32_t reserved;
+    const int32_t *pair_seg;     /* [K][pair_seg_nt] segment prefix of the lists (see doda_rulebook_pairs), with */
+    int32_t pair_seg_nt;         /* pair_num; both NULL / 0 for the full identity lists of a 1x1 convolution   */
+    int32_t reserved2;
 } doda_wgrad_job;
 #define DODA_WGRAD_ACCUMULATE 1   /* dw += result (second backward pass into an existing .grad) */
 size_t doda_spconv_wgrad_multi_workspace_bytes(const doda_wgrad_job *jobs_h, int32_t n_jobs);

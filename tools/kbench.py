@@ -74,6 +74,11 @@ def main():
                 bf = s * 2 * m * c + 4 * 27 * c * c + 8 * pairs
                 line = "L%d M=%7d c=%3d %-4s  fwd %8.1f us (%5.0f GB/s)  dgrad %8.1f  wgrad %8.1f" % (
                     lvl, m, c, dt, tf, bf / tf / 1e3, td, tw)
+                if dt == "bf16" and c % 16 == 0:
+                    te = timed(lambda: ops.rulebook_pairs(sub.tbl, m, True, pad=False), a.reps)
+                    pr, num, seg = ops.rulebook_pairs(sub.tbl, m, True, pad=False, with_seg=True)
+                    tp = timed(lambda: ops.spconv_wgrad_pairs(x, gy, pr[0], pr[1], num, seg), a.reps)
+                    line += " wgrad-pairs %7.1f (%5.0f GB/s; list export %6.1f)" % (tp, bf / tp / 1e3, te)
                 if down is not None:
                     mo = down.outids.shape[0]
                     wd = torch.randn(8, c, c + 16, device=dev) * 0.05
