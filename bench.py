@@ -48,6 +48,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-voxels", type=int, default=150000, help="size of the CPU-baseline sample scene")
     p.add_argument("--kernel-reps", type=int, default=50)
+    p.add_argument("--prefetch", type=int, default=1,
+                   help="1: rulebooks of the next batch are built on a helper thread during the step; 0: in line")
     return p.parse_args()
 
 
@@ -219,9 +221,21 @@ def main():
     fdt = torch.float32 if args.dtype == "f32" else torch.bfloat16
     labels = batch_dev["labels"]
 
+    # rulebooks ride in the data pipeline: those of the NEXT batch are built on a helper thread + side
+    # stream while this step is issued (every step still builds one full pyramid; nothing is cached)
+    from doda_amd.model import PyramidPrefetcher
+    from doda_amd import spconv
+    with_pairs = bool(spconv.functional.WGRAD_PAIRS and fdt == torch.bfloat16)
+    prefetch = PyramidPrefetcher(dev, len(net.unet.nPlanes)) if args.prefetch else None
+    pending = [prefetch.submit(batch_dev, with_pairs)] if prefetch else None
+
     def step():
         opt.zero_grad(set_to_none=True)
-        scores = voxelize_and_run(cfg, model, batch_dev, dev, feature_dtype=fdt, inputs_ready=True)
+        pyramid = None
+        if prefetch is not None:
+            pyramid = PyramidPrefetcher.take(pending[0], dev)
+            pending[0] = prefetch.submit(batch_dev, with_pairs)
+        scores = voxelize_and_run(cfg, model, batch_dev, dev, feature_dtype=fdt, inputs_ready=True, pyramid=pyramid)
         loss = cross_entropy(scores, labels, ignore_index=255)
         loss.backward()
         if reducer is not None:
@@ -239,6 +253,9 @@ def main():
     torch.cuda.synchronize()
     ddist.barrier()
     elapsed = time.perf_counter() - t0
+    if prefetch is not None:
+        pending[0].result()
+        prefetch.shutdown()
     elapsed, (m_total, n_total) = ddist.reduce_step_stats(elapsed, [m_local, n_local], dev)
     final_loss = float(loss.detach())
 

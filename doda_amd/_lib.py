@@ -73,6 +73,13 @@ _SIGNATURES = {
     "doda_cross_entropy_workspace_bytes": (c_sz, [c_i32]),
     "doda_cross_entropy_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, C.c_int64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "doda_cross_entropy_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, C.c_int64, c_vp, c_vp]),
+    "doda_spconv_stats_capacity": (c_sz, [c_i32]),
+    "doda_spconv_gather_ex": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32,
+                                      c_i32, c_vp, c_sz, c_vp, c_vp]),
+    "doda_bn_relu_fwd_stats": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp,
+                                       c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "doda_bn_relu_bwd_stats": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                       c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "doda_bn_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "doda_bn_relu_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -419,6 +419,104 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd(const typename T::elem 
     }
 }
 
+// ---- statistics delivered by a conv epilogue (doda_spconv_gather_ex) ---------------------------------
+// `stats` = [rows][2][c] partial sums, one row per workgroup tile of the conv.  One block per 4-channel
+// fragment: 256 threads walk the rows with 16-byte loads, fp64 sums, fixed-order tree in LDS.
+__device__ __forceinline__ void block_sum_d4(double (&v)[4], double (*lds)[4]) {   // 256 threads, fixed order
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = wave_sum(v[q]);
+    const int wid = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lds[wid][q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (lds[0][q] + lds[1][q]) + (lds[2][q] + lds[3][q]);
+}
+
+__global__ __launch_bounds__(BN_BLOCK) void bn_fwd_final_stats(const float *__restrict__ stats, int rows, int m, int c,
+                                                               float eps, float momentum, float *__restrict__ mean,
+                                                               float *__restrict__ invstd,
+                                                               float *__restrict__ running_mean,
+                                                               float *__restrict__ running_var,
+                                                               long long *__restrict__ nbt) {
+    __shared__ double lds[4][4];
+    const int f = blockIdx.x;
+    f32x4 rm = {0, 0, 0, 0}, rv = {0, 0, 0, 0};
+    long long n_tracked = 0;
+    if (threadIdx.x == 0 && running_mean) {   // requested before the partial sums: one round trip, not two
+        rm = *reinterpret_cast<const f32x4 *>(running_mean + f * 4);
+        rv = *reinterpret_cast<const f32x4 *>(running_var + f * 4);
+    }
+    if (threadIdx.x == 0 && f == 0 && nbt) n_tracked = *nbt;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (int r = threadIdx.x; r < rows; r += BN_BLOCK) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(stats + (long long)r * 2 * c + f * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(stats + (long long)r * 2 * c + c + f * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s1[q] += (double)a[q]; s2[q] += (double)b[q]; }
+    }
+    block_sum_d4(s1, lds);
+    block_sum_d4(s2, lds);
+    if (threadIdx.x != 0) return;
+    f32x4 mu, is;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double d = s1[q] / m;
+        double var = s2[q] / m - d * d;
+        if (var < 0.0) var = 0.0;
+        mu[q] = (float)d;
+        is[q] = (float)(1.0 / sqrt(var + (double)eps));
+        const double unbiased = m > 1 ? var * (double)m / (double)(m - 1) : var;
+        rm[q] = (float)((1.0 - momentum) * (double)rm[q] + momentum * d);
+        rv[q] = (float)((1.0 - momentum) * (double)rv[q] + momentum * unbiased);
+    }
+    *reinterpret_cast<f32x4 *>(mean + f * 4) = mu;
+    *reinterpret_cast<f32x4 *>(invstd + f * 4) = is;
+    if (running_mean) {
+        *reinterpret_cast<f32x4 *>(running_mean + f * 4) = rm;
+        *reinterpret_cast<f32x4 *>(running_var + f * 4) = rv;
+    }
+    if (f == 0 && nbt) *nbt = n_tracked + 1;
+}
+
+__global__ __launch_bounds__(BN_BLOCK) void bn_bwd_final_stats(const float *__restrict__ stats, int rows, int m, int c,
+                                                               const float *__restrict__ invstd,
+                                                               const float *__restrict__ gamma,
+                                                               float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                               float *__restrict__ coef /*[3][C]*/) {
+    __shared__ double lds[4][4];
+    const int f = blockIdx.x;
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + f * 4);
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (int r = threadIdx.x; r < rows; r += BN_BLOCK) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(stats + (long long)r * 2 * c + f * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(stats + (long long)r * 2 * c + c + f * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s1[q] += (double)a[q]; s2[q] += (double)b[q]; }
+    }
+    block_sum_d4(s1, lds);
+    block_sum_d4(s2, lds);
+    if (threadIdx.x != 0) return;
+    f32x4 db, dg, a, bb, dd;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        db[q] = (float)s1[q];
+        dg[q] = (float)s2[q];
+        a[q] = ga[q] * is[q];
+        bb[q] = (float)(s1[q] / m);
+        dd[q] = (float)(s2[q] / m);
+    }
+    *reinterpret_cast<f32x4 *>(dbeta + f * 4) = db;
+    *reinterpret_cast<f32x4 *>(dgamma + f * 4) = dg;
+    *reinterpret_cast<f32x4 *>(coef + f * 4) = a;           // dx = a * (dz - b - xhat * d)
+    *reinterpret_cast<f32x4 *>(coef + c + f * 4) = bb;
+    *reinterpret_cast<f32x4 *>(coef + 2 * c + f * 4) = dd;
+}
+
 Geo make_geo(int c) {
     Geo g;
     g.nf = c / 4;
@@ -553,4 +651,67 @@ extern "C" int doda_bn_relu_bwd_add(const void *x, const void *dy, int32_t m, in
                             ws_bytes, add, as_stream(stream));
     return run_bwd<BF16>(x, dy, m, c, save_mean, save_invstd, gamma, beta, relu, dx, dgamma, dbeta, ws,
                          ws_bytes, add, as_stream(stream));
+}
+
+// ---- BatchNorm(+ReLU) over statistics that a conv epilogue accumulated ------------------------------
+template <class T>
+static int run_fwd_stats(const void *x_, int m, int c, const float *stats, int rows, float eps, float momentum,
+                         const float *gamma, const float *beta, float *rm, float *rv, long long *nbt, int relu,
+                         void *y_, float *mean, float *invstd, hipStream_t s) {
+    typedef typename T::elem elem;
+    const Geo g = make_geo(c);
+    hipLaunchKernelGGL(bn_fwd_final_stats, dim3(c / 4), dim3(BN_BLOCK), 0, s, stats, rows, m, c, eps, momentum, mean,
+                       invstd, rm, rv, nbt);
+    const long long n_frag = (long long)m * g.nf;
+    const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
+    hipLaunchKernelGGL((bn_apply<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, n_frag, g.nf, mean, invstd,
+                       gamma, beta, relu, (elem *)y_);
+    return doda_check_launch();
+}
+
+template <class T>
+static int run_bwd_stats(const void *x_, const void *dy_, int m, int c, const float *stats, int rows,
+                         const float *mean, const float *invstd, const float *gamma, const float *beta, int relu,
+                         const void *add_, void *dx_, float *dgamma, float *dbeta, float *coef, hipStream_t s) {
+    typedef typename T::elem elem;
+    const Geo g = make_geo(c);
+    hipLaunchKernelGGL(bn_bwd_final_stats, dim3(c / 4), dim3(BN_BLOCK), 0, s, stats, rows, m, c, invstd, gamma, dgamma,
+                       dbeta, coef);
+    const long long n_frag = (long long)m * g.nf;
+    const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
+    hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, (const elem *)dy_, n_frag,
+                       g.nf, c, mean, invstd, gamma, beta, relu, coef, (elem *)dx_, (const elem *)add_);
+    return doda_check_launch();
+}
+
+extern "C" int doda_bn_relu_fwd_stats(const void *x, int32_t m, int32_t c, int32_t elem_bytes, const float *stats,
+                                      int32_t stats_rows, float eps, float momentum, const float *gamma,
+                                      const float *beta, float *running_mean, float *running_var,
+                                      int64_t *num_batches_tracked, int32_t relu, void *y, float *save_mean,
+                                      float *save_invstd, doda_stream_t stream) {
+    if (m == 0) return DODA_OK;
+    if (bn_args_bad(m, c, elem_bytes)) return DODA_ERR_UNSUPPORTED;
+    if (!x || !y || !stats || stats_rows <= 0 || !gamma || !beta || !save_mean || !save_invstd) return DODA_ERR_INVALID;
+    if (elem_bytes == 4)
+        return run_fwd_stats<F32>(x, m, c, stats, stats_rows, eps, momentum, gamma, beta, running_mean, running_var,
+                                  (long long *)num_batches_tracked, relu, y, save_mean, save_invstd, as_stream(stream));
+    return run_fwd_stats<BF16>(x, m, c, stats, stats_rows, eps, momentum, gamma, beta, running_mean, running_var,
+                               (long long *)num_batches_tracked, relu, y, save_mean, save_invstd, as_stream(stream));
+}
+
+extern "C" int doda_bn_relu_bwd_stats(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
+                                      const float *stats, int32_t stats_rows, const float *save_mean,
+                                      const float *save_invstd, const float *gamma, const float *beta, int32_t relu,
+                                      const void *add, void *dx, float *dgamma, float *dbeta, float *coef_ws,
+                                      doda_stream_t stream) {
+    if (m == 0) return DODA_OK;
+    if (bn_args_bad(m, c, elem_bytes)) return DODA_ERR_UNSUPPORTED;
+    if (!x || !dy || !dx || !stats || stats_rows <= 0 || !gamma || !beta || !save_mean || !save_invstd || !dgamma ||
+        !dbeta || !coef_ws)
+        return DODA_ERR_INVALID;
+    if (elem_bytes == 4)
+        return run_bwd_stats<F32>(x, dy, m, c, stats, stats_rows, save_mean, save_invstd, gamma, beta, relu, add, dx,
+                                  dgamma, dbeta, coef_ws, as_stream(stream));
+    return run_bwd_stats<BF16>(x, dy, m, c, stats, stats_rows, save_mean, save_invstd, gamma, beta, relu, add, dx,
+                               dgamma, dbeta, coef_ws, as_stream(stream));
 }

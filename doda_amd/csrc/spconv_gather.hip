@@ -470,11 +470,42 @@ __device__ __forceinline__ void touch(R &r) {
     asm volatile("" : "+v"(r));
 }
 
+// BatchNorm statistics riding in the store epilogue (reference model/unet_block.py:
+// 23-30,46-49,67-79: every conv sits between two BatchNorm1d+ReLU pairs).  Per workgroup row tile p:
+//   forward call  : stats[p][0][c] = sum_t y[t,c],   stats[p][1][c] = sum_t y[t,c]^2     (BN after the conv)
+//   data-grad call: stats[p][0][c] = sum_t dz[t,c],  stats[p][1][c] = sum_t dz[t,c] * xhat[t,c]
+//                   with dz = y * [gamma*xhat + beta > 0] (when bn_relu), xhat = (bn_x - mean) * invstd:
+//                   the two sums the backward of the BN(+ReLU) BEFORE the conv needs over dy = y.
+// y is taken as stored (after its bf16 rounding), so a standalone pass over the stored tensor would see
+// the same values.  One writer per (p, c), fixed summation order: deterministic.
+struct EpiArgs {
+    float *stats;            // [n_part][2][nc] or null
+    const void *bn_x;        // [n_out, nc] in the dtype of y, or null (forward statistics)
+    const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;   // [nc] each
+    int bn_relu;
+};
+
+__device__ __forceinline__ float bf16_rounded(float f) {
+    return __uint_as_float((unsigned)f2bf(f) << 16);
+}
+
 // SPLIT (few rows, S = NBW = 1): the block's four waves share ONE 16-row tile and one channel
 // block; each takes every fourth active offset and the four partial accumulators are summed in a
 // fixed order through LDS.  At the coarse U-Net levels a wave otherwise walks 80-190 units in
 // series (27 offsets x 3..7 chunks, ~70 ns each) while the chip is nearly empty.
-template <class P, int NBW, int S, int D, bool OUT32, bool SPLIT = false>
+// inclusive prefix sum along the 16 lanes of a DPP row (row_shr with zero fill): lane 15 ends up with
+// the row's total.  Plain VALU adds in a fixed order — no LDS traffic, deterministic.
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true));
+    return v;
+}
+
+// STATS: the BatchNorm-statistics epilogue is a compile-time variant, so the plain kernels keep their
+// register allocation and instruction stream.
+template <class P, int NBW, int S, int D, bool OUT32, bool SPLIT = false, bool STATS = false>
 __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restrict__ x,
                                                  unsigned x_bytes, int kc,
                                                  const void *__restrict__ wp,
@@ -482,7 +513,7 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                                                  const int32_t *__restrict__ tbl,
                                                  unsigned tbl_bytes, int ld, int K, int n_out,
                                                  void *__restrict__ y, unsigned y_bytes,
-                                                 const void *__restrict__ res) {
+                                                 const void *__restrict__ res, const EpiArgs ep) {
     typedef typename P::elem elem;
     typedef typename P::raw raw;
     constexpr unsigned OSZ = OUT32 ? 4u : (unsigned)sizeof(elem);   // output element size
@@ -686,13 +717,20 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                     for (int q = 0; q < 4; ++q) acc[s][nb][q] += p[q];
                 }
     }
-    // lane (row = lane&15, g) holds channels 4g..4g+3 of each 16-channel block: one wide store
+    // lane (row = lane&15, g) holds channels 4g..4g+3 of each 16-channel block: one wide store.
+    // Channel block outermost: the statistics of one block (8 registers) are reduced and parked in LDS
+    // before the next block starts, and the scheduling barrier keeps hipcc from interleaving the blocks
+    // (with all blocks in flight the epilogue needed more registers than the gather loop and cost
+    // occupancy: 46 -> 92 VGPRs on the 48-channel tile).
+    __shared__ f32x4 sred[STATS ? (SPLIT ? 1 : 4) : 1][STATS ? NBW : 1][2][4];
+    const int part = item / n_nbg;   // the workgroup's row tile
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const unsigned t = (unsigned)(row0 + s * 16 + i);
+    for (int nb = 0; nb < NBW; ++nb) {
+        const unsigned col = (unsigned)((nb0 + nb) * 16 + 4 * g);
+        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-            const unsigned col = (unsigned)((nb0 + nb) * 16 + 4 * g);
+        for (int s = 0; s < S; ++s) {
+            const unsigned t = (unsigned)(row0 + s * 16 + i);
             const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * (unsigned)nc + col) * OSZ : OOB;
             if (res) {   // y = conv + res (residual add of the block fused into the store; res has y's dtype)
                 const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, y_bytes, 0x00020000);
@@ -708,7 +746,68 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                     acc[s][nb][3] += __uint_as_float(r2[1] & 0xffff0000u);
                 }
             }
+            if constexpr (STATS) {
+                // rows past n_out / channels past nc carry zeros (their loads were out of range)
+                f32x4 v = acc[s][nb];
+                if (!(OUT32 || sizeof(elem) == 4)) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = bf16_rounded(v[q]);
+                }
+                if (ep.bn_x) {
+                    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)ep.bn_x, 0, y_bytes, 0x00020000);
+                    f32x4 xr;
+                    if (OUT32 || sizeof(elem) == 4) {
+                        xr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff, 0, 0));
+                    } else {
+                        const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rs_x, voff, 0, 0);
+                        xr = (f32x4){__uint_as_float(r2[0] << 16), __uint_as_float(r2[0] & 0xffff0000u),
+                                     __uint_as_float(r2[1] << 16), __uint_as_float(r2[1] & 0xffff0000u)};
+                    }
+                    const unsigned cc = col < (unsigned)nc ? col : 0u;
+                    const f32x4 mu = *reinterpret_cast<const f32x4 *>(ep.bn_mean + cc);
+                    const f32x4 is = *reinterpret_cast<const f32x4 *>(ep.bn_invstd + cc);
+                    const f32x4 xh = (xr - mu) * is;
+                    if (ep.bn_relu) {
+                        const f32x4 ga = *reinterpret_cast<const f32x4 *>(ep.bn_gamma + cc);
+                        const f32x4 be = *reinterpret_cast<const f32x4 *>(ep.bn_beta + cc);
+                        const f32x4 yv = xh * ga + be;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = yv[q] > 0.f ? v[q] : 0.f;
+                    }
+                    st1 += v;
+                    st2 += v * xh;
+                } else {
+                    st1 += v;
+                    st2 += v * v;
+                }
+            }
             store_frag<P, OUT32>(acc[s][nb], rs_y, voff);
+        }
+        if constexpr (STATS) {
+            // sum over the 16 rows of the lane group: lane 15 of each group holds the total
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { st1[q] = row_sum16(st1[q]); st2[q] = row_sum16(st2[q]); }
+            if (i == 15) { sred[SPLIT ? 0 : wid][nb][0][g] = st1; sred[SPLIT ? 0 : wid][nb][1][g] = st2; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if constexpr (STATS) {
+        if constexpr (!SPLIT) __syncthreads();   // the four waves hold four row ranges of the tile
+        if (wid == 0 && i == 15) {
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                const int col = (nb0 + nb) * 16 + 4 * g;
+                if (col < nc) {   // (nc % 4 == 0 on this path)
+                    f32x4 a1 = sred[0][nb][0][g], a2 = sred[0][nb][1][g];
+                    if constexpr (!SPLIT) {
+                        a1 = (a1 + sred[1][nb][0][g]) + (sred[2][nb][0][g] + sred[3][nb][0][g]);
+                        a2 = (a2 + sred[1][nb][1][g]) + (sred[2][nb][1][g] + sred[3][nb][1][g]);
+                    }
+                    float *dst = ep.stats + (long long)part * 2 * nc + col;
+                    *reinterpret_cast<f32x4 *>(dst) = a1;
+                    *reinterpret_cast<f32x4 *>(dst + nc) = a2;
+                }
+            }
         }
     }
 }
@@ -716,8 +815,9 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
 template <class P, int NBW, int S, bool SPLIT = false>
 int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_bytes, int nc, int NB,
                 const int32_t *tbl, int ld, int K, int n_out, long long n_in, void *y, bool out32,
-                const void *res, hipStream_t s) {
+                const void *res, const EpiArgs &ep, int *n_part, hipStream_t s) {
     const dim3 grid(div_up(n_out, (SPLIT ? 1 : 4) * 16 * S) * div_up(NB, NBW)), block(256);
+    if (n_part) *n_part = div_up(n_out, (SPLIT ? 1 : 4) * 16 * S);
     // Ring depth.  Re-measured after the EXEC-masked gathers and the wide / pair units went in: with
     // every load hitting L1 (ablation) the kernel time did not move, i.e. the unit loop is paced by
     // instruction issue and by how many waves a SIMD can interleave, not by memory latency.  Depth 8
@@ -727,12 +827,20 @@ int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_byt
     const unsigned tb = (unsigned)((size_t)K * ld * 4);
     if (out32 && sizeof(typename P::elem) != 4) {
         const unsigned yb = (unsigned)((size_t)n_out * nc * 4);
-        hipLaunchKernelGGL((conv_fast<P, NBW, S, D, true, SPLIT>), grid, block, 0, s, x, xb, kc, wp,
-                           (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res);
+        if (ep.stats)
+            hipLaunchKernelGGL((conv_fast<P, NBW, S, D, true, SPLIT, true>), grid, block, 0, s, x, xb, kc, wp,
+                               (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep);
+        else
+            hipLaunchKernelGGL((conv_fast<P, NBW, S, D, true, SPLIT, false>), grid, block, 0, s, x, xb, kc, wp,
+                               (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep);
     } else {
         const unsigned yb = (unsigned)((size_t)n_out * nc * sizeof(typename P::elem));
-        hipLaunchKernelGGL((conv_fast<P, NBW, S, D, false, SPLIT>), grid, block, 0, s, x, xb, kc, wp,
-                           (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res);
+        if (ep.stats)
+            hipLaunchKernelGGL((conv_fast<P, NBW, S, D, false, SPLIT, true>), grid, block, 0, s, x, xb, kc, wp,
+                               (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep);
+        else
+            hipLaunchKernelGGL((conv_fast<P, NBW, S, D, false, SPLIT, false>), grid, block, 0, s, x, xb, kc, wp,
+                               (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep);
     }
     return doda_check_launch();
 }
@@ -762,7 +870,9 @@ inline int pack_mode(int K, int kc, int elem_bytes) {
 template <class T>
 int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tbl, int ld, int K,
                int n_out, void *y_, int wl, void *ws, size_t ws_bytes, long long n_in, bool out32,
-               const void *res, hipStream_t s) {
+               const void *res, hipStream_t s,
+               const EpiArgs &ep = EpiArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
+               int *n_part = nullptr) {
     typedef typename T::elem elem;
     typedef typename T::frag frag;
     const elem *x = (const elem *)x_;
@@ -777,6 +887,7 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
                       ((uintptr_t)y % 16 == 0) && ((size_t)n_out * nc * 4 < 0x7fffffffull) &&
                       ((size_t)K * ld * 4 < 0xffffffffull) && x_rows_bytes_ok;
     if (out32 && sizeof(elem) != 4 && !fast) return DODA_ERR_UNSUPPORTED;
+    if (ep.stats && !fast) return DODA_ERR_UNSUPPORTED;   // the statistics ride in the fast kernel's epilogue only
     const int mode = pack_mode(K, kc, (int)sizeof(elem));
     const bool wide = fast && mode == 0x10, pair = fast && mode == 0x20;
     const int n_chunk = wide ? (kc + 31) / 32 : (kc + 15) / 16;
@@ -805,9 +916,9 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     typedef typename FastPolicy<T>::pair PP;
 #define GO(NBW, S)                                                                                 \
     do {                                                                                           \
-        if (wide) return launch_fast<PW, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, s); \
-        if (pair) return launch_fast<PP, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, s); \
-        if (fast) return launch_fast<PN, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, s); \
+        if (wide) return launch_fast<PW, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, ep, n_part, s); \
+        if (pair) return launch_fast<PP, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, ep, n_part, s); \
+        if (fast) return launch_fast<PN, NBW, S>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, ep, n_part, s); \
         return launch<T, NBW, S>(x, kc, (const frag *)wp, nc, NB, tbl, ld, K, n_out, y, vec_ok, (const elem *)res, s); \
     } while (0)
     {   // few rows, long unit chains: split the offsets of a 16-row tile over the block's waves
@@ -815,9 +926,9 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
         // 16.0 -> 6.3 us; 2808 blocks (level 4) 18.0 -> 24.7 us, so only below ~1k blocks
 #define GS(NBW, S)                                                                                 \
     do {                                                                                           \
-        if (wide) return launch_fast<PW, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, s); \
-        if (pair) return launch_fast<PP, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, s); \
-        return launch_fast<PN, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, s); \
+        if (wide) return launch_fast<PW, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, ep, n_part, s); \
+        if (pair) return launch_fast<PP, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, ep, n_part, s); \
+        return launch_fast<PN, NBW, S, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, ep, n_part, s); \
     } while (0)
         // (two channel blocks / 32-row tiles per split block were tried at level 4: 14.2 us against
         // 13.0 us for the unsplit <4,1> tile, so the split stays at one block, 16 rows)
@@ -953,4 +1064,44 @@ extern "C" int doda_spconv_gather_add_bf16(const uint16_t *x, int32_t n_in, int3
     if (!res) return DODA_ERR_INVALID;
     return run_gather<BF16>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, y_is_f32 != 0,
                             res, as_stream(stream));
+}
+
+// ---- gather with epilogue options (residual add, BatchNorm statistics) ------------------------------
+extern "C" size_t doda_spconv_stats_capacity(int32_t n_out) { return n_out > 0 ? (size_t)div_up(n_out, 16) : 1; }
+
+extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, int32_t elem_bytes, const float *w,
+                                     int32_t nc, const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, void *y,
+                                     int32_t y_is_f32, int32_t w_layout, void *ws, size_t ws_bytes,
+                                     const doda_conv_epilogue *epi, doda_stream_t stream) {
+    int st;
+    if (elem_bytes != 2 && elem_bytes != 4) return DODA_ERR_INVALID;
+    if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) {
+        if (st == DODA_OK && epi && epi->stats_rows_h) *epi->stats_rows_h = 0;
+        return st;
+    }
+    EpiArgs ep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    const void *res = nullptr;
+    int n_part = 0;
+    if (epi) {
+        res = epi->residual;
+        if (epi->stats) {
+            if (!epi->stats_rows_h) return DODA_ERR_INVALID;
+            ep.stats = epi->stats;
+            if (epi->bn_x) {
+                if (!epi->bn_mean || !epi->bn_invstd || !epi->bn_gamma || !epi->bn_beta) return DODA_ERR_INVALID;
+                ep.bn_x = epi->bn_x;
+                ep.bn_mean = epi->bn_mean; ep.bn_invstd = epi->bn_invstd;
+                ep.bn_gamma = epi->bn_gamma; ep.bn_beta = epi->bn_beta;
+                ep.bn_relu = epi->bn_relu;
+            }
+        }
+    }
+    if (elem_bytes == 4)
+        st = run_gather<F32>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, false, res,
+                             as_stream(stream), ep, &n_part);
+    else
+        st = run_gather<BF16>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, y_is_f32 != 0, res,
+                              as_stream(stream), ep, &n_part);
+    if (st == DODA_OK && epi && epi->stats_rows_h) *epi->stats_rows_h = n_part;
+    return st;
 }

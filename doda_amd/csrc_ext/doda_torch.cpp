@@ -40,10 +40,20 @@ inline int elem_bytes(const at::Tensor &t) {
     return 2;
 }
 
-// y[t] = sum_o x[tbl[o][t]] . B_o   (include/doda_hip.h: doda_spconv_gather_*)
+// BatchNorm statistics that ride in a conv epilogue (doda_spconv_gather_ex).  Forward: `want` asks for
+// (sum y, sum y^2) of the output; data-grad: bn_* describe the BatchNorm(+ReLU) in FRONT of the conv and
+// the sums are (sum dz, sum dz*xhat).  On return `stats` is [rows, 2, nc] or undefined (generic kernel).
+struct GatherEpi {
+    bool want = false;
+    at::Tensor bn_x, bn_mean, bn_invstd, bn_gamma, bn_beta;
+    bool bn_relu = false;
+    at::Tensor stats;
+};
+
+// y[t] = sum_o x[tbl[o][t]] . B_o   (include/doda_hip.h: doda_spconv_gather_ex)
 at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
                   const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32,
-                  const c10::optional<at::Tensor> &residual = c10::nullopt) {
+                  const c10::optional<at::Tensor> &residual = c10::nullopt, GatherEpi *epi = nullptr) {
     const at::Tensor x = x_in.contiguous();
     TORCH_CHECK(x.is_cuda() && x.dim() == 2 && tbl.is_cuda() && tbl.dim() == 2, "doda gather: bad inputs");
     const int esz = elem_bytes(x);
@@ -51,11 +61,32 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
     void *st = stream_of(x);
     const bool f32_out = esz == 4 || out_f32;
     at::Tensor y = at::empty({n_out, nc}, x.options().dtype(f32_out ? at::kFloat : at::kBFloat16));
-    at::Tensor res;   // y = conv + res (doda_spconv_gather_add_*)
+    at::Tensor res;   // y = conv + res
     if (residual.has_value() && residual->defined()) {
         res = residual->contiguous();
         TORCH_CHECK(res.is_cuda() && res.scalar_type() == y.scalar_type() && res.dim() == 2 &&
                     res.size(0) == n_out && res.size(1) == nc, "doda gather: residual must be [n_out, nc] in the output dtype");
+    }
+    doda_conv_epilogue ep;
+    memset(&ep, 0, sizeof(ep));
+    int32_t stats_rows = 0;
+    at::Tensor stats;
+    ep.residual = res.defined() ? res.data_ptr() : nullptr;
+    bool with_stats = epi && epi->want && n_out > 0;
+    if (with_stats) {
+        stats = at::empty({(int64_t)doda_spconv_stats_capacity((int32_t)n_out), 2, nc}, x.options().dtype(at::kFloat));
+        ep.stats = (float *)stats.data_ptr();
+        ep.stats_rows_h = &stats_rows;
+        if (epi->bn_x.defined()) {
+            TORCH_CHECK(epi->bn_x.scalar_type() == y.scalar_type() && epi->bn_x.is_contiguous() &&
+                        epi->bn_x.size(0) == n_out && epi->bn_x.size(1) == nc, "doda gather: bn_x must match the output");
+            ep.bn_x = epi->bn_x.data_ptr();
+            ep.bn_mean = (const float *)epi->bn_mean.data_ptr();
+            ep.bn_invstd = (const float *)epi->bn_invstd.data_ptr();
+            ep.bn_gamma = (const float *)epi->bn_gamma.data_ptr();
+            ep.bn_beta = (const float *)epi->bn_beta.data_ptr();
+            ep.bn_relu = epi->bn_relu ? 1 : 0;
+        }
     }
     const void *wptr;
     void *ws = nullptr;
@@ -63,7 +94,7 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
     at::Tensor ws_t, wc;
     int lay = (int)layout;
     bool use_packed = packed.has_value() && packed->defined();
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         if (use_packed) {
             wptr = packed->data_ptr();
             lay = (int)layout | 0x100;
@@ -76,32 +107,25 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
             ws = ws_t.data_ptr();
             lay = (int)layout;
         }
-        int status;
-        if (esz == 4 && !res.defined())
-            status = doda_spconv_gather_f32((const float *)x.data_ptr(), (int)x.size(0), (int)kc, (const float *)wptr,
-                                            (int)nc, (const int32_t *)tbl.data_ptr(), (int)ld, (int)K, (int)n_out,
-                                            (float *)y.data_ptr(), lay, ws, ws_bytes, st);
-        else if (esz == 4)
-            status = doda_spconv_gather_add_f32((const float *)x.data_ptr(), (int)x.size(0), (int)kc,
-                                                (const float *)wptr, (int)nc, (const int32_t *)tbl.data_ptr(), (int)ld,
-                                                (int)K, (int)n_out, (const float *)res.data_ptr(),
-                                                (float *)y.data_ptr(), lay, ws, ws_bytes, st);
-        else if (!res.defined())
-            status = doda_spconv_gather_bf16((const uint16_t *)x.data_ptr(), (int)x.size(0), (int)kc,
-                                             (const float *)wptr, (int)nc, (const int32_t *)tbl.data_ptr(), (int)ld,
-                                             (int)K, (int)n_out, y.data_ptr(), out_f32 ? 1 : 0, lay, ws, ws_bytes, st);
-        else
-            status = doda_spconv_gather_add_bf16((const uint16_t *)x.data_ptr(), (int)x.size(0), (int)kc,
-                                                 (const float *)wptr, (int)nc, (const int32_t *)tbl.data_ptr(), (int)ld,
-                                                 (int)K, (int)n_out, res.data_ptr(), y.data_ptr(), out_f32 ? 1 : 0,
-                                                 lay, ws, ws_bytes, st);
+        const int status = doda_spconv_gather_ex(x.data_ptr(), (int)x.size(0), (int)kc, esz, (const float *)wptr,
+                                                 (int)nc, (const int32_t *)tbl.data_ptr(), (int)ld, (int)K, (int)n_out,
+                                                 y.data_ptr(), out_f32 ? 1 : 0, lay, ws, ws_bytes, &ep, st);
         if (status == DODA_ERR_UNSUPPORTED && use_packed) {  // fast path refused the pre-packed weights
             use_packed = false;
+            continue;
+        }
+        if (status == DODA_ERR_UNSUPPORTED && with_stats) {  // generic kernel: no statistics in its epilogue
+            with_stats = false;
+            ep.stats = nullptr;
+            ep.stats_rows_h = nullptr;
+            ep.bn_x = nullptr;
+            use_packed = packed.has_value() && packed->defined();
             continue;
         }
         check(status, "doda_spconv_gather");
         break;
     }
+    if (epi) epi->stats = (with_stats && stats_rows > 0) ? stats.narrow(0, 0, stats_rows) : at::Tensor();
     return y;
 }
 
@@ -191,8 +215,9 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> export_pairs(const at::Tensor &tb
 // for the pair-list weight gradient — on the same (side) stream, off the critical path.
 typedef std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, std::vector<int64_t>, at::Tensor, at::Tensor,
                    at::Tensor, at::Tensor, at::Tensor, at::Tensor> PyramidLevel;
+// pairs_min_rows < 0: no lists; else lists for rulebooks of at least that many rows.
 std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vector<int64_t> shape, int64_t batch,
-                                        int64_t n_levels, bool with_pairs) {
+                                        int64_t n_levels, int64_t pairs_min_rows) {
     TORCH_CHECK(indices_in.is_cuda() && indices_in.scalar_type() == at::kInt && indices_in.dim() == 2 &&
                 indices_in.size(1) == 4 && shape.size() == 3, "doda build_pyramid: indices must be int32 [M,4] on the GPU");
     std::vector<PyramidLevel> out;
@@ -209,6 +234,7 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
                                  (int32_t *)nbr.data_ptr(), m, ws.data_ptr(), (size_t)ws.numel(), st),
               "doda_rulebook_subm");
         at::Tensor sp, sn, sh, dp, dn, dh;
+        const bool with_pairs = pairs_min_rows >= 0 && m >= pairs_min_rows;
         if (with_pairs) std::tie(sp, sn, sh) = export_pairs(nbr, m, true, st);
         if (lvl == n_levels - 1) {
             out.emplace_back(nbr, at::Tensor(), at::Tensor(), at::Tensor(), std::vector<int64_t>(), sp, sn, sh, dp, dn, dh);
@@ -361,6 +387,26 @@ bool try_defer_wgrad(const at::Tensor &features, const at::Tensor &dy, const at:
 using torch::autograd::SavedVariable;
 using torch::autograd::variable_list;
 
+// Link between a fused BatchNorm(+ReLU) and the convolution that consumes its output (the BN -> ReLU ->
+// conv triple of reference model/unet_block.py:23-30,46-49,67-79).  In backward the conv's data-grad
+// kernel produces dz = d loss / d (BN output); the two sums the BatchNorm backward needs over dz
+// (sum dz*mask, sum dz*mask*xhat) are accumulated in that kernel's store epilogue, and the BatchNorm node
+// then runs final + apply only.  The link is made when the conv's input IS the tensor the BatchNorm just
+// returned (same TensorImpl, still alive); the BatchNorm node uses the statistics only if the gradient it
+// receives IS the tensor the conv produced — had the BN output a second consumer, autograd would hand
+// over a sum (a different tensor) and the node falls back to its own statistics pass.
+struct BNLink {
+    at::Tensor x, mean, invstd, gamma, beta;   // the BatchNorm's input and per-channel tensors
+    bool relu = false;
+    c10::weak_intrusive_ptr<c10::TensorImpl> y;   // the BatchNorm's output
+    at::Tensor stats;                             // [rows, 2, c] from the conv's data-grad epilogue
+    c10::TensorImpl *dz = nullptr;                // the gradient tensor those statistics belong to
+    BNLink() : y(c10::weak_intrusive_ptr<c10::TensorImpl>(c10::intrusive_ptr<c10::TensorImpl>())) {}
+};
+thread_local std::shared_ptr<BNLink> g_last_bn;
+bool g_bn_fusion = true;
+constexpr int64_t BN_SMALL_ROWS = 4096;   // below: the one-launch BatchNorm kernels win (csrc/bn.hip)
+
 // features, weight [k,k,k,Cin,Cout], fwd_tbl, bwd_tbl, n_out, bwd_layout, packed fwd / data-grad,
 // optional residual (y = conv + residual; its gradient is the incoming gradient itself).
 // Gradient edges: 0 features, 1 weight, 2 residual.
@@ -368,6 +414,7 @@ struct ConvNode : public torch::autograd::Node {
     SavedVariable features_, weight_;
     at::Tensor fwd_tbl, bwd_tbl, pk_bwd;
     PairLists pl;
+    std::shared_ptr<BNLink> bn;   // the BatchNorm in front of this conv, if linked
     int64_t n_out = 0, bwd_layout = 0;
 
     variable_list apply(variable_list &&grads) override {
@@ -376,10 +423,22 @@ struct ConvNode : public torch::autograd::Node {
         variable_list out(3);
         if (!grads[0].defined()) return out;
         const at::Tensor dy = grads[0].contiguous();  // reference fork patch llijiang/spconv@740a5b7
-        if (task_should_compute_output(0))
+        if (task_should_compute_output(0)) {
+            GatherEpi epi;
+            if (bn && bn->x.defined() && bn->x.scalar_type() == dy.scalar_type() && bn->x.size(0) == features.size(0) &&
+                bn->x.size(1) == cin) {
+                epi.want = true;
+                epi.bn_x = bn->x; epi.bn_mean = bn->mean; epi.bn_invstd = bn->invstd;
+                epi.bn_gamma = bn->gamma; epi.bn_beta = bn->beta; epi.bn_relu = bn->relu;
+            }
             out[0] = gather(dy, weight.reshape({K, cin, cout}),
                             pk_bwd.defined() ? c10::optional<at::Tensor>(pk_bwd) : c10::nullopt, bwd_tbl,
-                            features.size(0), bwd_layout, cin, false);
+                            features.size(0), bwd_layout, cin, false, c10::nullopt, &epi);
+            if (epi.stats.defined()) {
+                bn->stats = epi.stats;
+                bn->dz = out[0].unsafeGetTensorImpl();
+            }
+        }
         if (task_should_compute_output(1) && !try_defer_wgrad(features, dy, fwd_tbl, n_out, weight, pl))
             out[1] = wgrad(features, dy, fwd_tbl, n_out, pl).reshape(weight.sizes()).to(weight.scalar_type());
         if (task_should_compute_output(2)) out[2] = grads[0];
@@ -392,27 +451,41 @@ struct ConvNode : public torch::autograd::Node {
         bwd_tbl.reset();
         pk_bwd.reset();
         pl = PairLists();
+        bn.reset();
     }
     std::string name() const override { return "DodaIndiceConvBackward"; }
 };
 
-at::Tensor indice_conv(const at::Tensor &features, const at::Tensor &weight, const at::Tensor &fwd_tbl,
+// want_stats: also return the (sum y, sum y^2) partials of the output for a BatchNorm that follows
+// ([rows, 2, Cout]; undefined when the generic kernel ran).
+std::vector<at::Tensor> indice_conv_impl(const at::Tensor &features, const at::Tensor &weight, const at::Tensor &fwd_tbl,
                        const at::Tensor &bwd_tbl, int64_t n_out, int64_t bwd_layout,
                        const c10::optional<at::Tensor> &pk_fwd, const c10::optional<at::Tensor> &pk_bwd,
                        const c10::optional<at::Tensor> &residual, const c10::optional<at::Tensor> &pair_in,
                        const c10::optional<at::Tensor> &pair_out, const c10::optional<at::Tensor> &pair_num,
-                       const c10::optional<at::Tensor> &pair_seg) {
+                       const c10::optional<at::Tensor> &pair_seg, bool want_stats) {
     const at::Tensor res = residual.has_value() ? *residual : at::Tensor();
     const bool need_grad = at::GradMode::is_enabled() &&
                            (features.requires_grad() || weight.requires_grad() || (res.defined() && res.requires_grad()));
     const int64_t cin = weight.size(-2), cout = weight.size(-1), K = fwd_tbl.size(0);
     at::Tensor y;
+    GatherEpi epi;
+    epi.want = want_stats;
     {
         at::AutoDispatchBelowADInplaceOrView guard;
-        y = gather(features, weight.reshape({K, cin, cout}), pk_fwd, fwd_tbl, n_out, 0, cout, false, residual);
+        y = gather(features, weight.reshape({K, cin, cout}), pk_fwd, fwd_tbl, n_out, 0, cout, false, residual, &epi);
+    }
+    // the BatchNorm that produced `features` (if it was the last fused BatchNorm and its output is this tensor)
+    std::shared_ptr<BNLink> link;
+    if (g_last_bn) {
+        auto alive = g_last_bn->y.lock();
+        if (g_bn_fusion && alive && alive.get() == features.unsafeGetTensorImpl() && features.size(0) > BN_SMALL_ROWS)
+            link = g_last_bn;
+        g_last_bn.reset();
     }
     if (need_grad) {
         auto node = std::shared_ptr<ConvNode>(new ConvNode(), torch::autograd::deleteNode);
+        node->bn = link;
         node->set_next_edges(torch::autograd::collect_next_edges(features, weight, res));
         node->features_ = SavedVariable(features, false);
         node->weight_ = SavedVariable(weight, false);
@@ -438,7 +511,17 @@ at::Tensor indice_conv(const at::Tensor &features, const at::Tensor &weight, con
         }
         torch::autograd::set_history(y, node);
     }
-    return y;
+    return {y, epi.stats};
+}
+
+at::Tensor indice_conv(const at::Tensor &features, const at::Tensor &weight, const at::Tensor &fwd_tbl,
+                       const at::Tensor &bwd_tbl, int64_t n_out, int64_t bwd_layout,
+                       const c10::optional<at::Tensor> &pk_fwd, const c10::optional<at::Tensor> &pk_bwd,
+                       const c10::optional<at::Tensor> &residual, const c10::optional<at::Tensor> &pair_in,
+                       const c10::optional<at::Tensor> &pair_out, const c10::optional<at::Tensor> &pair_num,
+                       const c10::optional<at::Tensor> &pair_seg) {
+    return indice_conv_impl(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd, residual, pair_in,
+                            pair_out, pair_num, pair_seg, false)[0];
 }
 
 // ---- fused BatchNorm1d(+ReLU).  Gradient edges: 0 x, 1 weight, 2 bias. ----------------------------
@@ -448,6 +531,7 @@ at::Tensor indice_conv(const at::Tensor &features, const at::Tensor &weight, con
 struct BNNode : public torch::autograd::Node {
     SavedVariable x_, weight_, bias_;
     at::Tensor mean, invstd;
+    std::shared_ptr<BNLink> link;   // statistics may arrive from the consuming conv's data-grad epilogue
     bool training = true, relu = false;
 
     variable_list apply(variable_list &&grads) override {
@@ -461,7 +545,31 @@ struct BNNode : public torch::autograd::Node {
         }
         const at::Tensor dy = grads[0].contiguous();
         at::Tensor dx, dg, db;
-        if (training && extra.defined() && extra.scalar_type() == x.scalar_type()) {
+        at::Tensor stats;
+        if (link) {
+            if (training && link->stats.defined() && link->dz == grads[0].unsafeGetTensorImpl() && grads[0].is_contiguous() &&
+                (!extra.defined() || extra.scalar_type() == x.scalar_type()))
+                stats = link->stats;
+            link->stats.reset();
+            link->dz = nullptr;
+        }
+        if (stats.defined()) {
+            const int64_t m = x.size(0), c = x.size(1);
+            const at::Tensor add = extra.defined() ? extra.contiguous() : at::Tensor();
+            dx = at::empty_like(x);
+            dg = at::empty({c}, x.options().dtype(at::kFloat));
+            db = at::empty({c}, x.options().dtype(at::kFloat));
+            at::Tensor coef = at::empty({3 * c}, x.options().dtype(at::kFloat));
+            check(doda_bn_relu_bwd_stats(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
+                                         (const float *)stats.data_ptr(), (int)stats.size(0),
+                                         (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(),
+                                         (const float *)weight.data_ptr(), (const float *)bias.data_ptr(), relu ? 1 : 0,
+                                         add.defined() ? add.data_ptr() : nullptr, dx.data_ptr(),
+                                         (float *)dg.data_ptr(), (float *)db.data_ptr(), (float *)coef.data_ptr(),
+                                         stream_of(x)),
+                  "doda_bn_relu_bwd_stats");
+            extra = at::Tensor();
+        } else if (training && extra.defined() && extra.scalar_type() == x.scalar_type()) {
             const at::Tensor add = extra.contiguous();
             const int64_t m = x.size(0), c = x.size(1);
             dx = at::empty_like(x);
@@ -509,14 +617,16 @@ struct BNNode : public torch::autograd::Node {
         bias_.reset_data();
         mean.reset();
         invstd.reset();
+        link.reset();
     }
     std::string name() const override { return "DodaBNReLUBackward"; }
 };
 
+// stats: (sum x, sum x^2) partials of x from the epilogue of the conv that produced it, or undefined
 std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &weight, const at::Tensor &bias,
                                      const at::Tensor &running_mean, const at::Tensor &running_var,
                                      const at::Tensor &nbt, bool training, double momentum, double eps,
-                                     bool relu, bool passthrough) {
+                                     bool relu, bool passthrough, const at::Tensor &stats = at::Tensor()) {
     const bool need_grad = at::GradMode::is_enabled() &&
                            (x_in.requires_grad() || weight.requires_grad() || bias.requires_grad());
     at::Tensor x, y, mean, invstd, xp;
@@ -534,6 +644,16 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
             mean = running_mean.to(at::kFloat).contiguous();
             invstd = at::rsqrt(running_var.to(at::kFloat) + eps).contiguous();
         }
+        if (training && stats.defined() && m > BN_SMALL_ROWS && stats.dim() == 3 && stats.size(2) == c &&
+            stats.scalar_type() == at::kFloat && stats.is_contiguous()) {
+            check(doda_bn_relu_fwd_stats(x.data_ptr(), (int)m, (int)c, esz, (const float *)stats.data_ptr(),
+                                         (int)stats.size(0), (float)eps, (float)momentum,
+                                         (const float *)weight.data_ptr(), (const float *)bias.data_ptr(),
+                                         (float *)running_mean.data_ptr(), (float *)running_var.data_ptr(),
+                                         nbt.defined() ? (int64_t *)nbt.data_ptr() : nullptr, relu ? 1 : 0, y.data_ptr(),
+                                         (float *)mean.data_ptr(), (float *)invstd.data_ptr(), stream_of(x)),
+                  "doda_bn_relu_fwd_stats");
+        } else {
         const size_t wsb = doda_bn_workspace_bytes((int)m, (int)c);
         at::Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
         check(doda_bn_relu_fwd(x.data_ptr(), (int)m, (int)c, esz, (float)eps, (float)momentum,
@@ -544,9 +664,21 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
                                relu ? 1 : 0, y.data_ptr(), (float *)mean.data_ptr(), (float *)invstd.data_ptr(),
                                ws.data_ptr(), wsb, stream_of(x)),
               "doda_bn_relu_fwd");
+        }
     }
+    g_last_bn.reset();
     if (need_grad) {
         auto node = std::shared_ptr<BNNode>(new BNNode(), torch::autograd::deleteNode);
+        if (training && weight.scalar_type() == at::kFloat && bias.scalar_type() == at::kFloat) {
+            auto link = std::make_shared<BNLink>();
+            link->x = x;
+            link->mean = mean; link->invstd = invstd;
+            link->gamma = weight.detach(); link->beta = bias.detach();
+            link->relu = relu;
+            link->y = c10::weak_intrusive_ptr<c10::TensorImpl>(y.getIntrusivePtr());
+            node->link = link;
+            g_last_bn = link;
+        }
         node->set_next_edges(torch::autograd::collect_next_edges(x_in, weight, bias));
         node->x_ = SavedVariable(x_in.is_contiguous() ? x_in : x, false);
         node->weight_ = SavedVariable(weight, false);
@@ -564,15 +696,18 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
 
 at::Tensor bn_relu(const at::Tensor &x, const at::Tensor &weight, const at::Tensor &bias,
                    const at::Tensor &running_mean, const at::Tensor &running_var, const at::Tensor &nbt,
-                   bool training, double momentum, double eps, bool relu) {
-    return bn_relu_impl(x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, relu, false)[0];
+                   bool training, double momentum, double eps, bool relu, const c10::optional<at::Tensor> &stats) {
+    return bn_relu_impl(x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, relu, false,
+                        stats.has_value() ? *stats : at::Tensor())[0];
 }
 
 // (y, x_alias): use x_alias wherever the block needs x again (its gradient is summed inside this op's backward)
 std::vector<at::Tensor> bn_relu_pass(const at::Tensor &x, const at::Tensor &weight, const at::Tensor &bias,
                                      const at::Tensor &running_mean, const at::Tensor &running_var,
-                                     const at::Tensor &nbt, bool training, double momentum, double eps, bool relu) {
-    return bn_relu_impl(x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, relu, true);
+                                     const at::Tensor &nbt, bool training, double momentum, double eps, bool relu,
+                                     const c10::optional<at::Tensor> &stats) {
+    return bn_relu_impl(x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, relu, true,
+                        stats.has_value() ? *stats : at::Tensor());
 }
 
 }  // namespace
@@ -583,8 +718,28 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("bwd_layout"), py::arg("pk_fwd"), py::arg("pk_bwd"), py::arg("residual"),
           py::arg("pair_in") = py::none(), py::arg("pair_out") = py::none(), py::arg("pair_num") = py::none(),
           py::arg("pair_seg") = py::none());
-    m.def("bn_relu", &bn_relu, "fused BatchNorm1d(+ReLU) with autograd");
-    m.def("bn_relu_pass", &bn_relu_pass, "fused BatchNorm1d(+ReLU) returning (y, alias of x) for residual blocks");
+    m.def("bn_relu", &bn_relu, "fused BatchNorm1d(+ReLU) with autograd", py::arg("x"), py::arg("weight"),
+          py::arg("bias"), py::arg("running_mean"), py::arg("running_var"), py::arg("nbt"), py::arg("training"),
+          py::arg("momentum"), py::arg("eps"), py::arg("relu"), py::arg("stats") = py::none());
+    m.def("bn_relu_pass", &bn_relu_pass, "fused BatchNorm1d(+ReLU) returning (y, alias of x) for residual blocks",
+          py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("running_mean"), py::arg("running_var"),
+          py::arg("nbt"), py::arg("training"), py::arg("momentum"), py::arg("eps"), py::arg("relu"),
+          py::arg("stats") = py::none());
+    m.def("indice_conv_stats", [](const at::Tensor &features, const at::Tensor &weight, const at::Tensor &fwd_tbl,
+                                  const at::Tensor &bwd_tbl, int64_t n_out, int64_t bwd_layout,
+                                  const c10::optional<at::Tensor> &pk_fwd, const c10::optional<at::Tensor> &pk_bwd,
+                                  const c10::optional<at::Tensor> &residual, const c10::optional<at::Tensor> &pair_in,
+                                  const c10::optional<at::Tensor> &pair_out, const c10::optional<at::Tensor> &pair_num,
+                                  const c10::optional<at::Tensor> &pair_seg) {
+        auto r = indice_conv_impl(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd, residual,
+                                  pair_in, pair_out, pair_num, pair_seg, true);
+        return std::make_pair(r[0], r[1].defined() ? c10::optional<at::Tensor>(r[1]) : c10::nullopt);
+    }, "sparse conv that also returns the BatchNorm statistics partials of its output",
+          py::arg("features"), py::arg("weight"), py::arg("fwd_tbl"), py::arg("bwd_tbl"), py::arg("n_out"),
+          py::arg("bwd_layout"), py::arg("pk_fwd"), py::arg("pk_bwd"), py::arg("residual"),
+          py::arg("pair_in") = py::none(), py::arg("pair_out") = py::none(), py::arg("pair_num") = py::none(),
+          py::arg("pair_seg") = py::none());
+    m.def("set_bn_fusion", [](bool on) { g_bn_fusion = on; }, "BatchNorm statistics in the conv epilogues (default on)");
     m.def("gather", [](const at::Tensor &x, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
                        const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32) {
         return gather(x, w, packed, tbl, n_out, layout, nc, out_f32);
@@ -594,7 +749,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     }, "raw weight gradient");
     m.def("build_pyramid", &build_pyramid,
           "all SubM k3 and k2s2 rulebooks of an n-level U-Net in one call (13 native builds, 6 size read-backs)",
-          py::arg("indices"), py::arg("shape"), py::arg("batch"), py::arg("n_levels"), py::arg("with_pairs") = false);
+          py::arg("indices"), py::arg("shape"), py::arg("batch"), py::arg("n_levels"), py::arg("pairs_min_rows") = -1,
+          py::call_guard<py::gil_scoped_release>());   // its size read-backs block: let other Python threads run
     m.def("pending_wgrads", []() { std::lock_guard<std::mutex> lock(g_wq_mu); return (int64_t)g_wq.size(); });
     m.def("set_defer_wgrad", [](bool on) { g_defer_wgrad = on; },
           "queue conv weight gradients during backward and issue them in one multi-layer call at its end");

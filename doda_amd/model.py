@@ -246,11 +246,64 @@ def _prebuild_pyramid(voxel_coords, spatial_shape, batch_size, n_levels, device,
     return idx32, probe.indice_dict
 
 
+class PyramidPrefetcher:
+    """Rulebooks as part of the data pipeline: the 13 rulebooks of batch k+1 are built on a helper thread
+    and a side stream while the main thread issues step k.
+
+    Rulebooks depend only on voxel coordinates — in the reference they are built inside spconv's forward,
+    while its voxelisation already runs ahead of the step in DataLoader workers (dataset/dataset.py:121-187).
+    Built in line, the six size read-backs of a pyramid (one per strided level) block the issuing thread
+    for ~1.2 ms per step (tools/hostprof.py), and the step is paced by host issue time as much as by the
+    GPU.  Here they block the helper thread instead (the extension call releases the GIL); the consumer
+    picks the finished pyramid up with one stream-wait.  Every batch still gets its own rulebooks: nothing
+    is cached across batches."""
+
+    def __init__(self, device, n_levels):
+        from concurrent.futures import ThreadPoolExecutor
+        self.device, self.n_levels = device, n_levels
+        self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="doda-rulebooks")
+        self.stream = torch.cuda.Stream(device=device)
+
+    def submit(self, batch, with_pairs=False):
+        """batch: collated dictionary whose `voxel_locs` is resident on the device with no pending producer."""
+        coords, shape = batch["voxel_locs"], batch["spatial_shape"]
+        bs = batch["offsets"].numel() - 1
+        return self.pool.submit(self._build, coords, shape, bs, with_pairs)
+
+    def _build(self, coords, shape, bs, with_pairs):
+        torch.cuda.set_device(self.device)
+        with torch.cuda.stream(self.stream):
+            idx32 = coords.int()
+            probe = spconv.SparseConvTensor(None, idx32, shape, bs)
+            spconv.ops.build_pyramid(probe, self.n_levels, with_pairs=with_pairs)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return idx32, probe.indice_dict, done
+
+    @staticmethod
+    def take(future, device):
+        """(indices int32, indice_dict) of a submitted batch, handed over to the current stream."""
+        idx32, book, done = future.result()
+        main = torch.cuda.current_stream(device)
+        main.wait_event(done)
+        idx32.record_stream(main)
+        for data in book.values():
+            for t in vars(data).values():
+                for u in (t if isinstance(t, tuple) else (t,)):
+                    if torch.is_tensor(u) and u.is_cuda:
+                        u.record_stream(main)
+        return idx32, book
+
+    def shutdown(self):
+        self.pool.shutdown(wait=True)
+
+
 def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fused_head=True,
-                     inputs_ready=False):
+                     inputs_ready=False, pyramid=None):
     """reference model/unet.py:72-99 (test_model_feat): H2D, voxel mean-pooling, network.
     inputs_ready: the batch is resident on `device` with no copy or kernel still producing it, so the
-    rulebooks may be built on a side stream ahead of the main stream's queue (_prebuild_pyramid)."""
+    rulebooks may be built on a side stream ahead of the main stream's queue (_prebuild_pyramid).
+    pyramid: (indices int32, indice_dict) of this batch from PyramidPrefetcher.take."""
     voxel_coords = batch["voxel_locs"].to(device, non_blocking=True)
     p2v = batch["p2v_map"].to(device, non_blocking=True)
     v2p = batch["v2p_map"].to(device, non_blocking=True)
@@ -260,7 +313,11 @@ def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fus
     voxel_feats = pointgroup_ops.voxelization(feats, v2p, cfg.DATA_CONFIG.DATA_PROCESSOR.voxel_mode)
     batch_size = batch["offsets"].numel() - 1
     net = model.module if hasattr(model, "module") else model
-    if (inputs_ready and batch["voxel_locs"].is_cuda and voxel_coords.shape[0] > 0
+    if pyramid is not None:
+        idx32, book = pyramid
+        inp = spconv.SparseConvTensor(voxel_feats.to(feature_dtype), idx32, batch["spatial_shape"], batch_size)
+        inp.indice_dict.update(book)
+    elif (inputs_ready and batch["voxel_locs"].is_cuda and voxel_coords.shape[0] > 0
             and hasattr(net, "unet") and device.type == "cuda"):
         idx32, pyramid = _prebuild_pyramid(voxel_coords, batch["spatial_shape"], batch_size,
                                            len(net.unet.nPlanes), device,

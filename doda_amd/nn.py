@@ -78,10 +78,12 @@ def fusable(bn, features):
             and not (bn.training and features.shape[0] < 2))
 
 
-def batch_norm_relu(features, bn, relu, passthrough=False):
+def batch_norm_relu(features, bn, relu, passthrough=False, stats=None):
     """BatchNorm1d `bn` (+ReLU when `relu`) on features through the fused HIP kernels.
     passthrough: return (y, x_alias) — x_alias is `features` again, for a skip connection; its gradient
-    is summed inside this op's backward kernel instead of by an autograd accumulation pass."""
+    is summed inside this op's backward kernel instead of by an autograd accumulation pass.
+    stats: (sum x, sum x^2) partials [rows, 2, C] from the epilogue of the conv that produced `features`
+    (doda_spconv_gather_ex): the statistics pass over x is skipped (compiled glue, training mode)."""
     # num_batches_tracked += 1 happens inside the stats kernel (65 one-element add kernels per step
     # otherwise)
     if type(bn) is nn.BatchNorm1d:
@@ -93,9 +95,9 @@ def batch_norm_relu(features, bn, relu, passthrough=False):
         par = bn._parameters
         if passthrough:
             return _ext.bn_relu_pass(features, par["weight"], par["bias"], running_mean, running_var,
-                                     bn._buffers["num_batches_tracked"], bn.training, bn.momentum, bn.eps, relu)
+                                     bn._buffers["num_batches_tracked"], bn.training, bn.momentum, bn.eps, relu, stats)
         return _ext.bn_relu(features, par["weight"], par["bias"], running_mean, running_var,
-                            bn._buffers["num_batches_tracked"], bn.training, bn.momentum, bn.eps, relu)
+                            bn._buffers["num_batches_tracked"], bn.training, bn.momentum, bn.eps, relu, stats)
     if passthrough:
         return _BNReLU.apply(features, bn.weight, bn.bias, running_mean, running_var,
                              bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, relu), features

@@ -113,17 +113,44 @@ class _IndiceConv(Function):
         return d_feat, d_w, None, None, None, None, None, (grad_output if ctx.needs_input_grad[7] else None), None
 
 
-def _conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual=None, pairs=None):
+# BatchNorm statistics in the conv epilogues (needs the compiled glue): a conv that
+# is asked for them returns (y, stats) with stats = [rows, 2, Cout] partial sums of (y, y^2), which the
+# fused BatchNorm that follows turns into mean / invstd without reading y again; in backward the
+# data-grad kernel of a conv whose input came straight out of a fused BatchNorm(+ReLU) accumulates that
+# BatchNorm's backward sums the same way (linked inside the extension).  DODA_BN_FUSION=0 switches both off.
+BN_FUSION = os.environ.get("DODA_BN_FUSION", "1") == "1" and _ext is not None and _SERIAL
+if _ext is not None:
+    _ext.set_bn_fusion(BN_FUSION)
+STATS_MIN_ROWS = 4096   # below: the one-launch BatchNorm kernels win (csrc/bn.hip BN_SMALL_ROWS)
+
+
+def set_bn_fusion(on):
+    global BN_FUSION
+    BN_FUSION = bool(on) and _ext is not None and _SERIAL
+    if _ext is not None:
+        _ext.set_bn_fusion(BN_FUSION)
+    return BN_FUSION
+
+
+def _conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual=None, pairs=None,
+          want_stats=False):
     """residual: optional [n_out, Cout] tensor in the output dtype; returns conv + residual with the
     add fused into the kernel's store (the residual's gradient is the incoming gradient).
-    pairs: (pair_in [K,ld], pair_out [K,ld], pair_num [K] | None) of the rulebook, for the weight gradient."""
+    pairs: (pair_in [K,ld], pair_out [K,ld], pair_num [K] | None) of the rulebook, for the weight gradient.
+    want_stats: return (y, stats | None) instead of y."""
     if _ext is not None and _SERIAL:   # compiled autograd glue (no Python per launch)
         pk_fwd, pk_bwd = packed if packed is not None else (None, None)
+        fn = _ext.indice_conv_stats if (want_stats and BN_FUSION and n_out > STATS_MIN_ROWS) else _ext.indice_conv
         if pairs is None:
-            return _ext.indice_conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd, residual)
-        return _ext.indice_conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd, residual,
-                                pairs[0], pairs[1], pairs[2], pairs[3] if len(pairs) > 3 else None)
-    return _IndiceConv.apply(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual, pairs)
+            out = fn(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd, residual)
+        else:
+            out = fn(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, pk_fwd, pk_bwd, residual,
+                     pairs[0], pairs[1], pairs[2], pairs[3] if len(pairs) > 3 else None)
+        if want_stats:
+            return out if fn is _ext.indice_conv_stats else (out, None)
+        return out
+    y = _IndiceConv.apply(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual, pairs)
+    return (y, None) if want_stats else y
 
 
 # The pair-list weight gradient (doda_spconv_wgrad_pairs_bf16) needs the rulebook's pair lists (exported
@@ -131,34 +158,40 @@ def _conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residua
 WGRAD_PAIRS = os.environ.get("DODA_WGRAD_PAIRS", "1") == "1"
 
 
-def _want_pairs(features, weight):
-    """bf16 operands, 16-multiple channel counts, gradient recording on and a weight that wants one."""
+PAIRS_MIN_ROWS = 65536   # smaller rulebooks stay on the gather-table kernel: the list export (three launches
+#                          per rulebook, issued by a host that is as busy as the GPU) would cost more than it saves
+
+
+def _want_pairs(features, weight, n_rows=None):
+    """bf16 operands, 16-multiple channel counts, gradient recording on, a weight that wants one, and a
+    rulebook large enough for the lists to pay off."""
     return (WGRAD_PAIRS and features.dtype == torch.bfloat16 and weight.requires_grad and torch.is_grad_enabled()
-            and weight.shape[-2] % 16 == 0 and weight.shape[-1] % 16 == 0)
+            and weight.shape[-2] % 16 == 0 and weight.shape[-1] % 16 == 0
+            and (features.shape[0] if n_rows is None else n_rows) >= PAIRS_MIN_ROWS)
 
 
-def conv1x1(features, weight, ident, packed=None):
+def conv1x1(features, weight, ident, packed=None, want_stats=False):
     """SubMConv3d(kernel_size=1) (upstream: features @ W.view(Cin,Cout)) as a K = 1 gather-GEMM over an
     identity table: the library GEMM picked for these skinny shapes ([600k,32] @ [32,16]) runs 5-10x
     slower than the gather kernel on MI355X.  The identity table doubles as both pair lists."""
     pairs = (ident, ident, None) if _want_pairs(features, weight) else None
-    return _conv(features, weight, ident, ident, features.shape[0], 1, packed, None, pairs)
+    return _conv(features, weight, ident, ident, features.shape[0], 1, packed, None, pairs, want_stats)
 
 
-def indice_subm_conv(features, weight, data, packed=None, residual=None):
+def indice_subm_conv(features, weight, data, packed=None, residual=None, want_stats=False):
     pairs = data.wgrad_lists() if _want_pairs(features, weight) else None
-    return _conv(features, weight, data.tbl, data.tbl, data.outids.shape[0], 2, packed, residual, pairs)
+    return _conv(features, weight, data.tbl, data.tbl, data.outids.shape[0], 2, packed, residual, pairs, want_stats)
 
 
-def indice_conv(features, weight, data, packed=None):
+def indice_conv(features, weight, data, packed=None, want_stats=False):
     pairs = data.wgrad_lists() if _want_pairs(features, weight) else None
-    return _conv(features, weight, data.tbl, data.tbl_rev, data.outids.shape[0], 1, packed, None, pairs)
+    return _conv(features, weight, data.tbl, data.tbl_rev, data.outids.shape[0], 1, packed, None, pairs, want_stats)
 
 
-def indice_inverse_conv(features, weight, data, packed=None):
+def indice_inverse_conv(features, weight, data, packed=None, want_stats=False):
     # roles swapped: outputs live on the saved (fine) input indices of the strided conv
-    pairs = data.wgrad_lists(inverse=True) if _want_pairs(features, weight) else None
-    return _conv(features, weight, data.tbl_rev, data.tbl, data.indices.shape[0], 1, packed, None, pairs)
+    pairs = data.wgrad_lists(inverse=True) if _want_pairs(features, weight, data.indices.shape[0]) else None
+    return _conv(features, weight, data.tbl_rev, data.tbl, data.indices.shape[0], 1, packed, None, pairs, want_stats)
 
 
 class _IndiceMaxPool(Function):

@@ -93,12 +93,15 @@ class SparseSequential(SparseModule):
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
                     if _dnn.fusable(module, input.features):
-                        # BatchNorm1d [-> ReLU] on .features: one fused HIP path (doda_amd.nn)
+                        # BatchNorm1d [-> ReLU] on .features: one fused HIP path (doda_amd.nn); when the
+                        # features came out of a conv that accumulated their statistics, those are used
                         relu = k < len(mods) and type(mods[k]) is nn.ReLU
+                        st = input.__dict__.get("_doda_stats")
+                        stats = st[1] if (st is not None and st[0] is input.features) else None
                         if take_input and k == 1 and module.training:
-                            input.features, residual = _dnn.batch_norm_relu(input.features, module, relu, True)
+                            input.features, residual = _dnn.batch_norm_relu(input.features, module, relu, True, stats)
                         else:
-                            input.features = _dnn.batch_norm_relu(input.features, module, relu)
+                            input.features = _dnn.batch_norm_relu(input.features, module, relu, False, stats)
                         k += int(relu)
                     else:
                         input.features = _run(module, input.features)

@@ -11,6 +11,8 @@ from .. import ops as _ops
 from .._ext import ext as _ext
 from .core import IndiceData
 
+PAIRS_MIN_ROWS = 65536   # as doda_amd.spconv.functional.PAIRS_MIN_ROWS (pair lists only for large rulebooks)
+
 
 def _triple(v):
     if isinstance(v, (list, tuple, np.ndarray)):
@@ -74,7 +76,7 @@ def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", firs
     if (_ext is not None and not tensor.indice_dict and indices.is_cuda and indices.dtype == torch.int32
             and indices.shape[0] > 0 and all(int(v) >= 2 for v in shape)):
         levels = _ext.build_pyramid(indices, [int(v) for v in shape], int(tensor.batch_size), int(n_levels),
-                                    bool(with_pairs))
+                                    PAIRS_MIN_ROWS if with_pairs else -1)
         for k, (nbr, outids, child, par_off, oshape, sp, sn, sh, dp, dn, dh) in enumerate(levels):   # s*/d*: lists, counts, segments
             lvl = first_level + k
             data = tensor.indice_dict[subm_key % lvl] = IndiceData("subm", indices, indices, list(shape),
@@ -93,7 +95,7 @@ def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", firs
         key = subm_key % lvl
         if key not in tensor.indice_dict:
             tensor.indice_dict[key] = build_subm(indices, tensor.batch_size, shape, 3)
-        if with_pairs:
+        if with_pairs and indices.shape[0] >= PAIRS_MIN_ROWS:
             tensor.indice_dict[key].wgrad_lists()
         if lvl == first_level + n_levels - 1:
             break
@@ -102,7 +104,7 @@ def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", firs
         if data is None:
             data = build_down2(indices, tensor.batch_size, shape, 2, 2, 0, 1)
             tensor.indice_dict[key] = data
-        if with_pairs:
+        if with_pairs and indices.shape[0] >= PAIRS_MIN_ROWS:
             data.wgrad_lists()
         indices, shape = data.outids, data.out_spatial_shape
     return tensor.indice_dict

@@ -217,6 +217,38 @@ int doda_spconv_gather_add_bf16(const uint16_t *x, int32_t n_in, int32_t kc, con
                                 const void *res, void *y, int32_t y_is_f32, int32_t w_layout,
                                 void *ws, size_t ws_bytes, doda_stream_t stream);
 
+/* Gather with epilogue options: the conv fused with its neighbours in the layer graph (reference
+ * model/unet_block.py:23-37,46-49,67-79: BatchNorm1d -> ReLU -> conv [-> + identity]).
+ *   residual : y = conv + residual ([n_out, nc], dtype of y), as doda_spconv_gather_add_*.
+ *   stats    : BatchNorm statistics accumulated while the output rows are stored — the separate read
+ *              pass over y (forward) or over dy and x (backward) of a BatchNorm disappears:
+ *     bn_x == NULL (forward call; the BatchNorm FOLLOWS the conv):
+ *              stats[p][0][c] = sum_t y[t,c], stats[p][1][c] = sum_t y[t,c]^2 over the rows of
+ *              workgroup tile p, y as stored (after its bf16 rounding);
+ *     bn_x != NULL (data-grad call; y = d loss / d z with z = [relu](bn(bn_x)), the BatchNorm PRECEDES
+ *              the conv): stats[p][0][c] = sum dz, stats[p][1][c] = sum dz * xhat, with
+ *              xhat = (bn_x - mean) * invstd and dz = y * [gamma * xhat + beta > 0] when bn_relu;
+ *              bn_mean / bn_invstd / bn_gamma / bn_beta: float [nc] each.
+ *     `stats` holds doda_spconv_stats_capacity(n_out) rows of 2*nc floats; *stats_rows_h (HOST) receives
+ *     the number of rows written (known when the call returns: it depends on the tile the library
+ *     picks, not on device data).  Feed them to doda_bn_relu_fwd_stats / doda_bn_relu_bwd_stats.
+ * Statistics need the fast kernel (kc, nc multiples of 4, 16-byte aligned, < 2 GB): otherwise
+ * DODA_ERR_UNSUPPORTED and the caller runs the plain call plus a standalone BatchNorm. */
+typedef struct doda_conv_epilogue {
+    const void *residual;
+    float *stats;
+    int32_t *stats_rows_h;
+    const void *bn_x;
+    const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
+    int32_t bn_relu;
+    int32_t reserved;
+} doda_conv_epilogue;
+size_t doda_spconv_stats_capacity(int32_t n_out);
+int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, int32_t elem_bytes, const float *w,
+                          int32_t nc, const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, void *y,
+                          int32_t y_is_f32, int32_t w_layout, void *ws, size_t ws_bytes,
+                          const doda_conv_epilogue *epi, doda_stream_t stream);
+
 /* dw[o][i][j] = sum_t a[tbl[o][t], i] * b[t, j],  a: [*, ca], b: [n_rows, cb], dw: fp32
  * [K][ca][cb].  Two deterministic stages inside one call (per-row-chunk partials in ws, then a
  * fixed-order reduce); K <= 28. */
@@ -313,6 +345,23 @@ int doda_bn_relu_bwd_add(const void *x, const void *dy, int32_t m, int32_t c, in
                          const float *save_mean, const float *save_invstd, const float *gamma,
                          const float *beta, int32_t relu, const void *add, void *dx, float *dgamma,
                          float *dbeta, void *ws, size_t ws_bytes, doda_stream_t stream);
+
+/* BatchNorm(+ReLU) whose statistics pass already happened in a conv epilogue (doda_spconv_gather_ex):
+ * `stats` = [stats_rows][2][c] partial sums.  Forward: (sum x, sum x^2) -> mean / invstd / running
+ * statistics (fp64 combine), then y = [relu]((x - mean) * invstd * gamma + beta): two launches instead
+ * of three, x read once instead of twice.  Backward: (sum dz, sum dz*xhat) -> dgamma, dbeta and
+ * dx = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat)) [+ add]: dy and x read once instead of
+ * twice.  coef_ws: 3*c floats of scratch. */
+int doda_bn_relu_fwd_stats(const void *x, int32_t m, int32_t c, int32_t elem_bytes, const float *stats,
+                           int32_t stats_rows, float eps, float momentum, const float *gamma,
+                           const float *beta, float *running_mean, float *running_var,
+                           int64_t *num_batches_tracked, int32_t relu, void *y, float *save_mean,
+                           float *save_invstd, doda_stream_t stream);
+int doda_bn_relu_bwd_stats(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
+                           const float *stats, int32_t stats_rows, const float *save_mean,
+                           const float *save_invstd, const float *gamma, const float *beta, int32_t relu,
+                           const void *add, void *dx, float *dgamma, float *dbeta, float *coef_ws,
+                           doda_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Neighbour queries

@@ -409,3 +409,107 @@ def test_dsnorm_convert_and_batchnorm_checkpoint(native_lib):
     assert ds.domain_label == 1
     net.apply(set_ds_source)
     assert ds.domain_label == 0
+
+
+# ------------------------------------------------------------------ BatchNorm statistics in the conv epilogues
+def _ext_or_skip():
+    from doda_amd._ext import ext
+    if ext is None:
+        pytest.skip("compiled extension not built")
+    return ext
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("m,cin,cout", [(60000, 16, 16), (9000, 32, 48), (5000, 64, 112), (12000, 4, 16)])
+def test_conv_epilogue_statistics_forward_and_backward(native_lib, dtype, m, cin, cout):
+    """doda_spconv_gather_ex: (sum y, sum y^2) of the stored output, and for a data-grad call the
+    BatchNorm-backward sums (sum dz, sum dz*xhat) with the ReLU mask recomputed from bn_x."""
+    ext = _ext_or_skip()
+    from doda_amd import ops
+    d = dev()
+    shape = [60, 50, 40]
+    idx = torch.from_numpy(surface_voxels(m % 97, m, 2, shape)).to(d)
+    n = idx.shape[0]
+    tbl = ops.rulebook_subm(idx, shape, 2, 3)
+    torch.manual_seed(cin + cout)
+    x = torch.randn(n, cin, device=d).to(dtype)
+    w = torch.randn(27, cin, cout, device=d) * 0.1
+    res = torch.randn(n, cout, device=d).to(dtype)
+    y_plain = ops.spconv_gather(x, w, tbl, n, 0, cout, residual=res)
+    wt = torch.nn.Parameter(w.view(3, 3, 3, cin, cout).clone())
+    y, stats = ext.indice_conv_stats(x, wt, tbl, tbl, n, 2, None, None, res)
+    assert torch.equal(y.detach(), y_plain)
+    assert stats is not None and stats.shape[1:] == (2, cout)
+    yf = y.detach().double()
+    s1, s2 = stats.double().sum(0)
+    assert rel_err(s1.cpu(), yf.sum(0).cpu()) < 1e-5
+    assert rel_err(s2.cpu(), (yf * yf).sum(0).cpu()) < 1e-5
+    # backward sums through the public gather_ex path: use the ext's conv node with a BatchNorm in front
+    from doda_amd import spconv
+    torch.manual_seed(3)
+    bn = torch.nn.BatchNorm1d(cin, eps=1e-4).to(d).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    if cin % 4:
+        return
+    seq = spconv.SparseSequential(bn, torch.nn.ReLU(), spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="k").to(d))
+    seq.train()
+    outs = []
+    from doda_amd.spconv import functional as Fsp
+    try:
+        for fused in (False, True):
+            Fsp.set_bn_fusion(fused)
+            bn.zero_grad(set_to_none=True)
+            seq[2].zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            out = seq(spconv.SparseConvTensor(xin, idx, shape, 2)).features
+            out.float().square().mean().backward()
+            outs.append((out.detach().clone(), xin.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+    finally:
+        Fsp.set_bn_fusion(True)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for a, b in zip(*outs):
+        assert rel_err(b.float().cpu(), a.float().cpu()) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unet_step_with_and_without_bn_fusion(native_lib, dtype):
+    """Whole U-Net training step: loss, every parameter gradient and the BatchNorm running statistics agree
+    between the fused path (statistics in the conv epilogues, forward and backward) and the standalone
+    BatchNorm kernels."""
+    _ext_or_skip()
+    from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
+    from doda_amd.scene import make_batch
+    from doda_amd.spconv import functional as Fsp
+    d = dev()
+    cfg = default_cfg()
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in make_batch(2, 30000, 5).items()}
+    net = deterministic_init(SparseConvNet(cfg), seed=1).to(d).train()
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    runs = []
+    try:
+        for fused in (False, True):
+            Fsp.set_bn_fusion(fused)
+            net.load_state_dict(state)
+            net.zero_grad(set_to_none=True)
+            loss = cross_entropy(voxelize_and_run(cfg, net, bd, d, feature_dtype=dtype), bd["labels"])
+            loss.backward()
+            torch.cuda.synchronize()
+            runs.append((float(loss), {k: p.grad.double().cpu() for k, p in net.named_parameters()},
+                         {k: v.double().cpu() for k, v in net.state_dict().items() if "running" in k}))
+    finally:
+        Fsp.set_bn_fusion(True)
+    (l0, g0, r0), (l1, g1, r1) = runs
+    tol_l, tol_g = (1e-5, 2e-3) if dtype == torch.float32 else (3e-3, 8e-2)
+    assert abs(l0 - l1) <= tol_l * abs(l0), (l0, l1)
+    top = max(float(g.norm()) for g in g0.values())
+    for k in g0:
+        na, nb = float(g0[k].norm()), float(g1[k].norm())
+        assert np.isfinite(nb)
+        # bf16: gradients two orders of magnitude below the largest are rounding noise at the deep levels
+        # (a few dozen rows per BatchNorm, 1/sqrt(var + 1e-4) up to 100); fp32 checks every parameter
+        if dtype == torch.float32 or na >= 1e-2 * top:
+            assert abs(na - nb) <= tol_g * na + 1e-9, (k, na, nb)
+    for k in r0:
+        assert rel_err(r1[k], r0[k]) < (1e-5 if dtype == torch.float32 else 2e-2), k

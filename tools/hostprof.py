@@ -11,9 +11,17 @@ net = SparseConvNet(cfg).to(dev).train()
 opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)
 from doda_amd.spconv import functional as Fsp
 print('deferred wgrad:', Fsp.set_deferred_wgrad(os.environ.get('DEFER', '1') == '1'))
+from doda_amd.model import PyramidPrefetcher
+from doda_amd import spconv
+PF = PyramidPrefetcher(dev, 7) if os.environ.get('PREFETCH', '1') == '1' else None
+wp = bool(spconv.functional.WGRAD_PAIRS)
+pend = [PF.submit(bd, wp)] if PF else None
 def fwd():
     opt.zero_grad(set_to_none=True)
-    s = voxelize_and_run(cfg, net, bd, dev, feature_dtype=torch.bfloat16, inputs_ready=True)
+    pyr = None
+    if PF:
+        pyr = PyramidPrefetcher.take(pend[0], dev); pend[0] = PF.submit(bd, wp)
+    s = voxelize_and_run(cfg, net, bd, dev, feature_dtype=torch.bfloat16, inputs_ready=True, pyramid=pyr)
     return cross_entropy(s, bd["labels"])
 for _ in range(5):
     l = fwd(); l.backward(); opt.step()
