@@ -48,29 +48,32 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-voxels", type=int, default=150000, help="size of the CPU-baseline sample scene")
     p.add_argument("--kernel-reps", type=int, default=50)
+    p.add_argument("--fp32-steps", type=int, default=40,
+                   help="timed steps of the fp32 sub-record (reference precision); 0 = skip")
     p.add_argument("--prefetch", type=int, default=1,
                    help="1: rulebooks of the next batch are built on a helper thread during the step; 0: in line")
     return p.parse_args()
 
 
-def kernel_roofline(batch_dev, dtype, reps):
-    """Time the dominant kernel live: SubMConv3d 16->16 forward gather on the batch's level-1
-    rulebook.  Algorithmic bytes per launch: s*(M*Cin + M*Cout) + s*K*Cin*Cout + 8*P."""
+def _subm16_times(idx, shape, nb, dtype, reps):
+    """SubMConv3d 16->16 on the level-1 rulebook of `idx`: forward gather, data-grad gather and weight
+    gradient, timed with HIP events on the launch stream exactly as the training step issues them:
+    weights fragment-packed beforehand (one launch per optimizer step in the model), the weight gradient
+    through the multi-layer call with the level's 8 block convolutions in one call (pair lists exported
+    once per rulebook for bf16).  Returns the per-launch / per-layer times and the algorithmic bytes
+    (B_f = s(M Cin + M Cout) + 4 K Cin Cout + 8 P, B_b = s(2 M Cin + M Cout) + 2*4 K Cin Cout + 8 P)."""
     from doda_amd import ops, spconv
-    dev = batch_dev["voxel_locs"].device
-    idx = batch_dev["voxel_locs"].int()
+    dev = idx.device
     m = idx.shape[0]
-    nb = int(batch_dev["offsets"].numel() - 1)
-    data = spconv.ops.build_subm(idx, nb, batch_dev["spatial_shape"], 3)
+    data = spconv.ops.build_subm(idx, nb, shape, 3)
     pairs_total = int((data.tbl >= 0).sum().item())
     tdt = torch.float32 if dtype == "f32" else torch.bfloat16
     x = torch.randn(m, 16, device=dev).to(tdt)
     gy = torch.randn(m, 16, device=dev).to(tdt)
     w = torch.randn(27, 16, 16, device=dev) * 0.1
     s = 4 if dtype == "f32" else 2
-    out = {}
 
-    def timed(fn):
+    def timed(fn, per=1):
         for _ in range(5):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -80,33 +83,56 @@ def kernel_roofline(batch_dev, dtype, reps):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e-3 / reps
+        return e0.elapsed_time(e1) * 1e-3 / reps / per
 
     b_f = s * (m * 16 + m * 16) + 4 * 27 * 16 * 16 + 8 * pairs_total
-    b_w = s * (m * 16 + m * 16) + 4 * 27 * 16 * 16 + 8 * pairs_total
-    # weights fragment-packed once (as the model does once per optimizer step), so one timed call is
-    # exactly one launch of the conv kernel
+    b_b = s * (2 * m * 16 + m * 16) + 2 * 4 * 27 * 16 * 16 + 8 * pairs_total
     plan = ops.PackPlan([(w, 27, 16, 16, 0, s), (w, 27, 16, 16, 2, s)], dev)
     plan.run()
     pk_f, pk_d = plan.outputs
     t_f = timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, 16, packed=pk_f))
     t_d = timed(lambda: ops.spconv_gather(gy, None, data.tbl, m, 2, 16, packed=pk_d))
-    t_w = timed(lambda: ops.spconv_wgrad(x, gy, data.tbl, m))
-    out["subm16_fwd"] = {"us": t_f * 1e6, "GBs": b_f / t_f / 1e9}
-    out["subm16_dgrad"] = {"us": t_d * 1e6, "GBs": b_f / t_d / 1e9}
-    out["subm16_wgrad"] = {"us": t_w * 1e6, "GBs": b_w / t_w / 1e9}
-    # north-star gate: whole SubMConv3d fwd+bwd vs (B_f + B_b)
-    b_b = s * (2 * m * 16 + m * 16) + 2 * 4 * 27 * 16 * 16 + 8 * pairs_total
+    n_layers = 8   # the 16 -> 16 block convolutions of level 1 share the rulebook and one multi-layer call
+    wg_kernel = "wgrad_multi_kernel (gather table)"
+    pairs = None
+    if dtype == "bf16" and spconv.functional.WGRAD_PAIRS:
+        pairs = data.wgrad_lists()
+        wg_kernel = "wgrad_pairs_kernel<1,1> (pair lists)"
+    jobs = [(x, gy, data.tbl, m, pairs) if pairs is not None else (x, gy, data.tbl, m) for _ in range(n_layers)]
+    t_w = timed(lambda: ops.spconv_wgrad_multi(jobs), per=n_layers)
     t_all = t_f + t_d + t_w
-    out["subm16_fwd_bwd"] = {"us": t_all * 1e6, "GBs": (b_f + b_b) / t_all / 1e9,
-                             "frac_of_hbm_peak": (b_f + b_b) / t_all / 1e9 / HBM_PEAK_GBS}
-    dom = "subm16_fwd"
+    return {"M": m, "P": pairs_total,
+            "fwd": {"us": t_f * 1e6, "GBs": b_f / t_f / 1e9},
+            "dgrad": {"us": t_d * 1e6, "GBs": b_f / t_d / 1e9},
+            "wgrad": {"us": t_w * 1e6, "GBs": b_f / t_w / 1e9, "kernel": wg_kernel,
+                      "note": "%d layers per multi-layer call, time per layer incl. the partial reduce" % n_layers},
+            "fwd_bwd": {"us": t_all * 1e6, "GBs": (b_f + b_b) / t_all / 1e9,
+                        "frac_of_hbm_peak": (b_f + b_b) / t_all / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes": b_f + b_b},
+            "b_f": b_f}
+
+
+def kernel_roofline(batch_dev, dtype, reps, gate_scene=None):
+    """Dominant kernel live: SubMConv3d 16->16 forward gather on the batch's level-1 rulebook; plus the
+    north-star gate (whole 16->16 fwd+bwd) at the batch size and on ONE ~150 k-voxel scene."""
+    idx = batch_dev["voxel_locs"].int()
+    nb = int(batch_dev["offsets"].numel() - 1)
+    big = _subm16_times(idx, batch_dev["spatial_shape"], nb, dtype, reps)
+    out = {"subm16_fwd": big["fwd"], "subm16_dgrad": big["dgrad"], "subm16_wgrad": big["wgrad"],
+           "subm16_fwd_bwd": big["fwd_bwd"]}
+    if gate_scene is not None:
+        one = _subm16_times(gate_scene["voxel_locs"].int(), gate_scene["spatial_shape"], 1, dtype, reps)
+        out["gate_150k"] = {"M": one["M"], "P": one["P"], "fwd_us": one["fwd"]["us"], "dgrad_us": one["dgrad"]["us"],
+                            "wgrad_us": one["wgrad"]["us"], **one["fwd_bwd"],
+                            "note": "north_star gate: SubMConv3d 16->16 fwd+bwd on one ~150k-voxel scene; its 45 MB "
+                                    "working set sits in the 256 MB Infinity Cache between back-to-back launches"}
+    m, pairs_total, b_f = big["M"], big["P"], big["b_f"]
     kname = "conv_fast<PF32,1,2,3>" if dtype == "f32" else "conv_fast<PBF16P,1,2,3>"
     traffic, traffic_src = pmc_traffic(dtype)
     roof = {"kernel": "%s (SubMConv3d 16->16 fwd gather, M=%d, P=%d)" % (kname, m, pairs_total),
-            "bound": "hbm", "achieved": out[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": out[dom]["GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": b_f, "avg_launch_us": out[dom]["us"], "detail": out}
+            "bound": "hbm", "achieved": out["subm16_fwd"]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": out["subm16_fwd"]["GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": b_f, "avg_launch_us": out["subm16_fwd"]["us"], "detail": out}
     return roof, pairs_total / max(m, 1)
 
 
@@ -156,14 +182,17 @@ def pmc_traffic(dtype):
     MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950 (check: the doubled value,
     86.5 MB, sits 2.5 % above the compulsory x + table bytes, 84.4 MB; WRITE_SIZE equals the output
     bytes exactly).  A counter pass cannot run inside this process, hence the file."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_raw.json")
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = os.path.join(prof, "r02_pmc_traffic_raw.json")
+    if not os.path.exists(path):
+        path = os.path.join(prof, "r01_pmc_traffic_raw.json")
     try:
         with open(path) as f:
             d = json.load(f)[dtype]
         fetch, write = d["FETCH_SIZE_KB_mean"], d["WRITE_SIZE_KB_mean"]
         if fetch is None or write is None:
             return None, None
-        return (2.0 * fetch + write) * 1024.0, "profiles/r01_pmc_traffic_raw.json (2 x FETCH_SIZE + WRITE_SIZE, KiB)"
+        return (2.0 * fetch + write) * 1024.0, "profiles/%s (2 x FETCH_SIZE + WRITE_SIZE, KiB)" % os.path.basename(path)
     except (OSError, KeyError, ValueError):
         return None, None
 
@@ -209,58 +238,75 @@ def main():
     n_local = batch["locs"].shape[0]
 
     cfg = default_cfg()
-    torch.manual_seed(0)
-    net = SparseConvNet(cfg).to(dev).train()
-    # gradients: weight gradients deferred to one multi-layer launch at the end of backward, then (N > 1)
-    # one flat all-reduce over RCCL; torch DDP (the reference's wrapper) when the extension is absent
     from doda_amd.spconv import functional as Fsp
-    deferred = Fsp.set_deferred_wgrad(True)
-    model = net if deferred else ddist.wrap_ddp(net, local_rank)
-    reducer = ddist.GradAllReduce(net) if deferred else None
-    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)
-    fdt = torch.float32 if args.dtype == "f32" else torch.bfloat16
-    labels = batch_dev["labels"]
-
-    # rulebooks ride in the data pipeline: those of the NEXT batch are built on a helper thread + side
-    # stream while this step is issued (every step still builds one full pyramid; nothing is cached)
     from doda_amd.model import PyramidPrefetcher
     from doda_amd import spconv
-    with_pairs = bool(spconv.functional.WGRAD_PAIRS and fdt == torch.bfloat16)
-    prefetch = PyramidPrefetcher(dev, len(net.unet.nPlanes)) if args.prefetch else None
-    pending = [prefetch.submit(batch_dev, with_pairs)] if prefetch else None
+    deferred = Fsp.set_deferred_wgrad(True)
+    labels = batch_dev["labels"]
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        pyramid = None
+    def run_training(dtype_name, steps, warmup):
+        """`warmup` untimed + `steps` timed training steps with a fresh network; returns
+        (max-over-ranks seconds, final loss, network)."""
+        torch.manual_seed(0)
+        net = SparseConvNet(cfg).to(dev).train()
+        # gradients: weight gradients deferred to one multi-layer launch at the end of backward, then (N > 1)
+        # bucketed all-reduces over RCCL; torch DDP (the reference's wrapper) when the extension is absent
+        model = net if deferred else ddist.wrap_ddp(net, local_rank)
+        reducer = ddist.GradAllReduce(net) if deferred else None
+        opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)
+        fdt = torch.float32 if dtype_name == "f32" else torch.bfloat16
+        # rulebooks ride in the data pipeline: those of the NEXT batch are built on a helper thread + side
+        # stream while this step is issued (every step still builds one full pyramid; nothing is cached)
+        with_pairs = bool(spconv.functional.WGRAD_PAIRS and fdt == torch.bfloat16)
+        prefetch = PyramidPrefetcher(dev, len(net.unet.nPlanes)) if args.prefetch else None
+        pending = [prefetch.submit(batch_dev, with_pairs)] if prefetch else None
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            pyramid = None
+            if prefetch is not None:
+                pyramid = PyramidPrefetcher.take(pending[0], dev)
+                pending[0] = prefetch.submit(batch_dev, with_pairs)
+            scores = voxelize_and_run(cfg, model, batch_dev, dev, feature_dtype=fdt, inputs_ready=True,
+                                      pyramid=pyramid)
+            loss = cross_entropy(scores, labels, ignore_index=255)
+            loss.backward()
+            if reducer is not None:
+                reducer.reduce()
+            opt.step()
+            return loss
+
+        for _ in range(warmup):
+            step()
+        ddist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        ddist.barrier()
+        dt = time.perf_counter() - t0
         if prefetch is not None:
-            pyramid = PyramidPrefetcher.take(pending[0], dev)
-            pending[0] = prefetch.submit(batch_dev, with_pairs)
-        scores = voxelize_and_run(cfg, model, batch_dev, dev, feature_dtype=fdt, inputs_ready=True, pyramid=pyramid)
-        loss = cross_entropy(scores, labels, ignore_index=255)
-        loss.backward()
-        if reducer is not None:
-            reducer.reduce()
-        opt.step()
-        return loss
+            pending[0].result()
+            prefetch.shutdown()
+        return dt, float(loss.detach()), net
 
-    for _ in range(args.warmup):
-        step()
-    ddist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    ddist.barrier()
-    elapsed = time.perf_counter() - t0
-    if prefetch is not None:
-        pending[0].result()
-        prefetch.shutdown()
+    elapsed, final_loss, net = run_training(args.dtype, args.steps, args.warmup)
     elapsed, (m_total, n_total) = ddist.reduce_step_stats(elapsed, [m_local, n_local], dev)
-    final_loss = float(loss.detach())
+    # the reference computes in fp32 end to end (lib/pointgroup_ops/src/cuda.cu:11-13): the same step in
+    # fp32 rides along as a sub-record, timed by the same clock (N = 1 only, fewer steps)
+    fp32 = None
+    if world == 1 and args.dtype != "f32" and args.fp32_steps > 0:
+        e32, l32, _ = run_training("f32", args.fp32_steps, max(5, args.warmup // 3))
+        fp32 = {"ms_per_step": e32 / args.fp32_steps * 1e3, "value": m_local * args.fp32_steps / e32,
+                "unit": "voxels/s", "steps": args.fp32_steps, "final_loss": l32}
 
     if rank == 0:
-        roof, ppv = kernel_roofline(batch_dev, args.dtype, args.kernel_reps)
+        gate_scene = None
+        if world == 1:   # the north-star gate is stated on ONE ~150k-voxel scene
+            one = make_batch(1, 150000, 1000, args.voxel_scale)
+            gate_scene = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in one.items()}
+        roof, ppv = kernel_roofline(batch_dev, args.dtype, args.kernel_reps, gate_scene)
         step_bytes, n_layers = step_algorithmic_bytes(net, batch_dev, args.dtype)
         step_gbs = step_bytes / (elapsed / args.steps) / 1e9
         roof["step"] = {"algorithmic_bytes": step_bytes, "conv_layers": n_layers, "GBs": step_gbs,
@@ -279,9 +325,20 @@ def main():
                        "global_batch": args.scenes * world, "voxels_per_gpu": m_local,
                        "points_per_gpu": n_local, "pairs_per_voxel_subm1": round(ppv, 2),
                        "parallelism": "dp%d" % world, "n_classes": 20, "final_loss": final_loss,
-                       "grad_sync": "deferred multi-layer wgrad + flat all-reduce" if deferred else "torch DDP"},
+                       "grad_sync": "deferred multi-layer wgrad + bucketed all-reduce" if deferred else "torch DDP",
+                       "rulebooks": "13 per step, built for the next batch on a helper thread + side stream "
+                                    "during the step" if args.prefetch else "13 per step, built in line",
+                       "rulebook_parity": "bit-exact vs this repo's restatement of spconv-1.2's CPU algorithm; "
+                                          "spconv is not vendored by the reference: orderings unpinned"},
             "roofline": roof,
         }
+        if fp32 is not None:
+            r32, _ = kernel_roofline(batch_dev, "f32", max(10, args.kernel_reps // 2), gate_scene)
+            b32, _ = step_algorithmic_bytes(net, batch_dev, "f32")
+            fp32["roofline"] = {"kernel": r32["kernel"], "achieved": r32["achieved"], "frac": r32["frac"],
+                                "avg_launch_us": r32["avg_launch_us"], "detail": r32["detail"],
+                                "step_frac_of_hbm_peak": b32 / (fp32["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            line["fp32"] = fp32
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)

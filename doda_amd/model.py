@@ -8,8 +8,8 @@ pre-activation order, k2s2 down / inverse up sharing `spconv{i}`, concatenation 
 bias 0 init) and the same module names, so state dicts are interchangeable with the reference's
 checkpoints (`input_conv.0.weight`, `unet.blocks.block0.conv_branch.2.weight`, `unet.conv.2.weight`,
 `unet.u...`, `unet.deconv.2.weight`, `unet.blocks_tail.block0.i_branch.0.weight`, `linear.weight`).
-tests/test_model_graph.py checks that equivalence against the reference files when they are
-present.
+tests/test_oracle_unet.py and tests/test_gpu_unet.py check that equivalence through
+tests/golden/unet_golden.npz / unet_state_keys.json, which the reference's own model files produced.
 """
 import functools
 from collections import OrderedDict

@@ -256,8 +256,9 @@ class SparseConvolution(SparseModule):
                 ident = _identity_table(features.shape[0], features.device)
                 # (no rulebook is involved, and the reference hands its 1x1 skip convolution a FRESH tensor
                 # header, model/unet_block.py:33: an empty dictionary here is not the start of a forward pass)
-                out_features, stats = Fsp.conv1x1(features, self.weight, ident, self._packed(
+                out_features = Fsp.conv1x1(features, self.weight, ident, self._packed(
                     features, input.indice_dict if len(input.indice_dict) else None), want_stats=self.training)
+                out_features, stats = out_features if self.training else (out_features, None)
             else:
                 w2 = self.weight.view(self.in_channels, self.out_channels)
                 out_features = torch.mm(features, w2.to(features.dtype))
@@ -293,7 +294,7 @@ class SparseConvolution(SparseModule):
                 raise RuntimeError("SparseInverseConv3d: no strided rulebook under indice_key %r"
                                    % (self.indice_key,))
             outids, out_spatial_shape = data.indices, data.spatial_shape
-            out_features, stats = Fsp.indice_inverse_conv(features, weight, data, packed, want_stats=self.training)
+            out_features = Fsp.indice_inverse_conv(features, weight, data, packed, want_stats=self.training)
         else:
             if data is None:
                 if self.subm:
@@ -307,13 +308,15 @@ class SparseConvolution(SparseModule):
             if self.subm:
                 fuse = (residual is not None and features.is_cuda and residual.dtype == features.dtype
                         and tuple(residual.shape) == (outids.shape[0], self.out_channels))
-                out_features, stats = Fsp.indice_subm_conv(features, weight, data, packed, residual if fuse else None,
-                                                           want_stats=self.training)
+                out_features = Fsp.indice_subm_conv(features, weight, data, packed, residual if fuse else None,
+                                                    want_stats=self.training)
                 if fuse:
                     residual = None
             else:
-                out_features, stats = Fsp.indice_conv(features, weight, data, packed, want_stats=self.training)
+                out_features = Fsp.indice_conv(features, weight, data, packed, want_stats=self.training)
 
+        # (training mode: the conv also returned the BatchNorm statistics partials of its output, or None)
+        out_features, stats = out_features if self.training else (out_features, None)
         if residual is not None:
             out_features = out_features + residual
             stats = None

@@ -137,7 +137,7 @@ def _conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residua
     """residual: optional [n_out, Cout] tensor in the output dtype; returns conv + residual with the
     add fused into the kernel's store (the residual's gradient is the incoming gradient).
     pairs: (pair_in [K,ld], pair_out [K,ld], pair_num [K] | None) of the rulebook, for the weight gradient.
-    want_stats: return (y, stats | None) instead of y."""
+    want_stats: return (y, stats | None) instead of y (stats: BatchNorm partials of y, see above)."""
     if _ext is not None and _SERIAL:   # compiled autograd glue (no Python per launch)
         pk_fwd, pk_bwd = packed if packed is not None else (None, None)
         fn = _ext.indice_conv_stats if (want_stats and BN_FUSION and n_out > STATS_MIN_ROWS) else _ext.indice_conv

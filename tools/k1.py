@@ -24,9 +24,13 @@ m = idx.shape[0]
 tdt = torch.float32 if dt == "f32" else torch.bfloat16
 x = torch.randn(m, c, device=dev).to(tdt); gy = torch.randn(m, c, device=dev).to(tdt)
 w = torch.randn(27, c, c, device=dev) * 0.05
+s = 4 if dt == "f32" else 2
+plan = ops.PackPlan([(w, 27, c, c, 0, s), (w, 27, c, c, 2, s)], dev); plan.run()
+pairs = sub.wgrad_lists() if which == "wgradp" else None
 for _ in range(reps):
-    if which == "fwd": ops.spconv_gather(x, w, sub.tbl, m, 0, c)
-    elif which == "dgrad": ops.spconv_gather(gy, w, sub.tbl, m, 2, c)
-    else: ops.spconv_wgrad(x, gy, sub.tbl, m)
+    if which == "fwd": ops.spconv_gather(x, None, sub.tbl, m, 0, c, packed=plan.outputs[0])
+    elif which == "dgrad": ops.spconv_gather(gy, None, sub.tbl, m, 2, c, packed=plan.outputs[1])
+    elif which == "wgradp": ops.spconv_wgrad_multi([(x, gy, sub.tbl, m, pairs)] * 8)   # pair-list kernel, 8 layers per call
+    else: ops.spconv_wgrad_multi([(x, gy, sub.tbl, m)] * 8)                              # gather-table kernel
 torch.cuda.synchronize()
 print("done", m)
