@@ -196,6 +196,22 @@ def indice_maxpool(features, pairs, pair_num, num_act_out):
     return out
 
 
+def indice_maxpool_backward(features, out_features, dout, pairs, pair_num):
+    """spconv indice_maxpool backward (maxPoolBwd): every pair whose input equals the pooled output
+    receives that output's gradient: din[i, c] += dout[t, c] where features[i, c] == out[t, c]."""
+    features, out_features, dout = (torch.as_tensor(a) for a in (features, out_features, dout))
+    pairs = torch.as_tensor(np.asarray(pairs)).long()
+    din = torch.zeros_like(features)
+    for o in range(pairs.shape[1]):
+        n_hot = int(pair_num[o])
+        if n_hot == 0:
+            continue
+        i, t = pairs[0, o, :n_hot], pairs[1, o, :n_hot]
+        hit = features[i] == out_features[t]
+        din.index_add_(0, i, torch.where(hit, dout[t], torch.zeros_like(dout[t])))
+    return din
+
+
 # ---------------------------------------------------------------------------------------------
 def knnquery(nsample, xyz, new_xyz, offset_ends, new_offset_ends):
     xyz, new_xyz = _f32(xyz), _f32(new_xyz)

@@ -9,6 +9,8 @@
   summation order differs: 1e-4 rel as north_star states for fp32 features);
 * deferred weight gradients: a second backward pass accumulates, a weight used twice in one graph gets
   both contributions, an aborted backward leaves nothing behind."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -513,3 +515,124 @@ def test_unet_step_with_and_without_bn_fusion(native_lib, dtype):
             assert abs(na - nb) <= tol_g * na + 1e-9, (k, na, nb)
     for k in r0:
         assert rel_err(r1[k], r0[k]) < (1e-5 if dtype == torch.float32 else 2e-2), k
+
+
+# ------------------------------------------------------------------ thin spots of round 1 (VERDICT "tighten")
+def test_maxpool_backward_elementwise_vs_oracle(native_lib, oracle):
+    """Indice max-pool backward against the oracle's restatement of spconv's maxPoolBwd, element by element,
+    with ties (duplicated maxima receive the gradient once each)."""
+    from doda_amd import spconv
+    from tests.util import random_voxels
+    shape, batch = [12, 10, 8], 2
+    idx = random_voxels(9, 500, batch, shape)
+    rng = np.random.default_rng(4)
+    x = rng.integers(-3, 4, size=(idx.shape[0], 8)).astype(np.float32)   # small integers: many exact ties
+    oi, pairs, pn, _ = oracle.indice_pairs_conv(idx, batch, shape, 2, 2, 0, 1)
+    y = oracle.indice_maxpool(torch.from_numpy(x), pairs, pn, oi.shape[0])
+    dy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    ref = oracle.indice_maxpool_backward(torch.from_numpy(x), y, torch.from_numpy(dy), pairs, pn)
+    pool = spconv.SparseMaxPool3d(2, 2)
+    xt = torch.from_numpy(x).to(dev()).requires_grad_(True)
+    out = pool(spconv.SparseConvTensor(xt, torch.from_numpy(idx).to(dev()), shape, batch))
+    assert np.array_equal(out.features.detach().cpu().numpy(), y.numpy())
+    out.features.backward(torch.from_numpy(dy).to(dev()))
+    assert np.array_equal(xt.grad.cpu().numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_full_size_tail_layer_properties(native_lib, dtype):
+    """BASELINE config 2 at full size: 4 x ~150k voxels, the widest level-1 layer shape x 6 (192 -> 96
+    channels: 231 MB bf16 / 463 MB fp32 of input features — the regime of the 32-bit buffer offsets and
+    the < 2 GB guards).  Size-independent checks: a centre-only identity kernel copies its channels
+    exactly; linearity; sampled rows against a direct fp64 evaluation of y[t] = sum_o x[nbr[o][t]] W[o];
+    the weight gradient of sampled (offset, ci, co) entries against fp64."""
+    from doda_amd import ops
+    from doda_amd.scene import make_batch
+    d = dev()
+    b = make_batch(4, 150000, 1000)
+    idx = b["voxel_locs"].int().to(d)
+    m = idx.shape[0]
+    assert m > 590000
+    tbl = ops.rulebook_subm(idx, b["spatial_shape"], 4, 3)
+    cin, cout = 192, 96
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x1 = torch.randn(m, cin, generator=g).to(d).to(dtype)
+    x2 = torch.randn(m, cin, generator=g).to(d).to(dtype)
+    w = (torch.randn(27, cin, cout, generator=g) * 0.05).to(d)
+    # identity on the centre offset
+    wi = torch.zeros(27, cin, cout, device=d)
+    wi[13, :cout, :] = torch.eye(cout, device=d)
+    assert torch.equal(ops.spconv_gather(x1, wi, tbl, m, 0, cout), x1[:, :cout].contiguous())
+    y1 = ops.spconv_gather(x1, w, tbl, m, 0, cout).float()
+    y2 = ops.spconv_gather(x2, w, tbl, m, 0, cout).float()
+    if dtype == torch.float32:   # linearity (exact inputs; bf16 would round x1 + x2)
+        y12 = ops.spconv_gather(x1 + 0.5 * x2, w, tbl, m, 0, cout)
+        assert float((y12 - (y1 + 0.5 * y2)).abs().max()) < 2e-4 * float(y1.abs().max())
+    # sampled rows, fp64 (rows near the end of the buffers included)
+    rows = torch.cat([torch.randint(0, m, (1500,), generator=g), torch.arange(m - 300, m)]).to(d)
+    wk = w if dtype == torch.float32 else w.to(torch.bfloat16).float()
+    nb = tbl[:, rows].long()                                  # [27, R]
+    xs = torch.where((nb >= 0).unsqueeze(-1), x1[nb.clamp_min(0)].double(), torch.zeros((), dtype=torch.float64, device=d))
+    ref = torch.einsum("orc,ocd->rd", xs, wk.double())
+    tol = RTOL if dtype == torch.float32 else 8e-3
+    assert rel_err(y1[rows].cpu(), ref.cpu()) < tol
+    # weight gradient: all offsets, a sampled block of channels
+    gy = torch.randn(m, cout, generator=g).to(d).to(dtype)
+    dw = ops.spconv_wgrad(x1, gy, tbl, m)
+    ci, co = slice(40, 56), slice(80, 96)
+    ref_dw = torch.empty(27, 16, 16, dtype=torch.float64, device=d)
+    for o in range(27):
+        nbo = tbl[o].long()
+        ok = nbo >= 0
+        ref_dw[o] = x1[nbo[ok]][:, ci].double().t() @ gy[ok][:, co].double()
+    assert rel_err(dw[:, ci, co].cpu(), ref_dw.cpu()) < (RTOL if dtype == torch.float32 else 2e-3)
+
+
+def test_one_cm_scene_rulebooks_and_step(native_lib, oracle):
+    """BASELINE config 5 shape: 1 cm voxels, ~500 k active voxels in one scene.  Rulebooks bit-exact
+    against the oracle at that size, a U-Net training step runs (finite loss, every gradient finite), and
+    the hash-key guard: a grid of >= 2^32 - 1 cells is refused with DODA_ERR_GRID_TOO_LARGE, one just
+    below is accepted."""
+    from doda_amd import ops
+    from doda_amd._lib import DodaNativeError
+    from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
+    from doda_amd.scene import make_batch
+    d = dev()
+    b = make_batch(1, 500000, 77, voxel_scale=100)
+    idx = b["voxel_locs"].int()
+    shape = [int(v) for v in b["spatial_shape"]]
+    assert idx.shape[0] > 450000
+    pairs, pn = oracle.indice_pairs_subm(idx.numpy(), 1, shape, 3)
+    tbl = ops.rulebook_subm(idx.to(d), shape, 1, 3)
+    got, num = ops.rulebook_pairs(tbl, idx.shape[0], flip=True)
+    assert np.array_equal(num.cpu().numpy(), pn) and np.array_equal(got.cpu().numpy(), pairs)
+    oi, dpairs, dpn, oshape = oracle.indice_pairs_conv(idx.numpy(), 1, shape, 2, 2, 0, 1)
+    out_idx, child, par_off, out_shape = ops.rulebook_down2(idx.to(d), shape, 1)
+    assert out_shape == oshape and np.array_equal(out_idx.cpu().numpy(), oi)
+    gp, gn = ops.rulebook_pairs(par_off, idx.shape[0], flip=False)
+    assert np.array_equal(gn.cpu().numpy(), dpn) and np.array_equal(gp.cpu().numpy(), dpairs)
+    cfg = default_cfg()
+    net = deterministic_init(SparseConvNet(cfg), seed=2).to(d).train()
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in b.items()}
+    loss = cross_entropy(voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.bfloat16), bd["labels"])
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in net.parameters())
+    # hash key = 32-bit cell id
+    few = torch.tensor([[0, 1, 2, 3], [1, 5, 6, 7]], dtype=torch.int32, device=d)
+    with pytest.raises(DodaNativeError, match="-3|grid|GRID"):
+        ops.rulebook_subm(few, [2048, 2048, 512], 2, 3)            # 2 * 2^31 cells
+    ops.rulebook_subm(few, [2048, 2048, 511], 2, 3)                # just below 2^32 - 1
+
+
+def test_python_glue_without_the_compiled_extension(native_lib):
+    """DODA_NO_EXT=1: the pure Python / ctypes glue drives the same kernels; the reference-model golden
+    must hold on that route too (round 1 never exercised it on the GPU)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DODA_NO_EXT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_unet.py", "-k",
+                        "golden or bf16_tracks"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
