@@ -746,12 +746,17 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                     acc[s][nb][3] += __uint_as_float(r2[1] & 0xffff0000u);
                 }
             }
+            u32x2 packed_out = {0u, 0u};   // bf16 output: rounded ONCE, for the store and for the statistics
+            if constexpr (!(OUT32 || sizeof(elem) == 4)) {
+                packed_out[0] = (unsigned)f2bf(acc[s][nb][0]) | ((unsigned)f2bf(acc[s][nb][1]) << 16);
+                packed_out[1] = (unsigned)f2bf(acc[s][nb][2]) | ((unsigned)f2bf(acc[s][nb][3]) << 16);
+            }
             if constexpr (STATS) {
                 // rows past n_out / channels past nc carry zeros (their loads were out of range)
                 f32x4 v = acc[s][nb];
-                if (!(OUT32 || sizeof(elem) == 4)) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = bf16_rounded(v[q]);
+                if constexpr (!(OUT32 || sizeof(elem) == 4)) {
+                    v = (f32x4){__uint_as_float(packed_out[0] << 16), __uint_as_float(packed_out[0] & 0xffff0000u),
+                                __uint_as_float(packed_out[1] << 16), __uint_as_float(packed_out[1] & 0xffff0000u)};
                 }
                 if (ep.bn_x) {
                     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)ep.bn_x, 0, y_bytes, 0x00020000);
@@ -781,7 +786,10 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                     st2 += v * v;
                 }
             }
-            store_frag<P, OUT32>(acc[s][nb], rs_y, voff);
+            if constexpr (OUT32 || sizeof(elem) == 4)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[s][nb]), rs_y, voff, 0, 0);
+            else
+                __builtin_amdgcn_raw_buffer_store_b64(packed_out, rs_y, voff, 0, 0);
         }
         if constexpr (STATS) {
             // sum over the 16 rows of the lane group: lane 15 of each group holds the total

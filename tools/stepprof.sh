@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=$1; shift
 out=gpurun_out/sp_$tag; rm -rf $out; mkdir -p $out
-env "$@" timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $out -o k -- python bench.py --no-cpu-baseline --kernel-reps 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/err.txt
+env "$@" timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $out -o k -- python bench.py --no-cpu-baseline --fp32-steps 0 --kernel-reps 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/err.txt
 python - <<PY
 import csv, json, collections
 rows = list(csv.DictReader(open("$out/k_kernel_stats.csv")))
