@@ -24,12 +24,35 @@ static inline uint32_t next_pow2(uint32_t x) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Cell-id hash table.  One 64-bit word per slot: (cell id : 32 | value : 32).  A single
-// atomicCAS inserts; because the key sits in the high half, atomicMin on the whole word keeps
-// the smallest value among inserts of the same key (first-touch numbering needs exactly that).
+// Cell-id hash table.  One 64-bit word per slot: (cell id : 64 - vbits | value : vbits).  A single
+// atomicCAS inserts; because the key sits in the high part, atomicMin on the whole word keeps the
+// smallest value among inserts of the same key (first-touch numbering needs exactly that).
+// The split is chosen per build (HashFmt): grids below 2^32 cells keep 32 value bits; larger grids
+// (1 cm voxels: batch x 2000^3 cells, SURVEY §7 "64-bit packed keys") take key bits from the value,
+// which only has to hold a row number — e.g. 2^40 cells with 2^24 rows.
 // Capacity is a power of two >= 2 * n (load factor <= 0.5), linear probing.
 // ---------------------------------------------------------------------------------------------
 #define DODA_HASH_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+typedef unsigned long long cellkey_t;
+
+struct HashFmt {
+    int vbits;                  // low bits holding the value
+    unsigned long long vmask;   // (1 << vbits) - 1
+};
+
+// key / value split for a grid of `cells` cells and values 0 .. n_values-1; false if 64 bits cannot hold both
+static inline bool make_hash_fmt(long double cells, unsigned long long n_values, HashFmt *f) {
+    int kbits = 1;
+    while (kbits < 63 && (long double)(1ull << kbits) < cells + 2.0L) ++kbits;   // all-ones key stays free
+    if ((long double)(1ull << kbits) < cells + 2.0L) return false;
+    int vb = 64 - kbits;
+    if (vb > 32) vb = 32;
+    if (n_values > (1ull << vb)) return false;
+    f->vbits = vb;
+    f->vmask = (1ull << vb) - 1ull;
+    return true;
+}
 
 __device__ __forceinline__ uint32_t hash_mix(uint32_t k) {
     k ^= k >> 16;
@@ -40,15 +63,19 @@ __device__ __forceinline__ uint32_t hash_mix(uint32_t k) {
     return k;
 }
 
+__device__ __forceinline__ uint32_t hash_key(cellkey_t k) {
+    return hash_mix((uint32_t)k ^ ((uint32_t)(k >> 32) * 0x9e3779b1u));
+}
+
 // insert (key, val); duplicates of key keep the minimum val.
-__device__ __forceinline__ void hash_insert_min(unsigned long long *tab, uint32_t mask,
-                                                uint32_t key, uint32_t val) {
-    const unsigned long long mine = ((unsigned long long)key << 32) | val;
-    uint32_t slot = hash_mix(key) & mask;
+__device__ __forceinline__ void hash_insert_min(unsigned long long *tab, uint32_t mask, HashFmt f,
+                                                cellkey_t key, uint32_t val) {
+    const unsigned long long mine = (key << f.vbits) | val;
+    uint32_t slot = hash_key(key) & mask;
     for (;;) {
         unsigned long long old = atomicCAS(&tab[slot], DODA_HASH_EMPTY, mine);
         if (old == DODA_HASH_EMPTY) return;
-        if ((uint32_t)(old >> 32) == key) {
+        if ((old >> f.vbits) == key) {
             if (mine < old) atomicMin(&tab[slot], mine);
             return;
         }
@@ -58,12 +85,12 @@ __device__ __forceinline__ void hash_insert_min(unsigned long long *tab, uint32_
 
 // returns the value stored for key, or -1.
 __device__ __forceinline__ int hash_find(const unsigned long long *__restrict__ tab,
-                                         uint32_t mask, uint32_t key) {
-    uint32_t slot = hash_mix(key) & mask;
+                                         uint32_t mask, HashFmt f, cellkey_t key) {
+    uint32_t slot = hash_key(key) & mask;
     for (;;) {
         unsigned long long cur = tab[slot];
         if (cur == DODA_HASH_EMPTY) return -1;
-        if ((uint32_t)(cur >> 32) == key) return (int)(uint32_t)cur;
+        if ((cur >> f.vbits) == key) return (int)(uint32_t)(cur & f.vmask);
         slot = (slot + 1) & mask;
     }
 }

@@ -8,7 +8,7 @@ extern "C" const char *doda_strerror(int status) {
         case DODA_OK: return "ok";
         case DODA_ERR_INVALID: return "invalid argument";
         case DODA_ERR_LAUNCH: return "HIP kernel launch failed";
-        case DODA_ERR_GRID_TOO_LARGE: return "batch*X*Y*Z does not fit a 32-bit cell id";
+        case DODA_ERR_GRID_TOO_LARGE: return "cell id (batch*X*Y*Z) and row number do not fit one 64-bit hash word";
         case DODA_ERR_UNSUPPORTED: return "size outside the compiled range";
         case DODA_ERR_WORKSPACE: return "workspace too small";
         case DODA_ERR_NOMEM: return "host allocation failed";

@@ -20,8 +20,8 @@ struct GridDesc {
     int X, Y, Z;  // spatial shape the cell ids are computed in
 };
 
-__device__ __forceinline__ uint32_t cell_id(int b, int x, int y, int z, const GridDesc g) {
-    return (uint32_t)((((long long)b * g.X + x) * g.Y + y) * g.Z + z);
+__device__ __forceinline__ cellkey_t cell_id(int b, int x, int y, int z, const GridDesc g) {
+    return (cellkey_t)((((long long)b * g.X + x) * g.Y + y) * g.Z + z);
 }
 
 // ---- SubM ---------------------------------------------------------------------------------
@@ -29,12 +29,12 @@ __device__ __forceinline__ uint32_t cell_id(int b, int x, int y, int z, const Gr
 // probe kernel only writes hits there (saves a memset launch per rulebook).
 __global__ __launch_bounds__(256) void subm_insert(const int4 *__restrict__ indices, int m,
                                                    GridDesc g, unsigned long long *tab,
-                                                   uint32_t mask, int32_t *__restrict__ nbr, int ld,
+                                                   uint32_t mask, HashFmt hf, int32_t *__restrict__ nbr, int ld,
                                                    int first_fill, int k3) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const int4 c = indices[t];
-    hash_insert_min(tab, mask, cell_id(c.x, c.y, c.z, c.w, g), (uint32_t)t);
+    hash_insert_min(tab, mask, hf, cell_id(c.x, c.y, c.z, c.w, g), (uint32_t)t);
     for (int o = first_fill; o < k3; ++o) nbr[(long long)o * ld + t] = -1;
 }
 
@@ -49,16 +49,16 @@ template <int KS>
 __global__ __launch_bounds__(256) void subm_probe(const int4 *__restrict__ indices, int m,
                                                   GridDesc g,
                                                   const unsigned long long *__restrict__ tab,
-                                                  uint32_t mask, int32_t *__restrict__ nbr,
+                                                  uint32_t mask, HashFmt hf, int32_t *__restrict__ nbr,
                                                   int ld) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const int4 c = indices[t];  // (b, x, y, z)
     constexpr int R = KS / 2, K3 = KS * KS * KS, NP = K3 / 2;   // offsets 0..NP-1 are probed
-    const uint32_t own = cell_id(c.x, c.y, c.z, c.w, g);
+    const cellkey_t own = cell_id(c.x, c.y, c.z, c.w, g);
     nbr[(long long)NP * ld + t] = t;   // centre
     if (NP == 0) return;
-    uint32_t key[NP > 0 ? NP : 1];
+    cellkey_t key[NP > 0 ? NP : 1];
     unsigned long long first[NP > 0 ? NP : 1];
 #pragma unroll
     for (int o = 0; o < NP; ++o) {
@@ -68,20 +68,20 @@ __global__ __launch_bounds__(256) void subm_probe(const int4 *__restrict__ indic
         // out-of-grid neighbours read the voxel's own slot chain head (a valid address) and are
         // discarded below through key == own
         key[o] = inb ? cell_id(c.x, x, y, z, g) : own;
-        first[o] = tab[hash_mix(key[o]) & mask];
+        first[o] = tab[hash_key(key[o]) & mask];
     }
 #pragma unroll
     for (int o = 0; o < NP; ++o) {
         int v = -1;
         if (key[o] != own) {
             const unsigned long long cur = first[o];
-            if ((uint32_t)(cur >> 32) == key[o]) v = (int)(uint32_t)cur;
+            if ((cur >> hf.vbits) == key[o]) v = (int)(uint32_t)(cur & hf.vmask);
             else if (cur != DODA_HASH_EMPTY) {   // collision: continue along the chain
-                uint32_t slot = (hash_mix(key[o]) + 1) & mask;
+                uint32_t slot = (hash_key(key[o]) + 1) & mask;
                 for (;;) {
                     const unsigned long long nx = tab[slot];
                     if (nx == DODA_HASH_EMPTY) break;
-                    if ((uint32_t)(nx >> 32) == key[o]) { v = (int)(uint32_t)nx; break; }
+                    if ((nx >> hf.vbits) == key[o]) { v = (int)(uint32_t)(nx & hf.vmask); break; }
                     slot = (slot + 1) & mask;
                 }
             }
@@ -94,20 +94,20 @@ __global__ __launch_bounds__(256) void subm_probe(const int4 *__restrict__ indic
 // ---- Down2 (kernel 2, stride 2, pad 0) ------------------------------------------------------
 __global__ __launch_bounds__(256) void down2_insert(const int4 *__restrict__ indices, int m,
                                                     GridDesc go, unsigned long long *tab,
-                                                    uint32_t mask, int32_t *__restrict__ off) {
+                                                    uint32_t mask, HashFmt hf, int32_t *__restrict__ off) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const int4 c = indices[j];
     off[j] = ((c.y & 1) * 2 + (c.z & 1)) * 2 + (c.w & 1);
     const int qx = c.y >> 1, qy = c.z >> 1, qz = c.w >> 1;
     if (c.y < 0 || c.z < 0 || c.w < 0 || qx >= go.X || qy >= go.Y || qz >= go.Z) return;
-    hash_insert_min(tab, mask, cell_id(c.x, qx, qy, qz, go), (uint32_t)j);
+    hash_insert_min(tab, mask, hf, cell_id(c.x, qx, qy, qz, go), (uint32_t)j);
 }
 
 __global__ __launch_bounds__(256) void down2_first(const int4 *__restrict__ indices, int m,
                                                    GridDesc go,
                                                    const unsigned long long *__restrict__ tab,
-                                                   uint32_t mask, int32_t *__restrict__ firstj,
+                                                   uint32_t mask, HashFmt hf, int32_t *__restrict__ firstj,
                                                    int32_t *__restrict__ flag) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void down2_first(const int4 *__restrict__ indi
     const int qx = c.y >> 1, qy = c.z >> 1, qz = c.w >> 1;
     int f = -1;
     if (!(c.y < 0 || c.z < 0 || c.w < 0 || qx >= go.X || qy >= go.Y || qz >= go.Z))
-        f = hash_find(tab, mask, cell_id(c.x, qx, qy, qz, go));
+        f = hash_find(tab, mask, hf, cell_id(c.x, qx, qy, qz, go));
     firstj[j] = f;
     flag[j] = (f == j) ? 1 : 0;
 }
@@ -264,33 +264,33 @@ __device__ __forceinline__ void for_valid_out(const int4 c, const ConvGeo &g, F 
 }
 
 __global__ __launch_bounds__(256) void conv_touch(const int4 *__restrict__ indices, int m, ConvGeo g,
-                                                  unsigned long long *tab, uint32_t mask) {
+                                                  unsigned long long *tab, uint32_t mask, HashFmt hf) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const int4 c = indices[j];
     for_valid_out(c, g, [&](int rank, int ox, int oy, int oz, int) {
-        hash_insert_min(tab, mask, cell_id(c.x, ox, oy, oz, g.out), (uint32_t)j * (uint32_t)g.K + (uint32_t)rank);
+        hash_insert_min(tab, mask, hf, cell_id(c.x, ox, oy, oz, g.out), (uint32_t)j * (uint32_t)g.K + (uint32_t)rank);
     });
 }
 
 // flag[j*K + rank] = 1 where that candidate is the first touch of its output cell
 __global__ __launch_bounds__(256) void conv_first(const int4 *__restrict__ indices, int m, ConvGeo g,
                                                   const unsigned long long *__restrict__ tab,
-                                                  uint32_t mask, int32_t *__restrict__ flag) {
+                                                  uint32_t mask, HashFmt hf, int32_t *__restrict__ flag) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const int4 c = indices[j];
     for (int r = 0; r < g.K; ++r) flag[(long long)j * g.K + r] = 0;
     for_valid_out(c, g, [&](int rank, int ox, int oy, int oz, int) {
         const uint32_t mine = (uint32_t)j * (uint32_t)g.K + (uint32_t)rank;
-        if ((uint32_t)hash_find(tab, mask, cell_id(c.x, ox, oy, oz, g.out)) == mine) flag[mine] = 1;
+        if ((uint32_t)hash_find(tab, mask, hf, cell_id(c.x, ox, oy, oz, g.out)) == mine) flag[mine] = 1;
     });
 }
 
 // the first-touch candidates write their output's coordinates and replace the table value (touch
 // key) of their cell by the output id
 __global__ __launch_bounds__(256) void conv_number(const int4 *__restrict__ indices, int m, ConvGeo g,
-                                                   unsigned long long *tab, uint32_t mask,
+                                                   unsigned long long *tab, uint32_t mask, HashFmt hf,
                                                    const int32_t *__restrict__ flag,
                                                    const int32_t *__restrict__ rank_of,
                                                    int4 *__restrict__ out_indices) {
@@ -302,24 +302,24 @@ __global__ __launch_bounds__(256) void conv_number(const int4 *__restrict__ indi
         if (!flag[e]) return;
         const int id = rank_of[e];
         out_indices[id] = make_int4(c.x, ox, oy, oz);
-        const uint32_t key = cell_id(c.x, ox, oy, oz, g.out);
-        uint32_t slot = hash_mix(key) & mask;
-        while ((uint32_t)(tab[slot] >> 32) != key) slot = (slot + 1) & mask;   // present by construction
-        tab[slot] = ((unsigned long long)key << 32) | (uint32_t)id;
+        const cellkey_t key = cell_id(c.x, ox, oy, oz, g.out);
+        uint32_t slot = hash_key(key) & mask;
+        while ((tab[slot] >> hf.vbits) != key) slot = (slot + 1) & mask;   // present by construction
+        tab[slot] = (key << hf.vbits) | (uint32_t)id;
     });
 }
 
 // tbl[off][out] = j and tbl_rev[off][j] = out for every (input, output, offset) triple
 __global__ __launch_bounds__(256) void conv_tables(const int4 *__restrict__ indices, int m, ConvGeo g,
                                                    const unsigned long long *__restrict__ tab,
-                                                   uint32_t mask, int32_t *__restrict__ tbl, int ld_out,
+                                                   uint32_t mask, HashFmt hf, int32_t *__restrict__ tbl, int ld_out,
                                                    int32_t *__restrict__ tbl_rev, int ld_in) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const int4 c = indices[j];
     for (int o = 0; o < g.K; ++o) tbl_rev[(long long)o * ld_in + j] = -1;
     for_valid_out(c, g, [&](int, int ox, int oy, int oz, int off) {
-        const int out = hash_find(tab, mask, cell_id(c.x, ox, oy, oz, g.out));
+        const int out = hash_find(tab, mask, hf, cell_id(c.x, ox, oy, oz, g.out));
         tbl_rev[(long long)off * ld_in + j] = out;
         tbl[(long long)off * ld_out + out] = j;
     });
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void conv_tables(const int4 *__restrict__ indi
 __global__ __launch_bounds__(256) void subm_probe_generic(const int4 *__restrict__ indices, int m,
                                                           GridDesc g, int k0, int k1, int k2,
                                                           const unsigned long long *__restrict__ tab,
-                                                          uint32_t mask, int32_t *__restrict__ nbr, int ld) {
+                                                          uint32_t mask, HashFmt hf, int32_t *__restrict__ nbr, int ld) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const int4 c = indices[t];
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void subm_probe_generic(const int4 *__restrict
                 const int x = c.y + a - k0 / 2, y = c.z + b - k1 / 2, z = c.w + d - k2 / 2;
                 int v = -1;
                 if (x >= 0 && x < g.X && y >= 0 && y < g.Y && z >= 0 && z < g.Z)
-                    v = hash_find(tab, mask, cell_id(c.x, x, y, z, g));
+                    v = hash_find(tab, mask, hf, cell_id(c.x, x, y, z, g));
                 nbr[(long long)o * ld + t] = v;
             }
 }
@@ -373,10 +373,11 @@ RbWs carve(void *ws, int m) {
     return r;
 }
 
-bool grid_fits(int batch, int X, int Y, int Z) {
+// key / value split of the hash words for this grid and value range (values are row numbers, or
+// row * K + rank in the generic builder); false = 64 bits cannot hold both (DODA_ERR_GRID_TOO_LARGE)
+bool grid_fmt(int batch, int X, int Y, int Z, unsigned long long max_value, HashFmt *hf) {
     if (batch <= 0 || X <= 0 || Y <= 0 || Z <= 0) return false;
-    const long double cells = (long double)batch * X * Y * Z;
-    return cells < 4294967295.0L;
+    return make_hash_fmt((long double)batch * X * Y * Z, max_value, hf);
 }
 }  // namespace
 
@@ -389,7 +390,8 @@ extern "C" int doda_rulebook_subm(const int32_t *indices, int32_t m, const int32
     if (ksize != 1 && ksize != 3) return DODA_ERR_UNSUPPORTED;
     if (m == 0) return DODA_OK;
     if (!indices || !nbr || !ws) return DODA_ERR_INVALID;
-    if (!grid_fits(batch, shape_h[0], shape_h[1], shape_h[2])) return DODA_ERR_GRID_TOO_LARGE;
+    HashFmt hf;
+    if (!grid_fmt(batch, shape_h[0], shape_h[1], shape_h[2], (unsigned long long)m, &hf)) return DODA_ERR_GRID_TOO_LARGE;
     const RbWs w = carve(ws, m);
     if (ws_bytes < w.total) return DODA_ERR_WORKSPACE;
     hipStream_t s = as_stream(stream);
@@ -398,14 +400,14 @@ extern "C" int doda_rulebook_subm(const int32_t *indices, int32_t m, const int32
     if (ksize == 1) {
         // identity table
         hipLaunchKernelGGL((subm_probe<1>), dim3(grid), dim3(256), 0, s, (const int4 *)indices, m,
-                           g, w.tab, w.cap - 1, nbr, ld);
+                           g, w.tab, w.cap - 1, hf, nbr, ld);
         return doda_check_launch();
     }
     hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
     hipLaunchKernelGGL(subm_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g,
-                       w.tab, w.cap - 1, nbr, ld, 14, 27);   // + mirrored half := -1
+                       w.tab, w.cap - 1, hf, nbr, ld, 14, 27);   // + mirrored half := -1
     hipLaunchKernelGGL((subm_probe<3>), dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g,
-                       w.tab, w.cap - 1, nbr, ld);
+                       w.tab, w.cap - 1, hf, nbr, ld);
     return doda_check_launch();
 }
 
@@ -426,15 +428,16 @@ extern "C" int doda_rulebook_down2_assign(const int32_t *indices, int32_t m,
     go.Y = (shape_h[1] - 2) / 2 + 1;
     go.Z = (shape_h[2] - 2) / 2 + 1;
     if (shape_h[0] < 2 || shape_h[1] < 2 || shape_h[2] < 2) return DODA_ERR_INVALID;
-    if (!grid_fits(batch, go.X, go.Y, go.Z)) return DODA_ERR_GRID_TOO_LARGE;
+    HashFmt hf;
+    if (!grid_fmt(batch, go.X, go.Y, go.Z, (unsigned long long)m, &hf)) return DODA_ERR_GRID_TOO_LARGE;
     const RbWs w = carve(ws, m);
     if (ws_bytes < w.total) return DODA_ERR_WORKSPACE;
     const int grid = div_up(m, 256);
     hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
     hipLaunchKernelGGL(down2_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, go,
-                       w.tab, w.cap - 1, off);
+                       w.tab, w.cap - 1, hf, off);
     hipLaunchKernelGGL(down2_first, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, go,
-                       w.tab, w.cap - 1, w.a /*firstj*/, w.b /*flag*/);
+                       w.tab, w.cap - 1, hf, w.a /*firstj*/, w.b /*flag*/);
     int st = exclusive_scan_i32(w.b, w.c /*rank*/, m, counts_out, w.scan, s);
     if (st != DODA_OK) return st;
     hipLaunchKernelGGL(down2_finalize, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, w.a,
@@ -546,13 +549,14 @@ extern "C" int doda_rulebook_conv_assign(const int32_t *indices, int32_t m, cons
     hipStream_t s = as_stream(stream);
     if (m == 0) { hipMemsetAsync(count_out, 0, sizeof(int32_t), s); return DODA_OK; }
     if (!indices || !ws) return DODA_ERR_INVALID;
-    if (!grid_fits(batch, g.out.X, g.out.Y, g.out.Z)) return DODA_ERR_GRID_TOO_LARGE;
+    HashFmt hf;   // values are touch keys j * K + rank
+    if (!grid_fmt(batch, g.out.X, g.out.Y, g.out.Z, (unsigned long long)m * g.K, &hf)) return DODA_ERR_GRID_TOO_LARGE;
     const ConvWs w = carve_conv(ws, m, g.K);
     if (ws_bytes < w.total) return DODA_ERR_WORKSPACE;
     const int grid = div_up(m, 256);
     hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
-    hipLaunchKernelGGL(conv_touch, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1);
-    hipLaunchKernelGGL(conv_first, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1,
+    hipLaunchKernelGGL(conv_touch, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1, hf);
+    hipLaunchKernelGGL(conv_first, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1, hf,
                        w.flag);
     return exclusive_scan_i32(w.flag, w.rank, m * g.K, count_out, w.scan, s);
 }
@@ -570,15 +574,16 @@ extern "C" int doda_rulebook_conv_tables(const int32_t *indices, int32_t m, cons
     if (!make_geo(shape_h, ksize_h, stride_h, pad_h, dil_h, &g)) return DODA_ERR_INVALID;
     if (g.K > 27) return DODA_ERR_UNSUPPORTED;
     if (!indices || !out_indices || !tbl || !tbl_rev || !ws) return DODA_ERR_INVALID;
-    (void)batch;
+    HashFmt hf;   // the split doda_rulebook_conv_assign used for this table
+    if (!grid_fmt(batch, g.out.X, g.out.Y, g.out.Z, (unsigned long long)m * g.K, &hf)) return DODA_ERR_GRID_TOO_LARGE;
     const ConvWs w = carve_conv(ws, m, g.K);
     if (ws_bytes < w.total) return DODA_ERR_WORKSPACE;
     hipStream_t s = as_stream(stream);
     const int grid = div_up(m, 256);
     if (m_out > 0) hipMemsetAsync(tbl, 0xFF, (size_t)g.K * ld_out * 4, s);
-    hipLaunchKernelGGL(conv_number, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1,
+    hipLaunchKernelGGL(conv_number, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1, hf,
                        w.flag, w.rank, (int4 *)out_indices);
-    hipLaunchKernelGGL(conv_tables, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1,
+    hipLaunchKernelGGL(conv_tables, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1, hf,
                        tbl, ld_out, tbl_rev, ld_in);
     return doda_check_launch();
 }
@@ -594,16 +599,17 @@ extern "C" int doda_rulebook_subm_generic(const int32_t *indices, int32_t m, con
     if (K > 27) return DODA_ERR_UNSUPPORTED;
     if (m == 0) return DODA_OK;
     if (!indices || !nbr || !ws) return DODA_ERR_INVALID;
-    if (!grid_fits(batch, shape_h[0], shape_h[1], shape_h[2])) return DODA_ERR_GRID_TOO_LARGE;
+    HashFmt hf;
+    if (!grid_fmt(batch, shape_h[0], shape_h[1], shape_h[2], (unsigned long long)m, &hf)) return DODA_ERR_GRID_TOO_LARGE;
     const RbWs w = carve(ws, m);
     if (ws_bytes < w.total) return DODA_ERR_WORKSPACE;
     hipStream_t s = as_stream(stream);
     const GridDesc g{shape_h[0], shape_h[1], shape_h[2]};
     const int grid = div_up(m, 256);
     hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
-    hipLaunchKernelGGL(subm_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1,
+    hipLaunchKernelGGL(subm_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1, hf,
                        nbr, ld, K, K);   // no prefill
     hipLaunchKernelGGL(subm_probe_generic, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g,
-                       ksize_h[0], ksize_h[1], ksize_h[2], w.tab, w.cap - 1, nbr, ld);
+                       ksize_h[0], ksize_h[1], ksize_h[2], w.tab, w.cap - 1, hf, nbr, ld);
     return doda_check_launch();
 }

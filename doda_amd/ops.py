@@ -187,6 +187,7 @@ def rulebook_down2(indices, spatial_shape, batch_size):
 
 
 def _i3(v):
+    v = [v] * 3 if isinstance(v, int) else list(v)
     arr = (C.c_int32 * 3)(*[int(x) for x in v])
     return arr
 

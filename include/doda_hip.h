@@ -28,7 +28,7 @@ extern "C" {
 #define DODA_OK 0
 #define DODA_ERR_INVALID (-1)        /* bad argument (null pointer, negative size, bad mode) */
 #define DODA_ERR_LAUNCH (-2)         /* hipGetLastError() != hipSuccess after a launch          */
-#define DODA_ERR_GRID_TOO_LARGE (-3) /* batch*X*Y*Z >= 2^32-1: cell id does not fit the hash key */
+#define DODA_ERR_GRID_TOO_LARGE (-3) /* bits(batch*X*Y*Z) + bits(rows) > 64: cell id and row number do not fit one hash word */
 #define DODA_ERR_UNSUPPORTED (-4)    /* channel count / k outside the compiled range            */
 #define DODA_ERR_WORKSPACE (-5)      /* workspace smaller than the *_workspace_bytes answer     */
 #define DODA_ERR_NOMEM (-6)          /* host allocation failed (host entry points only)         */

@@ -590,11 +590,8 @@ def test_full_size_tail_layer_properties(native_lib, dtype):
 
 def test_one_cm_scene_rulebooks_and_step(native_lib, oracle):
     """BASELINE config 5 shape: 1 cm voxels, ~500 k active voxels in one scene.  Rulebooks bit-exact
-    against the oracle at that size, a U-Net training step runs (finite loss, every gradient finite), and
-    the hash-key guard: a grid of >= 2^32 - 1 cells is refused with DODA_ERR_GRID_TOO_LARGE, one just
-    below is accepted."""
+    against the oracle at that size, and a U-Net training step runs (finite loss, every gradient finite)."""
     from doda_amd import ops
-    from doda_amd._lib import DodaNativeError
     from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
     from doda_amd.scene import make_batch
     d = dev()
@@ -618,11 +615,59 @@ def test_one_cm_scene_rulebooks_and_step(native_lib, oracle):
     loss.backward()
     torch.cuda.synchronize()
     assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in net.parameters())
-    # hash key = 32-bit cell id
+
+
+def _huge_grid_scene(seed, batch, shape, n):
+    """n distinct voxels in clusters spread over a grid of more than 2^32 cells, some in the last cells
+    of the last sample (largest cell ids), with neighbours inside each cluster."""
+    rng = np.random.RandomState(seed)
+    centres = np.stack([rng.randint(0, batch, 64)] + [rng.randint(4, s - 4, 64) for s in shape], 1)
+    centres[0] = [batch - 1] + [s - 3 for s in shape]
+    centres[1] = [0, 2, 2, 2]
+    pick = centres[rng.randint(0, 64, 2 * n)]
+    pts = pick + np.concatenate([np.zeros((2 * n, 1), np.int64), rng.randint(-2, 3, (2 * n, 3))], 1)
+    pts[:, 1:] = np.clip(pts[:, 1:], 0, np.array(shape) - 1)
+    pts = np.unique(pts, axis=0)
+    pts = pts[rng.permutation(len(pts))][:n]
+    return np.ascontiguousarray(pts, dtype=np.int32)
+
+
+def test_rulebooks_on_a_grid_of_more_than_2_pow_32_cells(native_lib, oracle):
+    """batch x X x Y x Z >= 2^32 (batch 4 of 1 cm scenes, 2000 x 2000 x 600 each = 9.6e9 cells): the hash
+    words give the cell id more than 32 bits and the row number fewer (common.hpp HashFmt); all three
+    rulebook builders stay bit-exact against the oracle, which keys on 64-bit cell ids.  A grid whose
+    cell id and row number cannot share 64 bits is still refused with DODA_ERR_GRID_TOO_LARGE."""
+    from doda_amd import ops
+    from doda_amd._lib import DodaNativeError
+    d = dev()
+    batch, shape = 4, [2000, 2000, 600]
+    idx_h = _huge_grid_scene(5, batch, shape, 3000)
+    cell = ((idx_h[:, 0].astype(np.int64) * shape[0] + idx_h[:, 1]) * shape[1] + idx_h[:, 2]) * shape[2] + idx_h[:, 3]
+    assert cell.max() >= 2 ** 33 and len(np.unique(cell)) == len(cell)
+    idx = torch.from_numpy(idx_h).to(d)
+    m = idx.shape[0]
+    pairs, pn = oracle.indice_pairs_subm(idx_h, batch, shape, 3)
+    assert pn.sum() > 4 * m                                        # the clusters do have neighbours
+    got, num = ops.rulebook_pairs(ops.rulebook_subm(idx, shape, batch, 3), m, flip=True)
+    assert np.array_equal(num.cpu().numpy(), pn) and np.array_equal(got.cpu().numpy(), pairs)
+    oi, dpairs, dpn, oshape = oracle.indice_pairs_conv(idx_h, batch, shape, 2, 2, 0, 1)
+    out_idx, child, par_off, out_shape = ops.rulebook_down2(idx, shape, batch)
+    assert out_shape == oshape and np.array_equal(out_idx.cpu().numpy(), oi)
+    gp, gn = ops.rulebook_pairs(par_off, m, flip=False)
+    assert np.array_equal(gn.cpu().numpy(), dpn) and np.array_equal(gp.cpu().numpy(), dpairs)
+    # generic builder (3x3x3 stride 1 padding 1: the output grid is as large as the input grid; the
+    # hash values are row * 27 + rank)
+    oi, cpairs, cpn, oshape = oracle.indice_pairs_conv(idx_h, batch, shape, 3, 1, 1, 1)
+    out_idx, tbl, tbl_rev, out_shape = ops.rulebook_conv(idx, shape, batch, 3, 1, 1, 1)
+    assert out_shape == oshape and np.array_equal(out_idx.cpu().numpy(), oi)
+    gp, gn = ops.rulebook_pairs(tbl_rev, m, flip=False)
+    assert np.array_equal(gn.cpu().numpy(), cpn) and np.array_equal(gp.cpu().numpy(), cpairs)
+    # the limit that remains: bits(cell id) + bits(row number) <= 64
     few = torch.tensor([[0, 1, 2, 3], [1, 5, 6, 7]], dtype=torch.int32, device=d)
+    ops.rulebook_subm(few, [2048, 2048, 512], 2, 3)                # 2^32 cells: refused before, fine now
+    ops.rulebook_subm(few, [1 << 20, 1 << 20, 1 << 20], 4, 3)      # 2^62 cells, 2 rows
     with pytest.raises(DodaNativeError, match="-3|grid|GRID"):
-        ops.rulebook_subm(few, [2048, 2048, 512], 2, 3)            # 2 * 2^31 cells
-    ops.rulebook_subm(few, [2048, 2048, 511], 2, 3)                # just below 2^32 - 1
+        ops.rulebook_subm(few, [1 << 21, 1 << 21, 1 << 21], 2, 3)  # 2^64 cells
 
 
 def test_python_glue_without_the_compiled_extension(native_lib):

@@ -20,7 +20,7 @@ def test_header_symbols_all_exported(native_lib):
     for name in declared:
         assert hasattr(native_lib, name), name
     assert native_lib.doda_abi_version() == 2
-    assert native_lib.doda_strerror(-3).decode().startswith("batch*X*Y*Z")
+    assert native_lib.doda_strerror(-3).decode().startswith("cell id")
 
 
 def test_product_never_imports_oracle():
