@@ -240,6 +240,7 @@ def main():
     cfg = default_cfg()
     from doda_amd.spconv import functional as Fsp
     from doda_amd.model import PyramidPrefetcher
+    from doda_amd.optim import FusedSGD
     from doda_amd import spconv
     deferred = Fsp.set_deferred_wgrad(True)
     labels = batch_dev["labels"]
@@ -253,7 +254,8 @@ def main():
         # bucketed all-reduces over RCCL; torch DDP (the reference's wrapper) when the extension is absent
         model = net if deferred else ddist.wrap_ddp(net, local_rank)
         reducer = ddist.GradAllReduce(net) if deferred else None
-        opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)
+        # torch.optim.SGD with its update in one native launch (doda_amd.optim; same state and arithmetic)
+        opt = FusedSGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
         fdt = torch.float32 if dtype_name == "f32" else torch.bfloat16
         # rulebooks ride in the data pipeline: those of the NEXT batch are built on a helper thread + side
         # stream while this step is issued (every step still builds one full pyramid; nothing is cached)

@@ -80,6 +80,9 @@ _SIGNATURES = {
                                        c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "doda_bn_relu_bwd_stats": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "doda_sgd_multi_desc_bytes": (c_sz, [c_i32]),
+    "doda_sgd_multi": (c_i32, [c_vp, c_i32, C.c_double, C.c_double, C.c_double, C.c_double, c_i32, c_i32, c_vp,
+                               c_sz, c_vp]),
     "doda_bn_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "doda_bn_relu_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

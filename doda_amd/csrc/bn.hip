@@ -436,6 +436,33 @@ __device__ __forceinline__ void block_sum_d4(double (&v)[4], double (*lds)[4]) {
     for (int q = 0; q < 4; ++q) v[q] = (lds[0][q] + lds[1][q]) + (lds[2][q] + lds[3][q]);
 }
 
+// this thread's share of the partial rows of channel quad f.  Four rows per trip with all eight loads
+// issued before the first add: a level-1 layer has ~4700 partial rows and four blocks to reduce them, so
+// the kernel is a chain of L2 round trips (13.4 us with one row per trip)
+__device__ __forceinline__ void sum_partials(const float *__restrict__ stats, int rows, int c, int f,
+                                             double (&s1)[4], double (&s2)[4]) {
+    int r = threadIdx.x;
+    for (; r + 3 * BN_BLOCK < rows; r += 4 * BN_BLOCK) {
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float *p = stats + (long long)(r + k * BN_BLOCK) * 2 * c + f * 4;
+            a[k] = *reinterpret_cast<const f32x4 *>(p);
+            b[k] = *reinterpret_cast<const f32x4 *>(p + c);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s1[q] += (double)a[k][q]; s2[q] += (double)b[k][q]; }
+    }
+    for (; r < rows; r += BN_BLOCK) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(stats + (long long)r * 2 * c + f * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(stats + (long long)r * 2 * c + c + f * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s1[q] += (double)a[q]; s2[q] += (double)b[q]; }
+    }
+}
+
 __global__ __launch_bounds__(BN_BLOCK) void bn_fwd_final_stats(const float *__restrict__ stats, int rows, int m, int c,
                                                                float eps, float momentum, float *__restrict__ mean,
                                                                float *__restrict__ invstd,
@@ -452,12 +479,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_fwd_final_stats(const float *__re
     }
     if (threadIdx.x == 0 && f == 0 && nbt) n_tracked = *nbt;
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    for (int r = threadIdx.x; r < rows; r += BN_BLOCK) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(stats + (long long)r * 2 * c + f * 4);
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(stats + (long long)r * 2 * c + c + f * 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { s1[q] += (double)a[q]; s2[q] += (double)b[q]; }
-    }
+    sum_partials(stats, rows, c, f, s1, s2);
     block_sum_d4(s1, lds);
     block_sum_d4(s2, lds);
     if (threadIdx.x != 0) return;
@@ -492,12 +514,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_final_stats(const float *__re
     const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
     const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + f * 4);
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    for (int r = threadIdx.x; r < rows; r += BN_BLOCK) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(stats + (long long)r * 2 * c + f * 4);
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(stats + (long long)r * 2 * c + c + f * 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { s1[q] += (double)a[q]; s2[q] += (double)b[q]; }
-    }
+    sum_partials(stats, rows, c, f, s1, s2);
     block_sum_d4(s1, lds);
     block_sum_d4(s2, lds);
     if (threadIdx.x != 0) return;

@@ -63,6 +63,9 @@ __device__ __forceinline__ uint32_t hash_mix(uint32_t k) {
     return k;
 }
 
+// (A home slot that keeps the eight cells of a z-run in one 64-byte line — mix(k >> 3) * 8 + (k & 7) — was
+// measured: the occupied runs cluster, absent neighbours walk through them, and the level-1 probe kernel
+// went from 117 to 280 us.)
 __device__ __forceinline__ uint32_t hash_key(cellkey_t k) {
     return hash_mix((uint32_t)k ^ ((uint32_t)(k >> 32) * 0x9e3779b1u));
 }

@@ -402,6 +402,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce4(const float4 *__restrict__ 
 struct Plan {
     int TA, TB, OGW, n_og, n_tag, n_tbg, R, rows_per_chunk;
 };
+static const int MULTI_MIN_ROWS = getenv("DODA_WGRAD_MIN_ROWS") ? atoi(getenv("DODA_WGRAD_MIN_ROWS")) : 512;
 
 // multi: the job is one of many in a doda_spconv_wgrad_multi launch — the other layers fill the chip,
 // so a layer needs far fewer row chunks (each chunk costs K*ca*cb*4 bytes of partials to write and reduce)
@@ -427,7 +428,11 @@ Plan make_plan(int K, int ca, int cb, int n_rows, int elem_bytes, bool multi = f
     // multi (whole U-Net step, wgrad + reduce): 1024 -> 1.86 ms, 512 -> 1.67, 256 -> 1.67, 128 -> 1.99
     const int target = multi ? 512 : ((p.TA * p.TB == 4) ? 512 : 1024);
     int R = div_up(target, gy);         // blocks over the whole grid
-    const int max_r = div_up(rows, RT);
+    // multi: at least MULTI_MIN_ROWS rows per chunk.  Every chunk writes K*ca*cb*4 bytes of partials; with
+    // 512 blocks per job the coarse levels (64..112 channels, a few thousand rows) wrote and re-read
+    // 5-28 MB per layer for a few hundred rows per chunk, and the launch holds ~40 other jobs to fill the
+    // chip with anyway
+    const int max_r = multi ? (rows / MULTI_MIN_ROWS > 1 ? rows / MULTI_MIN_ROWS : 1) : div_up(rows, RT);
     if (R > max_r) R = max_r;
     if (R < 1) R = 1;
     p.rows_per_chunk = div_up(div_up(rows, R), RT) * RT;

@@ -712,6 +712,41 @@ std::vector<at::Tensor> bn_relu_pass(const at::Tensor &x, const at::Tensor &weig
 
 }  // namespace
 
+// ---- optimizer step: all parameters in one launch (doda_sgd_multi) ------------------------------------
+void sgd_step(const std::vector<at::Tensor> &params, const std::vector<at::Tensor> &grads,
+              const std::vector<at::Tensor> &bufs, const std::vector<int64_t> &first, double lr, double momentum,
+              double dampening, double weight_decay, bool nesterov, bool maximize) {
+    const size_t n = params.size();
+    if (n == 0) return;
+    TORCH_CHECK(grads.size() == n && first.size() == n && (momentum == 0.0 || bufs.size() == n),
+                "doda sgd_step: list lengths differ");
+    std::vector<doda_sgd_tensor> t(n);
+    const auto dev = params[0].device();
+    for (size_t k = 0; k < n; ++k) {
+        const at::Tensor &p = params[k], &g = grads[k];
+        TORCH_CHECK(p.is_cuda() && p.device() == dev && g.device() == dev && p.scalar_type() == at::kFloat &&
+                    g.scalar_type() == at::kFloat && p.is_contiguous() && g.is_contiguous() && g.sizes() == p.sizes(),
+                    "doda sgd_step: parameters and gradients must be contiguous fp32 tensors on one device");
+        t[k].p = (float *)p.data_ptr();
+        t[k].g = (const float *)g.data_ptr();
+        t[k].buf = nullptr;
+        if (momentum != 0.0) {
+            const at::Tensor &b = bufs[k];
+            TORCH_CHECK(b.defined() && b.device() == dev && b.scalar_type() == at::kFloat && b.is_contiguous() &&
+                        b.sizes() == p.sizes(), "doda sgd_step: bad momentum buffer");
+            t[k].buf = (float *)b.data_ptr();
+        }
+        t[k].n = p.numel();
+        t[k].first_step = first[k] ? 1 : 0;
+        t[k].reserved = 0;
+    }
+    c10::DeviceGuard guard(dev);
+    const size_t nb = doda_sgd_multi_desc_bytes((int32_t)n);
+    at::Tensor desc = at::empty({(int64_t)nb}, params[0].options().dtype(at::kByte));
+    check(doda_sgd_multi(t.data(), (int32_t)n, lr, momentum, dampening, weight_decay, nesterov ? 1 : 0,
+                         maximize ? 1 : 0, desc.data_ptr(), nb, stream_of(params[0])), "doda_sgd_multi");
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("indice_conv", &indice_conv, "sparse conv (gather table) with autograd",
           py::arg("features"), py::arg("weight"), py::arg("fwd_tbl"), py::arg("bwd_tbl"), py::arg("n_out"),
@@ -756,6 +791,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           "queue conv weight gradients during backward and issue them in one multi-layer call at its end");
     m.def("get_defer_wgrad", []() { return g_defer_wgrad; });
     m.def("flush_wgrads", &flush_wgrads);
+    m.def("sgd_step", &sgd_step, "torch.optim.SGD's update of all parameters in one launch",
+          py::call_guard<py::gil_scoped_release>());
     m.def("abi_version", []() { return doda_abi_version(); });
     m.def("built_for_abi", []() { return (int)DODA_ABI_VERSION; });
 }

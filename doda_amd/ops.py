@@ -596,3 +596,33 @@ def cross_entropy_bwd(logits, labels, lse, out, grad, ignore_index):
     check(lib().doda_cross_entropy_bwd(_p(logits), _p(labels), _p(lse), _p(out), _p(grad), n, c, int(ignore_index),
                                        _p(d), _stream()), "doda_cross_entropy_bwd")
     return d
+
+
+# ---- optimizer step -------------------------------------------------------------------------------
+class _SgdTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("buf", C.c_void_p), ("n", C.c_int64),
+                ("first_step", C.c_int32), ("reserved", C.c_int32)]
+
+
+def sgd_multi(params, grads, bufs, first, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False,
+              maximize=False):
+    """torch.optim.SGD's update of all (param, grad, momentum buffer) triples in one launch (doda_sgd_multi).
+    fp32 contiguous device tensors; bufs[k] may be None when momentum == 0; first[k]: buffer not initialised."""
+    n = len(params)
+    if n == 0:
+        return
+    dev = params[0].device
+    arr = (_SgdTensor * n)()
+    for k, (p, g, b) in enumerate(zip(params, grads, bufs)):
+        for t in (p, g) + ((b,) if b is not None else ()):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev or not t.is_cuda:
+                raise ValueError("sgd_multi needs contiguous fp32 tensors on one HIP device")
+        if g.shape != p.shape or (b is not None and b.shape != p.shape):
+            raise ValueError("sgd_multi: shape mismatch")
+        arr[k].p, arr[k].g, arr[k].buf = p.data_ptr(), g.data_ptr(), (b.data_ptr() if b is not None else None)
+        arr[k].n, arr[k].first_step = p.numel(), int(bool(first[k]))
+    nbytes = lib().doda_sgd_multi_desc_bytes(n)
+    desc = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib().doda_sgd_multi(C.cast(arr, C.c_void_p), n, float(lr), float(momentum), float(dampening),
+                               float(weight_decay), int(bool(nesterov)), int(bool(maximize)), _p(desc), nbytes,
+                               _stream()), "doda_sgd_multi")

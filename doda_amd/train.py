@@ -137,6 +137,10 @@ def build_optimizer(optim_cfg, model, fused=None):
     if fused:
         kw["fused"] = True
     if kind == "sgd":
+        if fused and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            from .optim import FusedSGD   # torch.optim.SGD, update of all tensors in one native launch
+            return FusedSGD(params, lr=optim_cfg.base_lr, momentum=optim_cfg.momentum,
+                            weight_decay=optim_cfg.weight_decay)
         return torch.optim.SGD(params, lr=optim_cfg.base_lr, momentum=optim_cfg.momentum,
                                weight_decay=optim_cfg.weight_decay, **kw)
     if kind == "adam":

@@ -409,6 +409,28 @@ int doda_cross_entropy_bwd(const float *logits, const int64_t *labels, const flo
                            const float *grad, int32_t n, int32_t c, int64_t ignore_index, float *dlogits,
                            doda_stream_t stream);
 
+/* ---- optimizer step -------------------------------------------------------------------------------
+ * SGD over all parameter tensors of a network in one launch (replaces the five multi-tensor launches of
+ * torch.optim.SGD(fused=True) the reference's trainer would issue per step: util/common_utils.py:196-215,
+ * tool/train.py:255-262 optimizer.step()).  torch's update rule term by term:
+ *   g' = g (+ weight_decay * p);  buf = first_step ? g' : momentum * buf + (1 - dampening) * g';
+ *   g'' = nesterov ? g' + momentum * buf : buf  (g' when momentum == 0);  p -= lr * g''
+ * with the hyper-parameters as doubles.  p, g, buf: fp32 device arrays of n elements (buf may be NULL
+ * when momentum == 0); first_step: the buffer holds no value yet.  desc_dev: device scratch of
+ * doda_sgd_multi_desc_bytes(n_tensors) bytes, owned by the call until the stream has passed it. */
+typedef struct {
+    float *p;
+    const float *g;
+    float *buf;
+    int64_t n;
+    int32_t first_step;
+    int32_t reserved;
+} doda_sgd_tensor;
+size_t doda_sgd_multi_desc_bytes(int32_t n_tensors);
+int doda_sgd_multi(const doda_sgd_tensor *tensors_h, int32_t n_tensors, double lr, double momentum,
+                   double dampening, double weight_decay, int32_t nesterov, int32_t maximize, void *desc_dev,
+                   size_t desc_bytes, doda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -681,3 +681,51 @@ def test_python_glue_without_the_compiled_extension(native_lib):
                         "golden or bf16_tracks"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("momentum,dampening,nesterov,wd", [(0.9, 0.0, False, 1e-4), (0.9, 0.0, True, 1e-4),
+                                                            (0.8, 0.1, False, 0.0), (0.0, 0.0, False, 5e-4)])
+def test_fused_sgd_is_torch_sgd(native_lib, momentum, dampening, nesterov, wd):
+    """doda_amd.optim.FusedSGD (one launch for all tensors) against torch.optim.SGD: bit-identical to torch's
+    fused multi-tensor path, within an ulp of its single-tensor path (float instead of double products);
+    odd sizes, unaligned views, a parameter without gradient, lr changed between steps (the reference's
+    schedulers write param_group["lr"]), state_dict round trip."""
+    from doda_amd.optim import FusedSGD
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(40000, generator=g)
+    shapes = [(27, 16, 16), (16,), (1,), (3, 3, 3, 3, 16), (224,), (20, 16), (1031,), (7, 5)]
+
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(*s, generator=g).to(d)) for s in shapes]
+        ps.append(torch.nn.Parameter(base.to(d)[1:1 + 4097].clone()))
+        ps.append(torch.nn.Parameter(torch.zeros(5, device=d)))   # never gets a gradient
+        return ps
+    g = torch.Generator().manual_seed(3); pa = make()
+    g = torch.Generator().manual_seed(3); pb = make()
+    g = torch.Generator().manual_seed(3); pc = make()
+    kw = dict(lr=0.05, momentum=momentum, dampening=dampening, nesterov=nesterov, weight_decay=wd)
+    oa, ob, oc = FusedSGD(pa, **kw), torch.optim.SGD(pb, fused=True, **kw), torch.optim.SGD(pc, foreach=False, **kw)
+    gg = torch.Generator().manual_seed(11)
+    for it in range(4):
+        if it == 2:
+            for o in (oa, ob, oc):
+                o.param_groups[0]["lr"] = 0.0125
+        if it == 3:   # checkpoint round trip of the optimizer state into a fresh FusedSGD
+            sd = oa.state_dict()
+            oa = FusedSGD(pa, **kw)
+            oa.load_state_dict(sd)
+        grads = [torch.randn(p.shape, generator=gg).to(d) for p in pa[:-1]]
+        for ps in (pa, pb, pc):
+            for p, gr in zip(ps[:-1], grads):
+                p.grad = gr.clone()
+        oa.step(); ob.step(); oc.step()
+    torch.cuda.synchronize()
+    for a, b, c in zip(pa, pb, pc):
+        assert torch.equal(a, b)
+        assert torch.allclose(a, c, rtol=2e-6, atol=1e-7)
+    if momentum:
+        for a, b in zip(pa[:-1], pb[:-1]):
+            assert torch.equal(oa.state[a]["momentum_buffer"], ob.state[b]["momentum_buffer"])
+    assert set(oa.state_dict()["state"].keys()) == set(ob.state_dict()["state"].keys())

@@ -8,7 +8,9 @@ batch = make_batch(4, int(sys.argv[1]) if len(sys.argv) > 1 else 20000, 1000)
 bd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
 cfg = default_cfg(); torch.manual_seed(0)
 net = SparseConvNet(cfg).to(dev).train()
-opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)
+from doda_amd.optim import FusedSGD
+opt = (torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True) if os.environ.get("TORCH_SGD") == "1"
+       else FusedSGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4))
 from doda_amd.spconv import functional as Fsp
 print('deferred wgrad:', Fsp.set_deferred_wgrad(os.environ.get('DEFER', '1') == '1'))
 from doda_amd.model import PyramidPrefetcher
