@@ -411,6 +411,10 @@ Plan make_plan(int K, int ca, int cb, int n_rows, int elem_bytes, bool multi = f
     const int ta = (ca + 15) / 16, tb = (cb + 15) / 16;
     p.TA = (ta % 2 == 0) ? 2 : 1;
     p.TB = (tb % 2 == 0) ? 2 : 1;
+    // 48-channel operands (level 3 of the U-Net): one 3 x 3 tile block gathers every row once instead of nine
+    // 1 x 1 blocks gathering a third of it each (and reading the table nine times)
+    static const bool no33 = getenv("DODA_WGRAD_NO33") && getenv("DODA_WGRAD_NO33")[0] == '1';
+    if (ta == 3 && tb == 3 && elem_bytes == 2 && K > 8 && !no33) { p.TA = 3; p.TB = 3; }
     p.n_tag = ta / p.TA;
     p.n_tbg = tb / p.TB;
     // 2x2 accumulator tiles x 7 offsets would need 112 accumulator registers (1 wave/SIMD): give
@@ -419,6 +423,7 @@ Plan make_plan(int K, int ca, int cb, int n_rows, int elem_bytes, bool multi = f
     // 54.8 -> 52.2, 39.6 -> 35.3, 19.0 -> 14.3 us (fewer registers, half the partials); fp32 the other
     // way round (91 vs 106 us at level 3): its 16 dY fragment reads per step amortise over more offsets
     p.OGW = (p.TA * p.TB == 4 || elem_bytes == 2) ? 4 : MAX_OGW;
+    if (p.TA * p.TB == 9) p.OGW = 2;   // 72 accumulator registers
     if (K <= 8) p.OGW = (p.TA * p.TB == 4) ? 2 : 2;
     p.n_og = div_up(K, 4 * p.OGW);
     const int gy = p.n_tag * p.n_tbg * p.n_og;
@@ -426,7 +431,9 @@ Plan make_plan(int K, int ca, int cb, int n_rows, int elem_bytes, bool multi = f
     // measured at M = 600k / 183k (rocprofv3): 1x1 and 2x1 tiles 68 -> 50 us going from 512 to 1024
     // blocks (+5 us of partial reduce); 2x2 tiles are fastest at 512
     // multi (whole U-Net step, wgrad + reduce): 1024 -> 1.86 ms, 512 -> 1.67, 256 -> 1.67, 128 -> 1.99
-    const int target = multi ? 512 : ((p.TA * p.TB == 4) ? 512 : 1024);
+    // (3 x 3 blocks: a block does nine tiles' worth of work and its chunk writes all K*ca*cb partials)
+    static const int t33 = getenv("DODA_WGRAD_T33") ? atoi(getenv("DODA_WGRAD_T33")) : 128;
+    const int target = p.TA * p.TB == 9 ? t33 : (multi ? 512 : ((p.TA * p.TB == 4) ? 512 : 1024));
     int R = div_up(target, gy);         // blocks over the whole grid
     // multi: at least MULTI_MIN_ROWS rows per chunk.  Every chunk writes K*ca*cb*4 bytes of partials; with
     // 512 blocks per job the coarse levels (64..112 channels, a few thousand rows) wrote and re-read
@@ -465,7 +472,8 @@ int run_wgrad(const void *a_, int ca, const void *b_, int cb, const int32_t *tbl
                                ld, K, n_rows, p.rows_per_chunk, p.n_tag, p.n_tbg, p.n_og, partial); \
     } while (0)
     if (p.OGW == 2) {
-        if (p.TA == 1 && p.TB == 1) GO(1, 1, 2);
+        if (p.TA == 3 && p.TB == 3) GO(3, 3, 2);
+        else if (p.TA == 1 && p.TB == 1) GO(1, 1, 2);
         else if (p.TA == 2 && p.TB == 1) GO(2, 1, 2);
         else if (p.TA == 1 && p.TB == 2) GO(1, 2, 2);
         else GO(2, 2, 2);
@@ -542,7 +550,8 @@ void launch_multi_variant(const Plan &p, int vok, int total_blocks, const WJob *
         else hipLaunchKernelGGL((wgrad_multi_kernel<T, TA, TB, OG, false>), grid, block, 0, s, jobs_dev, n); \
     } while (0)
     if (p.OGW == 2) {
-        if (p.TA == 1 && p.TB == 1) GO(1, 1, 2);
+        if (p.TA == 3 && p.TB == 3) GO(3, 3, 2);
+        else if (p.TA == 1 && p.TB == 1) GO(1, 1, 2);
         else if (p.TA == 2 && p.TB == 1) GO(2, 1, 2);
         else if (p.TA == 1 && p.TB == 2) GO(1, 2, 2);
         else GO(2, 2, 2);

@@ -440,7 +440,7 @@ def test_wgrad_multi_matches_per_layer(native_lib, dtype):
     from doda_amd import ops, spconv
     d = dev()
     jobs, refs = [], []
-    for m, c_in, c_out, seed in ((50000, 16, 16, 0), (9000, 32, 32, 1), (9000, 32, 48, 2), (700, 96, 112, 3),
+    for m, c_in, c_out, seed in ((50000, 16, 16, 0), (9000, 32, 32, 1), (9000, 32, 48, 2), (9000, 48, 48, 7), (700, 96, 112, 3),
                                  (150, 48, 16, 4), (50000, 16, 32, 5), (40, 64, 64, 6)):
         shape = [64, 64, 48]
         idx = surface_voxels(seed, m, 2, shape)
