@@ -46,7 +46,7 @@ def parse():
     p.add_argument("--voxels", type=int, default=150000, help="target active voxels per scene")
     p.add_argument("--voxel-scale", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-voxels", type=int, default=150000, help="size of the CPU-baseline sample scene")
+    p.add_argument("--cpu-voxels", type=int, default=100000, help="size of the CPU-baseline sample scene")
     p.add_argument("--kernel-reps", type=int, default=50)
     p.add_argument("--fp32-steps", type=int, default=40,
                    help="timed steps of the fp32 sub-record (reference precision); 0 = skip")

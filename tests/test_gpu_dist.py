@@ -103,3 +103,26 @@ def test_two_rank_unet_step_gradient_average(native_lib, dtype_name):
         # deferred gradients of the two ranks' own runs vs. the locally recomputed ones: identical kernels,
         # so the averaged gradient matches the mean to float rounding of the division
         assert info < 1e-5, (rank, info)
+
+
+def test_bench_two_ranks_on_one_gpu(native_lib):
+    """The driver's multi-GPU launch line for bench.py (`python -m torch.distributed.run --nproc-per-node N
+    bench.py --gpus N ...`), two ranks sharing the one MI355X over gloo: the N > 1 code path of the bench
+    itself (rank-local batches, rulebook prefetch per rank, deferred weight gradients + GradAllReduce +
+    FusedSGD, barrier + max-over-ranks timing, aggregate voxels/s) must run and print its one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DODA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--voxels", "20000", "--kernel-reps", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 4 and out["value"] > 0
+    assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 8
+    assert out["config"]["final_loss"] == out["config"]["final_loss"]   # not NaN
