@@ -14,6 +14,7 @@
 #include <torch/csrc/autograd/saved_variable.h>
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
 
 #include <cstring>
 #include <mutex>
@@ -333,6 +334,33 @@ void issue_wgrads(std::vector<PendingWgrad> &q, const c10::hip::HIPStream &st) {
         if (fresh[k].defined()) q[k].weight.mutable_grad() = fresh[k];
 }
 
+// jobs whose weight already appeared earlier in the queue wait for a follow-up call
+void issue_in_rounds(std::vector<PendingWgrad> &q, const c10::hip::HIPStream &st) {
+    while (!q.empty()) {
+        std::vector<PendingWgrad> now, later;
+        for (PendingWgrad &p : q) {
+            bool dup = false;
+            for (const PendingWgrad &e : now) dup |= e.weight.unsafeGetTensorImpl() == p.weight.unsafeGetTensorImpl();
+            (dup ? later : now).push_back(std::move(p));
+        }
+        issue_wgrads(now, st);
+        q.swap(later);
+    }
+}
+
+// Split flush for data-parallel training (doda_amd.dist.GradAllReduce, world size > 1).  Nearly all gradient
+// BYTES belong to the coarse levels (64..224 channels: 28 of the U-Net's 30 MB), nearly all weight-gradient
+// TIME to levels 1-2 (16 / 32 channels, 600k / 180k rows).  The wide layers are issued first and an event is
+// recorded behind them: the all-reduce of their gradients (and of everything AccumulateGrad delivered during
+// backward) can start on another stream while the narrow layers' kernels still run.  The rule is static
+// (channel counts of the weight), so every rank cuts its gradients the same way whatever its batch looks like.
+bool g_wq_split = false, g_ev_early_valid = false;
+hipEvent_t g_ev_early = nullptr;
+
+inline bool narrow_weight(const at::Tensor &w) {   // [kD, kH, kW, Cin, Cout]
+    return w.dim() == 5 && w.size(3) <= 32 && w.size(4) <= 32;
+}
+
 void flush_wgrads() {
     std::vector<PendingWgrad> q;
     c10::optional<c10::hip::HIPStream> st;
@@ -343,17 +371,18 @@ void flush_wgrads() {
         g_wq_callback = false;
         g_wq_task = -2;
     }
-    // jobs whose weight already appeared earlier in the queue wait for a follow-up call
-    while (!q.empty()) {
-        std::vector<PendingWgrad> now, later;
-        for (PendingWgrad &p : q) {
-            bool dup = false;
-            for (const PendingWgrad &e : now) dup |= e.weight.unsafeGetTensorImpl() == p.weight.unsafeGetTensorImpl();
-            (dup ? later : now).push_back(std::move(p));
-        }
-        issue_wgrads(now, *st);
-        q.swap(later);
+    if (!g_wq_split || !st) {
+        issue_in_rounds(q, *st);
+        return;
     }
+    std::vector<PendingWgrad> wide, narrow;
+    for (PendingWgrad &p : q) (narrow_weight(p.weight) ? narrow : wide).push_back(std::move(p));
+    issue_in_rounds(wide, *st);
+    if (!g_ev_early)
+        TORCH_CHECK(hipEventCreateWithFlags(&g_ev_early, hipEventDisableTiming) == hipSuccess, "doda: hipEventCreate");
+    TORCH_CHECK(hipEventRecord(g_ev_early, st->stream()) == hipSuccess, "doda: hipEventRecord");
+    g_ev_early_valid = true;
+    issue_in_rounds(narrow, *st);
 }
 
 // true when the job was queued (the caller then returns no gradient for the weight)
@@ -791,6 +820,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           "queue conv weight gradients during backward and issue them in one multi-layer call at its end");
     m.def("get_defer_wgrad", []() { return g_defer_wgrad; });
     m.def("flush_wgrads", &flush_wgrads);
+    m.def("set_wgrad_split", [](bool on) { g_wq_split = on; if (!on) g_ev_early_valid = false; },
+          "issue the wide layers' weight gradients first and record an event behind them (GradAllReduce)");
+    m.def("wait_wide_wgrads", [](int64_t stream) {
+              if (!g_ev_early_valid) return false;
+              g_ev_early_valid = false;
+              TORCH_CHECK(hipStreamWaitEvent((hipStream_t)stream, g_ev_early, 0) == hipSuccess, "doda: hipStreamWaitEvent");
+              return true;
+          }, "make `stream` wait for the wide layers' weight gradients of the last flush; false if there was no split flush");
     m.def("sgd_step", &sgd_step, "torch.optim.SGD's update of all parameters in one launch",
           py::call_guard<py::gil_scoped_release>());
     m.def("abi_version", []() { return doda_abi_version(); });

@@ -86,24 +86,46 @@ class GradAllReduce:
       all-reduce (RCCL ring over xGMI, per-link bound) is asynchronous and overlaps the flattening copy
       of bucket k+1 and the copy-back of bucket k-1.  With world size 1 everything is a no-op."""
 
-    def __init__(self, module, bucket_mb=8.0, broadcast_buffers=True):
+    def __init__(self, module, bucket_mb=8.0, broadcast_buffers=True, overlap=True):
         self.module = module
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.buckets = []
-        cur, cur_bytes, limit = [], 0, int(bucket_mb * (1 << 20))
-        for p in self.params:
-            cur.append(p)
-            cur_bytes += p.numel() * p.element_size()
-            if cur_bytes >= limit:
-                self.buckets.append(cur)
-                cur, cur_bytes = [], 0
-        if cur:
-            self.buckets.append(cur)
+        # (overlap) conv weights of the 16- / 32-channel levels: their gradients are the LAST kernels of a step
+        # (the pair-list launches of the deferred flush) and 2 of the 30 MB; everything else is reduced on a
+        # side stream while those kernels run.  Static rule on the weight shape: identical on every rank.
+        self._split = False
+        narrow = []
+        if overlap and self.world > 1 and self.params and self.params[0].is_cuda:
+            try:
+                from ._ext import ext as _ext
+            except Exception:
+                _ext = None
+            if _ext is not None and hasattr(_ext, "set_wgrad_split"):
+                narrow = [p for p in self.params if p.dim() == 5 and p.shape[3] <= 32 and p.shape[4] <= 32]
+                if narrow and len(narrow) < len(self.params):
+                    self._split, self._ext = True, _ext
+                    self._side = torch.cuda.Stream(device=self.params[0].device)
+                    _ext.set_wgrad_split(True)
+        narrow_ids = {id(p) for p in narrow} if self._split else set()
+        self.buckets = self._cut([p for p in self.params if id(p) not in narrow_ids], bucket_mb)
+        self.late_buckets = self._cut([p for p in self.params if id(p) in narrow_ids], bucket_mb)
         if self.world > 1:
             _flat_broadcast(self.params)
             if broadcast_buffers:
                 self.sync_buffers()
+
+    @staticmethod
+    def _cut(params, bucket_mb):
+        buckets, cur, cur_bytes, limit = [], [], 0, int(bucket_mb * (1 << 20))
+        for p in params:
+            cur.append(p)
+            cur_bytes += p.numel() * p.element_size()
+            if cur_bytes >= limit:
+                buckets.append(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            buckets.append(cur)
+        return buckets
 
     def sync_buffers(self):
         """Rank 0's buffers (running statistics, batch counters) to every rank."""
@@ -112,14 +134,15 @@ class GradAllReduce:
             if bufs:
                 _flat_broadcast(bufs)
 
-    def reduce(self):
-        """Call between loss.backward() and optimizer.step()."""
-        if self.world == 1:
-            return
+    @staticmethod
+    def _start(buckets):
         pending = []
-        for bucket in self.buckets:
+        for bucket in buckets:
             flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
             pending.append((bucket, flat, dist.all_reduce(flat, async_op=True)))
+        return pending
+
+    def _finish(self, pending):
         inv = 1.0 / self.world
         for bucket, flat, work in pending:
             work.wait()
@@ -131,3 +154,23 @@ class GradAllReduce:
             for p, v in zip(bucket, views):
                 if p.grad is None:
                     p.grad = v.clone()
+
+    def reduce(self):
+        """Call between loss.backward() and optimizer.step()."""
+        if self.world == 1:
+            return
+        main = torch.cuda.current_stream() if self._split else None
+        if self._split and self._ext.wait_wide_wgrads(self._side.cuda_stream):
+            # the side stream now waits for the wide layers' weight gradients only (and for everything backward
+            # put on the stream before them); the narrow layers' kernels keep running on the main stream
+            # (gradients stay alive until the next zero_grad, which the main stream reaches after it has
+            # joined the side stream: no allocator hand-over needed)
+            with torch.cuda.stream(self._side):
+                early = self._start(self.buckets)
+            late = self._start(self.late_buckets)
+            with torch.cuda.stream(self._side):
+                self._finish(early)
+            self._finish(late)
+            main.wait_stream(self._side)
+            return
+        self._finish(self._start(self.buckets + self.late_buckets))

@@ -43,6 +43,7 @@ def _worker(rank, world, port, dtype_name, q):
                 b.add_(float(rank))
         assert Fsp.set_deferred_wgrad(True)
         red = ddist.GradAllReduce(net)              # ... and are made identical here (rank 0's)
+        assert red._split and red.late_buckets      # overlapped reduction: wide layers on the side stream
         flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()] +
                          [b.detach().reshape(-1).float() for b in net.buffers()])
         both = [torch.empty_like(flat) for _ in range(world)]
