@@ -90,8 +90,10 @@ def _subm16_times(idx, shape, nb, dtype, reps):
     plan = ops.PackPlan([(w, 27, 16, 16, 0, s), (w, 27, 16, 16, 2, s)], dev)
     plan.run()
     pk_f, pk_d = plan.outputs
-    t_f = timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, 16, packed=pk_f))
-    t_d = timed(lambda: ops.spconv_gather(gy, None, data.tbl, m, 2, 16, packed=pk_d))
+    # bf16: the LDS-staged tile kernel over the rulebook's tilebook (built once per rulebook, as the model does)
+    tb = ops.tilebook_build(data.tbl) if (dtype == "bf16" and spconv.ops.TILE_KERNEL) else None
+    t_f = timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, 16, packed=pk_f, tilebook=tb))
+    t_d = timed(lambda: ops.spconv_gather(gy, None, data.tbl, m, 2, 16, packed=pk_d, tilebook=tb))
     n_layers = 8   # the 16 -> 16 block convolutions of level 1 share the rulebook and one multi-layer call
     wg_kernel = "wgrad_multi_kernel (gather table)"
     pairs = None
@@ -101,7 +103,7 @@ def _subm16_times(idx, shape, nb, dtype, reps):
     jobs = [(x, gy, data.tbl, m, pairs) if pairs is not None else (x, gy, data.tbl, m) for _ in range(n_layers)]
     t_w = timed(lambda: ops.spconv_wgrad_multi(jobs), per=n_layers)
     t_all = t_f + t_d + t_w
-    return {"M": m, "P": pairs_total,
+    return {"M": m, "P": pairs_total, "tile_kernel": tb is not None,
             "fwd": {"us": t_f * 1e6, "GBs": b_f / t_f / 1e9},
             "dgrad": {"us": t_d * 1e6, "GBs": b_f / t_d / 1e9},
             "wgrad": {"us": t_w * 1e6, "GBs": b_f / t_w / 1e9, "kernel": wg_kernel,
@@ -127,7 +129,8 @@ def kernel_roofline(batch_dev, dtype, reps, gate_scene=None):
                             "note": "north_star gate: SubMConv3d 16->16 fwd+bwd on one ~150k-voxel scene; its 45 MB "
                                     "working set sits in the 256 MB Infinity Cache between back-to-back launches"}
     m, pairs_total, b_f = big["M"], big["P"], big["b_f"]
-    kname = "conv_fast<PF32,1,2,3>" if dtype == "f32" else "conv_fast<PBF16P,1,2,3>"
+    kname = "conv_fast<PF32,1,2,3>" if dtype == "f32" else (
+        "conv_tile (LDS-staged, tilebook)" if big["tile_kernel"] else "conv_fast<PBF16P,1,2,3>")
     traffic, traffic_src = pmc_traffic(dtype)
     roof = {"kernel": "%s (SubMConv3d 16->16 fwd gather, M=%d, P=%d)" % (kname, m, pairs_total),
             "bound": "hbm", "achieved": out["subm16_fwd"]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

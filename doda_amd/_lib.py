@@ -73,6 +73,14 @@ _SIGNATURES = {
     "doda_cross_entropy_workspace_bytes": (c_sz, [c_i32]),
     "doda_cross_entropy_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, C.c_int64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "doda_cross_entropy_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, C.c_int64, c_vp, c_vp]),
+    "doda_tilebook_tile": (c_i32, []),
+    "doda_tilebook_umax": (c_i32, []),
+    "doda_tilebook_bytes": (c_sz, [c_i32, c_i32]),
+    "doda_tilebook_build": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
+    "doda_spconv_set_tile_kernel": (None, [c_i32]),
+    "doda_spconv_bwd_tile_workspace_bytes": (c_sz, []),
+    "doda_spconv_bwd_tile_bf16": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp,
+                                          c_sz, c_vp, c_vp]),
     "doda_spconv_stats_capacity": (c_sz, [c_i32]),
     "doda_spconv_gather_ex": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32,
                                       c_i32, c_vp, c_sz, c_vp, c_vp]),
@@ -96,7 +104,7 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-ABI_VERSION = 2   # include/doda_hip.h DODA_ABI_VERSION
+ABI_VERSION = 3   # include/doda_hip.h DODA_ABI_VERSION
 
 _lib = None
 

@@ -24,6 +24,7 @@
 //     accumulate, one RNE rounding at the store.
 // Bound: HBM for table + feature bytes; MFMA only for the dense contraction.
 #include "common.hpp"
+#include "tilebook.hpp"
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi(const PackDesc *__rest
 }
 
 constexpr int MAX_K = 27;
+bool g_use_tile = true;   // doda_spconv_set_tile_kernel (A/B measurements)
 
 template <class T, int NBW, int S>
 __global__ __launch_bounds__(256) void conv_gather(const typename T::elem *__restrict__ x, int kc,
@@ -820,6 +822,542 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-staged tile kernel (bf16, 16 input channels, K = 27 SubM: the level-1 layers of the U-Net and the
+// north-star gate).  conv_fast is paced by the texture path: 28 gather instructions per 32 output rows at
+// 37 % lane use, each costing >= 16 cycles of the CU's L1 whatever its EXEC mask.  Here a
+// workgroup owns a tile of TB_T = 256 consecutive output rows whose neighbourhood the tilebook
+// (tilebook.hpp) lists as ~2.2 x 256 DISTINCT input rows:
+//   phase A  every distinct row is loaded once, 64 lanes covering 32 consecutive list entries (runs of
+//            consecutive rows -> whole 128-byte lines), and parked in LDS; the tile's local-index strip
+//            (27 x 256 uint16) is copied to LDS; each wave loads the 14 offset-pair weight fragments of its
+//            channel block ONCE into registers (56 VGPRs — the workgroup's LDS footprint caps the CU at 3
+//            workgroups = 3 waves per SIMD, so registers are free);
+//   phase B  per offset pair one 8-byte LDS read returns the lane's four local indices (one per 16-row
+//            subtile), four 16-byte LDS reads fetch the operand rows (an absent neighbour is the shared
+//            zero row: same address in every lane, a broadcast), four MFMAs accumulate.  No vector-memory
+//            instruction in the loop.
+// Vector-memory instructions per 64 output rows: ~1 + 5 (list + rows) + 4 (indices) + 14 (weights) + 4
+// (stores) = 28 against 96.  A tile whose neighbourhood exceeds TB_UMAX rows (never seen on surface data)
+// takes the same loop with the operands gathered from global memory through the dense table.
+// Same arithmetic as conv_fast<PBF16P> up to the order in which offsets are paired (fixed (2u, 2u+1)
+// here, pairs of ACTIVE offsets there): fp32 accumulation, one bf16 rounding at the store.
+// ---------------------------------------------------------------------------------------------
+// Store epilogue of the tile kernel: conv_fast's epilogue for bf16 features, one channel block, four waves
+// holding four row ranges of the workgroup's tile (residual add, single bf16 rounding, BatchNorm statistics
+// as one partial row per workgroup — see EpiArgs).
+template <int S, bool OUT32, bool STATS>
+__device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], int row0, int i, int g, int wid, int nb0, int nc,
+                                              int n_out, __amdgpu_buffer_rsrc_t rs_y, unsigned y_bytes,
+                                              const void *__restrict__ res, const EpiArgs &ep, int part) {
+    constexpr unsigned OSZ = OUT32 ? 4u : 2u;
+    __shared__ f32x4 sred[STATS ? 4 : 1][2][4];
+    const unsigned col = (unsigned)(nb0 * 16 + 4 * g);
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const unsigned t = (unsigned)(row0 + s * 16 + i);
+        const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * (unsigned)nc + col) * OSZ : OOB;
+        f32x4 a = acc[s][0];
+        if (res) {
+            const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, y_bytes, 0x00020000);
+            if (OUT32) {
+                const f32x4 r4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, voff, 0, 0));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] += r4[q];
+            } else {
+                const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rs_r, voff, 0, 0);
+                a[0] += __uint_as_float(r2[0] << 16);
+                a[1] += __uint_as_float(r2[0] & 0xffff0000u);
+                a[2] += __uint_as_float(r2[1] << 16);
+                a[3] += __uint_as_float(r2[1] & 0xffff0000u);
+            }
+        }
+        u32x2 packed_out = {0u, 0u};
+        if constexpr (!OUT32) {
+            packed_out[0] = (unsigned)f2bf(a[0]) | ((unsigned)f2bf(a[1]) << 16);
+            packed_out[1] = (unsigned)f2bf(a[2]) | ((unsigned)f2bf(a[3]) << 16);
+        }
+        if constexpr (STATS) {
+            f32x4 v = a;
+            if constexpr (!OUT32) {
+                v = (f32x4){__uint_as_float(packed_out[0] << 16), __uint_as_float(packed_out[0] & 0xffff0000u),
+                            __uint_as_float(packed_out[1] << 16), __uint_as_float(packed_out[1] & 0xffff0000u)};
+            }
+            if (ep.bn_x) {
+                const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)ep.bn_x, 0, y_bytes, 0x00020000);
+                f32x4 xr;
+                if (OUT32) {
+                    xr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff, 0, 0));
+                } else {
+                    const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rs_b, voff, 0, 0);
+                    xr = (f32x4){__uint_as_float(r2[0] << 16), __uint_as_float(r2[0] & 0xffff0000u),
+                                 __uint_as_float(r2[1] << 16), __uint_as_float(r2[1] & 0xffff0000u)};
+                }
+                const unsigned cc = col < (unsigned)nc ? col : 0u;
+                const f32x4 mu = *reinterpret_cast<const f32x4 *>(ep.bn_mean + cc);
+                const f32x4 is = *reinterpret_cast<const f32x4 *>(ep.bn_invstd + cc);
+                const f32x4 xh = (xr - mu) * is;
+                if (ep.bn_relu) {
+                    const f32x4 ga = *reinterpret_cast<const f32x4 *>(ep.bn_gamma + cc);
+                    const f32x4 be = *reinterpret_cast<const f32x4 *>(ep.bn_beta + cc);
+                    const f32x4 yv = xh * ga + be;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = yv[q] > 0.f ? v[q] : 0.f;
+                }
+                st1 += v;
+                st2 += v * xh;
+            } else {
+                st1 += v;
+                st2 += v * v;
+            }
+        }
+        if constexpr (OUT32)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), rs_y, voff, 0, 0);
+        else
+            __builtin_amdgcn_raw_buffer_store_b64(packed_out, rs_y, voff, 0, 0);
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { st1[q] = row_sum16(st1[q]); st2[q] = row_sum16(st2[q]); }
+        if (i == 15) { sred[wid][0][g] = st1; sred[wid][1][g] = st2; }
+        __syncthreads();
+        if (wid == 0 && i == 15 && col < (unsigned)nc) {
+            const f32x4 a1 = (sred[0][0][g] + sred[1][0][g]) + (sred[2][0][g] + sred[3][0][g]);
+            const f32x4 a2 = (sred[0][1][g] + sred[1][1][g]) + (sred[2][1][g] + sred[3][1][g]);
+            float *dst = ep.stats + (long long)part * 2 * nc + col;
+            *reinterpret_cast<f32x4 *>(dst) = a1;
+            *reinterpret_cast<f32x4 *>(dst + nc) = a2;
+        }
+    }
+}
+
+template <bool OUT32, bool STATS>
+__global__ __launch_bounds__(256) void conv_tile(const unsigned short *__restrict__ x, unsigned x_bytes,
+                                                 const void *__restrict__ wp, unsigned wp_bytes, int nc, int NB,
+                                                 const int32_t *__restrict__ tbl, int ld, int n_out,
+                                                 const TileBookView tb, void *__restrict__ y, unsigned y_bytes,
+                                                 const void *__restrict__ res, const EpiArgs ep) {
+    constexpr int S = 4, NU = (TB_K + 1) / 2;
+    __shared__ __attribute__((aligned(16))) unsigned char rows_s[(TB_UMAX + 1) * 32];
+    __shared__ __attribute__((aligned(16))) unsigned short lidx_s[TB_K * TB_T];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int item = xcd_work_item(blockIdx.x, gridDim.x);
+    const int tile = item / NB, nb0 = item % NB;
+    const int t0 = tile * TB_T;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, wp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, y_bytes, 0x00020000);
+
+    // ---- phase A ----
+    // Everything that does not depend on device data is requested at once: the distinct-row list, the
+    // local-index strip, the count and the weight fragments of the 14 offset pairs (offset 27 lies past
+    // the packed buffer: zeros); the rows follow as soon as the list is in registers.  An overflowing
+    // tile (count > TB_UMAX) has a list of -1 and an unwritten strip; both loads are harmless.
+    // half-row h = 16 bytes: lanes 2k, 2k+1 take the two halves of list entry k (a wave reads 32
+    // consecutive entries = one 128-byte line per instruction).  Entries past the count are -1: their
+    // row offset is out of range and loads zeros — no lane is masked, no branch.
+    constexpr int NRL = (2 * TB_UMAX + 255) / 256;            // row loads per thread
+    unsigned rid[NRL];
+    {
+        const int32_t *ul = tb.ulist + (size_t)tile * TB_UMAX;
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) {
+            const int e = (k * 256 + tid) >> 1;
+            rid[k] = e < TB_UMAX ? (unsigned)ul[e] : 0xffffffffu;
+        }
+    }
+    constexpr int NLI = (TB_K * TB_T * 2 / 16 + 255) / 256;   // 16-byte pieces of the strip per thread
+    u32x4 li4[NLI];
+    {
+        const u32x4 *li = reinterpret_cast<const u32x4 *>(tb.lidx + (size_t)tile * TB_K * TB_T);
+#pragma unroll
+        for (int k = 0; k < NLI; ++k) {
+            const int e = k * 256 + tid;
+            li4[k] = li[e < TB_K * TB_T * 2 / 16 ? e : 0];
+        }
+    }
+    const int U = tb.ucount[tile];
+    u32x4 wf[NU];
+    {
+        const unsigned lane_w = (unsigned)((g & 1) * 16 + i) * 16u + (unsigned)nb0 * 512u;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const unsigned osel = 2u * u + (unsigned)(g >> 1);
+            wf[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, osel * (unsigned)NB * 512u + lane_w, 0, 0);
+        }
+    }
+    const bool staged = U <= TB_UMAX;
+    if (staged) {
+        u32x4 rr[NRL];
+#pragma unroll
+        for (int k = 0; k < NRL; ++k)
+            rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, rid[k] * 32u + (unsigned)(tid & 1) * 16u, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NLI; ++k) {
+            const int e = k * 256 + tid;
+            if (e < TB_K * TB_T * 2 / 16) reinterpret_cast<u32x4 *>(lidx_s)[e] = li4[k];
+        }
+        if (tid < 2) reinterpret_cast<u32x4 *>(rows_s)[TB_ZROW * 2 + tid] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < NRL; ++k)
+            if (k * 256 + tid < 2 * TB_UMAX) reinterpret_cast<u32x4 *>(rows_s)[k * 256 + tid] = rr[k];
+        __syncthreads();
+    }
+
+    // ---- phase B ----
+    f32x4 acc[S][1];
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int row0 = t0 + wid * 64;
+    const unsigned half = (unsigned)(g & 1) * 16u;
+    if (staged) {
+        // all local indices of the lane first (14 x 8 bytes), then the units with the operand reads of
+        // unit u+1 issued before the MFMAs of unit u (the scheduling barriers keep hipcc from sinking the
+        // reads next to their use, which left one LDS round trip exposed per MFMA)
+        const unsigned short *my = lidx_s + wid * 64 + i * 4;
+        u32x2 l4[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int osel = 2 * u + (g >> 1);
+            l4[u] = (u32x2){(unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16), (unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16)};
+            if (osel < TB_K) l4[u] = *reinterpret_cast<const u32x2 *>(my + osel * TB_T);
+        }
+        auto fetch = [&](int u, u32x4 (&xa)[S]) {
+            xa[0] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][0] & 0xffffu) * 32u + half);
+            xa[1] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][0] >> 16) * 32u + half);
+            xa[2] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][1] & 0xffffu) * 32u + half);
+            xa[3] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][1] >> 16) * 32u + half);
+        };
+        u32x4 xa[2][S];
+        fetch(0, xa[0]);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (u + 1 < NU) fetch(u + 1, xa[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < S; ++s) PBF16P::mma(acc[s][0], wf[u], xa[u & 1][s]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // overflow tile: same units, operands gathered from global memory through the dense table; the
+        // table entries of two units, then their rows (straight-line code, counted waits)
+        const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void *)tbl, 0, (unsigned)TB_K * (unsigned)ld * 4u, 0x00020000);
+#pragma unroll
+        for (int u0 = 0; u0 < NU; u0 += 2) {
+            unsigned go[2][S];
+#pragma unroll
+            for (int du = 0; du < 2; ++du) {
+                const int osel = 2 * (u0 + du) + (g >> 1);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int t = row0 + s * 16 + i;
+                    const unsigned voff = (osel < TB_K && t < n_out) ? ((unsigned)osel * (unsigned)ld + (unsigned)t) * 4u : OOB;
+                    go[du][s] = __builtin_amdgcn_raw_buffer_load_b32(rs_t, voff, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int du = 0; du < 2; ++du) {
+                const int osel = 2 * (u0 + du) + (g >> 1);
+                u32x4 xa[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int t = row0 + s * 16 + i;
+                    const bool present = osel < TB_K && t < n_out && (int)go[du][s] >= 0;   // out-of-range table reads return 0
+                    xa[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, present ? go[du][s] * 32u + half : OOB, 0, 0);
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) PBF16P::mma(acc[s][0], wf[u0 + du], xa[s]);
+            }
+        }
+    }
+    tile_epilogue<S, OUT32, STATS>(acc, row0, i, g, wid, nb0, nc, n_out, rs_y, y_bytes, res, ep, tile);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused SubM backward of a 16 -> 16 bf16 layer over a tilebook: data gradient AND weight gradient from ONE
+// staging of the output gradient's neighbourhood.  SubM tables are their own transpose
+// under offset mirroring, so both gradients read dy through the SAME table entries of the tile's rows s:
+//     dx[s]    = sum_o  dy[nbr_o(s)] . W[26-o]^T                    (rows are the MFMA M dimension)
+//     dW[o]   += sum_s  x[s]^T . dy[nbr_{26-o}(s)]                  (rows are the MFMA k dimension)
+// Phase A stages the distinct dy rows of the tile in LDS exactly as conv_tile does, plus the tile's own x
+// rows (8 KB).  Phase B1 is conv_tile's loop.  Phase B2 reads the SAME staged rows in k-order with
+// ds_read_b64_tr_b16, whose per-lane addresses make it a gather: lane s = 4q + c of a 16-lane group points
+// at chunk c (4 channels) of the row that local index q selects and receives channel t of rows q = 0..3 —
+// no second copy of the data, no LDS write -> read round trip (the LDS kernel's 70 % bank-conflict wall,
+// profiles/r01_pmc_wgrad_bf16_l1.txt).  Wave w owns the offsets o = w (mod 4): its 7 accumulators (28
+// VGPRs) stay in registers across all tiles of the PERSISTENT workgroup, which writes one partial
+// [27][16][16] at the end; bwd_tile_reduce sums the partials in a fixed order (deterministic).
+// Workgroups: 3 per CU (LDS 53 KB), XCD x walks its own contiguous range of tiles.
+// An overflow tile (more distinct rows than TB_UMAX) takes the dense table: B1 gathers from global memory,
+// B2 stages four offsets at a time (4 x 256 rows, tile order) and runs the same transposed reads.
+// ---------------------------------------------------------------------------------------------
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ s16x4 lds_tr_b64(unsigned addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// hipcc does not count LDS operations issued from inline asm: wait for all of them before the first use
+template <class R>
+__device__ __forceinline__ void lds_wait(R &first) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(first) : : "memory");
+}
+
+constexpr int BT_MAX_GROUPS = 768;   // 3 workgroups per CU x 256 CUs
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict__ dy, unsigned feat_bytes,
+                                                const unsigned short *__restrict__ x,
+                                                const void *__restrict__ wp, unsigned wp_bytes,
+                                                const int32_t *__restrict__ tbl, int ld, int n,
+                                                const TileBookView tb, void *__restrict__ dx,
+                                                const EpiArgs ep, float *__restrict__ part) {
+    constexpr int S = 4, NU = (TB_K + 1) / 2;
+    // staged rows and the local-index strip sit back to back: the overflow path, which has no strip, stages
+    // 4 x TB_T rows across both
+    constexpr int ROWS_BYTES = (TB_UMAX + 1) * 32;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ROWS_BYTES + TB_K * TB_T * 2];
+    __shared__ __attribute__((aligned(16))) unsigned short xs[TB_T * 16];
+    static_assert(ROWS_BYTES % 16 == 0 && 4 * TB_T * 32 <= ROWS_BYTES + TB_K * TB_T * 2, "overflow path stages 4 x TB_T rows");
+    unsigned char *const rows_s = smem;
+    unsigned short *const lidx_s = reinterpret_cast<unsigned short *>(smem + ROWS_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, feat_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, feat_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, wp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void *)dx, 0, feat_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void *)tbl, 0, (unsigned)TB_K * (unsigned)ld * 4u, 0x00020000);
+
+    // persistent schedule: XCD (blockIdx & 7) owns one contiguous range of tiles, its L workgroups stride it
+    const int L = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int qn = tb.nt >> 3, rn = tb.nt & 7;
+    const int lo = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
+    const int cnt = qn + (xcd < rn ? 1 : 0);
+
+    u32x4 wf[NU];   // data-grad weight fragments (W[26-o]^T, pair packing), once per workgroup
+    {
+        const unsigned lane_w = (unsigned)((g & 1) * 16 + i) * 16u;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+            wf[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (2u * u + (unsigned)(g >> 1)) * 512u + lane_w, 0, 0);
+    }
+    f32x4 dw[7];
+#pragma unroll
+    for (int m = 0; m < 7; ++m) dw[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const unsigned half = (unsigned)(g & 1) * 16u;
+    const int q4 = i >> 2, c4 = i & 3;
+    const unsigned rows_base = (unsigned)(uintptr_t)rows_s, xs_base = (unsigned)(uintptr_t)xs;
+    // transposed-read addresses of k-step 0: row 8g + q4 (and +4), chunk c4
+    const unsigned xs_addr = xs_base + (unsigned)((8 * g + q4) * 32 + c4 * 8);
+    const unsigned short *li_b2 = lidx_s + tb_pos(8 * g + q4);
+
+    for (int tt = slot; tt < cnt; tt += L) {
+        const int tile = lo + tt, t0 = tile * TB_T;
+        // ---- phase A ----
+        constexpr int NRL = (2 * TB_UMAX + 255) / 256;
+        unsigned rid[NRL];
+        {
+            const int32_t *ul = tb.ulist + (size_t)tile * TB_UMAX;
+#pragma unroll
+            for (int k = 0; k < NRL; ++k) {
+                const int e = (k * 256 + tid) >> 1;
+                rid[k] = e < TB_UMAX ? (unsigned)ul[e] : 0xffffffffu;
+            }
+        }
+        constexpr int NLI = (TB_K * TB_T * 2 / 16 + 255) / 256;
+        u32x4 li4[NLI];
+        {
+            const u32x4 *li = reinterpret_cast<const u32x4 *>(tb.lidx + (size_t)tile * TB_K * TB_T);
+#pragma unroll
+            for (int k = 0; k < NLI; ++k) {
+                const int e = k * 256 + tid;
+                li4[k] = li[e < TB_K * TB_T * 2 / 16 ? e : 0];
+            }
+        }
+        u32x4 xt[2];   // the tile's own x rows (rows past n: out of range -> zeros)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int h = k * 256 + tid;
+            xt[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(t0 + (h >> 1)) * 32u + (unsigned)(h & 1) * 16u, 0, 0);
+        }
+        const int U = tb.ucount[tile];
+        const bool staged = U <= TB_UMAX;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) reinterpret_cast<u32x4 *>(xs)[k * 256 + tid] = xt[k];
+        if (staged) {
+            u32x4 rr[NRL];
+#pragma unroll
+            for (int k = 0; k < NRL; ++k)
+                rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, rid[k] * 32u + (unsigned)(tid & 1) * 16u, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NLI; ++k) {
+                const int e = k * 256 + tid;
+                if (e < TB_K * TB_T * 2 / 16) reinterpret_cast<u32x4 *>(lidx_s)[e] = li4[k];
+            }
+            if (tid < 2) reinterpret_cast<u32x4 *>(rows_s)[TB_ZROW * 2 + tid] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < NRL; ++k)
+                if (k * 256 + tid < 2 * TB_UMAX) reinterpret_cast<u32x4 *>(rows_s)[k * 256 + tid] = rr[k];
+        }
+        __syncthreads();
+
+        // ---- phase B1: data gradient (conv_tile's loop) ----
+        f32x4 acc[S][1];
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int row0 = t0 + wid * 64;
+        if (staged) {
+            const unsigned short *my = lidx_s + wid * 64 + i * 4;
+            u32x2 l4[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int osel = 2 * u + (g >> 1);
+                l4[u] = (u32x2){(unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16), (unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16)};
+                if (osel < TB_K) l4[u] = *reinterpret_cast<const u32x2 *>(my + osel * TB_T);
+            }
+            auto fetch = [&](int u, u32x4 (&xa)[S]) {
+                xa[0] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][0] & 0xffffu) * 32u + half);
+                xa[1] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][0] >> 16) * 32u + half);
+                xa[2] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][1] & 0xffffu) * 32u + half);
+                xa[3] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][1] >> 16) * 32u + half);
+            };
+            u32x4 xa[2][S];
+            fetch(0, xa[0]);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (u + 1 < NU) fetch(u + 1, xa[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < S; ++s) PBF16P::mma(acc[s][0], wf[u], xa[u & 1][s]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int u0 = 0; u0 < NU; u0 += 2) {
+                unsigned go[2][S];
+#pragma unroll
+                for (int du = 0; du < 2; ++du) {
+                    const int osel = 2 * (u0 + du) + (g >> 1);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const int t = row0 + s * 16 + i;
+                        const unsigned voff = (osel < TB_K && t < n) ? ((unsigned)osel * (unsigned)ld + (unsigned)t) * 4u : OOB;
+                        go[du][s] = __builtin_amdgcn_raw_buffer_load_b32(rs_t, voff, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int du = 0; du < 2; ++du) {
+                    const int osel = 2 * (u0 + du) + (g >> 1);
+                    u32x4 xa[S];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const int t = row0 + s * 16 + i;
+                        const bool present = osel < TB_K && t < n && (int)go[du][s] >= 0;
+                        xa[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, present ? go[du][s] * 32u + half : OOB, 0, 0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < S; ++s) PBF16P::mma(acc[s][0], wf[u0 + du], xa[s]);
+                }
+            }
+        }
+        tile_epilogue<S, false, STATS>(acc, row0, i, g, wid, 0, 16, n, rs_o, feat_bytes, nullptr, ep, tile);
+
+        // ---- phase B2: weight gradient ----
+        if (staged) {
+#pragma unroll
+            for (int ks = 0; ks < TB_T / 32; ++ks) {
+                // x^T fragment of the k-step: channel i of rows 32 ks + 8 g + 0..7
+                const unsigned xa_addr = xs_addr + (unsigned)ks * 32u * 32u;
+                s16x4 a_lo = lds_tr_b64(xa_addr), a_hi = lds_tr_b64(xa_addr + 4u * 32u);
+                const unsigned short *lk = li_b2 + (ks >> 1) * 64 + (ks & 1) * 2;
+                unsigned ra[7], rb[7];
+#pragma unroll
+                for (int m = 0; m < 7; ++m) {
+                    const int o = wid + 4 * m;             // owned offset; the table entry is its mirror
+                    const int om = o < TB_K ? TB_K - 1 - o : 0;
+                    ra[m] = rows_base + (unsigned)lk[om * TB_T] * 32u + (unsigned)c4 * 8u;
+                    rb[m] = rows_base + (unsigned)lk[om * TB_T + 16] * 32u + (unsigned)c4 * 8u;
+                }
+                s16x4 b_lo[7], b_hi[7];
+#pragma unroll
+                for (int m = 0; m < 7; ++m) { b_lo[m] = lds_tr_b64(ra[m]); b_hi[m] = lds_tr_b64(rb[m]); }
+                lds_wait(a_lo);
+                const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int m = 0; m < 7; ++m) {
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b_lo[m], b_hi[m], 0, 1, 2, 3, 4, 5, 6, 7));
+                    if (wid + 4 * m < TB_K) dw[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, dw[m], 0, 0, 0);
+                }
+            }
+        } else {
+            // four offsets per pass: wave w' stages dy[tbl[26 - (4 pass + w')][t0 + r]] at rows_s[w' * 256 + r]
+            for (int pass = 0; pass < 7; ++pass) {
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int h = k * 256 + tid, w2 = h >> 9, r = (h >> 1) & 255, o = 4 * pass + w2;
+                    int gi = -1;
+                    if (o < TB_K && t0 + r < n) gi = tbl[(long long)(TB_K - 1 - o) * ld + t0 + r];
+                    reinterpret_cast<u32x4 *>(rows_s)[h] =
+                        __builtin_amdgcn_raw_buffer_load_b128(rs_dy, gi >= 0 ? (unsigned)gi * 32u + (unsigned)(h & 1) * 16u : OOB, 0, 0);
+                }
+                __syncthreads();
+                if (4 * pass + wid < TB_K) {
+#pragma unroll
+                    for (int ks = 0; ks < TB_T / 32; ++ks) {
+                        const unsigned xa_addr = xs_addr + (unsigned)ks * 32u * 32u;
+                        const unsigned ba = rows_base + (unsigned)(wid * 256 + ks * 32 + 8 * g + q4) * 32u + (unsigned)c4 * 8u;
+                        s16x4 a_lo = lds_tr_b64(xa_addr), a_hi = lds_tr_b64(xa_addr + 4u * 32u);
+                        s16x4 b_lo = lds_tr_b64(ba), b_hi = lds_tr_b64(ba + 4u * 32u);
+                        lds_wait(a_lo);
+                        const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < 7; ++m)
+                            if (m == pass) dw[m] += d;
+                    }
+                }
+            }
+        }
+        __syncthreads();   // the next tile overwrites the staged rows
+    }
+    // partial of this workgroup: dW[o][ci = 4 g + r][co = i] for the wave's offsets
+    float *dst = part + (size_t)blockIdx.x * (TB_K * 256);
+#pragma unroll
+    for (int m = 0; m < 7; ++m) {
+        const int o = wid + 4 * m;
+        if (o < TB_K) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[o * 256 + (4 * g + r) * 16 + i] = dw[m][r];
+        }
+    }
+}
+
+// dw[e] (+)= sum over workgroups, fixed order
+__global__ __launch_bounds__(256) void bwd_tile_reduce(const float *__restrict__ part, int n_part, float *__restrict__ dw,
+                                                       int accumulate) {
+    const int e = blockIdx.x * 256 + threadIdx.x;   // < 27 * 256
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 3 < n_part; b += 4) {
+        a0 += part[(size_t)b * (TB_K * 256) + e];
+        a1 += part[(size_t)(b + 1) * (TB_K * 256) + e];
+        a2 += part[(size_t)(b + 2) * (TB_K * 256) + e];
+        a3 += part[(size_t)(b + 3) * (TB_K * 256) + e];
+    }
+    for (; b < n_part; ++b) a0 += part[(size_t)b * (TB_K * 256) + e];
+    const float v = (a0 + a1) + (a2 + a3);
+    dw[e] = accumulate ? dw[e] + v : v;
+}
+
 template <class P, int NBW, int S, bool SPLIT = false>
 int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_bytes, int nc, int NB,
                 const int32_t *tbl, int ld, int K, int n_out, long long n_in, void *y, bool out32,
@@ -880,7 +1418,7 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
                int n_out, void *y_, int wl, void *ws, size_t ws_bytes, long long n_in, bool out32,
                const void *res, hipStream_t s,
                const EpiArgs &ep = EpiArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
-               int *n_part = nullptr) {
+               int *n_part = nullptr, const void *tilebook = nullptr, int tilebook_rows = 0) {
     typedef typename T::elem elem;
     typedef typename T::frag frag;
     const elem *x = (const elem *)x_;
@@ -914,6 +1452,21 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
         else
             hipLaunchKernelGGL((pack_weights<T>), dim3(div_up(total, 256)), dim3(256), 0, s, w, K, kc,
                                nc, n_chunk, NB, wl & 3, (frag *)ws);
+    }
+    // Level-1 shape with a tilebook of this table: the LDS-staged tile kernel (conv_tile)
+    if (pair && tilebook && K == TB_K && tilebook_rows == n_out && g_use_tile) {
+        const TileBookView tb = tilebook_view(const_cast<void *>(tilebook), n_out);
+        const dim3 grid(tb.nt * NB), block(256);
+        if (n_part) *n_part = tb.nt;
+        const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
+        const unsigned yb = (unsigned)((size_t)n_out * nc * (out32 ? 4 : sizeof(elem)));
+#define GT(O32, ST)                                                                                \
+        hipLaunchKernelGGL((conv_tile<O32, ST>), grid, block, 0, s, (const unsigned short *)x_, xb, wp, (unsigned)need, \
+                           nc, NB, tbl, ld, n_out, tb, y_, yb, res, ep)
+        if (out32) { if (ep.stats) GT(true, true); else GT(true, false); }
+        else { if (ep.stats) GT(false, true); else GT(false, false); }
+#undef GT
+        return doda_check_launch();
     }
     // Tile choice: many rows -> more subtiles per wave and all channel blocks in one wave (x is
     // gathered once); few rows -> one subtile, channel blocks spread over the grid so the chip
@@ -1075,6 +1628,62 @@ extern "C" int doda_spconv_gather_add_bf16(const uint16_t *x, int32_t n_in, int3
 }
 
 // ---- gather with epilogue options (residual add, BatchNorm statistics) ------------------------------
+extern "C" size_t doda_spconv_bwd_tile_workspace_bytes(void) {
+    return (size_t)BT_MAX_GROUPS * TB_K * 256 * sizeof(float) + align_up((size_t)TB_K * 32 * 16, 256);
+}
+
+extern "C" int doda_spconv_bwd_tile_bf16(const uint16_t *dy, const uint16_t *x, int32_t n_rows, const float *w,
+                                         int32_t w_packed, const int32_t *tbl, int32_t ld, const void *tilebook,
+                                         void *dx, float *dw, int32_t accumulate, void *ws, size_t ws_bytes,
+                                         const doda_conv_epilogue *epi, doda_stream_t stream) {
+    if (n_rows < 0 || ld < n_rows) return DODA_ERR_INVALID;
+    if (n_rows == 0) {
+        if (epi && epi->stats_rows_h) *epi->stats_rows_h = 0;
+        return DODA_OK;
+    }
+    if (!dy || !x || !w || !tbl || !tilebook || !dx || !dw || !ws) return DODA_ERR_INVALID;
+    if (ws_bytes < doda_spconv_bwd_tile_workspace_bytes()) return DODA_ERR_WORKSPACE;
+    if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)tilebook | (uintptr_t)ws) & 15) return DODA_ERR_UNSUPPORTED;
+    if ((size_t)n_rows * 32 >= 0x7ffffff0ull || (size_t)TB_K * ld * 4 >= 0xffffffffull) return DODA_ERR_UNSUPPORTED;
+    hipStream_t s = as_stream(stream);
+    float *part = (float *)ws;
+    void *wpk = (char *)ws + (size_t)BT_MAX_GROUPS * TB_K * 256 * sizeof(float);
+    const size_t need = (size_t)TB_K * 32 * 16;
+    const void *wp = w;
+    if (!w_packed) {   // w: fp32 [27][16 out... stored [K][nc][kc] as every data-grad call] -> W[26-o]^T pair fragments
+        hipLaunchKernelGGL(pack_weights_wide, dim3(div_up((long long)TB_K * 32, 256)), dim3(256), 0, s, w, TB_K, 16, 16,
+                           1, 1, 2, (u32x4_t *)wpk, 1);
+        wp = wpk;
+    }
+    EpiArgs ep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (epi && epi->stats) {
+        if (!epi->stats_rows_h) return DODA_ERR_INVALID;
+        ep.stats = epi->stats;
+        if (epi->bn_x) {
+            if (!epi->bn_mean || !epi->bn_invstd || !epi->bn_gamma || !epi->bn_beta) return DODA_ERR_INVALID;
+            ep.bn_x = epi->bn_x;
+            ep.bn_mean = epi->bn_mean; ep.bn_invstd = epi->bn_invstd;
+            ep.bn_gamma = epi->bn_gamma; ep.bn_beta = epi->bn_beta;
+            ep.bn_relu = epi->bn_relu;
+        }
+    }
+    const TileBookView tb = tilebook_view(const_cast<void *>(tilebook), n_rows);
+    int groups = (tb.nt + 7) / 8 * 8;
+    if (groups > BT_MAX_GROUPS) groups = BT_MAX_GROUPS;
+    const unsigned fb = (unsigned)((size_t)n_rows * 32);
+    if (ep.stats)
+        hipLaunchKernelGGL((bwd_tile<true>), dim3(groups), dim3(256), 0, s, dy, fb, x, wp, (unsigned)need, tbl, (int)ld,
+                           (int)n_rows, tb, dx, ep, part);
+    else
+        hipLaunchKernelGGL((bwd_tile<false>), dim3(groups), dim3(256), 0, s, dy, fb, x, wp, (unsigned)need, tbl, (int)ld,
+                           (int)n_rows, tb, dx, ep, part);
+    hipLaunchKernelGGL(bwd_tile_reduce, dim3(TB_K), dim3(256), 0, s, part, groups, dw, accumulate);
+    if (epi && epi->stats_rows_h) *epi->stats_rows_h = ep.stats ? tb.nt : 0;
+    return doda_check_launch();
+}
+
+extern "C" void doda_spconv_set_tile_kernel(int32_t on) { g_use_tile = on != 0; }
+
 extern "C" size_t doda_spconv_stats_capacity(int32_t n_out) { return n_out > 0 ? (size_t)div_up(n_out, 16) : 1; }
 
 extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, int32_t elem_bytes, const float *w,
@@ -1109,7 +1718,8 @@ extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, in
                              as_stream(stream), ep, &n_part);
     else
         st = run_gather<BF16>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, y_is_f32 != 0, res,
-                              as_stream(stream), ep, &n_part);
+                              as_stream(stream), ep, &n_part, epi ? epi->tilebook : nullptr,
+                              epi ? epi->tilebook_rows : 0);
     if (st == DODA_OK && epi && epi->stats_rows_h) *epi->stats_rows_h = n_part;
     return st;
 }

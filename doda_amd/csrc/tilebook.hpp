@@ -1,0 +1,49 @@
+// Tile-local form of a SubM gather table ("tilebook"), shared by the builder (tilebook.hip) and the
+// LDS-staged convolution kernel (spconv_gather.hip: conv_tile).
+//
+// The dense table tbl[K][M] makes every (offset, row) slot a vector-memory gather of its own: at level 1
+// of DODA's U-Net a 32-row wave issues 28 gather instructions at 37 % lane use, and the kernel is paced by
+// the per-CU texture path.  A tile of TB_T consecutive output rows references only
+// ~2.2 x TB_T distinct input rows (raster-ordered surface voxels), so the tilebook stores per tile
+//   ulist [TB_UMAX]   int32   the distinct input rows, ascending (-1 past the count)
+//   lidx  [K][TB_T]   uint16  position of tbl[o][t] in ulist, or TB_ZROW when absent
+//   ucount            int32   number of distinct rows (> TB_UMAX: overflow, the kernel falls back to tbl)
+// and the kernel loads each distinct row ONCE, coalesced, into LDS and serves all K gathers from there.
+// Inside a tile lidx is swizzled so that one 8-byte LDS read returns the four subtile entries of a lane:
+//   pos(r) = (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+constexpr int TB_T = 256;        // output rows per tile
+constexpr int TB_UMAX = 960;     // distinct input rows staged per tile (LDS budget of the fused backward: 3 workgroups per CU)
+constexpr int TB_ZROW = TB_UMAX; // local index of the all-zero row
+constexpr int TB_K = 27;
+
+struct TileBookView {
+    int32_t *ulist;     // [nt][TB_UMAX]
+    uint16_t *lidx;     // [nt][TB_K][TB_T]
+    int32_t *ucount;    // [nt]
+    int nt;
+};
+
+static inline size_t tilebook_bytes_for(long long n_rows) {
+    const size_t nt = (size_t)((n_rows + TB_T - 1) / TB_T);
+    return nt * ((size_t)TB_UMAX * 4 + (size_t)TB_K * TB_T * 2 + 4);
+}
+
+static inline TileBookView tilebook_view(void *base, long long n_rows) {
+    TileBookView v;
+    v.nt = (int)((n_rows + TB_T - 1) / TB_T);
+    char *p = (char *)base;
+    v.ulist = (int32_t *)p;
+    p += (size_t)v.nt * TB_UMAX * 4;
+    v.lidx = (uint16_t *)p;
+    p += (size_t)v.nt * TB_K * TB_T * 2;
+    v.ucount = (int32_t *)p;
+    return v;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int tb_pos(int r) { return (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3); }
+#endif

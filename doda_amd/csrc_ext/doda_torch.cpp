@@ -51,6 +51,36 @@ struct GatherEpi {
     at::Tensor stats;
 };
 
+// A SubM table allocated by table_with_tilebook() carries its tilebook (doda_tilebook_build) in the same
+// storage, 256-byte aligned behind the K x ld entries: the table tensor is the one handle every layer of
+// the rulebook already passes around (forward, data-grad, saved for backward), so the tilebook reaches
+// the kernels without a second argument through the Python and autograd layers.  Recognised by the exact
+// storage size; any other table has exactly K * ld * 4 bytes.
+inline size_t tilebook_offset(int64_t K, int64_t ld) { return ((size_t)(K * ld * 4) + 255) / 256 * 256; }
+
+const void *tilebook_behind(const at::Tensor &tbl, int64_t n_out) {
+    if (tbl.dim() != 2 || !tbl.is_contiguous() || tbl.storage_offset() != 0 || tbl.size(1) != n_out) return nullptr;
+    const size_t tb = doda_tilebook_bytes((int32_t)n_out, (int32_t)tbl.size(0));
+    if (tb == 0 || tbl.storage().nbytes() != tilebook_offset(tbl.size(0), tbl.size(1)) + tb) return nullptr;
+    return (const char *)tbl.data_ptr() + tilebook_offset(tbl.size(0), tbl.size(1));
+}
+
+// int32 [K, m] table whose storage has room for the tilebook (written later by build_tilebook)
+at::Tensor table_with_tilebook(int64_t K, int64_t m, const at::TensorOptions &iopt) {
+    const size_t tb = doda_tilebook_bytes((int32_t)m, (int32_t)K);
+    if (tb == 0) return at::empty({K, m}, iopt);
+    at::Tensor buf = at::empty({(int64_t)((tilebook_offset(K, m) + tb) / 4)}, iopt);
+    return buf.narrow(0, 0, K * m).view({K, m});
+}
+
+void build_tilebook(const at::Tensor &tbl, void *st) {
+    const void *tb = tilebook_behind(tbl, tbl.size(1));
+    TORCH_CHECK(tb, "doda: the table has no room for a tilebook");
+    check(doda_tilebook_build((const int32_t *)tbl.data_ptr(), (int32_t)tbl.size(1), (int32_t)tbl.size(0),
+                              (int32_t)tbl.size(1), const_cast<void *>(tb),
+                              doda_tilebook_bytes((int32_t)tbl.size(1), (int32_t)tbl.size(0)), st), "doda_tilebook_build");
+}
+
 // y[t] = sum_o x[tbl[o][t]] . B_o   (include/doda_hip.h: doda_spconv_gather_ex)
 at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
                   const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32,
@@ -89,6 +119,8 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
             ep.bn_relu = epi->bn_relu ? 1 : 0;
         }
     }
+    ep.tilebook = tilebook_behind(tbl, n_out);
+    ep.tilebook_rows = ep.tilebook ? (int32_t)n_out : 0;
     const void *wptr;
     void *ws = nullptr;
     size_t ws_bytes = 0;
@@ -218,7 +250,7 @@ typedef std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, std::vector<i
                    at::Tensor, at::Tensor, at::Tensor, at::Tensor> PyramidLevel;
 // pairs_min_rows < 0: no lists; else lists for rulebooks of at least that many rows.
 std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vector<int64_t> shape, int64_t batch,
-                                        int64_t n_levels, int64_t pairs_min_rows) {
+                                        int64_t n_levels, int64_t pairs_min_rows, int64_t tile_min_rows) {
     TORCH_CHECK(indices_in.is_cuda() && indices_in.scalar_type() == at::kInt && indices_in.dim() == 2 &&
                 indices_in.size(1) == 4 && shape.size() == 3, "doda build_pyramid: indices must be int32 [M,4] on the GPU");
     std::vector<PyramidLevel> out;
@@ -230,10 +262,13 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
         int32_t shp[3] = {(int32_t)shape[0], (int32_t)shape[1], (int32_t)shape[2]};
         const size_t wsb = doda_rulebook_workspace_bytes(m);
         at::Tensor ws = at::empty({(int64_t)(wsb > 256 ? wsb : 256)}, iopt.dtype(at::kByte));
-        at::Tensor nbr = at::empty({27, m}, iopt);
+        // tilebook for the finest level only: its layers are the 16-channel ones the tile kernel serves
+        const bool tiled = lvl == 0 && tile_min_rows >= 0 && m >= tile_min_rows;
+        at::Tensor nbr = tiled ? table_with_tilebook(27, m, iopt) : at::empty({27, m}, iopt);
         check(doda_rulebook_subm((const int32_t *)indices.data_ptr(), m, shp, (int32_t)batch, 3,
                                  (int32_t *)nbr.data_ptr(), m, ws.data_ptr(), (size_t)ws.numel(), st),
               "doda_rulebook_subm");
+        if (tiled) build_tilebook(nbr, st);
         at::Tensor sp, sn, sh, dp, dn, dh;
         const bool with_pairs = pairs_min_rows >= 0 && m >= pairs_min_rows;
         if (with_pairs) std::tie(sp, sn, sh) = export_pairs(nbr, m, true, st);
@@ -814,7 +849,28 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("build_pyramid", &build_pyramid,
           "all SubM k3 and k2s2 rulebooks of an n-level U-Net in one call (13 native builds, 6 size read-backs)",
           py::arg("indices"), py::arg("shape"), py::arg("batch"), py::arg("n_levels"), py::arg("pairs_min_rows") = -1,
+          py::arg("tile_min_rows") = -1,
           py::call_guard<py::gil_scoped_release>());   // its size read-backs block: let other Python threads run
+    m.def("with_tilebook", [](const at::Tensor &tbl) {
+              TORCH_CHECK(tbl.is_cuda() && tbl.scalar_type() == at::kInt && tbl.dim() == 2, "doda with_tilebook: int32 [K, M] table");
+              at::Tensor out = table_with_tilebook(tbl.size(0), tbl.size(1), tbl.options());
+              out.copy_(tbl);
+              if (tilebook_behind(out, out.size(1))) build_tilebook(out, stream_of(out));
+              return out;
+          }, "copy of a gather table with its tilebook (doda_tilebook_build) in the same storage");
+    m.def("has_tilebook", [](const at::Tensor &tbl) { return tilebook_behind(tbl, tbl.dim() == 2 ? tbl.size(1) : 0) != nullptr; });
+    m.def("tilebook_parts", [](const at::Tensor &tbl) {   // (ulist [nt,UMAX] int32, lidx [nt,K,T] int16, ucount [nt] int32) views, for tests
+              const void *tb = tilebook_behind(tbl, tbl.size(1));
+              TORCH_CHECK(tb, "doda tilebook_parts: no tilebook");
+              const int64_t T = doda_tilebook_tile(), nt = (tbl.size(1) + T - 1) / T, K = tbl.size(0), UMAX = doda_tilebook_umax();
+              char *p = (char *)const_cast<void *>(tb);
+              auto o32 = tbl.options(), o16 = tbl.options().dtype(at::kShort);
+              at::Tensor ulist = at::from_blob(p, {nt, UMAX}, o32).clone();
+              at::Tensor lidx = at::from_blob(p + nt * UMAX * 4, {nt, K, T}, o16).clone();
+              at::Tensor ucount = at::from_blob(p + nt * UMAX * 4 + nt * K * T * 2, {nt}, o32).clone();
+              return std::make_tuple(ulist, lidx, ucount);
+          });
+    m.def("set_tile_kernel", [](bool on) { doda_spconv_set_tile_kernel(on ? 1 : 0); });
     m.def("pending_wgrads", []() { std::lock_guard<std::mutex> lock(g_wq_mu); return (int64_t)g_wq.size(); });
     m.def("set_defer_wgrad", [](bool on) { g_defer_wgrad = on; },
           "queue conv weight gradients during backward and issue them in one multi-layer call at its end");

@@ -266,7 +266,29 @@ def _feat_ok(x, name):
         raise RuntimeError("%s must be a contiguous [rows, channels] tensor" % name)
 
 
-def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, residual=None):
+class _ConvEpilogue(C.Structure):   # doda_conv_epilogue (include/doda_hip.h, ABI 3)
+    _fields_ = [("residual", C.c_void_p), ("stats", C.c_void_p), ("stats_rows_h", C.POINTER(C.c_int32)),
+                ("bn_x", C.c_void_p), ("bn_mean", C.c_void_p), ("bn_invstd", C.c_void_p), ("bn_gamma", C.c_void_p),
+                ("bn_beta", C.c_void_p), ("bn_relu", C.c_int32), ("tilebook_rows", C.c_int32),
+                ("tilebook", C.c_void_p)]
+
+
+def tilebook_build(tbl, n_rows=None):
+    """Tile-local form of a K = 27 gather table (doda_tilebook_build) as a byte tensor, or None when the
+    library has no tilebook for this K.  Pass it to spconv_gather(tilebook=...)."""
+    _need_cuda(tbl)
+    K, ld = tbl.shape
+    n_rows = ld if n_rows is None else int(n_rows)
+    nbytes = lib().doda_tilebook_bytes(n_rows, K)
+    if nbytes == 0:
+        return None
+    tb = torch.empty(nbytes, dtype=torch.uint8, device=tbl.device)
+    check(lib().doda_tilebook_build(_p(tbl), ld, K, n_rows, _p(tb), nbytes, _stream()), "doda_tilebook_build")
+    tb._doda_rows = n_rows
+    return tb
+
+
+def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, residual=None, tilebook=None):
     """y[t] = sum_o x[tbl[o][t]] @ B_o (see doda_hip.h).  x: [n_in,kc] f32|bf16; w: fp32 weights
     viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2), or `packed`: the fragment-packed buffer
     produced by PackPlan for this (weight, layout, dtype).  Returns y [n_out, nc] in x.dtype (or
@@ -294,6 +316,16 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
         _need_cuda(residual)
         if residual.dtype != ydt or tuple(residual.shape) != (n_out, nc) or not residual.is_contiguous():
             raise RuntimeError("residual must be a contiguous [n_out, nc] tensor in the output dtype")
+    if tilebook is not None:   # epilogue-struct entry point: the tilebook rides in doda_conv_epilogue
+        y = torch.empty((n_out, nc), dtype=ydt, device=x.device)
+        ep = _ConvEpilogue()
+        ep.residual = _p(residual) if residual is not None else None
+        ep.tilebook = _p(tilebook)
+        ep.tilebook_rows = int(getattr(tilebook, "_doda_rows", n_out))
+        check(lib().doda_spconv_gather_ex(_p(x), x.shape[0], kc, esz, w_ptr, nc, _p(tbl), ld, K, n_out, _p(y),
+                                          int(bool(out_f32)), layout, ws_ptr, ws_n, C.byref(ep), _stream()),
+              "doda_spconv_gather_ex")
+        return y
     if x.dtype == torch.float32:
         y = torch.empty((n_out, nc), dtype=torch.float32, device=x.device)
         if residual is None:

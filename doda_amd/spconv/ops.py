@@ -3,6 +3,8 @@ get_indice_pairs).  The geometries DODA instantiates — SubM with a cubic kerne
 kernel-2 / stride-2 / padding-0 convolution (model/unet.py:36, model/unet_block.py:18-29,48,70,78) —
 have dedicated native builders; any other kernel_size / stride / padding / dilation with a kernel
 volume of at most 27 goes through the generic one (doda_rulebook_conv_*, doda_rulebook_subm_generic)."""
+import os
+
 import numpy as np
 
 import torch
@@ -65,7 +67,12 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     return data.outids, data.indice_pairs, data.indice_pair_num
 
 
-def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", first_level=1, with_pairs=False):
+TILE_MIN_ROWS = 32768    # finest-level rulebooks of at least this many rows get a tilebook (LDS-staged conv kernel)
+TILE_KERNEL = os.environ.get("DODA_NO_TILE", "0") != "1"
+
+
+def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", first_level=1, with_pairs=False,
+                  with_tiles=None):
     """Build every rulebook of an n-level U-Net up front and store it in `tensor.indice_dict`
     (SubM k3 under subm_key % i, k2s2 under down_key % i), so the convolutions find them cached.
     Rulebooks depend only on the voxel indices; building them before any feature kernel is queued
@@ -76,7 +83,8 @@ def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", firs
     if (_ext is not None and not tensor.indice_dict and indices.is_cuda and indices.dtype == torch.int32
             and indices.shape[0] > 0 and all(int(v) >= 2 for v in shape)):
         levels = _ext.build_pyramid(indices, [int(v) for v in shape], int(tensor.batch_size), int(n_levels),
-                                    PAIRS_MIN_ROWS if with_pairs else -1)
+                                    PAIRS_MIN_ROWS if with_pairs else -1,
+                                    TILE_MIN_ROWS if (TILE_KERNEL and (with_pairs if with_tiles is None else with_tiles)) else -1)
         for k, (nbr, outids, child, par_off, oshape, sp, sn, sh, dp, dn, dh) in enumerate(levels):   # s*/d*: lists, counts, segments
             lvl = first_level + k
             data = tensor.indice_dict[subm_key % lvl] = IndiceData("subm", indices, indices, list(shape),

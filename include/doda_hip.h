@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DODA_ABI_VERSION 2
+#define DODA_ABI_VERSION 3
 
 #define DODA_OK 0
 #define DODA_ERR_INVALID (-1)        /* bad argument (null pointer, negative size, bad mode) */
@@ -241,8 +241,40 @@ typedef struct doda_conv_epilogue {
     const void *bn_x;
     const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
     int32_t bn_relu;
-    int32_t reserved;
+    int32_t tilebook_rows;   /* ABI 3: rows the tilebook was built for (must equal n_out) */
+    const void *tilebook;    /* ABI 3: doda_tilebook_build of `tbl`, or NULL */
 } doda_conv_epilogue;
+/* ABI 3.  Tile-local form of a SubM gather table ("tilebook") for the LDS-staged convolution kernel:
+ * per tile of doda_tilebook_tile() consecutive output rows, the sorted list of DISTINCT input rows the
+ * tile's K x tile table entries reference and, per entry, its position in that list.  The kernel loads
+ * every distinct row once into LDS and serves all K gathers of the tile from there (replaces spconv's
+ * per-offset sparse_gather kernels the same way the dense table does — reference call sites
+ * model/unet_block.py:26,29,48 —, with ~1/3 of the vector-memory instructions).  Built once per
+ * rulebook, used by every forward and data-grad call of its layers through doda_conv_epilogue.tilebook
+ * when the features are bf16 with 16 input channels and K == 27; other calls ignore it.  Results equal
+ * the dense-table path up to the fp32 summation order over offsets.  K must be 27 (else bytes == 0 /
+ * DODA_ERR_UNSUPPORTED); `tilebook` 16-byte aligned. */
+int32_t doda_tilebook_tile(void);
+int32_t doda_tilebook_umax(void);   /* list capacity per tile; layout: ulist int32 [nt][umax], lidx uint16 [nt][K][tile], ucount int32 [nt] */
+size_t doda_tilebook_bytes(int32_t n_rows, int32_t K);
+int doda_tilebook_build(const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, void *tilebook,
+                        size_t tilebook_bytes, doda_stream_t stream);
+/* Fused SubM backward of a bf16 16 -> 16, K = 27 layer over the rulebook's tilebook (spconv
+ * indice_conv_backward, reference call sites model/unet_block.py:26,29 through autograd): ONE staging of
+ * dy's neighbourhood serves both gradients,
+ *     dx[s]  = sum_o dy[tbl[o][s]] . W[26-o]^T        (bf16 [n_rows,16]; epilogue statistics as gather_ex)
+ *     dw[o]  (+)= sum_s x[s]^T . dy[tbl[26-o][s]]     (fp32 [27][16][16]; `accumulate` adds into dw)
+ * which equals the separate data-grad (w_layout 2) and weight-gradient calls up to summation order.
+ * `w`: fp32 [27][16][16] stored [K][Cout][Cin] exactly as a w_layout-2 gather call receives it, or with
+ * w_packed != 0 the fragment-packed buffer doda_spconv_pack_multi wrote for (layout 2, bf16).
+ * Deterministic: persistent workgroups write one partial each, a second launch sums them in order. */
+size_t doda_spconv_bwd_tile_workspace_bytes(void);
+int doda_spconv_bwd_tile_bf16(const uint16_t *dy, const uint16_t *x, int32_t n_rows, const float *w,
+                              int32_t w_packed, const int32_t *tbl, int32_t ld, const void *tilebook,
+                              void *dx, float *dw, int32_t accumulate, void *ws, size_t ws_bytes,
+                              const doda_conv_epilogue *epi, doda_stream_t stream);
+/* A/B switch for measurements: 0 = ignore tilebooks (dense-table kernels only).  Default 1. */
+void doda_spconv_set_tile_kernel(int32_t on);
 size_t doda_spconv_stats_capacity(int32_t n_out);
 int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, int32_t elem_bytes, const float *w,
                           int32_t nc, const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, void *y,

@@ -1,0 +1,209 @@
+"""GPU tests of the tilebook (doda_tilebook_build) and the LDS-staged convolution kernel (conv_tile).
+
+* the tilebook is a lossless re-encoding of the dense gather table: per tile the sorted distinct rows and
+  per entry its position, so  ulist[tile][lidx[tile][o][pos(r)]] == tbl[o][tile*T + r]  bit for bit;
+* the tile kernel against the CPU oracle's indice_conv on the SAME bf16-rounded operands (products exact in
+  fp32, only the summation order differs: 1e-4 relative as north_star states) and against the dense-table
+  kernel (fp32 outputs to 1e-5, bf16 outputs within one rounding step);
+* every epilogue option (residual, fp32 output, BatchNorm statistics forward and backward form);
+* a table whose tiles reference more than the staged capacity falls back to the dense table inside the
+  kernel; ragged last tile, NB = 2 (16 -> 32, the data-grad of a 32 -> 16 layer);
+* the whole U-Net training step with and without tilebooks.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import deterministic_init, surface_voxels
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def _ext_or_skip():
+    from doda_amd._ext import ext
+    if ext is None:
+        pytest.skip("compiled extension not built")
+    return ext
+
+
+def _scene_table(m, seed=0, batch=2, shape=(80, 70, 60)):
+    from doda_amd import ops
+    d = dev()
+    idx = torch.from_numpy(surface_voxels(seed, m, batch, list(shape))).to(d)
+    # raster order (the order real scans and the synthetic scenes arrive in): neighbours of a tile overlap
+    key = ((idx[:, 0].long() * shape[0] + idx[:, 1]) * shape[1] + idx[:, 2]) * shape[2] + idx[:, 3]
+    idx = idx[torch.argsort(key)].contiguous()
+    return idx, ops.rulebook_subm(idx, list(shape), batch, 3)
+
+
+@pytest.mark.parametrize("m", [40000, 1000, 256, 255])
+def test_tilebook_is_a_lossless_encoding(native_lib, m):
+    ext = _ext_or_skip()
+    _, tbl = _scene_table(m, seed=m)
+    n = tbl.shape[1]
+    t = ext.with_tilebook(tbl)
+    assert ext.has_tilebook(t) and torch.equal(t, tbl)
+    ulist, lidx, ucount = (v.cpu().numpy() for v in ext.tilebook_parts(t))
+    lidx = lidx.view(np.uint16)
+    T, UMAX = lidx.shape[2], ulist.shape[1]
+    tb = tbl.cpu().numpy()
+    r = np.arange(T)
+    pos = (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3)
+    for tile in range(ulist.shape[0]):
+        rows = np.arange(tile * T, min((tile + 1) * T, n))
+        ent = np.full((27, T), -1, np.int64)
+        ent[:, :len(rows)] = tb[:, rows]
+        uniq = np.unique(ent[ent >= 0])
+        assert ucount[tile] == len(uniq) <= UMAX
+        assert np.array_equal(ulist[tile, :len(uniq)], uniq) and (ulist[tile, len(uniq):] == -1).all()
+        loc = lidx[tile][:, pos].astype(np.int64)          # un-swizzled [27, T]
+        absent = loc == UMAX
+        assert np.array_equal(absent, ent < 0)
+        back = np.where(absent, -1, ulist[tile][np.minimum(loc, UMAX - 1)])
+        assert np.array_equal(back, ent)
+
+
+def _oracle_conv(x, w, tbl, layout):
+    """fp64 reference over the dense table (definition in include/doda_hip.h)."""
+    xd, wd = x.double().cpu(), w.double().cpu()
+    t = tbl.cpu().long()
+    K = t.shape[0]
+    y = torch.zeros(t.shape[1], w.shape[2] if layout == 0 else w.shape[1], dtype=torch.float64)
+    for o in range(K):
+        b = wd[o] if layout == 0 else wd[K - 1 - o].t()
+        sel = t[o] >= 0
+        y[sel] += xd[t[o][sel]] @ b
+    return y
+
+
+@pytest.mark.parametrize("m,nc,layout", [(40000, 16, 0), (40000, 16, 2), (9000, 32, 2), (777, 16, 0), (40000, 48, 0)])
+def test_tile_kernel_matches_oracle_and_dense_kernel(native_lib, m, nc, layout):
+    from doda_amd import ops
+    d = dev()
+    _, tbl = _scene_table(m, seed=3 + m)
+    n = tbl.shape[1]
+    torch.manual_seed(m + nc)
+    x = torch.randn(n, 16, device=d).bfloat16()
+    w = (torch.randn(27, 16, nc, device=d) * 0.1).bfloat16().float()   # bf16-representable: products exact
+    wk = w if layout == 0 else w.transpose(1, 2).contiguous()            # [K][nc][kc] for layout 2
+    tb = ops.tilebook_build(tbl)
+    assert tb is not None
+    ref = _oracle_conv(x, wk, tbl, layout)
+    y32_tile = ops.spconv_gather(x, wk, tbl, n, layout, nc, out_f32=True, tilebook=tb)
+    y32_dense = ops.spconv_gather(x, wk, tbl, n, layout, nc, out_f32=True)
+    assert rel_err(y32_tile.cpu(), ref) < 1e-4
+    assert rel_err(y32_tile.cpu(), y32_dense.cpu()) < 1e-5
+    y_tile = ops.spconv_gather(x, wk, tbl, n, layout, nc, tilebook=tb)
+    y_dense = ops.spconv_gather(x, wk, tbl, n, layout, nc)
+    assert y_tile.dtype == torch.bfloat16
+    # one bf16 rounding of nearly equal fp32 sums: at most one step apart, almost always equal
+    diff = (y_tile.float() - y_dense.float()).abs()
+    assert (diff <= 2.0 ** -7 * y_dense.float().abs() + 1e-6).all()
+    assert (y_tile != y_dense).float().mean().item() < 0.02
+    res = torch.randn(n, nc, device=d).bfloat16()
+    y_res = ops.spconv_gather(x, wk, tbl, n, layout, nc, residual=res, tilebook=tb)
+    assert rel_err(y_res.float().cpu(), ref + res.double().cpu()) < 2.0 ** -7
+
+
+def test_tile_kernel_overflow_tiles_fall_back(native_lib):
+    """Random neighbours: every tile references far more than the staged capacity."""
+    ext = _ext_or_skip()
+    from doda_amd import ops
+    d = dev()
+    n = 3000
+    g = torch.Generator().manual_seed(5)
+    tbl = torch.randint(0, n, (27, n), generator=g, dtype=torch.int32)
+    tbl[torch.rand(27, n, generator=g) < 0.5] = -1
+    tbl = tbl.to(d)
+    t = ext.with_tilebook(tbl)
+    ulist, _, ucount = ext.tilebook_parts(t)
+    assert (ucount > ulist.shape[1]).all()
+    x = torch.randn(n, 16, device=d).bfloat16()
+    w = (torch.randn(27, 16, 16, device=d) * 0.1).bfloat16().float()
+    tb = ops.tilebook_build(tbl)
+    y = ops.spconv_gather(x, w, tbl, n, 0, 16, out_f32=True, tilebook=tb)
+    assert rel_err(y.cpu(), _oracle_conv(x, w, tbl, 0)) < 1e-4
+
+
+def test_tile_kernel_statistics_epilogue(native_lib):
+    """The conv node of the extension on a table that carries its tilebook: output, statistics rows
+    (forward) and the fused BatchNorm backward (data-grad statistics) equal the dense-table kernels."""
+    ext = _ext_or_skip()
+    from doda_amd import spconv
+    from doda_amd.spconv import functional as Fsp
+    d = dev()
+    idx, tbl = _scene_table(50000, seed=11)
+    n = tbl.shape[1]
+    torch.manual_seed(0)
+    x = torch.randn(n, 16, device=d).bfloat16()
+    w = torch.nn.Parameter((torch.randn(3, 3, 3, 16, 16, device=d) * 0.1))
+    res = torch.randn(n, 16, device=d).bfloat16()
+    t = ext.with_tilebook(tbl)
+    y0, s0 = ext.indice_conv_stats(x, w, tbl, tbl, n, 2, None, None, res)
+    y1, s1 = ext.indice_conv_stats(x, w, t, t, n, 2, None, None, res)
+    assert s1 is not None and s1.shape[0] == (n + 255) // 256
+    assert (y0 != y1).float().mean().item() < 0.02
+    assert rel_err(s1.double().sum(0).cpu(), s0.double().sum(0).cpu()) < 1e-3
+    yf = y1.detach().double()
+    assert rel_err(s1.double().sum(0)[0].cpu(), yf.sum(0).cpu()) < 1e-5
+    assert rel_err(s1.double().sum(0)[1].cpu(), (yf * yf).sum(0).cpu()) < 1e-5
+    # BatchNorm -> ReLU -> conv, backward through the data-grad statistics
+    bn = torch.nn.BatchNorm1d(16, eps=1e-4).to(d).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    conv = spconv.SubMConv3d(16, 16, 3, padding=1, bias=False, indice_key="k").to(d)
+    seq = spconv.SparseSequential(bn, torch.nn.ReLU(), conv).train()
+    outs = []
+    for tiled in (False, True):
+        bn.zero_grad(set_to_none=True)
+        conv.zero_grad(set_to_none=True)
+        xin = x.clone().requires_grad_(True)
+        inp = spconv.SparseConvTensor(xin, idx, [80, 70, 60], 2)
+        data = spconv.ops.build_subm(idx, 2, [80, 70, 60], 3)
+        if tiled:
+            data.tbl = ext.with_tilebook(data.tbl)
+        inp.indice_dict["k"] = data
+        out = seq(inp).features
+        out.float().square().mean().backward()
+        outs.append((out.detach().clone(), xin.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                     conv.weight.grad.clone()))
+    for a, b in zip(*outs):
+        assert rel_err(b.float().cpu(), a.float().cpu()) < 2e-2
+
+
+def test_unet_step_with_and_without_tilebooks(native_lib):
+    _ext_or_skip()
+    from doda_amd import spconv
+    from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
+    from doda_amd.scene import make_batch
+    d = dev()
+    cfg = default_cfg()
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in make_batch(2, 40000, 5).items()}
+    net = deterministic_init(SparseConvNet(cfg), seed=1).to(d).train()
+    runs = []
+    old = spconv.ops.TILE_KERNEL
+    try:
+        for tiled in (False, True):
+            spconv.ops.TILE_KERNEL = tiled
+            net.zero_grad(set_to_none=True)
+            loss = cross_entropy(voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.bfloat16), bd["labels"])
+            loss.backward()
+            torch.cuda.synchronize()
+            runs.append((loss.item(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    finally:
+        spconv.ops.TILE_KERNEL = old
+    assert abs(runs[0][0] - runs[1][0]) < 2e-2 * abs(runs[0][0])
+    for k, g0 in runs[0][1].items():
+        g1 = runs[1][1][k]
+        assert (g0.float() - g1.float()).norm().item() <= 0.1 * g0.float().norm().item() + 1e-6, k

@@ -24,13 +24,13 @@ def mean(pattern, kernel, cs):
     vals = []
     for f in glob.glob(pattern):
         for r in csv.DictReader(open(f)):
-            if kernel in r["Kernel_Name"] and r["Counter_Name"] == cs:
+            if any(k in r["Kernel_Name"] for k in kernel.split("|")) and r["Counter_Name"] == cs:
                 vals.append(float(r["Counter_Value"]))
     return (sum(vals) / len(vals) if vals else None), len(vals)
 for dt in ("bf16", "f32"):
     d = {}
     for cs in ("FETCH_SIZE", "WRITE_SIZE"):
-        d[cs + "_KB_mean"], d[cs + "_n"] = mean("$out/pmc_%s_%s/*counter_collection.csv" % (dt, cs), "conv_fast", cs)
+        d[cs + "_KB_mean"], d[cs + "_n"] = mean("$out/pmc_%s_%s/*counter_collection.csv" % (dt, cs), "conv_tile|conv_fast", cs)
     res[dt] = d
 d = {}
 for cs in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -1,0 +1,63 @@
+"""Tile kernel (conv_tile over a tilebook) against the dense-table kernel (conv_fast) on the level-1
+rulebook of the benchmark batch: tilebook build time, forward / data-grad times, HIP events on the launch
+stream.  python tools/tilebench.py [--scenes 4] [--voxels 150000] [--reps 50]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scenes", type=int, default=4)
+    ap.add_argument("--voxels", type=int, default=150000)
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--nc", type=int, default=16)
+    a = ap.parse_args()
+    from doda_amd import ops, spconv
+    from doda_amd.scene import make_batch
+    d = torch.device("cuda:0")
+    b = make_batch(a.scenes, a.voxels, 1000)
+    idx = b["voxel_locs"].int().to(d)
+    data = spconv.ops.build_subm(idx, a.scenes, b["spatial_shape"], 3)
+    m = idx.shape[0]
+    x = torch.randn(m, 16, device=d).bfloat16()
+    w = torch.randn(27, 16, a.nc, device=d) * 0.1
+    plan = ops.PackPlan([(w, 27, 16, a.nc, 0, 2)], d)
+    plan.run()
+    pk = plan.outputs[0]
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(a.reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / a.reps
+
+    tb = ops.tilebook_build(data.tbl)
+    out = {"M": m, "P": int((data.tbl >= 0).sum().item()),
+           "tilebook_build_us": timed(lambda: ops.tilebook_build(data.tbl)),
+           "tilebook_bytes": tb.numel(), "table_bytes": data.tbl.numel() * 4,
+           "dense_us": timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk)),
+           "tile_us": timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk, tilebook=tb))}
+    y0 = ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk, out_f32=True)
+    y1 = ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk, out_f32=True, tilebook=tb)
+    out["max_rel_diff"] = ((y0 - y1).abs().max() / y0.abs().max()).item()
+    nt = (m + 255) // 256
+    from doda_amd._lib import lib
+    uc = tb[nt * (lib().doda_tilebook_umax() * 4 + 27 * 512):].view(torch.int32)[:nt]
+    out["distinct_rows_per_tile"] = {"mean": uc.float().mean().item(), "max": int(uc.max().item())}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
