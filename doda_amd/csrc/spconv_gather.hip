@@ -1126,8 +1126,7 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
     unsigned char *const rows_s = smem;
     unsigned short *const lidx_s = reinterpret_cast<unsigned short *>(smem + ROWS_BYTES);
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 15, g = lane >> 4;
+    const int tid0 = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, feat_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, feat_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, wp_bytes, 0x00020000);
@@ -1140,26 +1139,27 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
     const int lo = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
     const int cnt = qn + (xcd < rn ? 1 : 0);
 
-    u32x4 wf[NU];   // data-grad weight fragments (W[26-o]^T, pair packing), once per workgroup
-    {
-        const unsigned lane_w = (unsigned)((g & 1) * 16 + i) * 16u;
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-            wf[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (2u * u + (unsigned)(g >> 1)) * 512u + lane_w, 0, 0);
-    }
     f32x4 dw[7];
 #pragma unroll
     for (int m = 0; m < 7; ++m) dw[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const unsigned half = (unsigned)(g & 1) * 16u;
-    const int q4 = i >> 2, c4 = i & 3;
-    const unsigned rows_base = (unsigned)(uintptr_t)rows_s, xs_base = (unsigned)(uintptr_t)xs;
-    // transposed-read addresses of k-step 0: row 8g + q4 (and +4), chunk c4
-    const unsigned xs_addr = xs_base + (unsigned)((8 * g + q4) * 32 + c4 * 8);
-    const unsigned short *li_b2 = lidx_s + tb_pos(8 * g + q4);
-
     for (int tt = slot; tt < cnt; tt += L) {
         const int tile = lo + tt, t0 = tile * TB_T;
+        // Every address below depends only on the lane: left alone, hipcc hoists ~100 of them out of the
+        // tile loop and holds them in registers for the whole kernel (occupancy 3 -> 2).  The lane id is
+        // laundered once per tile, so they are recomputed (a few dozen VALU operations per tile).
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, i = lane & 15, g = lane >> 4;
+        const unsigned half = (unsigned)(g & 1) * 16u;
+        const int q4 = i >> 2, c4 = i & 3;
+        const unsigned rows_base = (unsigned)(uintptr_t)rows_s, xs_base = (unsigned)(uintptr_t)xs;
+        // transposed-read address of k-step 0: row 8g + q4 (and +4), chunk c4
+        const unsigned xs_addr = xs_base + (unsigned)((8 * g + q4) * 32 + c4 * 8);
+        // data-grad weight fragments (W[26-o]^T, pair packing) are streamed per unit, three units ahead (the
+        // registers go to the weight-gradient accumulators; 13.8 KB of fragments stay in the CU's L1)
+        const unsigned lane_w = (unsigned)(g >> 1) * 512u + (unsigned)((g & 1) * 16 + i) * 16u;
+        auto loadw = [&](int u) { return __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)u * 1024u + lane_w, 0, 0); };
         // ---- phase A ----
         constexpr int NRL = (2 * TB_UMAX + 255) / 256;
         unsigned rid[NRL];
@@ -1214,31 +1214,42 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
         for (int s = 0; s < S; ++s) acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int row0 = t0 + wid * 64;
         if (staged) {
+            // local indices two units ahead, operand rows one unit ahead, weight fragments three ahead
             const unsigned short *my = lidx_s + wid * 64 + i * 4;
-            u32x2 l4[NU];
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
+            auto loadl = [&](int u) {
                 const int osel = 2 * u + (g >> 1);
-                l4[u] = (u32x2){(unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16), (unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16)};
-                if (osel < TB_K) l4[u] = *reinterpret_cast<const u32x2 *>(my + osel * TB_T);
-            }
-            auto fetch = [&](int u, u32x4 (&xa)[S]) {
-                xa[0] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][0] & 0xffffu) * 32u + half);
-                xa[1] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][0] >> 16) * 32u + half);
-                xa[2] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][1] & 0xffffu) * 32u + half);
-                xa[3] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][1] >> 16) * 32u + half);
+                u32x2 v = {(unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16), (unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16)};
+                if (osel < TB_K) v = *reinterpret_cast<const u32x2 *>(my + osel * TB_T);
+                return v;
             };
-            u32x4 xa[2][S];
-            fetch(0, xa[0]);
+            auto fetch = [&](const u32x2 &l, u32x4 (&xa)[S]) {
+                xa[0] = *reinterpret_cast<const u32x4 *>(rows_s + (l[0] & 0xffffu) * 32u + half);
+                xa[1] = *reinterpret_cast<const u32x4 *>(rows_s + (l[0] >> 16) * 32u + half);
+                xa[2] = *reinterpret_cast<const u32x4 *>(rows_s + (l[1] & 0xffffu) * 32u + half);
+                xa[3] = *reinterpret_cast<const u32x4 *>(rows_s + (l[1] >> 16) * 32u + half);
+            };
+            u32x4 xa[2][S], wr[4];
+            u32x2 lr[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) wr[u] = loadw(u);
+            lr[0] = loadl(0);
+            lr[1] = loadl(1);
+            fetch(lr[0], xa[0]);
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-                if (u + 1 < NU) fetch(u + 1, xa[(u + 1) & 1]);
+                if (u + 2 < NU) lr[(u + 2) % 3] = loadl(u + 2);
+                if (u + 1 < NU) fetch(lr[(u + 1) % 3], xa[(u + 1) & 1]);
+                if (u + 3 < NU) wr[(u + 3) & 3] = loadw(u + 3);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s = 0; s < S; ++s) PBF16P::mma(acc[s][0], wf[u], xa[u & 1][s]);
+                for (int s = 0; s < S; ++s) PBF16P::mma(acc[s][0], wr[u & 3], xa[u & 1][s]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
+            // (ld laundered per tile: otherwise hipcc hoists the 27 x ld table offsets of this rarely taken
+            // path out of the tile loop and holds them in ~60 registers)
+            unsigned ldv = (unsigned)ld;
+            asm volatile("" : "+s"(ldv));
 #pragma unroll
             for (int u0 = 0; u0 < NU; u0 += 2) {
                 unsigned go[2][S];
@@ -1248,7 +1259,7 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         const int t = row0 + s * 16 + i;
-                        const unsigned voff = (osel < TB_K && t < n) ? ((unsigned)osel * (unsigned)ld + (unsigned)t) * 4u : OOB;
+                        const unsigned voff = (osel < TB_K && t < n) ? ((unsigned)osel * ldv + (unsigned)t) * 4u : OOB;
                         go[du][s] = __builtin_amdgcn_raw_buffer_load_b32(rs_t, voff, 0, 0);
                     }
                 }
@@ -1262,8 +1273,9 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
                         const bool present = osel < TB_K && t < n && (int)go[du][s] >= 0;
                         xa[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, present ? go[du][s] * 32u + half : OOB, 0, 0);
                     }
+                    const u32x4 wu = loadw(u0 + du);
 #pragma unroll
-                    for (int s = 0; s < S; ++s) PBF16P::mma(acc[s][0], wf[u0 + du], xa[s]);
+                    for (int s = 0; s < S; ++s) PBF16P::mma(acc[s][0], wu, xa[s]);
                 }
             }
         }
@@ -1271,12 +1283,14 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
 
         // ---- phase B2: weight gradient ----
         if (staged) {
+            const unsigned xs_a = xs_addr;
+            const unsigned short *li_t = lidx_s + tb_pos(8 * g + q4);
 #pragma unroll
             for (int ks = 0; ks < TB_T / 32; ++ks) {
                 // x^T fragment of the k-step: channel i of rows 32 ks + 8 g + 0..7
-                const unsigned xa_addr = xs_addr + (unsigned)ks * 32u * 32u;
+                const unsigned xa_addr = xs_a + (unsigned)ks * 32u * 32u;
                 s16x4 a_lo = lds_tr_b64(xa_addr), a_hi = lds_tr_b64(xa_addr + 4u * 32u);
-                const unsigned short *lk = li_b2 + (ks >> 1) * 64 + (ks & 1) * 2;
+                const unsigned short *lk = li_t + (ks >> 1) * 64 + (ks & 1) * 2;
                 unsigned ra[7], rb[7];
 #pragma unroll
                 for (int m = 0; m < 7; ++m) {
@@ -1298,13 +1312,15 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
             }
         } else {
             // four offsets per pass: wave w' stages dy[tbl[26 - (4 pass + w')][t0 + r]] at rows_s[w' * 256 + r]
+            unsigned ldw = (unsigned)ld;
+            asm volatile("" : "+s"(ldw));
             for (int pass = 0; pass < 7; ++pass) {
                 __syncthreads();
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int h = k * 256 + tid, w2 = h >> 9, r = (h >> 1) & 255, o = 4 * pass + w2;
                     int gi = -1;
-                    if (o < TB_K && t0 + r < n) gi = tbl[(long long)(TB_K - 1 - o) * ld + t0 + r];
+                    if (o < TB_K && t0 + r < n) gi = tbl[(size_t)(TB_K - 1 - o) * ldw + (size_t)(t0 + r)];
                     reinterpret_cast<u32x4 *>(rows_s)[h] =
                         __builtin_amdgcn_raw_buffer_load_b128(rs_dy, gi >= 0 ? (unsigned)gi * 32u + (unsigned)(h & 1) * 16u : OOB, 0, 0);
                 }
@@ -1330,6 +1346,7 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
         __syncthreads();   // the next tile overwrites the staged rows
     }
     // partial of this workgroup: dW[o][ci = 4 g + r][co = i] for the wave's offsets
+    const int i = tid0 & 15, g = (tid0 & 63) >> 4;
     float *dst = part + (size_t)blockIdx.x * (TB_K * 256);
 #pragma unroll
     for (int m = 0; m < 7; ++m) {
@@ -1341,21 +1358,32 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
     }
 }
 
-// dw[e] (+)= sum over workgroups, fixed order
-__global__ __launch_bounds__(256) void bwd_tile_reduce(const float *__restrict__ part, int n_part, float *__restrict__ dw,
+// dw[e] (+)= sum over workgroups, fixed order.  One workgroup per 32 outputs (128-byte segments of the
+// partial rows); its 16 lane groups take every 16th partial, eight loads in flight each, and are combined in
+// a fixed tree through LDS.  (A thread per output walking all partials serially took ~90 us: 27 workgroups,
+// one dependent HBM round trip per four partials.)
+__global__ __launch_bounds__(512) void bwd_tile_reduce(const float *__restrict__ part, int n_part, float *__restrict__ dw,
                                                        int accumulate) {
-    const int e = blockIdx.x * 256 + threadIdx.x;   // < 27 * 256
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int b = 0;
-    for (; b + 3 < n_part; b += 4) {
-        a0 += part[(size_t)b * (TB_K * 256) + e];
-        a1 += part[(size_t)(b + 1) * (TB_K * 256) + e];
-        a2 += part[(size_t)(b + 2) * (TB_K * 256) + e];
-        a3 += part[(size_t)(b + 3) * (TB_K * 256) + e];
+    __shared__ float red[16][32];
+    const int j = threadIdx.x & 31, p = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + j;
+    float a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = 0.f;
+    int b = p;
+    for (; b + 7 * 16 < n_part; b += 8 * 16) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += part[(size_t)(b + q * 16) * (TB_K * 256) + e];
     }
-    for (; b < n_part; ++b) a0 += part[(size_t)b * (TB_K * 256) + e];
-    const float v = (a0 + a1) + (a2 + a3);
-    dw[e] = accumulate ? dw[e] + v : v;
+    for (int q = 0; b < n_part; b += 16, ++q) a[q & 7] += part[(size_t)b * (TB_K * 256) + e];
+    red[p][j] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (p == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += red[q][j];
+        dw[e] = accumulate ? dw[e] + v : v;
+    }
 }
 
 template <class P, int NBW, int S, bool SPLIT = false>
@@ -1677,7 +1705,7 @@ extern "C" int doda_spconv_bwd_tile_bf16(const uint16_t *dy, const uint16_t *x, 
     else
         hipLaunchKernelGGL((bwd_tile<false>), dim3(groups), dim3(256), 0, s, dy, fb, x, wp, (unsigned)need, tbl, (int)ld,
                            (int)n_rows, tb, dx, ep, part);
-    hipLaunchKernelGGL(bwd_tile_reduce, dim3(TB_K), dim3(256), 0, s, part, groups, dw, accumulate);
+    hipLaunchKernelGGL(bwd_tile_reduce, dim3(TB_K * 256 / 32), dim3(512), 0, s, part, groups, dw, accumulate);
     if (epi && epi->stats_rows_h) *epi->stats_rows_h = ep.stats ? tb.nt : 0;
     return doda_check_launch();
 }

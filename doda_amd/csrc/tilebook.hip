@@ -4,7 +4,7 @@
 //   2. the distinct rows are compacted (slot order) and sorted ascending by a bitonic network in LDS —
 //      the sorted list is what makes the kernel's row loads coalesce (runs of consecutive rows) and makes
 //      the result independent of the order in which the atomics landed (deterministic bytes);
-//   3. every entry is replaced by its position in the sorted list (branch-free binary search).
+//   3. every entry is replaced by its position in the sorted list (rank stored next to the hash slot).
 // A tile with more than TB_UMAX distinct rows only records its count; the convolution kernel then reads
 // the dense table for that tile.  spconv has no counterpart (it keeps pair lists and gathers per offset);
 // the dense table stays the source of truth and the reference for parity (tests/test_gpu_tile.py).
@@ -21,6 +21,8 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
     __shared__ unsigned htab[HCAP];
     constexpr int UQ = 1024;          // sort buffer: the power of two above TB_UMAX
     __shared__ unsigned uq[UQ];
+    static_assert(TB_UMAX <= UQ, "sort buffer");
+    __shared__ unsigned short hrank[HCAP];
     __shared__ int cnt;
     __shared__ int wsum[4];
     const int tile = blockIdx.x, tid = threadIdx.x, t0 = tile * TB_T;
@@ -100,24 +102,28 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
     for (int k = tid; k < TB_UMAX; k += 256) ul[k] = k < U ? (int32_t)uq[k] : -1;
 
     // ---- 3. local indices ----
-    // the 27 searches of a thread advance together: 10 rounds of 27 independent LDS reads instead of 270
-    // dependent ones
-    uint16_t *li = v.lidx + (size_t)tile * TB_K * TB_T + tb_pos(tid);
-    int lo[TB_K];
-#pragma unroll
-    for (int o = 0; o < TB_K; ++o) lo[o] = 0;
-    static_assert(TB_UMAX <= UQ && UQ == 1024, "sort buffer / search steps");
-#pragma unroll
-    for (int s = 512; s > 0; s >>= 1) {
-#pragma unroll
-        for (int o = 0; o < TB_K; ++o) {
-            const int m = lo[o] + s;
-            const unsigned probe = uq[m < UQ ? m : UQ - 1];
-            lo[o] = (m < U && probe <= (unsigned)e[o]) ? m : lo[o];   // absent entries (-1) run to U-1, discarded below
-        }
+    // position of every key: the sorted list writes each key's rank next to its hash slot, then every
+    // table entry is one hash probe (~1.1 LDS reads) + one rank read.  (A binary search per entry — 270 LDS
+    // reads per thread — made this phase as expensive as the sort: the builder is LDS-throughput bound.)
+    for (int k = tid; k < U; k += 256) {
+        const unsigned key = uq[k];
+        unsigned slot = hash_mix(key) & (HCAP - 1);
+        while (htab[slot] != key) slot = (slot + 1) & (HCAP - 1);
+        hrank[slot] = (unsigned short)k;
     }
+    __syncthreads();
+    uint16_t *li = v.lidx + (size_t)tile * TB_K * TB_T + tb_pos(tid);
 #pragma unroll
-    for (int o = 0; o < TB_K; ++o) li[o * TB_T] = (uint16_t)(e[o] >= 0 ? lo[o] : TB_ZROW);
+    for (int o = 0; o < TB_K; ++o) {
+        unsigned short r = (unsigned short)TB_ZROW;
+        if (e[o] >= 0) {
+            const unsigned key = (unsigned)e[o];
+            unsigned slot = hash_mix(key) & (HCAP - 1);
+            while (htab[slot] != key) slot = (slot + 1) & (HCAP - 1);
+            r = hrank[slot];
+        }
+        li[o * TB_T] = r;
+    }
 }
 
 }  // namespace

@@ -288,6 +288,32 @@ def tilebook_build(tbl, n_rows=None):
     return tb
 
 
+def spconv_bwd_tile(dy, x, w, tbl, tilebook, packed=None, dw_out=None):
+    """Fused SubM backward of a bf16 16 -> 16, K = 27 layer (doda_spconv_bwd_tile_bf16): returns (dx, dw) with
+    dx = data gradient [n,16] bf16 and dw = weight gradient fp32 [27,16,16].  w: the layer's fp32 weight viewed
+    [27,16,16] ([K][Cin][Cout], what a w_layout-2 gather call takes) or `packed` = its layout-2 fragment buffer;
+    dw_out: accumulate into this tensor instead of returning a fresh one."""
+    _need_cuda(dy, x, tbl, tilebook)
+    n = dy.shape[0]
+    if (dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or tuple(dy.shape) != (n, 16) or tuple(x.shape) != (n, 16)
+            or tbl.shape[0] != 27 or not dy.is_contiguous() or not x.is_contiguous()):
+        raise RuntimeError("spconv_bwd_tile: contiguous bf16 [n,16] dy and x, 27-offset table")
+    dx = torch.empty_like(dy)
+    dw = dw_out if dw_out is not None else torch.empty((27, 16, 16), dtype=torch.float32, device=dy.device)
+    ws = _ws(lib().doda_spconv_bwd_tile_workspace_bytes(), dy.device)
+    if packed is not None:
+        w_ptr, is_packed = _p(packed), 1
+    else:
+        w = w.contiguous()
+        if w.dtype != torch.float32 or w.numel() != 27 * 256:
+            raise RuntimeError("spconv_bwd_tile: weight must be float32 [27,16,16]")
+        w_ptr, is_packed = _p(w), 0
+    check(lib().doda_spconv_bwd_tile_bf16(_p(dy), _p(x), n, w_ptr, is_packed, _p(tbl), tbl.shape[1], _p(tilebook), _p(dx),
+                                          _p(dw), int(dw_out is not None), _p(ws), ws.numel(), None, _stream()),
+          "doda_spconv_bwd_tile_bf16")
+    return dx, dw
+
+
 def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, residual=None, tilebook=None):
     """y[t] = sum_o x[tbl[o][t]] @ B_o (see doda_hip.h).  x: [n_in,kc] f32|bf16; w: fp32 weights
     viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2), or `packed`: the fragment-packed buffer

@@ -49,6 +49,15 @@ def main():
            "tilebook_bytes": tb.numel(), "table_bytes": data.tbl.numel() * 4,
            "dense_us": timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk)),
            "tile_us": timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk, tilebook=tb))}
+    if a.nc == 16:
+        gy = torch.randn(m, 16, device=d).bfloat16()
+        plan2 = ops.PackPlan([(w, 27, 16, 16, 2, 2)], d)
+        plan2.run()
+        out["bwd_tile_us"] = timed(lambda: ops.spconv_bwd_tile(gy, x, None, data.tbl, tb, packed=plan2.outputs[0]))
+        out["dgrad_tile_us"] = timed(lambda: ops.spconv_gather(gy, None, data.tbl, m, 2, 16, packed=plan2.outputs[0], tilebook=tb))
+        pairs = data.wgrad_lists()
+        jobs = [(x, gy, data.tbl, m, pairs)] * 8
+        out["wgrad_pairs_us_per_layer"] = timed(lambda: ops.spconv_wgrad_multi(jobs)) / 8
     y0 = ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk, out_f32=True)
     y1 = ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk, out_f32=True, tilebook=tb)
     out["max_rel_diff"] = ((y0 - y1).abs().max() / y0.abs().max()).item()
