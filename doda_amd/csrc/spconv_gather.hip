@@ -843,12 +843,45 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
 // Same arithmetic as conv_fast<PBF16P> up to the order in which offsets are paired (fixed (2u, 2u+1)
 // here, pairs of ACTIVE offsets there): fp32 accumulation, one bf16 rounding at the store.
 // ---------------------------------------------------------------------------------------------
-// Store epilogue of the tile kernel: conv_fast's epilogue for bf16 features, one channel block, four waves
+// Store epilogue of the tile kernels: conv_fast's epilogue for bf16 features, one channel block, four waves
 // holding four row ranges of the workgroup's tile (residual add, single bf16 rounding, BatchNorm statistics
-// as one partial row per workgroup — see EpiArgs).
+// as one partial row per workgroup — see EpiArgs).  The two operands it reads from global memory — the
+// residual rows and the BatchNorm input rows — are requested by epi_prefetch BEFORE the multiply phase, so
+// the store does not wait for another memory round trip at the end of a tile's dependency chain.
+template <bool OUT32> struct EpiPre { u32x4 res[4], bnx[4]; };   // four channels of a row: fp32 ...
+template <> struct EpiPre<false> { u32x2 res[4], bnx[4]; };        // ... or bf16
+
 template <int S, bool OUT32, bool STATS>
-__device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], int row0, int i, int g, int wid, int nb0, int nc,
-                                              int n_out, __amdgpu_buffer_rsrc_t rs_y, unsigned y_bytes,
+__device__ __forceinline__ void epi_prefetch(EpiPre<OUT32> &pre, int row0, int i, int g, int nb0, int nc, int n_out,
+                                             unsigned y_bytes, const void *__restrict__ res, const EpiArgs &ep) {
+    constexpr unsigned OSZ = OUT32 ? 4u : 2u;
+    const unsigned col = (unsigned)(nb0 * 16 + 4 * g);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)ep.bn_x, 0, y_bytes, 0x00020000);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const unsigned t = (unsigned)(row0 + s * 16 + i);
+        const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * (unsigned)nc + col) * OSZ : OOB;
+        if (res) {
+            if constexpr (OUT32) pre.res[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, voff, 0, 0);
+            else pre.res[s] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, voff, 0, 0);
+        }
+        if (STATS && ep.bn_x) {
+            if constexpr (OUT32) pre.bnx[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff, 0, 0);
+            else pre.bnx[s] = __builtin_amdgcn_raw_buffer_load_b64(rs_b, voff, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ f32x4 epi_unpack(const u32x4 &v) { return __builtin_bit_cast(f32x4, v); }
+__device__ __forceinline__ f32x4 epi_unpack(const u32x2 &v) {
+    return (f32x4){__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u),
+                   __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
+}
+
+template <int S, bool OUT32, bool STATS>
+__device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<OUT32> &pre, int row0, int i, int g, int wid,
+                                              int nb0, int nc, int n_out, __amdgpu_buffer_rsrc_t rs_y,
                                               const void *__restrict__ res, const EpiArgs &ep, int part) {
     constexpr unsigned OSZ = OUT32 ? 4u : 2u;
     __shared__ f32x4 sred[STATS ? 4 : 1][2][4];
@@ -859,20 +892,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], int row0, int 
         const unsigned t = (unsigned)(row0 + s * 16 + i);
         const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * (unsigned)nc + col) * OSZ : OOB;
         f32x4 a = acc[s][0];
-        if (res) {
-            const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, y_bytes, 0x00020000);
-            if (OUT32) {
-                const f32x4 r4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, voff, 0, 0));
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a[q] += r4[q];
-            } else {
-                const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rs_r, voff, 0, 0);
-                a[0] += __uint_as_float(r2[0] << 16);
-                a[1] += __uint_as_float(r2[0] & 0xffff0000u);
-                a[2] += __uint_as_float(r2[1] << 16);
-                a[3] += __uint_as_float(r2[1] & 0xffff0000u);
-            }
-        }
+        if (res) a += epi_unpack(pre.res[s]);
         u32x2 packed_out = {0u, 0u};
         if constexpr (!OUT32) {
             packed_out[0] = (unsigned)f2bf(a[0]) | ((unsigned)f2bf(a[1]) << 16);
@@ -880,20 +900,9 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], int row0, int 
         }
         if constexpr (STATS) {
             f32x4 v = a;
-            if constexpr (!OUT32) {
-                v = (f32x4){__uint_as_float(packed_out[0] << 16), __uint_as_float(packed_out[0] & 0xffff0000u),
-                            __uint_as_float(packed_out[1] << 16), __uint_as_float(packed_out[1] & 0xffff0000u)};
-            }
+            if constexpr (!OUT32) v = epi_unpack(packed_out);
             if (ep.bn_x) {
-                const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)ep.bn_x, 0, y_bytes, 0x00020000);
-                f32x4 xr;
-                if (OUT32) {
-                    xr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff, 0, 0));
-                } else {
-                    const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rs_b, voff, 0, 0);
-                    xr = (f32x4){__uint_as_float(r2[0] << 16), __uint_as_float(r2[0] & 0xffff0000u),
-                                 __uint_as_float(r2[1] << 16), __uint_as_float(r2[1] & 0xffff0000u)};
-                }
+                const f32x4 xr = epi_unpack(pre.bnx[s]);
                 const unsigned cc = col < (unsigned)nc ? col : 0u;
                 const f32x4 mu = *reinterpret_cast<const f32x4 *>(ep.bn_mean + cc);
                 const f32x4 is = *reinterpret_cast<const f32x4 *>(ep.bn_invstd + cc);
@@ -932,6 +941,12 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], int row0, int 
     }
 }
 
+// PERSISTENT: 3 workgroups per CU (LDS footprint), XCD (blockIdx & 7) walks its own contiguous range of
+// tiles.  A tile's dependency chain is  list -> rows -> LDS -> multiply -> store; inside a training step the
+// operands come from HBM, not from the Infinity Cache a back-to-back micro-benchmark enjoys, and each link
+// costs 1-2 us.  So the list (and count) of the workgroup's NEXT tile is requested while the current one is
+// multiplied, the epilogue's operands are requested before the multiply phase, and the weight fragments are
+// loaded once per workgroup: one exposed round trip per tile (the rows) instead of three.
 template <bool OUT32, bool STATS>
 __global__ __launch_bounds__(256) void conv_tile(const unsigned short *__restrict__ x, unsigned x_bytes,
                                                  const void *__restrict__ wp, unsigned wp_bytes, int nc, int NB,
@@ -939,141 +954,174 @@ __global__ __launch_bounds__(256) void conv_tile(const unsigned short *__restric
                                                  const TileBookView tb, void *__restrict__ y, unsigned y_bytes,
                                                  const void *__restrict__ res, const EpiArgs ep) {
     constexpr int S = 4, NU = (TB_K + 1) / 2;
+    constexpr int NRL = (2 * TB_UMAX + 255) / 256;            // row loads per thread
+    constexpr int NLI = (TB_K * TB_T * 2 / 16 + 255) / 256;   // 16-byte pieces of the index strip per thread
     __shared__ __attribute__((aligned(16))) unsigned char rows_s[(TB_UMAX + 1) * 32];
     __shared__ __attribute__((aligned(16))) unsigned short lidx_s[TB_K * TB_T];
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 15, g = lane >> 4;
-    const int item = xcd_work_item(blockIdx.x, gridDim.x);
-    const int tile = item / NB, nb0 = item % NB;
-    const int t0 = tile * TB_T;
+    const int tid0 = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, wp_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void *)tbl, 0, (unsigned)TB_K * (unsigned)ld * 4u, 0x00020000);
 
-    // ---- phase A ----
-    // Everything that does not depend on device data is requested at once: the distinct-row list, the
-    // local-index strip, the count and the weight fragments of the 14 offset pairs (offset 27 lies past
-    // the packed buffer: zeros); the rows follow as soon as the list is in registers.  An overflowing
-    // tile (count > TB_UMAX) has a list of -1 and an unwritten strip; both loads are harmless.
-    // half-row h = 16 bytes: lanes 2k, 2k+1 take the two halves of list entry k (a wave reads 32
-    // consecutive entries = one 128-byte line per instruction).  Entries past the count are -1: their
-    // row offset is out of range and loads zeros — no lane is masked, no branch.
-    constexpr int NRL = (2 * TB_UMAX + 255) / 256;            // row loads per thread
-    unsigned rid[NRL];
-    {
+    const int L = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int qn = tb.nt >> 3, rn = tb.nt & 7;
+    const int lo = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
+    const int cnt = qn + (xcd < rn ? 1 : 0);
+
+    // half-row h = 16 bytes: lanes 2k, 2k+1 take the two halves of list entry k (a wave reads 32 consecutive
+    // entries = one 128-byte line per instruction).  Entries past the count are -1: their row offset is out
+    // of range and loads zeros — no lane is masked, no branch.
+    auto load_list = [&](int tile, int tid, unsigned (&rid)[NRL]) {
         const int32_t *ul = tb.ulist + (size_t)tile * TB_UMAX;
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
             const int e = (k * 256 + tid) >> 1;
             rid[k] = e < TB_UMAX ? (unsigned)ul[e] : 0xffffffffu;
         }
+    };
+    unsigned rid[NRL];
+    int U = 0;
+    if (slot < cnt) {
+        load_list(lo + slot, tid0, rid);
+        U = tb.ucount[lo + slot];
     }
-    constexpr int NLI = (TB_K * TB_T * 2 / 16 + 255) / 256;   // 16-byte pieces of the strip per thread
-    u32x4 li4[NLI];
-    {
-        const u32x4 *li = reinterpret_cast<const u32x4 *>(tb.lidx + (size_t)tile * TB_K * TB_T);
-#pragma unroll
-        for (int k = 0; k < NLI; ++k) {
-            const int e = k * 256 + tid;
-            li4[k] = li[e < TB_K * TB_T * 2 / 16 ? e : 0];
-        }
-    }
-    const int U = tb.ucount[tile];
-    u32x4 wf[NU];
-    {
-        const unsigned lane_w = (unsigned)((g & 1) * 16 + i) * 16u + (unsigned)nb0 * 512u;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const unsigned osel = 2u * u + (unsigned)(g >> 1);
-            wf[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, osel * (unsigned)NB * 512u + lane_w, 0, 0);
-        }
-    }
-    const bool staged = U <= TB_UMAX;
-    if (staged) {
-        u32x4 rr[NRL];
-#pragma unroll
-        for (int k = 0; k < NRL; ++k)
-            rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, rid[k] * 32u + (unsigned)(tid & 1) * 16u, 0, 0);
-#pragma unroll
-        for (int k = 0; k < NLI; ++k) {
-            const int e = k * 256 + tid;
-            if (e < TB_K * TB_T * 2 / 16) reinterpret_cast<u32x4 *>(lidx_s)[e] = li4[k];
-        }
-        if (tid < 2) reinterpret_cast<u32x4 *>(rows_s)[TB_ZROW * 2 + tid] = (u32x4){0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int k = 0; k < NRL; ++k)
-            if (k * 256 + tid < 2 * TB_UMAX) reinterpret_cast<u32x4 *>(rows_s)[k * 256 + tid] = rr[k];
-        __syncthreads();
-    }
+    for (int tt = slot; tt < cnt; tt += L) {
+        const int tile = lo + tt, t0 = tile * TB_T;
+        // every address below depends only on the lane; laundering the lane id once per tile keeps hipcc from
+        // hoisting them out of the tile loop into ~100 long-lived registers
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, i = lane & 15, g = lane >> 4;
+        const bool staged = U <= TB_UMAX;
+        const int row0 = t0 + wid * 64;
+        const unsigned half = (unsigned)(g & 1) * 16u;
+        // weight fragments (pair packing; offset 27 lies past the packed buffer: zeros) are streamed per unit,
+        // three units ahead: held in registers (56) next to the prefetch state they cost the third wave per
+        // SIMD; 13.8 KB of fragments stay in the CU's L1
+        unsigned lane_w = (unsigned)(g >> 1) * (unsigned)NB * 512u + (unsigned)((g & 1) * 16 + i) * 16u;
+        auto loadw = [&](int u) { return __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)u * (unsigned)NB * 1024u + lane_w, 0, 0); };
+        // the epilogue's operands of the first channel block travel with the rows
+        EpiPre<OUT32> pre;
+        epi_prefetch<S, OUT32, STATS>(pre, row0, i, g, 0, nc, n_out, y_bytes, res, ep);
 
-    // ---- phase B ----
-    f32x4 acc[S][1];
+        // ---- phase A: rows of this tile (their list is already here), index strip, next tile's list ----
+        if (staged) {
+            u32x4 rr[NRL];
 #pragma unroll
-    for (int s = 0; s < S; ++s) acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int row0 = t0 + wid * 64;
-    const unsigned half = (unsigned)(g & 1) * 16u;
-    if (staged) {
-        // all local indices of the lane first (14 x 8 bytes), then the units with the operand reads of
-        // unit u+1 issued before the MFMAs of unit u (the scheduling barriers keep hipcc from sinking the
-        // reads next to their use, which left one LDS round trip exposed per MFMA)
-        const unsigned short *my = lidx_s + wid * 64 + i * 4;
-        u32x2 l4[NU];
+            for (int k = 0; k < NRL; ++k)
+                rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, rid[k] * 32u + (unsigned)(tid & 1) * 16u, 0, 0);
+            u32x4 li4[NLI];
+            const u32x4 *li = reinterpret_cast<const u32x4 *>(tb.lidx + (size_t)tile * TB_K * TB_T);
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int osel = 2 * u + (g >> 1);
-            l4[u] = (u32x2){(unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16), (unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16)};
-            if (osel < TB_K) l4[u] = *reinterpret_cast<const u32x2 *>(my + osel * TB_T);
-        }
-        auto fetch = [&](int u, u32x4 (&xa)[S]) {
-            xa[0] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][0] & 0xffffu) * 32u + half);
-            xa[1] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][0] >> 16) * 32u + half);
-            xa[2] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][1] & 0xffffu) * 32u + half);
-            xa[3] = *reinterpret_cast<const u32x4 *>(rows_s + (l4[u][1] >> 16) * 32u + half);
-        };
-        u32x4 xa[2][S];
-        fetch(0, xa[0]);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            if (u + 1 < NU) fetch(u + 1, xa[(u + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < S; ++s) PBF16P::mma(acc[s][0], wf[u], xa[u & 1][s]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-        // overflow tile: same units, operands gathered from global memory through the dense table; the
-        // table entries of two units, then their rows (straight-line code, counted waits)
-        const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void *)tbl, 0, (unsigned)TB_K * (unsigned)ld * 4u, 0x00020000);
-#pragma unroll
-        for (int u0 = 0; u0 < NU; u0 += 2) {
-            unsigned go[2][S];
-#pragma unroll
-            for (int du = 0; du < 2; ++du) {
-                const int osel = 2 * (u0 + du) + (g >> 1);
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const int t = row0 + s * 16 + i;
-                    const unsigned voff = (osel < TB_K && t < n_out) ? ((unsigned)osel * (unsigned)ld + (unsigned)t) * 4u : OOB;
-                    go[du][s] = __builtin_amdgcn_raw_buffer_load_b32(rs_t, voff, 0, 0);
-                }
+            for (int k = 0; k < NLI; ++k) {
+                const int e = k * 256 + tid;
+                li4[k] = li[e < TB_K * TB_T * 2 / 16 ? e : 0];
+            }
+            if (tt + L < cnt) {
+                load_list(tile + L, tid, rid);
+                U = tb.ucount[tile + L];
             }
 #pragma unroll
-            for (int du = 0; du < 2; ++du) {
-                const int osel = 2 * (u0 + du) + (g >> 1);
-                u32x4 xa[S];
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const int t = row0 + s * 16 + i;
-                    const bool present = osel < TB_K && t < n_out && (int)go[du][s] >= 0;   // out-of-range table reads return 0
-                    xa[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, present ? go[du][s] * 32u + half : OOB, 0, 0);
-                }
-#pragma unroll
-                for (int s = 0; s < S; ++s) PBF16P::mma(acc[s][0], wf[u0 + du], xa[s]);
+            for (int k = 0; k < NLI; ++k) {
+                const int e = k * 256 + tid;
+                if (e < TB_K * TB_T * 2 / 16) reinterpret_cast<u32x4 *>(lidx_s)[e] = li4[k];
             }
+            if (tid < 2) reinterpret_cast<u32x4 *>(rows_s)[TB_ZROW * 2 + tid] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < NRL; ++k)
+                if (k * 256 + tid < 2 * TB_UMAX) reinterpret_cast<u32x4 *>(rows_s)[k * 256 + tid] = rr[k];
+        } else if (tt + L < cnt) {
+            load_list(tile + L, tid, rid);
+            U = tb.ucount[tile + L];
         }
+        __syncthreads();
+
+        for (int nb0 = 0; nb0 < NB; ++nb0) {
+            if (nb0 > 0) {
+                lane_w += 512u;
+                epi_prefetch<S, OUT32, STATS>(pre, row0, i, g, nb0, nc, n_out, y_bytes, res, ep);
+            }
+
+            // ---- phase B ----
+            f32x4 acc[S][1];
+#pragma unroll
+            for (int s = 0; s < S; ++s) acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (staged) {
+                // local indices two units ahead, operand rows one unit ahead of the MFMAs (the scheduling
+                // barriers keep hipcc from sinking the reads next to their use, which left one LDS round trip
+                // exposed per MFMA)
+                const unsigned short *my = lidx_s + wid * 64 + i * 4;
+                auto loadl = [&](int u) {
+                    const int osel = 2 * u + (g >> 1);
+                    u32x2 v = {(unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16), (unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16)};
+                    if (osel < TB_K) v = *reinterpret_cast<const u32x2 *>(my + osel * TB_T);
+                    return v;
+                };
+                auto fetch = [&](const u32x2 &l, u32x4 (&xa)[S]) {
+                    xa[0] = *reinterpret_cast<const u32x4 *>(rows_s + (l[0] & 0xffffu) * 32u + half);
+                    xa[1] = *reinterpret_cast<const u32x4 *>(rows_s + (l[0] >> 16) * 32u + half);
+                    xa[2] = *reinterpret_cast<const u32x4 *>(rows_s + (l[1] & 0xffffu) * 32u + half);
+                    xa[3] = *reinterpret_cast<const u32x4 *>(rows_s + (l[1] >> 16) * 32u + half);
+                };
+                u32x4 xa[2][S], wr[4];
+                u32x2 lr[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) wr[u] = loadw(u);
+                lr[0] = loadl(0);
+                lr[1] = loadl(1);
+                fetch(lr[0], xa[0]);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    if (u + 2 < NU) lr[(u + 2) % 3] = loadl(u + 2);
+                    if (u + 1 < NU) fetch(lr[(u + 1) % 3], xa[(u + 1) & 1]);
+                    if (u + 3 < NU) wr[(u + 3) & 3] = loadw(u + 3);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) PBF16P::mma(acc[s][0], wr[u & 3], xa[u & 1][s]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // overflow tile: same units, operands gathered from global memory through the dense table; the
+                // table entries of two units, then their rows (straight-line code, counted waits).  (ld
+                // laundered: otherwise its 27 multiples are hoisted out of the tile loop.)
+                unsigned ldv = (unsigned)ld;
+                asm volatile("" : "+s"(ldv));
+#pragma unroll
+                for (int u0 = 0; u0 < NU; u0 += 2) {
+                    unsigned go[2][S];
+#pragma unroll
+                    for (int du = 0; du < 2; ++du) {
+                        const int osel = 2 * (u0 + du) + (g >> 1);
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            const int t = row0 + s * 16 + i;
+                            const unsigned voff = (osel < TB_K && t < n_out) ? ((unsigned)osel * ldv + (unsigned)t) * 4u : OOB;
+                            go[du][s] = __builtin_amdgcn_raw_buffer_load_b32(rs_t, voff, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int du = 0; du < 2; ++du) {
+                        const int osel = 2 * (u0 + du) + (g >> 1);
+                        u32x4 xa[S];
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            const int t = row0 + s * 16 + i;
+                            const bool present = osel < TB_K && t < n_out && (int)go[du][s] >= 0;   // out-of-range table reads return 0
+                            xa[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, present ? go[du][s] * 32u + half : OOB, 0, 0);
+                        }
+                        const u32x4 wu = loadw(u0 + du);
+#pragma unroll
+                        for (int s = 0; s < S; ++s) PBF16P::mma(acc[s][0], wu, xa[s]);
+                    }
+                }
+            }
+            tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, wid, nb0, nc, n_out, rs_y, res, ep, tile);
+            if (STATS && nb0 + 1 < NB) __syncthreads();   // the statistics scratch is reused by the next channel block
+        }
+        __syncthreads();   // the next tile overwrites the staged rows
     }
-    tile_epilogue<S, OUT32, STATS>(acc, row0, i, g, wid, nb0, nc, n_out, rs_y, y_bytes, res, ep, tile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1209,6 +1257,8 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
         __syncthreads();
 
         // ---- phase B1: data gradient (conv_tile's loop) ----
+        EpiPre<false> pre;
+        epi_prefetch<S, false, STATS>(pre, t0 + wid * 64, i, g, 0, 16, n, feat_bytes, nullptr, ep);
         f32x4 acc[S][1];
 #pragma unroll
         for (int s = 0; s < S; ++s) acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1279,7 +1329,7 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
                 }
             }
         }
-        tile_epilogue<S, false, STATS>(acc, row0, i, g, wid, 0, 16, n, rs_o, feat_bytes, nullptr, ep, tile);
+        tile_epilogue<S, false, STATS>(acc, pre, row0, i, g, wid, 0, 16, n, rs_o, nullptr, ep, tile);
 
         // ---- phase B2: weight gradient ----
         if (staged) {
@@ -1484,7 +1534,9 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     // Level-1 shape with a tilebook of this table: the LDS-staged tile kernel (conv_tile)
     if (pair && tilebook && K == TB_K && tilebook_rows == n_out && g_use_tile) {
         const TileBookView tb = tilebook_view(const_cast<void *>(tilebook), n_out);
-        const dim3 grid(tb.nt * NB), block(256);
+        int groups = (tb.nt + 7) / 8 * 8;   // persistent: 3 workgroups per CU, a multiple of the 8 XCDs
+        if (groups > BT_MAX_GROUPS) groups = BT_MAX_GROUPS;
+        const dim3 grid(groups), block(256);
         if (n_part) *n_part = tb.nt;
         const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
         const unsigned yb = (unsigned)((size_t)n_out * nc * (out32 ? 4 : sizeof(elem)));

@@ -58,6 +58,30 @@ def main():
         pairs = data.wgrad_lists()
         jobs = [(x, gy, data.tbl, m, pairs)] * 8
         out["wgrad_pairs_us_per_layer"] = timed(lambda: ops.spconv_wgrad_multi(jobs)) / 8
+    # cold variant: cycle through inputs / tables so that consecutive launches do not find their operands in the
+    # 256 MB Infinity Cache (what a kernel meets inside the training step)
+    xs = [torch.randn(m, 16, device=d).bfloat16() for _ in range(6)]
+    tbls = [data.tbl.clone() for _ in range(6)]
+    tbs = [ops.tilebook_build(t) for t in tbls]
+    k = [0]
+
+    def cold(tiled):
+        j = k[0] = (k[0] + 1) % 6
+        ops.spconv_gather(xs[j], None, tbls[j], m, 0, a.nc, packed=pk, tilebook=tbs[j] if tiled else None)
+    out["dense_cold_us"] = timed(lambda: cold(False))
+    out["tile_cold_us"] = timed(lambda: cold(True))
+    from doda_amd._ext import ext
+    if ext is not None and a.nc == 16:
+        wt = torch.nn.Parameter(w.view(3, 3, 3, 16, 16).clone())
+        res = torch.randn(m, 16, device=d).bfloat16()
+        tt = [ext.with_tilebook(t) for t in tbls]
+
+        def stats(tiled):
+            j = k[0] = (k[0] + 1) % 6
+            with torch.no_grad():
+                ext.indice_conv_stats(xs[j], wt, tt[j] if tiled else tbls[j], tt[j] if tiled else tbls[j], m, 2, pk, None, res)
+        out["dense_stats_res_cold_us"] = timed(lambda: stats(False))
+        out["tile_stats_res_cold_us"] = timed(lambda: stats(True))
     y0 = ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk, out_f32=True)
     y1 = ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk, out_f32=True, tilebook=tb)
     out["max_rel_diff"] = ((y0 - y1).abs().max() / y0.abs().max()).item()
