@@ -947,16 +947,21 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<O
 // costs 1-2 us.  So the list (and count) of the workgroup's NEXT tile is requested while the current one is
 // multiplied, the epilogue's operands are requested before the multiply phase, and the weight fragments are
 // loaded once per workgroup: one exposed round trip per tile (the rows) instead of three.
-template <bool OUT32, bool STATS>
+// WIDE: 32 input channels (64-byte rows, one kernel offset per MFMA k = 32, 27 units; LDS 75 KB -> 2 workgroups
+// per CU, which still keeps ~70 KB of row loads in flight per CU); else 16 input channels (32-byte rows, a PAIR
+// of offsets per MFMA, 14 units, 3 workgroups per CU).
+template <bool WIDE, bool OUT32, bool STATS>
 __global__ __launch_bounds__(256) void conv_tile(const unsigned short *__restrict__ x, unsigned x_bytes,
                                                  const void *__restrict__ wp, unsigned wp_bytes, int nc, int NB,
                                                  const int32_t *__restrict__ tbl, int ld, int n_out,
                                                  const TileBookView tb, void *__restrict__ y, unsigned y_bytes,
                                                  const void *__restrict__ res, const EpiArgs ep) {
-    constexpr int S = 4, NU = (TB_K + 1) / 2;
-    constexpr int NRL = (2 * TB_UMAX + 255) / 256;            // row loads per thread
+    constexpr int S = 4, NU = WIDE ? TB_K : (TB_K + 1) / 2;
+    constexpr int RB = WIDE ? 64 : 32;                         // bytes per staged row
+    constexpr int PPR = RB / 16;                               // 16-byte pieces per row
+    constexpr int NRL = (PPR * TB_UMAX + 255) / 256;           // row loads per thread
     constexpr int NLI = (TB_K * TB_T * 2 / 16 + 255) / 256;   // 16-byte pieces of the index strip per thread
-    __shared__ __attribute__((aligned(16))) unsigned char rows_s[(TB_UMAX + 1) * 32];
+    __shared__ __attribute__((aligned(16))) unsigned char rows_s[(TB_UMAX + 1) * RB];
     __shared__ __attribute__((aligned(16))) unsigned short lidx_s[TB_K * TB_T];
 
     const int tid0 = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -970,14 +975,14 @@ __global__ __launch_bounds__(256) void conv_tile(const unsigned short *__restric
     const int lo = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
     const int cnt = qn + (xcd < rn ? 1 : 0);
 
-    // half-row h = 16 bytes: lanes 2k, 2k+1 take the two halves of list entry k (a wave reads 32 consecutive
-    // entries = one 128-byte line per instruction).  Entries past the count are -1: their row offset is out
+    // piece h = 16 bytes: PPR consecutive lanes take the pieces of one list entry (a wave reads 32 or 16
+    // consecutive entries per instruction).  Entries past the count are -1: their row offset is out
     // of range and loads zeros — no lane is masked, no branch.
     auto load_list = [&](int tile, int tid, unsigned (&rid)[NRL]) {
         const int32_t *ul = tb.ulist + (size_t)tile * TB_UMAX;
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
-            const int e = (k * 256 + tid) >> 1;
+            const int e = (k * 256 + tid) / PPR;
             rid[k] = e < TB_UMAX ? (unsigned)ul[e] : 0xffffffffu;
         }
     };
@@ -996,11 +1001,13 @@ __global__ __launch_bounds__(256) void conv_tile(const unsigned short *__restric
         const int lane = tid & 63, i = lane & 15, g = lane >> 4;
         const bool staged = U <= TB_UMAX;
         const int row0 = t0 + wid * 64;
-        const unsigned half = (unsigned)(g & 1) * 16u;
+        const unsigned half = (unsigned)(WIDE ? g : (g & 1)) * 16u;   // the lane's 16-byte piece of an operand row
         // weight fragments (pair packing; offset 27 lies past the packed buffer: zeros) are streamed per unit,
         // three units ahead: held in registers (56) next to the prefetch state they cost the third wave per
         // SIMD; 13.8 KB of fragments stay in the CU's L1
-        unsigned lane_w = (unsigned)(g >> 1) * (unsigned)NB * 512u + (unsigned)((g & 1) * 16 + i) * 16u;
+        // pair packing [o][nb][32 slots], wide packing [o][nb][64 lanes]; 16 bytes per slot
+        unsigned lane_w = WIDE ? (unsigned)lane * 16u
+                               : (unsigned)(g >> 1) * (unsigned)NB * 512u + (unsigned)((g & 1) * 16 + i) * 16u;
         auto loadw = [&](int u) { return __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)u * (unsigned)NB * 1024u + lane_w, 0, 0); };
         // the epilogue's operands of the first channel block travel with the rows
         EpiPre<OUT32> pre;
@@ -1011,7 +1018,7 @@ __global__ __launch_bounds__(256) void conv_tile(const unsigned short *__restric
             u32x4 rr[NRL];
 #pragma unroll
             for (int k = 0; k < NRL; ++k)
-                rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, rid[k] * 32u + (unsigned)(tid & 1) * 16u, 0, 0);
+                rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, rid[k] * (unsigned)RB + (unsigned)(tid & (PPR - 1)) * 16u, 0, 0);
             u32x4 li4[NLI];
             const u32x4 *li = reinterpret_cast<const u32x4 *>(tb.lidx + (size_t)tile * TB_K * TB_T);
 #pragma unroll
@@ -1028,10 +1035,10 @@ __global__ __launch_bounds__(256) void conv_tile(const unsigned short *__restric
                 const int e = k * 256 + tid;
                 if (e < TB_K * TB_T * 2 / 16) reinterpret_cast<u32x4 *>(lidx_s)[e] = li4[k];
             }
-            if (tid < 2) reinterpret_cast<u32x4 *>(rows_s)[TB_ZROW * 2 + tid] = (u32x4){0u, 0u, 0u, 0u};
+            if (tid < PPR) reinterpret_cast<u32x4 *>(rows_s)[TB_ZROW * PPR + tid] = (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
             for (int k = 0; k < NRL; ++k)
-                if (k * 256 + tid < 2 * TB_UMAX) reinterpret_cast<u32x4 *>(rows_s)[k * 256 + tid] = rr[k];
+                if (k * 256 + tid < PPR * TB_UMAX) reinterpret_cast<u32x4 *>(rows_s)[k * 256 + tid] = rr[k];
         } else if (tt + L < cnt) {
             load_list(tile + L, tid, rid);
             U = tb.ucount[tile + L];
@@ -1040,7 +1047,7 @@ __global__ __launch_bounds__(256) void conv_tile(const unsigned short *__restric
 
         for (int nb0 = 0; nb0 < NB; ++nb0) {
             if (nb0 > 0) {
-                lane_w += 512u;
+                lane_w += WIDE ? 1024u : 512u;
                 epi_prefetch<S, OUT32, STATS>(pre, row0, i, g, nb0, nc, n_out, y_bytes, res, ep);
             }
 
@@ -1054,16 +1061,16 @@ __global__ __launch_bounds__(256) void conv_tile(const unsigned short *__restric
                 // exposed per MFMA)
                 const unsigned short *my = lidx_s + wid * 64 + i * 4;
                 auto loadl = [&](int u) {
-                    const int osel = 2 * u + (g >> 1);
+                    const int osel = WIDE ? u : 2 * u + (g >> 1);
                     u32x2 v = {(unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16), (unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16)};
                     if (osel < TB_K) v = *reinterpret_cast<const u32x2 *>(my + osel * TB_T);
                     return v;
                 };
                 auto fetch = [&](const u32x2 &l, u32x4 (&xa)[S]) {
-                    xa[0] = *reinterpret_cast<const u32x4 *>(rows_s + (l[0] & 0xffffu) * 32u + half);
-                    xa[1] = *reinterpret_cast<const u32x4 *>(rows_s + (l[0] >> 16) * 32u + half);
-                    xa[2] = *reinterpret_cast<const u32x4 *>(rows_s + (l[1] & 0xffffu) * 32u + half);
-                    xa[3] = *reinterpret_cast<const u32x4 *>(rows_s + (l[1] >> 16) * 32u + half);
+                    xa[0] = *reinterpret_cast<const u32x4 *>(rows_s + (l[0] & 0xffffu) * (unsigned)RB + half);
+                    xa[1] = *reinterpret_cast<const u32x4 *>(rows_s + (l[0] >> 16) * (unsigned)RB + half);
+                    xa[2] = *reinterpret_cast<const u32x4 *>(rows_s + (l[1] & 0xffffu) * (unsigned)RB + half);
+                    xa[3] = *reinterpret_cast<const u32x4 *>(rows_s + (l[1] >> 16) * (unsigned)RB + half);
                 };
                 u32x4 xa[2][S], wr[4];
                 u32x2 lr[3];
@@ -1093,7 +1100,7 @@ __global__ __launch_bounds__(256) void conv_tile(const unsigned short *__restric
                     unsigned go[2][S];
 #pragma unroll
                     for (int du = 0; du < 2; ++du) {
-                        const int osel = 2 * (u0 + du) + (g >> 1);
+                        const int osel = WIDE ? u0 + du : 2 * (u0 + du) + (g >> 1);
 #pragma unroll
                         for (int s = 0; s < S; ++s) {
                             const int t = row0 + s * 16 + i;
@@ -1103,13 +1110,14 @@ __global__ __launch_bounds__(256) void conv_tile(const unsigned short *__restric
                     }
 #pragma unroll
                     for (int du = 0; du < 2; ++du) {
-                        const int osel = 2 * (u0 + du) + (g >> 1);
+                        const int osel = WIDE ? u0 + du : 2 * (u0 + du) + (g >> 1);
+                        if (u0 + du >= NU) break;
                         u32x4 xa[S];
 #pragma unroll
                         for (int s = 0; s < S; ++s) {
                             const int t = row0 + s * 16 + i;
                             const bool present = osel < TB_K && t < n_out && (int)go[du][s] >= 0;   // out-of-range table reads return 0
-                            xa[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, present ? go[du][s] * 32u + half : OOB, 0, 0);
+                            xa[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, present ? go[du][s] * (unsigned)RB + half : OOB, 0, 0);
                         }
                         const u32x4 wu = loadw(u0 + du);
 #pragma unroll
@@ -1532,17 +1540,25 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
                                nc, n_chunk, NB, wl & 3, (frag *)ws);
     }
     // Level-1 shape with a tilebook of this table: the LDS-staged tile kernel (conv_tile)
-    if (pair && tilebook && K == TB_K && tilebook_rows == n_out && g_use_tile) {
+    const bool wide32 = wide && kc == 32;
+    if ((pair || wide32) && tilebook && K == TB_K && tilebook_rows == n_out && g_use_tile) {
         const TileBookView tb = tilebook_view(const_cast<void *>(tilebook), n_out);
-        int groups = (tb.nt + 7) / 8 * 8;   // persistent: 3 workgroups per CU, a multiple of the 8 XCDs
-        if (groups > BT_MAX_GROUPS) groups = BT_MAX_GROUPS;
+        int groups = (tb.nt + 7) / 8 * 8;   // persistent: 3 (2: 64-byte rows) workgroups per CU, a multiple of the 8 XCDs
+        const int max_groups = wide32 ? BT_MAX_GROUPS * 2 / 3 : BT_MAX_GROUPS;
+        if (groups > max_groups) groups = max_groups;
         const dim3 grid(groups), block(256);
         if (n_part) *n_part = tb.nt;
         const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
         const unsigned yb = (unsigned)((size_t)n_out * nc * (out32 ? 4 : sizeof(elem)));
 #define GT(O32, ST)                                                                                \
-        hipLaunchKernelGGL((conv_tile<O32, ST>), grid, block, 0, s, (const unsigned short *)x_, xb, wp, (unsigned)need, \
-                           nc, NB, tbl, ld, n_out, tb, y_, yb, res, ep)
+        do {                                                                                       \
+            if (wide32)                                                                            \
+                hipLaunchKernelGGL((conv_tile<true, O32, ST>), grid, block, 0, s, (const unsigned short *)x_, xb, wp, \
+                                   (unsigned)need, nc, NB, tbl, ld, n_out, tb, y_, yb, res, ep);   \
+            else                                                                                   \
+                hipLaunchKernelGGL((conv_tile<false, O32, ST>), grid, block, 0, s, (const unsigned short *)x_, xb, wp, \
+                                   (unsigned)need, nc, NB, tbl, ld, n_out, tb, y_, yb, res, ep);   \
+        } while (0)
         if (out32) { if (ep.stats) GT(true, true); else GT(true, false); }
         else { if (ep.stats) GT(false, true); else GT(false, false); }
 #undef GT

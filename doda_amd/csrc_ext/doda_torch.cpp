@@ -262,8 +262,8 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
         int32_t shp[3] = {(int32_t)shape[0], (int32_t)shape[1], (int32_t)shape[2]};
         const size_t wsb = doda_rulebook_workspace_bytes(m);
         at::Tensor ws = at::empty({(int64_t)(wsb > 256 ? wsb : 256)}, iopt.dtype(at::kByte));
-        // tilebook for the finest level only: its layers are the 16-channel ones the tile kernel serves
-        const bool tiled = lvl == 0 && tile_min_rows >= 0 && m >= tile_min_rows;
+        // tilebooks for the two finest levels: DODA's 16- and 32-channel layers, the row sizes the tile kernel serves
+        const bool tiled = lvl <= 1 && tile_min_rows >= 0 && m >= tile_min_rows;
         at::Tensor nbr = tiled ? table_with_tilebook(27, m, iopt) : at::empty({27, m}, iopt);
         check(doda_rulebook_subm((const int32_t *)indices.data_ptr(), m, shp, (int32_t)batch, 3,
                                  (int32_t *)nbr.data_ptr(), m, ws.data_ptr(), (size_t)ws.numel(), st),

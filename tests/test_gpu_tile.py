@@ -86,15 +86,17 @@ def _oracle_conv(x, w, tbl, layout):
     return y
 
 
-@pytest.mark.parametrize("m,nc,layout", [(40000, 16, 0), (40000, 16, 2), (9000, 32, 2), (777, 16, 0), (40000, 48, 0)])
-def test_tile_kernel_matches_oracle_and_dense_kernel(native_lib, m, nc, layout):
+@pytest.mark.parametrize("m,kc,nc,layout", [(40000, 16, 16, 0), (40000, 16, 16, 2), (9000, 16, 32, 2), (777, 16, 16, 0),
+                                            (40000, 16, 48, 0), (40000, 32, 32, 0), (40000, 32, 32, 2), (9000, 32, 16, 2),
+                                            (5000, 32, 48, 0), (300, 32, 32, 0)])
+def test_tile_kernel_matches_oracle_and_dense_kernel(native_lib, m, kc, nc, layout):
     from doda_amd import ops
     d = dev()
     _, tbl = _scene_table(m, seed=3 + m)
     n = tbl.shape[1]
-    torch.manual_seed(m + nc)
-    x = torch.randn(n, 16, device=d).bfloat16()
-    w = (torch.randn(27, 16, nc, device=d) * 0.1).bfloat16().float()   # bf16-representable: products exact
+    torch.manual_seed(m + nc + kc)
+    x = torch.randn(n, kc, device=d).bfloat16()
+    w = (torch.randn(27, kc, nc, device=d) * 0.1).bfloat16().float()   # bf16-representable: products exact
     wk = w if layout == 0 else w.transpose(1, 2).contiguous()            # [K][nc][kc] for layout 2
     tb = ops.tilebook_build(tbl)
     assert tb is not None
@@ -191,11 +193,12 @@ def test_tile_kernel_overflow_tiles_fall_back(native_lib):
     t = ext.with_tilebook(tbl)
     ulist, _, ucount = ext.tilebook_parts(t)
     assert (ucount > ulist.shape[1]).all()
-    x = torch.randn(n, 16, device=d).bfloat16()
-    w = (torch.randn(27, 16, 16, device=d) * 0.1).bfloat16().float()
     tb = ops.tilebook_build(tbl)
-    y = ops.spconv_gather(x, w, tbl, n, 0, 16, out_f32=True, tilebook=tb)
-    assert rel_err(y.cpu(), _oracle_conv(x, w, tbl, 0)) < 1e-4
+    for kc in (16, 32):
+        x = torch.randn(n, kc, device=d).bfloat16()
+        w = (torch.randn(27, kc, 16, device=d) * 0.1).bfloat16().float()
+        y = ops.spconv_gather(x, w, tbl, n, 0, 16, out_f32=True, tilebook=tb)
+        assert rel_err(y.cpu(), _oracle_conv(x, w, tbl, 0)) < 1e-4
 
 
 def test_tile_kernel_statistics_epilogue(native_lib):

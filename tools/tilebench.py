@@ -17,17 +17,23 @@ def main():
     ap.add_argument("--voxels", type=int, default=150000)
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--nc", type=int, default=16)
+    ap.add_argument("--kc", type=int, default=16)
+    ap.add_argument("--level", type=int, default=1, help="1: finest rulebook, 2: the rulebook after one k2s2 downsampling")
     a = ap.parse_args()
     from doda_amd import ops, spconv
     from doda_amd.scene import make_batch
     d = torch.device("cuda:0")
     b = make_batch(a.scenes, a.voxels, 1000)
     idx = b["voxel_locs"].int().to(d)
-    data = spconv.ops.build_subm(idx, a.scenes, b["spatial_shape"], 3)
+    shape = b["spatial_shape"]
+    if a.level == 2:
+        down = spconv.ops.build_down2(idx, a.scenes, shape, 2, 2, 0, 1)
+        idx, shape = down.outids, down.out_spatial_shape
+    data = spconv.ops.build_subm(idx, a.scenes, shape, 3)
     m = idx.shape[0]
-    x = torch.randn(m, 16, device=d).bfloat16()
-    w = torch.randn(27, 16, a.nc, device=d) * 0.1
-    plan = ops.PackPlan([(w, 27, 16, a.nc, 0, 2)], d)
+    x = torch.randn(m, a.kc, device=d).bfloat16()
+    w = torch.randn(27, a.kc, a.nc, device=d) * 0.1
+    plan = ops.PackPlan([(w, 27, a.kc, a.nc, 0, 2)], d)
     plan.run()
     pk = plan.outputs[0]
 
@@ -49,7 +55,7 @@ def main():
            "tilebook_bytes": tb.numel(), "table_bytes": data.tbl.numel() * 4,
            "dense_us": timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk)),
            "tile_us": timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk, tilebook=tb))}
-    if a.nc == 16:
+    if a.nc == 16 and a.kc == 16:
         gy = torch.randn(m, 16, device=d).bfloat16()
         plan2 = ops.PackPlan([(w, 27, 16, 16, 2, 2)], d)
         plan2.run()
@@ -60,7 +66,7 @@ def main():
         out["wgrad_pairs_us_per_layer"] = timed(lambda: ops.spconv_wgrad_multi(jobs)) / 8
     # cold variant: cycle through inputs / tables so that consecutive launches do not find their operands in the
     # 256 MB Infinity Cache (what a kernel meets inside the training step)
-    xs = [torch.randn(m, 16, device=d).bfloat16() for _ in range(6)]
+    xs = [torch.randn(m, a.kc, device=d).bfloat16() for _ in range(6)]
     tbls = [data.tbl.clone() for _ in range(6)]
     tbs = [ops.tilebook_build(t) for t in tbls]
     k = [0]
@@ -71,9 +77,9 @@ def main():
     out["dense_cold_us"] = timed(lambda: cold(False))
     out["tile_cold_us"] = timed(lambda: cold(True))
     from doda_amd._ext import ext
-    if ext is not None and a.nc == 16:
-        wt = torch.nn.Parameter(w.view(3, 3, 3, 16, 16).clone())
-        res = torch.randn(m, 16, device=d).bfloat16()
+    if ext is not None:
+        wt = torch.nn.Parameter(w.view(3, 3, 3, a.kc, a.nc).clone())
+        res = torch.randn(m, a.nc, device=d).bfloat16()
         tt = [ext.with_tilebook(t) for t in tbls]
 
         def stats(tiled):
