@@ -74,16 +74,23 @@ def _subm16_times(idx, shape, nb, dtype, reps):
     s = 4 if dtype == "f32" else 2
 
     def timed(fn, per=1):
+        """Average launch time over back-to-back launches, HIP events on the launch stream.  The reps are
+        timed in five event-bracketed chunks and the MEDIAN chunk average is returned: one host stall
+        (allocator growth, a descheduled issue thread) inside a single bracket once produced a 5x outlier
+        for a kernel whose rocprofv3 average in the same run was unchanged."""
         for _ in range(5):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_chunk, per_chunk = 5, max(1, reps // 5)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_chunk + 1)]
         torch.cuda.synchronize()
-        e0.record()  # current stream == the stream ops.* launches on
-        for _ in range(reps):
-            fn()
-        e1.record()
+        ev[0].record()  # current stream == the stream ops.* launches on
+        for c in range(n_chunk):
+            for _ in range(per_chunk):
+                fn()
+            ev[c + 1].record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e-3 / reps / per
+        chunks = sorted(ev[c].elapsed_time(ev[c + 1]) for c in range(n_chunk))
+        return chunks[n_chunk // 2] * 1e-3 / per_chunk / per
 
     b_f = s * (m * 16 + m * 16) + 4 * 27 * 16 * 16 + 8 * pairs_total
     b_b = s * (2 * m * 16 + m * 16) + 2 * 4 * 27 * 16 * 16 + 8 * pairs_total

@@ -203,7 +203,8 @@ class SparseConvNet(nn.Module):
             # all 13 rulebooks up front (+ their pair lists when a bf16 backward pass will follow)
             spconv.ops.build_pyramid(input, len(self.unet.nPlanes), with_pairs=(
                 spconv.functional.WGRAD_PAIRS and torch.is_grad_enabled() and self.training
-                and input.features.dtype == torch.bfloat16))
+                and input.features.dtype == torch.bfloat16),
+                with_tiles=input.features.dtype == torch.bfloat16)   # tilebooks serve inference as well
         out = self.output_layer(self.unet(self.input_conv(input)))
         feats = out.features
         fused = (v2p_map is not None and not return_mid_feat and feats.is_cuda
