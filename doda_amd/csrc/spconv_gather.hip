@@ -823,25 +823,24 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-staged tile kernel (bf16, 16 input channels, K = 27 SubM: the level-1 layers of the U-Net and the
-// north-star gate).  conv_fast is paced by the texture path: 28 gather instructions per 32 output rows at
-// 37 % lane use, each costing >= 16 cycles of the CU's L1 whatever its EXEC mask.  Here a
-// workgroup owns a tile of TB_T = 256 consecutive output rows whose neighbourhood the tilebook
+// LDS-staged tile kernel (bf16, 16 or 32 input channels, K = 27 SubM: the layers of the two finest U-Net
+// levels and the north-star gate).  conv_fast is paced by the texture path: 28 gather instructions per 32
+// output rows at 37 % lane use, each costing >= 16 cycles of the CU's L1 whatever its EXEC mask (DESIGN.md
+// §4).  Here a workgroup owns a tile of TB_T = 256 consecutive output rows whose neighbourhood the tilebook
 // (tilebook.hpp) lists as ~2.2 x 256 DISTINCT input rows:
-//   phase A  every distinct row is loaded once, 64 lanes covering 32 consecutive list entries (runs of
-//            consecutive rows -> whole 128-byte lines), and parked in LDS; the tile's local-index strip
-//            (27 x 256 uint16) is copied to LDS; each wave loads the 14 offset-pair weight fragments of its
-//            channel block ONCE into registers (56 VGPRs — the workgroup's LDS footprint caps the CU at 3
-//            workgroups = 3 waves per SIMD, so registers are free);
-//   phase B  per offset pair one 8-byte LDS read returns the lane's four local indices (one per 16-row
-//            subtile), four 16-byte LDS reads fetch the operand rows (an absent neighbour is the shared
-//            zero row: same address in every lane, a broadcast), four MFMAs accumulate.  No vector-memory
-//            instruction in the loop.
-// Vector-memory instructions per 64 output rows: ~1 + 5 (list + rows) + 4 (indices) + 14 (weights) + 4
-// (stores) = 28 against 96.  A tile whose neighbourhood exceeds TB_UMAX rows (never seen on surface data)
-// takes the same loop with the operands gathered from global memory through the dense table.
-// Same arithmetic as conv_fast<PBF16P> up to the order in which offsets are paired (fixed (2u, 2u+1)
-// here, pairs of ACTIVE offsets there): fp32 accumulation, one bf16 rounding at the store.
+//   phase A  every distinct row is loaded once, consecutive lanes covering consecutive list entries (runs
+//            of consecutive rows -> whole 128-byte lines), and parked in LDS next to the tile's local-index
+//            strip (27 x 256 uint16);
+//   phase B  per unit (a pair of offsets x 16 channels, or one offset x 32 channels) one 8-byte LDS read
+//            returns the lane's four local indices (one per 16-row subtile), four 16-byte LDS reads fetch
+//            the operand rows (an absent neighbour is the shared zero row: same address in every lane, a
+//            broadcast), four MFMAs accumulate.  The only vector-memory instruction in the loop is the
+//            streamed weight fragment (L1-resident).
+// Vector-memory instructions per 64 output rows (16 channels): ~9 rows + 8 list + 4 strip + 14 weights + 4
+// stores = 39 against 96.  A tile whose neighbourhood exceeds TB_UMAX rows (never seen on surface data) takes
+// the same loop with the operands gathered from global memory through the dense table.
+// Same arithmetic as conv_fast up to the order in which offsets are paired (fixed (2u, 2u+1) here, pairs of
+// ACTIVE offsets there): fp32 accumulation, one bf16 rounding at the store.
 // ---------------------------------------------------------------------------------------------
 // Store epilogue of the tile kernels: conv_fast's epilogue for bf16 features, one channel block, four waves
 // holding four row ranges of the workgroup's tile (residual add, single bf16 rounding, BatchNorm statistics
