@@ -97,7 +97,8 @@ def _subm16_times(idx, shape, nb, dtype, reps):
     plan = ops.PackPlan([(w, 27, 16, 16, 0, s), (w, 27, 16, 16, 2, s)], dev)
     plan.run()
     pk_f, pk_d = plan.outputs
-    # bf16: the LDS-staged tile kernel over the rulebook's tilebook (built once per rulebook, as the model does)
+    # bf16: the LDS-staged tile kernel over the rulebook's tilebook (built once per rulebook, as the model does);
+    # fp32 is bound by the fp32 matrix rate either way (tile kernel 83.7 us, dense 86.3 us) and stays on conv_fast
     tb = ops.tilebook_build(data.tbl) if (dtype == "bf16" and spconv.ops.TILE_KERNEL) else None
     t_f = timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, 16, packed=pk_f, tilebook=tb))
     t_d = timed(lambda: ops.spconv_gather(gy, None, data.tbl, m, 2, 16, packed=pk_d, tilebook=tb))
@@ -136,8 +137,8 @@ def kernel_roofline(batch_dev, dtype, reps, gate_scene=None):
                             "note": "north_star gate: SubMConv3d 16->16 fwd+bwd on one ~150k-voxel scene; its 45 MB "
                                     "working set sits in the 256 MB Infinity Cache between back-to-back launches"}
     m, pairs_total, b_f = big["M"], big["P"], big["b_f"]
-    kname = "conv_fast<PF32,1,2,3>" if dtype == "f32" else (
-        "conv_tile (LDS-staged, tilebook)" if big["tile_kernel"] else "conv_fast<PBF16P,1,2,3>")
+    kname = "conv_tile (LDS-staged, tilebook)" if big["tile_kernel"] else (
+        "conv_fast<PF32,1,2,3>" if dtype == "f32" else "conv_fast<PBF16P,1,2,3>")
     traffic, traffic_src = pmc_traffic(dtype)
     roof = {"kernel": "%s (SubMConv3d 16->16 fwd gather, M=%d, P=%d)" % (kname, m, pairs_total),
             "bound": "hbm", "achieved": out["subm16_fwd"]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -271,14 +272,16 @@ def main():
         # stream while this step is issued (every step still builds one full pyramid; nothing is cached)
         with_pairs = bool(spconv.functional.WGRAD_PAIRS and fdt == torch.bfloat16)
         prefetch = PyramidPrefetcher(dev, len(net.unet.nPlanes)) if args.prefetch else None
-        pending = [prefetch.submit(batch_dev, with_pairs)] if prefetch else None
+        from doda_amd.model import tile_levels_for
+        with_tiles = tile_levels_for(fdt)
+        pending = [prefetch.submit(batch_dev, with_pairs, with_tiles)] if prefetch else None
 
         def step():
             opt.zero_grad(set_to_none=True)
             pyramid = None
             if prefetch is not None:
                 pyramid = PyramidPrefetcher.take(pending[0], dev)
-                pending[0] = prefetch.submit(batch_dev, with_pairs)
+                pending[0] = prefetch.submit(batch_dev, with_pairs, with_tiles)
             scores = voxelize_and_run(cfg, model, batch_dev, dev, feature_dtype=fdt, inputs_ready=True,
                                       pyramid=pyramid)
             loss = cross_entropy(scores, labels, ignore_index=255)
@@ -350,6 +353,17 @@ def main():
             fp32["roofline"] = {"kernel": r32["kernel"], "achieved": r32["achieved"], "frac": r32["frac"],
                                 "avg_launch_us": r32["avg_launch_us"], "detail": r32["detail"],
                                 "step_frac_of_hbm_peak": b32 / (fp32["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            # the fp32 gather is bound by the fp32 matrix rate (157.3 TFLOP/s: 1/16 of bf16, MI355X_MICROARCH.md),
+            # not by HBM: its tiles multiply all 27 offsets of every 16-row subtile with a present neighbour
+            m32, p32 = r32["detail"]["subm16_fwd"], r32["kernel"]
+            n_rows = int(p32.split("M=")[1].split(",")[0])
+            pairs = int(p32.split("P=")[1].split(")")[0])
+            t32 = r32["avg_launch_us"] * 1e-6
+            fp32["roofline"]["mfma_f32"] = {
+                "peak_TFLOPs": 157.3, "algorithmic_flops": 2 * pairs * 256, "dense_tile_flops": 2 * n_rows * 27 * 256,
+                "frac_algorithmic": 2 * pairs * 256 / t32 / 157.3e12, "frac_dense_tile_upper": 2 * n_rows * 27 * 256 / t32 / 157.3e12,
+                "note": "algorithmic = 2 P Cin Cout (present pairs only); dense_tile = every offset of every row, an upper "
+                        "bound on what the kernel issues (it skips offsets absent from a whole 32-row wave)"}
             line["fp32"] = fp32
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)

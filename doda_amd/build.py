@@ -29,7 +29,8 @@ def _sources():
 
 def _stamp(src):
     h = hashlib.sha1()
-    for p in [src, os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "doda_hip.h")]:
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))   # every shared header
+    for p in [src] + headers + [os.path.join(HERE, "..", "include", "doda_hip.h")]:
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())

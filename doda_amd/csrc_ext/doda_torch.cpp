@@ -250,7 +250,8 @@ typedef std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, std::vector<i
                    at::Tensor, at::Tensor, at::Tensor, at::Tensor> PyramidLevel;
 // pairs_min_rows < 0: no lists; else lists for rulebooks of at least that many rows.
 std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vector<int64_t> shape, int64_t batch,
-                                        int64_t n_levels, int64_t pairs_min_rows, int64_t tile_min_rows) {
+                                        int64_t n_levels, int64_t pairs_min_rows, int64_t tile_min_rows,
+                                        int64_t tile_levels) {
     TORCH_CHECK(indices_in.is_cuda() && indices_in.scalar_type() == at::kInt && indices_in.dim() == 2 &&
                 indices_in.size(1) == 4 && shape.size() == 3, "doda build_pyramid: indices must be int32 [M,4] on the GPU");
     std::vector<PyramidLevel> out;
@@ -262,8 +263,9 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
         int32_t shp[3] = {(int32_t)shape[0], (int32_t)shape[1], (int32_t)shape[2]};
         const size_t wsb = doda_rulebook_workspace_bytes(m);
         at::Tensor ws = at::empty({(int64_t)(wsb > 256 ? wsb : 256)}, iopt.dtype(at::kByte));
-        // tilebooks for the two finest levels: DODA's 16- and 32-channel layers, the row sizes the tile kernel serves
-        const bool tiled = lvl <= 1 && tile_min_rows >= 0 && m >= tile_min_rows;
+        // tilebooks for the finest `tile_levels` levels: DODA's 16- and 32-channel bf16 layers (2) or the 16-channel
+        // fp32 layers (1) — rows of 32 or 64 bytes, what the tile kernel stages
+        const bool tiled = lvl < tile_levels && tile_min_rows >= 0 && m >= tile_min_rows;
         at::Tensor nbr = tiled ? table_with_tilebook(27, m, iopt) : at::empty({27, m}, iopt);
         check(doda_rulebook_subm((const int32_t *)indices.data_ptr(), m, shp, (int32_t)batch, 3,
                                  (int32_t *)nbr.data_ptr(), m, ws.data_ptr(), (size_t)ws.numel(), st),
@@ -849,7 +851,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("build_pyramid", &build_pyramid,
           "all SubM k3 and k2s2 rulebooks of an n-level U-Net in one call (13 native builds, 6 size read-backs)",
           py::arg("indices"), py::arg("shape"), py::arg("batch"), py::arg("n_levels"), py::arg("pairs_min_rows") = -1,
-          py::arg("tile_min_rows") = -1,
+          py::arg("tile_min_rows") = -1, py::arg("tile_levels") = 2,
           py::call_guard<py::gil_scoped_release>());   // its size read-backs block: let other Python threads run
     m.def("with_tilebook", [](const at::Tensor &tbl) {
               TORCH_CHECK(tbl.is_cuda() && tbl.scalar_type() == at::kInt && tbl.dim() == 2, "doda with_tilebook: int32 [K, M] table");

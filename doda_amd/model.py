@@ -204,7 +204,7 @@ class SparseConvNet(nn.Module):
             spconv.ops.build_pyramid(input, len(self.unet.nPlanes), with_pairs=(
                 spconv.functional.WGRAD_PAIRS and torch.is_grad_enabled() and self.training
                 and input.features.dtype == torch.bfloat16),
-                with_tiles=input.features.dtype == torch.bfloat16)   # tilebooks serve inference as well
+                with_tiles=tile_levels_for(input.features.dtype))   # tilebooks serve inference as well
         out = self.output_layer(self.unet(self.input_conv(input)))
         feats = out.features
         fused = (v2p_map is not None and not return_mid_feat and feats.is_cuda
@@ -221,7 +221,14 @@ class SparseConvNet(nn.Module):
 _PYR_STREAMS = {}
 
 
-def _prebuild_pyramid(voxel_coords, spatial_shape, batch_size, n_levels, device, with_pairs=False):
+def tile_levels_for(dtype):
+    """Levels whose SubM rulebook gets a tilebook: the two finest for bf16 (rows of 32 / 64 bytes).  The tile kernel
+    also takes fp32 16-channel rows, but that layer is bound by the fp32 matrix rate (83.7 us against 86.3 us for the
+    dense-table kernel at level 1), which does not pay for the tilebook build: off by default."""
+    return 2 if dtype == torch.bfloat16 else 0
+
+
+def _prebuild_pyramid(voxel_coords, spatial_shape, batch_size, n_levels, device, with_pairs=False, with_tiles=None):
     """Build the int32 indices and all rulebooks on a side stream that does NOT wait for the main
     stream.  Rulebooks depend only on the voxel coordinates; built at the head of the forward pass on
     the main stream, each of their six size read-backs blocks the host until the previous step's
@@ -236,7 +243,7 @@ def _prebuild_pyramid(voxel_coords, spatial_shape, batch_size, n_levels, device,
     with torch.cuda.stream(side):
         idx32 = voxel_coords.int()
         probe = spconv.SparseConvTensor(None, idx32, spatial_shape, batch_size)
-        spconv.ops.build_pyramid(probe, n_levels, with_pairs=with_pairs)
+        spconv.ops.build_pyramid(probe, n_levels, with_pairs=with_pairs, with_tiles=with_tiles)
     main.wait_stream(side)
     idx32.record_stream(main)
     for data in probe.indice_dict.values():
@@ -265,18 +272,18 @@ class PyramidPrefetcher:
         self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="doda-rulebooks")
         self.stream = torch.cuda.Stream(device=device)
 
-    def submit(self, batch, with_pairs=False):
+    def submit(self, batch, with_pairs=False, with_tiles=None):
         """batch: collated dictionary whose `voxel_locs` is resident on the device with no pending producer."""
         coords, shape = batch["voxel_locs"], batch["spatial_shape"]
         bs = batch["offsets"].numel() - 1
-        return self.pool.submit(self._build, coords, shape, bs, with_pairs)
+        return self.pool.submit(self._build, coords, shape, bs, with_pairs, with_tiles)
 
-    def _build(self, coords, shape, bs, with_pairs):
+    def _build(self, coords, shape, bs, with_pairs, with_tiles=None):
         torch.cuda.set_device(self.device)
         with torch.cuda.stream(self.stream):
             idx32 = coords.int()
             probe = spconv.SparseConvTensor(None, idx32, shape, bs)
-            spconv.ops.build_pyramid(probe, self.n_levels, with_pairs=with_pairs)
+            spconv.ops.build_pyramid(probe, self.n_levels, with_pairs=with_pairs, with_tiles=with_tiles)
             done = torch.cuda.Event()
             done.record(self.stream)
         return idx32, probe.indice_dict, done
@@ -323,7 +330,8 @@ def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fus
         idx32, pyramid = _prebuild_pyramid(voxel_coords, batch["spatial_shape"], batch_size,
                                            len(net.unet.nPlanes), device,
                                            with_pairs=(spconv.functional.WGRAD_PAIRS and torch.is_grad_enabled()
-                                                       and net.training and feature_dtype == torch.bfloat16))
+                                                       and net.training and feature_dtype == torch.bfloat16),
+                                           with_tiles=tile_levels_for(feature_dtype))
         inp = spconv.SparseConvTensor(voxel_feats.to(feature_dtype), idx32, batch["spatial_shape"], batch_size)
         inp.indice_dict.update(pyramid)
     else:

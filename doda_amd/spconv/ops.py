@@ -80,11 +80,14 @@ def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", firs
     stalling the host in the middle of the forward pass.  with_pairs: also export every rulebook's pair
     lists for the pair-list weight gradient (training with bf16 features)."""
     indices, shape = tensor.indices, tensor.spatial_shape
+    # with_tiles: number of finest levels that get a tilebook (True = 2: bf16 rows of 32 / 64 bytes at DODA's
+    # widths; 1 for fp32 features); None follows with_pairs (bf16 training)
+    n_tile_levels = (2 if with_pairs else 0) if with_tiles is None else (2 if with_tiles is True else int(with_tiles))
     if (_ext is not None and not tensor.indice_dict and indices.is_cuda and indices.dtype == torch.int32
             and indices.shape[0] > 0 and all(int(v) >= 2 for v in shape)):
         levels = _ext.build_pyramid(indices, [int(v) for v in shape], int(tensor.batch_size), int(n_levels),
                                     PAIRS_MIN_ROWS if with_pairs else -1,
-                                    TILE_MIN_ROWS if (TILE_KERNEL and (with_pairs if with_tiles is None else with_tiles)) else -1)
+                                    TILE_MIN_ROWS if (TILE_KERNEL and n_tile_levels > 0) else -1, n_tile_levels)
         for k, (nbr, outids, child, par_off, oshape, sp, sn, sh, dp, dn, dh) in enumerate(levels):   # s*/d*: lists, counts, segments
             lvl = first_level + k
             data = tensor.indice_dict[subm_key % lvl] = IndiceData("subm", indices, indices, list(shape),

@@ -276,6 +276,8 @@ class Trainer:
             else:
                 self.model = ddist.wrap_ddp(self.model, device.index)
         self.with_pairs = bool(Fsp.WGRAD_PAIRS and self.fdt == torch.bfloat16)
+        from .model import tile_levels_for
+        self.with_tiles = tile_levels_for(self.fdt)
         net = self.model.module if hasattr(self.model, "module") else self.model
         self.n_levels = len(net.unet.nPlanes)
         self.prefetch = PyramidPrefetcher(device, self.n_levels) if device.type == "cuda" else None
@@ -299,11 +301,11 @@ class Trainer:
         from .model import PyramidPrefetcher
         it = make_loader(self.cfg, self.args, self.device, self.rank, self.world, epoch, split)
         nxt = next(it, None)
-        fut = self.prefetch.submit(nxt, self.with_pairs) if (nxt is not None and self.prefetch) else None
+        fut = self.prefetch.submit(nxt, self.with_pairs, self.with_tiles) if (nxt is not None and self.prefetch) else None
         while nxt is not None:
             cur, cur_fut = nxt, fut
             nxt = next(it, None)
-            fut = self.prefetch.submit(nxt, self.with_pairs) if (nxt is not None and self.prefetch) else None
+            fut = self.prefetch.submit(nxt, self.with_pairs, self.with_tiles) if (nxt is not None and self.prefetch) else None
             yield cur, (PyramidPrefetcher.take(cur_fut, self.device) if cur_fut is not None else None)
 
     def train_epoch(self, epoch, total_epochs):
