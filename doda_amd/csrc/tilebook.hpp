@@ -1,5 +1,5 @@
 // Tile-local form of a SubM gather table ("tilebook"), shared by the builder (tilebook.hip) and the
-// LDS-staged convolution kernel (spconv_gather.hip: conv_tile).
+// LDS-staged convolution kernels (spconv_tile.hip: conv_tile, bwd_tile).
 //
 // The dense table tbl[K][M] makes every (offset, row) slot a vector-memory gather of its own: at level 1
 // of DODA's U-Net a 32-row wave issues 28 gather instructions at 37 % lane use, and the kernel is paced by
