@@ -24,7 +24,8 @@ namespace {
 //            broadcast), four MFMAs accumulate.  The only vector-memory instruction in the loop is the
 //            streamed weight fragment (L1-resident).
 // Vector-memory instructions per 64 output rows (16 channels): ~9 rows + 8 list + 4 strip + 14 weights + 4
-// stores = 39 against 96.  A tile whose neighbourhood exceeds TB_UMAX rows (never seen on surface data) takes
+// stores = 39 against 96.  A tile whose neighbourhood exceeds the kernel's capacity (1216 rows of 32 bytes, 960 of
+// 64 bytes; 0.05 % / 17 % of the tiles of a 1 cm scene, none at 2 cm) takes
 // the same loop with the operands gathered from global memory through the dense table.
 // Same arithmetic as conv_fast up to the order in which offsets are paired (fixed (2u, 2u+1) here, pairs of
 // ACTIVE offsets there): fp32 accumulation, one bf16 rounding at the store.
@@ -149,9 +150,10 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
     constexpr int S = 4, NU = WIDE ? TB_K : (TB_K + 1) / 2;
     constexpr int RB = WIDE ? 64 : 32;                         // bytes per staged row
     constexpr int PPR = RB / 16;                               // 16-byte pieces per row
-    constexpr int NRL = (PPR * TB_UMAX + 255) / 256;           // row loads per thread
+    constexpr int CAP = WIDE ? TB_CAP64 : TB_UMAX;             // distinct rows this kernel stages (LDS budget)
+    constexpr int NRL = (PPR * CAP + 255) / 256;               // row loads per thread
     constexpr int NLI = (TB_K * TB_T * 2 / 16 + 255) / 256;   // 16-byte pieces of the index strip per thread
-    __shared__ __attribute__((aligned(16))) unsigned char rows_s[(TB_UMAX + 1) * RB];
+    __shared__ __attribute__((aligned(16))) unsigned char rows_s[(CAP + 1) * RB];   // slot 0: the zero row
     __shared__ __attribute__((aligned(16))) unsigned short lidx_s[TB_K * TB_T];
 
     const int tid0 = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
             const int e = (k * 256 + tid) / PPR;
-            rid[k] = e < TB_UMAX ? (unsigned)ul[e] : 0xffffffffu;
+            rid[k] = e < CAP ? (unsigned)ul[e] : 0xffffffffu;
         }
     };
     unsigned rid[NRL];
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, i = lane & 15, g = lane >> 4;
-        const bool staged = U <= TB_UMAX;
+        const bool staged = U <= CAP;
         const int row0 = t0 + wid * 64;
         const unsigned half = (unsigned)(WIDE ? g : (g & 1)) * 16u;   // the lane's 16-byte piece of an operand row
         // weight fragments (pair packing; offset 27 lies past the packed buffer: zeros) are streamed per unit,
@@ -225,10 +227,10 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                 const int e = k * 256 + tid;
                 if (e < TB_K * TB_T * 2 / 16) reinterpret_cast<u32x4 *>(lidx_s)[e] = li4[k];
             }
-            if (tid < PPR) reinterpret_cast<u32x4 *>(rows_s)[TB_ZROW * PPR + tid] = (u32x4){0u, 0u, 0u, 0u};
+            if (tid < PPR) reinterpret_cast<u32x4 *>(rows_s)[tid] = (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
             for (int k = 0; k < NRL; ++k)
-                if (k * 256 + tid < PPR * TB_UMAX) reinterpret_cast<u32x4 *>(rows_s)[k * 256 + tid] = rr[k];
+                if (k * 256 + tid < PPR * CAP) reinterpret_cast<u32x4 *>(rows_s)[PPR + k * 256 + tid] = rr[k];
         } else if (tt + L < cnt) {
             load_list(tile + L, tid, rid);
             U = tb.ucount[tile + L];
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                 const unsigned short *my = lidx_s + wid * 64 + i * 4;
                 auto loadl = [&](int u) {
                     const int osel = WIDE ? u : 2 * u + (g >> 1);
-                    u32x2 v = {(unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16), (unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16)};
+                    u32x2 v = {0u, 0u};   // offset 27 of the last pair: the zero row
                     if (osel < TB_K) v = *reinterpret_cast<const u32x2 *>(my + osel * TB_T);
                     return v;
                 };
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
 // VGPRs) stay in registers across all tiles of the PERSISTENT workgroup, which writes one partial
 // [27][16][16] at the end; bwd_tile_reduce sums the partials in a fixed order (deterministic).
 // Workgroups: 3 per CU (LDS 53 KB), XCD x walks its own contiguous range of tiles.
-// An overflow tile (more distinct rows than TB_UMAX) takes the dense table: B1 gathers from global memory,
+// An overflow tile (more distinct rows than TB_CAP64) takes the dense table: B1 gathers from global memory,
 // B2 stages four offsets at a time (4 x 256 rows, tile order) and runs the same transposed reads.
 // ---------------------------------------------------------------------------------------------
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
@@ -371,7 +373,8 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
     constexpr int S = 4, NU = (TB_K + 1) / 2;
     // staged rows and the local-index strip sit back to back: the overflow path, which has no strip, stages
     // 4 x TB_T rows across both
-    constexpr int ROWS_BYTES = (TB_UMAX + 1) * 32;
+    constexpr int CAP = TB_CAP64;   // LDS budget with the x tile next to the rows: 3 workgroups per CU
+    constexpr int ROWS_BYTES = (CAP + 1) * 32;   // slot 0: the zero row
     __shared__ __attribute__((aligned(16))) unsigned char smem[ROWS_BYTES + TB_K * TB_T * 2];
     __shared__ __attribute__((aligned(16))) unsigned short xs[TB_T * 16];
     static_assert(ROWS_BYTES % 16 == 0 && 4 * TB_T * 32 <= ROWS_BYTES + TB_K * TB_T * 2, "overflow path stages 4 x TB_T rows");
@@ -413,14 +416,14 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
         const unsigned lane_w = (unsigned)(g >> 1) * 512u + (unsigned)((g & 1) * 16 + i) * 16u;
         auto loadw = [&](int u) { return __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)u * 1024u + lane_w, 0, 0); };
         // ---- phase A ----
-        constexpr int NRL = (2 * TB_UMAX + 255) / 256;
+        constexpr int NRL = (2 * CAP + 255) / 256;
         unsigned rid[NRL];
         {
             const int32_t *ul = tb.ulist + (size_t)tile * TB_UMAX;
 #pragma unroll
             for (int k = 0; k < NRL; ++k) {
                 const int e = (k * 256 + tid) >> 1;
-                rid[k] = e < TB_UMAX ? (unsigned)ul[e] : 0xffffffffu;
+                rid[k] = e < CAP ? (unsigned)ul[e] : 0xffffffffu;
             }
         }
         constexpr int NLI = (TB_K * TB_T * 2 / 16 + 255) / 256;
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
             xt[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(t0 + (h >> 1)) * 32u + (unsigned)(h & 1) * 16u, 0, 0);
         }
         const int U = tb.ucount[tile];
-        const bool staged = U <= TB_UMAX;
+        const bool staged = U <= CAP;
 #pragma unroll
         for (int k = 0; k < 2; ++k) reinterpret_cast<u32x4 *>(xs)[k * 256 + tid] = xt[k];
         if (staged) {
@@ -453,10 +456,10 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
                 const int e = k * 256 + tid;
                 if (e < TB_K * TB_T * 2 / 16) reinterpret_cast<u32x4 *>(lidx_s)[e] = li4[k];
             }
-            if (tid < 2) reinterpret_cast<u32x4 *>(rows_s)[TB_ZROW * 2 + tid] = (u32x4){0u, 0u, 0u, 0u};
+            if (tid < 2) reinterpret_cast<u32x4 *>(rows_s)[tid] = (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
             for (int k = 0; k < NRL; ++k)
-                if (k * 256 + tid < 2 * TB_UMAX) reinterpret_cast<u32x4 *>(rows_s)[k * 256 + tid] = rr[k];
+                if (k * 256 + tid < 2 * CAP) reinterpret_cast<u32x4 *>(rows_s)[2 + k * 256 + tid] = rr[k];
         }
         __syncthreads();
 
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
             const unsigned short *my = lidx_s + wid * 64 + i * 4;
             auto loadl = [&](int u) {
                 const int osel = 2 * u + (g >> 1);
-                u32x2 v = {(unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16), (unsigned)TB_ZROW | ((unsigned)TB_ZROW << 16)};
+                u32x2 v = {0u, 0u};   // offset 27 of the last pair: the zero row
                 if (osel < TB_K) v = *reinterpret_cast<const u32x2 *>(my + osel * TB_T);
                 return v;
             };

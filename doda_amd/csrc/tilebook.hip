@@ -19,7 +19,7 @@ constexpr unsigned EMPTY = 0xFFFFFFFFu;
 __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict__ tbl, int ld, int n,
                                                       TileBookView v) {
     __shared__ unsigned htab[HCAP];
-    constexpr int UQ = 1024;          // sort buffer: the power of two above TB_UMAX
+    constexpr int UQ = 2048;          // sort buffer: the power of two above TB_UMAX
     __shared__ unsigned uq[UQ];
     static_assert(TB_UMAX <= UQ, "sort buffer");
     __shared__ unsigned short hrank[HCAP];
@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
     // compare-exchange p of a stage pairs idx = insert-zero-bit(p, j) with idx | j.  Thread tid takes
     // p = tid + 256 q, so for j <= 64 both elements lie in the 128-element chunk its own wave handles and
     // LDS operations of one wave execute in order: only stages with j >= 128 (and the first j <= 64 stage
-    // after one) need the workgroup barrier — 12 barriers instead of 55 for P = 1024.
+    // after one) need the workgroup barrier — 12 barriers instead of 55 for P = 1024.  (P = 2048: a thread's four
+    // pairs p = tid + 256 q still stay inside its wave's chunks for j <= 64.)
     bool crossed = true;
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -115,12 +116,12 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
     uint16_t *li = v.lidx + (size_t)tile * TB_K * TB_T + tb_pos(tid);
 #pragma unroll
     for (int o = 0; o < TB_K; ++o) {
-        unsigned short r = (unsigned short)TB_ZROW;
+        unsigned short r = 0;   // absent: LDS slot 0, the zero row
         if (e[o] >= 0) {
             const unsigned key = (unsigned)e[o];
             unsigned slot = hash_mix(key) & (HCAP - 1);
             while (htab[slot] != key) slot = (slot + 1) & (HCAP - 1);
-            r = hrank[slot];
+            r = (unsigned short)(hrank[slot] + 1);
         }
         li[o * TB_T] = r;
     }

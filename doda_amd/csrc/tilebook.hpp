@@ -6,8 +6,10 @@
 // the per-CU texture path.  A tile of TB_T consecutive output rows references only
 // ~2.2 x TB_T distinct input rows (raster-ordered surface voxels), so the tilebook stores per tile
 //   ulist [TB_UMAX]   int32   the distinct input rows, ascending (-1 past the count)
-//   lidx  [K][TB_T]   uint16  position of tbl[o][t] in ulist, or TB_ZROW when absent
-//   ucount            int32   number of distinct rows (> TB_UMAX: overflow, the kernel falls back to tbl)
+//   lidx  [K][TB_T]   uint16  1 + position of tbl[o][t] in ulist, or 0 when absent (LDS slot 0 = the zero row)
+//   ucount            int32   number of distinct rows (> TB_UMAX: the list is not kept)
+// A kernel stages at most its own capacity (what its LDS budget allows for its row size: tile_cap()) and
+// serves a tile above it from the dense table.
 // and the kernel loads each distinct row ONCE, coalesced, into LDS and serves all K gathers from there.
 // Inside a tile lidx is swizzled so that one 8-byte LDS read returns the four subtile entries of a lane:
 //   pos(r) = (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3).
@@ -16,8 +18,8 @@
 #include <stddef.h>
 
 constexpr int TB_T = 256;        // output rows per tile
-constexpr int TB_UMAX = 960;     // distinct input rows staged per tile (LDS budget of the fused backward: 3 workgroups per CU)
-constexpr int TB_ZROW = TB_UMAX; // local index of the all-zero row
+constexpr int TB_UMAX = 1216;    // list capacity per tile = the largest kernel capacity (32-byte rows, 3 workgroups per CU)
+constexpr int TB_CAP64 = 960;    // kernel capacity for 64-byte rows (2 workgroups per CU) and for the fused backward
 constexpr int TB_K = 27;
 
 struct TileBookView {

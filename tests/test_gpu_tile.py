@@ -1,7 +1,7 @@
 """GPU tests of the tilebook (doda_tilebook_build) and the LDS-staged convolution kernel (conv_tile).
 
 * the tilebook is a lossless re-encoding of the dense gather table: per tile the sorted distinct rows and
-  per entry its position, so  ulist[tile][lidx[tile][o][pos(r)]] == tbl[o][tile*T + r]  bit for bit;
+  per entry 1 + its position (0 = absent), so  ulist[tile][lidx[tile][o][pos(r)] - 1] == tbl[o][tile*T + r];
 * the tile kernel against the CPU oracle's indice_conv on the SAME bf16-rounded operands (products exact in
   fp32, only the summation order differs: 1e-4 relative as north_star states) and against the dense-table
   kernel (fp32 outputs to 1e-5, bf16 outputs within one rounding step);
@@ -66,10 +66,11 @@ def test_tilebook_is_a_lossless_encoding(native_lib, m):
         uniq = np.unique(ent[ent >= 0])
         assert ucount[tile] == len(uniq) <= UMAX
         assert np.array_equal(ulist[tile, :len(uniq)], uniq) and (ulist[tile, len(uniq):] == -1).all()
-        loc = lidx[tile][:, pos].astype(np.int64)          # un-swizzled [27, T]
-        absent = loc == UMAX
+        loc = lidx[tile][:, pos].astype(np.int64)          # un-swizzled [27, T]; 0 = absent, else 1 + position
+        absent = loc == 0
         assert np.array_equal(absent, ent < 0)
-        back = np.where(absent, -1, ulist[tile][np.minimum(loc, UMAX - 1)])
+        assert loc.max() <= len(uniq)
+        back = np.where(absent, -1, ulist[tile][np.maximum(loc - 1, 0)])
         assert np.array_equal(back, ent)
 
 
