@@ -51,7 +51,11 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
     }
     __syncthreads();
     const int U = cnt;
-    if (tid == 0) v.ucount[tile] = U;
+    if (tid == 0) {
+        v.ucount[tile] = U;
+        if (U > TB_CAP64) atomicAdd(&v.n_over[0], 1);
+        if (U > TB_UMAX) atomicAdd(&v.n_over[1], 1);
+    }
     int32_t *ul = v.ulist + (size_t)tile * TB_UMAX;
     if (U > TB_UMAX) {
         for (int k = tid; k < TB_UMAX; k += 256) ul[k] = -1;
@@ -145,6 +149,7 @@ extern "C" int doda_tilebook_build(const int32_t *tbl, int32_t ld, int32_t K, in
     if (!tbl || !tilebook || ((uintptr_t)tilebook & 15)) return DODA_ERR_INVALID;
     if (tilebook_bytes < tilebook_bytes_for(n_rows)) return DODA_ERR_WORKSPACE;
     const TileBookView v = tilebook_view(tilebook, n_rows);
+    if (hipMemsetAsync(v.n_over, 0, 8, as_stream(stream)) != hipSuccess) return DODA_ERR_LAUNCH;
     hipLaunchKernelGGL(tilebook_build, dim3(v.nt), dim3(256), 0, as_stream(stream), tbl, (int)ld, (int)n_rows, v);
     return doda_check_launch();
 }

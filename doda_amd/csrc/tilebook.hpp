@@ -8,6 +8,8 @@
 //   ulist [TB_UMAX]   int32   the distinct input rows, ascending (-1 past the count)
 //   lidx  [K][TB_T]   uint16  1 + position of tbl[o][t] in ulist, or 0 when absent (LDS slot 0 = the zero row)
 //   ucount            int32   number of distinct rows (> TB_UMAX: the list is not kept)
+// plus, once per tilebook, n_over int32 [2]: tiles above TB_CAP64 / above TB_UMAX (the caller's safety valve:
+// voxel orders without locality overflow everywhere and are better served by the dense-table kernels).
 // A kernel stages at most its own capacity (what its LDS budget allows for its row size: tile_cap()) and
 // serves a tile above it from the dense table.
 // and the kernel loads each distinct row ONCE, coalesced, into LDS and serves all K gathers from there.
@@ -26,12 +28,13 @@ struct TileBookView {
     int32_t *ulist;     // [nt][TB_UMAX]
     uint16_t *lidx;     // [nt][TB_K][TB_T]
     int32_t *ucount;    // [nt]
+    int32_t *n_over;    // [2]
     int nt;
 };
 
 static inline size_t tilebook_bytes_for(long long n_rows) {
     const size_t nt = (size_t)((n_rows + TB_T - 1) / TB_T);
-    return nt * ((size_t)TB_UMAX * 4 + (size_t)TB_K * TB_T * 2 + 4);
+    return nt * ((size_t)TB_UMAX * 4 + (size_t)TB_K * TB_T * 2 + 4) + 8;
 }
 
 static inline TileBookView tilebook_view(void *base, long long n_rows) {
@@ -43,6 +46,8 @@ static inline TileBookView tilebook_view(void *base, long long n_rows) {
     v.lidx = (uint16_t *)p;
     p += (size_t)v.nt * TB_K * TB_T * 2;
     v.ucount = (int32_t *)p;
+    p += (size_t)v.nt * 4;
+    v.n_over = (int32_t *)p;
     return v;
 }
 

@@ -872,6 +872,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               at::Tensor ucount = at::from_blob(p + nt * UMAX * 4 + nt * K * T * 2, {nt}, o32).clone();
               return std::make_tuple(ulist, lidx, ucount);
           });
+    m.def("tilebook_overflow", [](const at::Tensor &tbl) {   // (tiles, tiles above the 64-byte-row capacity, above the list capacity); syncs
+              const void *tb = tilebook_behind(tbl, tbl.size(1));
+              TORCH_CHECK(tb, "doda tilebook_overflow: no tilebook");
+              const int64_t T = doda_tilebook_tile(), nt = (tbl.size(1) + T - 1) / T, K = tbl.size(0), UMAX = doda_tilebook_umax();
+              char *p = (char *)const_cast<void *>(tb) + nt * UMAX * 4 + nt * K * T * 2 + nt * 4;
+              at::Tensor over = at::from_blob(p, {2}, tbl.options()).cpu();
+              return std::make_tuple(nt, (int64_t)over[0].item<int32_t>(), (int64_t)over[1].item<int32_t>());
+          });
     m.def("set_tile_kernel", [](bool on) { doda_spconv_set_tile_kernel(on ? 1 : 0); });
     m.def("pending_wgrads", []() { std::lock_guard<std::mutex> lock(g_wq_mu); return (int64_t)g_wq.size(); });
     m.def("set_defer_wgrad", [](bool on) { g_defer_wgrad = on; },

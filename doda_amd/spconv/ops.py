@@ -69,6 +69,13 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
 
 TILE_MIN_ROWS = 32768    # finest-level rulebooks of at least this many rows get a tilebook (LDS-staged conv kernel)
 TILE_KERNEL = os.environ.get("DODA_NO_TILE", "0") != "1"
+# Safety valve: the tile kernel lives on the locality of the voxel order (raster-like scans: ~2-3 x 256 distinct
+# neighbour rows per 256-row tile).  If more than TILE_OVERFLOW_MAX of a batch's finest-level tiles exceed the
+# staging capacity (they are then served from the dense table inside the tile kernel, slower than the dense
+# kernel itself), tilebooks are skipped for the next TILE_BACKOFF batches and probed again afterwards.
+TILE_OVERFLOW_MAX = 0.25
+TILE_BACKOFF = 64
+_tile_state = {"skip": 0, "last": None}   # batches still to skip; (tiles, over 64-byte capacity, over list capacity)
 
 
 def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", first_level=1, with_pairs=False,
@@ -85,9 +92,21 @@ def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", firs
     n_tile_levels = (2 if with_pairs else 0) if with_tiles is None else (2 if with_tiles is True else int(with_tiles))
     if (_ext is not None and not tensor.indice_dict and indices.is_cuda and indices.dtype == torch.int32
             and indices.shape[0] > 0 and all(int(v) >= 2 for v in shape)):
+        tiles_on = TILE_KERNEL and n_tile_levels > 0
+        if tiles_on and _tile_state["skip"] > 0:
+            _tile_state["skip"] -= 1
+            tiles_on = False
         levels = _ext.build_pyramid(indices, [int(v) for v in shape], int(tensor.batch_size), int(n_levels),
                                     PAIRS_MIN_ROWS if with_pairs else -1,
-                                    TILE_MIN_ROWS if (TILE_KERNEL and n_tile_levels > 0) else -1, n_tile_levels)
+                                    TILE_MIN_ROWS if tiles_on else -1, n_tile_levels)
+        if tiles_on and _ext.has_tilebook(levels[0][0]):
+            # the builds are complete (the pyramid's size read-backs came after them on this stream): 8 bytes back
+            nt, over64, over32 = _ext.tilebook_overflow(levels[0][0])
+            _tile_state["last"] = (nt, over64, over32)
+            if over32 > TILE_OVERFLOW_MAX * nt:
+                _tile_state["skip"] = TILE_BACKOFF
+                # this batch too: plain copies of the tables (no tilebook behind them) keep it on the dense kernels
+                levels = [((lv[0].clone() if _ext.has_tilebook(lv[0]) else lv[0]),) + tuple(lv[1:]) for lv in levels]
         for k, (nbr, outids, child, par_off, oshape, sp, sn, sh, dp, dn, dh) in enumerate(levels):   # s*/d*: lists, counts, segments
             lvl = first_level + k
             data = tensor.indice_dict[subm_key % lvl] = IndiceData("subm", indices, indices, list(shape),

@@ -255,7 +255,10 @@ typedef struct doda_conv_epilogue {
  * the dense-table path up to the fp32 summation order over offsets.  K must be 27 (else bytes == 0 /
  * DODA_ERR_UNSUPPORTED); `tilebook` 16-byte aligned. */
 int32_t doda_tilebook_tile(void);
-int32_t doda_tilebook_umax(void);   /* list capacity per tile; layout: ulist int32 [nt][umax], lidx uint16 [nt][K][tile], ucount int32 [nt] */
+int32_t doda_tilebook_umax(void);   /* list capacity per tile; layout: ulist int32 [nt][umax], lidx uint16 [nt][K][tile],
+                                     * ucount int32 [nt], n_over int32 [2] = tiles whose neighbourhood exceeds the 64-byte-row /
+                                     * 32-byte-row staging capacity (they are served from the dense table: a caller whose voxel
+                                     * order has no locality reads n_over and stops building tilebooks) */
 size_t doda_tilebook_bytes(int32_t n_rows, int32_t K);
 int doda_tilebook_build(const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, void *tilebook,
                         size_t tilebook_bytes, doda_stream_t stream);

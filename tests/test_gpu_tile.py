@@ -302,3 +302,38 @@ def test_unet_step_with_and_without_tilebooks(native_lib, dtype, monkeypatch):
     for k, g0 in runs[0][1].items():
         g1 = runs[1][1][k]
         assert (g0.float() - g1.float()).norm().item() <= tol[1] * g0.float().norm().item() + 1e-6, k
+
+
+def test_safety_valve_for_voxel_orders_without_locality(native_lib):
+    """A shuffled voxel order makes every tile exceed the staging capacity: the pyramid builder notices (overflow
+    counters of the tilebook), hands out plain tables for this batch and skips tilebooks for the next batches."""
+    ext = _ext_or_skip()
+    from doda_amd import spconv
+    d = dev()
+    from doda_amd.scene import make_batch
+    b = make_batch(1, 40000, 7)                                          # dense surfaces: ~9 neighbours per voxel
+    shape = [int(v) for v in b["spatial_shape"]]
+    idx = b["voxel_locs"].int()
+    idx = idx[torch.randperm(idx.shape[0], generator=torch.Generator().manual_seed(1))].contiguous().to(d)
+    state = spconv.ops._tile_state
+    saved = dict(state)
+    try:
+        state["skip"] = 0
+        t = spconv.SparseConvTensor(None, idx, shape, 1)
+        spconv.ops.build_pyramid(t, 3, with_tiles=2)
+        nt, over64, over32 = state["last"]
+        assert over32 > 0.9 * nt and state["skip"] == spconv.ops.TILE_BACKOFF
+        assert not ext.has_tilebook(t.indice_dict["subm1"].tbl)
+        # a well-ordered batch while the valve is closed: no tilebooks either, the counter runs down
+        key = ((idx[:, 0].long() * shape[0] + idx[:, 1]) * shape[1] + idx[:, 2]) * shape[2] + idx[:, 3]
+        idx2 = idx[torch.argsort(key)].contiguous()
+        t2 = spconv.SparseConvTensor(None, idx2, shape, 1)
+        spconv.ops.build_pyramid(t2, 3, with_tiles=2)
+        assert not ext.has_tilebook(t2.indice_dict["subm1"].tbl) and state["skip"] == spconv.ops.TILE_BACKOFF - 1
+        state["skip"] = 0
+        t3 = spconv.SparseConvTensor(None, idx2, shape, 1)
+        spconv.ops.build_pyramid(t3, 3, with_tiles=2)
+        assert ext.has_tilebook(t3.indice_dict["subm1"].tbl) and state["skip"] == 0
+        assert state["last"][2] == 0
+    finally:
+        state.update(saved)
