@@ -67,3 +67,11 @@ int launch_conv_tile(int mode, bool out32, const void *x, unsigned x_bytes, cons
                      const EpiArgs &ep, int *n_part, hipStream_t s);
 void pack_pair_layout2(const float *w, void *out, hipStream_t s);   // defined next to the pack kernels
 }  // namespace doda_tile
+
+namespace doda_wlds {
+bool enabled();
+void set_enabled(bool on);
+// bf16 48 -> 48 channels, K = 27, weights in LDS (spconv_wlds.hip); wp = wide-packed fragments [27][2][3][64] x 16 B
+int launch_conv48(const void *x, unsigned x_bytes, const void *wp, const int32_t *tbl, unsigned tbl_bytes, int ld, int n_out,
+                  void *y, unsigned y_bytes, const void *res, const EpiArgs &ep, int *n_part, hipStream_t s);
+}  // namespace doda_wlds

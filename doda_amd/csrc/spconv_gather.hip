@@ -884,6 +884,12 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
                                                n_out, tilebook, y_, yb, res, ep, n_part, s);
         }
     }
+    // 48 -> 48 channels on a mid-size level: the layer's fragments in LDS, one workgroup per CU (spconv_wlds.hip)
+    if (wide && kc == 48 && nc == 48 && K == 27 && !out32 && n_out >= 8192 && n_out <= 262144 && doda_wlds::enabled()) {
+        const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
+        const unsigned yb = (unsigned)((size_t)n_out * nc * sizeof(elem));
+        return doda_wlds::launch_conv48(x_, xb, wp, tbl, (unsigned)((size_t)K * ld * 4), ld, n_out, y_, yb, res, ep, n_part, s);
+    }
     // Tile choice: many rows -> more subtiles per wave and all channel blocks in one wave (x is
     // gathered once); few rows -> one subtile, channel blocks spread over the grid so the chip
     // still sees thousands of waves.
@@ -1050,6 +1056,8 @@ extern "C" int doda_spconv_gather_add_bf16(const uint16_t *x, int32_t n_in, int3
 }
 
 // ---- gather with epilogue options (residual add, BatchNorm statistics) ------------------------------
+extern "C" void doda_spconv_set_wlds_kernel(int32_t on) { doda_wlds::set_enabled(on != 0); }
+
 extern "C" size_t doda_spconv_stats_capacity(int32_t n_out) { return n_out > 0 ? (size_t)div_up(n_out, 16) : 1; }
 
 extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, int32_t elem_bytes, const float *w,

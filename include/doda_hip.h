@@ -278,6 +278,9 @@ int doda_spconv_bwd_tile_bf16(const uint16_t *dy, const uint16_t *x, int32_t n_r
                               const doda_conv_epilogue *epi, doda_stream_t stream);
 /* A/B switch for measurements: 0 = ignore tilebooks (dense-table kernels only).  Default 1. */
 void doda_spconv_set_tile_kernel(int32_t on);
+/* A/B switch: 0 = the 48 -> 48 channel layers stay on the streaming-weights kernel instead of the weights-in-LDS
+ * one.  Default 1. */
+void doda_spconv_set_wlds_kernel(int32_t on);
 size_t doda_spconv_stats_capacity(int32_t n_out);
 int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, int32_t elem_bytes, const float *w,
                           int32_t nc, const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, void *y,

@@ -337,3 +337,40 @@ def test_safety_valve_for_voxel_orders_without_locality(native_lib):
         assert state["last"][2] == 0
     finally:
         state.update(saved)
+
+
+@pytest.mark.parametrize("m,layout", [(20000, 0), (20000, 2), (8300, 0)])
+def test_weights_in_lds_kernel_48_channels(native_lib, m, layout):
+    """conv_wlds48 (bf16 48 -> 48, the level-3 layers): against the fp64 oracle on bf16-representable operands, against
+    the streaming-weights kernel (switch off), with residual; statistics rows through the extension."""
+    from doda_amd import ops
+    from doda_amd._lib import lib
+    d = dev()
+    _, tbl = _scene_table(m, seed=31 + m)
+    n = tbl.shape[1]
+    assert n >= 8192
+    torch.manual_seed(m)
+    x = torch.randn(n, 48, device=d).bfloat16()
+    w = (torch.randn(27, 48, 48, device=d) * 0.1).bfloat16().float()
+    wk = w if layout == 0 else w.transpose(1, 2).contiguous()
+    ref = _oracle_conv(x, wk, tbl, layout)
+    res = torch.randn(n, 48, device=d).bfloat16()
+    try:
+        lib().doda_spconv_set_wlds_kernel(0)
+        y_stream = ops.spconv_gather(x, wk, tbl, n, layout, 48)
+        lib().doda_spconv_set_wlds_kernel(1)
+        y = ops.spconv_gather(x, wk, tbl, n, layout, 48)
+        y_res = ops.spconv_gather(x, wk, tbl, n, layout, 48, residual=res)
+    finally:
+        lib().doda_spconv_set_wlds_kernel(1)
+    assert rel_err(y.float().cpu(), ref) < 2.0 ** -7
+    assert (y != y_stream).float().mean().item() < 0.02
+    assert rel_err(y_res.float().cpu(), ref + res.double().cpu()) < 2.0 ** -7
+    ext = _ext_or_skip()
+    wt = torch.nn.Parameter(w.view(3, 3, 3, 48, 48).clone())
+    with torch.no_grad():
+        yy, st = ext.indice_conv_stats(x, wt, tbl, tbl, n, 2, None, None, res)
+    assert st is not None and st.shape[0] == (n + 255) // 256
+    yf = yy.double()
+    assert rel_err(st.double().sum(0)[0].cpu(), yf.sum(0).cpu()) < 1e-5
+    assert rel_err(st.double().sum(0)[1].cpu(), (yf * yf).sum(0).cpu()) < 1e-5

@@ -26,7 +26,7 @@ def main():
     b = make_batch(a.scenes, a.voxels, 1000)
     idx = b["voxel_locs"].int().to(d)
     shape = b["spatial_shape"]
-    if a.level == 2:
+    for _ in range(a.level - 1):
         down = spconv.ops.build_down2(idx, a.scenes, shape, 2, 2, 0, 1)
         idx, shape = down.outids, down.out_spatial_shape
     data = spconv.ops.build_subm(idx, a.scenes, shape, 3)
@@ -88,6 +88,14 @@ def main():
                 ext.indice_conv_stats(xs[j], wt, tt[j] if tiled else tbls[j], tt[j] if tiled else tbls[j], m, 2, pk, None, res)
         out["dense_stats_res_cold_us"] = timed(lambda: stats(False))
         out["tile_stats_res_cold_us"] = timed(lambda: stats(True))
+    if a.kc == 48 and a.nc == 48:
+        from doda_amd._lib import lib as _l
+        _l().doda_spconv_set_wlds_kernel(0)
+        out["stream_weights_us"] = timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, 48, packed=pk))
+        out["stream_weights_cold_us"] = timed(lambda: cold(False))
+        _l().doda_spconv_set_wlds_kernel(1)
+        out["weights_in_lds_us"] = timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, 48, packed=pk))
+        out["weights_in_lds_cold_us"] = timed(lambda: cold(False))
     y0 = ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk, out_f32=True)
     y1 = ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk, out_f32=True, tilebook=tb)
     out["max_rel_diff"] = ((y0 - y1).abs().max() / y0.abs().max()).item()
