@@ -55,95 +55,195 @@ def parse():
     return p.parse_args()
 
 
+COLD_BYTES = 320 << 20   # operands of consecutive timed launches cycle through more than the 256 MB Infinity Cache
+
+
+def _timed(fn, reps, per=1):
+    """Average launch time over back-to-back launches, HIP events on the launch stream.  The reps are timed in
+    five event-bracketed chunks and the MEDIAN chunk average is returned: one host stall (allocator growth, a
+    descheduled issue thread) inside a single bracket once produced a 5x outlier for a kernel whose rocprofv3
+    average in the same run was unchanged."""
+    for _ in range(5):
+        fn()
+    n_chunk, per_chunk = 5, max(1, reps // 5)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_chunk + 1)]
+    torch.cuda.synchronize()
+    ev[0].record()  # current stream == the stream ops.* launches on
+    for c in range(n_chunk):
+        for _ in range(per_chunk):
+            fn()
+        ev[c + 1].record()
+    torch.cuda.synchronize()
+    chunks = sorted(ev[c].elapsed_time(ev[c + 1]) for c in range(n_chunk))
+    return chunks[n_chunk // 2] * 1e-3 / per_chunk / per
+
+
 def _subm16_times(idx, shape, nb, dtype, reps):
-    """SubMConv3d 16->16 on the level-1 rulebook of `idx`: forward gather, data-grad gather and weight
-    gradient, timed with HIP events on the launch stream exactly as the training step issues them:
-    weights fragment-packed beforehand (one launch per optimizer step in the model), the weight gradient
-    through the multi-layer call with the level's 8 block convolutions in one call (pair lists exported
-    once per rulebook for bf16).  Returns the per-launch / per-layer times and the algorithmic bytes
-    (B_f = s(M Cin + M Cout) + 4 K Cin Cout + 8 P, B_b = s(2 M Cin + M Cout) + 2*4 K Cin Cout + 8 P)."""
+    """SubMConv3d 16->16 on the level-1 rulebook of `idx`: forward gather, data-grad gather and weight gradient,
+    HIP events on the launch stream, issued as the training step issues them (weights fragment-packed beforehand,
+    tilebook / pair lists built once per rulebook, the weight gradient through the multi-layer call with the
+    level's 8 block convolutions in one call).
+
+    Every kernel is timed twice: WARM (the same buffers back to back: at these sizes the working set sits in the
+    256 MB Infinity Cache, which a kernel inside the training step never enjoys) and COLD (operands cycle through
+    enough buffer sets to exceed COLD_BYTES).  The forward and data-grad kernels are timed in two forms: PLAIN
+    (no epilogue options: the SURVEY 8d gate) and STEP — the instantiation the training step launches: BatchNorm
+    statistics in the epilogue plus the fused residual add (forward) or the BatchNorm-backward sums over the
+    BatchNorm input (data gradient).  Algorithmic bytes: B_f = s(M Cin + M Cout) + 4 K Cin Cout + 8 P,
+    B_b = s(2 M Cin + M Cout) + 2*4 K Cin Cout + 8 P; the STEP forms add the one extra operand they read
+    (s M C: residual rows / BatchNorm input rows)."""
     from doda_amd import ops, spconv
     dev = idx.device
     m = idx.shape[0]
     data = spconv.ops.build_subm(idx, nb, shape, 3)
     pairs_total = int((data.tbl >= 0).sum().item())
     tdt = torch.float32 if dtype == "f32" else torch.bfloat16
-    x = torch.randn(m, 16, device=dev).to(tdt)
-    gy = torch.randn(m, 16, device=dev).to(tdt)
-    w = torch.randn(27, 16, 16, device=dev) * 0.1
     s = 4 if dtype == "f32" else 2
-
-    def timed(fn, per=1):
-        """Average launch time over back-to-back launches, HIP events on the launch stream.  The reps are
-        timed in five event-bracketed chunks and the MEDIAN chunk average is returned: one host stall
-        (allocator growth, a descheduled issue thread) inside a single bracket once produced a 5x outlier
-        for a kernel whose rocprofv3 average in the same run was unchanged."""
-        for _ in range(5):
-            fn()
-        n_chunk, per_chunk = 5, max(1, reps // 5)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_chunk + 1)]
-        torch.cuda.synchronize()
-        ev[0].record()  # current stream == the stream ops.* launches on
-        for c in range(n_chunk):
-            for _ in range(per_chunk):
-                fn()
-            ev[c + 1].record()
-        torch.cuda.synchronize()
-        chunks = sorted(ev[c].elapsed_time(ev[c + 1]) for c in range(n_chunk))
-        return chunks[n_chunk // 2] * 1e-3 / per_chunk / per
-
+    w = torch.randn(27, 16, 16, device=dev) * 0.1
     b_f = s * (m * 16 + m * 16) + 4 * 27 * 16 * 16 + 8 * pairs_total
     b_b = s * (2 * m * 16 + m * 16) + 2 * 4 * 27 * 16 * 16 + 8 * pairs_total
+    b_extra = s * m * 16
     plan = ops.PackPlan([(w, 27, 16, 16, 0, s), (w, 27, 16, 16, 2, s)], dev)
     plan.run()
     pk_f, pk_d = plan.outputs
-    # bf16: the LDS-staged tile kernel over the rulebook's tilebook (built once per rulebook, as the model does);
-    # fp32 is bound by the fp32 matrix rate either way (tile kernel 83.7 us, dense 86.3 us) and stays on conv_fast
-    tb = ops.tilebook_build(data.tbl) if (dtype == "bf16" and spconv.ops.TILE_KERNEL) else None
-    t_f = timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, 16, packed=pk_f, tilebook=tb))
-    t_d = timed(lambda: ops.spconv_gather(gy, None, data.tbl, m, 2, 16, packed=pk_d, tilebook=tb))
+    use_tile = dtype == "bf16" and spconv.ops.TILE_KERNEL
+    use_pairs = dtype == "bf16" and spconv.functional.WGRAD_PAIRS
+    # one buffer set = everything one fwd + dgrad + wgrad of a layer touches
+    per_set = 3 * s * m * 16 + (73 * m if use_tile else 108 * m)
+    n_sets = max(2, -(-COLD_BYTES // per_set) + 1)
+
+    class Set:
+        pass
+    sets = []
+    for j in range(n_sets):
+        st = Set()
+        st.x = torch.randn(m, 16, device=dev).to(tdt)
+        st.gy = torch.randn(m, 16, device=dev).to(tdt)
+        st.res = torch.randn(m, 16, device=dev).to(tdt)
+        st.y = torch.empty(m, 16, device=dev, dtype=tdt)
+        st.tbl = data.tbl if j == 0 else data.tbl.clone()
+        st.tb = ops.tilebook_build(st.tbl) if use_tile else None
+        st.pairs = None
+        if use_pairs:
+            st.pairs = data.wgrad_lists() if j == 0 else tuple(
+                t.clone() if torch.is_tensor(t) else t for t in data.wgrad_lists())
+        sets.append(st)
+    mean = torch.zeros(16, device=dev)
+    invstd = torch.ones(16, device=dev)
+    gamma = torch.ones(16, device=dev)
+    beta = torch.zeros(16, device=dev)
+    k = [0]
+
+    def nxt(cold):
+        if cold:
+            k[0] = (k[0] + 1) % n_sets
+        return sets[k[0] if cold else 0]
+
+    def fwd(cold, step):
+        st = nxt(cold)
+        ops.spconv_gather(st.x, None, st.tbl, m, 0, 16, packed=pk_f, tilebook=st.tb, out=st.y,
+                          residual=st.res if step else None, want_stats=step)
+
+    def dgrad(cold, step):
+        st = nxt(cold)
+        ops.spconv_gather(st.gy, None, st.tbl, m, 2, 16, packed=pk_d, tilebook=st.tb, out=st.y, want_stats=step,
+                          bn=(st.x, mean, invstd, gamma, beta, True) if step else None)
+
     n_layers = 8   # the 16 -> 16 block convolutions of level 1 share the rulebook and one multi-layer call
-    wg_kernel = "wgrad_multi_kernel (gather table)"
-    pairs = None
-    if dtype == "bf16" and spconv.functional.WGRAD_PAIRS:
-        pairs = data.wgrad_lists()
-        wg_kernel = "wgrad_pairs_kernel<1,1> (pair lists)"
-    jobs = [(x, gy, data.tbl, m, pairs) if pairs is not None else (x, gy, data.tbl, m) for _ in range(n_layers)]
-    t_w = timed(lambda: ops.spconv_wgrad_multi(jobs), per=n_layers)
-    t_all = t_f + t_d + t_w
-    return {"M": m, "P": pairs_total, "tile_kernel": tb is not None,
-            "fwd": {"us": t_f * 1e6, "GBs": b_f / t_f / 1e9},
-            "dgrad": {"us": t_d * 1e6, "GBs": b_f / t_d / 1e9},
-            "wgrad": {"us": t_w * 1e6, "GBs": b_f / t_w / 1e9, "kernel": wg_kernel,
+    jobs_warm = [(sets[0].x, sets[0].gy, sets[0].tbl, m, sets[0].pairs) if use_pairs else
+                 (sets[0].x, sets[0].gy, sets[0].tbl, m) for _ in range(n_layers)]
+    jobs_cold = [(sets[j % n_sets].x, sets[j % n_sets].gy, sets[j % n_sets].tbl, m, sets[j % n_sets].pairs) if use_pairs else
+                 (sets[j % n_sets].x, sets[j % n_sets].gy, sets[j % n_sets].tbl, m) for j in range(n_layers)]
+    wg_kernel = "wgrad_pairs_kernel<1,1> (pair lists)" if use_pairs else "wgrad_multi_kernel (gather table)"
+
+    t = {}
+    for name, fn in (("fwd", fwd), ("dgrad", dgrad)):
+        for cold in (False, True):
+            for step in (False, True):
+                t[(name, cold, step)] = _timed(lambda: fn(cold, step), reps)
+    t_w = {False: _timed(lambda: ops.spconv_wgrad_multi(jobs_warm), max(5, reps // 4), per=n_layers),
+           True: _timed(lambda: ops.spconv_wgrad_multi(jobs_cold), max(5, reps // 4), per=n_layers)}
+
+    def rec(sec, nbytes):
+        return {"us": sec * 1e6, "GBs": nbytes / sec / 1e9, "frac_of_hbm_peak": nbytes / sec / 1e9 / HBM_PEAK_GBS}
+
+    def kernel(name):
+        return {"plain_warm": rec(t[(name, False, False)], b_f), "plain_cold": rec(t[(name, True, False)], b_f),
+                "step_warm": rec(t[(name, False, True)], b_f + b_extra), "step_cold": rec(t[(name, True, True)], b_f + b_extra),
+                "algorithmic_bytes": {"plain": b_f, "step": b_f + b_extra}}
+
+    def gate(cold):
+        tot = t[("fwd", cold, False)] + t[("dgrad", cold, False)] + t_w[cold]
+        return {"fwd_us": t[("fwd", cold, False)] * 1e6, "dgrad_us": t[("dgrad", cold, False)] * 1e6,
+                "wgrad_us": t_w[cold] * 1e6, **rec(tot, b_f + b_b), "algorithmic_bytes": b_f + b_b}
+    return {"M": m, "P": pairs_total, "tile_kernel": use_tile, "buffer_sets": n_sets, "bytes_per_set": per_set,
+            "fwd": kernel("fwd"), "dgrad": kernel("dgrad"),
+            "wgrad": {"warm": rec(t_w[False], b_f), "cold": rec(t_w[True], b_f), "kernel": wg_kernel,
                       "note": "%d layers per multi-layer call, time per layer incl. the partial reduce" % n_layers},
-            "fwd_bwd": {"us": t_all * 1e6, "GBs": (b_f + b_b) / t_all / 1e9,
-                        "frac_of_hbm_peak": (b_f + b_b) / t_all / 1e9 / HBM_PEAK_GBS,
-                        "algorithmic_bytes": b_f + b_b},
-            "b_f": b_f}
+            "fwd_bwd": {"cold": gate(True), "warm": gate(False)}, "b_f": b_f}
+
+
+def in_step_average(dtype):
+    """AverageNs of the roofline kernel's in-step instantiation from the committed rocprofv3 --kernel-trace --stats
+    summary of `python bench.py` (profiles/r03_*_kernel_stats.csv; a counter/trace pass cannot run inside this
+    process).  Returns (microseconds, file) or (None, None)."""
+    import csv
+    prof = os.path.join(ROOT, "profiles")
+    for rnd in ("r03", "r02"):
+        path = os.path.join(prof, "%s_%s_kernel_stats.csv" % (rnd, "bf16" if dtype == "bf16" else "f32"))
+        if not os.path.exists(path):
+            continue
+        want = "conv_tile<0, false, true>" if dtype == "bf16" else "::PF32,"
+        try:
+            with open(path) as f:
+                rows = [r for r in csv.DictReader(f) if want in r["Name"]]
+            if rows:   # (fp32: the statistics instantiation with the largest total time = the level-1 layers)
+                top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+                return float(top["AverageNs"]) / 1e3, "profiles/" + os.path.basename(path)
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
 
 
 def kernel_roofline(batch_dev, dtype, reps, gate_scene=None):
-    """Dominant kernel live: SubMConv3d 16->16 forward gather on the batch's level-1 rulebook; plus the
-    north-star gate (whole 16->16 fwd+bwd) at the batch size and on ONE ~150 k-voxel scene."""
+    """Dominant kernel live: the SubMConv3d 16->16 forward gather on the batch's level-1 rulebook IN THE FORM THE
+    STEP LAUNCHES IT (BatchNorm statistics + residual add in the epilogue), operands cold; plus the north-star gate
+    (whole 16->16 fwd+bwd, plain kernels as SURVEY 8d states it) at the batch size and on ONE ~150 k-voxel scene,
+    cold and warm side by side."""
     idx = batch_dev["voxel_locs"].int()
     nb = int(batch_dev["offsets"].numel() - 1)
     big = _subm16_times(idx, batch_dev["spatial_shape"], nb, dtype, reps)
     out = {"subm16_fwd": big["fwd"], "subm16_dgrad": big["dgrad"], "subm16_wgrad": big["wgrad"],
-           "subm16_fwd_bwd": big["fwd_bwd"]}
+           "subm16_fwd_bwd": {**big["fwd_bwd"]["cold"], "measured": "cold", "warm": big["fwd_bwd"]["warm"]},
+           "buffer_sets": big["buffer_sets"], "bytes_per_set": big["bytes_per_set"]}
     if gate_scene is not None:
         one = _subm16_times(gate_scene["voxel_locs"].int(), gate_scene["spatial_shape"], 1, dtype, reps)
-        out["gate_150k"] = {"M": one["M"], "P": one["P"], "fwd_us": one["fwd"]["us"], "dgrad_us": one["dgrad"]["us"],
-                            "wgrad_us": one["wgrad"]["us"], **one["fwd_bwd"],
-                            "note": "north_star gate: SubMConv3d 16->16 fwd+bwd on one ~150k-voxel scene; its 45 MB "
-                                    "working set sits in the 256 MB Infinity Cache between back-to-back launches"}
-    m, pairs_total, b_f = big["M"], big["P"], big["b_f"]
-    kname = "conv_tile (LDS-staged, tilebook)" if big["tile_kernel"] else (
-        "conv_fast<PF32,1,2,3>" if dtype == "f32" else "conv_fast<PBF16P,1,2,3>")
+        out["gate_150k"] = {"M": one["M"], "P": one["P"], **one["fwd_bwd"]["cold"], "measured": "cold",
+                            "warm": one["fwd_bwd"]["warm"], "buffer_sets": one["buffer_sets"],
+                            "note": "north_star gate: SubMConv3d 16->16 fwd+bwd on one ~150k-voxel scene; cold = operands "
+                                    "cycled through %d buffer sets (> 256 MB), warm = the same 45 MB back to back "
+                                    "(Infinity-Cache resident)" % one["buffer_sets"]}
+    m, pairs_total = big["M"], big["P"]
+    step_cold = big["fwd"]["step_cold"]
+    b_step = big["fwd"]["algorithmic_bytes"]["step"]
+    if big["tile_kernel"]:
+        kname = "conv_tile<0,false,true> (LDS-staged over the tilebook; BatchNorm statistics + residual add in the epilogue: the instantiation the step launches)"
+    else:
+        kname = ("conv_fast<PF32,1,2,3,STATS>" if dtype == "f32" else "conv_fast<PBF16P,1,2,3,STATS>") + " (statistics + residual epilogue)"
     traffic, traffic_src = pmc_traffic(dtype)
-    roof = {"kernel": "%s (SubMConv3d 16->16 fwd gather, M=%d, P=%d)" % (kname, m, pairs_total),
-            "bound": "hbm", "achieved": out["subm16_fwd"]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": out["subm16_fwd"]["GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": b_f, "avg_launch_us": out["subm16_fwd"]["us"], "detail": out}
+    in_step_us, in_step_src = in_step_average(dtype)
+    roof = {"kernel": "%s, SubMConv3d 16->16 fwd gather, M=%d, P=%d" % (kname, m, pairs_total),
+            "M": m, "P": pairs_total, "bound": "hbm", "achieved": step_cold["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": step_cold["frac_of_hbm_peak"], "measured": "cold (operands cycled through %d buffer sets, %d MB)" % (
+                big["buffer_sets"], big["buffer_sets"] * big["bytes_per_set"] >> 20),
+            "frac_cold": step_cold["frac_of_hbm_peak"], "frac_warm": big["fwd"]["step_warm"]["frac_of_hbm_peak"],
+            "frac_plain_cold": big["fwd"]["plain_cold"]["frac_of_hbm_peak"],
+            "frac_plain_warm": big["fwd"]["plain_warm"]["frac_of_hbm_peak"],
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": b_step, "avg_launch_us": step_cold["us"],
+            "in_step_rocprof_avg_us": in_step_us, "in_step_rocprof_source": in_step_src,
+            "in_step_frac": (b_step / (in_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if in_step_us else None,
+            "detail": out}
     return roof, pairs_total / max(m, 1)
 
 
@@ -208,21 +308,62 @@ def pmc_traffic(dtype):
         return None, None
 
 
-def cpu_baseline(args):
-    """Oracle U-Net fwd+bwd (fp32, torch-CPU threads = all host cores) on ONE scene."""
+def voxelize_legs(batch, batch_dev, reps=20):
+    """SURVEY 8d CPU-baseline leg (1): point -> voxel maps (`voxelize_idx`, reference voxelize.cpp:61-155 — the
+    collate step the reference runs single-threaded in each DataLoader worker) on the bench batch's points.  Host:
+    doda_voxelize_idx_h, one thread, and x `workers` threads each voxelising its own copy of the batch (how
+    n_workers DataLoader processes scale it).  Device: doda_voxelize_idx_assign + _fill incl. the size read-back,
+    against the HBM roofline with the algorithmic bytes of DESIGN.md §3 (36 B per point + 32 + 4(1+maxActive) per
+    voxel).  The reference's own compiled voxelize_idx cannot be built in this image (needs sparsehash +
+    cuda_runtime_api.h): the host figure is this repository's restatement of it."""
+    from concurrent.futures import ThreadPoolExecutor
+    from doda_amd import ops
+    locs, nb = batch["locs"], int(batch["offsets"].numel() - 1)
+    n = locs.shape[0]
+    vl, _, v2p = ops.voxelize_idx_host(locs, nb, 4)   # warm-up (first-touch page faults of the allocator)
+    t1 = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ops.voxelize_idx_host(locs, nb, 4)
+        t1 = min(t1, time.perf_counter() - t0)
+    workers = max(1, min(8, (os.cpu_count() or 1)))
+    copies = [locs.clone() for _ in range(workers)]
+    with ThreadPoolExecutor(workers) as ex:   # (the C entry point releases the GIL)
+        list(ex.map(lambda c: ops.voxelize_idx_host(c, nb, 4), copies))
+        t0 = time.perf_counter()
+        list(ex.map(lambda c: ops.voxelize_idx_host(c, nb, 4), copies))
+        tw = time.perf_counter() - t0
+    locs_dev = batch_dev["locs"]
+    t_dev = _timed(lambda: ops.voxelize_idx_device(locs_dev, nb, 4), reps)
+    m, width = vl.shape[0], v2p.shape[1]
+    nbytes = 36 * n + (32 + 4 * width) * m
+    return {"points": n, "voxels": m, "host_1_thread": {"seconds": t1, "points_per_s": n / t1},
+            "host_workers": {"workers": workers, "seconds": tw, "points_per_s": workers * n / tw},
+            "device": {"us": t_dev * 1e6, "points_per_s": n / t_dev, "algorithmic_bytes": nbytes,
+                       "GBs": nbytes / t_dev / 1e9, "frac_of_hbm_peak": nbytes / t_dev / 1e9 / HBM_PEAK_GBS,
+                       "note": "assign + fill kernels incl. the D2H read-back of the output sizes"},
+            "kind": "port", "note": "host = doda_voxelize_idx_h (restatement of voxelize.cpp:61-155; the reference's own "
+                                    "translation unit does not build here)"}
+
+
+def cpu_baseline(args, batch=None, batch_dev=None):
+    """Oracle U-Net fwd+bwd (fp32, torch-CPU threads = all host cores) on ONE scene; plus the voxelisation leg."""
     from doda_amd.scene import make_batch
     from oracle.unet_cpu import OracleUNet, forward_backward
-    batch = make_batch(1, args.cpu_voxels, 1000, args.voxel_scale)
+    sample = make_batch(1, args.cpu_voxels, 1000, args.voxel_scale)
     torch.manual_seed(0)
     net = OracleUNet().train()
     t0 = time.time()
-    forward_backward(net, batch)
+    forward_backward(net, sample)
     dt = time.time() - t0
-    m = batch["voxel_locs"].shape[0]
-    return {"value": m / dt, "unit": "voxels/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 scene (%d active voxels), 1 U-Net fwd+bwd incl. serial rulebook build, fp32, "
-                      "oracle/unet_cpu.py (spconv CPU path cannot be built: restatement stands in)" % m,
-            "seconds": dt}
+    m = sample["voxel_locs"].shape[0]
+    out = {"value": m / dt, "unit": "voxels/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "1 scene (%d active voxels), 1 U-Net fwd+bwd incl. serial rulebook build, fp32, "
+                     "oracle/unet_cpu.py (spconv CPU path cannot be built: restatement stands in)" % m,
+           "seconds": dt}
+    if batch is not None:
+        out["voxelize_idx"] = voxelize_legs(batch, batch_dev)
+    return out
 
 
 def main():
@@ -341,6 +482,9 @@ def main():
                        "points_per_gpu": n_local, "pairs_per_voxel_subm1": round(ppv, 2),
                        "parallelism": "dp%d" % world, "n_classes": 20, "final_loss": final_loss,
                        "grad_sync": "deferred multi-layer wgrad + bucketed all-reduce" if deferred else "torch DDP",
+                       "collectives": ("none (single process)" if not dist.is_initialized() else
+                                       "%s (forced, 1 rank)" % dist.get_backend() if world == 1 else
+                                       "%s, %d ranks" % (dist.get_backend(), world)),
                        "rulebooks": "13 per step, built for the next batch on a helper thread + side stream "
                                     "during the step" if args.prefetch else "13 per step, built in line",
                        "rulebook_parity": "bit-exact vs this repo's restatement of spconv-1.2's CPU algorithm; "
@@ -351,14 +495,12 @@ def main():
             r32, _ = kernel_roofline(batch_dev, "f32", max(10, args.kernel_reps // 2), gate_scene)
             b32, _ = step_algorithmic_bytes(net, batch_dev, "f32")
             fp32["roofline"] = {"kernel": r32["kernel"], "achieved": r32["achieved"], "frac": r32["frac"],
-                                "avg_launch_us": r32["avg_launch_us"], "detail": r32["detail"],
+                                "measured": r32["measured"], "avg_launch_us": r32["avg_launch_us"], "detail": r32["detail"],
                                 "step_frac_of_hbm_peak": b32 / (fp32["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
             # the fp32 gather is bound by the fp32 matrix rate (157.3 TFLOP/s: 1/16 of bf16, MI355X_MICROARCH.md),
             # not by HBM: its tiles multiply all 27 offsets of every 16-row subtile with a present neighbour
-            m32, p32 = r32["detail"]["subm16_fwd"], r32["kernel"]
-            n_rows = int(p32.split("M=")[1].split(",")[0])
-            pairs = int(p32.split("P=")[1].split(")")[0])
-            t32 = r32["avg_launch_us"] * 1e-6
+            n_rows, pairs = r32["M"], r32["P"]
+            t32 = r32["detail"]["subm16_fwd"]["plain_cold"]["us"] * 1e-6
             fp32["roofline"]["mfma_f32"] = {
                 "peak_TFLOPs": 157.3, "algorithmic_flops": 2 * pairs * 256, "dense_tile_flops": 2 * n_rows * 27 * 256,
                 "frac_algorithmic": 2 * pairs * 256 / t32 / 157.3e12, "frac_dense_tile_upper": 2 * n_rows * 27 * 256 / t32 / 157.3e12,
@@ -366,10 +508,11 @@ def main():
                         "bound on what the kernel issues (it skips offsets absent from a whole 32-row wave)"}
             line["fp32"] = fp32
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args)
+            line["cpu_baseline"] = cpu_baseline(args, batch, batch_dev)
+            roof["detail"]["voxelize_idx_device"] = line["cpu_baseline"]["voxelize_idx"]["device"]
         print(json.dumps(line), flush=True)
     ddist.barrier()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -86,6 +86,7 @@ struct Slot {
     void *host = nullptr;
     size_t cap = 0;
     hipEvent_t ev = nullptr;
+    int ev_dev = -1;    // device the event was created on (an event can only be recorded on that device's streams)
     bool pending = false;
 };
 std::mutex g_mu;
@@ -118,7 +119,11 @@ extern "C" int doda_sgd_multi(const doda_sgd_tensor *t, int32_t n_tensors, doubl
             sl.cap = align_up(need, 4096) * 2;
             if (hipHostMalloc(&sl.host, sl.cap, hipHostMallocDefault) != hipSuccess) { sl.host = nullptr; sl.cap = 0; return DODA_ERR_NOMEM; }
         }
+        int cur_dev = 0;
+        hipGetDevice(&cur_dev);
+        if (sl.ev && sl.ev_dev != cur_dev) { hipEventDestroy(sl.ev); sl.ev = nullptr; }   // library used from another device
         if (!sl.ev && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) return DODA_ERR_LAUNCH;
+        sl.ev_dev = cur_dev;
         SgdDesc *d = (SgdDesc *)sl.host;
         int *first = (int *)((char *)sl.host + first_off);
         for (int k = 0; k < n_tensors; ++k) {

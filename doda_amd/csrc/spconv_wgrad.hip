@@ -571,6 +571,7 @@ struct Staging {
     void *host = nullptr;
     size_t cap = 0;
     hipEvent_t ev = nullptr;
+    int ev_dev = -1;   // device the event was created on
     bool pending = false;
 };
 Staging g_staging;
@@ -696,7 +697,11 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
             st.cap = align_up(total_desc, 4096) * 2;
             if (hipHostMalloc(&st.host, st.cap, hipHostMallocDefault) != hipSuccess) { st.host = nullptr; st.cap = 0; return DODA_ERR_NOMEM; }
         }
+        int cur_dev = 0;
+        hipGetDevice(&cur_dev);
+        if (st.ev && st.ev_dev != cur_dev) { hipEventDestroy(st.ev); st.ev = nullptr; }   // library used from another device
         if (!st.ev && hipEventCreateWithFlags(&st.ev, hipEventDisableTiming) != hipSuccess) return DODA_ERR_LAUNCH;
+        st.ev_dev = cur_dev;
         if (wbytes) memcpy(st.host, wj.data(), wbytes);
         if (rbytes) memcpy((char *)st.host + wbytes, rj.data(), rbytes);
         if (pbytes) memcpy((char *)st.host + pair_off, prep.desc.data(), pbytes);

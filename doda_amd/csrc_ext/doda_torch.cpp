@@ -393,6 +393,7 @@ void issue_in_rounds(std::vector<PendingWgrad> &q, const c10::hip::HIPStream &st
 // (channel counts of the weight), so every rank cuts its gradients the same way whatever its batch looks like.
 bool g_wq_split = false, g_ev_early_valid = false;
 hipEvent_t g_ev_early = nullptr;
+int g_ev_early_dev = -1;   // device the event lives on (one training process drives one device; re-made if that changes)
 
 inline bool narrow_weight(const at::Tensor &w) {   // [kD, kH, kW, Cin, Cout]
     return w.dim() == 5 && w.size(3) <= 32 && w.size(4) <= 32;
@@ -408,15 +409,23 @@ void flush_wgrads() {
         g_wq_callback = false;
         g_wq_task = -2;
     }
-    if (!g_wq_split || !st) {
+    if (q.empty() || !st) return;   // nothing queued (or no backward pass has run yet: no stream recorded)
+    if (!g_wq_split) {
         issue_in_rounds(q, *st);
         return;
     }
     std::vector<PendingWgrad> wide, narrow;
     for (PendingWgrad &p : q) (narrow_weight(p.weight) ? narrow : wide).push_back(std::move(p));
     issue_in_rounds(wide, *st);
-    if (!g_ev_early)
+    if (g_ev_early && g_ev_early_dev != (int)st->device_index()) {
+        hipEventDestroy(g_ev_early);
+        g_ev_early = nullptr;
+    }
+    if (!g_ev_early) {
+        c10::hip::HIPGuard dev_guard(st->device_index());
         TORCH_CHECK(hipEventCreateWithFlags(&g_ev_early, hipEventDisableTiming) == hipSuccess, "doda: hipEventCreate");
+        g_ev_early_dev = (int)st->device_index();
+    }
     TORCH_CHECK(hipEventRecord(g_ev_early, st->stream()) == hipSuccess, "doda: hipEventRecord");
     g_ev_early_valid = true;
     issue_in_rounds(narrow, *st);
@@ -466,7 +475,13 @@ struct BNLink {
     bool relu = false;
     c10::weak_intrusive_ptr<c10::TensorImpl> y;   // the BatchNorm's output
     at::Tensor stats;                             // [rows, 2, c] from the conv's data-grad epilogue
-    c10::TensorImpl *dz = nullptr;                // the gradient tensor those statistics belong to
+    // The gradient tensor those statistics belong to, held STRONGLY together with its version counter: with a
+    // second consumer of the BatchNorm output the engine's InputBuffer would otherwise accumulate that
+    // consumer's gradient IN PLACE into this very TensorImpl (use_count 1, GradMode off: old_var.add_(var)) —
+    // same pointer, different values.  The extra reference forces an out-of-place sum (a different tensor), the
+    // version check catches any other in-place edit, and a live reference rules out address reuse.
+    at::Tensor dz;
+    uint32_t dz_version = 0;
     BNLink() : y(c10::weak_intrusive_ptr<c10::TensorImpl>(c10::intrusive_ptr<c10::TensorImpl>())) {}
 };
 thread_local std::shared_ptr<BNLink> g_last_bn;
@@ -502,7 +517,8 @@ struct ConvNode : public torch::autograd::Node {
                             features.size(0), bwd_layout, cin, false, c10::nullopt, &epi);
             if (epi.stats.defined()) {
                 bn->stats = epi.stats;
-                bn->dz = out[0].unsafeGetTensorImpl();
+                bn->dz = out[0];
+                bn->dz_version = out[0]._version();
             }
         }
         if (task_should_compute_output(1) && !try_defer_wgrad(features, dy, fwd_tbl, n_out, weight, pl))
@@ -613,11 +629,13 @@ struct BNNode : public torch::autograd::Node {
         at::Tensor dx, dg, db;
         at::Tensor stats;
         if (link) {
-            if (training && link->stats.defined() && link->dz == grads[0].unsafeGetTensorImpl() && grads[0].is_contiguous() &&
+            if (training && link->stats.defined() && link->dz.defined() &&
+                link->dz.unsafeGetTensorImpl() == grads[0].unsafeGetTensorImpl() &&
+                grads[0]._version() == link->dz_version && grads[0].is_contiguous() &&
                 (!extra.defined() || extra.scalar_type() == x.scalar_type()))
                 stats = link->stats;
             link->stats.reset();
-            link->dz = nullptr;
+            link->dz.reset();
         }
         if (stats.defined()) {
             const int64_t m = x.size(0), c = x.size(1);

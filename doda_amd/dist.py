@@ -17,7 +17,11 @@ def setup(backend=None):
     """Initialise the default process group from the launcher's environment (idempotent).
     Returns (world, rank, local_rank)."""
     world, rank, local_rank = env_world()
-    if world > 1 and not dist.is_initialized():
+    # DODA_DIST_FORCE=1: a launcher-started single rank still joins a process group and runs the collectives
+    # (a 1-rank RCCL communicator executes the same all-reduce / broadcast calls: the way to exercise the
+    # RCCL streams on a one-GPU box)
+    forced = os.environ.get("DODA_DIST_FORCE", "0") == "1" and "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if (world > 1 or forced) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver
         if backend is None:
             backend = os.environ.get("DODA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -84,18 +88,23 @@ class GradAllReduce:
     * reduce(): the FIXED parameter list (a missing gradient counts as zeros, so every rank sends the
       same message sizes whatever its batch touched) is cut into buckets of ~`bucket_mb` MB; bucket k's
       all-reduce (RCCL ring over xGMI, per-link bound) is asynchronous and overlaps the flattening copy
-      of bucket k+1 and the copy-back of bucket k-1.  With world size 1 everything is a no-op."""
+      of bucket k+1 and the copy-back of bucket k-1.  With world size 1 everything is a no-op unless
+      `force` (or DODA_DIST_FORCE=1) asks for the collectives anyway (process group of one rank)."""
 
-    def __init__(self, module, bucket_mb=8.0, broadcast_buffers=True, overlap=True):
+    def __init__(self, module, bucket_mb=8.0, broadcast_buffers=True, overlap=True, force=None):
         self.module = module
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        if force is None:
+            force = os.environ.get("DODA_DIST_FORCE", "0") == "1"
+        # the collectives run when there is someone to talk to, or when forced on an initialised group of one
+        self.active = dist.is_initialized() and (self.world > 1 or bool(force))
         # (overlap) conv weights of the 16- / 32-channel levels: their gradients are the LAST kernels of a step
         # (the pair-list launches of the deferred flush) and 2 of the 30 MB; everything else is reduced on a
         # side stream while those kernels run.  Static rule on the weight shape: identical on every rank.
         self._split = False
         narrow = []
-        if overlap and self.world > 1 and self.params and self.params[0].is_cuda:
+        if overlap and self.active and self.params and self.params[0].is_cuda:
             try:
                 from ._ext import ext as _ext
             except Exception:
@@ -109,7 +118,7 @@ class GradAllReduce:
         narrow_ids = {id(p) for p in narrow} if self._split else set()
         self.buckets = self._cut([p for p in self.params if id(p) not in narrow_ids], bucket_mb)
         self.late_buckets = self._cut([p for p in self.params if id(p) in narrow_ids], bucket_mb)
-        if self.world > 1:
+        if self.active:
             _flat_broadcast(self.params)
             if broadcast_buffers:
                 self.sync_buffers()
@@ -129,7 +138,7 @@ class GradAllReduce:
 
     def sync_buffers(self):
         """Rank 0's buffers (running statistics, batch counters) to every rank."""
-        if self.world > 1:
+        if self.active:
             bufs = [b for b in self.module.buffers() if b is not None and b.numel() > 0]
             if bufs:
                 _flat_broadcast(bufs)
@@ -157,7 +166,7 @@ class GradAllReduce:
 
     def reduce(self):
         """Call between loss.backward() and optimizer.step()."""
-        if self.world == 1:
+        if not self.active:
             return
         main = torch.cuda.current_stream() if self._split else None
         if self._split and self._ext.wait_wide_wgrads(self._side.cuda_stream):

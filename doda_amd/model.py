@@ -272,15 +272,25 @@ class PyramidPrefetcher:
         self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="doda-rulebooks")
         self.stream = torch.cuda.Stream(device=device)
 
-    def submit(self, batch, with_pairs=False, with_tiles=None):
-        """batch: collated dictionary whose `voxel_locs` is resident on the device with no pending producer."""
+    def submit(self, batch, with_pairs=False, with_tiles=None, resident=False):
+        """batch: collated dictionary whose `voxel_locs` is on the device.  Work still queued on the CALLER's
+        current stream that produces it (collate_device returns with doda_voxelize_idx_fill pending) is ordered
+        before the build through an event recorded here; resident=True (a batch that was complete before the
+        call, e.g. bench.py's reused one) skips that event, so the build does not queue behind the step in flight."""
         coords, shape = batch["voxel_locs"], batch["spatial_shape"]
         bs = batch["offsets"].numel() - 1
-        return self.pool.submit(self._build, coords, shape, bs, with_pairs, with_tiles)
+        ready = None
+        if coords.is_cuda and not resident:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+        return self.pool.submit(self._build, coords, shape, bs, with_pairs, with_tiles, ready)
 
-    def _build(self, coords, shape, bs, with_pairs, with_tiles=None):
+    def _build(self, coords, shape, bs, with_pairs, with_tiles=None, ready=None):
         torch.cuda.set_device(self.device)
         with torch.cuda.stream(self.stream):
+            if ready is not None:
+                self.stream.wait_event(ready)
+                coords.record_stream(self.stream)   # read here; the allocator must not recycle it under the build
             idx32 = coords.int()
             probe = spconv.SparseConvTensor(None, idx32, shape, bs)
             spconv.ops.build_pyramid(probe, self.n_levels, with_pairs=with_pairs, with_tiles=with_tiles)

@@ -314,11 +314,15 @@ def spconv_bwd_tile(dy, x, w, tbl, tilebook, packed=None, dw_out=None):
     return dx, dw
 
 
-def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, residual=None, tilebook=None):
+def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, residual=None, tilebook=None,
+                  want_stats=False, bn=None, out=None):
     """y[t] = sum_o x[tbl[o][t]] @ B_o (see doda_hip.h).  x: [n_in,kc] f32|bf16; w: fp32 weights
     viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2), or `packed`: the fragment-packed buffer
     produced by PackPlan for this (weight, layout, dtype).  Returns y [n_out, nc] in x.dtype (or
-    float32 when out_f32); with `residual` ([n_out, nc], dtype of y) returns conv + residual."""
+    float32 when out_f32); with `residual` ([n_out, nc], dtype of y) returns conv + residual.
+    want_stats: returns (y, stats [rows, 2, nc] fp32): the BatchNorm partial sums of the epilogue
+    (doda_conv_epilogue.stats) — (sum y, sum y^2), or with bn = (bn_x, mean, invstd, gamma, beta, relu) the
+    BatchNorm-backward sums of a data-grad call.  out: write into this tensor instead of allocating."""
     _feat_ok(x, "x")
     _need_cuda(tbl)
     K, ld = tbl.shape
@@ -342,16 +346,25 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
         _need_cuda(residual)
         if residual.dtype != ydt or tuple(residual.shape) != (n_out, nc) or not residual.is_contiguous():
             raise RuntimeError("residual must be a contiguous [n_out, nc] tensor in the output dtype")
-    if tilebook is not None:   # epilogue-struct entry point: the tilebook rides in doda_conv_epilogue
-        y = torch.empty((n_out, nc), dtype=ydt, device=x.device)
+    if tilebook is not None or want_stats or out is not None:   # epilogue-struct entry point
+        y = out if out is not None else torch.empty((n_out, nc), dtype=ydt, device=x.device)
         ep = _ConvEpilogue()
         ep.residual = _p(residual) if residual is not None else None
-        ep.tilebook = _p(tilebook)
-        ep.tilebook_rows = int(getattr(tilebook, "_doda_rows", n_out))
+        if tilebook is not None:
+            ep.tilebook = _p(tilebook)
+            ep.tilebook_rows = int(getattr(tilebook, "_doda_rows", n_out))
+        stats, rows = None, C.c_int32(0)
+        if want_stats:
+            stats = torch.empty((int(lib().doda_spconv_stats_capacity(n_out)), 2, nc), dtype=torch.float32, device=x.device)
+            ep.stats, ep.stats_rows_h = _p(stats), C.pointer(rows)
+            if bn is not None:
+                bx, mean, invstd, gamma, beta, relu = bn
+                ep.bn_x, ep.bn_mean, ep.bn_invstd, ep.bn_gamma, ep.bn_beta = _p(bx), _p(mean), _p(invstd), _p(gamma), _p(beta)
+                ep.bn_relu = int(bool(relu))
         check(lib().doda_spconv_gather_ex(_p(x), x.shape[0], kc, esz, w_ptr, nc, _p(tbl), ld, K, n_out, _p(y),
                                           int(bool(out_f32)), layout, ws_ptr, ws_n, C.byref(ep), _stream()),
               "doda_spconv_gather_ex")
-        return y
+        return (y, stats[:rows.value]) if want_stats else y
     if x.dtype == torch.float32:
         y = torch.empty((n_out, nc), dtype=torch.float32, device=x.device)
         if residual is None:

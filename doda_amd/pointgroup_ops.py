@@ -1,138 +1,104 @@
-"""Host-side mirror of DODA's pointgroup_ops wrapper module
-(reference lib/pointgroup_ops/functions/pointgroup_ops.py): same function names, argument order,
-return values and error behaviour for the entry points on DODA's hot path, over doda_amd.pg_op.
+"""The five entry points DODA imports from `lib.pointgroup_ops.functions.pointgroup_ops`
+(reference lib/pointgroup_ops/functions/pointgroup_ops.py:13-153), as plain functions over doda_amd.ops.
 
-    voxelization_idx(coords, batchsize, mode=4) -> (output_coords, input_map, output_map)
-    voxelization(feats, map_rule, mode=4)       -> output_feats           (differentiable)
-    point_recover(feats, map_rule, nPoint)      -> output_feats           (differentiable)
-    ballquery_batch_p(coords, batch_idxs, batch_offsets, radius, meanActive) -> (idx, start_len)
-    knn(xyz, query_xyz, batch_idxs, query_batch_offsets, k) -> idx
+    voxelization_idx(coords, batchsize, mode=4)  -> (voxel_coords int64 [M,ncol], p2v int32 [N], v2p int32 [M,1+maxActive])
+    voxelization(feats, map_rule, mode=4)         -> [M,C]      differentiable w.r.t. feats
+    point_recover(feats, map_rule, nPoint)        -> [nPoint,C] differentiable w.r.t. feats
+    ballquery_batch_p(coords, batch_idxs, batch_offsets, radius, meanActive) -> (idx int32 [total], start_len int32 [n,2])
+    knn(xyz, query_xyz, batch_idxs, query_batch_offsets, k) -> idx int32 [n,k]
+
+Names, positional argument order, dtypes and return tuples are the reference's (its callers: dataset/dataset.py:182,
+model/unet.py:88, model/unet.py:136-141); the bodies are this repository's.  The two differentiable ops are ONE
+autograd function: pooling rows of `feats` through a voxel->point map and spreading voxel rows back to points are
+transposes of each other, so each one's backward is the other's forward kernel.
 """
 import torch
 from torch.autograd import Function
 
-from . import pg_op as PG_OP
+from . import ops as _ops
+
+# kernel pairs (forward, backward) per direction; all four take (src, dst_zeroed, map, [mode,] M, maxActive, C)
+_POOL, _SPREAD = 0, 1
 
 
-class Voxelization_Idx(Function):
-    """pointgroup_ops.py:13-42.  coords: int64 (N, 3|4), contiguous; CPU in DODA's collate
-    (dataset/dataset.py:182), device tensors take the HIP path."""
-
-    @staticmethod
-    def forward(ctx, coords, batchsize, mode=4):
-        assert coords.is_contiguous()
-        n = coords.size(0)
-        output_coords = coords.new_empty(0)
-        input_map = torch.zeros(n, dtype=torch.int32, device=coords.device)
-        output_map = input_map.new_empty(0)
-        PG_OP.voxelize_idx(coords, output_coords, input_map, output_map, batchsize, mode)
-        return output_coords, input_map, output_map
-
-    @staticmethod
-    def backward(ctx, a=None, b=None, c=None):
-        return None
+def _launch(direction, backward, src, dst, rules, mode):
+    m, width = rules.shape
+    c = src.shape[1]
+    if direction == _POOL:
+        (_ops.voxelize_bp if backward else _ops.voxelize_fp)(src, dst, rules, mode, m, width - 1, c)
+    else:
+        (_ops.point_recover_bp if backward else _ops.point_recover_fp)(src, dst, rules, m, width - 1, c)
 
 
-voxelization_idx = Voxelization_Idx.apply
-
-
-class Voxelization(Function):
-    """pointgroup_ops.py:44-77: feats (N,C) float32 device, map_rule (M,1+maxActive) int32."""
+class _MapRows(Function):
+    """dst = A(src) with A the row map of `rules` (pool: points -> voxels with mode 3 sum / 4 mean; spread:
+    voxels -> points); backward applies A^T through the partner kernel."""
 
     @staticmethod
-    def forward(ctx, feats, map_rule, mode=4):
-        assert map_rule.is_contiguous()
-        assert feats.is_contiguous()
-        n, c = feats.size()
-        m = map_rule.size(0)
-        max_active = map_rule.size(1) - 1
-        output_feats = torch.zeros((m, c), dtype=torch.float32, device=feats.device)
-        ctx.for_backwards = (map_rule, mode, max_active, n)
-        PG_OP.voxelize_fp(feats, output_feats, map_rule, mode, m, max_active, c)
-        return output_feats
+    def forward(ctx, src, rules, direction, mode, n_dst):
+        if not (src.is_contiguous() and rules.is_contiguous()):
+            raise AssertionError("pointgroup_ops: feats and map_rule must be contiguous")   # reference asserts
+        dst = src.new_zeros((n_dst, src.shape[1]), dtype=torch.float32)
+        _launch(direction, False, src, dst, rules, mode)
+        ctx.rules, ctx.key, ctx.n_src = rules, (direction, mode), src.shape[0]
+        return dst
 
     @staticmethod
-    def backward(ctx, d_output_feats):
-        map_rule, mode, max_active, n = ctx.for_backwards
-        m, c = d_output_feats.size()
-        d_feats = torch.zeros((n, c), dtype=torch.float32, device=d_output_feats.device)
-        PG_OP.voxelize_bp(d_output_feats.contiguous(), d_feats, map_rule, mode, m, max_active, c)
-        return d_feats, None, None
+    def backward(ctx, d_dst):
+        direction, mode = ctx.key
+        d_src = d_dst.new_zeros((ctx.n_src, d_dst.shape[1]), dtype=torch.float32)
+        _launch(direction, True, d_dst.contiguous(), d_src, ctx.rules, mode)
+        return d_src, None, None, None, None
 
 
-voxelization = Voxelization.apply
+def voxelization(feats, map_rule, mode=4):
+    """Voxel features = sum (mode 3) / mean (mode 4) of the voxel's points; map_rule = v2p_map."""
+    return _MapRows.apply(feats, map_rule, _POOL, mode, map_rule.shape[0])
 
 
-class PointRecover(Function):
-    """pointgroup_ops.py:80-117: voxel feats (M,C) -> point feats (nPoint,C)."""
-
-    @staticmethod
-    def forward(ctx, feats, map_rule, nPoint):
-        assert map_rule.is_contiguous()
-        assert feats.is_contiguous()
-        m, c = feats.size()
-        max_active = map_rule.size(1) - 1
-        output_feats = torch.zeros((nPoint, c), dtype=torch.float32, device=feats.device)
-        ctx.for_backwards = (map_rule, max_active, m)
-        PG_OP.point_recover_fp(feats, output_feats, map_rule, m, max_active, c)
-        return output_feats
-
-    @staticmethod
-    def backward(ctx, d_output_feats):
-        map_rule, max_active, m = ctx.for_backwards
-        n, c = d_output_feats.size()
-        d_feats = torch.zeros((m, c), dtype=torch.float32, device=d_output_feats.device)
-        PG_OP.point_recover_bp(d_output_feats.contiguous(), d_feats, map_rule, m, max_active, c)
-        return d_feats, None, None
+def point_recover(feats, map_rule, nPoint):
+    """Voxel features copied back to the voxel's points."""
+    return _MapRows.apply(feats, map_rule, _SPREAD, 4, int(nPoint))
 
 
-point_recover = PointRecover.apply
+@torch.no_grad()
+def voxelization_idx(coords, batchsize, mode=4):
+    """coords int64 [N, 3|4] (batch index first when 4 columns).  CPU tensors take the fork-safe host path (this is
+    what DataLoader workers call), device tensors the HIP path."""
+    if not coords.is_contiguous():
+        raise AssertionError("voxelization_idx: coords must be contiguous")
+    build = _ops.voxelize_idx_device if coords.is_cuda else _ops.voxelize_idx_host
+    voxel_coords, p2v, v2p = build(coords, batchsize, mode)
+    return voxel_coords, p2v, v2p
 
 
-class BallQueryBatchP(Function):
-    """pointgroup_ops.py:120-153, including the grow-and-retry loop on meanActive."""
-
-    @staticmethod
-    def forward(ctx, coords, batch_idxs, batch_offsets, radius, meanActive):
-        n = coords.size(0)
-        assert coords.is_contiguous() and coords.is_cuda
-        assert batch_idxs.is_contiguous() and batch_idxs.is_cuda
-        assert batch_offsets.is_contiguous() and batch_offsets.is_cuda
-        while True:
-            idx = torch.zeros(n * meanActive, dtype=torch.int32, device=coords.device)
-            start_len = torch.zeros((n, 2), dtype=torch.int32, device=coords.device)
-            n_active = PG_OP.ballquery_batch_p(coords, batch_idxs, batch_offsets, idx, start_len, n,
-                                               meanActive, radius)
-            if n_active <= n * meanActive:
-                break
-            meanActive = int(n_active // n + 1)
-        return idx[:n_active], start_len
-
-    @staticmethod
-    def backward(ctx, a=None, b=None):
-        return None, None, None
+@torch.no_grad()
+def ballquery_batch_p(coords, batch_idxs, batch_offsets, radius, meanActive):
+    """Neighbours within `radius` inside each batch item, packed; start_len[i] = (offset, count).  The packed
+    buffer holds n * meanActive entries; when the kernel reports more, it is re-sized to fit and the query repeated
+    (the reference's contract: pointgroup_ops.py:137-144)."""
+    for t in (coords, batch_idxs, batch_offsets):
+        if not (t.is_cuda and t.is_contiguous()):
+            raise AssertionError("ballquery_batch_p: device-resident contiguous tensors expected")
+    n = coords.shape[0]
+    cap = int(meanActive)
+    total = None
+    while total is None or total > n * cap:
+        if total is not None:
+            cap = total // n + 1
+        idx = torch.zeros(n * cap, dtype=torch.int32, device=coords.device)
+        start_len = torch.zeros((n, 2), dtype=torch.int32, device=coords.device)
+        total = int(_ops.ballquery_batch_p(coords, batch_idxs, batch_offsets, idx, start_len, n, cap, radius))
+    return idx[:total], start_len
 
 
-ballquery_batch_p = BallQueryBatchP.apply
-
-
-class KNN(Function):
-    """k nearest points of query_xyz (same batch item) for every point of xyz; k <= 40."""
-
-    @staticmethod
-    def forward(ctx, xyz, query_xyz, batch_idxs, query_batch_offsets, k):
-        n, m = xyz.size(0), query_xyz.size(0)
-        assert xyz.is_contiguous() and xyz.is_cuda
-        assert query_xyz.is_contiguous() and query_xyz.is_cuda
-        assert batch_idxs.is_contiguous() and batch_idxs.is_cuda
-        assert query_batch_offsets.is_contiguous() and query_batch_offsets.is_cuda
-        idx = torch.zeros((n, k), dtype=torch.int32, device=xyz.device)
-        PG_OP.knn_batch(xyz, query_xyz, batch_idxs, query_batch_offsets, idx, n, m, k)
-        return idx
-
-    @staticmethod
-    def backward(ctx, a=None):
-        return None, None, None, None, None
-
-
-knn = KNN.apply
+@torch.no_grad()
+def knn(xyz, query_xyz, batch_idxs, query_batch_offsets, k):
+    """For every point of `xyz`: its k nearest points of `query_xyz` in the same batch item (k <= 40)."""
+    for t in (xyz, query_xyz, batch_idxs, query_batch_offsets):
+        if not (t.is_cuda and t.is_contiguous()):
+            raise AssertionError("knn: device-resident contiguous tensors expected")
+    n, m = xyz.shape[0], query_xyz.shape[0]
+    idx = torch.zeros((n, k), dtype=torch.int32, device=xyz.device)
+    _ops.knn_batch(xyz, query_xyz, batch_idxs, query_batch_offsets, idx, n, m, k)
+    return idx

@@ -1,10 +1,12 @@
 """Synthetic ScanNet-shaped scenes and the batch contract of DODA's collate.
 
 Generator (SURVEY §8d / BASELINE.md §3): a box room (floor + 4 walls) with axis-aligned furniture
-boxes (5 faces each), points on a regular 1.75 cm lattice per surface (mesh-vertex-like, see
-_sample), centred, random rotation about z, +-5 mm jitter, then scaled by `voxel_scale` (50 = 2 cm), shifted to the positive octant and truncated to
-integers — the same coordinate pipeline as reference dataset/scannet.py:76-78.  The room size is
-bisected so the scene has `target_voxels` active voxels (+-2 %); N ~= pts_per_voxel * M.
+boxes (5 faces each), points on a dense regular lattice per surface thinned to ~1.3 points per voxel
+(mesh-vertex-like, see _sample / make_scene), centred, random rotation about z, +-5 mm jitter, then scaled by
+`voxel_scale` (50 = 2 cm), shifted to the positive octant and truncated to integers — the same coordinate
+pipeline as reference dataset/scannet.py:76-78.  The room size is searched so the scene has `target_voxels`
+active voxels (+-2 %); N ~= pts_per_voxel * M; 11.4-12.1 occupied 27-neighbours per voxel and a 4.0-4.5x
+population drop per stride-2 level, as the SURVEY 8d probe measured.
 Scene s of a batch seeded `seed` uses seed + s.
 
 make_batch() reproduces the dictionary of reference dataset/dataset.py:121-187 (collate_fn):
@@ -41,15 +43,20 @@ def _surfaces(rng, scale):
     return surf
 
 
+OVERSAMPLE = 3.0   # lattice density of the surface sampling relative to the points that are kept (see make_scene)
+
+
 def _sample(seed, scale, voxel_scale, pts_per_voxel):
-    """Mesh-vertex-like sampling: every surface carries a regular lattice of points with pitch
-    1/(voxel_scale*sqrt(pts_per_voxel)) (1.75 cm at 2 cm voxels, 1.3 pts/voxel), in raster order,
-    so surfaces are densely covered the way a reconstructed ScanNet mesh is (N ~= 1.3 M with
-    ~11-12 occupied 27-neighbours per voxel and a ~4x population drop per stride-2 level) —
-    i.i.d. uniform samples at the same N leave half of the surface voxels empty."""
+    """Mesh-vertex-like sampling: every surface carries a regular lattice of points in raster order, dense
+    enough (pitch 1/(voxel_scale*sqrt(OVERSAMPLE*pts_per_voxel)): ~1 cm at 2 cm voxels) that every voxel a
+    surface passes through is hit, including the ones it only clips — those are what give a scanned surface its
+    11-12 occupied 27-neighbours per voxel (SURVEY 8d probe).  make_scene thins the points back to
+    `pts_per_voxel` per voxel without emptying any voxel.  (A lattice at 1.3 points per voxel directly, the
+    round-1/2 generator, left the clipped voxels empty: 9.7 neighbours per voxel; i.i.d. uniform samples at the
+    same N leave half of the surface voxels empty.)"""
     rng = np.random.default_rng(seed)
     surf = _surfaces(rng, scale)
-    pitch = 1.0 / (voxel_scale * np.sqrt(pts_per_voxel))
+    pitch = 1.0 / (voxel_scale * np.sqrt(pts_per_voxel * OVERSAMPLE))
     pts, labels = [], []
     for (o, u, v, lab) in surf:
         lu, lv = np.linalg.norm(u), np.linalg.norm(v)
@@ -78,21 +85,33 @@ def _count_voxels(xyz, voxel_scale):
 
 def make_scene(seed, target_voxels=150000, voxel_scale=50, pts_per_voxel=1.3):
     """-> (xyz int64 [N,3] voxel coords, xyz_mid float32 [N,3] metres centred, labels int64 [N])."""
-    lo, hi = 0.05, 8.0
-    scale = None
-    for _ in range(40):
-        scale = 0.5 * (lo + hi)
+    # the voxel count of a surface scene grows with the square of the room scale: a secant step on sqrt(M)
+    # lands within 2 % in two or three samplings (bisection needed ~12, each over a few million lattice points)
+    scale = float(np.sqrt(target_voxels / 190000.0)) * 50.0 / voxel_scale
+    lo, hi = 0.0, float("inf")
+    for _ in range(20):
         xyz_mid, labels = _sample(seed, scale, voxel_scale, pts_per_voxel)
         m = _count_voxels(xyz_mid, voxel_scale)
         if abs(m - target_voxels) <= 0.02 * target_voxels:
             break
-        if m < target_voxels:
-            lo = scale
-        else:
-            hi = scale
+        lo, hi = (max(lo, scale), hi) if m < target_voxels else (lo, min(hi, scale))
+        nxt = scale * float(np.sqrt(target_voxels / max(m, 1)))
+        if not (lo < nxt < hi):   # the secant step left the bracket (tiny scenes: the count is not smooth)
+            nxt = 0.5 * (lo + hi) if np.isfinite(hi) else 2.0 * scale
+        scale = nxt
     xyz = xyz_mid.astype(np.float64) * voxel_scale
     xyz -= xyz.min(0)
-    return xyz.astype(np.int64), xyz_mid, labels
+    xyz = xyz.astype(np.int64)
+    # thin the dense lattice to ~pts_per_voxel points per voxel (ScanNet-like multiplicity, SURVEY 8d) keeping
+    # every voxel occupied: the first point of each voxel stays, the others with one common probability;
+    # raster order is preserved
+    key = (xyz[:, 0] * 4096 + xyz[:, 1]) * 4096 + xyz[:, 2]
+    _, first = np.unique(key, return_index=True)
+    keep = np.zeros(xyz.shape[0], dtype=bool)
+    keep[first] = True
+    extra = max(0.0, (pts_per_voxel - 1.0) * first.size) / max(xyz.shape[0] - first.size, 1)
+    keep |= np.random.default_rng(seed ^ 0x5eed).random(xyz.shape[0]) < extra
+    return xyz[keep], xyz_mid[keep], labels[keep]
 
 
 def make_batch(n_scenes=4, target_voxels=150000, seed=1000, voxel_scale=50, full_scale=(128, 512),

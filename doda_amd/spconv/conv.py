@@ -273,7 +273,7 @@ class SparseConvolution(SparseModule):
             out.indice_dict = input.indice_dict
             out.grid = input.grid
             if stats is not None:
-                out._doda_stats = (out_features, stats)
+                out._doda_stats = (out_features, stats, out_features._version)
             return out
 
         weight, packed = self.weight, None
@@ -327,7 +327,9 @@ class SparseConvolution(SparseModule):
         out.indice_dict = input.indice_dict
         out.grid = input.grid
         if stats is not None:   # (sum y, sum y^2) partials for a fused BatchNorm applied to exactly these features
-            out._doda_stats = (out_features, stats)
+            # (... and to exactly this VERSION of them: `output.features += skip` of the reference's residual
+            # block, model/unet_block.py:36, edits the same tensor object in place)
+            out._doda_stats = (out_features, stats, out_features._version)
         return out
 
 

@@ -97,7 +97,10 @@ class SparseSequential(SparseModule):
                         # features came out of a conv that accumulated their statistics, those are used
                         relu = k < len(mods) and type(mods[k]) is nn.ReLU
                         st = input.__dict__.get("_doda_stats")
-                        stats = st[1] if (st is not None and st[0] is input.features) else None
+                        # the statistics belong to one tensor object AND one version of it: an in-place edit
+                        # (`output.features += ...`, reference model/unet_block.py:36) keeps the object
+                        feats = input.features
+                        stats = st[1] if (st is not None and st[0] is feats and st[2] == feats._version) else None
                         if take_input and k == 1 and module.training:
                             input.features, residual = _dnn.batch_norm_relu(input.features, module, relu, True, stats)
                         else:

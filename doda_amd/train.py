@@ -207,15 +207,23 @@ class DeviceMeters:
 
     @torch.no_grad()
     def update(self, loss, preds, labels):
-        valid = labels != self.ignore
-        p, t = preds[valid], labels[valid]
-        inter = torch.bincount(t[p == t], minlength=self.k)[:self.k]
-        area_p = torch.bincount(p, minlength=self.k)[:self.k]
-        area_t = torch.bincount(t, minlength=self.k)[:self.k]
+        """No host synchronisation: every shape below is fixed (boolean-mask indexing and bincount would each
+        read a size back).  Ignored / out-of-range labels fall into an extra bin k that is dropped."""
+        k = self.k
+        valid = (labels != self.ignore) & (labels >= 0) & (labels < k)
+        t = torch.where(valid, labels, k)
+        p = torch.where(valid, preds.clamp(0, k - 1), k)
+        hit = torch.where(p == t, t, k)
+        ones = torch.ones_like(t)
+        cnt = torch.zeros(3, k + 1, dtype=torch.int64, device=t.device)
+        cnt[0].scatter_add_(0, hit, ones)
+        cnt[1].scatter_add_(0, p, ones)
+        cnt[2].scatter_add_(0, t, ones)
+        inter, area_p, area_t = cnt[0, :k], cnt[1, :k], cnt[2, :k]
         self.hist += torch.stack((inter, area_p + area_t - inter, area_t)).to(torch.float64)
-        n = labels.shape[0]
-        self.loss += torch.stack((loss.detach().double() * n, torch.tensor(float(n), dtype=torch.float64,
-                                                                            device=loss.device)))
+        n = float(labels.shape[0])
+        self.loss[0] += loss.detach().double() * n
+        self.loss[1] += n
 
     def all_reduce(self):
         import torch.distributed as dist
@@ -260,10 +268,13 @@ class Trainer:
         from .model import PyramidPrefetcher, SparseConvNet
         from .spconv import functional as Fsp
         self.args, self.cfg, self.device, self.rank, self.world, self.log = args, cfg, device, rank, world, log
-        if args.sync_bn:
-            raise NotImplementedError("--sync_bn: BatchNorm statistics are rank-local on this path (reference default)")
         model = SparseConvNet(cfg)
-        if cfg.MODEL.get("dsnorm", False):
+        if args.sync_bn:
+            # tool/train.py:329-330, literally: torch's SyncBatchNorm (statistics all-gathered over the process
+            # group, RCCL on GPUs).  It is not nn.BatchNorm1d, so SparseSequential applies it as a plain module:
+            # torch's kernels, no conv-epilogue statistics.  As in the reference it takes precedence over DSNorm.
+            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        elif cfg.MODEL.get("dsnorm", False):
             model = DSNorm.convert_dsnorm(model)
         self.model = model.to(device)
         self.fdt = torch.float32 if args.dtype == "f32" else torch.bfloat16

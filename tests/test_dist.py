@@ -108,3 +108,36 @@ def test_grad_allreduce_world2_gloo():
     want = [(a + b) / 2 for a, b in zip(g_a, g_b)]
     assert max(abs(x - y) for x, y in zip(avg_a, want)) < 1e-6
     assert avg_a == avg_b
+
+
+def _forced_single_rank_worker(port, q):
+    os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      DODA_DIST_FORCE="1", DODA_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from doda_amd import dist as ddist
+    assert ddist.setup() == (1, 0, 0) and dist.is_initialized() and dist.get_world_size() == 1
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    red = ddist.GradAllReduce(net, bucket_mb=1e-4)        # several buckets
+    assert red.active and len(red.buckets) > 1
+    net(torch.randn(4, 6)).square().sum().backward()
+    net[2].bias.grad = None                                # a missing gradient travels as zeros and comes back as zeros
+    local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+    red.reduce()
+    same = all(torch.equal(p.grad, g) if g is not None else bool((p.grad == 0).all())
+               for p, g in zip(net.parameters(), local))
+    q.put(same)
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_on_a_group_of_one():
+    """DODA_DIST_FORCE=1: a single launcher-started rank joins a process group and GradAllReduce runs its
+    bucketed all-reduces anyway (how the RCCL path is exercised on a one-GPU box, tests/test_gpu_round3.py);
+    the average over one rank is the gradient itself."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_single_rank_worker, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=120) is True
+    p.join(60)
+    assert p.exitcode == 0
