@@ -68,6 +68,14 @@ int launch_conv_tile(int mode, bool out32, const void *x, unsigned x_bytes, cons
 void pack_pair_layout2(const float *w, void *out, hipStream_t s);   // defined next to the pack kernels
 }  // namespace doda_tile
 
+namespace doda_dma {
+bool enabled();
+void set_enabled(bool on);
+// bf16 16 -> 16, K = 27 over a tilebook: one persistent workgroup per CU fed by LDS-DMA (spconv_dma.hip); wp = pair-packed
+int launch_conv16(const void *x, unsigned x_bytes, const void *wp, unsigned wp_bytes, const int32_t *tbl, int ld, int n_out,
+                  const void *tilebook, void *y, unsigned y_bytes, const void *res, const EpiArgs &ep, int *n_part, hipStream_t s);
+}  // namespace doda_dma
+
 namespace doda_wlds {
 bool enabled();
 void set_enabled(bool on);

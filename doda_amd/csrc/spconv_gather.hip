@@ -880,6 +880,9 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
         if (tmode >= 0 && tilebook && K == TB_K && tilebook_rows == n_out && doda_tile::enabled()) {
             const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
             const unsigned yb = (unsigned)((size_t)n_out * nc * (out32 ? 4 : sizeof(elem)));
+            // 16 -> 16 with bf16 outputs (the level-1 block convolutions, both directions): the LDS-DMA pipeline
+            if (tmode == 0 && !out32 && nc == 16 && doda_dma::enabled())
+                return doda_dma::launch_conv16(x_, xb, wp, (unsigned)need, tbl, ld, n_out, tilebook, y_, yb, res, ep, n_part, s);
             return doda_tile::launch_conv_tile(tmode, out32 || sizeof(elem) == 4, x_, xb, wp, (unsigned)need, nc, NB, tbl, ld,
                                                n_out, tilebook, y_, yb, res, ep, n_part, s);
         }

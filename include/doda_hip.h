@@ -281,6 +281,9 @@ void doda_spconv_set_tile_kernel(int32_t on);
 /* A/B switch: 0 = the 48 -> 48 channel layers stay on the streaming-weights kernel instead of the weights-in-LDS
  * one.  Default 1. */
 void doda_spconv_set_wlds_kernel(int32_t on);
+/* A/B switch: 0 = the bf16 16 -> 16 layers with a tilebook stay on the three-workgroups-per-CU tile kernel instead of
+ * the one-workgroup-per-CU LDS-DMA pipeline (spconv_dma.hip).  Default 1. */
+void doda_spconv_set_dma_kernel(int32_t on);
 size_t doda_spconv_stats_capacity(int32_t n_out);
 int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, int32_t elem_bytes, const float *w,
                           int32_t nc, const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, void *y,
