@@ -150,11 +150,16 @@ def _subm16_times(idx, shape, nb, dtype, reps):
                           bn=(st.x, mean, invstd, gamma, beta, True) if step else None)
 
     n_layers = 8   # the 16 -> 16 block convolutions of level 1 share the rulebook and one multi-layer call
-    jobs_warm = [(sets[0].x, sets[0].gy, sets[0].tbl, m, sets[0].pairs) if use_pairs else
-                 (sets[0].x, sets[0].gy, sets[0].tbl, m) for _ in range(n_layers)]
-    jobs_cold = [(sets[j % n_sets].x, sets[j % n_sets].gy, sets[j % n_sets].tbl, m, sets[j % n_sets].pairs) if use_pairs else
-                 (sets[j % n_sets].x, sets[j % n_sets].gy, sets[j % n_sets].tbl, m) for j in range(n_layers)]
-    wg_kernel = "wgrad_pairs_kernel<1,1> (pair lists)" if use_pairs else "wgrad_multi_kernel (gather table)"
+    # (a job carries the rulebook's pair lists AND its tilebook, as the model's deferred queue does; the library picks
+    # the LDS-staged tile kernel when it is enabled, else the pair-list kernel)
+    use_wtile = use_tile and os.environ.get("DODA_NO_WDMA", "0") != "1"
+
+    def job(st):
+        return (st.x, st.gy, st.tbl, m, st.pairs if use_pairs else None, None, st.tb if use_wtile else None)
+    jobs_warm = [job(sets[0]) for _ in range(n_layers)]
+    jobs_cold = [job(sets[j % n_sets]) for j in range(n_layers)]
+    wg_kernel = ("wgrad_dma16 (LDS-staged over the tilebook)" if use_wtile else
+                 "wgrad_pairs_kernel<1,1> (pair lists)" if use_pairs else "wgrad_multi_kernel (gather table)")
 
     t = {}
     for name, fn in (("fwd", fwd), ("dgrad", dgrad)):

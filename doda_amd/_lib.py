@@ -80,6 +80,7 @@ _SIGNATURES = {
     "doda_spconv_set_tile_kernel": (None, [c_i32]),
     "doda_spconv_set_wlds_kernel": (None, [c_i32]),
     "doda_spconv_set_dma_kernel": (None, [c_i32]),
+    "doda_spconv_set_wdma_kernel": (None, [c_i32]),
     "doda_spconv_bwd_tile_workspace_bytes": (c_sz, []),
     "doda_spconv_bwd_tile_bf16": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp,
                                           c_sz, c_vp, c_vp]),
@@ -106,7 +107,7 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-ABI_VERSION = 3   # include/doda_hip.h DODA_ABI_VERSION
+ABI_VERSION = 4   # include/doda_hip.h DODA_ABI_VERSION
 
 _lib = None
 

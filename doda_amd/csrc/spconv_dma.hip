@@ -27,6 +27,7 @@
 #include "common.hpp"
 #include "tilebook.hpp"
 #include "spconv_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -39,7 +40,6 @@ constexpr int DM_NBUF = 3;
 constexpr int DM_ROW_PIECES = DM_CAP * 2 / 64 / DM_WAVES;     // DMA instructions per wave and tile: rows (4)
 constexpr int DM_LIDX_PIECES = DM_LIDX_BYTES / 1024 / DM_WAVES;   // index strip (2)
 constexpr int DM_NG = DM_ROW_PIECES + DM_LIDX_PIECES;
-constexpr int DM_NL = DM_ROW_PIECES + 1;              // list registers + the tile's count
 static_assert(DM_ROW_PIECES * 64 * DM_WAVES == DM_CAP * 2 && DM_LIDX_PIECES * 1024 * DM_WAVES == DM_LIDX_BYTES, "uniform DMA counts");
 static_assert(DM_BUF_BYTES % 16 == 0, "buffers stay 16-byte aligned");
 
@@ -64,26 +64,36 @@ __device__ __forceinline__ void dma16(unsigned lds_base, unsigned voff, const u3
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_base), "v"(voff), "s"(rs) : "memory");
 }
-__device__ __forceinline__ void aload32(unsigned &dst, unsigned voff, const u32x4 &rs) {
-    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory");
-}
 __device__ __forceinline__ void aload64(u32x2 &dst, unsigned voff, const u32x4 &rs) {
     asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory");
 }
 
-struct DmList { unsigned rid[DM_ROW_PIECES]; unsigned ucount; };   // list entries of this lane's DMA pieces
-struct DmEpi { u32x2 res[2], bnx[2]; };                            // epilogue operands: four bf16 channels of two rows
-
-// wait until at most N vector-memory operations are outstanding, and tie the registers the landed loads wrote to
-// this point (their uses must not be scheduled above the wait)
-template <int N>
-__device__ __forceinline__ void dm_wait(DmList &l, DmEpi &e) {
-    asm volatile("s_waitcnt vmcnt(%9)"
-                 : "+v"(l.rid[0]), "+v"(l.rid[1]), "+v"(l.rid[2]), "+v"(l.rid[3]), "+v"(l.ucount),
-                   "+v"(e.res[0]), "+v"(e.res[1]), "+v"(e.bnx[0]), "+v"(e.bnx[1])
-                 : "n"(N) : "memory");
+// counted stores are asm as well: hipcc merged two identical placeholder stores into one, which shifts every
+// hand-counted wait by one
+__device__ __forceinline__ void astore64(const u32x2 &v, unsigned voff, const u32x4 &rs) {
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" : : "v"(v), "v"(voff), "s"(rs) : "memory");
 }
-static_assert(DM_ROW_PIECES == 4, "dm_wait names four list registers");
+__device__ __forceinline__ void astore128(const u32x4 &v, unsigned voff, const u32x4 &rs) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(v), "v"(voff), "s"(rs) : "memory");
+}
+
+struct DmList { u32x4 rid; };                 // list entries of this lane's four row pieces (one 16-byte load)
+struct DmEpi { u32x2 res[2], bnx[2]; };       // epilogue operands: four bf16 channels of two rows
+
+__device__ __forceinline__ void aload128(u32x4 &dst, unsigned voff, const u32x4 &rs) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory");
+}
+
+// wait until at most N vector-memory operations are outstanding (no register operands: see dm_tie)
+template <int N>
+__device__ __forceinline__ void dm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+// tie the registers the landed loads wrote to this point: their uses must not be scheduled above the wait that
+// precedes this statement (volatile asm statements keep their order)
+__device__ __forceinline__ void dm_tie(DmList &l, DmEpi &e) {
+    asm volatile("" : "+v"(l.rid), "+v"(e.res[0]), "+v"(e.res[1]), "+v"(e.bnx[0]), "+v"(e.bnx[1]) : : "memory");
+}
 
 __device__ __forceinline__ void dm_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -94,16 +104,22 @@ __device__ __forceinline__ f32x4 dm_unpack(const u32x2 &v) {
                    __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
 }
 
+// Vector-memory instructions of one wave and iteration i, in issue order (all counted by vmcnt, which retires in order):
+//     D(i+2)  DM_NG  DMA pieces of tile i+2 (rows of list(i+2), index strip), spread over the multiply loop of tile i
+//     LE_i    1+N_E  list(i+4) and the epilogue operands of tile i+2            -> registers
+//     S(i)    N_S    stores of tile i
+// At the top of iteration i the wave needs D(i), list(i+2) and operands(i) — all issued in iteration i-2 — and may
+// leave everything younger in flight: S(i-2), D(i+1), LE_{i-1}, S(i-1)  ->  s_waitcnt vmcnt(2 N_S + DM_NG + 1 + N_E).
 template <bool STATS>
 __global__ __launch_bounds__(512) void conv_dma16(const void *__restrict__ x, unsigned x_bytes,
                                                   const void *__restrict__ wp, unsigned wp_bytes,
                                                   const int32_t *__restrict__ tbl, int ld, int n_out,
                                                   const TileBookView tb, void *__restrict__ y, unsigned y_bytes,
-                                                  const void *__restrict__ res, const EpiArgs ep) {
+                                                  const void *__restrict__ res, const EpiArgs ep, const int dbg) {
     constexpr int NU = (TB_K + 1) / 2;
     constexpr int N_E = STATS ? 4 : 2;                 // epilogue operand loads per wave and tile
     constexpr int N_S = STATS ? 4 : 2;                 // stores per wave and tile
-    constexpr int N_LE = DM_NL + N_E;
+    constexpr int N_WAIT = 2 * N_S + DM_NG + 1 + N_E;
     __shared__ __attribute__((aligned(16))) unsigned char smem[DM_NBUF * DM_BUF_BYTES];
     __shared__ f32x4 sred[STATS ? DM_WAVES : 1][2][4];
 
@@ -112,12 +128,10 @@ __global__ __launch_bounds__(512) void conv_dma16(const void *__restrict__ x, un
     const u32x4 rs_x = dm_rsrc(x, x_bytes);
     const u32x4 rs_ul = dm_rsrc(tb.ulist, (unsigned)tb.nt * (unsigned)TB_UMAX * 4u);
     const u32x4 rs_li = dm_rsrc(tb.lidx, (unsigned)tb.nt * (unsigned)(TB_K * TB_T * 2));
-    const u32x4 rs_uc = dm_rsrc(tb.ucount, (unsigned)tb.nt * 4u);
     const u32x4 rs_res = dm_rsrc(res, res ? y_bytes : 0u);                 // absent operand: every offset out of range
     const u32x4 rs_bnx = dm_rsrc(ep.bn_x, (STATS && ep.bn_x) ? y_bytes : 0u);
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc((void *)ep.stats, 0,
-                                                                           STATS ? (unsigned)tb.nt * 2u * 16u * 4u : 0u, 0x00020000);
+    const u32x4 rs_y = dm_rsrc(y, y_bytes);
+    const u32x4 rs_st = dm_rsrc(ep.stats, STATS ? (unsigned)tb.nt * 2u * 16u * 4u : 0u);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, wp_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void *)tbl, 0, (unsigned)TB_K * (unsigned)ld * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_xb = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
@@ -158,16 +172,14 @@ __global__ __launch_bounds__(512) void conv_dma16(const void *__restrict__ x, un
     if (tid < 2 * DM_NBUF) reinterpret_cast<u32x4 *>(smem + (tid >> 1) * DM_BUF_BYTES)[tid & 1] = (u32x4){0u, 0u, 0u, 0u};
 
     const unsigned smem_base = (unsigned)(uintptr_t)smem;
-    // this lane's DMA pieces: row piece k -> list entry ((k * 8 + wid) * 64 + lane) >> 1, half lane & 1
+    // Row piece k of this lane: list entry e = (k*8 + wid)*32 + (lane >> 1), stored so that the lane's four entries
+    // are one 16-byte load (tb_upos).  Its half of the row is swizzled with bit 3 of e (= bit 4 of the lane): the
+    // 16 lanes of an LDS read phase ask for the same half of 16 different rows, which un-swizzled 32-byte rows put
+    // on HALF of the banks (>= 2-way conflicts by construction).
+    const unsigned src_half = (unsigned)((lane & 1) ^ ((lane >> 4) & 1)) * 16u;
     auto issue_list = [&](int j, DmList &l) {
-        const bool ok = j < nt_w;
-        const unsigned t = (unsigned)tile_of(j);
-#pragma unroll
-        for (int k = 0; k < DM_ROW_PIECES; ++k) {
-            const unsigned e = (unsigned)(((k * DM_WAVES + wid) * 64 + lane) >> 1);
-            aload32(l.rid[k], ok ? (t * (unsigned)TB_UMAX + e) * 4u : OOB, rs_ul);
-        }
-        aload32(l.ucount, ok ? t * 4u : OOB, rs_uc);
+        const bool ok = j < nt_w && !(dbg & 8);
+        aload128(l.rid, ok ? (unsigned)tile_of(j) * (unsigned)(TB_UMAX * 4) + (unsigned)(wid * 32 + (lane >> 1)) * 16u : OOB, rs_ul);
     };
     auto issue_epi = [&](int j, DmEpi &e) {
         const bool ok = j < nt_w;
@@ -180,32 +192,34 @@ __global__ __launch_bounds__(512) void conv_dma16(const void *__restrict__ x, un
             if constexpr (STATS) aload64(e.bnx[s], voff, rs_bnx);
         }
     };
-    auto issue_dma = [&](int j, const DmList &l) {
+    // DMA piece n of tile j into buffer j % 3: n < 4 rows of the list, n >= 4 the index strip
+    auto issue_piece = [&](int j, int n, const DmList &l) {
         const bool ok = j < nt_w;
         const unsigned buf = smem_base + (unsigned)(j % DM_NBUF) * (unsigned)DM_BUF_BYTES;
-#pragma unroll
-        for (int k = 0; k < DM_ROW_PIECES; ++k) {
-            // an absent entry is -1: its row offset is out of range and lands as zeros
-            const unsigned voff = ok ? l.rid[k] * 32u + (unsigned)(lane & 1) * 16u : OOB;
-            dma16(buf + 32u + (unsigned)((k * DM_WAVES + wid) * 1024), voff, rs_x);
-        }
-        const unsigned t = (unsigned)tile_of(j);
-#pragma unroll
-        for (int k = 0; k < DM_LIDX_PIECES; ++k) {
+        if (n < DM_ROW_PIECES) {
+            // an absent entry is negative: its row offset is out of range and lands as zeros
+            const unsigned voff = (ok && !(dbg & 2)) ? l.rid[n] * 32u + src_half : OOB;
+            dma16(buf + 32u + (unsigned)((n * DM_WAVES + wid) * 1024), voff, rs_x);
+        } else {
+            const int k = n - DM_ROW_PIECES;
             const unsigned p = (unsigned)((k * DM_WAVES + wid) * 64 + lane);
             dma16(buf + (unsigned)DM_ROWS_BYTES + (unsigned)((k * DM_WAVES + wid) * 1024),
-                  ok ? t * (unsigned)(TB_K * TB_T * 2) + p * 16u : OOB, rs_li);
+                  (ok && !(dbg & 4)) ? (unsigned)tile_of(j) * (unsigned)(TB_K * TB_T * 2) + p * 16u : OOB, rs_li);
         }
     };
 
-    // ---- one tile: multiply out of buffer j % 3, epilogue with operands `e`, stores ----
-    auto compute = [&](int j, unsigned ucount, const DmEpi &e) {
+    // ---- iteration j: multiply tile j out of buffer j % 3 while the DMA of tile j+2 (list lcur) is issued between
+    // the units; then list(j+4) -> lnew, operands(j+2) -> enew; epilogue of tile j with operands ecur; stores ----
+    auto iteration = [&](int j, bool overflow, const DmList &lcur, DmList &lnew, const DmEpi &ecur, DmEpi &enew) {
         const int tile = tile_of(j), t0 = tile * TB_T, row0 = t0 + wid * 32;
         const unsigned char *rows_s = smem + (j % DM_NBUF) * DM_BUF_BYTES;
         const unsigned short *lidx_s = reinterpret_cast<const unsigned short *>(rows_s + DM_ROWS_BYTES);
-        const unsigned half = (unsigned)(g & 1) * 16u;
+        const unsigned half = (unsigned)(g & 1);
         f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-        if (ucount <= (unsigned)DM_CAP) {
+        if (dbg & 1) {
+#pragma unroll
+            for (int n = 0; n < DM_NG; ++n) issue_piece(j + 2, n, lcur);
+        } else if (!overflow) {
             // the lane's two local indices of unit u (subtiles 2 (wid & 1), 2 (wid & 1) + 1 of its 64-row group)
             const unsigned short *my = lidx_s + (wid >> 1) * 64 + i * 4 + (wid & 1) * 2;
             auto loadl = [&](int u) {
@@ -214,9 +228,11 @@ __global__ __launch_bounds__(512) void conv_dma16(const void *__restrict__ x, un
                 if (osel < TB_K) v = *reinterpret_cast<const unsigned *>(my + osel * TB_T);
                 return v;
             };
+            // local index l (1 + list entry): byte l*32 + (half ^ bit 3 of the entry) * 16
+            auto addr = [&](unsigned l) { return l * 32u + ((half ^ (((l - 1u) >> 3) & 1u)) << 4); };
             auto fetch = [&](unsigned l, u32x4 (&xa)[2]) {
-                xa[0] = *reinterpret_cast<const u32x4 *>(rows_s + (l & 0xffffu) * 32u + half);
-                xa[1] = *reinterpret_cast<const u32x4 *>(rows_s + (l >> 16) * 32u + half);
+                xa[0] = *reinterpret_cast<const u32x4 *>(rows_s + addr(l & 0xffffu));
+                xa[1] = *reinterpret_cast<const u32x4 *>(rows_s + addr(l >> 16));
             };
             unsigned lr[NU];
 #pragma unroll
@@ -228,13 +244,18 @@ __global__ __launch_bounds__(512) void conv_dma16(const void *__restrict__ x, un
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 if (u + 3 < NU) fetch(lr[u + 3], xa[(u + 3) & 3]);
+                // one DMA piece of tile j+2 every other unit: the texture path works on them under the LDS reads
+                // and MFMAs of this tile instead of in a phase of its own
+                if ((u & 1) == 0 && u / 2 < DM_NG) issue_piece(j + 2, u / 2, lcur);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_bf16_k32(acc[0], wr[u], xa[u & 3][0]);
                 mma_bf16_k32(acc[1], wr[u], xa[u & 3][1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            // overflow tile (more distinct rows than the buffers hold): operands gathered from global memory through
+#pragma unroll
+            for (int n = 0; n < DM_NG; ++n) issue_piece(j + 2, n, lcur);
+            // overflow tile (more distinct rows than the list holds): operands gathered from global memory through
             // the dense table.  Rare (none at 2 cm); the compiler's own waits drain the pipeline here, which is only slow.
 #pragma unroll
             for (int u = 0; u < NU; ++u) {   // (unrolled: a run-time index into wr[] would move the fragments to scratch)
@@ -246,21 +267,24 @@ __global__ __launch_bounds__(512) void conv_dma16(const void *__restrict__ x, un
                     const unsigned voff = (osel < TB_K && t < n_out) ? ((unsigned)osel * (unsigned)ld + (unsigned)t) * 4u : OOB;
                     const unsigned go = __builtin_amdgcn_raw_buffer_load_b32(rs_t, voff, 0, 0);
                     const bool present = osel < TB_K && t < n_out && (int)go >= 0;
-                    xa[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_xb, present ? go * 32u + half : OOB, 0, 0);
+                    xa[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_xb, present ? go * 32u + half * 16u : OOB, 0, 0);
                 }
                 mma_bf16_k32(acc[0], wr[u], xa[0]);
                 mma_bf16_k32(acc[1], wr[u], xa[1]);
             }
         }
+        issue_list(j + 4, lnew);
+        issue_epi(j + 2, enew);
+        if (dbg & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (ablation: no overlap across iterations)
         // ---- epilogue: lane (i, g) holds output channels 4g .. 4g+3 of rows row0 + 16 s + i ----
         const unsigned col = 4u * (unsigned)g;
         f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const unsigned t = (unsigned)(row0 + s * 16 + i);
-            const unsigned voff = t < (unsigned)n_out ? (t * 16u + col) * 2u : OOB;
+            const unsigned voff = (t < (unsigned)n_out && !(dbg & 16)) ? (t * 16u + col) * 2u : OOB;
             f32x4 a = acc[s];
-            a += dm_unpack(e.res[s]);               // (no residual: the load was out of range: zeros)
+            a += dm_unpack(ecur.res[s]);            // (no residual: the load was out of range: zeros)
             u32x2 packed_out;
             packed_out[0] = (unsigned)f2bf(a[0]) | ((unsigned)f2bf(a[1]) << 16);
             packed_out[1] = (unsigned)f2bf(a[2]) | ((unsigned)f2bf(a[3]) << 16);
@@ -268,7 +292,7 @@ __global__ __launch_bounds__(512) void conv_dma16(const void *__restrict__ x, un
                 f32x4 v = dm_unpack(packed_out);    // y as stored
                 if (t >= (unsigned)n_out) v = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (ep.bn_x) {
-                    const f32x4 xr = dm_unpack(e.bnx[s]);
+                    const f32x4 xr = dm_unpack(ecur.bnx[s]);
                     const f32x4 xh = (xr - bn_mu) * bn_is;
                     if (ep.bn_relu) {
                         const f32x4 yv = xh * bn_ga + bn_be;
@@ -282,7 +306,7 @@ __global__ __launch_bounds__(512) void conv_dma16(const void *__restrict__ x, un
                     st2 += v * v;
                 }
             }
-            __builtin_amdgcn_raw_buffer_store_b64(packed_out, rs_y, voff, 0, 0);
+            astore64(packed_out, voff, rs_y);
         }
         if constexpr (STATS) {
 #pragma unroll
@@ -298,69 +322,64 @@ __global__ __launch_bounds__(512) void conv_dma16(const void *__restrict__ x, un
             }
             // every wave issues the two stores (constant vmcnt bookkeeping); only wave 0's lanes 15, 31, 47, 63 land
             const unsigned so = (wid == 0 && i == 15) ? ((unsigned)tile * 32u + col) * 4u : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a1), rs_st, so, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a2), rs_st, so + (so == OOB ? 0u : 64u), 0, 0);
+            astore128(__builtin_bit_cast(u32x4, a1), so, rs_st);
+            astore128(__builtin_bit_cast(u32x4, a2), so + (so == OOB ? 0u : 64u), rs_st);
         }
     };
+    auto dummy_stores = [&]() {
+#pragma unroll
+        for (int k = 0; k < N_S; ++k) astore64((u32x2){0u, 0u}, OOB, rs_y);
+    };
+    // a tile without a list (more than TB_UMAX distinct rows) carries -2 in every entry
+    auto no_list = [&](const DmList &l) { return __builtin_amdgcn_readfirstlane((int)l.rid[0]) == -2; };
 
-    // ---- prologue: lists of tiles 0 .. 2 and operands of tile 0, then the DMA of tiles 0 and 1 ----
+    // ---- prologue: the queue is given the shape of two past iterations (with stores that land nowhere), so that
+    // ONE wait constant serves every iteration ----
     DmList la, lb, lc;
-    DmEpi ea, eb;
-    eb.res[0] = eb.res[1] = eb.bnx[0] = eb.bnx[1] = (u32x2){0u, 0u};
-    if constexpr (!STATS) ea.bnx[0] = ea.bnx[1] = (u32x2){0u, 0u};
+    DmEpi ea, eb, ec;
+    if constexpr (!STATS) ea.bnx[0] = ea.bnx[1] = eb.bnx[0] = eb.bnx[1] = ec.bnx[0] = ec.bnx[1] = (u32x2){0u, 0u};
+    ec.res[0] = ec.res[1] = (u32x2){0u, 0u};
+    if constexpr (STATS) ec.bnx[0] = ec.bnx[1] = (u32x2){0u, 0u};
     issue_list(0, la);
     issue_list(1, lb);
+    dm_wait<0>();
+    dm_tie(la, ec);
+    dm_tie(lb, ec);
+    dm_barrier();                 // the zero rows are written
+    bool ov0 = no_list(la), ov1 = no_list(lb);
+#pragma unroll
+    for (int n = 0; n < DM_NG; ++n) issue_piece(0, n, la);      // "iteration -2": D(0), list(2), operands(0), stores
     issue_list(2, lc);
     issue_epi(0, ea);
-    dm_wait<0>(la, ea);
-    dm_wait<0>(lb, eb);
-    dm_wait<0>(lc, eb);
-    dm_barrier();                 // the zero rows are written
-    issue_dma(0, la);
-    issue_dma(1, lb);
-    // N_S stores that land nowhere: the queue of iteration 0 then has the shape of every later one (.. DMA(j+1),
-    // stores(j-1), list(j+3) ..) and ONE wait constant serves all iterations — two wait statements on a branch made
-    // hipcc merge their register operands through copies placed BEFORE the wait, i.e. copies of loads in flight
+    dummy_stores();
 #pragma unroll
-    for (int k = 0; k < N_S; ++k) __builtin_amdgcn_raw_buffer_store_b64((u32x2){0u, 0u}, rs_y, OOB, 0, 0);
-    // From here on: list registers rotate a <- c, b <- a, c <- b every iteration, written out three times so that no
-    // register holding a load in flight is ever copied (a copy would have to wait for it); the epilogue operands
-    // alternate between two sets the same way.
-    // step(j, lnext, lnew, ecur, enew):  lnext = list(j+2) (landed below), lnew receives list(j+3)
-    auto step = [&](int j, DmList &lnext, DmList &lnew, DmEpi &ecur, DmEpi &enew) {
-        issue_list(j + 3, lnew);                 // a
-        issue_epi(j + 1, enew);
-        dm_wait<DM_NG + N_S + N_LE>(lnext, ecur);                  // b
-        dm_barrier();                            // c
-        issue_dma(j + 2, lnext);                 // d
-    };
-    // the count of tile j travels with list(j): keep the three most recent ones in scalars
-    unsigned uc0 = (unsigned)__builtin_amdgcn_readfirstlane((int)la.ucount);
-    unsigned uc1 = (unsigned)__builtin_amdgcn_readfirstlane((int)lb.ucount);
-    for (int j = 0; j < nt_w; j += 6) {
-        // iteration j: list(j+2) = lc, new list -> la (list(j) = la is dead: its DMA was issued)
-        step(j, lc, la, ea, eb);
-        { const unsigned uc2 = (unsigned)__builtin_amdgcn_readfirstlane((int)lc.ucount); compute(j, uc0, ea); uc0 = uc1; uc1 = uc2; }
+    for (int n = 0; n < DM_NG; ++n) issue_piece(1, n, lb);      // "iteration -1": D(1), list(3), operands(1), stores
+    issue_list(3, la);
+    issue_epi(1, eb);
+    dummy_stores();
+    // Register sets rotate with period three (lists: the DMA of tile j+2 reads list(j+2) during iteration j, list(j+3)
+    // is landing, list(j+4) is requested; operands likewise), written out three times so that no register holding a
+    // load in flight is ever copied.
+    for (int j = 0; j < nt_w; j += 3) {
+        dm_wait<N_WAIT>();
+        dm_tie(lc, ea);                                  // list(j+2), operands(j)
+        dm_barrier();
+        { const bool ov2 = no_list(lc); iteration(j, ov0, lc, lb, ea, ec); ov0 = ov1; ov1 = ov2; }
         if (j + 1 >= nt_w) break;
-        step(j + 1, la, lb, eb, ea);
-        { const unsigned uc2 = (unsigned)__builtin_amdgcn_readfirstlane((int)la.ucount); compute(j + 1, uc0, eb); uc0 = uc1; uc1 = uc2; }
+        dm_wait<N_WAIT>();
+        dm_tie(la, eb);                                  // list(j+3), operands(j+1)
+        dm_barrier();
+        { const bool ov2 = no_list(la); iteration(j + 1, ov0, la, lc, eb, ea); ov0 = ov1; ov1 = ov2; }
         if (j + 2 >= nt_w) break;
-        step(j + 2, lb, lc, ea, eb);
-        { const unsigned uc2 = (unsigned)__builtin_amdgcn_readfirstlane((int)lb.ucount); compute(j + 2, uc0, ea); uc0 = uc1; uc1 = uc2; }
-        if (j + 3 >= nt_w) break;
-        step(j + 3, lc, la, eb, ea);
-        { const unsigned uc2 = (unsigned)__builtin_amdgcn_readfirstlane((int)lc.ucount); compute(j + 3, uc0, eb); uc0 = uc1; uc1 = uc2; }
-        if (j + 4 >= nt_w) break;
-        step(j + 4, la, lb, ea, eb);
-        { const unsigned uc2 = (unsigned)__builtin_amdgcn_readfirstlane((int)la.ucount); compute(j + 4, uc0, ea); uc0 = uc1; uc1 = uc2; }
-        if (j + 5 >= nt_w) break;
-        step(j + 5, lb, lc, eb, ea);
-        { const unsigned uc2 = (unsigned)__builtin_amdgcn_readfirstlane((int)lb.ucount); compute(j + 5, uc0, eb); uc0 = uc1; uc1 = uc2; }
+        dm_wait<N_WAIT>();
+        dm_tie(lb, ec);                                  // list(j+4), operands(j+2)
+        dm_barrier();
+        { const bool ov2 = no_list(lb); iteration(j + 2, ov0, lb, la, ec, eb); ov0 = ov1; ov1 = ov2; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // loads still in flight target registers and LDS of this workgroup
 }
 
-bool g_use_dma = true;
+bool g_use_dma = !(getenv("DODA_NO_DMA") && getenv("DODA_NO_DMA")[0] == '1');   // doda_spconv_set_dma_kernel / DODA_NO_DMA=1 (A/B measurements)
 
 }  // namespace
 
@@ -376,10 +395,11 @@ int launch_conv16(const void *x, unsigned xb, const void *wp, unsigned wpb, cons
     int groups = (tb.nt + 7) / 8 * 8;
     if (groups > 256) groups = 256;       // one workgroup per CU
     if (n_part) *n_part = tb.nt;
+    static const int dbg = getenv("DODA_DMA_DBG") ? atoi(getenv("DODA_DMA_DBG")) : 0;   // ablation switches (measurements only)
     if (ep.stats)
-        hipLaunchKernelGGL((conv_dma16<true>), dim3(groups), dim3(512), 0, s, x, xb, wp, wpb, tbl, ld, n_out, tb, y, yb, res, ep);
+        hipLaunchKernelGGL((conv_dma16<true>), dim3(groups), dim3(512), 0, s, x, xb, wp, wpb, tbl, ld, n_out, tb, y, yb, res, ep, dbg);
     else
-        hipLaunchKernelGGL((conv_dma16<false>), dim3(groups), dim3(512), 0, s, x, xb, wp, wpb, tbl, ld, n_out, tb, y, yb, res, ep);
+        hipLaunchKernelGGL((conv_dma16<false>), dim3(groups), dim3(512), 0, s, x, xb, wp, wpb, tbl, ld, n_out, tb, y, yb, res, ep, dbg);
     return doda_check_launch();
 }
 

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
 #pragma unroll
         for (int k = 0; k < NRL; ++k) {
             const int e = (k * 256 + tid) / PPR;
-            rid[k] = e < CAP ? (unsigned)ul[e] : 0xffffffffu;
+            rid[k] = e < CAP ? (unsigned)ul[tb_upos(e)] : 0xffffffffu;
         }
     };
     unsigned rid[NRL];
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void bwd_tile(const unsigned short *__restrict
 #pragma unroll
             for (int k = 0; k < NRL; ++k) {
                 const int e = (k * 256 + tid) >> 1;
-                rid[k] = e < CAP ? (unsigned)ul[e] : 0xffffffffu;
+                rid[k] = e < CAP ? (unsigned)ul[tb_upos(e)] : 0xffffffffu;
             }
         }
         constexpr int NLI = (TB_K * TB_T * 2 / 16 + 255) / 256;

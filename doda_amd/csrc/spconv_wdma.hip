@@ -1,0 +1,366 @@
+// wgrad_dma16: weight gradient of the SubM 16 -> 16 bf16 layers over the rulebook's TILEBOOK
+//     dw[o][ci][co] (+)= sum_t x[tbl[o][t]][ci] * dy[t][co]
+// (spconv v1.2 indice_conv_backward's per-offset `Xg^T . dYg`; reference call sites model/unet_block.py:26,29 through
+// autograd), for ALL layers of a rulebook in one launch.
+//
+// The pair-list kernel (spconv_wgrad_pairs.hip) gathers one 32-byte x row and one 32-byte dy row PER PAIR from
+// global memory: 12.4 pairs per voxel x 64 B = 0.8 KB of texture-path traffic per voxel against 137 B of operands
+// (PMC: GRBM_TA_BUSY 93 %); cold it runs at 57 us per level-1 layer.  Here a tile of 256 output rows t is staged
+// ONCE in LDS — the ~2.3 x 256 distinct x rows its table entries reference (LDS-DMA, exactly the forward kernel's
+// staging: spconv_dma.hip) and its 256 dy rows — and every (offset, 32-row k-step) is served from there:
+//   * dy (dense: rows t0 .. t0+255) reaches MFMA k-order through ds_read_b64_tr_b16 (conflict-free on contiguous rows);
+//   * the gathered x row slices (random LDS rows: the transposed read conflicts 4-way there, which is what sank
+//     bwd_tile) are brought into k-order by the matrix core itself, as in the pair kernel: a 16-byte row slice is the
+//     natural A operand of v_mfma_f32_16x16x32_bf16 (lane = row, registers = channels); multiplied by a one-hot B
+//     operand it comes back with lane = channel, registers = rows (products with 1.0, sums with zeros: exact).
+// Per (offset, k-step): one local-index read, one 16-byte LDS row read, two transposing MFMAs, one contraction MFMA;
+// an (offset, k-step) whose 32 rows have no neighbour under that offset is skipped (wave-uniform test).
+// ONE persistent 8-wave workgroup per CU with two tile buffers: the DMA of tile j+1 is issued between the units of
+// tile j, each wave at a different unit (the waves leave the barrier together, and eight waves queueing on the CU's
+// texture path at the same instant stall each other instead of overlapping with the matrix work).
+// The 54 units (offset, half of the tile's k-steps) are dealt to the 8 waves; accumulators stay in registers across
+// all tiles of a layer; per layer and workgroup one partial [27][16][16] is written (256 partials instead of the 768
+// a three-workgroups-per-CU schedule would produce), summed in a fixed order by wgrad_dma_reduce: deterministic.
+#include "common.hpp"
+#include "tilebook.hpp"
+#include "spconv_common.hpp"
+#include "wgrad_pairs.hpp"
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+constexpr int WD_WAVES = 8;
+constexpr int WD_ROWS_BYTES = (TB_UMAX + 1) * 32;     // slot 0: the shared zero row
+constexpr int WD_LIDX_BYTES = 16384;                  // 27 x 256 x 2 = 13824, rounded up to whole 1 KB DMA pieces
+constexpr int WD_DY_BYTES = TB_T * 32;
+constexpr int WD_BUF_BYTES = WD_ROWS_BYTES + WD_LIDX_BYTES + WD_DY_BYTES;
+constexpr int WD_NPIECE = 4 + 2 + 1;                  // DMA instructions per wave and tile: rows, index strip, dy
+constexpr int WD_UNITS = 2 * TB_K;                    // (offset, half of the k-steps)
+constexpr int WD_MAX_UNITS = (WD_UNITS + WD_WAVES - 1) / WD_WAVES;   // 7
+constexpr int WD_MAX_JOBS = 16;
+static_assert(WD_BUF_BYTES % 16 == 0 && 2 * WD_BUF_BYTES + 64 <= 160 * 1024, "two tile buffers per CU");
+static_assert(WD_UNITS * 256 * 4 <= WD_BUF_BYTES, "the final exchange re-uses ONE tile buffer (the other may be a DMA target)");
+static_assert(WD_NPIECE == WD_MAX_UNITS, "one DMA piece per unit of a wave");
+
+struct WdJob { const void *x, *dy; float *part; };    // part: [groups][27][256] of this layer
+struct WdJobs { int n; WdJob j[WD_MAX_JOBS]; };
+
+__device__ __forceinline__ u32x4 wd_rsrc(const void *p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    u32x4 r;
+    r[0] = (unsigned)a;
+    r[1] = (unsigned)(a >> 32) & 0xffffu;
+    r[2] = bytes;
+    r[3] = 0x00020000u;
+    return r;
+}
+// 16 bytes per lane from buffer offset `voff` straight into LDS at lds_base + lane * 16 (lds_base wave-uniform)
+__device__ __forceinline__ void wd_dma16(unsigned lds_base, unsigned voff, const u32x4 &rs) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_base), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void wd_aload128(u32x4 &dst, unsigned voff, const u32x4 &rs) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ s16x4 wd_tr_b64(unsigned addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ bf16x8 wd_pack_hi16(const f32x4 &d0, const f32x4 &d1) {
+    // the values are bf16-exact: keep the upper halves.  k-slot q of the lane: q < 4 -> d0[q], else d1[q-4]
+    u32x4 r;
+    r[0] = __builtin_amdgcn_perm(__float_as_uint(d0[1]), __float_as_uint(d0[0]), 0x07060302u);
+    r[1] = __builtin_amdgcn_perm(__float_as_uint(d0[3]), __float_as_uint(d0[2]), 0x07060302u);
+    r[2] = __builtin_amdgcn_perm(__float_as_uint(d1[1]), __float_as_uint(d1[0]), 0x07060302u);
+    r[3] = __builtin_amdgcn_perm(__float_as_uint(d1[3]), __float_as_uint(d1[2]), 0x07060302u);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(512) void wgrad_dma16(const WdJobs jobs, unsigned feat_bytes, const int32_t *__restrict__ tbl,
+                                                   int ld, int n, const TileBookView tb) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WD_BUF_BYTES];
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const u32x4 rs_ul = wd_rsrc(tb.ulist, (unsigned)tb.nt * (unsigned)TB_UMAX * 4u);
+    const u32x4 rs_li = wd_rsrc(tb.lidx, (unsigned)tb.nt * (unsigned)(TB_K * TB_T * 2));
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void *)tbl, 0, (unsigned)TB_K * (unsigned)ld * 4u, 0x00020000);
+
+    // persistent schedule: XCD (blockIdx & 7) owns one contiguous range of tiles, its L workgroups stride it
+    const int L = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int qn = tb.nt >> 3, rn = tb.nt & 7;
+    const int lo = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
+    const int cnt = qn + (xcd < rn ? 1 : 0);
+    const int nt_w = slot < cnt ? (cnt - slot + L - 1) / L : 0;      // tiles of this workgroup (per layer)
+    auto tile_of = [&](int j) { return lo + slot + j * L; };
+    const int n_items = nt_w * jobs.n;                               // (layer, tile) items, layer-major
+    if (nt_w == 0) {   // more workgroups than tiles: this one still owns a partial per layer
+        for (int job = 0; job < jobs.n; ++job) {
+            float *dst = jobs.j[job].part + (size_t)blockIdx.x * (TB_K * 256);
+            for (int e = tid; e < TB_K * 256; e += 512) dst[e] = 0.f;
+        }
+        return;
+    }
+
+    // one-hot B operands of the transposition: P[G][k = (g, q)][j = i] = 1 iff g >> 1 == G, g & 1 == j >> 3, q == j & 7
+    bf16x8 P[2];
+#pragma unroll
+    for (int G = 0; G < 2; ++G) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        const bool mine = (g >> 1) == G && (i >> 3) == (g & 1);
+        const int q = i & 7;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v[w] = (mine && (q >> 1) == w) ? ((q & 1) ? 0x3F800000u : 0x00003F80u) : 0u;
+        P[G] = __builtin_bit_cast(bf16x8, v);
+    }
+    if (tid < 4) reinterpret_cast<u32x4 *>(smem + (tid >> 1) * WD_BUF_BYTES)[tid & 1] = (u32x4){0u, 0u, 0u, 0u};   // zero rows
+
+    const unsigned smem_base = (unsigned)(uintptr_t)smem;
+    const unsigned src_half = (unsigned)((lane & 1) ^ ((lane >> 4) & 1)) * 16u;   // half-row swizzle (spconv_dma.hip)
+    auto issue_list = [&](int item, u32x4 &rid) {
+        const bool ok = item < n_items;
+        const int j = ok ? item % nt_w : 0;
+        wd_aload128(rid, ok ? (unsigned)tile_of(j) * (unsigned)(TB_UMAX * 4) + (unsigned)(wid * 32 + (lane >> 1)) * 16u : OOB, rs_ul);
+    };
+    // DMA piece p (0..6) of item `item` into buffer item & 1: rows of the list (4), index strip (2), dy rows (1)
+    auto issue_piece = [&](int item, int p, const u32x4 &rid) {
+        const bool ok = item < n_items;
+        const int job = ok ? item / nt_w : 0, j = ok ? item % nt_w : 0;
+        const unsigned buf = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
+        const unsigned tile = (unsigned)tile_of(j);
+        if (p < 4) {
+            const unsigned r = p == 0 ? rid[0] : p == 1 ? rid[1] : p == 2 ? rid[2] : rid[3];
+            const u32x4 rs_x = wd_rsrc(jobs.j[job].x, feat_bytes);
+            wd_dma16(buf + 32u + (unsigned)((p * WD_WAVES + wid) * 1024), ok ? r * 32u + src_half : OOB, rs_x);
+        } else if (p < 6) {
+            const unsigned pc = (unsigned)(((p - 4) * WD_WAVES + wid) * 64 + lane);
+            wd_dma16(buf + (unsigned)WD_ROWS_BYTES + (unsigned)(((p - 4) * WD_WAVES + wid) * 1024),
+                     ok ? tile * (unsigned)(TB_K * TB_T * 2) + pc * 16u : OOB, rs_li);
+        } else {
+            const u32x4 rs_dy = wd_rsrc(jobs.j[job].dy, feat_bytes);
+            // rows past n: out of range -> zeros
+            wd_dma16(buf + (unsigned)(WD_ROWS_BYTES + WD_LIDX_BYTES) + (unsigned)(wid * 1024),
+                     ok ? (tile * (unsigned)TB_T + (unsigned)(wid * 32 + (lane >> 1))) * 32u + (unsigned)(lane & 1) * 16u : OOB, rs_dy);
+        }
+    };
+
+    f32x4 acc[WD_MAX_UNITS];
+#pragma unroll
+    for (int m = 0; m < WD_MAX_UNITS; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    // prologue: list of items 0 and 1, DMA of item 0
+    u32x4 la, lb;
+    issue_list(0, la);
+    issue_list(1, lb);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(la), "+v"(lb) : : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // zero rows written
+#pragma unroll
+    for (int p = 0; p < WD_NPIECE; ++p) issue_piece(0, p, la);
+
+    // body(item, lnext = list(item+1) [landed], lnew <- list(item+2))
+    auto body = [&](int item, bool no_list, const u32x4 &lnext, u32x4 &lnew) {
+        const int job = item / nt_w, j = item - job * nt_w;
+        const int tile = tile_of(j), t0 = tile * TB_T;
+        const unsigned char *buf = smem + (item & 1) * WD_BUF_BYTES;
+        const unsigned rows_base = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
+        const unsigned short *lidx_s = reinterpret_cast<const unsigned short *>(buf + WD_ROWS_BYTES);
+        const unsigned dy_base = rows_base + (unsigned)(WD_ROWS_BYTES + WD_LIDX_BYTES);
+        const unsigned short *xg = reinterpret_cast<const unsigned short *>(jobs.j[job].x);
+        // ---- dy fragments of the wave's four k-steps (every unit of wave w covers the half h = w & 1 of the tile):
+        // channel i of rows 32 ks + 8 g + 0..7 ----
+        const int q4 = i >> 2, c4 = i & 3, hw = wid & 1;
+        bf16x8 bt[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const unsigned a = dy_base + (unsigned)((32 * (4 * hw + kk) + 8 * g + q4) * 32 + c4 * 8);
+            const s16x4 lo4 = wd_tr_b64(a), hi4 = wd_tr_b64(a + 4u * 32u);
+            bt[kk] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bt[0]), "+v"(bt[1]), "+v"(bt[2]), "+v"(bt[3]) : : "memory");
+        // gathered x slices: lane (i, g) reads the half g & 1 of the row of output row 32 ks + 8 (i >> 2) + 4 (g >> 1) + (i & 3)
+        const int rl = 8 * (i >> 2) + 4 * (g >> 1) + (i & 3);
+        const unsigned hsel = (unsigned)(g & 1);
+        // (two copies of the unit loop: a slice that may come from a compiler-tracked global load at a join point makes
+        // hipcc wait vmcnt(0) before every MFMA there — on the list path that would drain the DMA in flight)
+        auto step = [&](int m, int kk, const u32x4 &v) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, v);
+            const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[0], zero, 0, 0, 0);
+            const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[1], zero, 0, 0, 0);
+            const bf16x8 at = wd_pack_hi16(d0, d1);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at, bt[kk], acc[m], 0, 0, 0);
+        };
+        if (!no_list) {
+#pragma unroll
+            for (int m = 0; m < WD_MAX_UNITS; ++m) {
+                const int unit = wid + WD_WAVES * m;            // (offset o, half h of the k-steps)
+                // the next item's DMA pieces, one per unit, each wave starting at another piece
+                issue_piece(item + 1, (m + wid) % WD_MAX_UNITS, lnext);
+                if (unit < WD_UNITS) {
+                    const int o = unit >> 1;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int r = 32 * (4 * hw + kk) + rl;
+                        const unsigned l = lidx_s[o * TB_T + tb_pos(r)];
+                        if (__builtin_amdgcn_ballot_w64(l != 0u) == 0ull) continue;      // no pair of this offset in these 32 rows
+                        step(m, kk, *reinterpret_cast<const u32x4 *>(buf + l * 32u + ((hsel ^ (((l - 1u) >> 3) & 1u)) << 4)));
+                    }
+                }
+            }
+        } else {
+            // a tile without a list (more than TB_UMAX distinct rows; none at 2 cm): slices through the dense table
+#pragma unroll
+            for (int p = 0; p < WD_NPIECE; ++p) issue_piece(item + 1, p, lnext);
+#pragma unroll 1
+            for (int m = 0; m < WD_MAX_UNITS; ++m) {
+                const int unit = wid + WD_WAVES * m;
+                if (unit >= WD_UNITS) break;
+                const int o = unit >> 1;
+                f32x4 part = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int r = 32 * (4 * hw + kk) + rl;
+                    const int gi = t0 + r < n ? tbl[(size_t)o * ld + (size_t)(t0 + r)] : -1;
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (gi >= 0) v = *reinterpret_cast<const u32x4 *>(xg + (size_t)gi * 16 + hsel * 8);
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, v);
+                    const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[0], zero, 0, 0, 0);
+                    const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[1], zero, 0, 0, 0);
+                    part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd_pack_hi16(d0, d1), bt[kk], part, 0, 0, 0);
+                }
+#pragma unroll
+                for (int mm = 0; mm < WD_MAX_UNITS; ++mm)
+                    if (mm == m) acc[mm] += part;      // (static indices: acc[] stays in registers)
+            }
+        }
+        issue_list(item + 2, lnew);
+    };
+
+    // the layer's partial: units -> LDS, halves added, one [27][256] block per workgroup
+    // (exchange through the buffer the last tile was read from: the other one is the target of the next item's DMA)
+    auto flush = [&](int job, int bufsel) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done reading the buffer
+        float *ex = reinterpret_cast<float *>(smem + bufsel * WD_BUF_BYTES);
+#pragma unroll
+        for (int m = 0; m < WD_MAX_UNITS; ++m) {
+            const int unit = wid + WD_WAVES * m;
+            if (unit < WD_UNITS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ex[unit * 256 + (4 * g + r) * 16 + i] = acc[m][r];
+            }
+            acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float *dst = jobs.j[job].part + (size_t)blockIdx.x * (TB_K * 256);
+        for (int e = tid; e < TB_K * 256; e += 512) {
+            const int o = e >> 8, c = e & 255;
+            dst[e] = ex[(2 * o) * 256 + c] + ex[(2 * o + 1) * 256 + c];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid < 2) reinterpret_cast<u32x4 *>(smem + bufsel * WD_BUF_BYTES)[tid] = (u32x4){0u, 0u, 0u, 0u};   // its zero row again
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    bool nl_cur = __builtin_amdgcn_readfirstlane((int)la[0]) == -2;      // tile 0 has no list
+    for (int item = 0; item < n_items; item += 2) {
+        // everything issued so far has landed: DMA(item), list(item+1)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(lb) : : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            const bool nl_next = __builtin_amdgcn_readfirstlane((int)lb[0]) == -2;
+            body(item, nl_cur, lb, la);
+            nl_cur = nl_next;
+        }
+        if ((item + 1) % nt_w == 0) flush(item / nt_w, item & 1);
+        if (item + 1 >= n_items) break;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(la) : : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            const bool nl_next = __builtin_amdgcn_readfirstlane((int)la[0]) == -2;
+            body(item + 1, nl_cur, la, lb);
+            nl_cur = nl_next;
+        }
+        if ((item + 2) % nt_w == 0) flush((item + 1) / nt_w, (item + 1) & 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    (void)rs_t;
+}
+
+// dw[job][e] (+)= sum over workgroups of part[job][wg][e], fixed order.  One workgroup per 32 outputs and layer; its 16
+// lane groups take every 16th partial, eight loads in flight each, combined in a fixed tree through LDS.
+struct WdRJob { const float *part; float *dw; int accumulate, pad; };
+struct WdRJobs { WdRJob j[WD_MAX_JOBS]; };
+
+__global__ __launch_bounds__(512) void wgrad_dma_reduce(const WdRJobs jobs, int n_part) {
+    __shared__ float red[16][32];
+    const WdRJob d = jobs.j[blockIdx.y];
+    const int jx = threadIdx.x & 31, p = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + jx;
+    float a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = 0.f;
+    int b = p;
+    for (; b + 7 * 16 < n_part; b += 8 * 16) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += d.part[(size_t)(b + q * 16) * (TB_K * 256) + e];
+    }
+    for (int q = 0; b < n_part; b += 16, ++q) a[q & 7] += d.part[(size_t)b * (TB_K * 256) + e];
+    red[p][jx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (p == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += red[q][jx];
+        d.dw[e] = d.accumulate ? d.dw[e] + v : v;
+    }
+}
+
+bool g_use_wdma = !(getenv("DODA_NO_WDMA") && getenv("DODA_NO_WDMA")[0] == '1');
+
+}  // namespace
+
+namespace doda_wdma {
+
+bool enabled() { return g_use_wdma; }
+void set_enabled(bool on) { g_use_wdma = on; }
+
+int groups_for(int n_rows) {
+    const int nt = (n_rows + TB_T - 1) / TB_T;
+    int groups = (nt + 7) / 8 * 8;
+    return groups > 256 ? 256 : groups;
+}
+size_t partial_bytes(int n_rows) { return (size_t)groups_for(n_rows) * TB_K * 256 * sizeof(float); }
+int max_jobs() { return WD_MAX_JOBS; }
+
+// x[k], dy[k], dw[k]: the layers (all over the same table / tilebook, n_rows rows, bf16 [n_rows,16]); part: n x partial_bytes
+int launch(const void *const *x, const void *const *dy, float *const *dw, const int *accumulate, int n_layers,
+           const int32_t *tbl, int ld, int n_rows, const void *tilebook, void *part, hipStream_t s) {
+    const TileBookView tb = tilebook_view(const_cast<void *>(tilebook), n_rows);
+    const int groups = groups_for(n_rows);
+    for (int first = 0; first < n_layers; first += WD_MAX_JOBS) {
+        const int nj = n_layers - first < WD_MAX_JOBS ? n_layers - first : WD_MAX_JOBS;
+        WdJobs jobs;
+        WdRJobs rj;
+        ::memset(&jobs, 0, sizeof(jobs));
+        ::memset(&rj, 0, sizeof(rj));
+        jobs.n = nj;
+        for (int k = 0; k < nj; ++k) {
+            float *p = (float *)((char *)part + (size_t)(first + k) * partial_bytes(n_rows));
+            jobs.j[k] = WdJob{x[first + k], dy[first + k], p};
+            rj.j[k] = WdRJob{p, dw[first + k], accumulate[first + k], 0};
+        }
+        hipLaunchKernelGGL(wgrad_dma16, dim3(groups), dim3(512), 0, s, jobs, (unsigned)((size_t)n_rows * 32), tbl, ld, n_rows, tb);
+        hipLaunchKernelGGL(wgrad_dma_reduce, dim3(TB_K * 256 / 32, nj), dim3(512), 0, s, rj, groups);
+    }
+    return doda_check_launch();
+}
+
+}  // namespace doda_wdma
+
+extern "C" void doda_spconv_set_wdma_kernel(int32_t on) { doda_wdma::set_enabled(on != 0); }

@@ -578,11 +578,16 @@ Staging g_staging;
 }  // namespace
 
 // job classes of a multi call
-enum { J_SKIP = 0, J_ZERO = 1, J_DENSE = 2, J_PAIRS = 3 };
+enum { J_SKIP = 0, J_ZERO = 1, J_DENSE = 2, J_PAIRS = 3, J_TILE = 4 };
 
 static int classify(const doda_wgrad_job &j) {
     if (j.n_rows == 0 && j.dw && j.K > 0 && j.ca > 0 && j.cb > 0)
         return (j.flags & DODA_WGRAD_ACCUMULATE) ? J_SKIP : J_ZERO;
+    // a tilebook of the job's table: the LDS-staged kernel (bf16 16 -> 16, K = 27)
+    if (j.tilebook && j.tbl && j.elem_bytes == 2 && j.ca == 16 && j.cb == 16 && j.K == 27 && j.n_rows > 0 && j.a && j.b && j.dw &&
+        j.n_a == j.n_rows && j.ld >= j.n_rows && (size_t)j.n_rows * 32 < 0x7ffffff0ull && (size_t)j.K * j.ld * 4 < 0xffffffffull &&
+        !(((uintptr_t)j.a | (uintptr_t)j.b | (uintptr_t)j.tilebook) & 15) && doda_wdma::enabled())
+        return J_TILE;
     // DODA_WGRAD_NO_PAIRS=1 keeps every job on the gather-table kernel (A/B measurements)
     static const bool no_pairs = getenv("DODA_WGRAD_NO_PAIRS") && getenv("DODA_WGRAD_NO_PAIRS")[0] == '1';
     if (doda_pairs::eligible(j) && (!no_pairs || !j.tbl)) return J_PAIRS;
@@ -599,6 +604,7 @@ extern "C" size_t doda_spconv_wgrad_multi_workspace_bytes(const doda_wgrad_job *
     for (int k = 0; k < n_jobs; ++k) {
         const int cls = classify(jobs_h[k]);
         if (cls == J_PAIRS) { total += doda_pairs::partial_bytes(jobs_h[k]); continue; }
+        if (cls == J_TILE) { total += align_up(doda_wdma::partial_bytes(jobs_h[k].n_rows), 256); continue; }
         if (cls != J_DENSE) continue;
         JobPlan jp;
         if (!plan_job(jobs_h[k], &jp)) continue;
@@ -619,7 +625,7 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
     if (desc_bytes < doda_spconv_wgrad_multi_desc_bytes(n_jobs)) return DODA_ERR_WORKSPACE;
     hipStream_t s = as_stream(stream);
     std::vector<JobPlan> plans(n_jobs);
-    std::vector<int> keys, cls(n_jobs), pair_jobs;
+    std::vector<int> keys, cls(n_jobs), pair_jobs, tile_jobs;
     size_t off = 0;
     for (int k = 0; k < n_jobs; ++k) {
         plans[k].key = -1;
@@ -630,6 +636,7 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
         }
         if (cls[k] == J_SKIP) continue;
         if (cls[k] == J_PAIRS) { pair_jobs.push_back(k); continue; }
+        if (cls[k] == J_TILE) { tile_jobs.push_back(k); continue; }
         if (!plan_job(jobs_h[k], &plans[k])) return DODA_ERR_INVALID;
         plans[k].ws_off = off;
         if (dense_needs_partial(plans[k], jobs_h[k])) off += align_up((size_t)plans[k].p.R * plans[k].n_elem * 4, 256);
@@ -642,7 +649,48 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
         const int st = doda_pairs::prepare(jobs_h, pair_jobs.data(), (int)pair_jobs.size(), (char *)ws, &off, &prep);
         if (st != DODA_OK) return st;
     }
+    // tile jobs: one launch per rulebook (jobs sharing table + tilebook), partials behind everything else
+    std::vector<size_t> tile_off(tile_jobs.size());
+    for (size_t q = 0; q < tile_jobs.size(); ++q) {
+        tile_off[q] = off;
+        off += align_up(doda_wdma::partial_bytes(jobs_h[tile_jobs[q]].n_rows), 256);
+    }
     if (ws_bytes < off) return DODA_ERR_WORKSPACE;
+    {
+        std::vector<char> done(tile_jobs.size(), 0);
+        for (size_t q = 0; q < tile_jobs.size(); ++q) {
+            if (done[q]) continue;
+            const doda_wgrad_job &j0 = jobs_h[tile_jobs[q]];
+            std::vector<const void *> xs, dys;
+            std::vector<float *> dws;
+            std::vector<int> accs;
+            // the group's partials must be contiguous: members are taken in queue order and re-based on the first one
+            std::vector<size_t> members;
+            for (size_t r = q; r < tile_jobs.size(); ++r) {
+                const doda_wgrad_job &j = jobs_h[tile_jobs[r]];
+                if (done[r] || j.tilebook != j0.tilebook || j.tbl != j0.tbl || j.n_rows != j0.n_rows || j.ld != j0.ld) continue;
+                members.push_back(r);
+            }
+            // contiguity: partial slots of equal size were carved in queue order, so members r0 < r1 < ... are NOT
+            // necessarily adjacent; launch runs of adjacent members
+            size_t m0 = 0;
+            while (m0 < members.size()) {
+                size_t m1 = m0 + 1;
+                while (m1 < members.size() && members[m1] == members[m1 - 1] + 1) ++m1;
+                xs.clear(); dys.clear(); dws.clear(); accs.clear();
+                for (size_t m = m0; m < m1; ++m) {
+                    const doda_wgrad_job &j = jobs_h[tile_jobs[members[m]]];
+                    xs.push_back(j.a); dys.push_back(j.b); dws.push_back(j.dw);
+                    accs.push_back((j.flags & DODA_WGRAD_ACCUMULATE) ? 1 : 0);
+                    done[members[m]] = 1;
+                }
+                const int st = doda_wdma::launch(xs.data(), dys.data(), dws.data(), accs.data(), (int)xs.size(), j0.tbl, j0.ld,
+                                                 j0.n_rows, j0.tilebook, (char *)ws + tile_off[members[m0]], s);
+                if (st != DODA_OK) return st;
+                m0 = m1;
+            }
+        }
+    }
 
     // dense descriptors grouped by kernel variant, then the reductions
     std::vector<WJob> wj;

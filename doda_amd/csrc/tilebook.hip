@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
     }
     int32_t *ul = v.ulist + (size_t)tile * TB_UMAX;
     if (U > TB_UMAX) {
-        for (int k = tid; k < TB_UMAX; k += 256) ul[k] = -1;
+        for (int k = tid; k < TB_UMAX; k += 256) ul[k] = -2;   // no list: every reader sees the marker in its own entries
         return;
     }
 
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
         }
     }
     __syncthreads();
-    for (int k = tid; k < TB_UMAX; k += 256) ul[k] = k < U ? (int32_t)uq[k] : -1;
+    for (int k = tid; k < TB_UMAX; k += 256) ul[tb_upos(k)] = k < U ? (int32_t)uq[k] : -1;
 
     // ---- 3. local indices ----
     // position of every key: the sorted list writes each key's rank next to its hash slot, then every

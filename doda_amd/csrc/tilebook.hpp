@@ -5,7 +5,9 @@
 // of DODA's U-Net a 32-row wave issues 28 gather instructions at 37 % lane use, and the kernel is paced by
 // the per-CU texture path.  A tile of TB_T consecutive output rows references only
 // ~2.2 x TB_T distinct input rows (raster-ordered surface voxels), so the tilebook stores per tile
-//   ulist [TB_UMAX]   int32   the distinct input rows, ascending (-1 past the count)
+//   ulist [TB_UMAX]   int32   the distinct input rows, ascending (-1 past the count; every entry -2 when the tile
+//                             has more than TB_UMAX of them), stored in the order tb_upos() gives: the 16 bytes a
+//                             lane of the LDS-DMA kernel needs for its four row pieces are contiguous
 //   lidx  [K][TB_T]   uint16  1 + position of tbl[o][t] in ulist, or 0 when absent (LDS slot 0 = the zero row)
 //   ucount            int32   number of distinct rows (> TB_UMAX: the list is not kept)
 // plus, once per tilebook, n_over int32 [2]: tiles above TB_CAP64 / above TB_UMAX (the caller's safety valve:
@@ -20,7 +22,7 @@
 #include <stddef.h>
 
 constexpr int TB_T = 256;        // output rows per tile
-constexpr int TB_UMAX = 1216;    // list capacity per tile = the largest kernel capacity (32-byte rows, 3 workgroups per CU)
+constexpr int TB_UMAX = 1024;    // list capacity per tile = the largest kernel capacity (32-byte rows)
 constexpr int TB_CAP64 = 960;    // kernel capacity for 64-byte rows (2 workgroups per CU) and for the fused backward
 constexpr int TB_K = 27;
 
@@ -50,6 +52,16 @@ static inline TileBookView tilebook_view(void *base, long long n_rows) {
     v.n_over = (int32_t *)p;
     return v;
 }
+
+// Storage position of list entry e.  The LDS-DMA kernel (spconv_dma.hip) moves a tile's rows with four DMA
+// instructions per wave; lane l of wave w stages, with instruction k, the row of entry (k*8 + w)*32 + (l >> 1).
+// Stored at (w*32 + (l >> 1))*4 + k, the four entries of a lane are ONE 16-byte load (8 list instructions per tile
+// instead of 40 four-byte ones: these kernels are paced by the number of vector-memory instructions per CU).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline int tb_upos(int e) { return (((e >> 5) & 7) * 32 + (e & 31)) * 4 + (e >> 8); }
+static_assert(TB_UMAX == 1024, "tb_upos permutes exactly 1024 entries");
 
 #ifdef __HIPCC__
 __device__ __forceinline__ int tb_pos(int r) { return (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3); }

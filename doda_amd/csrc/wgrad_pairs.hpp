@@ -31,3 +31,12 @@ int launch(const Prepared &p, const void *desc_dev, hipStream_t s);
 size_t desc_bytes_per_job();
 
 }  // namespace doda_pairs
+
+// LDS-staged weight gradient over a tilebook (spconv_wdma.hip): bf16 16 -> 16 layers sharing one table
+namespace doda_wdma {
+bool enabled();
+int max_jobs();
+size_t partial_bytes(int n_rows);      // workspace per layer
+int launch(const void *const *x, const void *const *dy, float *const *dw, const int *accumulate, int n_layers,
+           const int32_t *tbl, int ld, int n_rows, const void *tilebook, void *part, hipStream_t s);
+}  // namespace doda_wdma

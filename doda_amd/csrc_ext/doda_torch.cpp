@@ -351,6 +351,7 @@ void issue_wgrads(std::vector<PendingWgrad> &q, const c10::hip::HIPStream &st) {
         j.n_rows = (int32_t)p.n_rows; j.elem_bytes = (int32_t)elem_bytes(p.a);
         j.n_a = (int32_t)p.a.size(0);
         j.flags = flags;
+        j.tilebook = tilebook_behind(p.tbl, p.n_rows);   // SubM rulebooks of the fine levels carry one behind the table
         if (pairs_usable(p.a, p.b, p.pl)) {
             j.pair_in = (const int32_t *)p.pl.in.data_ptr();
             j.pair_out = (const int32_t *)p.pl.out.data_ptr();
@@ -885,7 +886,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               const int64_t T = doda_tilebook_tile(), nt = (tbl.size(1) + T - 1) / T, K = tbl.size(0), UMAX = doda_tilebook_umax();
               char *p = (char *)const_cast<void *>(tb);
               auto o32 = tbl.options(), o16 = tbl.options().dtype(at::kShort);
-              at::Tensor ulist = at::from_blob(p, {nt, UMAX}, o32).clone();
+              // (stored in the DMA kernel's lane order, csrc/tilebook.hpp tb_upos: handed out in list order)
+              at::Tensor order = at::empty({UMAX}, at::TensorOptions().dtype(at::kLong));
+              for (int64_t e = 0; e < UMAX; ++e) order.data_ptr<int64_t>()[e] = (((e >> 5) & 7) * 32 + (e & 31)) * 4 + (e >> 8);
+              at::Tensor ulist = at::from_blob(p, {nt, UMAX}, o32).index_select(1, order.to(tbl.device()));
               at::Tensor lidx = at::from_blob(p + nt * UMAX * 4, {nt, K, T}, o16).clone();
               at::Tensor ucount = at::from_blob(p + nt * UMAX * 4 + nt * K * T * 2, {nt}, o32).clone();
               return std::make_tuple(ulist, lidx, ucount);

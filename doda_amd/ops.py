@@ -433,7 +433,8 @@ class _WgradJob(C.Structure):   # doda_wgrad_job (include/doda_hip.h, ABI 2)
                 ("n_rows", C.c_int32), ("elem_bytes", C.c_int32),
                 ("pair_in", C.c_void_p), ("pair_out", C.c_void_p), ("pair_num", C.c_void_p),
                 ("pair_ld", C.c_int32), ("n_a", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32),
-                ("pair_seg", C.c_void_p), ("pair_seg_nt", C.c_int32), ("reserved2", C.c_int32)]
+                ("pair_seg", C.c_void_p), ("pair_seg_nt", C.c_int32), ("reserved2", C.c_int32),
+                ("tilebook", C.c_void_p)]
 
 
 WGRAD_ACCUMULATE = 1
@@ -441,7 +442,8 @@ WGRAD_ACCUMULATE = 1
 
 def spconv_wgrad_multi(jobs):
     """Weight gradients of many layers in one native call (doda_spconv_wgrad_multi).
-    jobs: list of (a [*,ca], b [n_rows,cb], tbl int32 [K,ld], n_rows[, pairs[, dw]]); `pairs` = None or
+    jobs: list of (a [*,ca], b [n_rows,cb], tbl int32 [K,ld], n_rows[, pairs[, dw[, tilebook]]]); `tilebook` =
+    tilebook_build(tbl) (bf16 16 -> 16, K = 27 jobs then take the LDS-staged kernel); `pairs` = None or
     (pair_in int32 [K,ld_p], pair_out int32 [K,ld_p], pair_num int32 [K] | None, seg int32 [K,nt] | None): bf16 jobs with
     16-multiple channel counts then take the pair-list kernel; `dw` = an existing float32 [K,ca,cb] tensor
     to ACCUMULATE into.  Returns the list of dw tensors (float32 [K, ca, cb]), equal to spconv_wgrad per
@@ -454,6 +456,7 @@ def spconv_wgrad_multi(jobs):
         a, b, tbl, n_rows = job[:4]
         pairs = job[4] if len(job) > 4 else None
         acc_into = job[5] if len(job) > 5 else None
+        tilebook = job[6] if len(job) > 6 else None
         _feat_ok(a, "a")
         _feat_ok(b, "b")
         a, b = a.contiguous(), b.contiguous()
@@ -473,7 +476,9 @@ def spconv_wgrad_multi(jobs):
         arr[k] = _WgradJob(_p(a), _p(b), _p(tbl), _p(dw), a.shape[1], b.shape[1], ld, K, int(n_rows),
                            4 if a.dtype == torch.float32 else 2,
                            None, None, None, 0, a.shape[0], WGRAD_ACCUMULATE if acc_into is not None else 0, 0,
-                           None, 0, 0)
+                           None, 0, 0, _p(tilebook) if tilebook is not None else None)
+        if tilebook is not None:
+            keep.append(tilebook)
         if pairs is not None:
             pin, pout, pnum = pairs[:3]
             seg = pairs[3] if len(pairs) > 3 else None

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DODA_ABI_VERSION 3
+#define DODA_ABI_VERSION 4
 
 #define DODA_OK 0
 #define DODA_ERR_INVALID (-1)        /* bad argument (null pointer, negative size, bad mode) */
@@ -284,6 +284,8 @@ void doda_spconv_set_wlds_kernel(int32_t on);
 /* A/B switch: 0 = the bf16 16 -> 16 layers with a tilebook stay on the three-workgroups-per-CU tile kernel instead of
  * the one-workgroup-per-CU LDS-DMA pipeline (spconv_dma.hip).  Default 1. */
 void doda_spconv_set_dma_kernel(int32_t on);
+/* A/B switch: 0 = weight-gradient jobs ignore their tilebook (pair-list / gather-table kernels).  Default 1. */
+void doda_spconv_set_wdma_kernel(int32_t on);
 size_t doda_spconv_stats_capacity(int32_t n_out);
 int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, int32_t elem_bytes, const float *w,
                           int32_t nc, const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, void *y,
@@ -343,6 +345,10 @@ typedef struct doda_wgrad_job {
     const int32_t *pair_seg;     /* [K][pair_seg_nt] segment prefix of the lists (see doda_rulebook_pairs), with */
     int32_t pair_seg_nt;         /* pair_num; both NULL / 0 for the full identity lists of a 1x1 convolution   */
     int32_t reserved2;
+    /* ABI 4.  Optional tilebook of `tbl` (doda_tilebook_build, built for n_rows rows): bf16 jobs with ca == cb == 16 and
+     * K == 27 then run the LDS-staged kernel (spconv_wdma.hip: the tile's distinct a rows and its b rows are staged once
+     * per 256 rows by LDS-DMA instead of being gathered per pair); jobs of one call that share a tilebook share a launch. */
+    const void *tilebook;
 } doda_wgrad_job;
 #define DODA_WGRAD_ACCUMULATE 1   /* dw += result (second backward pass into an existing .grad) */
 size_t doda_spconv_wgrad_multi_workspace_bytes(const doda_wgrad_job *jobs_h, int32_t n_jobs);

@@ -108,6 +108,47 @@ def test_headline_kernels_vs_oracle_on_oracle_pairs(native_lib, oracle, cin, cou
     pr, num, seg = ops.rulebook_pairs(tbl, n, flip=True, pad=False, with_seg=True)
     dw_pairs = ops.spconv_wgrad_pairs(xd, dyd, pr[0], pr[1], num, seg)
     assert rel_err(dw_pairs.cpu().reshape(ref_dw.shape), ref_dw) < 1e-4
+    if cin == 16 and cout == 16:   # wgrad_dma16: LDS-staged over the tilebook, several layers per launch
+        x2 = torch.randn(n, 16, generator=g).bfloat16()
+        _, ref_dw2 = oracle.indice_conv_backward(x2.double(), w.double(), dy.double(), pairs, pn, False, True)
+        base = torch.randn(27, 16, 16, generator=g)
+        acc = base.clone().to(d)
+        outs = ops.spconv_wgrad_multi([(xd, dyd, tbl, n, None, None, tb), (x2.to(d), dyd, tbl, n, None, acc, tb)])
+        assert rel_err(outs[0].cpu().reshape(ref_dw.shape), ref_dw) < 1e-4
+        assert rel_err((outs[1].cpu() - base).reshape(ref_dw2.shape), ref_dw2) < 1e-4
+        again = ops.spconv_wgrad_multi([(xd, dyd, tbl, n, None, None, tb)])[0]
+        assert torch.equal(again, outs[0])                                  # deterministic
+
+
+@pytest.mark.parametrize("n,kind", [(255, "scene"), (300, "scene"), (3001, "scene"), (2000, "random")])
+def test_wgrad_tile_kernel_edges(native_lib, n, kind):
+    """wgrad_dma16 on ragged sizes (fewer tiles than workgroups, a last tile of 44 / 185 rows) and on a table whose
+    tiles reference more distinct rows than a tilebook lists (served through the dense table inside the kernel):
+    against the fp64 definition dw[o] = sum_t x[tbl[o][t]]^T dy[t] and against the gather-table kernel."""
+    from doda_amd import ops
+    d = dev()
+    if kind == "scene":
+        shape, batch = [40, 36, 30], 1
+        idx = torch.from_numpy(_raster_scene(n, n, batch, shape)).to(d)
+        tbl = ops.rulebook_subm(idx, shape, batch, 3)
+    else:
+        g = torch.Generator().manual_seed(9)
+        tbl = torch.randint(0, n, (27, n), generator=g, dtype=torch.int32)
+        tbl[torch.rand(27, n, generator=g) < 0.5] = -1
+        tbl = tbl.to(d)
+    m = tbl.shape[1]
+    torch.manual_seed(n)
+    x = torch.randn(m, 16, device=d).bfloat16()
+    dy = torch.randn(m, 16, device=d).bfloat16()
+    tb = ops.tilebook_build(tbl)
+    dw = ops.spconv_wgrad_multi([(x, dy, tbl, m, None, None, tb)])[0]
+    t = tbl.cpu().long()
+    ref = torch.zeros(27, 16, 16, dtype=torch.float64)
+    for o in range(27):
+        sel = t[o] >= 0
+        ref[o] = x.double().cpu()[t[o][sel]].t() @ dy.double().cpu()[sel]
+    assert rel_err(dw.cpu(), ref) < 1e-4
+    assert rel_err(dw.cpu(), ops.spconv_wgrad(x, dy, tbl, m).cpu()) < 1e-4
 
 
 # ------------------------------------------------------------------ the step bench.py times == the in-line step

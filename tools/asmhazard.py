@@ -52,7 +52,7 @@ def main(path, name):
                     hazards.append((start + n + 1, t, sorted((src | dest) & flying)))
                 queue.append((dest, t, start + n + 1))
                 continue
-            if op.startswith("buffer_store") or op.startswith("global_store"):
+            if op.startswith("buffer_store") or op.startswith("global_store"):  # (asm or compiler-issued: both count)
                 if regs(t) & flying:
                     hazards.append((start + n + 1, t, sorted(regs(t) & flying)))
                 queue.append((set(), t, start + n + 1))
