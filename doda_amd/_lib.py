@@ -81,6 +81,8 @@ _SIGNATURES = {
     "doda_spconv_set_wlds_kernel": (None, [c_i32]),
     "doda_spconv_set_dma_kernel": (None, [c_i32]),
     "doda_spconv_set_wdma_kernel": (None, [c_i32]),
+    "doda_debug_dma_stamps": (c_i32, [c_vp]),
+    "doda_debug_wdma_stamps": (c_i32, [c_vp]),
     "doda_spconv_bwd_tile_workspace_bytes": (c_sz, []),
     "doda_spconv_bwd_tile_bf16": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp,
                                           c_sz, c_vp, c_vp]),

@@ -77,6 +77,13 @@ __device__ __forceinline__ void astore128(const u32x4 &v, unsigned voff, const u
     asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(v), "v"(voff), "s"(rs) : "memory");
 }
 
+// phase time stamps of one workgroup (DODA_DMA_DBG bit 7; tools/dmastamps.py): [wave 0 | wave 5][iteration][phase]
+__device__ unsigned long long g_dm_stamps[2 * 16 * 8];
+__device__ __forceinline__ void dm_stamp(int dbg, int wid, int j, int phase) {
+    if ((dbg & 128) && blockIdx.x == 8 && (wid == 0 || wid == 5) && j < 16 && (threadIdx.x & 63) == 0)
+        g_dm_stamps[((wid ? 1 : 0) * 16 + j) * 8 + phase] = __builtin_amdgcn_s_memtime();
+}
+
 struct DmList { u32x4 rid; };                 // list entries of this lane's four row pieces (one 16-byte load)
 struct DmEpi { u32x2 res[2], bnx[2]; };       // epilogue operands: four bf16 channels of two rows
 
@@ -273,8 +280,10 @@ __global__ __launch_bounds__(512) void conv_dma16(const void *__restrict__ x, un
                 mma_bf16_k32(acc[1], wr[u], xa[1]);
             }
         }
+        dm_stamp(dbg, wid, j, 3);
         issue_list(j + 4, lnew);
         issue_epi(j + 2, enew);
+        dm_stamp(dbg, wid, j, 4);
         if (dbg & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (ablation: no overlap across iterations)
         // ---- epilogue: lane (i, g) holds output channels 4g .. 4g+3 of rows row0 + 16 s + i ----
         const unsigned col = 4u * (unsigned)g;
@@ -325,13 +334,14 @@ __global__ __launch_bounds__(512) void conv_dma16(const void *__restrict__ x, un
             astore128(__builtin_bit_cast(u32x4, a1), so, rs_st);
             astore128(__builtin_bit_cast(u32x4, a2), so + (so == OOB ? 0u : 64u), rs_st);
         }
+        dm_stamp(dbg, wid, j, 5);
     };
     auto dummy_stores = [&]() {
 #pragma unroll
         for (int k = 0; k < N_S; ++k) astore64((u32x2){0u, 0u}, OOB, rs_y);
     };
     // a tile without a list (more than TB_UMAX distinct rows) carries -2 in every entry
-    auto no_list = [&](const DmList &l) { return __builtin_amdgcn_readfirstlane((int)l.rid[0]) == -2; };
+    auto no_list = [&](const DmList &l) { return __builtin_amdgcn_readfirstlane((int)l.rid[0]) == -2 && !(dbg & 64); };
 
     // ---- prologue: the queue is given the shape of two past iterations (with stores that land nowhere), so that
     // ONE wait constant serves every iteration ----
@@ -361,25 +371,36 @@ __global__ __launch_bounds__(512) void conv_dma16(const void *__restrict__ x, un
     // is landing, list(j+4) is requested; operands likewise), written out three times so that no register holding a
     // load in flight is ever copied.
     for (int j = 0; j < nt_w; j += 3) {
+        dm_stamp(dbg, wid, j, 0);
         dm_wait<N_WAIT>();
+        dm_stamp(dbg, wid, j, 1);
         dm_tie(lc, ea);                                  // list(j+2), operands(j)
         dm_barrier();
+        dm_stamp(dbg, wid, j, 2);
         { const bool ov2 = no_list(lc); iteration(j, ov0, lc, lb, ea, ec); ov0 = ov1; ov1 = ov2; }
         if (j + 1 >= nt_w) break;
+        dm_stamp(dbg, wid, j + 1, 0);
         dm_wait<N_WAIT>();
+        dm_stamp(dbg, wid, j + 1, 1);
         dm_tie(la, eb);                                  // list(j+3), operands(j+1)
         dm_barrier();
+        dm_stamp(dbg, wid, j + 1, 2);
         { const bool ov2 = no_list(la); iteration(j + 1, ov0, la, lc, eb, ea); ov0 = ov1; ov1 = ov2; }
         if (j + 2 >= nt_w) break;
+        dm_stamp(dbg, wid, j + 2, 0);
         dm_wait<N_WAIT>();
+        dm_stamp(dbg, wid, j + 2, 1);
         dm_tie(lb, ec);                                  // list(j+4), operands(j+2)
         dm_barrier();
+        dm_stamp(dbg, wid, j + 2, 2);
         { const bool ov2 = no_list(lb); iteration(j + 2, ov0, lb, la, ec, eb); ov0 = ov1; ov1 = ov2; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // loads still in flight target registers and LDS of this workgroup
 }
 
-bool g_use_dma = !(getenv("DODA_NO_DMA") && getenv("DODA_NO_DMA")[0] == '1');   // doda_spconv_set_dma_kernel / DODA_NO_DMA=1 (A/B measurements)
+// OFF by default: measured on MI355X (gpurun_out / DESIGN.md §9) the pipeline equals conv_tile on the plain kernel (29 us cold)
+// and loses with the statistics epilogue (43 against 33 us); doda_spconv_set_dma_kernel(1) / DODA_DMA=1 switch it on
+bool g_use_dma = getenv("DODA_DMA") && getenv("DODA_DMA")[0] == '1';
 
 }  // namespace
 
@@ -406,3 +427,9 @@ int launch_conv16(const void *x, unsigned xb, const void *wp, unsigned wpb, cons
 }  // namespace doda_dma
 
 extern "C" void doda_spconv_set_dma_kernel(int32_t on) { doda_dma::set_enabled(on != 0); }
+
+// measurement aid: the phase time stamps DODA_DMA_DBG=128 makes workgroup 8 of conv_dma16 record (2 x 16 x 8 uint64)
+extern "C" int doda_debug_dma_stamps(unsigned long long *dst_h) {
+    return hipMemcpyFromSymbol(dst_h, HIP_SYMBOL(g_dm_stamps), sizeof(unsigned long long) * 2 * 16 * 8) == hipSuccess ? DODA_OK
+                                                                                                                   : DODA_ERR_LAUNCH;
+}

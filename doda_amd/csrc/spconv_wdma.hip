@@ -30,18 +30,23 @@
 
 namespace {
 
-constexpr int WD_WAVES = 8;
+constexpr int WD_WAVES = 16;
 constexpr int WD_ROWS_BYTES = (TB_UMAX + 1) * 32;     // slot 0: the shared zero row
 constexpr int WD_LIDX_BYTES = 16384;                  // 27 x 256 x 2 = 13824, rounded up to whole 1 KB DMA pieces
 constexpr int WD_DY_BYTES = TB_T * 32;
 constexpr int WD_BUF_BYTES = WD_ROWS_BYTES + WD_LIDX_BYTES + WD_DY_BYTES;
-constexpr int WD_NPIECE = 4 + 2 + 1;                  // DMA instructions per wave and tile: rows, index strip, dy
 constexpr int WD_UNITS = 2 * TB_K;                    // (offset, half of the k-steps)
-constexpr int WD_MAX_UNITS = (WD_UNITS + WD_WAVES - 1) / WD_WAVES;   // 7
+constexpr int WD_MAX_UNITS = (WD_UNITS + WD_WAVES - 1) / WD_WAVES;   // 4
 constexpr int WD_MAX_JOBS = 16;
 static_assert(WD_BUF_BYTES % 16 == 0 && 2 * WD_BUF_BYTES + 64 <= 160 * 1024, "two tile buffers per CU");
 static_assert(WD_UNITS * 256 * 4 <= WD_BUF_BYTES, "the final exchange re-uses ONE tile buffer (the other may be a DMA target)");
-static_assert(WD_NPIECE == WD_MAX_UNITS, "one DMA piece per unit of a wave");
+
+// phase time stamps of one workgroup (DODA_DMA_DBG bit 7; tools/wdmastamps.py): [wave 0 | wave 5][item][phase]
+__device__ unsigned long long g_wd_stamps[2 * 16 * 8];
+__device__ __forceinline__ void wd_stamp(int dbg, int wid, int item, int phase) {
+    if ((dbg & 128) && blockIdx.x == 8 && (wid == 0 || wid == 5) && item < 16 && (threadIdx.x & 63) == 0)
+        g_wd_stamps[((wid ? 1 : 0) * 16 + item) * 8 + phase] = __builtin_amdgcn_s_memtime();
+}
 
 struct WdJob { const void *x, *dy; float *part; };    // part: [groups][27][256] of this layer
 struct WdJobs { int n; WdJob j[WD_MAX_JOBS]; };
@@ -83,14 +88,13 @@ __device__ __forceinline__ bf16x8 wd_pack_hi16(const f32x4 &d0, const f32x4 &d1)
     return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(512) void wgrad_dma16(const WdJobs jobs, unsigned feat_bytes, const int32_t *__restrict__ tbl,
-                                                   int ld, int n, const TileBookView tb) {
+__global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned feat_bytes, const int32_t *__restrict__ tbl,
+                                                    int ld, int n, const TileBookView tb, const int dbg) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WD_BUF_BYTES];
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, i = lane & 15, g = lane >> 4;
     const u32x4 rs_ul = wd_rsrc(tb.ulist, (unsigned)tb.nt * (unsigned)TB_UMAX * 4u);
     const u32x4 rs_li = wd_rsrc(tb.lidx, (unsigned)tb.nt * (unsigned)(TB_K * TB_T * 2));
-    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void *)tbl, 0, (unsigned)TB_K * (unsigned)ld * 4u, 0x00020000);
 
     // persistent schedule: XCD (blockIdx & 7) owns one contiguous range of tiles, its L workgroups stride it
     const int L = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -98,12 +102,11 @@ __global__ __launch_bounds__(512) void wgrad_dma16(const WdJobs jobs, unsigned f
     const int lo = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
     const int cnt = qn + (xcd < rn ? 1 : 0);
     const int nt_w = slot < cnt ? (cnt - slot + L - 1) / L : 0;      // tiles of this workgroup (per layer)
-    auto tile_of = [&](int j) { return lo + slot + j * L; };
     const int n_items = nt_w * jobs.n;                               // (layer, tile) items, layer-major
     if (nt_w == 0) {   // more workgroups than tiles: this one still owns a partial per layer
         for (int job = 0; job < jobs.n; ++job) {
             float *dst = jobs.j[job].part + (size_t)blockIdx.x * (TB_K * 256);
-            for (int e = tid; e < TB_K * 256; e += 512) dst[e] = 0.f;
+            for (int e = tid; e < TB_K * 256; e += 1024) dst[e] = 0.f;
         }
         return;
     }
@@ -123,30 +126,41 @@ __global__ __launch_bounds__(512) void wgrad_dma16(const WdJobs jobs, unsigned f
 
     const unsigned smem_base = (unsigned)(uintptr_t)smem;
     const unsigned src_half = (unsigned)((lane & 1) ^ ((lane >> 4) & 1)) * 16u;   // half-row swizzle (spconv_dma.hip)
-    auto issue_list = [&](int item, u32x4 &rid) {
-        const bool ok = item < n_items;
-        const int j = ok ? item % nt_w : 0;
-        wd_aload128(rid, ok ? (unsigned)tile_of(j) * (unsigned)(TB_UMAX * 4) + (unsigned)(wid * 32 + (lane >> 1)) * 16u : OOB, rs_ul);
+    // Staging of one item by 16 waves.  Wave w moves two of the 32 row pieces — pieces (kb*8 + w8) and ((kb+1)*8 + w8)
+    // with w8 = w & 7, kb = 2 (w >> 3): in the list's storage order (tb_upos) their entries are one 8-byte load per
+    // lane —, one of the 16 index-strip pieces, and (waves 0..7) one of the 8 dy pieces.
+    const int w8 = wid & 7, kb = (wid >> 3) * 2;
+    struct Where { int job; unsigned tile; bool ok; };
+    auto where = [&](int item) {     // (one scalar division per item, not per piece)
+        Where q;
+        q.ok = item < n_items;
+        q.job = q.ok ? item / nt_w : 0;
+        q.tile = (unsigned)(lo + slot + (q.ok ? item - q.job * nt_w : 0) * L);
+        return q;
     };
-    // DMA piece p (0..6) of item `item` into buffer item & 1: rows of the list (4), index strip (2), dy rows (1)
-    auto issue_piece = [&](int item, int p, const u32x4 &rid) {
-        const bool ok = item < n_items;
-        const int job = ok ? item / nt_w : 0, j = ok ? item % nt_w : 0;
+    auto issue_list = [&](const Where &q, u32x2 &rid) {
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(rid)
+                     : "v"(q.ok ? q.tile * (unsigned)(TB_UMAX * 4) + (unsigned)((w8 * 32 + (lane >> 1)) * 4 + kb) * 4u : OOB), "s"(rs_ul)
+                     : "memory");
+    };
+    auto issue_rows = [&](const Where &q, int item, int k, const u32x2 &rid) {      // k = 0, 1
         const unsigned buf = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
-        const unsigned tile = (unsigned)tile_of(j);
-        if (p < 4) {
-            const unsigned r = p == 0 ? rid[0] : p == 1 ? rid[1] : p == 2 ? rid[2] : rid[3];
-            const u32x4 rs_x = wd_rsrc(jobs.j[job].x, feat_bytes);
-            wd_dma16(buf + 32u + (unsigned)((p * WD_WAVES + wid) * 1024), ok ? r * 32u + src_half : OOB, rs_x);
-        } else if (p < 6) {
-            const unsigned pc = (unsigned)(((p - 4) * WD_WAVES + wid) * 64 + lane);
-            wd_dma16(buf + (unsigned)WD_ROWS_BYTES + (unsigned)(((p - 4) * WD_WAVES + wid) * 1024),
-                     ok ? tile * (unsigned)(TB_K * TB_T * 2) + pc * 16u : OOB, rs_li);
-        } else {
-            const u32x4 rs_dy = wd_rsrc(jobs.j[job].dy, feat_bytes);
+        const u32x4 rs_x = wd_rsrc(jobs.j[q.job].x, feat_bytes);
+        // an absent entry is negative: its row offset is out of range and lands as zeros
+        wd_dma16(buf + 32u + (unsigned)(((kb + k) * 8 + w8) * 1024), q.ok ? rid[k] * 32u + src_half : OOB, rs_x);
+    };
+    auto issue_strip = [&](const Where &q, int item) {
+        const unsigned buf = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
+        wd_dma16(buf + (unsigned)WD_ROWS_BYTES + (unsigned)(wid * 1024),
+                 q.ok ? q.tile * (unsigned)(TB_K * TB_T * 2) + (unsigned)(wid * 64 + lane) * 16u : OOB, rs_li);
+    };
+    auto issue_dy = [&](const Where &q, int item) {
+        if (wid < 8) {      // (wave-uniform; every wait in this kernel is vmcnt(0), so waves need not issue equal counts)
+            const unsigned buf = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
+            const u32x4 rs_dy = wd_rsrc(jobs.j[q.job].dy, feat_bytes);
             // rows past n: out of range -> zeros
             wd_dma16(buf + (unsigned)(WD_ROWS_BYTES + WD_LIDX_BYTES) + (unsigned)(wid * 1024),
-                     ok ? (tile * (unsigned)TB_T + (unsigned)(wid * 32 + (lane >> 1))) * 32u + (unsigned)(lane & 1) * 16u : OOB, rs_dy);
+                     q.ok ? (q.tile * (unsigned)TB_T + (unsigned)(wid * 32 + (lane >> 1))) * 32u + (unsigned)(lane & 1) * 16u : OOB, rs_dy);
         }
     };
 
@@ -156,23 +170,30 @@ __global__ __launch_bounds__(512) void wgrad_dma16(const WdJobs jobs, unsigned f
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
     // prologue: list of items 0 and 1, DMA of item 0
-    u32x4 la, lb;
-    issue_list(0, la);
-    issue_list(1, lb);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(la), "+v"(lb) : : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // zero rows written
-#pragma unroll
-    for (int p = 0; p < WD_NPIECE; ++p) issue_piece(0, p, la);
+    u32x2 la, lb;
+    {
+        const Where q0 = where(0), q1 = where(1);
+        issue_list(q0, la);
+        issue_list(q1, lb);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(la), "+v"(lb) : : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // zero rows written
+        issue_rows(q0, 0, 0, la);
+        issue_rows(q0, 0, 1, la);
+        issue_strip(q0, 0);
+        issue_dy(q0, 0);
+    }
 
     // body(item, lnext = list(item+1) [landed], lnew <- list(item+2))
-    auto body = [&](int item, bool no_list, const u32x4 &lnext, u32x4 &lnew) {
-        const int job = item / nt_w, j = item - job * nt_w;
-        const int tile = tile_of(j), t0 = tile * TB_T;
+    auto body = [&](int item, bool no_list, const u32x2 &lnext, u32x2 &lnew) {
+        const Where qc = where(item), q1 = where(item + 1), q2 = where(item + 2);
+        const int t0 = (int)qc.tile * TB_T;
         const unsigned char *buf = smem + (item & 1) * WD_BUF_BYTES;
         const unsigned rows_base = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
         const unsigned short *lidx_s = reinterpret_cast<const unsigned short *>(buf + WD_ROWS_BYTES);
         const unsigned dy_base = rows_base + (unsigned)(WD_ROWS_BYTES + WD_LIDX_BYTES);
-        const unsigned short *xg = reinterpret_cast<const unsigned short *>(jobs.j[job].x);
+        const unsigned short *xg = reinterpret_cast<const unsigned short *>(jobs.j[qc.job].x);
+        wd_stamp(dbg, wid, item, 2);
+        issue_list(q2, lnew);        // first thing: it has the whole tile to land (lnew held list(item): dead)
         // ---- dy fragments of the wave's four k-steps (every unit of wave w covers the half h = w & 1 of the tile):
         // channel i of rows 32 ks + 8 g + 0..7 ----
         const int q4 = i >> 2, c4 = i & 3, hw = wid & 1;
@@ -184,62 +205,111 @@ __global__ __launch_bounds__(512) void wgrad_dma16(const WdJobs jobs, unsigned f
             bt[kk] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bt[0]), "+v"(bt[1]), "+v"(bt[2]), "+v"(bt[3]) : : "memory");
+        wd_stamp(dbg, wid, item, 3);
         // gathered x slices: lane (i, g) reads the half g & 1 of the row of output row 32 ks + 8 (i >> 2) + 4 (g >> 1) + (i & 3)
         const int rl = 8 * (i >> 2) + 4 * (g >> 1) + (i & 3);
         const unsigned hsel = (unsigned)(g & 1);
-        // (two copies of the unit loop: a slice that may come from a compiler-tracked global load at a join point makes
-        // hipcc wait vmcnt(0) before every MFMA there — on the list path that would drain the DMA in flight)
-        auto step = [&](int m, int kk, const u32x4 &v) {
-            const bf16x8 a = __builtin_bit_cast(bf16x8, v);
-            const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[0], zero, 0, 0, 0);
-            const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[1], zero, 0, 0, 0);
-            const bf16x8 at = wd_pack_hi16(d0, d1);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at, bt[kk], acc[m], 0, 0, 0);
-        };
         if (!no_list) {
+            // Branch-free and software-pipelined.  A step's chain (local index -> row slice -> two transposing MFMAs ->
+            // repack -> contraction) is ~500 cycles of latency: all local indices first (the four subtile entries of a
+            // lane's row in a 64-row group are one 8-byte read: two k-steps each), the row slices four steps ahead,
+            // and the transposing MFMAs of step s+1 issued BEFORE the repack + contraction of step s, so the matrix
+            // pipe works through the wait states an MFMA result needs before the VALU may read it.
+            constexpr int NS = WD_MAX_UNITS * 4;
+            const int sub = rl >> 4;                                   // the lane's subtile inside a 32-row k-step (0 / 1)
+            unsigned lsel[NS];
 #pragma unroll
             for (int m = 0; m < WD_MAX_UNITS; ++m) {
-                const int unit = wid + WD_WAVES * m;            // (offset o, half h of the k-steps)
-                // the next item's DMA pieces, one per unit, each wave starting at another piece
-                issue_piece(item + 1, (m + wid) % WD_MAX_UNITS, lnext);
-                if (unit < WD_UNITS) {
-                    const int o = unit >> 1;
+                const int unit = wid + WD_WAVES * m;
+                const int o = unit < WD_UNITS ? unit >> 1 : 0;          // (units past the end: any valid strip, results dropped)
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int r = 32 * (4 * hw + kk) + rl;
-                        const unsigned l = lidx_s[o * TB_T + tb_pos(r)];
-                        if (__builtin_amdgcn_ballot_w64(l != 0u) == 0ull) continue;      // no pair of this offset in these 32 rows
-                        step(m, kk, *reinterpret_cast<const u32x4 *>(buf + l * 32u + ((hsel ^ (((l - 1u) >> 3) & 1u)) << 4)));
-                    }
+                for (int kp = 0; kp < 2; ++kp) {
+                    // rows 64 (2 hw + kp) + 32 kk' + rl: entries 2 kk' + sub of the group's strip position 4 (rl & 15)
+                    const u32x2 v = *reinterpret_cast<const u32x2 *>(lidx_s + o * TB_T + (2 * hw + kp) * 64 + 4 * (rl & 15));
+                    const unsigned lo16 = sub ? (v[0] >> 16) : (v[0] & 0xffffu), hi16 = sub ? (v[1] >> 16) : (v[1] & 0xffffu);
+                    lsel[m * 4 + 2 * kp] = unit < WD_UNITS ? lo16 : 0u;
+                    lsel[m * 4 + 2 * kp + 1] = unit < WD_UNITS ? hi16 : 0u;
                 }
+            }
+            wd_stamp(dbg, wid, item, 4);
+            auto fetch = [&](unsigned l) {
+                return *reinterpret_cast<const u32x4 *>(buf + l * 32u + ((hsel ^ (((l - 1u) >> 3) & 1u)) << 4));
+            };
+            u32x4 xr[4];
+            xr[0] = fetch(lsel[0]);
+            xr[1] = fetch(lsel[1]);
+            xr[2] = fetch(lsel[2]);
+            f32x4 d0, d1;
+            {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, xr[0]);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[0], zero, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[1], zero, 0, 0, 0);
+            }
+            auto one_step = [&](int st) {
+                const int m = st >> 2, kk = st & 3;
+                // the next item's DMA: in the FIRST steps of the tile (two buffers: it needs the rest of the tile to land),
+                // odd and even waves on alternating steps
+                if (st == (wid & 1)) issue_rows(q1, item + 1, 0, lnext);
+                if (st == 2 + (wid & 1)) issue_rows(q1, item + 1, 1, lnext);
+                if (st == 4 + (wid & 1)) issue_strip(q1, item + 1);
+                if (st == 6 + (wid & 1)) issue_dy(q1, item + 1);
+                if (st + 3 < NS) xr[(st + 3) & 3] = fetch(lsel[st + 3]);
+                f32x4 n0 = zero, n1 = zero;
+                if (st + 1 < NS) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, xr[(st + 1) & 3]);
+                    n0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[0], zero, 0, 0, 0);
+                    n1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[1], zero, 0, 0, 0);
+                }
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd_pack_hi16(d0, d1), bt[kk], acc[m], 0, 0, 0);
+                d0 = n0;
+                d1 = n1;
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            constexpr int LAST_FULL = (WD_UNITS / WD_WAVES) * 4;       // steps every wave has (units 0 .. 47)
+#pragma unroll
+            for (int st = 0; st < LAST_FULL; ++st) one_step(st);
+            if (wid + WD_WAVES * (WD_MAX_UNITS - 1) < WD_UNITS) {       // the waves that own a unit 48 .. 53
+#pragma unroll
+                for (int st = LAST_FULL; st < NS; ++st) one_step(st);
             }
         } else {
             // a tile without a list (more than TB_UMAX distinct rows; none at 2 cm): slices through the dense table
-#pragma unroll
-            for (int p = 0; p < WD_NPIECE; ++p) issue_piece(item + 1, p, lnext);
+            issue_rows(q1, item + 1, 0, lnext);
+            issue_rows(q1, item + 1, 1, lnext);
+            issue_strip(q1, item + 1);
+            issue_dy(q1, item + 1);
 #pragma unroll 1
             for (int m = 0; m < WD_MAX_UNITS; ++m) {
                 const int unit = wid + WD_WAVES * m;
                 if (unit >= WD_UNITS) break;
                 const int o = unit >> 1;
                 f32x4 part = {0.f, 0.f, 0.f, 0.f};
+                // all four table entries, then all four slices: two round trips per unit
+                int gi[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int r = 32 * (4 * hw + kk) + rl;
-                    const int gi = t0 + r < n ? tbl[(size_t)o * ld + (size_t)(t0 + r)] : -1;
-                    u32x4 v = {0u, 0u, 0u, 0u};
-                    if (gi >= 0) v = *reinterpret_cast<const u32x4 *>(xg + (size_t)gi * 16 + hsel * 8);
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, v);
-                    const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[0], zero, 0, 0, 0);
-                    const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[1], zero, 0, 0, 0);
-                    part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd_pack_hi16(d0, d1), bt[kk], part, 0, 0, 0);
+                    gi[kk] = t0 + r < n ? tbl[(size_t)o * ld + (size_t)(t0 + r)] : -1;
+                }
+                u32x4 v[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    v[kk] = (u32x4){0u, 0u, 0u, 0u};
+                    if (gi[kk] >= 0) v[kk] = *reinterpret_cast<const u32x4 *>(xg + (size_t)gi[kk] * 16 + hsel * 8);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, v[kk]);
+                    const f32x4 e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[0], zero, 0, 0, 0);
+                    const f32x4 e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[1], zero, 0, 0, 0);
+                    part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd_pack_hi16(e0, e1), bt[kk], part, 0, 0, 0);
                 }
 #pragma unroll
                 for (int mm = 0; mm < WD_MAX_UNITS; ++mm)
                     if (mm == m) acc[mm] += part;      // (static indices: acc[] stays in registers)
             }
         }
-        issue_list(item + 2, lnew);
+        wd_stamp(dbg, wid, item, 5);
     };
 
     // the layer's partial: units -> LDS, halves added, one [27][256] block per workgroup
@@ -258,7 +328,7 @@ __global__ __launch_bounds__(512) void wgrad_dma16(const WdJobs jobs, unsigned f
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         float *dst = jobs.j[job].part + (size_t)blockIdx.x * (TB_K * 256);
-        for (int e = tid; e < TB_K * 256; e += 512) {
+        for (int e = tid; e < TB_K * 256; e += 1024) {
             const int o = e >> 8, c = e & 255;
             dst[e] = ex[(2 * o) * 256 + c] + ex[(2 * o + 1) * 256 + c];
         }
@@ -267,29 +337,32 @@ __global__ __launch_bounds__(512) void wgrad_dma16(const WdJobs jobs, unsigned f
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
-    bool nl_cur = __builtin_amdgcn_readfirstlane((int)la[0]) == -2;      // tile 0 has no list
+    bool nl_cur = __builtin_amdgcn_readfirstlane((int)la[0]) == -2 && !(dbg & 64);      // tile 0 has no list
     for (int item = 0; item < n_items; item += 2) {
         // everything issued so far has landed: DMA(item), list(item+1)
+        wd_stamp(dbg, wid, item, 0);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(lb) : : "memory");
+        wd_stamp(dbg, wid, item, 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         {
-            const bool nl_next = __builtin_amdgcn_readfirstlane((int)lb[0]) == -2;
+            const bool nl_next = __builtin_amdgcn_readfirstlane((int)lb[0]) == -2 && !(dbg & 64);
             body(item, nl_cur, lb, la);
             nl_cur = nl_next;
         }
         if ((item + 1) % nt_w == 0) flush(item / nt_w, item & 1);
         if (item + 1 >= n_items) break;
+        wd_stamp(dbg, wid, item + 1, 0);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(la) : : "memory");
+        wd_stamp(dbg, wid, item + 1, 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         {
-            const bool nl_next = __builtin_amdgcn_readfirstlane((int)la[0]) == -2;
+            const bool nl_next = __builtin_amdgcn_readfirstlane((int)la[0]) == -2 && !(dbg & 64);
             body(item + 1, nl_cur, la, lb);
             nl_cur = nl_next;
         }
         if ((item + 2) % nt_w == 0) flush((item + 1) / nt_w, (item + 1) & 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    (void)rs_t;
 }
 
 // dw[job][e] (+)= sum over workgroups of part[job][wg][e], fixed order.  One workgroup per 32 outputs and layer; its 16
@@ -355,7 +428,8 @@ int launch(const void *const *x, const void *const *dy, float *const *dw, const 
             jobs.j[k] = WdJob{x[first + k], dy[first + k], p};
             rj.j[k] = WdRJob{p, dw[first + k], accumulate[first + k], 0};
         }
-        hipLaunchKernelGGL(wgrad_dma16, dim3(groups), dim3(512), 0, s, jobs, (unsigned)((size_t)n_rows * 32), tbl, ld, n_rows, tb);
+        static const int dbg = getenv("DODA_DMA_DBG") ? atoi(getenv("DODA_DMA_DBG")) : 0;   // ablation switches (measurements only)
+        hipLaunchKernelGGL(wgrad_dma16, dim3(groups), dim3(1024), 0, s, jobs, (unsigned)((size_t)n_rows * 32), tbl, ld, n_rows, tb, dbg);
         hipLaunchKernelGGL(wgrad_dma_reduce, dim3(TB_K * 256 / 32, nj), dim3(512), 0, s, rj, groups);
     }
     return doda_check_launch();
@@ -364,3 +438,9 @@ int launch(const void *const *x, const void *const *dy, float *const *dw, const 
 }  // namespace doda_wdma
 
 extern "C" void doda_spconv_set_wdma_kernel(int32_t on) { doda_wdma::set_enabled(on != 0); }
+
+// measurement aid: kernel 0 = conv_dma16 (spconv_dma.hip), 1 = wgrad_dma16
+extern "C" int doda_debug_wdma_stamps(unsigned long long *dst_h) {
+    return hipMemcpyFromSymbol(dst_h, HIP_SYMBOL(g_wd_stamps), sizeof(unsigned long long) * 2 * 16 * 8) == hipSuccess ? DODA_OK
+                                                                                                                   : DODA_ERR_LAUNCH;
+}

@@ -281,9 +281,13 @@ void doda_spconv_set_tile_kernel(int32_t on);
 /* A/B switch: 0 = the 48 -> 48 channel layers stay on the streaming-weights kernel instead of the weights-in-LDS
  * one.  Default 1. */
 void doda_spconv_set_wlds_kernel(int32_t on);
-/* A/B switch: 0 = the bf16 16 -> 16 layers with a tilebook stay on the three-workgroups-per-CU tile kernel instead of
- * the one-workgroup-per-CU LDS-DMA pipeline (spconv_dma.hip).  Default 1. */
+/* A/B switch: 1 = the bf16 16 -> 16 layers with a tilebook take the one-workgroup-per-CU LDS-DMA pipeline
+ * (spconv_dma.hip) instead of the three-workgroups-per-CU tile kernel.  Default 0 (it measured no faster). */
 void doda_spconv_set_dma_kernel(int32_t on);
+/* Measurement aid (tools/dmastamps.py): shader-clock stamps of the pipeline phases of one conv_dma16 workgroup, recorded
+ * when DODA_DMA_DBG=128 is set in the environment; dst_h: host array of 2 * 16 * 8 uint64. */
+int doda_debug_dma_stamps(unsigned long long *dst_h);
+int doda_debug_wdma_stamps(unsigned long long *dst_h);   /* the same for wgrad_dma16 */
 /* A/B switch: 0 = weight-gradient jobs ignore their tilebook (pair-list / gather-table kernels).  Default 1. */
 void doda_spconv_set_wdma_kernel(int32_t on);
 size_t doda_spconv_stats_capacity(int32_t n_out);

@@ -120,6 +120,57 @@ def test_headline_kernels_vs_oracle_on_oracle_pairs(native_lib, oracle, cin, cou
         assert torch.equal(again, outs[0])                                  # deterministic
 
 
+@pytest.mark.parametrize("m,layout", [(40000, 0), (40000, 2), (777, 0), (70000, 0)])
+def test_dma_pipeline_kernel_matches_oracle_and_tile_kernel(native_lib, m, layout):
+    """conv_dma16 (spconv_dma.hip; off by default, doda_spconv_set_dma_kernel): the hand-counted LDS-DMA pipeline
+    against the fp64 definition over the table and against conv_tile — plain, with residual, and with the statistics
+    epilogue in both forms (every vmcnt constant of the pipeline is exercised by the 3 .. 35 tiles per workgroup)."""
+    from doda_amd import ops
+    from doda_amd._lib import lib
+    d = dev()
+    shape, batch = [80, 70, 60], 2
+    idx = torch.from_numpy(_raster_scene(5 + m, m, batch, shape)).to(d)
+    tbl = ops.rulebook_subm(idx, shape, batch, 3)
+    n = tbl.shape[1]
+    torch.manual_seed(m + layout)
+    x = torch.randn(n, 16, device=d).bfloat16()
+    res = torch.randn(n, 16, device=d).bfloat16()
+    bnx = torch.randn(n, 16, device=d).bfloat16()
+    w = (torch.randn(27, 16, 16, device=d) * 0.1).bfloat16().float()
+    tb = ops.tilebook_build(tbl)
+    bn = (bnx, torch.randn(16, device=d) * 0.1, torch.rand(16, device=d) + 0.5, torch.rand(16, device=d) + 0.5,
+          torch.randn(16, device=d) * 0.1, True)
+    t = tbl.cpu().long()
+    ref = torch.zeros(n, 16, dtype=torch.float64)
+    for o in range(27):
+        b = w.double().cpu()[o] if layout == 0 else w.double().cpu()[26 - o].t()
+        sel = t[o] >= 0
+        ref[sel] += x.double().cpu()[t[o][sel]] @ b
+
+    def run():
+        a = ops.spconv_gather(x, w, tbl, n, layout, 16, tilebook=tb)
+        b_, sb = ops.spconv_gather(x, w, tbl, n, layout, 16, tilebook=tb, residual=res, want_stats=True)
+        c, sc = ops.spconv_gather(x, w, tbl, n, layout, 16, tilebook=tb, want_stats=True, bn=bn)
+        torch.cuda.synchronize()
+        return a, b_, sb.sum(0), c, sc.sum(0)
+    try:
+        lib().doda_spconv_set_dma_kernel(1)
+        got = run()
+        again = run()
+    finally:
+        lib().doda_spconv_set_dma_kernel(0)
+    want = run()
+    assert rel_err(got[0].float().cpu(), ref) < 2.0 ** -7
+    assert rel_err(got[1].float().cpu(), ref + res.double().cpu()) < 2.0 ** -7
+    for g_, w_, a_ in zip(got, want, again):
+        assert torch.equal(g_, a_)                                            # repeatable bit for bit
+        if g_.dtype == torch.bfloat16:                                         # same sums, maybe another order: one rounding step
+            assert (g_ != w_).float().mean().item() < 0.02
+            assert ((g_.float() - w_.float()).abs() <= 2.0 ** -7 * w_.float().abs() + 1e-6).all()
+        else:
+            assert rel_err(g_.cpu(), w_.cpu()) < 1e-4
+
+
 @pytest.mark.parametrize("n,kind", [(255, "scene"), (300, "scene"), (3001, "scene"), (2000, "random")])
 def test_wgrad_tile_kernel_edges(native_lib, n, kind):
     """wgrad_dma16 on ragged sizes (fewer tiles than workgroups, a last tile of 44 / 185 rows) and on a table whose

@@ -32,8 +32,8 @@ for scenes in (4, 1):
     for dbg in (0, 15, 31, 16, 17, 32, 47, -1):
         env = dict(os.environ)
         if dbg < 0:
-            env["DODA_DMA_DBG"] = "0"; env["DODA_NO_DMA"] = "1"
+            env["DODA_DMA_DBG"] = "0"; env["DODA_DMA"] = "0"
         else:
-            env["DODA_DMA_DBG"] = str(dbg)
+            env["DODA_DMA_DBG"] = str(dbg); env["DODA_DMA"] = "1"
         r = subprocess.run([sys.executable, "-c", CODE, str(scenes)], env=env, capture_output=True, text=True)
         print(scenes, dbg, r.stdout.strip() or r.stderr[-500:], flush=True)
