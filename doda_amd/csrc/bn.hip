@@ -16,6 +16,7 @@
 // fragments, so every access is a contiguous wave-wide burst.  All reductions are fixed-order:
 // results are run-to-run deterministic.  Algorithmic bytes: fwd 3 passes, bwd 5 passes of M*C*s.
 #include "common.hpp"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -534,6 +535,185 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_final_stats(const float *__re
     *reinterpret_cast<f32x4 *>(coef + 2 * c + f * 4) = dd;
 }
 
+
+// ---- final + apply in ONE launch (round 3) ----------------------------------------------------------
+// The `final` kernels above are four to twelve blocks chasing L2 round trips: 6-7 us each, 75 of them per U-Net
+// step.  When the conv epilogue delivers few partial rows (the persistent tile kernels write ONE per workgroup:
+// <= 768 rows, ~100 KB) every workgroup of the apply pass can afford to reduce them itself — same rows, same
+// order, same fp64 combine in every workgroup, so all of them arrive at identical statistics — and the dependent
+// launch disappears.  A fixed grid of BN_FUSED_BLOCKS workgroups keeps the redundant reads (grid x partial bytes,
+// L2 hits) well below the tensor itself; mean / invstd / gamma / beta (or the backward coefficients) then sit in
+// LDS for the apply sweep instead of being re-read per element.  Workgroup 0 publishes the statistics.
+constexpr int BN_FUSED_BLOCKS = 256;
+constexpr int BN_FUSED_MAX_PARTIAL_BYTES = 160 * 1024;
+constexpr int BN_FUSED_MAX_C = 64;          // channels whose vectors fit the LDS arrays below
+
+// every thread's share of the partial rows of its fragment: thread = (row lane rl, fragment f); returns the totals of
+// fragment f in all threads with rl == 0 ... through LDS, fixed order
+__device__ __forceinline__ void fused_reduce(const float *__restrict__ stats, int rows, int c, int nf, int rpb,
+                                             double (*red)[8], double (&s1)[4], double (&s2)[4]) {
+    const int f = threadIdx.x % nf, rl = threadIdx.x / nf;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s1[q] = 0.0; s2[q] = 0.0; }
+    if (rl < rpb) {
+        int r = rl;
+        for (; r + 3 * rpb < rows; r += 4 * rpb) {      // four rows in flight
+            f32x4 a[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float *p = stats + (long long)(r + k * rpb) * 2 * c + f * 4;
+                a[k] = *reinterpret_cast<const f32x4 *>(p);
+                b[k] = *reinterpret_cast<const f32x4 *>(p + c);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { s1[q] += (double)a[k][q]; s2[q] += (double)b[k][q]; }
+        }
+        for (; r < rows; r += rpb) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(stats + (long long)r * 2 * c + f * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(stats + (long long)r * 2 * c + c + f * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s1[q] += (double)a[q]; s2[q] += (double)b[q]; }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { red[threadIdx.x][q] = s1[q]; red[threadIdx.x][4 + q] = s2[q]; }
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s1[q] = 0.0; s2[q] = 0.0; }
+        for (int k = 0; k < rpb; ++k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s1[q] += red[k * nf + f][q]; s2[q] += red[k * nf + f][4 + q]; }
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(BN_BLOCK) void bn_fused_fwd(const typename T::elem *__restrict__ x, long long n_frag, int nf,
+                                                         int rpb, const float *__restrict__ stats, int rows, int m,
+                                                         float eps, float momentum, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, float *__restrict__ mean,
+                                                         float *__restrict__ invstd, float *__restrict__ running_mean,
+                                                         float *__restrict__ running_var, long long *__restrict__ nbt,
+                                                         int relu, typename T::elem *__restrict__ y) {
+    __shared__ double red[BN_BLOCK][8];
+    __shared__ f32x4 v_mu[BN_FUSED_MAX_C / 4], v_is[BN_FUSED_MAX_C / 4];
+    const int c = nf * 4;
+    double s1[4], s2[4];
+    fused_reduce(stats, rows, c, nf, rpb, red, s1, s2);
+    if (threadIdx.x < nf) {
+        const int f = threadIdx.x;
+        f32x4 mu, is;
+        double dmu[4], dvar[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double d = s1[q] / m;
+            double var = s2[q] / m - d * d;
+            if (var < 0.0) var = 0.0;
+            dmu[q] = d;
+            dvar[q] = var;
+            mu[q] = (float)d;
+            is[q] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        v_mu[f] = mu;      // (the apply sweep evaluates (x - mean) * invstd * gamma + beta exactly as bn_apply does)
+        v_is[f] = is;
+        if (blockIdx.x == 0) {
+            *reinterpret_cast<f32x4 *>(mean + f * 4) = mu;
+            *reinterpret_cast<f32x4 *>(invstd + f * 4) = is;
+            if (running_mean) {
+                f32x4 rm = *reinterpret_cast<const f32x4 *>(running_mean + f * 4);
+                f32x4 rv = *reinterpret_cast<const f32x4 *>(running_var + f * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double unbiased = m > 1 ? dvar[q] * (double)m / (double)(m - 1) : dvar[q];
+                    rm[q] = (float)((1.0 - momentum) * (double)rm[q] + momentum * dmu[q]);
+                    rv[q] = (float)((1.0 - momentum) * (double)rv[q] + momentum * unbiased);
+                }
+                *reinterpret_cast<f32x4 *>(running_mean + f * 4) = rm;
+                *reinterpret_cast<f32x4 *>(running_var + f * 4) = rv;
+            }
+            if (f == 0 && nbt) *nbt = *nbt + 1;
+        }
+    }
+    __syncthreads();
+    for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < n_frag; e += (long long)gridDim.x * BN_BLOCK) {
+        const int f = (int)(e % nf);
+        const f32x4 v = T::load4(x + e * 4);
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
+        const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + f * 4);
+        f32x4 o = (v - v_mu[f]) * v_is[f] * ga + be;
+        if (relu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = o[q] > 0.f ? o[q] : 0.f;
+        }
+        T::store4(y + e * 4, o);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(BN_BLOCK) void bn_fused_bwd(const typename T::elem *__restrict__ x,
+                                                         const typename T::elem *__restrict__ dy, long long n_frag,
+                                                         int nf, int rpb, const float *__restrict__ stats, int rows,
+                                                         int m, const float *__restrict__ mean,
+                                                         const float *__restrict__ invstd,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                         int relu, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                         typename T::elem *__restrict__ dx,
+                                                         const typename T::elem *__restrict__ add) {
+    __shared__ double red[BN_BLOCK][8];
+    __shared__ f32x4 v_a[BN_FUSED_MAX_C / 4], v_b[BN_FUSED_MAX_C / 4], v_d[BN_FUSED_MAX_C / 4];
+    const int c = nf * 4;
+    double s1[4], s2[4];
+    fused_reduce(stats, rows, c, nf, rpb, red, s1, s2);
+    if (threadIdx.x < nf) {
+        const int f = threadIdx.x;
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + f * 4);
+        f32x4 db, dg, a, bb, dd;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            db[q] = (float)s1[q];
+            dg[q] = (float)s2[q];
+            a[q] = ga[q] * is[q];
+            bb[q] = (float)(s1[q] / m);
+            dd[q] = (float)(s2[q] / m);
+        }
+        v_a[f] = a; v_b[f] = bb; v_d[f] = dd;
+        if (blockIdx.x == 0) {
+            *reinterpret_cast<f32x4 *>(dbeta + f * 4) = db;
+            *reinterpret_cast<f32x4 *>(dgamma + f * 4) = dg;
+        }
+    }
+    __syncthreads();
+    for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < n_frag; e += (long long)gridDim.x * BN_BLOCK) {
+        const int f = (int)(e % nf);
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + f * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + f * 4);
+        const f32x4 xh = (T::load4(x + e * 4) - mu) * is;
+        f32x4 dz = T::load4(dy + e * 4);
+        if (relu) {
+            const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
+            const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + f * 4);
+            const f32x4 yv = xh * ga + be;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dz[q] = yv[q] > 0.f ? dz[q] : 0.f;
+        }
+        f32x4 o = v_a[f] * (dz - v_b[f] - xh * v_d[f]);
+        if (add) o += T::load4(add + e * 4);
+        T::store4(dx + e * 4, o);
+    }
+}
+
+inline bool fused_ok(int rows, int c) {
+    // OFF by default: measured in the U-Net step (same box, alternating runs) 7.7-7.8 ms against 6.45-6.54 ms — a
+    // 256-workgroup apply sweep is far below the HBM rate the 4096-block one reaches, and more workgroups multiply the
+    // redundant partial reads; DODA_BN_FUSED_FINAL=1 switches it on (kept for the parity tests and small tensors)
+    static const bool on = getenv("DODA_BN_FUSED_FINAL") && getenv("DODA_BN_FUSED_FINAL")[0] == '1';
+    return on && c <= BN_FUSED_MAX_C && c / 4 <= BN_BLOCK && (long long)rows * 2 * c * 4 <= BN_FUSED_MAX_PARTIAL_BYTES;
+}
+
 Geo make_geo(int c) {
     Geo g;
     g.nf = c / 4;
@@ -677,6 +857,13 @@ static int run_fwd_stats(const void *x_, int m, int c, const float *stats, int r
                          void *y_, float *mean, float *invstd, hipStream_t s) {
     typedef typename T::elem elem;
     const Geo g = make_geo(c);
+    if (fused_ok(rows, c)) {      // final + apply in one launch: few partial rows
+        const long long nfr = (long long)m * g.nf;
+        const int grid = (int)((nfr + BN_BLOCK - 1) / BN_BLOCK < BN_FUSED_BLOCKS ? (nfr + BN_BLOCK - 1) / BN_BLOCK : BN_FUSED_BLOCKS);
+        hipLaunchKernelGGL((bn_fused_fwd<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, nfr, g.nf, g.rpb, stats, rows,
+                           m, eps, momentum, gamma, beta, mean, invstd, rm, rv, nbt, relu, (elem *)y_);
+        return doda_check_launch();
+    }
     hipLaunchKernelGGL(bn_fwd_final_stats, dim3(c / 4), dim3(BN_BLOCK), 0, s, stats, rows, m, c, eps, momentum, mean,
                        invstd, rm, rv, nbt);
     const long long n_frag = (long long)m * g.nf;
@@ -692,6 +879,13 @@ static int run_bwd_stats(const void *x_, const void *dy_, int m, int c, const fl
                          const void *add_, void *dx_, float *dgamma, float *dbeta, float *coef, hipStream_t s) {
     typedef typename T::elem elem;
     const Geo g = make_geo(c);
+    if (fused_ok(rows, c)) {      // final + apply in one launch: few partial rows
+        const long long nfr = (long long)m * g.nf;
+        const int grid = (int)((nfr + BN_BLOCK - 1) / BN_BLOCK < BN_FUSED_BLOCKS ? (nfr + BN_BLOCK - 1) / BN_BLOCK : BN_FUSED_BLOCKS);
+        hipLaunchKernelGGL((bn_fused_bwd<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, (const elem *)dy_, nfr, g.nf,
+                           g.rpb, stats, rows, m, mean, invstd, gamma, beta, relu, dgamma, dbeta, (elem *)dx_, (const elem *)add_);
+        return doda_check_launch();
+    }
     hipLaunchKernelGGL(bn_bwd_final_stats, dim3(c / 4), dim3(BN_BLOCK), 0, s, stats, rows, m, c, invstd, gamma, dgamma,
                        dbeta, coef);
     const long long n_frag = (long long)m * g.nf;

@@ -69,7 +69,8 @@ __device__ __forceinline__ f32x4 epi_unpack(const u32x2 &v) {
 template <int S, bool OUT32, bool STATS>
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<OUT32> &pre, int row0, int i, int g, int wid,
                                               int nb0, int nc, int n_out, __amdgpu_buffer_rsrc_t rs_y,
-                                              const void *__restrict__ res, const EpiArgs &ep, int part) {
+                                              const void *__restrict__ res, const EpiArgs &ep, int part,
+                                              f32x4 *wg_acc = nullptr) {
     constexpr unsigned OSZ = OUT32 ? 4u : 2u;
     __shared__ f32x4 sred[STATS ? 4 : 1][2][4];
     const unsigned col = (unsigned)(nb0 * 16 + 4 * g);
@@ -121,9 +122,14 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<O
         if (wid == 0 && i == 15 && col < (unsigned)nc) {
             const f32x4 a1 = (sred[0][0][g] + sred[1][0][g]) + (sred[2][0][g] + sred[3][0][g]);
             const f32x4 a2 = (sred[0][1][g] + sred[1][1][g]) + (sred[2][1][g] + sred[3][1][g]);
-            float *dst = ep.stats + (long long)part * 2 * nc + col;
-            *reinterpret_cast<f32x4 *>(dst) = a1;
-            *reinterpret_cast<f32x4 *>(dst + nc) = a2;
+            if (wg_acc) {     // persistent caller: one partial row per WORKGROUP, summed over its tiles here (LDS, this lane only)
+                wg_acc[(nb0 * 2 + 0) * 4 + g] += a1;
+                wg_acc[(nb0 * 2 + 1) * 4 + g] += a2;
+            } else {
+                float *dst = ep.stats + (long long)part * 2 * nc + col;
+                *reinterpret_cast<f32x4 *>(dst) = a1;
+                *reinterpret_cast<f32x4 *>(dst + nc) = a2;
+            }
         }
     }
 }
@@ -155,6 +161,14 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
     constexpr int NLI = (TB_K * TB_T * 2 / 16 + 255) / 256;   // 16-byte pieces of the index strip per thread
     __shared__ __attribute__((aligned(16))) unsigned char rows_s[(CAP + 1) * RB];   // slot 0: the zero row
     __shared__ __attribute__((aligned(16))) unsigned short lidx_s[TB_K * TB_T];
+    // BatchNorm statistics: ONE partial row per persistent workgroup (its tiles summed in LDS by the lanes that used to
+    // write a row per tile): <= 768 rows instead of one per 256 output rows, few enough for the BatchNorm's apply pass
+    // to reduce them itself (bn.hip bn_fused_*: the separate `final` launch disappears)
+    constexpr int MAXNB = 8;
+    __shared__ f32x4 wg_acc[STATS ? MAXNB * 2 * 4 : 1];
+    if constexpr (STATS) {
+        if (threadIdx.x < MAXNB * 2 * 4) wg_acc[threadIdx.x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     const int tid0 = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
@@ -323,10 +337,24 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                     }
                 }
             }
-            tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, wid, nb0, nc, n_out, rs_y, res, ep, tile);
+            tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, wid, nb0, nc, n_out, rs_y, res, ep, tile, STATS ? wg_acc : nullptr);
             if (STATS && nb0 + 1 < NB) __syncthreads();   // the statistics scratch is reused by the next channel block
         }
         __syncthreads();   // the next tile overwrites the staged rows
+    }
+    if constexpr (STATS) {   // the workgroup's partial row (zeros when it had no tile)
+        __syncthreads();
+        const int lane = tid0 & 63, i = lane & 15, g = lane >> 4;
+        if (wid == 0 && i == 15) {
+            for (int nb0 = 0; nb0 < NB && nb0 < MAXNB; ++nb0) {
+                const int col = nb0 * 16 + 4 * g;
+                if (col < nc) {
+                    float *dst = ep.stats + (long long)blockIdx.x * 2 * nc + col;
+                    *reinterpret_cast<f32x4 *>(dst) = wg_acc[(nb0 * 2 + 0) * 4 + g];
+                    *reinterpret_cast<f32x4 *>(dst + nc) = wg_acc[(nb0 * 2 + 1) * 4 + g];
+                }
+            }
+        }
     }
 }
 
@@ -658,7 +686,8 @@ int doda_tile::launch_conv_tile(int mode, bool out32, const void *x, unsigned xb
     const int max_groups = mode == 0 ? BT_MAX_GROUPS : BT_MAX_GROUPS * 2 / 3;
     if (groups > max_groups) groups = max_groups;
     const dim3 grid(groups), block(256);
-    if (n_part) *n_part = tb.nt;
+    if (NB > 8 && ep.stats) return DODA_ERR_UNSUPPORTED;   // (the per-workgroup statistics accumulators hold 8 channel blocks)
+    if (n_part) *n_part = groups;      // one statistics row per persistent workgroup
 #define GT(M, O32, ST)                                                                             \
     hipLaunchKernelGGL((conv_tile<M, O32, ST>), grid, block, 0, s, x, xb, wp, wpb, nc, NB, tbl, ld, n_out, tb, y, yb, res, ep)
 #define GM(M)                                                                                      \

@@ -586,7 +586,10 @@ static int classify(const doda_wgrad_job &j) {
     // a tilebook of the job's table: the LDS-staged kernel (bf16 16 -> 16, K = 27)
     if (j.tilebook && j.tbl && j.elem_bytes == 2 && j.ca == 16 && j.cb == 16 && j.K == 27 && j.n_rows > 0 && j.a && j.b && j.dw &&
         j.n_a == j.n_rows && j.ld >= j.n_rows && (size_t)j.n_rows * 32 < 0x7ffffff0ull && (size_t)j.K * j.ld * 4 < 0xffffffffull &&
-        !(((uintptr_t)j.a | (uintptr_t)j.b | (uintptr_t)j.tilebook) & 15) && doda_wdma::enabled())
+        !(((uintptr_t)j.a | (uintptr_t)j.b | (uintptr_t)j.tilebook) & 15) && doda_wdma::enabled() &&
+        // four tiles per workgroup and more: below, the per-layer exchange + reduce of the persistent schedule cost more
+        // than the staging saves (one 150k-voxel scene: 20.5 us against 13 us for the pair lists; 600k voxels: 41 / 57)
+        (j.n_rows >= 4 * 256 * 256 || !doda_pairs::eligible(j)))
         return J_TILE;
     // DODA_WGRAD_NO_PAIRS=1 keeps every job on the gather-table kernel (A/B measurements)
     static const bool no_pairs = getenv("DODA_WGRAD_NO_PAIRS") && getenv("DODA_WGRAD_NO_PAIRS")[0] == '1';

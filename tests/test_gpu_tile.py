@@ -242,7 +242,8 @@ def test_tile_kernel_statistics_epilogue(native_lib):
     t = ext.with_tilebook(tbl)
     y0, s0 = ext.indice_conv_stats(x, w, tbl, tbl, n, 2, None, None, res)
     y1, s1 = ext.indice_conv_stats(x, w, t, t, n, 2, None, None, res)
-    assert s1 is not None and s1.shape[0] == (n + 255) // 256
+    # one statistics row per persistent workgroup (<= 768; round 2: one per tile)
+    assert s1 is not None and 1 <= s1.shape[0] <= min(768, ((n + 255) // 256 + 7) // 8 * 8)
     assert (y0 != y1).float().mean().item() < 0.02
     assert rel_err(s1.double().sum(0).cpu(), s0.double().sum(0).cpu()) < 1e-3
     yf = y1.detach().double()
