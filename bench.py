@@ -46,7 +46,7 @@ def parse():
     p.add_argument("--voxels", type=int, default=150000, help="target active voxels per scene")
     p.add_argument("--voxel-scale", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-voxels", type=int, default=100000, help="size of the CPU-baseline sample scene")
+    p.add_argument("--cpu-voxels", type=int, default=40000, help="size of the CPU-baseline sample scene (10-30 s of host work)")
     p.add_argument("--kernel-reps", type=int, default=50)
     p.add_argument("--fp32-steps", type=int, default=40,
                    help="timed steps of the fp32 sub-record (reference precision); 0 = skip")
@@ -293,18 +293,24 @@ def step_algorithmic_bytes(net, batch_dev, dtype):
 
 def pmc_traffic(dtype):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
-    (tools/profile_round.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of the same kernel
-    on the same 4 x 150k-voxel batch).  Counters are in KiB; FETCH_SIZE is doubled as
+    (tools/profile_r03.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of the same kernel — round 3: the
+    statistics + residual instantiation the step launches — on the same 4 x 150k-voxel batch).  Counters are in KiB; FETCH_SIZE is doubled as
     MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950 (check: the doubled value,
     86.5 MB, sits 2.5 % above the compulsory x + table bytes, 84.4 MB; WRITE_SIZE equals the output
     bytes exactly).  A counter pass cannot run inside this process, hence the file."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = os.path.join(prof, "r02_pmc_traffic_raw.json")
-    if not os.path.exists(path):
-        path = os.path.join(prof, "r01_pmc_traffic_raw.json")
     try:
-        with open(path) as f:
-            d = json.load(f)[dtype]
+        d, path = None, None
+        for rnd in ("r03", "r02", "r01"):   # newest committed pass that holds this dtype
+            cand = os.path.join(prof, "%s_pmc_traffic_raw.json" % rnd)
+            if os.path.exists(cand):
+                with open(cand) as f:
+                    got = json.load(f).get(dtype)
+                if got and got.get("FETCH_SIZE_KB_mean") is not None:
+                    d, path = got, cand
+                    break
+        if d is None:
+            return None, None
         fetch, write = d["FETCH_SIZE_KB_mean"], d["WRITE_SIZE_KB_mean"]
         if fetch is None or write is None:
             return None, None
@@ -417,17 +423,17 @@ def main():
         # rulebooks ride in the data pipeline: those of the NEXT batch are built on a helper thread + side
         # stream while this step is issued (every step still builds one full pyramid; nothing is cached)
         with_pairs = bool(spconv.functional.WGRAD_PAIRS and fdt == torch.bfloat16)
-        prefetch = PyramidPrefetcher(dev, len(net.unet.nPlanes)) if args.prefetch else None
+        prefetch = PyramidPrefetcher(dev, len(net.unet.nPlanes), gated=os.environ.get("DODA_PREFETCH_GATE", "0") == "1") if args.prefetch else None
         from doda_amd.model import tile_levels_for
         with_tiles = tile_levels_for(fdt)
-        pending = [prefetch.submit(batch_dev, with_pairs, with_tiles)] if prefetch else None
+        pending = [prefetch.submit(batch_dev, with_pairs, with_tiles, resident=True, now=True)] if prefetch else None
 
         def step():
             opt.zero_grad(set_to_none=True)
             pyramid = None
             if prefetch is not None:
                 pyramid = PyramidPrefetcher.take(pending[0], dev)
-                pending[0] = prefetch.submit(batch_dev, with_pairs, with_tiles)
+                pending[0] = prefetch.submit(batch_dev, with_pairs, with_tiles, resident=True)
             scores = voxelize_and_run(cfg, model, batch_dev, dev, feature_dtype=fdt, inputs_ready=True,
                                       pyramid=pyramid)
             loss = cross_entropy(scores, labels, ignore_index=255)

@@ -113,7 +113,8 @@ class GradAllReduce:
                 narrow = [p for p in self.params if p.dim() == 5 and p.shape[3] <= 32 and p.shape[4] <= 32]
                 if narrow and len(narrow) < len(self.params):
                     self._split, self._ext = True, _ext
-                    self._side = torch.cuda.Stream(device=self.params[0].device)
+                    from .streams import independent_stream
+                    self._side = independent_stream(self.params[0].device, tag="allreduce")
                     _ext.set_wgrad_split(True)
         narrow_ids = {id(p) for p in narrow} if self._split else set()
         self.buckets = self._cut([p for p in self.params if id(p) not in narrow_ids], bucket_mb)

@@ -312,7 +312,7 @@ class Trainer:
         from .model import PyramidPrefetcher
         it = make_loader(self.cfg, self.args, self.device, self.rank, self.world, epoch, split)
         nxt = next(it, None)
-        fut = self.prefetch.submit(nxt, self.with_pairs, self.with_tiles) if (nxt is not None and self.prefetch) else None
+        fut = self.prefetch.submit(nxt, self.with_pairs, self.with_tiles, now=True) if (nxt is not None and self.prefetch) else None
         while nxt is not None:
             cur, cur_fut = nxt, fut
             nxt = next(it, None)

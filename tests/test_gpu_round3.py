@@ -227,7 +227,7 @@ def _bench_steps(prefetch, n_steps=3, dtype=torch.bfloat16, seed_scene=77):
         with_pairs = bool(spconv.functional.WGRAD_PAIRS and dtype == torch.bfloat16)
         with_tiles = tile_levels_for(dtype)
         pf = PyramidPrefetcher(d, len(net.unet.nPlanes)) if prefetch else None
-        pending = [pf.submit(batch_dev, with_pairs, with_tiles, resident=True)] if pf else None
+        pending = [pf.submit(batch_dev, with_pairs, with_tiles, resident=True, now=True)] if pf else None
         losses, grads = [], None
         for k in range(n_steps):
             opt.zero_grad(set_to_none=True)
@@ -505,3 +505,24 @@ def test_train_entry_point_accepts_sync_bn(native_lib, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     losses = [float(ln.split("Loss ")[1].split()[0]) for ln in r.stdout.splitlines() if "Loss " in ln]
     assert losses and all(np.isfinite(v) for v in losses), r.stdout[-1500:]
+
+
+def test_side_streams_do_not_share_the_main_hardware_queue(native_lib):
+    """doda_amd.streams.independent_stream: the stream handed to the rulebook prefetcher makes progress while the
+    main stream is busy (one plain stream creation in four lands on the main stream's hardware queue)."""
+    from doda_amd import streams
+    d = dev()
+    streams._CACHE.clear()
+    s = streams.independent_stream(d, tag="test")
+    assert streams._runs_beside(torch.cuda.current_stream(d), s, d)
+    assert streams.independent_stream(d, tag="test") is s          # cached
+
+
+def test_bn_final_and_apply_in_one_launch_opt_in(native_lib):
+    """bn_fused_fwd / bn_fused_bwd (DODA_BN_FUSED_FINAL=1; off by default: slower in the step): the epilogue-statistics
+    and BatchNorm-fusion tests pass with the fused kernels as well."""
+    env = dict(os.environ, DODA_BN_FUSED_FINAL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_round2.py", "tests/test_gpu_tile.py", "-m", "gpu", "-x", "-q",
+                        "-k", "statistics or bn_fusion or dsnorm_fused"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
