@@ -204,6 +204,7 @@ at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tenso
         j.a = a.data_ptr(); j.b = b.data_ptr(); j.tbl = (const int32_t *)tbl.data_ptr(); j.dw = (float *)dw.data_ptr();
         j.ca = (int32_t)ca; j.cb = (int32_t)cb; j.ld = (int32_t)ld; j.K = (int32_t)K; j.n_rows = (int32_t)n_rows;
         j.elem_bytes = 2; j.n_a = (int32_t)a.size(0);
+        j.tilebook = tilebook_behind(tbl, n_rows);   // LDS-staged kernel when the table carries its tilebook (16 -> 16)
         const size_t wsb = doda_spconv_wgrad_multi_workspace_bytes(&j, 1), dsb = doda_spconv_wgrad_multi_desc_bytes(1);
         at::Tensor ws = at::empty({(int64_t)wsb}, a.options().dtype(at::kByte));
         at::Tensor desc = at::empty({(int64_t)dsb}, a.options().dtype(at::kByte));
