@@ -46,7 +46,7 @@ def parse():
     p.add_argument("--voxels", type=int, default=150000, help="target active voxels per scene")
     p.add_argument("--voxel-scale", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-voxels", type=int, default=40000, help="size of the CPU-baseline sample scene (10-30 s of host work)")
+    p.add_argument("--cpu-voxels", type=int, default=0, help="CPU-baseline sample: 0 = the bench batch itself (~10 s of host work at 16 threads), else one scene of this many voxels")
     p.add_argument("--kernel-reps", type=int, default=50)
     p.add_argument("--fp32-steps", type=int, default=40,
                    help="timed steps of the fp32 sub-record (reference precision); 0 = skip")
@@ -361,16 +361,27 @@ def cpu_baseline(args, batch=None, batch_dev=None):
     """Oracle U-Net fwd+bwd (fp32, torch-CPU threads = all host cores) on ONE scene; plus the voxelisation leg."""
     from doda_amd.scene import make_batch
     from oracle.unet_cpu import OracleUNet, forward_backward
-    sample = make_batch(1, args.cpu_voxels, 1000, args.voxel_scale)
+    # the bench batch itself when it is given (the same 4 x 150k-voxel workload), else one scene of --cpu-voxels
+    sample = batch if (batch is not None and args.cpu_voxels <= 0) else make_batch(1, args.cpu_voxels, 1000, args.voxel_scale)
     torch.manual_seed(0)
     net = OracleUNet().train()
-    t0 = time.time()
-    forward_backward(net, sample)
-    dt = time.time() - t0
+    # torch-CPU threads: at most 16 — the port issues ~4000 small matrix products, and with all 128+ host threads of
+    # the GPU box their fork/join dominates (measured there: the same 40k-voxel sample in 26 s on one run and 133 s
+    # on another with 128 threads)
+    n_thr_before = torch.get_num_threads()
+    n_thr = max(1, min(16, os.cpu_count() or 1))
+    torch.set_num_threads(n_thr)
+    try:
+        t0 = time.time()
+        forward_backward(net, sample)
+        dt = time.time() - t0
+    finally:
+        torch.set_num_threads(n_thr_before)
     m = sample["voxel_locs"].shape[0]
-    out = {"value": m / dt, "unit": "voxels/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": "1 scene (%d active voxels), 1 U-Net fwd+bwd incl. serial rulebook build, fp32, "
-                     "oracle/unet_cpu.py (spconv CPU path cannot be built: restatement stands in)" % m,
+    out = {"value": m / dt, "unit": "voxels/s", "cores": n_thr, "kind": "port",
+           "sample": "%d scene(s), %d active voxels, 1 U-Net fwd+bwd incl. serial rulebook build, fp32, "
+                     "oracle/unet_cpu.py (spconv CPU path cannot be built: restatement stands in)" % (
+                         int(sample["offsets"].numel() - 1), m),
            "seconds": dt}
     if batch is not None:
         out["voxelize_idx"] = voxelize_legs(batch, batch_dev)
