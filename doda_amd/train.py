@@ -388,6 +388,8 @@ def main(argv=None):
         raise RuntimeError("doda_amd.train needs an MI355X: the native ops have no CPU fallback")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
+    from .host import pin_to_device_numa
+    pin_to_device_numa(device.index)     # issuing threads on the GPU's NUMA node (doda_amd/host.py)
     if args.batch_size is None:
         args.batch_size = cfg.OPTIMIZATION.BATCH_SIZE_PER_GPU
     else:

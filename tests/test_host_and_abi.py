@@ -144,3 +144,14 @@ def test_reference_model_files_run_on_doda_spconv_surface():
         "assert ka==kb and type(a.input_conv).__module__.startswith('doda_amd'); print('OK')" % (ROOT, ROOT))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_numa_pinning_helper_is_safe_without_a_gpu():
+    """doda_amd.host: cpulist parsing, and pin_to_device_numa() is a no-op (None) when the topology is unknown."""
+    from doda_amd import host
+    assert host._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    import os
+    before = os.sched_getaffinity(0)
+    res = host.pin_to_device_numa(0)
+    assert res is None or (isinstance(res, dict) and res["cpus"] >= 1)
+    assert os.sched_getaffinity(0) <= before
