@@ -93,6 +93,11 @@ _SIGNATURES = {
                                        c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "doda_bn_relu_bwd_stats": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "doda_bn_relu_fwd_totals": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "doda_bn_relu_bwd_totals": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
+                                        c_vp, c_vp, c_vp, c_vp]),
+    "doda_spconv_set_stats_finish": (None, [c_i32]),
     "doda_sgd_multi_desc_bytes": (c_sz, [c_i32]),
     "doda_sgd_multi": (c_i32, [c_vp, c_i32, C.c_double, C.c_double, C.c_double, C.c_double, c_i32, c_i32, c_vp,
                                c_sz, c_vp]),
@@ -109,7 +114,7 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-ABI_VERSION = 4   # include/doda_hip.h DODA_ABI_VERSION
+ABI_VERSION = 5   # include/doda_hip.h DODA_ABI_VERSION
 
 _lib = None
 

@@ -536,6 +536,102 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_final_stats(const float *__re
 }
 
 
+// ---- apply passes fed by TOTALS (round 3: the conv kernel's last workgroup summed the partial rows, spconv_common.hpp
+// stats_finish) ---------------------------------------------------------------------------------------------------
+// The first c threads of every workgroup turn the two totals of their channel into the per-channel vectors (the
+// arithmetic of bn_fwd_final_stats / bn_bwd_final_stats, fp64) and park them in LDS; the sweep is bn_apply /
+// bn_bwd_apply with the vectors read from LDS instead of L1.  Workgroup 0 publishes what later kernels need.
+constexpr int BN_TOT_MAX_C = 256;
+
+template <class T>
+__global__ __launch_bounds__(BN_BLOCK) void bn_apply_tot(const typename T::elem *__restrict__ x, long long n_frag, int nf,
+                                                         const double *__restrict__ totals, int m, float eps, float momentum,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                         float *__restrict__ mean, float *__restrict__ invstd,
+                                                         float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                         long long *__restrict__ nbt, int relu,
+                                                         typename T::elem *__restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float v_mu[BN_TOT_MAX_C], v_a[BN_TOT_MAX_C];
+    const int c = nf * 4;
+    for (int ch = threadIdx.x; ch < c; ch += BN_BLOCK) {
+        const double d = totals[ch] / m;
+        double var = totals[c + ch] / m - d * d;
+        if (var < 0.0) var = 0.0;
+        const float mu = (float)d, is = (float)(1.0 / sqrt(var + (double)eps));
+        v_mu[ch] = mu;
+        v_a[ch] = is;
+        if (blockIdx.x == 0) {
+            mean[ch] = mu;
+            invstd[ch] = is;
+            if (running_mean) {
+                const double unbiased = m > 1 ? var * (double)m / (double)(m - 1) : var;
+                running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * d);
+                running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unbiased);
+            }
+            if (ch == 0 && nbt) *nbt = *nbt + 1;
+        }
+    }
+    __syncthreads();
+    for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < n_frag; e += (long long)gridDim.x * BN_BLOCK) {
+        const int f = (int)(e % nf);
+        const f32x4 v = T::load4(x + e * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(v_mu + f * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4 *>(v_a + f * 4);
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
+        const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + f * 4);
+        f32x4 o = (v - mu) * is * ga + be;     // (the expression of bn_apply: same rounding)
+        if (relu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = o[q] > 0.f ? o[q] : 0.f;
+        }
+        T::store4(y + e * 4, o);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_tot(const typename T::elem *__restrict__ x,
+                                                             const typename T::elem *__restrict__ dy, long long n_frag,
+                                                             int nf, const double *__restrict__ totals, int m,
+                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             int relu, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                             typename T::elem *__restrict__ dx,
+                                                             const typename T::elem *__restrict__ add) {
+    __shared__ __attribute__((aligned(16))) float v_a[BN_TOT_MAX_C], v_b[BN_TOT_MAX_C], v_d[BN_TOT_MAX_C];
+    const int c = nf * 4;
+    for (int ch = threadIdx.x; ch < c; ch += BN_BLOCK) {
+        const double s1 = totals[ch], s2 = totals[c + ch];
+        v_a[ch] = gamma[ch] * invstd[ch];
+        v_b[ch] = (float)(s1 / m);
+        v_d[ch] = (float)(s2 / m);
+        if (blockIdx.x == 0) {
+            dbeta[ch] = (float)s1;
+            dgamma[ch] = (float)s2;
+        }
+    }
+    __syncthreads();
+    for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < n_frag; e += (long long)gridDim.x * BN_BLOCK) {
+        const int f = (int)(e % nf);
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + f * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + f * 4);
+        const f32x4 xh = (T::load4(x + e * 4) - mu) * is;
+        f32x4 dz = T::load4(dy + e * 4);
+        if (relu) {
+            const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
+            const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + f * 4);
+            const f32x4 yv = xh * ga + be;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dz[q] = yv[q] > 0.f ? dz[q] : 0.f;
+        }
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(v_a + f * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(v_b + f * 4);
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(v_d + f * 4);
+        f32x4 o = a * (dz - b - xh * d);
+        if (add) o += T::load4(add + e * 4);
+        T::store4(dx + e * 4, o);
+    }
+}
+
 // ---- final + apply in ONE launch (round 3) ----------------------------------------------------------
 // The `final` kernels above are four to twelve blocks chasing L2 round trips: 6-7 us each, 75 of them per U-Net
 // step.  When the conv epilogue delivers few partial rows (the persistent tile kernels write ONE per workgroup:
@@ -908,6 +1004,62 @@ extern "C" int doda_bn_relu_fwd_stats(const void *x, int32_t m, int32_t c, int32
                                   (long long *)num_batches_tracked, relu, y, save_mean, save_invstd, as_stream(stream));
     return run_fwd_stats<BF16>(x, m, c, stats, stats_rows, eps, momentum, gamma, beta, running_mean, running_var,
                                (long long *)num_batches_tracked, relu, y, save_mean, save_invstd, as_stream(stream));
+}
+
+template <class T>
+static int run_fwd_totals(const void *x_, int m, int c, const double *totals, float eps, float momentum, const float *gamma,
+                          const float *beta, float *rm, float *rv, long long *nbt, int relu, void *y_, float *mean,
+                          float *invstd, hipStream_t s) {
+    typedef typename T::elem elem;
+    const Geo g = make_geo(c);
+    const long long n_frag = (long long)m * g.nf;
+    const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
+    hipLaunchKernelGGL((bn_apply_tot<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, n_frag, g.nf, totals, m, eps,
+                       momentum, gamma, beta, mean, invstd, rm, rv, nbt, relu, (elem *)y_);
+    return doda_check_launch();
+}
+
+template <class T>
+static int run_bwd_totals(const void *x_, const void *dy_, int m, int c, const double *totals, const float *mean,
+                          const float *invstd, const float *gamma, const float *beta, int relu, const void *add_, void *dx_,
+                          float *dgamma, float *dbeta, hipStream_t s) {
+    typedef typename T::elem elem;
+    const Geo g = make_geo(c);
+    const long long n_frag = (long long)m * g.nf;
+    const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
+    hipLaunchKernelGGL((bn_bwd_apply_tot<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, (const elem *)dy_, n_frag,
+                       g.nf, totals, m, mean, invstd, gamma, beta, relu, dgamma, dbeta, (elem *)dx_, (const elem *)add_);
+    return doda_check_launch();
+}
+
+extern "C" int doda_bn_relu_fwd_totals(const void *x, int32_t m, int32_t c, int32_t elem_bytes, const double *totals,
+                                       float eps, float momentum, const float *gamma, const float *beta,
+                                       float *running_mean, float *running_var, int64_t *num_batches_tracked, int32_t relu,
+                                       void *y, float *save_mean, float *save_invstd, doda_stream_t stream) {
+    if (m == 0) return DODA_OK;
+    if (bn_args_bad(m, c, elem_bytes) || c > BN_TOT_MAX_C) return DODA_ERR_UNSUPPORTED;
+    if (!x || !y || !totals || !gamma || !beta || !save_mean || !save_invstd || (!running_mean != !running_var))
+        return DODA_ERR_INVALID;
+    if (elem_bytes == 4)
+        return run_fwd_totals<F32>(x, m, c, totals, eps, momentum, gamma, beta, running_mean, running_var,
+                                   (long long *)num_batches_tracked, relu, y, save_mean, save_invstd, as_stream(stream));
+    return run_fwd_totals<BF16>(x, m, c, totals, eps, momentum, gamma, beta, running_mean, running_var,
+                                (long long *)num_batches_tracked, relu, y, save_mean, save_invstd, as_stream(stream));
+}
+
+extern "C" int doda_bn_relu_bwd_totals(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
+                                       const double *totals, const float *save_mean, const float *save_invstd,
+                                       const float *gamma, const float *beta, int32_t relu, const void *add, void *dx,
+                                       float *dgamma, float *dbeta, doda_stream_t stream) {
+    if (m == 0) return DODA_OK;
+    if (bn_args_bad(m, c, elem_bytes) || c > BN_TOT_MAX_C) return DODA_ERR_UNSUPPORTED;
+    if (!x || !dy || !dx || !totals || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta)
+        return DODA_ERR_INVALID;
+    if (elem_bytes == 4)
+        return run_bwd_totals<F32>(x, dy, m, c, totals, save_mean, save_invstd, gamma, beta, relu, add, dx, dgamma, dbeta,
+                                   as_stream(stream));
+    return run_bwd_totals<BF16>(x, dy, m, c, totals, save_mean, save_invstd, gamma, beta, relu, add, dx, dgamma, dbeta,
+                                as_stream(stream));
 }
 
 extern "C" int doda_bn_relu_bwd_stats(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,

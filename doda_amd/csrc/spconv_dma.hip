@@ -74,7 +74,7 @@ __device__ __forceinline__ void astore64(const u32x2 &v, unsigned voff, const u3
     asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" : : "v"(v), "v"(voff), "s"(rs) : "memory");
 }
 __device__ __forceinline__ void astore128(const u32x4 &v, unsigned voff, const u32x4 &rs) {
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(v), "v"(voff), "s"(rs) : "memory");
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 2" : : "v"(v), "v"(voff), "s"(rs) : "memory");   // (data registers are read after issue)
 }
 
 // phase time stamps of one workgroup (DODA_DMA_DBG bit 7; tools/dmastamps.py): [wave 0 | wave 5][iteration][phase]

@@ -27,6 +27,9 @@
 #include "tilebook.hpp"
 #include "spconv_common.hpp"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace {
 
@@ -771,20 +774,23 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                         a2 = (a2 + sred[1][nb][1][g]) + (sred[2][nb][1][g] + sred[3][nb][1][g]);
                     }
                     float *dst = ep.stats + (long long)part * 2 * nc + col;
-                    *reinterpret_cast<f32x4 *>(dst) = a1;
-                    *reinterpret_cast<f32x4 *>(dst + nc) = a2;
+                    stats_store4(dst, a1);
+                    stats_store4(dst + nc, a2);
                 }
             }
         }
+        stats_finish<SPLIT>(ep, nc);
     }
 }
 
 template <class P, int NBW, int S, bool SPLIT = false>
 int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_bytes, int nc, int NB,
                 const int32_t *tbl, int ld, int K, int n_out, long long n_in, void *y, bool out32,
-                const void *res, const EpiArgs &ep, int *n_part, hipStream_t s) {
+                const void *res, const EpiArgs &ep_in, int *n_part, hipStream_t s) {
     const dim3 grid(div_up(n_out, (SPLIT ? 1 : 4) * 16 * S) * div_up(NB, NBW)), block(256);
     if (n_part) *n_part = div_up(n_out, (SPLIT ? 1 : 4) * 16 * S);
+    EpiArgs ep = ep_in;
+    if (ep.stats) doda_fin::arm(ep, div_up(n_out, (SPLIT ? 1 : 4) * 16 * S), grid.x, s);
     // Ring depth.  Re-measured after the EXEC-masked gathers and the wide / pair units went in: with
     // every load hitting L1 (ablation) the kernel time did not move, i.e. the unit loop is paced by
     // instruction issue and by how many waves a SIMD can interleave, not by memory latency.  Depth 8
@@ -1058,6 +1064,49 @@ extern "C" int doda_spconv_gather_add_bf16(const uint16_t *x, int32_t n_in, int3
                             res, as_stream(stream));
 }
 
+// ---- in-kernel finish of the epilogue statistics (spconv_common.hpp: EpiArgs.totals) ----------------
+namespace doda_fin {
+namespace {
+// OFF by default: measured on MI355X (profiles/r03_stats_finish_ab.txt) the end-of-workgroup protocol — drain the
+// write-through stores, one or two memory-side atomics — costs 3-7 us per workgroup: +6 us on the persistent tile kernels
+// (what the separate `final` launch costs) and +25..55 us on conv_fast's thousands of short workgroups.
+bool g_on = getenv("DODA_STATS_FINISH") && getenv("DODA_STATS_FINISH")[0] == '1';
+std::mutex g_mu;
+std::map<std::pair<int, hipStream_t>, unsigned *> g_tickets;
+}  // namespace
+thread_local int last_finished = 0;
+bool enabled() { return g_on; }
+void set_enabled(bool on) { g_on = on; }
+unsigned *ticket_for(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_tickets.find({dev, s});
+    if (it != g_tickets.end()) return it->second;
+    unsigned *p = nullptr;   // root + FIN_MAX_GROUPS group counters, one 256-byte line each; never freed (a handful per process)
+    const size_t bytes = (size_t)(1 + FIN_MAX_GROUPS) * FIN_STRIDE * sizeof(unsigned);
+    if (hipMalloc((void **)&p, bytes) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(p, 0, bytes, s) != hipSuccess) return nullptr;
+    g_tickets[{dev, s}] = p;
+    return p;
+}
+bool arm(EpiArgs &ep, int rows, unsigned n_wg, hipStream_t s) {
+    last_finished = 0;
+    if (!ep.totals) return false;
+    unsigned *t = (g_on && n_wg <= FIN_GROUP * FIN_MAX_GROUPS) ? ticket_for(s) : nullptr;
+    if (!t) {
+        ep.totals = nullptr;
+        return false;
+    }
+    ep.ticket = t;
+    ep.fin_rows = rows;
+    last_finished = 1;
+    return true;
+}
+}  // namespace doda_fin
+
+extern "C" void doda_spconv_set_stats_finish(int32_t on) { doda_fin::set_enabled(on != 0); }
+
 // ---- gather with epilogue options (residual add, BatchNorm statistics) ------------------------------
 extern "C" void doda_spconv_set_wlds_kernel(int32_t on) { doda_wlds::set_enabled(on != 0); }
 
@@ -1076,11 +1125,16 @@ extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, in
     EpiArgs ep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     const void *res = nullptr;
     int n_part = 0;
+    doda_fin::last_finished = 0;
     if (epi) {
         res = epi->residual;
         if (epi->stats) {
             if (!epi->stats_rows_h) return DODA_ERR_INVALID;
             ep.stats = epi->stats;
+            if (epi->totals) {
+                if (!epi->finished_h || ((uintptr_t)epi->totals & 7)) return DODA_ERR_INVALID;
+                ep.totals = epi->totals;
+            }
             if (epi->bn_x) {
                 if (!epi->bn_mean || !epi->bn_invstd || !epi->bn_gamma || !epi->bn_beta) return DODA_ERR_INVALID;
                 ep.bn_x = epi->bn_x;
@@ -1098,5 +1152,6 @@ extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, in
                               as_stream(stream), ep, &n_part, epi ? epi->tilebook : nullptr,
                               epi ? epi->tilebook_rows : 0);
     if (st == DODA_OK && epi && epi->stats_rows_h) *epi->stats_rows_h = n_part;
+    if (epi && epi->finished_h) *epi->finished_h = (st == DODA_OK && ep.totals) ? doda_fin::last_finished : 0;
     return st;
 }

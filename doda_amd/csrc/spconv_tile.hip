@@ -350,11 +350,12 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                 const int col = nb0 * 16 + 4 * g;
                 if (col < nc) {
                     float *dst = ep.stats + (long long)blockIdx.x * 2 * nc + col;
-                    *reinterpret_cast<f32x4 *>(dst) = wg_acc[(nb0 * 2 + 0) * 4 + g];
-                    *reinterpret_cast<f32x4 *>(dst + nc) = wg_acc[(nb0 * 2 + 1) * 4 + g];
+                    stats_store4(dst, wg_acc[(nb0 * 2 + 0) * 4 + g]);
+                    stats_store4(dst + nc, wg_acc[(nb0 * 2 + 1) * 4 + g]);
                 }
             }
         }
+        stats_finish(ep, nc);
     }
 }
 
@@ -680,14 +681,16 @@ bool doda_tile::enabled() { return g_use_tile; }
 
 int doda_tile::launch_conv_tile(int mode, bool out32, const void *x, unsigned xb, const void *wp, unsigned wpb, int nc, int NB,
                                 const int32_t *tbl, int ld, int n_out, const void *tilebook, void *y, unsigned yb,
-                                const void *res, const EpiArgs &ep, int *n_part, hipStream_t s) {
+                                const void *res, const EpiArgs &ep_in, int *n_part, hipStream_t s) {
     const TileBookView tb = tilebook_view(const_cast<void *>(tilebook), n_out);
     int groups = (tb.nt + 7) / 8 * 8;   // persistent: 3 (64-byte rows: 2) workgroups per CU, a multiple of the 8 XCDs
     const int max_groups = mode == 0 ? BT_MAX_GROUPS : BT_MAX_GROUPS * 2 / 3;
     if (groups > max_groups) groups = max_groups;
     const dim3 grid(groups), block(256);
-    if (NB > 8 && ep.stats) return DODA_ERR_UNSUPPORTED;   // (the per-workgroup statistics accumulators hold 8 channel blocks)
+    if (NB > 8 && ep_in.stats) return DODA_ERR_UNSUPPORTED;   // (the per-workgroup statistics accumulators hold 8 channel blocks)
     if (n_part) *n_part = groups;      // one statistics row per persistent workgroup
+    EpiArgs ep = ep_in;
+    if (ep.stats) doda_fin::arm(ep, groups, (unsigned)groups, s);
 #define GT(M, O32, ST)                                                                             \
     hipLaunchKernelGGL((conv_tile<M, O32, ST>), grid, block, 0, s, x, xb, wp, wpb, nc, NB, tbl, ld, n_out, tb, y, yb, res, ep)
 #define GM(M)                                                                                      \

@@ -100,14 +100,20 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
     }
     doda_conv_epilogue ep;
     memset(&ep, 0, sizeof(ep));
-    int32_t stats_rows = 0;
-    at::Tensor stats;
+    int32_t stats_rows = 0, finished = 0;
+    at::Tensor stats, totals;
     ep.residual = res.defined() ? res.data_ptr() : nullptr;
     bool with_stats = epi && epi->want && n_out > 0;
     if (with_stats) {
         stats = at::empty({(int64_t)doda_spconv_stats_capacity((int32_t)n_out), 2, nc}, x.options().dtype(at::kFloat));
         ep.stats = (float *)stats.data_ptr();
         ep.stats_rows_h = &stats_rows;
+        // the conv kernel's last workgroup sums the rows itself when it can (ABI 5): the BatchNorm then gets totals
+        if (nc <= 256) {
+            totals = at::empty({1, 2, nc}, x.options().dtype(at::kDouble));
+            ep.totals = (double *)totals.data_ptr();
+            ep.finished_h = &finished;
+        }
         if (epi->bn_x.defined()) {
             TORCH_CHECK(epi->bn_x.scalar_type() == y.scalar_type() && epi->bn_x.is_contiguous() &&
                         epi->bn_x.size(0) == n_out && epi->bn_x.size(1) == nc, "doda gather: bn_x must match the output");
@@ -151,6 +157,8 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
             with_stats = false;
             ep.stats = nullptr;
             ep.stats_rows_h = nullptr;
+            ep.totals = nullptr;
+            ep.finished_h = nullptr;
             ep.bn_x = nullptr;
             use_packed = packed.has_value() && packed->defined();
             continue;
@@ -158,7 +166,10 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
         check(status, "doda_spconv_gather");
         break;
     }
-    if (epi) epi->stats = (with_stats && stats_rows > 0) ? stats.narrow(0, 0, stats_rows) : at::Tensor();
+    if (epi) {
+        if (with_stats && finished) epi->stats = totals;      // double [1, 2, nc]: already summed over all rows
+        else epi->stats = (with_stats && stats_rows > 0) ? stats.narrow(0, 0, stats_rows) : at::Tensor();
+    }
     return y;
 }
 
@@ -639,7 +650,21 @@ struct BNNode : public torch::autograd::Node {
             link->stats.reset();
             link->dz.reset();
         }
-        if (stats.defined()) {
+        if (stats.defined() && stats.scalar_type() == at::kDouble) {   // totals: one launch
+            const int64_t m = x.size(0), c = x.size(1);
+            const at::Tensor add = extra.defined() ? extra.contiguous() : at::Tensor();
+            dx = at::empty_like(x);
+            dg = at::empty({c}, x.options().dtype(at::kFloat));
+            db = at::empty({c}, x.options().dtype(at::kFloat));
+            check(doda_bn_relu_bwd_totals(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
+                                          (const double *)stats.data_ptr(), (const float *)mean.data_ptr(),
+                                          (const float *)invstd.data_ptr(), (const float *)weight.data_ptr(),
+                                          (const float *)bias.data_ptr(), relu ? 1 : 0,
+                                          add.defined() ? add.data_ptr() : nullptr, dx.data_ptr(), (float *)dg.data_ptr(),
+                                          (float *)db.data_ptr(), stream_of(x)),
+                  "doda_bn_relu_bwd_totals");
+            extra = at::Tensor();
+        } else if (stats.defined()) {
             const int64_t m = x.size(0), c = x.size(1);
             const at::Tensor add = extra.defined() ? extra.contiguous() : at::Tensor();
             dx = at::empty_like(x);
@@ -730,7 +755,15 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
             mean = running_mean.to(at::kFloat).contiguous();
             invstd = at::rsqrt(running_var.to(at::kFloat) + eps).contiguous();
         }
-        if (training && stats.defined() && m > BN_SMALL_ROWS && stats.dim() == 3 && stats.size(2) == c &&
+        if (training && stats.defined() && m > BN_SMALL_ROWS && stats.dim() == 3 && stats.size(0) == 1 && stats.size(2) == c &&
+            c <= 256 && stats.scalar_type() == at::kDouble && stats.is_contiguous()) {
+            check(doda_bn_relu_fwd_totals(x.data_ptr(), (int)m, (int)c, esz, (const double *)stats.data_ptr(), (float)eps,
+                                          (float)momentum, (const float *)weight.data_ptr(), (const float *)bias.data_ptr(),
+                                          (float *)running_mean.data_ptr(), (float *)running_var.data_ptr(),
+                                          nbt.defined() ? (int64_t *)nbt.data_ptr() : nullptr, relu ? 1 : 0, y.data_ptr(),
+                                          (float *)mean.data_ptr(), (float *)invstd.data_ptr(), stream_of(x)),
+                  "doda_bn_relu_fwd_totals");
+        } else if (training && stats.defined() && m > BN_SMALL_ROWS && stats.dim() == 3 && stats.size(2) == c &&
             stats.scalar_type() == at::kFloat && stats.is_contiguous()) {
             check(doda_bn_relu_fwd_stats(x.data_ptr(), (int)m, (int)c, esz, (const float *)stats.data_ptr(),
                                          (int)stats.size(0), (float)eps, (float)momentum,

@@ -266,11 +266,11 @@ def _feat_ok(x, name):
         raise RuntimeError("%s must be a contiguous [rows, channels] tensor" % name)
 
 
-class _ConvEpilogue(C.Structure):   # doda_conv_epilogue (include/doda_hip.h, ABI 3)
+class _ConvEpilogue(C.Structure):   # doda_conv_epilogue (include/doda_hip.h, ABI 5)
     _fields_ = [("residual", C.c_void_p), ("stats", C.c_void_p), ("stats_rows_h", C.POINTER(C.c_int32)),
                 ("bn_x", C.c_void_p), ("bn_mean", C.c_void_p), ("bn_invstd", C.c_void_p), ("bn_gamma", C.c_void_p),
                 ("bn_beta", C.c_void_p), ("bn_relu", C.c_int32), ("tilebook_rows", C.c_int32),
-                ("tilebook", C.c_void_p)]
+                ("tilebook", C.c_void_p), ("totals", C.c_void_p), ("finished_h", C.POINTER(C.c_int32))]
 
 
 def tilebook_build(tbl, n_rows=None):
@@ -315,14 +315,16 @@ def spconv_bwd_tile(dy, x, w, tbl, tilebook, packed=None, dw_out=None):
 
 
 def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, residual=None, tilebook=None,
-                  want_stats=False, bn=None, out=None):
+                  want_stats=False, bn=None, out=None, want_totals=False):
     """y[t] = sum_o x[tbl[o][t]] @ B_o (see doda_hip.h).  x: [n_in,kc] f32|bf16; w: fp32 weights
     viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2), or `packed`: the fragment-packed buffer
     produced by PackPlan for this (weight, layout, dtype).  Returns y [n_out, nc] in x.dtype (or
     float32 when out_f32); with `residual` ([n_out, nc], dtype of y) returns conv + residual.
     want_stats: returns (y, stats [rows, 2, nc] fp32): the BatchNorm partial sums of the epilogue
     (doda_conv_epilogue.stats) — (sum y, sum y^2), or with bn = (bn_x, mean, invstd, gamma, beta, relu) the
-    BatchNorm-backward sums of a data-grad call.  out: write into this tensor instead of allocating."""
+    BatchNorm-backward sums of a data-grad call.  out: write into this tensor instead of allocating.
+    want_totals (with want_stats): returns (y, stats, totals) — totals: float64 [2, nc], the rows summed by the conv
+    kernel's last workgroup (doda_conv_epilogue.totals), or None when that kernel does not finish in place."""
     _feat_ok(x, "x")
     _need_cuda(tbl)
     K, ld = tbl.shape
@@ -361,9 +363,15 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
                 bx, mean, invstd, gamma, beta, relu = bn
                 ep.bn_x, ep.bn_mean, ep.bn_invstd, ep.bn_gamma, ep.bn_beta = _p(bx), _p(mean), _p(invstd), _p(gamma), _p(beta)
                 ep.bn_relu = int(bool(relu))
+        totals, fin = None, C.c_int32(0)
+        if want_stats and want_totals:
+            totals = torch.empty((2, nc), dtype=torch.float64, device=x.device)
+            ep.totals, ep.finished_h = _p(totals), C.pointer(fin)
         check(lib().doda_spconv_gather_ex(_p(x), x.shape[0], kc, esz, w_ptr, nc, _p(tbl), ld, K, n_out, _p(y),
                                           int(bool(out_f32)), layout, ws_ptr, ws_n, C.byref(ep), _stream()),
               "doda_spconv_gather_ex")
+        if want_stats and want_totals:
+            return y, stats[:rows.value], (totals if fin.value else None)
         return (y, stats[:rows.value]) if want_stats else y
     if x.dtype == torch.float32:
         y = torch.empty((n_out, nc), dtype=torch.float32, device=x.device)
@@ -616,6 +624,44 @@ def bn_relu_bwd(x, dy, save_mean, save_invstd, gamma, beta, relu):
     check(lib().doda_bn_relu_bwd(_p(x), _p(dy), m, c, _esz(x), _p(save_mean), _p(save_invstd),
                                  _p(gamma), _p(beta), int(bool(relu)), _p(dx), _p(dgamma), _p(dbeta),
                                  _p(ws), ws.numel(), _stream()), "doda_bn_relu_bwd")
+    return dx, dgamma, dbeta
+
+
+def bn_relu_fwd_totals(x, totals, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None):
+    """Training-mode BatchNorm(+ReLU) from the totals of a conv epilogue (doda_bn_relu_fwd_totals): one launch.
+    -> (y, save_mean, save_invstd)."""
+    _feat_ok(x, "x")
+    _need_cuda(totals)
+    m, c = x.shape
+    if totals.dtype != torch.float64 or totals.numel() != 2 * c or not totals.is_contiguous():
+        raise RuntimeError("totals must be a contiguous float64 [2, c] tensor")
+    y = torch.empty_like(x)
+    save_mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    save_invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(lib().doda_bn_relu_fwd_totals(_p(x), m, c, _esz(x), _p(totals), float(eps), float(momentum), _p(gamma), _p(beta),
+                                        _p(running_mean) if running_mean is not None else None,
+                                        _p(running_var) if running_var is not None else None,
+                                        _p(num_batches_tracked) if num_batches_tracked is not None else None,
+                                        int(bool(relu)), _p(y), _p(save_mean), _p(save_invstd), _stream()),
+          "doda_bn_relu_fwd_totals")
+    return y, save_mean, save_invstd
+
+
+def bn_relu_bwd_totals(x, dy, totals, save_mean, save_invstd, gamma, beta, relu, add=None):
+    """BatchNorm(+ReLU) backward from the totals (sum dz, sum dz * xhat) of a data-grad conv epilogue
+    (doda_bn_relu_bwd_totals): one launch.  -> (dx [+ add], dgamma, dbeta)."""
+    _feat_ok(x, "x")
+    _feat_ok(dy, "dy")
+    _need_cuda(totals)
+    m, c = x.shape
+    if totals.dtype != torch.float64 or totals.numel() != 2 * c or not totals.is_contiguous():
+        raise RuntimeError("totals must be a contiguous float64 [2, c] tensor")
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(lib().doda_bn_relu_bwd_totals(_p(x), _p(dy), m, c, _esz(x), _p(totals), _p(save_mean), _p(save_invstd), _p(gamma),
+                                        _p(beta), int(bool(relu)), _p(add) if add is not None else None, _p(dx),
+                                        _p(dgamma), _p(dbeta), _stream()), "doda_bn_relu_bwd_totals")
     return dx, dgamma, dbeta
 
 

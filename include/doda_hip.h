@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DODA_ABI_VERSION 4
+#define DODA_ABI_VERSION 5
 
 #define DODA_OK 0
 #define DODA_ERR_INVALID (-1)        /* bad argument (null pointer, negative size, bad mode) */
@@ -243,7 +243,17 @@ typedef struct doda_conv_epilogue {
     int32_t bn_relu;
     int32_t tilebook_rows;   /* ABI 3: rows the tilebook was built for (must equal n_out) */
     const void *tilebook;    /* ABI 3: doda_tilebook_build of `tbl`, or NULL */
+    /* ABI 5: in-kernel finish of the statistics.  With `totals` (device, double [2][nc], 8-byte aligned) the last
+     * workgroup of the conv kernel to retire sums the partial rows — fixed order, fp64 — into totals[0][c] / totals[1][c]
+     * (the two sums over ALL rows), and *finished_h (HOST, required with totals) receives 1; hand the totals to
+     * doda_bn_relu_fwd_totals / doda_bn_relu_bwd_totals and the BatchNorm needs no reduction launch of its own.
+     * *finished_h == 0: this kernel does not finish in place (or doda_spconv_set_stats_finish(0)); use the rows. */
+    double *totals;
+    int32_t *finished_h;
 } doda_conv_epilogue;
+/* Switch: 1 = finish statistics in the conv kernels, 0 = never (finished_h always 0).  Default 0 (DODA_STATS_FINISH=1
+ * turns it on): on MI355X the end-of-workgroup protocol costs more than the BatchNorm's own reduction launch. */
+void doda_spconv_set_stats_finish(int32_t on);
 /* ABI 3.  Tile-local form of a SubM gather table ("tilebook") for the LDS-staged convolution kernel:
  * per tile of doda_tilebook_tile() consecutive output rows, the sorted list of DISTINCT input rows the
  * tile's K x tile table entries reference and, per entry, its position in that list.  The kernel loads
@@ -413,6 +423,19 @@ int doda_bn_relu_bwd_stats(const void *x, const void *dy, int32_t m, int32_t c, 
                            const float *save_invstd, const float *gamma, const float *beta, int32_t relu,
                            const void *add, void *dx, float *dgamma, float *dbeta, float *coef_ws,
                            doda_stream_t stream);
+
+/* ABI 5.  Same with the statistics already summed over all rows by the conv kernel itself
+ * (doda_conv_epilogue.totals: double [2][c]): ONE launch per direction.  Every workgroup of the apply pass derives the
+ * per-channel vectors from the totals (fp64, as the `final` kernels do); workgroup 0 also writes save_mean /
+ * save_invstd, the running statistics and num_batches_tracked (forward) or dgamma / dbeta (backward). */
+int doda_bn_relu_fwd_totals(const void *x, int32_t m, int32_t c, int32_t elem_bytes, const double *totals, float eps,
+                            float momentum, const float *gamma, const float *beta, float *running_mean,
+                            float *running_var, int64_t *num_batches_tracked, int32_t relu, void *y, float *save_mean,
+                            float *save_invstd, doda_stream_t stream);
+int doda_bn_relu_bwd_totals(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
+                            const double *totals, const float *save_mean, const float *save_invstd, const float *gamma,
+                            const float *beta, int32_t relu, const void *add, void *dx, float *dgamma, float *dbeta,
+                            doda_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Neighbour queries
