@@ -26,6 +26,7 @@
 #include "spconv_common.hpp"
 #include "wgrad_pairs.hpp"
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 namespace {
@@ -73,9 +74,13 @@ __device__ __forceinline__ void wd_dma16(unsigned lds_base, unsigned voff, const
 __device__ __forceinline__ void wd_aload128(u32x4 &dst, unsigned voff, const u32x4 &rs) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory");
 }
+// TAG: call sites on the two sides of a branch carry different tags — identical asm statements at the head of both
+// successors are hoisted above the branch, and the values then cross it through register copies that hipcc places
+// BEFORE the hand-written s_waitcnt (it does not know the registers are still in flight)
+template <int TAG = 0>
 __device__ __forceinline__ s16x4 wd_tr_b64(unsigned addr) {
     s16x4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 ; %2" : "=v"(v) : "v"(addr), "n"(TAG) : "memory");
     return v;
 }
 __device__ __forceinline__ bf16x8 wd_pack_hi16(const f32x4 &d0, const f32x4 &d1) {
@@ -111,21 +116,10 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
         return;
     }
 
-    // one-hot B operands of the transposition: P[G][k = (g, q)][j = i] = 1 iff g >> 1 == G, g & 1 == j >> 3, q == j & 7
-    bf16x8 P[2];
-#pragma unroll
-    for (int G = 0; G < 2; ++G) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        const bool mine = (g >> 1) == G && (i >> 3) == (g & 1);
-        const int q = i & 7;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) v[w] = (mine && (q >> 1) == w) ? ((q & 1) ? 0x3F800000u : 0x00003F80u) : 0u;
-        P[G] = __builtin_bit_cast(bf16x8, v);
-    }
     if (tid < 4) reinterpret_cast<u32x4 *>(smem + (tid >> 1) * WD_BUF_BYTES)[tid & 1] = (u32x4){0u, 0u, 0u, 0u};   // zero rows
 
     const unsigned smem_base = (unsigned)(uintptr_t)smem;
-    const unsigned src_half = (unsigned)((lane & 1) ^ ((lane >> 4) & 1)) * 16u;   // half-row swizzle (spconv_dma.hip)
+    const unsigned src_half = (unsigned)(lane & 1) * 16u;      // rows land linearly: slot l at byte 32 l (read by transposed gathers)
     // Staging of one item by 16 waves.  Wave w moves two of the 32 row pieces — pieces (kb*8 + w8) and ((kb+1)*8 + w8)
     // with w8 = w & 7, kb = 2 (w >> 3): in the list's storage order (tb_upos) their entries are one 8-byte load per
     // lane —, one of the 16 index-strip pieces, and (waves 0..7) one of the 8 dy pieces.
@@ -146,8 +140,12 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
     auto issue_rows = [&](const Where &q, int item, int k, const u32x2 &rid) {      // k = 0, 1
         const unsigned buf = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
         const u32x4 rs_x = wd_rsrc(jobs.j[q.job].x, feat_bytes);
-        // an absent entry is negative: its row offset is out of range and lands as zeros
-        wd_dma16(buf + 32u + (unsigned)(((kb + k) * 8 + w8) * 1024), q.ok ? rid[k] * 32u + src_half : OOB, rs_x);
+        // The list is sorted with the absent entries (negative) at its end, and a piece covers 32 consecutive entries: a
+        // piece whose FIRST entry is absent stages nothing any local index points at — not issued (40 % of the pieces at
+        // ~600 distinct rows per tile; every wait in this kernel is vmcnt(0), so counts may differ between waves).  Inside
+        // the last used piece an absent entry's row offset is out of range and lands as zeros.
+        if (!q.ok || __builtin_amdgcn_readfirstlane((int)rid[k]) < 0) return;
+        wd_dma16(buf + 32u + (unsigned)(((kb + k) * 8 + w8) * 1024), rid[k] * 32u + src_half, rs_x);
     };
     auto issue_strip = [&](const Where &q, int item) {
         const unsigned buf = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
@@ -194,6 +192,13 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
         const unsigned short *xg = reinterpret_cast<const unsigned short *>(jobs.j[qc.job].x);
         wd_stamp(dbg, wid, item, 2);
         issue_list(q2, lnew);        // first thing: it has the whole tile to land (lnew held list(item): dead)
+        const bool early = (dbg & 256) != 0;      // (measurement) the next item's DMA at once instead of between the first steps
+        if (early) {
+            issue_rows(q1, item + 1, 0, lnext);
+            issue_rows(q1, item + 1, 1, lnext);
+            issue_strip(q1, item + 1);
+            issue_dy(q1, item + 1);
+        }
         // ---- dy fragments of the wave's four k-steps (every unit of wave w covers the half h = w & 1 of the tile):
         // channel i of rows 32 ks + 8 g + 0..7 ----
         const int q4 = i >> 2, c4 = i & 3, hw = wid & 1;
@@ -206,71 +211,76 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bt[0]), "+v"(bt[1]), "+v"(bt[2]), "+v"(bt[3]) : : "memory");
         wd_stamp(dbg, wid, item, 3);
-        // gathered x slices: lane (i, g) reads the half g & 1 of the row of output row 32 ks + 8 (i >> 2) + 4 (g >> 1) + (i & 3)
+        // (overflow path below) lane (i, g) reads the half g & 1 of the row of output row 32 ks + 8 (i >> 2) + 4 (g >> 1) + (i & 3)
         const int rl = 8 * (i >> 2) + 4 * (g >> 1) + (i & 3);
         const unsigned hsel = (unsigned)(g & 1);
         if (!no_list) {
-            // Branch-free and software-pipelined.  A step's chain (local index -> row slice -> two transposing MFMAs ->
-            // repack -> contraction) is ~500 cycles of latency: all local indices first (the four subtile entries of a
-            // lane's row in a 64-row group are one 8-byte read: two k-steps each), the row slices four steps ahead,
-            // and the transposing MFMAs of step s+1 issued BEFORE the repack + contraction of step s, so the matrix
-            // pipe works through the wait states an MFMA result needs before the VALU may read it.
-            constexpr int NS = WD_MAX_UNITS * 4;
-            const int sub = rl >> 4;                                   // the lane's subtile inside a 32-row k-step (0 / 1)
-            unsigned lsel[NS];
-#pragma unroll
-            for (int m = 0; m < WD_MAX_UNITS; ++m) {
-                const int unit = wid + WD_WAVES * m;
-                const int o = unit < WD_UNITS ? unit >> 1 : 0;          // (units past the end: any valid strip, results dropped)
-#pragma unroll
-                for (int kp = 0; kp < 2; ++kp) {
-                    // rows 64 (2 hw + kp) + 32 kk' + rl: entries 2 kk' + sub of the group's strip position 4 (rl & 15)
-                    const u32x2 v = *reinterpret_cast<const u32x2 *>(lidx_s + o * TB_T + (2 * hw + kp) * 64 + 4 * (rl & 15));
-                    const unsigned lo16 = sub ? (v[0] >> 16) : (v[0] & 0xffffu), hi16 = sub ? (v[1] >> 16) : (v[1] & 0xffffu);
-                    lsel[m * 4 + 2 * kp] = unit < WD_UNITS ? lo16 : 0u;
-                    lsel[m * 4 + 2 * kp + 1] = unit < WD_UNITS ? hi16 : 0u;
-                }
-            }
+            // The gathered operand comes out of LDS already in MFMA k-order: ds_read_b64_tr_b16 with per-lane addresses is a
+            // gather — lane 4 q + c of a 16-lane group points at chunk c (4 channels) of the staged row that the local index
+            // of output row 32 ks + 8 g + q selects and receives channel i of the rows q = 0..3 (second read: q + 4).
+            // Round 3 first used the matrix core for this (two one-hot MFMAs + four v_perm per k-step): PMC showed that
+            // form ISSUE-bound (per SIMD 30 % MFMA busy + ~19 VALU per step, LDS only 33 % busy: profiles/
+            // r03_pmc_wgrad_dma16.txt); the transposed gather costs ~2.5-way bank conflicts on an LDS that has the room.
+            // Per k-step: one 8-byte index read (two k-steps x lo/hi halves share two of them), two transposed reads, one
+            // MFMA.  Addresses of all the wave's steps first, reads three steps ahead of the MFMAs.
+            // Two units (eight steps) at a time: their sixteen row addresses live in registers, the next pair's are computed
+            // when these are spent (the wave budget is 128 VGPRs at 16 waves per workgroup).
+            const unsigned lane_off = rows_base + (unsigned)c4 * 8u;
+            const unsigned sh = (unsigned)(g >> 1) * 16u;                 // entry 2 (ks & 1) + (g >> 1) of the strip position
+            const bool tail_unit = wid + WD_WAVES * (WD_MAX_UNITS - 1) < WD_UNITS;   // the waves that own a unit 48 .. 53
             wd_stamp(dbg, wid, item, 4);
-            auto fetch = [&](unsigned l) {
-                return *reinterpret_cast<const u32x4 *>(buf + l * 32u + ((hsel ^ (((l - 1u) >> 3) & 1u)) << 4));
-            };
-            u32x4 xr[4];
-            xr[0] = fetch(lsel[0]);
-            xr[1] = fetch(lsel[1]);
-            xr[2] = fetch(lsel[2]);
-            f32x4 d0, d1;
-            {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, xr[0]);
-                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[0], zero, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[1], zero, 0, 0, 0);
-            }
-            auto one_step = [&](int st) {
-                const int m = st >> 2, kk = st & 3;
-                // the next item's DMA: in the FIRST steps of the tile (two buffers: it needs the rest of the tile to land),
-                // odd and even waves on alternating steps
-                if (st == (wid & 1)) issue_rows(q1, item + 1, 0, lnext);
-                if (st == 2 + (wid & 1)) issue_rows(q1, item + 1, 1, lnext);
-                if (st == 4 + (wid & 1)) issue_strip(q1, item + 1);
-                if (st == 6 + (wid & 1)) issue_dy(q1, item + 1);
-                if (st + 3 < NS) xr[(st + 3) & 3] = fetch(lsel[st + 3]);
-                f32x4 n0 = zero, n1 = zero;
-                if (st + 1 < NS) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, xr[(st + 1) & 3]);
-                    n0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[0], zero, 0, 0, 0);
-                    n1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, P[1], zero, 0, 0, 0);
+#pragma unroll
+            for (int mp = 0; mp < WD_MAX_UNITS / 2; ++mp) {
+                unsigned ra[8], rb[8];
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    const int unit = wid + WD_WAVES * (2 * mp + mm);
+                    const int o = unit < WD_UNITS ? unit >> 1 : 0;      // (a unit past the end: any valid strip, result dropped)
+#pragma unroll
+                    for (int kp = 0; kp < 2; ++kp) {
+                        // k-steps ks = 4 hw + 2 kp (+1): rows 32 ks + 8 g + q4 (+4) sit at strip position 8 (g & 1) + q4 (+4)
+                        // of the 64-row group ks >> 1 = 2 hw + kp
+                        const unsigned short *sp = lidx_s + o * TB_T + (2 * hw + kp) * 64 + (8 * (g & 1) + q4) * 4;
+                        const u32x2 v0 = *reinterpret_cast<const u32x2 *>(sp), v1 = *reinterpret_cast<const u32x2 *>(sp + 16);
+                        ra[mm * 4 + 2 * kp] = (__builtin_amdgcn_ubfe(v0[0], sh, 16u) << 5) + lane_off;
+                        ra[mm * 4 + 2 * kp + 1] = (__builtin_amdgcn_ubfe(v0[1], sh, 16u) << 5) + lane_off;
+                        rb[mm * 4 + 2 * kp] = (__builtin_amdgcn_ubfe(v1[0], sh, 16u) << 5) + lane_off;
+                        rb[mm * 4 + 2 * kp + 1] = (__builtin_amdgcn_ubfe(v1[1], sh, 16u) << 5) + lane_off;
+                    }
                 }
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd_pack_hi16(d0, d1), bt[kk], acc[m], 0, 0, 0);
-                d0 = n0;
-                d1 = n1;
                 __builtin_amdgcn_sched_barrier(0);
-            };
-            constexpr int LAST_FULL = (WD_UNITS / WD_WAVES) * 4;       // steps every wave has (units 0 .. 47)
+                // (the whole pipeline of a pair — first reads included — sits on ONE side of the branch below: a value of an
+                // inline-asm read that crossed it would be copied before its wait)
+                auto run_pair = [&](auto tagc) {
+                    constexpr int TAG = decltype(tagc)::value;
+                    constexpr int last = TAG == 1 ? 4 : 8;     // steps the wave runs in this pair
+                    s16x4 xl[3], xh[3];
+                    xl[0] = wd_tr_b64<TAG>(ra[0]); xh[0] = wd_tr_b64<TAG>(rb[0]);
+                    xl[1] = wd_tr_b64<TAG>(ra[1]); xh[1] = wd_tr_b64<TAG>(rb[1]);
 #pragma unroll
-            for (int st = 0; st < LAST_FULL; ++st) one_step(st);
-            if (wid + WD_WAVES * (WD_MAX_UNITS - 1) < WD_UNITS) {       // the waves that own a unit 48 .. 53
-#pragma unroll
-                for (int st = LAST_FULL; st < NS; ++st) one_step(st);
+                    for (int st = 0; st < last; ++st) {
+                        const int gs = mp * 8 + st, m = gs >> 2, kk = gs & 3;
+                        // the next item's DMA: in the FIRST steps of the tile (two buffers: it needs the rest of the tile to
+                        // land), odd and even waves on alternating steps
+                        if (!early) {
+                            if (gs == (wid & 1)) issue_rows(q1, item + 1, 0, lnext);
+                            if (gs == 2 + (wid & 1)) issue_rows(q1, item + 1, 1, lnext);
+                            if (gs == 4 + (wid & 1)) issue_strip(q1, item + 1);
+                            if (gs == 6 + (wid & 1)) issue_dy(q1, item + 1);
+                        }
+                        if (st + 2 < last) { xl[(st + 2) % 3] = wd_tr_b64<TAG>(ra[st + 2]); xh[(st + 2) % 3] = wd_tr_b64<TAG>(rb[st + 2]); }
+                        // LDS returns in order: everything but the reads of the steps after this one has landed
+                        const int newer = st + 2 < last ? 4 : 2 * (last - 1 - st);
+                        if (newer == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xl[st % 3]), "+v"(xh[st % 3]) : : "memory");
+                        else if (newer == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xl[st % 3]), "+v"(xh[st % 3]) : : "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xl[st % 3]), "+v"(xh[st % 3]) : : "memory");
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_shufflevector(xl[st % 3], xh[st % 3], 0, 1, 2, 3, 4, 5, 6, 7));
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bt[kk], acc[m], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                if (mp < WD_MAX_UNITS / 2 - 1 || tail_unit) run_pair(std::integral_constant<int, 0>{});
+                else run_pair(std::integral_constant<int, 1>{});      // the last pair of a wave without a fourth unit: four steps
             }
         } else {
             // a tile without a list (more than TB_UMAX distinct rows; none at 2 cm): slices through the dense table
@@ -278,6 +288,19 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
             issue_rows(q1, item + 1, 1, lnext);
             issue_strip(q1, item + 1);
             issue_dy(q1, item + 1);
+            // here the row slices (a 16-byte slice is the natural A operand: lane = row, registers = channels) reach k-order
+            // through the matrix core, as in the pair kernel: multiplied by a one-hot B operand they come back with
+            // lane = channel, registers = rows.  P[G][k = (g, q)][j = i] = 1 iff g >> 1 == G, g & 1 == j >> 3, q == j & 7
+            bf16x8 P[2];
+#pragma unroll
+            for (int G = 0; G < 2; ++G) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                const bool mine = (g >> 1) == G && (i >> 3) == (g & 1);
+                const int q = i & 7;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v[w] = (mine && (q >> 1) == w) ? ((q & 1) ? 0x3F800000u : 0x00003F80u) : 0u;
+                P[G] = __builtin_bit_cast(bf16x8, v);
+            }
 #pragma unroll 1
             for (int m = 0; m < WD_MAX_UNITS; ++m) {
                 const int unit = wid + WD_WAVES * m;

@@ -829,6 +829,37 @@ std::vector<at::Tensor> bn_relu_pass(const at::Tensor &x, const at::Tensor &weig
                         stats.has_value() ? *stats : at::Tensor());
 }
 
+// ---- a whole pre-activation residual block in ONE extension call ------------------------------------
+// reference model/unet_block.py:14-37:  y = conv2(relu(bn2(conv1(relu(bn1(x)))))) + skip,  skip = x or i_branch(x).
+// The same four ops (and the same autograd nodes, BatchNorm links, epilogue statistics) the Python modules issue one
+// by one — bn_relu_impl / indice_conv_impl — without ~50 us of interpreter work between them: the step is paced by
+// the issuing thread as much as by the GPU (tools/modeprobe.py).
+//   bn1, bn2 : {gamma, beta, running_mean, running_var, num_batches_tracked}
+//   cv1, cv2 : {weight [3,3,3,Cin,Cout], packed forward, packed data-grad}   (packed: may be None)
+//   rb       : {table (SubM: forward and data-grad), pair_in, pair_out, pair_num, pair_seg}   (lists: may be None)
+//   skip     : features of the 1x1 branch, or None for the identity skip (its gradient is then summed inside bn1's
+//              backward kernel: bn_relu_pass)
+// Returns {y, statistics of y or undefined}.
+std::vector<at::Tensor> residual_block(const at::Tensor &x, const c10::optional<at::Tensor> &stats_in,
+                                       const std::vector<at::Tensor> &bn1, const std::vector<at::Tensor> &bn2,
+                                       bool training, double momentum1, double eps1, double momentum2, double eps2,
+                                       const std::vector<c10::optional<at::Tensor>> &cv1,
+                                       const std::vector<c10::optional<at::Tensor>> &cv2,
+                                       const std::vector<c10::optional<at::Tensor>> &rb, int64_t n_out,
+                                       const c10::optional<at::Tensor> &skip, bool want_stats) {
+    TORCH_CHECK(bn1.size() == 5 && bn2.size() == 5 && cv1.size() == 3 && cv2.size() == 3 && rb.size() == 5 &&
+                cv1[0].has_value() && cv2[0].has_value() && rb[0].has_value(), "doda residual_block: bad argument lists");
+    const bool identity = !(skip.has_value() && skip->defined());
+    const at::Tensor &tbl = *rb[0];
+    auto a = bn_relu_impl(x, bn1[0], bn1[1], bn1[2], bn1[3], bn1[4], training, momentum1, eps1, true,
+                          identity && training, stats_in.has_value() ? *stats_in : at::Tensor());
+    auto z1 = indice_conv_impl(a[0], *cv1[0], tbl, tbl, n_out, 2, cv1[1], cv1[2], c10::nullopt, rb[1], rb[2], rb[3], rb[4],
+                               want_stats);
+    auto y2 = bn_relu_impl(z1[0], bn2[0], bn2[1], bn2[2], bn2[3], bn2[4], training, momentum2, eps2, true, false, z1[1]);
+    const at::Tensor res = identity ? (training ? a[1] : x) : *skip;
+    return indice_conv_impl(y2[0], *cv2[0], tbl, tbl, n_out, 2, cv2[1], cv2[2], res, rb[1], rb[2], rb[3], rb[4], want_stats);
+}
+
 }  // namespace
 
 // ---- optimizer step: all parameters in one launch (doda_sgd_multi) ------------------------------------
@@ -893,6 +924,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("bwd_layout"), py::arg("pk_fwd"), py::arg("pk_bwd"), py::arg("residual"),
           py::arg("pair_in") = py::none(), py::arg("pair_out") = py::none(), py::arg("pair_num") = py::none(),
           py::arg("pair_seg") = py::none());
+    m.def("residual_block", [](const at::Tensor &x, const c10::optional<at::Tensor> &stats_in, const std::vector<at::Tensor> &bn1,
+                               const std::vector<at::Tensor> &bn2, bool training, double momentum1, double eps1,
+                               double momentum2, double eps2, const std::vector<c10::optional<at::Tensor>> &cv1,
+                               const std::vector<c10::optional<at::Tensor>> &cv2,
+                               const std::vector<c10::optional<at::Tensor>> &rb, int64_t n_out,
+                               const c10::optional<at::Tensor> &skip, bool want_stats) {
+        auto r = residual_block(x, stats_in, bn1, bn2, training, momentum1, eps1, momentum2, eps2, cv1, cv2, rb, n_out, skip,
+                                want_stats);
+        return std::make_pair(r[0], r[1].defined() ? c10::optional<at::Tensor>(r[1]) : c10::nullopt);
+    }, "BatchNorm -> ReLU -> SubM conv -> BatchNorm -> ReLU -> SubM conv (+ skip) in one call");
     m.def("set_bn_fusion", [](bool on) { g_bn_fusion = on; }, "BatchNorm statistics in the conv epilogues (default on)");
     m.def("gather", [](const at::Tensor &x, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
                        const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32) {

@@ -45,6 +45,11 @@ def _shallow(t):
     return c
 
 
+# One extension call per residual block instead of one per BatchNorm / convolution (DODA_FAST_BLOCKS=0: module by module)
+import os as _os
+FAST_BLOCKS = _os.environ.get("DODA_FAST_BLOCKS", "1") == "1"
+
+
 def _subm3(cin, cout, key):
     return spconv.SubMConv3d(cin, cout, kernel_size=3, padding=1, bias=False, indice_key=key)
 
@@ -65,10 +70,94 @@ class ResidualBlock(SparseModule):
         # reference: output = conv_branch(input); output.features += i_branch(identity).features
         # (model/unet_block.py:33-37).  Here the add rides in the last convolution's store and, for an
         # identity skip, the skip's gradient in the first BatchNorm's backward kernel.
-        if type(self.i_branch[0]) is nn.Identity and len(self.i_branch) == 1:
+        identity = type(self.i_branch[0]) is nn.Identity and len(self.i_branch) == 1
+        if FAST_BLOCKS:
+            out = self._forward_one_call(input, identity)
+            if out is not None:
+                return out
+        if identity:
             return self.conv_branch(input, residual="input")
         skip = self.i_branch(_shallow(input))
         return self.conv_branch(input, residual=skip.features)
+
+    def _plan(self):
+        """The block's static operands for ext.residual_block — (generation, bn1 list, bn2 list, bn1, bn2, conv1, conv2) —
+        or False when the block is not the plain [BN, ReLU, SubM3, BN, ReLU, SubM3] of the reference."""
+        from .spconv import conv as _cv
+        plan = self.__dict__.get("_doda_plan")
+        if plan is not None and (plan is False or plan[0] == _cv._GEN[0]):
+            return plan
+        mods = list(self.conv_branch._modules.values())
+        ok = (len(mods) == 6 and type(mods[0]) is nn.BatchNorm1d and type(mods[1]) is nn.ReLU
+              and type(mods[3]) is nn.BatchNorm1d and type(mods[4]) is nn.ReLU
+              and all(type(m) is spconv.SubMConv3d and m.bias is None and m.kernel_size == [3, 3, 3] and not m.inverse
+                      and m.in_channels % 4 == 0 and m.out_channels % 4 == 0 for m in (mods[2], mods[5]))
+              and mods[2].indice_key is not None and mods[2].indice_key == mods[5].indice_key
+              and all(m.affine and m.track_running_stats and m.momentum is not None and not m._forward_hooks
+                      and not m._forward_pre_hooks for m in (mods[0], mods[3]))
+              and not any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in mods))
+        if not ok:
+            plan = False
+        else:
+            def bn_list(bn):
+                return [bn._parameters["weight"], bn._parameters["bias"], bn._buffers["running_mean"],
+                        bn._buffers["running_var"], bn._buffers["num_batches_tracked"]]
+            plan = (_cv._GEN[0], bn_list(mods[0]), bn_list(mods[3]), mods[0], mods[3], mods[2], mods[5])
+        self.__dict__["_doda_plan"] = plan
+        return plan
+
+    def _forward_one_call(self, input, identity):
+        """The whole block as ONE extension call (csrc_ext residual_block: the same native ops and autograd nodes the
+        module-by-module path issues, without the interpreter between them), or None when any precondition of that
+        path does not hold — then the modules run one by one as before."""
+        from .spconv import functional as Fsp
+        ext = Fsp._ext
+        if ext is None or not Fsp._SERIAL or not hasattr(ext, "residual_block"):
+            return None
+        plan = self._plan()
+        if plan is False:
+            return None
+        _, l1, l2, bn1, bn2, c1, c2 = plan
+        feats = input.features
+        training = bn1.training
+        if (not feats.is_cuda or feats.dim() != 2 or feats.shape[0] < 2 or feats.dtype not in (torch.float32, torch.bfloat16)
+                or bn2.training != training or c1.training != training or c2.training != training
+                or l1[0] is not bn1._parameters["weight"] or l2[0] is not bn2._parameters["weight"]
+                or l1[2] is not bn1._buffers["running_mean"] or l2[2] is not bn2._buffers["running_mean"]
+                or l1[0].dtype != torch.float32 or l2[0].dtype != torch.float32):
+            return None
+        data = input.find_indice_pair(c1.indice_key)
+        if data is None or data.kind != "subm":
+            return None
+        pk1 = c1._packed(feats, input.indice_dict)
+        pk2 = c2._packed(feats, input.indice_dict)
+        if pk1 is None or pk2 is None:
+            return None
+        skip = None
+        if not identity:
+            skip = self.i_branch(_shallow(input)).features
+            if skip.dtype != feats.dtype:
+                return None
+        n_out = data.outids.shape[0]
+        w1, w2 = c1._parameters["weight"], c2._parameters["weight"]
+        if Fsp._want_pairs(feats, w1) and Fsp._want_pairs(feats, w2):
+            p = data.wgrad_lists()
+            rb = [data.tbl, p[0], p[1], p[2], p[3] if len(p) > 3 else None]
+        elif Fsp._want_pairs(feats, w1) or Fsp._want_pairs(feats, w2):
+            return None
+        else:
+            rb = [data.tbl, None, None, None, None]
+        st = input.__dict__.get("_doda_stats")
+        stats_in = st[1] if (st is not None and st[0] is feats and st[2] == feats._version) else None
+        want_stats = training and Fsp.BN_FUSION and n_out > Fsp.STATS_MIN_ROWS
+        y, stats = ext.residual_block(feats, stats_in, l1, l2, training, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps,
+                                      [w1, pk1[0], pk1[1]], [w2, pk2[0], pk2[1]], rb, n_out, skip, want_stats)
+        out = spconv.SparseConvTensor(y, data.outids, data.out_spatial_shape, input.batch_size)
+        out.indice_dict = input.indice_dict
+        out.grid = input.grid
+        if stats is not None:
+            out._doda_stats = (y, stats, y._version)
+        return out
 
 
 class VGGBlock(SparseModule):

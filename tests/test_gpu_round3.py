@@ -652,3 +652,43 @@ def test_step_with_and_without_in_kernel_finish(native_lib):
     assert num / den < 2e-2, num / den
     for a, b in zip(b1, b0):
         assert rel_err(a, b) < 1e-3
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_residual_block_in_one_call_is_the_same_step(native_lib, dt):
+    """model.ResidualBlock through ext.residual_block (one extension call per block) issues the same native ops in the
+    same order as the module-by-module path: loss, every gradient, every BatchNorm buffer and the evaluation-mode output
+    must be BIT-equal, for identity and 1x1-conv skips, in both feature dtypes."""
+    _ext_or_skip()
+    from doda_amd import model as M
+    from doda_amd.scene import make_batch
+    d = dev()
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in make_batch(2, 30000, 11).items()}
+    cfg = M.default_cfg()
+
+    def run(fast):
+        M.FAST_BLOCKS = fast
+        torch.manual_seed(0)
+        net = M.SparseConvNet(cfg).to(d).train()
+        outs = []
+        for _ in range(2):      # second pass: weights repacked, running statistics moved
+            net.zero_grad(set_to_none=True)
+            loss = M.cross_entropy(M.voxelize_and_run(cfg, net, bd, d, feature_dtype=dt), bd["labels"])
+            loss.backward()
+            outs.append(loss.detach().clone())
+        grads = [p.grad.clone() for p in net.parameters()]
+        bufs = [b.clone() for b in net.buffers()]
+        net.eval()
+        with torch.no_grad():
+            ev = M.voxelize_and_run(cfg, net, bd, d, feature_dtype=dt).clone()
+        torch.cuda.synchronize()
+        return outs, grads, bufs, ev
+    try:
+        a = run(True)
+        b = run(False)
+    finally:
+        M.FAST_BLOCKS = True
+    assert all(torch.equal(x, y) for x, y in zip(a[0], b[0]))
+    assert all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+    assert torch.equal(a[3], b[3])

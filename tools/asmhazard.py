@@ -28,6 +28,7 @@ def main(path, name):
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = lines[start:end]
     queue = []   # (dest regs, text, line)
+    lqueue = []  # the same for LGKM operations
     in_asm = False
     hazards = []
     for rep in range(2):
@@ -43,6 +44,7 @@ def main(path, name):
                 continue
             op = t.split()[0]
             flying = set().union(*[q[0] for q in queue]) if queue else set()
+            lflying = set().union(*[q[0] for q in lqueue]) if lqueue else set()
             if in_asm and op.startswith("buffer_load"):
                 args = t[len(op):].split(",")
                 lds = " lds" in t
@@ -57,13 +59,29 @@ def main(path, name):
                     hazards.append((start + n + 1, t, sorted(regs(t) & flying)))
                 queue.append((set(), t, start + n + 1))
                 continue
+            # LDS reads issued from inline asm (ds_read_b64_tr_b16 ...): same rule against lgkmcnt.  Every LGKM operation
+            # enters the queue (LDS returns in order; a scalar load may return early, which only retires MORE); any
+            # s_waitcnt lgkmcnt(N), hand-written or hipcc's, retires all but the newest N.
+            if op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_memtime") or op.startswith("s_buffer_load"):
+                dest = regs(t[len(op):].split(",")[0]) if (in_asm and op.startswith("ds_read")) else set()
+                touched = regs(t)
+                if touched & lflying:
+                    hazards.append((start + n + 1, t, sorted(touched & lflying)))
+                lqueue.append((dest, t, start + n + 1))
+                continue
+            if op == "s_waitcnt" and "lgkmcnt" in t:
+                keep = int(re.search(r"lgkmcnt\((\d+)\)", t).group(1))
+                while len(lqueue) > keep:
+                    lqueue.pop(0)
+                if not ("vmcnt" in t):
+                    continue
             if in_asm and op == "s_waitcnt" and "vmcnt" in t:
                 keep = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
                 while len(queue) > keep:
                     queue.pop(0)
                 continue
-            if regs(t) & flying:
-                hazards.append((start + n + 1, t, sorted(regs(t) & flying)))
+            if regs(t) & (flying | lflying):
+                hazards.append((start + n + 1, t, sorted(regs(t) & (flying | lflying))))
     seen = set()
     for ln, t, r in hazards:
         if (ln, t) in seen:
