@@ -98,6 +98,8 @@ _SIGNATURES = {
     "doda_bn_relu_bwd_totals": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                         c_vp, c_vp, c_vp, c_vp]),
     "doda_spconv_set_stats_finish": (None, [c_i32]),
+    "doda_bn_set_chain": (None, [c_i32]),
+    "doda_bn_chain_errors": (C.c_int64, []),
     "doda_sgd_multi_desc_bytes": (c_sz, [c_i32]),
     "doda_sgd_multi": (c_i32, [c_vp, c_i32, C.c_double, C.c_double, C.c_double, C.c_double, c_i32, c_i32, c_vp,
                                c_sz, c_vp]),

@@ -424,6 +424,15 @@ int doda_bn_relu_bwd_stats(const void *x, const void *dy, int32_t m, int32_t c, 
                            const void *add, void *dx, float *dgamma, float *dbeta, float *coef_ws,
                            doda_stream_t stream);
 
+/* ABI 5.  doda_bn_relu_fwd_stats / _bwd_stats can run their two passes — the reduction of the partial rows and the apply
+ * sweep — as ONE launch: the grid's first c/4 workgroups reduce and publish, the others wait on a device flag and then
+ * sweep (csrc/bn.hip bn_fwd_chain).  Off by default (it saves issue time but not GPU time on MI355X); doda_bn_set_chain(1)
+ * or DODA_BN_CHAIN=1 turns it on;
+ * doda_bn_chain_errors() synchronises the device and returns how many launches gave up waiting (0 unless a kernel
+ * died; -1 on a runtime error). */
+void doda_bn_set_chain(int32_t on);
+int64_t doda_bn_chain_errors(void);
+
 /* ABI 5.  Same with the statistics already summed over all rows by the conv kernel itself
  * (doda_conv_epilogue.totals: double [2][c]): ONE launch per direction.  Every workgroup of the apply pass derives the
  * per-channel vectors from the totals (fp64, as the `final` kernels do); workgroup 0 also writes save_mean /

@@ -692,3 +692,38 @@ def test_residual_block_in_one_call_is_the_same_step(native_lib, dt):
     assert all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
     assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
     assert torch.equal(a[3], b[3])
+
+
+def test_batchnorm_passes_chained_in_one_launch(native_lib):
+    """doda_bn_relu_fwd_stats / _bwd_stats as ONE launch (bn_fwd_chain / bn_bwd_chain: the grid's first workgroups reduce
+    the partial rows and publish, the rest wait on a device flag, then sweep) against the two dependent launches: the
+    same arithmetic, so loss, gradients and BatchNorm buffers of a training step are BIT-equal; nobody gave up waiting."""
+    _ext_or_skip()
+    from doda_amd._lib import lib
+    from doda_amd import model as M
+    from doda_amd.scene import make_batch
+    d = dev()
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in make_batch(2, 40000, 13).items()}
+    cfg = M.default_cfg()
+
+    def run(on):
+        lib().doda_bn_set_chain(1 if on else 0)
+        torch.manual_seed(0)
+        net = M.SparseConvNet(cfg).to(d).train()
+        losses = []
+        for _ in range(3):
+            net.zero_grad(set_to_none=True)
+            loss = M.cross_entropy(M.voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.bfloat16), bd["labels"])
+            loss.backward()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        return losses, [p.grad.clone() for p in net.parameters()], [b.clone() for b in net.buffers()]
+    try:
+        a = run(True)
+        b = run(False)
+    finally:
+        lib().doda_bn_set_chain(0)      # (the default: it saves issue time, not GPU time)
+    assert all(torch.equal(x, y) for x, y in zip(a[0], b[0]))
+    assert all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+    assert lib().doda_bn_chain_errors() == 0
