@@ -6,19 +6,22 @@
 // The pair-list kernel (spconv_wgrad_pairs.hip) gathers one 32-byte x row and one 32-byte dy row PER PAIR from
 // global memory: 12.4 pairs per voxel x 64 B = 0.8 KB of texture-path traffic per voxel against 137 B of operands
 // (PMC: GRBM_TA_BUSY 93 %); cold it runs at 57 us per level-1 layer.  Here a tile of 256 output rows t is staged
-// ONCE in LDS — the ~2.3 x 256 distinct x rows its table entries reference (LDS-DMA, exactly the forward kernel's
-// staging: spconv_dma.hip) and its 256 dy rows — and every (offset, 32-row k-step) is served from there:
-//   * dy (dense: rows t0 .. t0+255) reaches MFMA k-order through ds_read_b64_tr_b16 (conflict-free on contiguous rows);
-//   * the gathered x row slices (random LDS rows: the transposed read conflicts 4-way there, which is what sank
-//     bwd_tile) are brought into k-order by the matrix core itself, as in the pair kernel: a 16-byte row slice is the
-//     natural A operand of v_mfma_f32_16x16x32_bf16 (lane = row, registers = channels); multiplied by a one-hot B
-//     operand it comes back with lane = channel, registers = rows (products with 1.0, sums with zeros: exact).
-// Per (offset, k-step): one local-index read, one 16-byte LDS row read, two transposing MFMAs, one contraction MFMA;
-// an (offset, k-step) whose 32 rows have no neighbour under that offset is skipped (wave-uniform test).
-// ONE persistent 8-wave workgroup per CU with two tile buffers: the DMA of tile j+1 is issued between the units of
-// tile j, each wave at a different unit (the waves leave the barrier together, and eight waves queueing on the CU's
+// ONCE in LDS — the ~2.5 x 256 distinct x rows its table entries reference (LDS-DMA through the tilebook's list, as the
+// forward kernel of spconv_dma.hip stages them; pieces past the list's end are not issued) and its 256 dy rows — and
+// every (offset, 32-row k-step) is served from there.  BOTH operands reach MFMA k-order through ds_read_b64_tr_b16:
+//   * dy (dense: rows t0 .. t0+255) with contiguous addresses (conflict-free);
+//   * the gathered x rows with PER-LANE addresses built from the tile's local indices: lane 4q + c of a 16-lane group
+//     points at chunk c (4 channels) of the staged row that output row q's index selects (an absent neighbour: the
+//     shared zero row) and receives channel i of the four rows — ~2.5-way bank conflicts on randomly placed rows.
+// Per (offset, k-step): one 8-byte local-index read per two steps, two transposed reads, one MFMA.
+// (Round 3's first form transposed the gathered 16-byte row slices on the matrix core — two one-hot MFMAs + four v_perm
+// per step, as the pair kernel does.  PMC showed it ISSUE bound: MFMA pipe 30 % busy, ~19 VALU per step, LDS only 33 %
+// busy, 34 % issue stalls; the transposed gather trades that for LDS conflicts the LDS had room for: 39 -> 31.5 us cold
+// per level-1 layer.  profiles/r03_pmc_wgrad_dma16.txt.)
+// ONE persistent 16-wave workgroup per CU with two tile buffers: the DMA of tile j+1 is issued between the first steps
+// of tile j, each wave at a different step (the waves leave the barrier together, and sixteen waves queueing on the CU's
 // texture path at the same instant stall each other instead of overlapping with the matrix work).
-// The 54 units (offset, half of the tile's k-steps) are dealt to the 8 waves; accumulators stay in registers across
+// The 54 units (offset, half of the tile's k-steps) are dealt to the 16 waves; accumulators stay in registers across
 // all tiles of a layer; per layer and workgroup one partial [27][16][16] is written (256 partials instead of the 768
 // a three-workgroups-per-CU schedule would produce), summed in a fixed order by wgrad_dma_reduce: deterministic.
 #include "common.hpp"
