@@ -81,7 +81,7 @@ class ResidualBlock(SparseModule):
         return self.conv_branch(input, residual=skip.features)
 
     def _plan(self):
-        """The block's static operands for ext.residual_block — (generation, bn1 list, bn2 list, bn1, bn2, conv1, conv2) —
+        """The block's static operands for ext.residual_block — (generation, bn1 list, bn2 list, bn1, bn2, conv1, conv2, the six modules) —
         or False when the block is not the plain [BN, ReLU, SubM3, BN, ReLU, SubM3] of the reference."""
         from .spconv import conv as _cv
         plan = self.__dict__.get("_doda_plan")
@@ -102,7 +102,7 @@ class ResidualBlock(SparseModule):
             def bn_list(bn):
                 return [bn._parameters["weight"], bn._parameters["bias"], bn._buffers["running_mean"],
                         bn._buffers["running_var"], bn._buffers["num_batches_tracked"]]
-            plan = (_cv._GEN[0], bn_list(mods[0]), bn_list(mods[3]), mods[0], mods[3], mods[2], mods[5])
+            plan = (_cv._GEN[0], bn_list(mods[0]), bn_list(mods[3]), mods[0], mods[3], mods[2], mods[5], tuple(mods))
         self.__dict__["_doda_plan"] = plan
         return plan
 
@@ -117,7 +117,15 @@ class ResidualBlock(SparseModule):
         plan = self._plan()
         if plan is False:
             return None
-        _, l1, l2, bn1, bn2, c1, c2 = plan
+        _, l1, l2, bn1, bn2, c1, c2, all_mods = plan
+        # hooks registered since the plan was made (feature taps, profilers) must fire: module by module then
+        from torch.nn.modules import module as _mod
+        if (_mod._global_forward_hooks or _mod._global_forward_pre_hooks or _mod._global_backward_hooks
+                or _mod._global_backward_pre_hooks or self.conv_branch._forward_hooks or self.conv_branch._forward_pre_hooks):
+            return None
+        for m in all_mods:
+            if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+                return None
         feats = input.features
         training = bn1.training
         if (not feats.is_cuda or feats.dim() != 2 or feats.shape[0] < 2 or feats.dtype not in (torch.float32, torch.bfloat16)

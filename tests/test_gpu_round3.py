@@ -727,3 +727,25 @@ def test_batchnorm_passes_chained_in_one_launch(native_lib):
     assert all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
     assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
     assert lib().doda_bn_chain_errors() == 0
+
+
+def test_one_call_block_yields_to_hooks(native_lib):
+    """A forward hook registered on a module inside a residual block AFTER the block already ran through the one-call path
+    must fire: the block falls back to module-by-module execution."""
+    _ext_or_skip()
+    from doda_amd import model as M
+    from doda_amd.scene import make_batch
+    d = dev()
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in make_batch(1, 20000, 3).items()}
+    cfg = M.default_cfg()
+    torch.manual_seed(0)
+    net = M.SparseConvNet(cfg).to(d).train()
+    M.voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.bfloat16)        # plans made, no hooks yet
+    seen = []
+    blk = net.unet.blocks.block0
+    h = blk.conv_branch[2].register_forward_hook(lambda mod, inp, out: seen.append(tuple(out.features.shape)))
+    try:
+        M.voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.bfloat16)
+    finally:
+        h.remove()
+    assert len(seen) == 1 and seen[0][1] == 16
