@@ -98,6 +98,8 @@ _SIGNATURES = {
     "doda_bn_relu_bwd_totals": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                         c_vp, c_vp, c_vp, c_vp]),
     "doda_spconv_set_stats_finish": (None, [c_i32]),
+    "doda_spconv_prologue_ok": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "doda_bn_fwd_final": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "doda_bn_set_chain": (None, [c_i32]),
     "doda_bn_chain_errors": (C.c_int64, []),
     "doda_sgd_multi_desc_bytes": (c_sz, [c_i32]),
@@ -116,7 +118,7 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-ABI_VERSION = 5   # include/doda_hip.h DODA_ABI_VERSION
+ABI_VERSION = 6   # include/doda_hip.h DODA_ABI_VERSION
 
 _lib = None
 

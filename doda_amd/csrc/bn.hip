@@ -1198,6 +1198,18 @@ extern "C" int doda_bn_relu_fwd_stats(const void *x, int32_t m, int32_t c, int32
                                (long long *)num_batches_tracked, relu, y, save_mean, save_invstd, as_stream(stream));
 }
 
+// ABI 6: the reduction alone — the apply pass rides in the consuming convolution's prologue (spconv_tile.hip, PRE)
+extern "C" int doda_bn_fwd_final(const float *stats, int32_t stats_rows, int32_t m, int32_t c, float eps, float momentum,
+                                 float *running_mean, float *running_var, int64_t *num_batches_tracked, float *save_mean,
+                                 float *save_invstd, doda_stream_t stream) {
+    if (m == 0) return DODA_OK;
+    if (bn_args_bad(m, c, 2)) return DODA_ERR_UNSUPPORTED;
+    if (!stats || stats_rows <= 0 || !save_mean || !save_invstd || (!running_mean != !running_var)) return DODA_ERR_INVALID;
+    hipLaunchKernelGGL(bn_fwd_final_stats, dim3(c / 4), dim3(BN_BLOCK), 0, as_stream(stream), stats, stats_rows, m, c, eps,
+                       momentum, save_mean, save_invstd, running_mean, running_var, (long long *)num_batches_tracked);
+    return doda_check_launch();
+}
+
 template <class T>
 static int run_fwd_totals(const void *x_, int m, int c, const double *totals, float eps, float momentum, const float *gamma,
                           const float *beta, float *rm, float *rv, long long *nbt, int relu, void *y_, float *mean,

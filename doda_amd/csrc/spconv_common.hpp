@@ -65,6 +65,10 @@ struct EpiArgs {   // plain data, shared across translation units
     int fin_rows;            // partial rows this launch writes (set by the launcher)
     double *totals;          // [2][nc] or null (the caller reduces the rows itself)
     unsigned *ticket;        // device counter of retired workgroups: zero between launches, re-armed by the last one
+    // BatchNorm(+ReLU) PROLOGUE (ABI 6, doda_conv_epilogue.pre_*): applied to every gathered input row; null = none
+    const float *pre_mean, *pre_invstd, *pre_gamma, *pre_beta;   // [kc] each
+    int pre_relu;
+    void *pre_out;           // [n_in, kc] normalised rows (bf16) or null
 };
 
 constexpr unsigned FIN_GROUP = 32;         // workgroups per first-level ticket
@@ -82,6 +86,46 @@ extern thread_local int last_finished;        // set by arm(): did the last laun
 }  // namespace doda_fin
 
 namespace {
+
+// ---- BatchNorm(+ReLU) prologue: the per-channel vectors of the eight channels a lane's 16-byte row piece holds, and
+// bn.hip's bn_apply arithmetic on that piece — the same operations in the same order (the library is built with
+// -ffp-contract=off), the same bf16 rounding: a conv with the prologue equals BatchNorm launch + conv bit for bit
+// (a NaN may come out with another payload).
+struct PreVec { f32x4 mu[2], is[2], ga[2], be[2]; };
+__device__ __forceinline__ void pre_load(PreVec &p, const EpiArgs &ep, unsigned c0) {   // channels c0 .. c0 + 7
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        p.mu[h] = *reinterpret_cast<const f32x4 *>(ep.pre_mean + c0 + 4 * h);
+        p.is[h] = *reinterpret_cast<const f32x4 *>(ep.pre_invstd + c0 + 4 * h);
+        p.ga[h] = *reinterpret_cast<const f32x4 *>(ep.pre_gamma + c0 + 4 * h);
+        p.be[h] = *reinterpret_cast<const f32x4 *>(ep.pre_beta + c0 + 4 * h);
+    }
+}
+// two fp32 -> packed bf16 by the hardware's v_cvt_pk_bf16_f32 (round to nearest even: the bits f2bf() produces for every
+// finite value and infinity; f2bf's NaN test compiles to EXEC-masked control flow — 4 scalar + ~8 vector instructions per
+// element, which made the prologue cost 32 us per level-1 layer instead of 4)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ u32x4 pre_apply8(const u32x4 &r, const PreVec &p, int relu) {
+    u32x4 o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x4 v = {__uint_as_float(r[2 * h] << 16), __uint_as_float(r[2 * h] & 0xffff0000u),
+                         __uint_as_float(r[2 * h + 1] << 16), __uint_as_float(r[2 * h + 1] & 0xffff0000u)};
+        f32x4 t = (v - p.mu[h]) * p.is[h] * p.ga[h] + p.be[h];
+        if (relu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = t[q] > 0.f ? t[q] : 0.f;
+        }
+        o[2 * h] = cvt_pk_bf16(t[0], t[1]);
+        o[2 * h + 1] = cvt_pk_bf16(t[2], t[3]);
+    }
+    return o;
+}
 
 // statistics rows travel between workgroups of ONE launch that may sit on different XCDs (one L2 each): write-through
 // stores, L2-bypassing loads (sc0 sc1 = system-coherent on gfx950), ordered by hand around the ticket
@@ -181,6 +225,8 @@ bool enabled();   // doda_spconv_set_tile_kernel
 int launch_conv_tile(int mode, bool out32, const void *x, unsigned x_bytes, const void *wp, unsigned wp_bytes, int nc, int NB,
                      const int32_t *tbl, int ld, int n_out, const void *tilebook, void *y, unsigned y_bytes, const void *res,
                      const EpiArgs &ep, int *n_part, hipStream_t s);
+// does launch_conv_tile take ep.pre_* (BatchNorm prologue) for this mode / output type
+inline bool takes_prologue(int mode, bool out32) { return (mode == 0 || mode == 1) && !out32; }
 void pack_pair_layout2(const float *w, void *out, hipStream_t s);   // defined next to the pack kernels
 }  // namespace doda_tile
 

@@ -887,12 +887,13 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
             const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
             const unsigned yb = (unsigned)((size_t)n_out * nc * (out32 ? 4 : sizeof(elem)));
             // 16 -> 16 with bf16 outputs (the level-1 block convolutions, both directions): the LDS-DMA pipeline
-            if (tmode == 0 && !out32 && nc == 16 && doda_dma::enabled())
+            if (tmode == 0 && !out32 && nc == 16 && doda_dma::enabled() && !ep.pre_mean)
                 return doda_dma::launch_conv16(x_, xb, wp, (unsigned)need, tbl, ld, n_out, tilebook, y_, yb, res, ep, n_part, s);
             return doda_tile::launch_conv_tile(tmode, out32 || sizeof(elem) == 4, x_, xb, wp, (unsigned)need, nc, NB, tbl, ld,
                                                n_out, tilebook, y_, yb, res, ep, n_part, s);
         }
     }
+    if (ep.pre_mean) return DODA_ERR_UNSUPPORTED;   // BatchNorm prologue: tile kernels only (doda_spconv_prologue_ok)
     // 48 -> 48 channels on a mid-size level: the layer's fragments in LDS, one workgroup per CU (spconv_wlds.hip)
     if (wide && kc == 48 && nc == 48 && K == 27 && !out32 && n_out >= 8192 && n_out <= 262144 && doda_wlds::enabled()) {
         const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
@@ -1112,6 +1113,14 @@ extern "C" void doda_spconv_set_wlds_kernel(int32_t on) { doda_wlds::set_enabled
 
 extern "C" size_t doda_spconv_stats_capacity(int32_t n_out) { return n_out > 0 ? (size_t)div_up(n_out, 16) : 1; }
 
+extern "C" int32_t doda_spconv_prologue_ok(int32_t kc, int32_t nc, int32_t K, int32_t elem_bytes, int32_t y_is_f32,
+                                           int32_t n_in, int32_t n_out, int32_t has_tilebook) {
+    if (elem_bytes != 2 || y_is_f32 || K != TB_K || !has_tilebook || n_in != n_out || n_out <= 0 || nc <= 0 || nc % 4) return 0;
+    if (!doda_tile::enabled()) return 0;
+    if ((size_t)n_out * nc * 4 >= 0x7fffffffull || (size_t)n_in * kc * 2 >= 0x7ffffff0ull) return 0;
+    return (kc == 16 || kc == 32) ? 1 : 0;   // conv_tile MODE 0 / MODE 1
+}
+
 extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, int32_t elem_bytes, const float *w,
                                      int32_t nc, const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, void *y,
                                      int32_t y_is_f32, int32_t w_layout, void *ws, size_t ws_bytes,
@@ -1142,6 +1151,16 @@ extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, in
                 ep.bn_gamma = epi->bn_gamma; ep.bn_beta = epi->bn_beta;
                 ep.bn_relu = epi->bn_relu;
             }
+        }
+        if (epi->pre_mean) {   // ABI 6: BatchNorm(+ReLU) prologue
+            if (!epi->pre_invstd || !epi->pre_gamma || !epi->pre_beta || ((uintptr_t)epi->pre_out & 15)) return DODA_ERR_INVALID;
+            if (!doda_spconv_prologue_ok(kc, nc, K, elem_bytes, y_is_f32, n_in, n_out, epi->tilebook != nullptr) ||
+                epi->tilebook_rows != n_out)
+                return DODA_ERR_UNSUPPORTED;
+            ep.pre_mean = epi->pre_mean; ep.pre_invstd = epi->pre_invstd;
+            ep.pre_gamma = epi->pre_gamma; ep.pre_beta = epi->pre_beta;
+            ep.pre_relu = epi->pre_relu;
+            ep.pre_out = epi->pre_out;
         }
     }
     if (elem_bytes == 4)

@@ -145,7 +145,19 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<O
 //         workgroups per CU, which still keeps ~70 KB of row loads in flight per CU).
 // MODE 2: fp32, 16 input channels (64-byte rows staged exactly as MODE 1; four v_mfma_f32_16x16x4_f32 per unit and
 //         subtile — the reference's precision; MFMA-bound at ~53 us for the level-1 layer instead of 80 us).
-template <int MODE, bool OUT32, bool STATS>
+// PRE (ABI 6): BatchNorm(+ReLU) prologue.  The staged rows pass through registers on their way to LDS, so the
+//         normalisation z = relu((x - mean) * invstd * gamma + beta) is applied THERE — once per distinct row of a tile
+//         (~2.5 x 256), not once per gathered operand (12 x 256) — and the multiply phase reads z from LDS as before.  The
+//         rows of the list that are the tile's OWN rows (SubM: the centre tap) are also stored to ep.pre_out: the
+//         normalised tensor the weight gradient gathers from.  The BatchNorm's apply launch (a read and a write of the
+//         whole tensor, and a launch) is gone; its statistics still come from the producing conv's epilogue + `final`.
+//         MEASURED (profiles/r03_bn_prologue.txt): bit-equal, and SLOWER than the launch it removes — the tile loop is a
+//         latency chain (list -> rows -> LDS -> multiply -> store, ~9 us per tile) and everything added between the row
+//         loads and the barrier lengthens it: level-1 16 -> 16 27.3 -> 38.9 us without overflow tiles (the apply launch
+//         costs 11 us), 28.5 -> 49.7 us with the bench scene's six tiles without a list, whose gathered operands are
+//         normalised 12 x per row in a serial chain (a tail the whole grid waits for); 32 channels +56 us at 601k rows.
+//         Kept as an opt-in (DODA_BN_PROLOGUE=1) with its parity tests.
+template <int MODE, bool OUT32, bool STATS, bool PRE = false>
 __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, unsigned x_bytes,
                                                  const void *__restrict__ wp, unsigned wp_bytes, int nc, int NB,
                                                  const int32_t *__restrict__ tbl, int ld, int n_out,
@@ -180,6 +192,32 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
     const int qn = tb.nt >> 3, rn = tb.nt & 7;
     const int lo = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
     const int cnt = qn + (xcd < rn ? 1 : 0);
+
+    // PRE: the BatchNorm vectors sit in LDS (4 x kc floats) and are read into registers per tile, AFTER the index strip
+    // has left its registers for LDS: held across the persistent loop their 32 VGPRs pushed the 16-channel kernel from
+    // 3 to 2 workgroups per CU (138 -> 196 VGPRs)
+    static_assert(!PRE || (MODE != 2 && !OUT32), "the prologue is built for bf16 features and outputs");
+    __shared__ __attribute__((aligned(16))) float pre_s[PRE ? 4 * (RB / 2) : 1];
+    __amdgpu_buffer_rsrc_t rs_z = rs_x;
+    if constexpr (PRE) {
+        constexpr int KC = RB / 2;
+        if (tid0 < 4 * KC) {
+            const float *src = tid0 < KC ? ep.pre_mean : tid0 < 2 * KC ? ep.pre_invstd : tid0 < 3 * KC ? ep.pre_gamma : ep.pre_beta;
+            pre_s[tid0] = src[tid0 & (KC - 1)];
+        }
+        rs_z = __builtin_amdgcn_make_buffer_rsrc(ep.pre_out, 0, ep.pre_out ? x_bytes : 0u, 0x00020000);
+        __syncthreads();
+    }
+    auto pre_vec = [&](PreVec &p, unsigned c0) {   // channels c0 .. c0 + 7
+        constexpr int KC = RB / 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            p.mu[h] = *reinterpret_cast<const f32x4 *>(pre_s + c0 + 4 * h);
+            p.is[h] = *reinterpret_cast<const f32x4 *>(pre_s + KC + c0 + 4 * h);
+            p.ga[h] = *reinterpret_cast<const f32x4 *>(pre_s + 2 * KC + c0 + 4 * h);
+            p.be[h] = *reinterpret_cast<const f32x4 *>(pre_s + 3 * KC + c0 + 4 * h);
+        }
+    };
 
     // piece h = 16 bytes: PPR consecutive lanes take the pieces of one list entry (a wave reads 32 or 16
     // consecutive entries per instruction).  Entries past the count are -1: their row offset is out
@@ -242,14 +280,48 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                 if (e < TB_K * TB_T * 2 / 16) reinterpret_cast<u32x4 *>(lidx_s)[e] = li4[k];
             }
             if (tid < PPR) reinterpret_cast<u32x4 *>(rows_s)[tid] = (u32x4){0u, 0u, 0u, 0u};
+            // PRE: every load slot is normalised, also the ones past the list's count (zeros in, never referenced): 40
+            // VALU instructions per slot, and NO branch — a wave-uniform skip of the empty slots made hipcc drain the
+            // vector-memory counter at the join, i.e. wait for the NEXT tile's list here (+17 us per level-1 layer)
+            PreVec pv;
+            if constexpr (PRE) pre_vec(pv, (unsigned)(tid & (PPR - 1)) * 8u);
 #pragma unroll
-            for (int k = 0; k < NRL; ++k)
+            for (int k = 0; k < NRL; ++k) {
+                if constexpr (PRE) rr[k] = pre_apply8(rr[k], pv, ep.pre_relu);
                 if (k * 256 + tid < PPR * CAP) reinterpret_cast<u32x4 *>(rows_s)[PPR + k * 256 + tid] = rr[k];
+            }
         } else if (tt + L < cnt) {
             load_list(tile + L, tid, rid);
             U = tb.ucount[tile + L];
         }
+        if constexpr (PRE) {
+            if (!staged && ep.pre_out) {   // a tile without a list: its own rows, normalised, straight to pre_out
+                PreVec pv;
+                pre_vec(pv, (unsigned)(tid & (PPR - 1)) * 8u);
+#pragma unroll
+                for (int k = 0; k < PPR; ++k) {
+                    const unsigned r = (unsigned)t0 + (unsigned)(k * 256 + tid) / (unsigned)PPR;
+                    const unsigned off = r < (unsigned)n_out ? r * (unsigned)RB + (unsigned)(tid & (PPR - 1)) * 16u : OOB;
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(pre_apply8(v, pv, ep.pre_relu), rs_z, off, 0, 0);
+                }
+            }
+        }
         __syncthreads();
+        if constexpr (PRE) {
+            // side output: the tile's own rows (SubM centre tap, offset 13: always present) leave LDS for pre_out, 64
+            // consecutive 16-byte pieces per store instruction, while the multiply phase runs
+            // (branch-free: a tile without a list, or a call without pre_out, stores out of range)
+#pragma unroll
+            for (int j = 0; j < PPR; ++j) {
+                const int rl = (lane / PPR) + j * (64 / PPR);          // row inside the wave's 64
+                const unsigned r = (unsigned)row0 + (unsigned)rl;
+                const unsigned slot_c = lidx_s[(TB_K / 2) * TB_T + wid * 64 + tb_pos(rl)];
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(rows_s + slot_c * (unsigned)RB + (unsigned)(lane & (PPR - 1)) * 16u);
+                const unsigned off = (staged && r < (unsigned)n_out) ? r * (unsigned)RB + (unsigned)(lane & (PPR - 1)) * 16u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_z, off, 0, 0);
+            }
+        }
 
         for (int nb0 = 0; nb0 < NB; ++nb0) {
             if (nb0 > 0) {
@@ -304,6 +376,8 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                 // laundered: otherwise its 27 multiples are hoisted out of the tile loop.)
                 unsigned ldv = (unsigned)ld;
                 asm volatile("" : "+s"(ldv));
+                PreVec pvh;   // PRE: the vectors of the operand piece this lane gathers (piece `half`, not the staging piece)
+                if constexpr (PRE) pre_vec(pvh, half / 2u);
 #pragma unroll
                 for (int u0 = 0; u0 < NU; u0 += 2) {
                     unsigned go[2][S];
@@ -327,6 +401,10 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                             const int t = row0 + s * 16 + i;
                             const bool present = osel < TB_K && t < n_out && (int)go[du][s] >= 0;   // out-of-range table reads return 0
                             xa[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, present ? go[du][s] * (unsigned)RB + half : OOB, 0, 0);
+                            if constexpr (PRE) {   // an absent neighbour stays zero
+                                const u32x4 z = pre_apply8(xa[s], pvh, ep.pre_relu);
+                                xa[s] = present ? z : (u32x4){0u, 0u, 0u, 0u};
+                            }
                         }
                         const u32x4 wu = loadw(u0 + du);
 #pragma unroll
@@ -691,6 +769,16 @@ int doda_tile::launch_conv_tile(int mode, bool out32, const void *x, unsigned xb
     if (n_part) *n_part = groups;      // one statistics row per persistent workgroup
     EpiArgs ep = ep_in;
     if (ep.stats) doda_fin::arm(ep, groups, (unsigned)groups, s);
+    if (ep.pre_mean) {   // BatchNorm prologue: bf16 features and outputs, SubM (the table's rows are the input's rows)
+        if (!doda_tile::takes_prologue(mode, out32) || (size_t)xb != (size_t)n_out * (mode == 0 ? 32u : 64u))
+            return DODA_ERR_UNSUPPORTED;
+#define GP(M, ST)                                                                                  \
+    hipLaunchKernelGGL((conv_tile<M, false, ST, true>), grid, block, 0, s, x, xb, wp, wpb, nc, NB, tbl, ld, n_out, tb, y, yb, res, ep)
+        if (mode == 1) { if (ep.stats) GP(1, true); else GP(1, false); }
+        else { if (ep.stats) GP(0, true); else GP(0, false); }
+#undef GP
+        return doda_check_launch();
+    }
 #define GT(M, O32, ST)                                                                             \
     hipLaunchKernelGGL((conv_tile<M, O32, ST>), grid, block, 0, s, x, xb, wp, wpb, nc, NB, tbl, ld, n_out, tb, y, yb, res, ep)
 #define GM(M)                                                                                      \

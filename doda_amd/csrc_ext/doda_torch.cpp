@@ -51,6 +51,17 @@ struct GatherEpi {
     at::Tensor stats;
 };
 
+// BatchNorm(+ReLU) whose apply pass rides in the consuming conv's PROLOGUE (ABI 6, doda_conv_epilogue.pre_*): the
+// BatchNorm op runs its reduction only and hands these to the conv, which reads the BatchNorm's INPUT x, normalises
+// the rows while staging them, and writes the BatchNorm's output z (the tensor the autograd graph knows as the conv's
+// input, saved for the weight gradient) as a side output.
+struct PreArgs {
+    bool active = false;
+    at::Tensor x, mean, invstd, gamma, beta;
+    bool relu = false;
+};
+bool g_bn_prologue = false;   // measured slower than the apply launch it removes (csrc/spconv_tile.hip, PRE): opt-in
+
 // A SubM table allocated by table_with_tilebook() carries its tilebook (doda_tilebook_build) in the same
 // storage, 256-byte aligned behind the K x ld entries: the table tensor is the one handle every layer of
 // the rulebook already passes around (forward, data-grad, saved for backward), so the tilebook reaches
@@ -84,8 +95,10 @@ void build_tilebook(const at::Tensor &tbl, void *st) {
 // y[t] = sum_o x[tbl[o][t]] . B_o   (include/doda_hip.h: doda_spconv_gather_ex)
 at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
                   const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32,
-                  const c10::optional<at::Tensor> &residual = c10::nullopt, GatherEpi *epi = nullptr) {
-    const at::Tensor x = x_in.contiguous();
+                  const c10::optional<at::Tensor> &residual = c10::nullopt, GatherEpi *epi = nullptr,
+                  const PreArgs *pre = nullptr) {
+    // with a prologue x_in is the (still unwritten) normalised tensor: the kernel reads pre->x and writes x_in
+    const at::Tensor x = (pre && pre->active) ? pre->x : x_in.contiguous();
     TORCH_CHECK(x.is_cuda() && x.dim() == 2 && tbl.is_cuda() && tbl.dim() == 2, "doda gather: bad inputs");
     const int esz = elem_bytes(x);
     const int64_t K = tbl.size(0), ld = tbl.size(1), kc = x.size(1);
@@ -127,6 +140,16 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
     }
     ep.tilebook = tilebook_behind(tbl, n_out);
     ep.tilebook_rows = ep.tilebook ? (int32_t)n_out : 0;
+    if (pre && pre->active) {
+        TORCH_CHECK(x_in.is_contiguous() && x_in.sizes() == x.sizes() && x_in.scalar_type() == x.scalar_type(),
+                    "doda gather: the prologue's output must be shaped like its input");
+        ep.pre_mean = (const float *)pre->mean.data_ptr();
+        ep.pre_invstd = (const float *)pre->invstd.data_ptr();
+        ep.pre_gamma = (const float *)pre->gamma.data_ptr();
+        ep.pre_beta = (const float *)pre->beta.data_ptr();
+        ep.pre_relu = pre->relu ? 1 : 0;
+        ep.pre_out = x_in.data_ptr();
+    }
     const void *wptr;
     void *ws = nullptr;
     size_t ws_bytes = 0;
@@ -558,7 +581,7 @@ std::vector<at::Tensor> indice_conv_impl(const at::Tensor &features, const at::T
                        const c10::optional<at::Tensor> &pk_fwd, const c10::optional<at::Tensor> &pk_bwd,
                        const c10::optional<at::Tensor> &residual, const c10::optional<at::Tensor> &pair_in,
                        const c10::optional<at::Tensor> &pair_out, const c10::optional<at::Tensor> &pair_num,
-                       const c10::optional<at::Tensor> &pair_seg, bool want_stats) {
+                       const c10::optional<at::Tensor> &pair_seg, bool want_stats, const PreArgs *pre = nullptr) {
     const at::Tensor res = residual.has_value() ? *residual : at::Tensor();
     const bool need_grad = at::GradMode::is_enabled() &&
                            (features.requires_grad() || weight.requires_grad() || (res.defined() && res.requires_grad()));
@@ -568,7 +591,7 @@ std::vector<at::Tensor> indice_conv_impl(const at::Tensor &features, const at::T
     epi.want = want_stats;
     {
         at::AutoDispatchBelowADInplaceOrView guard;
-        y = gather(features, weight.reshape({K, cin, cout}), pk_fwd, fwd_tbl, n_out, 0, cout, false, residual, &epi);
+        y = gather(features, weight.reshape({K, cin, cout}), pk_fwd, fwd_tbl, n_out, 0, cout, false, residual, &epi, pre);
     }
     // the BatchNorm that produced `features` (if it was the last fused BatchNorm and its output is this tensor)
     std::shared_ptr<BNLink> link;
@@ -737,7 +760,8 @@ struct BNNode : public torch::autograd::Node {
 std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &weight, const at::Tensor &bias,
                                      const at::Tensor &running_mean, const at::Tensor &running_var,
                                      const at::Tensor &nbt, bool training, double momentum, double eps,
-                                     bool relu, bool passthrough, const at::Tensor &stats = at::Tensor()) {
+                                     bool relu, bool passthrough, const at::Tensor &stats = at::Tensor(),
+                                     PreArgs *defer = nullptr) {
     const bool need_grad = at::GradMode::is_enabled() &&
                            (x_in.requires_grad() || weight.requires_grad() || bias.requires_grad());
     at::Tensor x, y, mean, invstd, xp;
@@ -755,7 +779,19 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
             mean = running_mean.to(at::kFloat).contiguous();
             invstd = at::rsqrt(running_var.to(at::kFloat) + eps).contiguous();
         }
-        if (training && stats.defined() && m > BN_SMALL_ROWS && stats.dim() == 3 && stats.size(0) == 1 && stats.size(2) == c &&
+        if (defer) {
+            // reduction only: the consuming conv's prologue applies the BatchNorm and writes y (the caller checked
+            // prologue_usable(): training, float statistics rows of a conv epilogue, m > BN_SMALL_ROWS)
+            check(doda_bn_fwd_final((const float *)stats.data_ptr(), (int)stats.size(0), (int)m, (int)c, (float)eps,
+                                    (float)momentum, (float *)running_mean.data_ptr(), (float *)running_var.data_ptr(),
+                                    nbt.defined() ? (int64_t *)nbt.data_ptr() : nullptr, (float *)mean.data_ptr(),
+                                    (float *)invstd.data_ptr(), stream_of(x)), "doda_bn_fwd_final");
+            defer->active = true;
+            defer->x = x;
+            defer->mean = mean; defer->invstd = invstd;
+            defer->gamma = weight.detach(); defer->beta = bias.detach();
+            defer->relu = relu;
+        } else if (training && stats.defined() && m > BN_SMALL_ROWS && stats.dim() == 3 && stats.size(0) == 1 && stats.size(2) == c &&
             c <= 256 && stats.scalar_type() == at::kDouble && stats.is_contiguous()) {
             check(doda_bn_relu_fwd_totals(x.data_ptr(), (int)m, (int)c, esz, (const double *)stats.data_ptr(), (float)eps,
                                           (float)momentum, (const float *)weight.data_ptr(), (const float *)bias.data_ptr(),
@@ -829,6 +865,24 @@ std::vector<at::Tensor> bn_relu_pass(const at::Tensor &x, const at::Tensor &weig
                         stats.has_value() ? *stats : at::Tensor());
 }
 
+// Can the BatchNorm (x, statistics rows `stats` from the producing conv's epilogue) leave its apply pass to the SubM conv
+// (weight w over table tbl) that consumes it?  Training mode, bf16 rows, float statistics rows, more rows than the
+// one-launch BatchNorm handles, fp32 affine parameters and running statistics, and a kernel that takes the prologue.
+bool prologue_usable(const at::Tensor &x, const at::Tensor &stats, const std::vector<at::Tensor> &bn, bool training,
+                     const at::Tensor &w, const at::Tensor &tbl, int64_t n_out) {
+    if (!g_bn_prologue || !training || !stats.defined() || !x.defined() || x.dim() != 2) return false;
+    const int64_t m = x.size(0), c = x.size(1);
+    if (m <= BN_SMALL_ROWS || m != n_out || x.scalar_type() != at::kBFloat16 || !x.is_contiguous() || !x.is_cuda()) return false;
+    if (stats.dim() != 3 || stats.size(2) != c || stats.scalar_type() != at::kFloat || !stats.is_contiguous() ||
+        stats.size(0) < 1)
+        return false;
+    for (int k = 0; k < 4; ++k)
+        if (!bn[k].defined() || bn[k].scalar_type() != at::kFloat || !bn[k].is_contiguous() || bn[k].numel() != c) return false;
+    if (w.dim() != 5 || w.size(3) != c || tbl.dim() != 2) return false;
+    return doda_spconv_prologue_ok((int32_t)c, (int32_t)w.size(4), (int32_t)tbl.size(0), 2, 0, (int32_t)m, (int32_t)n_out,
+                                   tilebook_behind(tbl, n_out) != nullptr) != 0;
+}
+
 // ---- a whole pre-activation residual block in ONE extension call ------------------------------------
 // reference model/unet_block.py:14-37:  y = conv2(relu(bn2(conv1(relu(bn1(x)))))) + skip,  skip = x or i_branch(x).
 // The same four ops (and the same autograd nodes, BatchNorm links, epilogue statistics) the Python modules issue one
@@ -851,13 +905,19 @@ std::vector<at::Tensor> residual_block(const at::Tensor &x, const c10::optional<
                 cv1[0].has_value() && cv2[0].has_value() && rb[0].has_value(), "doda residual_block: bad argument lists");
     const bool identity = !(skip.has_value() && skip->defined());
     const at::Tensor &tbl = *rb[0];
+    const at::Tensor st1 = stats_in.has_value() ? *stats_in : at::Tensor();
+    PreArgs p1, p2;
+    const bool f1 = prologue_usable(x, st1, bn1, training, *cv1[0], tbl, n_out);
     auto a = bn_relu_impl(x, bn1[0], bn1[1], bn1[2], bn1[3], bn1[4], training, momentum1, eps1, true,
-                          identity && training, stats_in.has_value() ? *stats_in : at::Tensor());
+                          identity && training, st1, f1 ? &p1 : nullptr);
     auto z1 = indice_conv_impl(a[0], *cv1[0], tbl, tbl, n_out, 2, cv1[1], cv1[2], c10::nullopt, rb[1], rb[2], rb[3], rb[4],
-                               want_stats);
-    auto y2 = bn_relu_impl(z1[0], bn2[0], bn2[1], bn2[2], bn2[3], bn2[4], training, momentum2, eps2, true, false, z1[1]);
+                               want_stats, f1 ? &p1 : nullptr);
+    const bool f2 = prologue_usable(z1[0], z1[1], bn2, training, *cv2[0], tbl, n_out);
+    auto y2 = bn_relu_impl(z1[0], bn2[0], bn2[1], bn2[2], bn2[3], bn2[4], training, momentum2, eps2, true, false, z1[1],
+                           f2 ? &p2 : nullptr);
     const at::Tensor res = identity ? (training ? a[1] : x) : *skip;
-    return indice_conv_impl(y2[0], *cv2[0], tbl, tbl, n_out, 2, cv2[1], cv2[2], res, rb[1], rb[2], rb[3], rb[4], want_stats);
+    return indice_conv_impl(y2[0], *cv2[0], tbl, tbl, n_out, 2, cv2[1], cv2[2], res, rb[1], rb[2], rb[3], rb[4], want_stats,
+                            f2 ? &p2 : nullptr);
 }
 
 }  // namespace
@@ -935,6 +995,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         return std::make_pair(r[0], r[1].defined() ? c10::optional<at::Tensor>(r[1]) : c10::nullopt);
     }, "BatchNorm -> ReLU -> SubM conv -> BatchNorm -> ReLU -> SubM conv (+ skip) in one call");
     m.def("set_bn_fusion", [](bool on) { g_bn_fusion = on; }, "BatchNorm statistics in the conv epilogues (default on)");
+    m.def("set_bn_prologue", [](bool on) { g_bn_prologue = on; },
+          "BatchNorm apply(+ReLU) in the consuming conv's prologue inside residual_block (default off)");
+    m.def("get_bn_prologue", []() { return g_bn_prologue; });
     m.def("gather", [](const at::Tensor &x, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
                        const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32) {
         return gather(x, w, packed, tbl, n_out, layout, nc, out_f32);

@@ -266,11 +266,13 @@ def _feat_ok(x, name):
         raise RuntimeError("%s must be a contiguous [rows, channels] tensor" % name)
 
 
-class _ConvEpilogue(C.Structure):   # doda_conv_epilogue (include/doda_hip.h, ABI 5)
+class _ConvEpilogue(C.Structure):   # doda_conv_epilogue (include/doda_hip.h, ABI 6)
     _fields_ = [("residual", C.c_void_p), ("stats", C.c_void_p), ("stats_rows_h", C.POINTER(C.c_int32)),
                 ("bn_x", C.c_void_p), ("bn_mean", C.c_void_p), ("bn_invstd", C.c_void_p), ("bn_gamma", C.c_void_p),
                 ("bn_beta", C.c_void_p), ("bn_relu", C.c_int32), ("tilebook_rows", C.c_int32),
-                ("tilebook", C.c_void_p), ("totals", C.c_void_p), ("finished_h", C.POINTER(C.c_int32))]
+                ("tilebook", C.c_void_p), ("totals", C.c_void_p), ("finished_h", C.POINTER(C.c_int32)),
+                ("pre_mean", C.c_void_p), ("pre_invstd", C.c_void_p), ("pre_gamma", C.c_void_p), ("pre_beta", C.c_void_p),
+                ("pre_relu", C.c_int32), ("reserved6", C.c_int32), ("pre_out", C.c_void_p)]
 
 
 def tilebook_build(tbl, n_rows=None):
@@ -315,7 +317,7 @@ def spconv_bwd_tile(dy, x, w, tbl, tilebook, packed=None, dw_out=None):
 
 
 def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, residual=None, tilebook=None,
-                  want_stats=False, bn=None, out=None, want_totals=False):
+                  want_stats=False, bn=None, out=None, want_totals=False, pre=None):
     """y[t] = sum_o x[tbl[o][t]] @ B_o (see doda_hip.h).  x: [n_in,kc] f32|bf16; w: fp32 weights
     viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2), or `packed`: the fragment-packed buffer
     produced by PackPlan for this (weight, layout, dtype).  Returns y [n_out, nc] in x.dtype (or
@@ -324,7 +326,9 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
     (doda_conv_epilogue.stats) — (sum y, sum y^2), or with bn = (bn_x, mean, invstd, gamma, beta, relu) the
     BatchNorm-backward sums of a data-grad call.  out: write into this tensor instead of allocating.
     want_totals (with want_stats): returns (y, stats, totals) — totals: float64 [2, nc], the rows summed by the conv
-    kernel's last workgroup (doda_conv_epilogue.totals), or None when that kernel does not finish in place."""
+    kernel's last workgroup (doda_conv_epilogue.totals), or None when that kernel does not finish in place.
+    pre = (mean, invstd, gamma, beta, relu, z_out): BatchNorm(+ReLU) prologue on the gathered rows (ABI 6,
+    doda_conv_epilogue.pre_*); z_out ([n_in, kc] bf16 or None) receives the normalised rows."""
     _feat_ok(x, "x")
     _need_cuda(tbl)
     K, ld = tbl.shape
@@ -348,7 +352,7 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
         _need_cuda(residual)
         if residual.dtype != ydt or tuple(residual.shape) != (n_out, nc) or not residual.is_contiguous():
             raise RuntimeError("residual must be a contiguous [n_out, nc] tensor in the output dtype")
-    if tilebook is not None or want_stats or out is not None:   # epilogue-struct entry point
+    if tilebook is not None or want_stats or out is not None or pre is not None:   # epilogue-struct entry point
         y = out if out is not None else torch.empty((n_out, nc), dtype=ydt, device=x.device)
         ep = _ConvEpilogue()
         ep.residual = _p(residual) if residual is not None else None
@@ -363,6 +367,15 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
                 bx, mean, invstd, gamma, beta, relu = bn
                 ep.bn_x, ep.bn_mean, ep.bn_invstd, ep.bn_gamma, ep.bn_beta = _p(bx), _p(mean), _p(invstd), _p(gamma), _p(beta)
                 ep.bn_relu = int(bool(relu))
+        if pre is not None:
+            pm, pi, pg, pb, prelu, zout = pre
+            _need_cuda(pm, pi, pg, pb)
+            ep.pre_mean, ep.pre_invstd, ep.pre_gamma, ep.pre_beta = _p(pm), _p(pi), _p(pg), _p(pb)
+            ep.pre_relu = int(bool(prelu))
+            if zout is not None:
+                if zout.dtype != x.dtype or tuple(zout.shape) != tuple(x.shape) or not zout.is_contiguous():
+                    raise RuntimeError("pre: z_out must be a contiguous tensor shaped like x")
+                ep.pre_out = _p(zout)
         totals, fin = None, C.c_int32(0)
         if want_stats and want_totals:
             totals = torch.empty((2, nc), dtype=torch.float64, device=x.device)
@@ -396,6 +409,26 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
     else:
         raise RuntimeError("spconv_gather: unsupported feature dtype %s" % x.dtype)
     return y
+
+
+def spconv_prologue_ok(kc, nc, K, elem_bytes, out_f32, n_in, n_out, has_tilebook):
+    """Does doda_spconv_gather_ex take a BatchNorm prologue (pre=...) for this call shape?"""
+    return bool(lib().doda_spconv_prologue_ok(kc, nc, K, elem_bytes, int(bool(out_f32)), n_in, n_out, int(bool(has_tilebook))))
+
+
+def bn_fwd_final(stats, m, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
+    """The reduction half of a training-mode BatchNorm whose statistics rode in a conv epilogue (doda_bn_fwd_final):
+    stats [rows, 2, c] fp32 -> (save_mean, save_invstd); running statistics updated in place when given."""
+    _need_cuda(stats)
+    rows, _, c = stats.shape
+    mean = torch.empty(c, dtype=torch.float32, device=stats.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=stats.device)
+    check(lib().doda_bn_fwd_final(_p(stats), rows, int(m), c, float(eps), float(momentum),
+                                  _p(running_mean) if running_mean is not None else None,
+                                  _p(running_var) if running_var is not None else None,
+                                  _p(num_batches_tracked) if num_batches_tracked is not None else None,
+                                  _p(mean), _p(invstd), _stream()), "doda_bn_fwd_final")
+    return mean, invstd
 
 
 class PackPlan:

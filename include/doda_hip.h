@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DODA_ABI_VERSION 5
+#define DODA_ABI_VERSION 6
 
 #define DODA_OK 0
 #define DODA_ERR_INVALID (-1)        /* bad argument (null pointer, negative size, bad mode) */
@@ -250,7 +250,24 @@ typedef struct doda_conv_epilogue {
      * *finished_h == 0: this kernel does not finish in place (or doda_spconv_set_stats_finish(0)); use the rows. */
     double *totals;
     int32_t *finished_h;
+    /* ABI 6: BatchNorm(+ReLU) PROLOGUE — the BN -> ReLU -> conv triple of reference model/unet_block.py:23-30,46-49 in one
+     * launch.  With pre_mean set, every gathered input row goes through
+     *     z = (x - pre_mean) * pre_invstd * pre_gamma + pre_beta,  z = z > 0 ? z : 0 (pre_relu),  rounded to bf16
+     * (doda_bn_relu_fwd's arithmetic, operation for operation: the results are bit-equal to BatchNorm launch + conv
+     * launch) on its way to the matrix core: the tile kernels transform each DISTINCT row once while staging it in LDS.
+     * Absent neighbours stay zero.  pre_out ([n_in, kc] bf16, optional, 16-byte aligned) receives the normalised rows —
+     * written by the workgroup whose output rows they are (SubM: input row t = output row t) — for the weight
+     * gradient, which needs z as its gathered operand; the BatchNorm's own apply launch disappears.
+     * float [kc] each.  Supported where doda_spconv_prologue_ok() says so; otherwise DODA_ERR_UNSUPPORTED. */
+    const float *pre_mean, *pre_invstd, *pre_gamma, *pre_beta;
+    int32_t pre_relu;
+    int32_t reserved6;
+    void *pre_out;
 } doda_conv_epilogue;
+/* ABI 6.  1 when doda_spconv_gather_ex takes a BatchNorm prologue for this call shape (bf16 SubM K = 27 layers of 16 or
+ * 32 input channels over a tilebook, bf16 output, n_in == n_out), else 0.  Depends on the A/B switches in force. */
+int32_t doda_spconv_prologue_ok(int32_t kc, int32_t nc, int32_t K, int32_t elem_bytes, int32_t y_is_f32, int32_t n_in,
+                                int32_t n_out, int32_t has_tilebook);
 /* Switch: 1 = finish statistics in the conv kernels, 0 = never (finished_h always 0).  Default 0 (DODA_STATS_FINISH=1
  * turns it on): on MI355X the end-of-workgroup protocol costs more than the BatchNorm's own reduction launch. */
 void doda_spconv_set_stats_finish(int32_t on);
@@ -418,6 +435,12 @@ int doda_bn_relu_fwd_stats(const void *x, int32_t m, int32_t c, int32_t elem_byt
                            const float *beta, float *running_mean, float *running_var,
                            int64_t *num_batches_tracked, int32_t relu, void *y, float *save_mean,
                            float *save_invstd, doda_stream_t stream);
+/* ABI 6.  The reduction half of doda_bn_relu_fwd_stats alone (training mode): save_mean / save_invstd [c] from the
+ * partial rows, running statistics and num_batches_tracked updated (any of the three may be NULL) — for a BatchNorm whose
+ * apply pass rides in the consuming convolution's prologue (doda_conv_epilogue.pre_*). */
+int doda_bn_fwd_final(const float *stats, int32_t stats_rows, int32_t m, int32_t c, float eps, float momentum,
+                      float *running_mean, float *running_var, int64_t *num_batches_tracked, float *save_mean,
+                      float *save_invstd, doda_stream_t stream);
 int doda_bn_relu_bwd_stats(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
                            const float *stats, int32_t stats_rows, const float *save_mean,
                            const float *save_invstd, const float *gamma, const float *beta, int32_t relu,

@@ -19,7 +19,7 @@ def test_header_symbols_all_exported(native_lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(native_lib, name), name
-    assert native_lib.doda_abi_version() == 5
+    assert native_lib.doda_abi_version() == 6
     assert native_lib.doda_strerror(-3).decode().startswith("cell id")
 
 
