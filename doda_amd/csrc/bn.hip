@@ -239,7 +239,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply(const typename T::elem 
                                                          const float *__restrict__ beta, int relu,
                                                          const float *__restrict__ coef,
                                                          typename T::elem *__restrict__ dx,
-                                                         const typename T::elem *__restrict__ add) {
+                                                         const typename T::elem *__restrict__ add, int add_ld = 0) {
     for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < n_frag;
          e += (long long)gridDim.x * BN_BLOCK) {
         const int f = (int)(e % nf);
@@ -258,7 +258,9 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply(const typename T::elem 
         const f32x4 b = *reinterpret_cast<const f32x4 *>(coef + c + f * 4);
         const f32x4 d = *reinterpret_cast<const f32x4 *>(coef + 2 * c + f * 4);
         f32x4 o = a * (dz - b - xh * d);
-        if (add) o += T::load4(add + e * 4);   // a second gradient of x (residual path) summed here
+        // a second gradient of x (residual / skip path) summed here; add_ld != 0: its rows lie add_ld elements apart
+        // (a column slice of a wider matrix: the gradient of torch.cat's input, reference model/unet_block.py:93)
+        if (add) o += T::load4(add_ld ? add + (e / nf) * add_ld + f * 4 : add + e * 4);
         T::store4(dx + e * 4, o);
     }
 }
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd(const typename T::elem 
                                                          typename T::elem *__restrict__ dx,
                                                          float *__restrict__ dgamma,
                                                          float *__restrict__ dbeta,
-                                                         const typename T::elem *__restrict__ add) {
+                                                         const typename T::elem *__restrict__ add, int add_ld = 0) {
     __shared__ float lds[4][4];
     const int f = blockIdx.x;
     const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + f * 4);
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd(const typename T::elem 
         const long long off = (long long)(r < m ? r : m - 1) * c + f * 4;
         xh[i] = T::load4(x + off);
         dz[i] = T::load4(dy + off);
-        ad[i] = add ? T::load4(add + off) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        ad[i] = add ? T::load4(add_ld ? add + (long long)(r < m ? r : m - 1) * add_ld + f * 4 : add + off) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
 #pragma unroll
@@ -992,14 +994,15 @@ int run_fwd(const void *x_, int m, int c, float eps, float momentum, const float
 template <class T>
 int run_bwd(const void *x_, const void *dy_, int m, int c, const float *mean, const float *invstd,
             const float *gamma, const float *beta, int relu, void *dx_, float *dgamma, float *dbeta,
-            void *ws, size_t ws_bytes, const void *add_, hipStream_t s) {
+            void *ws, size_t ws_bytes, const void *add_, hipStream_t s, int add_ld = 0) {
     typedef typename T::elem elem;
     const elem *x = (const elem *)x_, *dy = (const elem *)dy_, *add = (const elem *)add_;
     elem *dx = (elem *)dx_;
     const Geo g = make_geo(c);
+    if (add_ld == c) add_ld = 0;   // dense
     if (m <= BN_SMALL_ROWS) {
         hipLaunchKernelGGL((bn_small_bwd<T>), dim3(c / 4), dim3(BN_BLOCK), 0, s, x, dy, m, c, mean, invstd,
-                           gamma, beta, relu, dx, dgamma, dbeta, add);
+                           gamma, beta, relu, dx, dgamma, dbeta, add, add_ld);
         return doda_check_launch();
     }
     const int nb = n_blocks_for(m, g);
@@ -1013,7 +1016,7 @@ int run_bwd(const void *x_, const void *dy_, int m, int c, const float *mean, co
     const long long n_frag = (long long)m * g.nf;
     const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
     hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(grid), dim3(BN_BLOCK), 0, s, x, dy, n_frag, g.nf, c, mean,
-                       invstd, gamma, beta, relu, coef, dx, add);
+                       invstd, gamma, beta, relu, coef, dx, add, add_ld);
     return doda_check_launch();
 }
 
@@ -1092,20 +1095,29 @@ extern "C" int doda_bn_relu_bwd(const void *x, const void *dy, int32_t m, int32_
 // dx = BN backward + add: `add` ([m, c], dtype of x) is a second gradient of the same x — in a
 // pre-activation residual block x feeds both the BatchNorm and the skip connection — so the
 // gradient accumulation rides in the apply pass instead of a separate elementwise kernel.
+extern "C" int doda_bn_relu_bwd_add_ld(const void *x, const void *dy, int32_t m, int32_t c,
+                                       int32_t elem_bytes, const float *save_mean,
+                                       const float *save_invstd, const float *gamma, const float *beta,
+                                       int32_t relu, const void *add, int32_t add_ld, void *dx, float *dgamma,
+                                       float *dbeta, void *ws, size_t ws_bytes, doda_stream_t stream) {
+    if (m == 0) return DODA_OK;
+    if (bn_args_bad(m, c, elem_bytes)) return DODA_ERR_UNSUPPORTED;
+    if (!x || !dy || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !ws || !add)
+        return DODA_ERR_INVALID;
+    if (add_ld < c || add_ld % 4 || ((uintptr_t)add % (4 * (size_t)elem_bytes))) return DODA_ERR_INVALID;
+    if (elem_bytes == 4)
+        return run_bwd<F32>(x, dy, m, c, save_mean, save_invstd, gamma, beta, relu, dx, dgamma, dbeta, ws,
+                            ws_bytes, add, as_stream(stream), add_ld);
+    return run_bwd<BF16>(x, dy, m, c, save_mean, save_invstd, gamma, beta, relu, dx, dgamma, dbeta, ws,
+                         ws_bytes, add, as_stream(stream), add_ld);
+}
 extern "C" int doda_bn_relu_bwd_add(const void *x, const void *dy, int32_t m, int32_t c,
                                     int32_t elem_bytes, const float *save_mean,
                                     const float *save_invstd, const float *gamma, const float *beta,
                                     int32_t relu, const void *add, void *dx, float *dgamma, float *dbeta,
                                     void *ws, size_t ws_bytes, doda_stream_t stream) {
-    if (m == 0) return DODA_OK;
-    if (bn_args_bad(m, c, elem_bytes)) return DODA_ERR_UNSUPPORTED;
-    if (!x || !dy || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !ws || !add)
-        return DODA_ERR_INVALID;
-    if (elem_bytes == 4)
-        return run_bwd<F32>(x, dy, m, c, save_mean, save_invstd, gamma, beta, relu, dx, dgamma, dbeta, ws,
-                            ws_bytes, add, as_stream(stream));
-    return run_bwd<BF16>(x, dy, m, c, save_mean, save_invstd, gamma, beta, relu, dx, dgamma, dbeta, ws,
-                         ws_bytes, add, as_stream(stream));
+    return doda_bn_relu_bwd_add_ld(x, dy, m, c, elem_bytes, save_mean, save_invstd, gamma, beta, relu, add, c, dx, dgamma,
+                                   dbeta, ws, ws_bytes, stream);
 }
 
 // ---- BatchNorm(+ReLU) over statistics that a conv epilogue accumulated ------------------------------
@@ -1140,10 +1152,12 @@ static int run_fwd_stats(const void *x_, int m, int c, const float *stats, int r
 template <class T>
 static int run_bwd_stats(const void *x_, const void *dy_, int m, int c, const float *stats, int rows,
                          const float *mean, const float *invstd, const float *gamma, const float *beta, int relu,
-                         const void *add_, void *dx_, float *dgamma, float *dbeta, float *coef, hipStream_t s) {
+                         const void *add_, void *dx_, float *dgamma, float *dbeta, float *coef, hipStream_t s,
+                         int add_ld = 0) {
     typedef typename T::elem elem;
     const Geo g = make_geo(c);
-    if (fused_ok(rows, c)) {      // final + apply in one launch: few partial rows
+    if (add_ld == c || !add_) add_ld = 0;   // dense
+    if (!add_ld && fused_ok(rows, c)) {      // final + apply in one launch: few partial rows (opt-in; dense `add` only)
         const long long nfr = (long long)m * g.nf;
         const int grid = (int)((nfr + BN_BLOCK - 1) / BN_BLOCK < BN_FUSED_BLOCKS ? (nfr + BN_BLOCK - 1) / BN_BLOCK : BN_FUSED_BLOCKS);
         hipLaunchKernelGGL((bn_fused_bwd<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, (const elem *)dy_, nfr, g.nf,
@@ -1153,7 +1167,7 @@ static int run_bwd_stats(const void *x_, const void *dy_, int m, int c, const fl
     const long long n_frag = (long long)m * g.nf;
     const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
     ChainFlag cf;
-    if (c <= BN_CHAIN_MAX_C && chain_next(s, g.nf, &cf)) {
+    if (!add_ld && c <= BN_CHAIN_MAX_C && chain_next(s, g.nf, &cf)) {
         hipLaunchKernelGGL((bn_bwd_chain<T>), dim3(g.nf + grid), dim3(BN_BLOCK), 0, s, stats, rows, m, c, mean, invstd, gamma,
                            beta, dgamma, dbeta, coef, cf, (const elem *)x_, (const elem *)dy_, n_frag, g.nf, relu,
                            (elem *)dx_, (const elem *)add_);
@@ -1162,7 +1176,7 @@ static int run_bwd_stats(const void *x_, const void *dy_, int m, int c, const fl
     hipLaunchKernelGGL(bn_bwd_final_stats, dim3(c / 4), dim3(BN_BLOCK), 0, s, stats, rows, m, c, invstd, gamma, dgamma,
                        dbeta, coef);
     hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, (const elem *)dy_, n_frag,
-                       g.nf, c, mean, invstd, gamma, beta, relu, coef, (elem *)dx_, (const elem *)add_);
+                       g.nf, c, mean, invstd, gamma, beta, relu, coef, (elem *)dx_, (const elem *)add_, add_ld);
     return doda_check_launch();
 }
 
@@ -1271,6 +1285,15 @@ extern "C" int doda_bn_relu_bwd_stats(const void *x, const void *dy, int32_t m, 
                                       const float *save_invstd, const float *gamma, const float *beta, int32_t relu,
                                       const void *add, void *dx, float *dgamma, float *dbeta, float *coef_ws,
                                       doda_stream_t stream) {
+    return doda_bn_relu_bwd_stats_ld(x, dy, m, c, elem_bytes, stats, stats_rows, save_mean, save_invstd, gamma, beta, relu,
+                                     add, c, dx, dgamma, dbeta, coef_ws, stream);
+}
+extern "C" int doda_bn_relu_bwd_stats_ld(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
+                                         const float *stats, int32_t stats_rows, const float *save_mean,
+                                         const float *save_invstd, const float *gamma, const float *beta, int32_t relu,
+                                         const void *add, int32_t add_ld, void *dx, float *dgamma, float *dbeta,
+                                         float *coef_ws, doda_stream_t stream) {
+    if (add && (add_ld < c || add_ld % 4 || ((uintptr_t)add % (4 * (size_t)elem_bytes)))) return DODA_ERR_INVALID;
     if (m == 0) return DODA_OK;
     if (bn_args_bad(m, c, elem_bytes)) return DODA_ERR_UNSUPPORTED;
     if (!x || !dy || !dx || !stats || stats_rows <= 0 || !gamma || !beta || !save_mean || !save_invstd || !dgamma ||
@@ -1278,7 +1301,7 @@ extern "C" int doda_bn_relu_bwd_stats(const void *x, const void *dy, int32_t m, 
         return DODA_ERR_INVALID;
     if (elem_bytes == 4)
         return run_bwd_stats<F32>(x, dy, m, c, stats, stats_rows, save_mean, save_invstd, gamma, beta, relu, add, dx,
-                                  dgamma, dbeta, coef_ws, as_stream(stream));
+                                  dgamma, dbeta, coef_ws, as_stream(stream), add_ld);
     return run_bwd_stats<BF16>(x, dy, m, c, stats, stats_rows, save_mean, save_invstd, gamma, beta, relu, add, dx,
-                               dgamma, dbeta, coef_ws, as_stream(stream));
+                               dgamma, dbeta, coef_ws, as_stream(stream), add_ld);
 }

@@ -642,6 +642,21 @@ at::Tensor indice_conv(const at::Tensor &features, const at::Tensor &weight, con
                             pair_out, pair_num, pair_seg, false)[0];
 }
 
+// The second gradient of a BatchNorm's input as the backward kernels take it (doda_bn_relu_bwd_*_ld): dense, or — without
+// a copy — a column slice of a wider matrix whose rows lie `ld` elements apart: what torch.cat's backward hands to the
+// skip connection of a U-Net level (reference model/unet_block.py:93).
+at::Tensor add_operand(const at::Tensor &e, int64_t m, int64_t c, int64_t &ld) {
+    ld = c;
+    if (e.is_contiguous()) return e;
+    const int esz = e.scalar_type() == at::kFloat ? 4 : 2;
+    if (e.dim() == 2 && e.size(0) == m && e.size(1) == c && e.stride(1) == 1 && e.stride(0) >= c && e.stride(0) % 4 == 0 &&
+        ((uintptr_t)e.data_ptr() % (size_t)(4 * esz)) == 0 && (m - 1) * e.stride(0) + c < ((int64_t)1 << 40)) {
+        ld = e.stride(0);
+        return e;
+    }
+    return e.contiguous();
+}
+
 // ---- fused BatchNorm1d(+ReLU).  Gradient edges: 0 x, 1 weight, 2 bias. ----------------------------
 // With `passthrough` the op has a second output: an alias of x whose gradient (the skip connection of a
 // pre-activation residual block) is summed into dx by the apply pass (doda_bn_relu_bwd_add) instead of
@@ -689,33 +704,35 @@ struct BNNode : public torch::autograd::Node {
             extra = at::Tensor();
         } else if (stats.defined()) {
             const int64_t m = x.size(0), c = x.size(1);
-            const at::Tensor add = extra.defined() ? extra.contiguous() : at::Tensor();
+            int64_t add_ld = c;
+            const at::Tensor add = extra.defined() ? add_operand(extra, m, c, add_ld) : at::Tensor();
             dx = at::empty_like(x);
             dg = at::empty({c}, x.options().dtype(at::kFloat));
             db = at::empty({c}, x.options().dtype(at::kFloat));
             at::Tensor coef = at::empty({3 * c}, x.options().dtype(at::kFloat));
-            check(doda_bn_relu_bwd_stats(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
-                                         (const float *)stats.data_ptr(), (int)stats.size(0),
-                                         (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(),
-                                         (const float *)weight.data_ptr(), (const float *)bias.data_ptr(), relu ? 1 : 0,
-                                         add.defined() ? add.data_ptr() : nullptr, dx.data_ptr(),
-                                         (float *)dg.data_ptr(), (float *)db.data_ptr(), (float *)coef.data_ptr(),
-                                         stream_of(x)),
+            check(doda_bn_relu_bwd_stats_ld(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
+                                            (const float *)stats.data_ptr(), (int)stats.size(0),
+                                            (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(),
+                                            (const float *)weight.data_ptr(), (const float *)bias.data_ptr(), relu ? 1 : 0,
+                                            add.defined() ? add.data_ptr() : nullptr, (int)add_ld, dx.data_ptr(),
+                                            (float *)dg.data_ptr(), (float *)db.data_ptr(), (float *)coef.data_ptr(),
+                                            stream_of(x)),
                   "doda_bn_relu_bwd_stats");
             extra = at::Tensor();
         } else if (training && extra.defined() && extra.scalar_type() == x.scalar_type()) {
-            const at::Tensor add = extra.contiguous();
             const int64_t m = x.size(0), c = x.size(1);
+            int64_t add_ld = c;
+            const at::Tensor add = add_operand(extra, m, c, add_ld);
             dx = at::empty_like(x);
             dg = at::empty({c}, x.options().dtype(at::kFloat));
             db = at::empty({c}, x.options().dtype(at::kFloat));
             const size_t wsb = doda_bn_workspace_bytes((int)m, (int)c);
             at::Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
-            check(doda_bn_relu_bwd_add(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
-                                       (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(),
-                                       (const float *)weight.data_ptr(), (const float *)bias.data_ptr(),
-                                       relu ? 1 : 0, add.data_ptr(), dx.data_ptr(), (float *)dg.data_ptr(),
-                                       (float *)db.data_ptr(), ws.data_ptr(), wsb, stream_of(x)),
+            check(doda_bn_relu_bwd_add_ld(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
+                                          (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(),
+                                          (const float *)weight.data_ptr(), (const float *)bias.data_ptr(),
+                                          relu ? 1 : 0, add.data_ptr(), (int)add_ld, dx.data_ptr(), (float *)dg.data_ptr(),
+                                          (float *)db.data_ptr(), ws.data_ptr(), wsb, stream_of(x)),
                   "doda_bn_relu_bwd_add");
             extra = at::Tensor();
         } else if (training) {
@@ -900,22 +917,34 @@ std::vector<at::Tensor> residual_block(const at::Tensor &x, const c10::optional<
                                        const std::vector<c10::optional<at::Tensor>> &cv1,
                                        const std::vector<c10::optional<at::Tensor>> &cv2,
                                        const std::vector<c10::optional<at::Tensor>> &rb, int64_t n_out,
-                                       const c10::optional<at::Tensor> &skip, bool want_stats) {
+                                       const c10::optional<at::Tensor> &skip, bool want_stats,
+                                       const std::vector<c10::optional<at::Tensor>> &sc = {}) {
     TORCH_CHECK(bn1.size() == 5 && bn2.size() == 5 && cv1.size() == 3 && cv2.size() == 3 && rb.size() == 5 &&
                 cv1[0].has_value() && cv2[0].has_value() && rb[0].has_value(), "doda residual_block: bad argument lists");
-    const bool identity = !(skip.has_value() && skip->defined());
+    // sc = {weight [1,1,1,Cin,Cout], packed forward, packed data-grad, identity table, identity table as the pair lists or
+    // None}: the block's 1x1 skip convolution (reference model/unet_block.py:18-21), run HERE on the first BatchNorm's
+    // pass-through alias of x, so that its data gradient is summed inside that BatchNorm's backward kernel instead of
+    // by an autograd accumulation kernel (x has two consumers: the BatchNorm and the skip)
+    const bool conv_skip = sc.size() == 5 && sc[0].has_value() && sc[3].has_value();
+    TORCH_CHECK(!(conv_skip && skip.has_value() && skip->defined()), "doda residual_block: skip features AND a skip convolution");
+    const bool identity = !conv_skip && !(skip.has_value() && skip->defined());
     const at::Tensor &tbl = *rb[0];
     const at::Tensor st1 = stats_in.has_value() ? *stats_in : at::Tensor();
     PreArgs p1, p2;
     const bool f1 = prologue_usable(x, st1, bn1, training, *cv1[0], tbl, n_out);
     auto a = bn_relu_impl(x, bn1[0], bn1[1], bn1[2], bn1[3], bn1[4], training, momentum1, eps1, true,
-                          identity && training, st1, f1 ? &p1 : nullptr);
+                          (identity || conv_skip) && training, st1, f1 ? &p1 : nullptr);
+
     auto z1 = indice_conv_impl(a[0], *cv1[0], tbl, tbl, n_out, 2, cv1[1], cv1[2], c10::nullopt, rb[1], rb[2], rb[3], rb[4],
                                want_stats, f1 ? &p1 : nullptr);
+    at::Tensor skip_feats;   // (after conv1: the conv that follows a BatchNorm op picks up its statistics link)
+    if (conv_skip)
+        skip_feats = indice_conv_impl(training ? a[1] : x, *sc[0], *sc[3], *sc[3], x.size(0), 1, sc[1], sc[2], c10::nullopt,
+                                      sc[4], sc[4], c10::nullopt, c10::nullopt, false)[0];
     const bool f2 = prologue_usable(z1[0], z1[1], bn2, training, *cv2[0], tbl, n_out);
     auto y2 = bn_relu_impl(z1[0], bn2[0], bn2[1], bn2[2], bn2[3], bn2[4], training, momentum2, eps2, true, false, z1[1],
                            f2 ? &p2 : nullptr);
-    const at::Tensor res = identity ? (training ? a[1] : x) : *skip;
+    const at::Tensor res = conv_skip ? skip_feats : identity ? (training ? a[1] : x) : *skip;
     return indice_conv_impl(y2[0], *cv2[0], tbl, tbl, n_out, 2, cv2[1], cv2[2], res, rb[1], rb[2], rb[3], rb[4], want_stats,
                             f2 ? &p2 : nullptr);
 }
@@ -989,11 +1018,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                                double momentum2, double eps2, const std::vector<c10::optional<at::Tensor>> &cv1,
                                const std::vector<c10::optional<at::Tensor>> &cv2,
                                const std::vector<c10::optional<at::Tensor>> &rb, int64_t n_out,
-                               const c10::optional<at::Tensor> &skip, bool want_stats) {
+                               const c10::optional<at::Tensor> &skip, bool want_stats,
+                               const std::vector<c10::optional<at::Tensor>> &sc) {
         auto r = residual_block(x, stats_in, bn1, bn2, training, momentum1, eps1, momentum2, eps2, cv1, cv2, rb, n_out, skip,
-                                want_stats);
+                                want_stats, sc);
         return std::make_pair(r[0], r[1].defined() ? c10::optional<at::Tensor>(r[1]) : c10::nullopt);
-    }, "BatchNorm -> ReLU -> SubM conv -> BatchNorm -> ReLU -> SubM conv (+ skip) in one call");
+    }, "BatchNorm -> ReLU -> SubM conv -> BatchNorm -> ReLU -> SubM conv (+ skip) in one call",
+          py::arg("x"), py::arg("stats_in"), py::arg("bn1"), py::arg("bn2"), py::arg("training"), py::arg("momentum1"),
+          py::arg("eps1"), py::arg("momentum2"), py::arg("eps2"), py::arg("cv1"), py::arg("cv2"), py::arg("rb"),
+          py::arg("n_out"), py::arg("skip"), py::arg("want_stats"),
+          py::arg("sc") = std::vector<c10::optional<at::Tensor>>());
     m.def("set_bn_fusion", [](bool on) { g_bn_fusion = on; }, "BatchNorm statistics in the conv epilogues (default on)");
     m.def("set_bn_prologue", [](bool on) { g_bn_prologue = on; },
           "BatchNorm apply(+ReLU) in the consuming conv's prologue inside residual_block (default off)");

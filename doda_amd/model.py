@@ -48,6 +48,12 @@ def _shallow(t):
 # One extension call per residual block instead of one per BatchNorm / convolution (DODA_FAST_BLOCKS=0: module by module)
 import os as _os
 FAST_BLOCKS = _os.environ.get("DODA_FAST_BLOCKS", "1") == "1"
+# Skip connections through the BatchNorm's pass-through output (round 3): a tensor that feeds a fused BatchNorm AND a skip
+# (the U-Net level's concatenation, reference model/unet_block.py:89-93; the 1x1 skip of a channel-changing block) hands
+# the skip the BatchNorm op's alias of it, so the skip's gradient — for the concatenation a column slice of the wider
+# gradient, taken with its row stride, no copy — is summed inside the BatchNorm's backward kernel: 12 accumulation
+# kernels per step less.  DODA_SKIP_FUSION=0: off.
+SKIP_IN_BLOCK = SKIP_VIA_BN = _os.environ.get("DODA_SKIP_FUSION", "1") == "1"
 
 
 def _subm3(cin, cout, key):
@@ -141,11 +147,27 @@ class ResidualBlock(SparseModule):
         pk2 = c2._packed(feats, input.indice_dict)
         if pk1 is None or pk2 is None:
             return None
-        skip = None
+        skip, sc = None, []
         if not identity:
-            skip = self.i_branch(_shallow(input)).features
-            if skip.dtype != feats.dtype:
-                return None
+            # the 1x1 skip convolution (reference model/unet_block.py:18-21) runs inside the extension call, on the first
+            # BatchNorm's pass-through alias of the input: its data gradient is then summed inside that BatchNorm's
+            # backward kernel instead of by an autograd accumulation kernel (SKIP_IN_BLOCK; the input has two consumers)
+            sk = self.i_branch[0] if len(self.i_branch) == 1 else None
+            if (SKIP_IN_BLOCK and training and type(sk) is spconv.SubMConv3d and sk.conv1x1 and sk.bias is None
+                    and sk.training and sk.in_channels % 4 == 0 and sk.out_channels % 4 == 0
+                    and sk._parameters["weight"].dtype == torch.float32 and not (sk._forward_hooks or sk._forward_pre_hooks
+                                                                              or sk._backward_hooks or sk._backward_pre_hooks)
+                    and not (self.i_branch._forward_hooks or self.i_branch._forward_pre_hooks)):
+                pks = sk._packed(feats, input.indice_dict)
+                if pks is not None:
+                    from .spconv.conv import _identity_table
+                    ident = _identity_table(feats.shape[0], feats.device)
+                    wsk = sk._parameters["weight"]
+                    sc = [wsk, pks[0], pks[1], ident, ident if Fsp._want_pairs(feats, wsk) else None]
+            if not sc:
+                skip = self.i_branch(_shallow(input)).features
+                if skip.dtype != feats.dtype:
+                    return None
         n_out = data.outids.shape[0]
         w1, w2 = c1._parameters["weight"], c2._parameters["weight"]
         if Fsp._want_pairs(feats, w1) and Fsp._want_pairs(feats, w2):
@@ -159,7 +181,7 @@ class ResidualBlock(SparseModule):
         stats_in = st[1] if (st is not None and st[0] is feats and st[2] == feats._version) else None
         want_stats = training and Fsp.BN_FUSION and n_out > Fsp.STATS_MIN_ROWS
         y, stats = ext.residual_block(feats, stats_in, l1, l2, training, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps,
-                                      [w1, pk1[0], pk1[1]], [w2, pk2[0], pk2[1]], rb, n_out, skip, want_stats)
+                                      [w1, pk1[0], pk1[1]], [w2, pk2[0], pk2[1]], rb, n_out, skip, want_stats, sc)
         out = spconv.SparseConvTensor(y, data.outids, data.out_spatial_shape, input.batch_size)
         out.indice_dict = input.indice_dict
         out.grid = input.grid
@@ -214,11 +236,41 @@ class UBlock(nn.Module):
                 hook()
         out = self.blocks(input)
         if len(self.nPlanes) > 1:
-            skip = _shallow(out)
-            dec = self.deconv(self.u(self.conv(out)))
-            out.features = torch.cat((skip.features, dec.features), dim=1)
+            down = self._down_with_skip(out) if SKIP_VIA_BN else None
+            if down is not None:
+                skip_feats, down = down
+            else:
+                skip_feats = _shallow(out).features
+                down = self.conv(out)
+            dec = self.deconv(self.u(down))
+            out.features = torch.cat((skip_feats, dec.features), dim=1)
             out = self.blocks_tail(out)
         return out
+
+    def _down_with_skip(self, out):
+        """self.conv = [BatchNorm, ReLU, strided conv] with the BatchNorm's pass-through output: returns (alias of
+        out.features for the skip connection, the strided conv's output), or None when the sequence is not that plain
+        triple in training mode on the fused path.  The concatenation's gradient for the skip — a column slice of a
+        twice as wide matrix — then reaches the BatchNorm's backward kernel as its strided `add` operand."""
+        from . import nn as _dnn
+        from .spconv.modules import _run
+        seq = self.conv
+        mods = list(seq._modules.values())
+        feats = out.features
+        if (len(mods) != 3 or type(mods[1]) is not nn.ReLU or not isinstance(mods[2], spconv.SparseConvolution)
+                or not mods[0].training or not torch.is_grad_enabled() or not feats.requires_grad
+                or out.indices.shape[0] < 2 or not _dnn.fusable(mods[0], feats) or _dnn._ext is None
+                or seq._forward_hooks or seq._forward_pre_hooks or seq._backward_hooks or seq._backward_pre_hooks
+                or mods[0]._forward_hooks or mods[0]._forward_pre_hooks or mods[0]._backward_hooks
+                or mods[1]._forward_hooks or mods[1]._forward_pre_hooks or mods[1]._backward_hooks):
+            return None
+        st = out.__dict__.get("_doda_stats")
+        stats = st[1] if (st is not None and st[0] is feats and st[2] == feats._version) else None
+        y, alias = _dnn.batch_norm_relu(feats, mods[0], True, True, stats)
+        t = spconv.SparseConvTensor(y, out.indices, out.spatial_shape, out.batch_size)
+        t.indice_dict = out.indice_dict
+        t.grid = out.grid
+        return alias, _run(mods[2], t)
 
 
 class _PointLinear(Function):

@@ -660,6 +660,49 @@ def bn_relu_bwd(x, dy, save_mean, save_invstd, gamma, beta, relu):
     return dx, dgamma, dbeta
 
 
+def _add_ld(add, m, c, what):
+    """(pointer, row stride in elements) of the second-gradient operand: dense, or a column slice of a wider matrix."""
+    _need_cuda(add)
+    if add.dim() != 2 or tuple(add.shape) != (m, c) or add.stride(1) != 1 or add.stride(0) < c:
+        raise RuntimeError("%s: add must be [m, c] with unit column stride" % what)
+    return _p(add), int(add.stride(0))
+
+
+def bn_relu_bwd_add(x, dy, save_mean, save_invstd, gamma, beta, relu, add):
+    """bn_relu_bwd with a second gradient of x summed into dx inside the apply pass (doda_bn_relu_bwd_add_ld); `add`
+    may be a column slice of a wider matrix (e.g. g[:, :c] of torch.cat's gradient): no copy is made."""
+    _feat_ok(x, "x")
+    _feat_ok(dy, "dy")
+    m, c = x.shape
+    ap, ld = _add_ld(add, m, c, "bn_relu_bwd_add")
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    ws = _ws(lib().doda_bn_workspace_bytes(m, c), x.device)
+    check(lib().doda_bn_relu_bwd_add_ld(_p(x), _p(dy), m, c, _esz(x), _p(save_mean), _p(save_invstd), _p(gamma), _p(beta),
+                                        int(bool(relu)), ap, ld, _p(dx), _p(dgamma), _p(dbeta), _p(ws), ws.numel(),
+                                        _stream()), "doda_bn_relu_bwd_add_ld")
+    return dx, dgamma, dbeta
+
+
+def bn_relu_bwd_stats(x, dy, stats, save_mean, save_invstd, gamma, beta, relu, add=None):
+    """BatchNorm(+ReLU) backward over the (sum dz, sum dz * xhat) rows of a data-grad conv epilogue
+    (doda_bn_relu_bwd_stats_ld); add as in bn_relu_bwd_add.  -> (dx [+ add], dgamma, dbeta)."""
+    _feat_ok(x, "x")
+    _feat_ok(dy, "dy")
+    _need_cuda(stats)
+    m, c = x.shape
+    ap, ld = _add_ld(add, m, c, "bn_relu_bwd_stats") if add is not None else (None, c)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    coef = torch.empty(3 * c, dtype=torch.float32, device=x.device)
+    check(lib().doda_bn_relu_bwd_stats_ld(_p(x), _p(dy), m, c, _esz(x), _p(stats), stats.shape[0], _p(save_mean),
+                                          _p(save_invstd), _p(gamma), _p(beta), int(bool(relu)), ap, ld, _p(dx), _p(dgamma),
+                                          _p(dbeta), _p(coef), _stream()), "doda_bn_relu_bwd_stats_ld")
+    return dx, dgamma, dbeta
+
+
 def bn_relu_fwd_totals(x, totals, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None):
     """Training-mode BatchNorm(+ReLU) from the totals of a conv epilogue (doda_bn_relu_fwd_totals): one launch.
     -> (y, save_mean, save_invstd)."""

@@ -435,6 +435,19 @@ int doda_bn_relu_fwd_stats(const void *x, int32_t m, int32_t c, int32_t elem_byt
                            const float *beta, float *running_mean, float *running_var,
                            int64_t *num_batches_tracked, int32_t relu, void *y, float *save_mean,
                            float *save_invstd, doda_stream_t stream);
+/* ABI 6.  doda_bn_relu_bwd_stats / doda_bn_relu_bwd_add with a ROW-STRIDED `add` operand: row r of the second gradient
+ * starts at add + r * add_ld elements (add_ld >= c, a multiple of 4; `add` aligned to 4 elements) — a column slice of a
+ * wider matrix, i.e. the gradient torch.cat's backward hands to one of its inputs (the U-Net's skip connection,
+ * reference model/unet_block.py:93): no copy into a dense matrix, no separate accumulation kernel. */
+int doda_bn_relu_bwd_stats_ld(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
+                              const float *stats, int32_t stats_rows, const float *save_mean,
+                              const float *save_invstd, const float *gamma, const float *beta, int32_t relu,
+                              const void *add, int32_t add_ld, void *dx, float *dgamma, float *dbeta,
+                              float *coef_ws, doda_stream_t stream);
+int doda_bn_relu_bwd_add_ld(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
+                            const float *save_mean, const float *save_invstd, const float *gamma,
+                            const float *beta, int32_t relu, const void *add, int32_t add_ld, void *dx,
+                            float *dgamma, float *dbeta, void *ws, size_t ws_bytes, doda_stream_t stream);
 /* ABI 6.  The reduction half of doda_bn_relu_fwd_stats alone (training mode): save_mean / save_invstd [c] from the
  * partial rows, running statistics and num_batches_tracked updated (any of the three may be NULL) — for a BatchNorm whose
  * apply pass rides in the consuming convolution's prologue (doda_conv_epilogue.pre_*). */

@@ -668,6 +668,8 @@ def test_residual_block_in_one_call_is_the_same_step(native_lib, dt):
 
     def run(fast):
         M.FAST_BLOCKS = fast
+        M.SKIP_IN_BLOCK = False   # (the one-call block can also sum its 1x1 skip's gradient inside the BatchNorm kernel:
+        #                            one rounding instead of two — tested in test_skip_connections_through_the_batchnorm_alias)
         torch.manual_seed(0)
         net = M.SparseConvNet(cfg).to(d).train()
         outs = []
@@ -688,6 +690,7 @@ def test_residual_block_in_one_call_is_the_same_step(native_lib, dt):
         b = run(False)
     finally:
         M.FAST_BLOCKS = True
+        M.SKIP_IN_BLOCK = True
     assert all(torch.equal(x, y) for x, y in zip(a[0], b[0]))
     assert all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
     assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
@@ -749,3 +752,71 @@ def test_one_call_block_yields_to_hooks(native_lib):
     finally:
         h.remove()
     assert len(seen) == 1 and seen[0][1] == 16
+
+
+@pytest.mark.parametrize("m,c,dt", [(50000, 16, torch.bfloat16), (9001, 32, torch.float32), (3000, 80, torch.bfloat16),
+                                    (257, 112, torch.float32)])
+def test_batchnorm_backward_takes_a_strided_second_gradient(native_lib, m, c, dt):
+    """doda_bn_relu_bwd_add_ld / _stats_ld: the skip connection's gradient as a column slice of a twice as wide matrix
+    (what torch.cat's backward hands over, reference model/unet_block.py:93) gives BIT-equal results to the same
+    values in a dense matrix — two-pass kernels (m > 4096), the one-launch kernel (m <= 4096), both halves of the
+    wide matrix — and matches torch's fp64 BatchNorm backward + add."""
+    from doda_amd import ops
+    d = dev()
+    torch.manual_seed(m + c)
+    x = torch.randn(m, c, device=d).to(dt)
+    dy = torch.randn(m, c, device=d).to(dt)
+    wide = torch.randn(m, 2 * c, device=d).to(dt)
+    gamma = torch.rand(c, device=d) + 0.5
+    beta = torch.randn(c, device=d) * 0.3
+    y, mean, invstd = ops.bn_relu_fwd(x, gamma, beta, None, None, True, 0.1, 1e-4, True)
+    for half in (wide[:, :c], wide[:, c:]):
+        assert not half.is_contiguous()
+        a = ops.bn_relu_bwd_add(x, dy, mean, invstd, gamma, beta, True, half)
+        b = ops.bn_relu_bwd_add(x, dy, mean, invstd, gamma, beta, True, half.contiguous())
+        assert all(torch.equal(p, q) for p, q in zip(a, b))
+        # fp64 reference
+        xd = x.double().requires_grad_(True)
+        ref = torch.relu(torch.nn.functional.batch_norm(xd, None, None, gamma.double(), beta.double(), True, 0.1, 1e-4))
+        ref.backward(dy.double())
+        tol = 1e-4 if dt == torch.float32 else 2e-2
+        assert rel_err(a[0].float().cpu(), (xd.grad + half.double()).cpu()) < tol
+    # the statistics-row form: rows built from the definition (sum dz, sum dz * xhat), one row per 1000 input rows
+    xh = (x.float() - mean) * invstd
+    dz = dy.float() * ((xh * gamma + beta) > 0)
+    rows = torch.stack([torch.stack([dz[i:i + 1000].sum(0), (dz[i:i + 1000] * xh[i:i + 1000]).sum(0)]) for i in range(0, m, 1000)])
+    a = ops.bn_relu_bwd_stats(x, dy, rows.contiguous(), mean, invstd, gamma, beta, True, wide[:, c:])
+    b = ops.bn_relu_bwd_stats(x, dy, rows.contiguous(), mean, invstd, gamma, beta, True, wide[:, c:].contiguous())
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+
+
+def test_skip_connections_through_the_batchnorm_alias(native_lib):
+    """model.SKIP_VIA_BN / SKIP_IN_BLOCK: the U-Net level's concatenation and the 1x1 skip of the channel-changing
+    blocks take the BatchNorm op's pass-through alias, so their gradients are summed inside the BatchNorm's backward
+    kernel (fp32 sum, one rounding) instead of by accumulation kernels (two roundings).  The forward pass is unchanged
+    (loss and evaluation output BIT-equal); gradients agree to bf16 rounding; fp32 features: to 1e-5."""
+    _ext_or_skip()
+    from doda_amd import model as M
+    from doda_amd.scene import make_batch
+    d = dev()
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in make_batch(2, 30000, 23).items()}
+    cfg = M.default_cfg()
+
+    def run(on, dt):
+        M.SKIP_VIA_BN = M.SKIP_IN_BLOCK = on
+        torch.manual_seed(0)
+        net = M.SparseConvNet(cfg).to(d).train()
+        loss = M.cross_entropy(M.voxelize_and_run(cfg, net, bd, d, feature_dtype=dt), bd["labels"])
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), [p.grad.float().clone() for p in net.parameters()], [b.clone() for b in net.buffers()]
+    try:
+        for dt, tol in ((torch.bfloat16, 3e-2), (torch.float32, 1e-5)):
+            a, b = run(True, dt), run(False, dt)
+            assert torch.equal(a[0], b[0])
+            assert all(torch.equal(p, q) for p, q in zip(a[2], b[2]))
+            num = sum(float(((p - q) ** 2).sum()) for p, q in zip(a[1], b[1])) ** 0.5
+            den = sum(float((q ** 2).sum()) for q in b[1]) ** 0.5
+            assert num / den < tol, (dt, num / den)
+    finally:
+        M.SKIP_VIA_BN = M.SKIP_IN_BLOCK = True

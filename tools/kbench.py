@@ -74,6 +74,10 @@ def main():
                 bf = s * 2 * m * c + 4 * 27 * c * c + 8 * pairs
                 line = "L%d M=%7d c=%3d %-4s  fwd %8.1f us (%5.0f GB/s)  dgrad %8.1f  wgrad %8.1f" % (
                     lvl, m, c, dt, tf, bf / tf / 1e3, td, tw)
+                if dt == "f32" and c == 16:   # the tile kernel's fp32 mode over the rulebook's tilebook
+                    tb = ops.tilebook_build(sub.tbl)
+                    tt = timed(lambda: ops.spconv_gather(x, w, sub.tbl, m, 0, c, tilebook=tb), a.reps)
+                    line += "  fwd over the tilebook %7.1f" % tt
                 if dt == "bf16" and c % 16 == 0:
                     te = timed(lambda: ops.rulebook_pairs(sub.tbl, m, True, pad=False), a.reps)
                     pr, num, seg = ops.rulebook_pairs(sub.tbl, m, True, pad=False, with_seg=True)

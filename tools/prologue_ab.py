@@ -14,6 +14,7 @@ from doda_amd.spconv import functional as Fsp
 dev = torch.device("cuda:0")
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+which = sys.argv[3] if len(sys.argv) > 3 else "prologue"   # prologue | skip (model.SKIP_VIA_BN / SKIP_IN_BLOCK)
 bd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in make_batch(4, 150000, 1000).items()}
 cfg = default_cfg(); torch.manual_seed(0)
 net = SparseConvNet(cfg).to(dev).train()
@@ -32,7 +33,11 @@ def step():
 
 
 def run(n, on):
-    Fsp.set_bn_prologue(on)
+    if which == "skip":
+        import doda_amd.model as M
+        M.SKIP_VIA_BN = M.SKIP_IN_BLOCK = on
+    else:
+        Fsp.set_bn_prologue(on)
     for _ in range(8): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): step()
@@ -42,6 +47,6 @@ def run(n, on):
 
 for _ in range(20): step()
 for rnd in range(rounds):
-    print("round %d: " % rnd + "  ".join("prologue=%d %.3f ms" % (on, run(steps, bool(on))) for on in (1, 0, 1, 0)), flush=True)
+    print("round %d: " % rnd + "  ".join("%s=%d %.3f ms" % (which, on, run(steps, bool(on))) for on in (1, 0, 1, 0)), flush=True)
 pend[0].result()
 PF.shutdown()
