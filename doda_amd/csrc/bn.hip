@@ -36,8 +36,11 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 
 struct F32 {
     typedef float elem;
+    static constexpr int W = 1;   // 4-channel fragments per 16-byte access
     static __device__ __forceinline__ f32x4 load4(const elem *p) { return *reinterpret_cast<const f32x4 *>(p); }
     static __device__ __forceinline__ void store4(elem *p, const f32x4 &v) { *reinterpret_cast<f32x4 *>(p) = v; }
+    static __device__ __forceinline__ void loadw(const elem *p, f32x4 (&v)[1]) { v[0] = load4(p); }
+    static __device__ __forceinline__ void storew(elem *p, const f32x4 (&v)[1]) { store4(p, v[0]); }
 };
 struct BF16 {
     typedef unsigned short elem;
@@ -50,6 +53,21 @@ struct BF16 {
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = (short)f2bf(v[q]);
         *reinterpret_cast<s16x4 *>(p) = o;
+    }
+    static constexpr int W = 2;   // two 4-channel fragments (8 channels) per 16-byte access
+    typedef short s16x8_ __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ void loadw(const elem *p, f32x4 (&v)[2]) {
+        const s16x8_ r = *reinterpret_cast<const s16x8_ *>(p);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            v[h] = (f32x4){bf2f((unsigned short)r[4 * h]), bf2f((unsigned short)r[4 * h + 1]), bf2f((unsigned short)r[4 * h + 2]),
+                           bf2f((unsigned short)r[4 * h + 3])};
+    }
+    static __device__ __forceinline__ void storew(elem *p, const f32x4 (&v)[2]) {
+        s16x8_ o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (short)f2bf(v[q >> 2][q & 3]);
+        *reinterpret_cast<s16x8_ *>(p) = o;
     }
 };
 
@@ -138,7 +156,12 @@ __global__ __launch_bounds__(64) void bn_stats_final(const typename T::elem *__r
 }
 
 // ---- pass 2: normalise + affine (+ReLU) --------------------------------------------------------
-template <class T>
+// Round 3: the launcher picks a grid whose thread count is a multiple of the fragments per row, so a thread's channels
+// never change while it strides over the rows: the per-channel vectors are loaded ONCE into registers (they used to be
+// four extra vector loads per 8 bytes of payload — the sweep was bound by the texture path's instruction rate, 3.3 TB/s
+// at level 1, not by HBM), and bf16 rows move in 16-byte accesses (two fragments per thread).  Same arithmetic, same
+// order: results unchanged bit for bit.  FIXED = false: the general form (any grid).
+template <class T, bool FIXED>
 __global__ __launch_bounds__(BN_BLOCK) void bn_apply(const typename T::elem *__restrict__ x,
                                                      long long n_frag, int nf,
                                                      const float *__restrict__ mean,
@@ -146,6 +169,34 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply(const typename T::elem *__r
                                                      const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, int relu,
                                                      typename T::elem *__restrict__ y) {
+    if constexpr (FIXED) {
+        constexpr int W = T::W;
+        const long long n_w = n_frag / W, e0 = (long long)blockIdx.x * BN_BLOCK + threadIdx.x;
+        const int f = (int)(e0 % (nf / W)) * W;
+        f32x4 mu[W], is[W], ga[W], be[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            mu[w] = *reinterpret_cast<const f32x4 *>(mean + (f + w) * 4);
+            is[w] = *reinterpret_cast<const f32x4 *>(invstd + (f + w) * 4);
+            ga[w] = *reinterpret_cast<const f32x4 *>(gamma + (f + w) * 4);
+            be[w] = *reinterpret_cast<const f32x4 *>(beta + (f + w) * 4);
+        }
+        for (long long e = e0; e < n_w; e += (long long)gridDim.x * BN_BLOCK) {
+            f32x4 v[W];
+            T::loadw(x + e * (4 * W), v);
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                f32x4 o = (v[w] - mu[w]) * is[w] * ga[w] + be[w];
+                if (relu) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = o[q] > 0.f ? o[q] : 0.f;
+                }
+                v[w] = o;
+            }
+            T::storew(y + e * (4 * W), v);
+        }
+        return;
+    }
     for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < n_frag;
          e += (long long)gridDim.x * BN_BLOCK) {
         const int f = (int)(e % nf);
@@ -161,6 +212,26 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply(const typename T::elem *__r
         }
         T::store4(y + e * 4, o);
     }
+}
+
+// grid of an apply sweep: as many workgroups as fragments need (<= 4096), rounded DOWN so that the thread count is a
+// multiple of the 16-byte columns per row (then FIXED applies); *fixed = false when no such grid exists
+inline int apply_grid(long long n_frag, int nf, int W, bool *fixed) {
+    const long long n_w = n_frag / W;
+    const int cols = nf / W;
+    long long grid = (n_w + BN_BLOCK - 1) / BN_BLOCK;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    *fixed = false;
+    if (nf % W != 0 || n_frag % W != 0) return (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
+    int a = cols, b = BN_BLOCK;            // q = cols / gcd(cols, BN_BLOCK): grid must be a multiple of q
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int q = cols / a;
+    if (grid >= q) {
+        *fixed = true;
+        return (int)(grid - grid % q);
+    }
+    return (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
 }
 
 // ---- backward pass 1: per-block partial sums of dz and dz*xhat --------------------------------
@@ -229,7 +300,7 @@ __global__ __launch_bounds__(64) void bn_bwd_final(const float *__restrict__ par
     coef[2 * c + ch] = (float)(s2 / m);
 }
 
-template <class T>
+template <class T, bool FIXED>
 __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply(const typename T::elem *__restrict__ x,
                                                          const typename T::elem *__restrict__ dy,
                                                          long long n_frag, int nf, int c,
@@ -240,6 +311,43 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply(const typename T::elem 
                                                          const float *__restrict__ coef,
                                                          typename T::elem *__restrict__ dx,
                                                          const typename T::elem *__restrict__ add, int add_ld = 0) {
+    if constexpr (FIXED) {   // (see bn_apply: per-thread channel vectors in registers, 16-byte accesses)
+        constexpr int W = T::W;
+        const int cols = nf / W;
+        const long long n_w = n_frag / W, e0 = (long long)blockIdx.x * BN_BLOCK + threadIdx.x;
+        const int f = (int)(e0 % cols) * W;
+        f32x4 mu[W], is[W], ga[W], be[W], ca[W], cb[W], cd[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            mu[w] = *reinterpret_cast<const f32x4 *>(mean + (f + w) * 4);
+            is[w] = *reinterpret_cast<const f32x4 *>(invstd + (f + w) * 4);
+            ga[w] = *reinterpret_cast<const f32x4 *>(gamma + (f + w) * 4);
+            be[w] = *reinterpret_cast<const f32x4 *>(beta + (f + w) * 4);
+            ca[w] = *reinterpret_cast<const f32x4 *>(coef + (f + w) * 4);
+            cb[w] = *reinterpret_cast<const f32x4 *>(coef + c + (f + w) * 4);
+            cd[w] = *reinterpret_cast<const f32x4 *>(coef + 2 * c + (f + w) * 4);
+        }
+        for (long long e = e0; e < n_w; e += (long long)gridDim.x * BN_BLOCK) {
+            f32x4 xv[W], dz[W], av[W];
+            T::loadw(x + e * (4 * W), xv);
+            T::loadw(dy + e * (4 * W), dz);
+            if (add) T::loadw(add_ld ? add + (e / cols) * add_ld + f * 4 : add + e * (4 * W), av);
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const f32x4 xh = (xv[w] - mu[w]) * is[w];
+                if (relu) {
+                    const f32x4 yv = xh * ga[w] + be[w];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dz[w][q] = yv[q] > 0.f ? dz[w][q] : 0.f;
+                }
+                f32x4 o = ca[w] * (dz[w] - cb[w] - xh * cd[w]);
+                if (add) o += av[w];
+                xv[w] = o;
+            }
+            T::storew(dx + e * (4 * W), xv);
+        }
+        return;
+    }
     for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < n_frag;
          e += (long long)gridDim.x * BN_BLOCK) {
         const int f = (int)(e % nf);
@@ -263,6 +371,39 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply(const typename T::elem 
         if (add) o += T::load4(add_ld ? add + (e / nf) * add_ld + f * 4 : add + e * 4);
         T::store4(dx + e * 4, o);
     }
+}
+
+inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+inline int plain_grid(long long n_frag) {
+    return (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
+}
+template <class T>
+void launch_apply(const typename T::elem *x, long long n_frag, int nf, const float *mean, const float *invstd,
+                  const float *gamma, const float *beta, int relu, typename T::elem *y, hipStream_t s) {
+    bool fixed;
+    int grid = apply_grid(n_frag, nf, T::W, &fixed);
+    if (fixed && !(al16(x) && al16(y))) { fixed = false; grid = plain_grid(n_frag); }
+    if (fixed)
+        hipLaunchKernelGGL((bn_apply<T, true>), dim3(grid), dim3(BN_BLOCK), 0, s, x, n_frag, nf, mean, invstd, gamma, beta, relu, y);
+    else
+        hipLaunchKernelGGL((bn_apply<T, false>), dim3(grid), dim3(BN_BLOCK), 0, s, x, n_frag, nf, mean, invstd, gamma, beta, relu, y);
+}
+template <class T>
+void launch_bwd_apply(const typename T::elem *x, const typename T::elem *dy, long long n_frag, int nf, int c,
+                      const float *mean, const float *invstd, const float *gamma, const float *beta, int relu,
+                      const float *coef, typename T::elem *dx, const typename T::elem *add, int add_ld, hipStream_t s) {
+    bool fixed;
+    int grid = apply_grid(n_frag, nf, T::W, &fixed);
+    if (fixed && !(al16(x) && al16(dy) && al16(dx) && (!add || (al16(add) && add_ld % (4 * T::W) == 0)))) {
+        fixed = false;
+        grid = plain_grid(n_frag);
+    }
+    if (fixed)
+        hipLaunchKernelGGL((bn_bwd_apply<T, true>), dim3(grid), dim3(BN_BLOCK), 0, s, x, dy, n_frag, nf, c, mean, invstd, gamma,
+                           beta, relu, coef, dx, add, add_ld);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply<T, false>), dim3(grid), dim3(BN_BLOCK), 0, s, x, dy, n_frag, nf, c, mean, invstd, gamma,
+                           beta, relu, coef, dx, add, add_ld);
 }
 
 // ---- small-M variants: ONE launch per direction --------------------------------------------------
@@ -985,9 +1126,7 @@ int run_fwd(const void *x_, int m, int c, float eps, float momentum, const float
                            c, eps, momentum, mean, invstd, running_mean, running_var, nbt);
     }
     const long long n_frag = (long long)m * g.nf;
-    const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
-    hipLaunchKernelGGL((bn_apply<T>), dim3(grid), dim3(BN_BLOCK), 0, s, x, n_frag, g.nf, mean, invstd,
-                       gamma, beta, relu, y);
+    launch_apply<T>(x, n_frag, g.nf, mean, invstd, gamma, beta, relu, y, s);
     return doda_check_launch();
 }
 
@@ -1014,9 +1153,7 @@ int run_bwd(const void *x_, const void *dy_, int m, int c, const float *mean, co
     hipLaunchKernelGGL(bn_bwd_final, dim3(c), dim3(64), 0, s, partial, nb, m, c, invstd,
                        gamma, dgamma, dbeta, coef);
     const long long n_frag = (long long)m * g.nf;
-    const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
-    hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(grid), dim3(BN_BLOCK), 0, s, x, dy, n_frag, g.nf, c, mean,
-                       invstd, gamma, beta, relu, coef, dx, add, add_ld);
+    launch_bwd_apply<T>(x, dy, n_frag, g.nf, c, mean, invstd, gamma, beta, relu, coef, dx, add, add_ld, s);
     return doda_check_launch();
 }
 
@@ -1144,8 +1281,7 @@ static int run_fwd_stats(const void *x_, int m, int c, const float *stats, int r
     }
     hipLaunchKernelGGL(bn_fwd_final_stats, dim3(c / 4), dim3(BN_BLOCK), 0, s, stats, rows, m, c, eps, momentum, mean,
                        invstd, rm, rv, nbt);
-    hipLaunchKernelGGL((bn_apply<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, n_frag, g.nf, mean, invstd,
-                       gamma, beta, relu, (elem *)y_);
+    launch_apply<T>((const elem *)x_, n_frag, g.nf, mean, invstd, gamma, beta, relu, (elem *)y_, s);
     return doda_check_launch();
 }
 
@@ -1175,8 +1311,8 @@ static int run_bwd_stats(const void *x_, const void *dy_, int m, int c, const fl
     }
     hipLaunchKernelGGL(bn_bwd_final_stats, dim3(c / 4), dim3(BN_BLOCK), 0, s, stats, rows, m, c, invstd, gamma, dgamma,
                        dbeta, coef);
-    hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, (const elem *)dy_, n_frag,
-                       g.nf, c, mean, invstd, gamma, beta, relu, coef, (elem *)dx_, (const elem *)add_, add_ld);
+    launch_bwd_apply<T>((const elem *)x_, (const elem *)dy_, n_frag, g.nf, c, mean, invstd, gamma, beta, relu, coef,
+                        (elem *)dx_, (const elem *)add_, add_ld, s);
     return doda_check_launch();
 }
 
