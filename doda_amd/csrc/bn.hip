@@ -583,6 +583,23 @@ __device__ __forceinline__ void block_sum_d4(double (&v)[4], double (*lds)[4]) {
     for (int q = 0; q < 4; ++q) v[q] = (lds[0][q] + lds[1][q]) + (lds[2][q] + lds[3][q]);
 }
 
+// both sums at once: one pair of barriers instead of two (the `final` kernels are launch-floor kernels: 75 per step)
+__device__ __forceinline__ void block_sum_d8(double (&a)[4], double (&b)[4], double (*lds)[8]) {   // 256 threads, fixed order
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a[q] = wave_sum(a[q]); b[q] = wave_sum(b[q]); }
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lds[wid][q] = a[q]; lds[wid][4 + q] = b[q]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        a[q] = (lds[0][q] + lds[1][q]) + (lds[2][q] + lds[3][q]);
+        b[q] = (lds[0][4 + q] + lds[1][4 + q]) + (lds[2][4 + q] + lds[3][4 + q]);
+    }
+}
+
 // this thread's share of the partial rows of channel quad f.  Four rows per trip with all eight loads
 // issued before the first add: a level-1 layer has ~4700 partial rows and four blocks to reduce them, so
 // the kernel is a chain of L2 round trips (13.4 us with one row per trip)
@@ -615,38 +632,35 @@ __device__ __forceinline__ void fwd_final_body(int f, const float *__restrict__ 
                                                float momentum, float *__restrict__ mean, float *__restrict__ invstd,
                                                float *__restrict__ running_mean, float *__restrict__ running_var,
                                                long long *__restrict__ nbt) {
-    __shared__ double lds[4][4];
-    f32x4 rm = {0, 0, 0, 0}, rv = {0, 0, 0, 0};
+    __shared__ double lds[4][8];
+    // threads 0..3 finish one channel each (the fp64 divide / square root chains of the four channels side by side);
+    // what they need at the end is requested before the partial sums: one round trip, not two
+    const int q = threadIdx.x & 3;
+    float rm = 0.f, rv = 0.f;
     long long n_tracked = 0;
-    if (threadIdx.x == 0 && running_mean) {   // requested before the partial sums: one round trip, not two
-        rm = *reinterpret_cast<const f32x4 *>(running_mean + f * 4);
-        rv = *reinterpret_cast<const f32x4 *>(running_var + f * 4);
+    if (threadIdx.x < 4 && running_mean) {
+        rm = running_mean[f * 4 + q];
+        rv = running_var[f * 4 + q];
     }
     if (threadIdx.x == 0 && f == 0 && nbt) n_tracked = *nbt;
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     sum_partials(stats, rows, c, f, s1, s2);
-    block_sum_d4(s1, lds);
-    block_sum_d4(s2, lds);
-    if (threadIdx.x != 0) return;
-    f32x4 mu, is;
+    block_sum_d8(s1, s2, lds);
+    if (threadIdx.x >= 4) return;
+    double a1 = s1[0], a2 = s2[0];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const double d = s1[q] / m;
-        double var = s2[q] / m - d * d;
-        if (var < 0.0) var = 0.0;
-        mu[q] = (float)d;
-        is[q] = (float)(1.0 / sqrt(var + (double)eps));
-        const double unbiased = m > 1 ? var * (double)m / (double)(m - 1) : var;
-        rm[q] = (float)((1.0 - momentum) * (double)rm[q] + momentum * d);
-        rv[q] = (float)((1.0 - momentum) * (double)rv[q] + momentum * unbiased);
-    }
-    *reinterpret_cast<f32x4 *>(mean + f * 4) = mu;
-    *reinterpret_cast<f32x4 *>(invstd + f * 4) = is;
+    for (int k = 1; k < 4; ++k) { if (q == k) { a1 = s1[k]; a2 = s2[k]; } }
+    const double d = a1 / m;
+    double var = a2 / m - d * d;
+    if (var < 0.0) var = 0.0;
+    mean[f * 4 + q] = (float)d;
+    invstd[f * 4 + q] = (float)(1.0 / sqrt(var + (double)eps));
     if (running_mean) {
-        *reinterpret_cast<f32x4 *>(running_mean + f * 4) = rm;
-        *reinterpret_cast<f32x4 *>(running_var + f * 4) = rv;
+        const double unbiased = m > 1 ? var * (double)m / (double)(m - 1) : var;
+        running_mean[f * 4 + q] = (float)((1.0 - momentum) * (double)rm + momentum * d);
+        running_var[f * 4 + q] = (float)((1.0 - momentum) * (double)rv + momentum * unbiased);
     }
-    if (f == 0 && nbt) *nbt = n_tracked + 1;
+    if (threadIdx.x == 0 && f == 0 && nbt) *nbt = n_tracked + 1;
 }
 
 __global__ __launch_bounds__(BN_BLOCK) void bn_fwd_final_stats(const float *__restrict__ stats, int rows, int m, int c,
@@ -662,13 +676,12 @@ __device__ __forceinline__ void bwd_final_body(int f, const float *__restrict__ 
                                                const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                float *__restrict__ coef /*[3][C]*/) {
-    __shared__ double lds[4][4];
+    __shared__ double lds[4][8];
     const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
     const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + f * 4);
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     sum_partials(stats, rows, c, f, s1, s2);
-    block_sum_d4(s1, lds);
-    block_sum_d4(s2, lds);
+    block_sum_d8(s1, s2, lds);
     if (threadIdx.x != 0) return;
     f32x4 db, dg, a, bb, dd;
 #pragma unroll
