@@ -103,6 +103,7 @@ _SIGNATURES = {
                                           c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "doda_bn_relu_bwd_add_ld": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp,
                                         c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "doda_bn_relu_apply": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "doda_bn_fwd_final": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "doda_bn_set_chain": (None, [c_i32]),
     "doda_bn_chain_errors": (C.c_int64, []),

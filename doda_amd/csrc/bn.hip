@@ -1361,6 +1361,22 @@ extern "C" int doda_bn_relu_fwd_stats(const void *x, int32_t m, int32_t c, int32
                                (long long *)num_batches_tracked, relu, y, save_mean, save_invstd, as_stream(stream));
 }
 
+extern "C" int doda_bn_relu_apply(const void *x, int32_t m, int32_t c, int32_t elem_bytes, const float *mean,
+                                  const float *invstd, const float *gamma, const float *beta, int32_t relu, void *y,
+                                  doda_stream_t stream) {
+    if (m == 0) return DODA_OK;
+    if (bn_args_bad(m, c, elem_bytes)) return DODA_ERR_UNSUPPORTED;
+    if (!x || !y || !mean || !invstd || !gamma || !beta) return DODA_ERR_INVALID;
+    const Geo g = make_geo(c);
+    const long long n_frag = (long long)m * g.nf;
+    if (elem_bytes == 4)
+        launch_apply<F32>((const float *)x, n_frag, g.nf, mean, invstd, gamma, beta, relu, (float *)y, as_stream(stream));
+    else
+        launch_apply<BF16>((const unsigned short *)x, n_frag, g.nf, mean, invstd, gamma, beta, relu, (unsigned short *)y,
+                           as_stream(stream));
+    return doda_check_launch();
+}
+
 // ABI 6: the reduction alone — the apply pass rides in the consuming convolution's prologue (spconv_tile.hip, PRE)
 extern "C" int doda_bn_fwd_final(const float *stats, int32_t stats_rows, int32_t m, int32_t c, float eps, float momentum,
                                  float *running_mean, float *running_var, int64_t *num_batches_tracked, float *save_mean,

@@ -778,7 +778,7 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
                                      const at::Tensor &running_mean, const at::Tensor &running_var,
                                      const at::Tensor &nbt, bool training, double momentum, double eps,
                                      bool relu, bool passthrough, const at::Tensor &stats = at::Tensor(),
-                                     PreArgs *defer = nullptr) {
+                                     PreArgs *defer = nullptr, const at::Tensor &stats_b = at::Tensor()) {
     const bool need_grad = at::GradMode::is_enabled() &&
                            (x_in.requires_grad() || weight.requires_grad() || bias.requires_grad());
     at::Tensor x, y, mean, invstd, xp;
@@ -796,7 +796,26 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
             mean = running_mean.to(at::kFloat).contiguous();
             invstd = at::rsqrt(running_var.to(at::kFloat) + eps).contiguous();
         }
-        if (defer) {
+        if (training && stats.defined() && stats_b.defined() && !defer && m > BN_SMALL_ROWS && stats.dim() == 3 &&
+            stats_b.dim() == 3 && stats.size(2) + stats_b.size(2) == c && stats.scalar_type() == at::kFloat &&
+            stats_b.scalar_type() == at::kFloat && stats.is_contiguous() && stats_b.is_contiguous() && stats.size(2) % 4 == 0) {
+            // x is a channel concatenation [a | b] (the U-Net level's skip + upsampled features): BatchNorm statistics are
+            // per channel, so the two halves' statistics rows — from the epilogues of the two convs that produced them —
+            // are reduced separately into the halves of the per-channel vectors, and one apply pass follows: the
+            // standalone statistics sweep over the concatenated tensor is gone
+            const int64_t ca = stats.size(2), cb = stats_b.size(2);
+            float *mp = (float *)mean.data_ptr(), *ip = (float *)invstd.data_ptr();
+            float *rmp = (float *)running_mean.data_ptr(), *rvp = (float *)running_var.data_ptr();
+            check(doda_bn_fwd_final((const float *)stats.data_ptr(), (int)stats.size(0), (int)m, (int)ca, (float)eps,
+                                    (float)momentum, rmp, rvp, nbt.defined() ? (int64_t *)nbt.data_ptr() : nullptr, mp, ip,
+                                    stream_of(x)), "doda_bn_fwd_final");
+            check(doda_bn_fwd_final((const float *)stats_b.data_ptr(), (int)stats_b.size(0), (int)m, (int)cb, (float)eps,
+                                    (float)momentum, rmp + ca, rvp + ca, nullptr, mp + ca, ip + ca, stream_of(x)),
+                  "doda_bn_fwd_final");
+            check(doda_bn_relu_apply(x.data_ptr(), (int)m, (int)c, esz, mp, ip, (const float *)weight.data_ptr(),
+                                     (const float *)bias.data_ptr(), relu ? 1 : 0, y.data_ptr(), stream_of(x)),
+                  "doda_bn_relu_apply");
+        } else if (defer) {
             // reduction only: the consuming conv's prologue applies the BatchNorm and writes y (the caller checked
             // prologue_usable(): training, float statistics rows of a conv epilogue, m > BN_SMALL_ROWS)
             check(doda_bn_fwd_final((const float *)stats.data_ptr(), (int)stats.size(0), (int)m, (int)c, (float)eps,
@@ -868,18 +887,19 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
 
 at::Tensor bn_relu(const at::Tensor &x, const at::Tensor &weight, const at::Tensor &bias,
                    const at::Tensor &running_mean, const at::Tensor &running_var, const at::Tensor &nbt,
-                   bool training, double momentum, double eps, bool relu, const c10::optional<at::Tensor> &stats) {
+                   bool training, double momentum, double eps, bool relu, const c10::optional<at::Tensor> &stats,
+                   const c10::optional<at::Tensor> &stats_b) {
     return bn_relu_impl(x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, relu, false,
-                        stats.has_value() ? *stats : at::Tensor())[0];
+                        stats.has_value() ? *stats : at::Tensor(), nullptr, stats_b.has_value() ? *stats_b : at::Tensor())[0];
 }
 
 // (y, x_alias): use x_alias wherever the block needs x again (its gradient is summed inside this op's backward)
 std::vector<at::Tensor> bn_relu_pass(const at::Tensor &x, const at::Tensor &weight, const at::Tensor &bias,
                                      const at::Tensor &running_mean, const at::Tensor &running_var,
                                      const at::Tensor &nbt, bool training, double momentum, double eps, bool relu,
-                                     const c10::optional<at::Tensor> &stats) {
+                                     const c10::optional<at::Tensor> &stats, const c10::optional<at::Tensor> &stats_b) {
     return bn_relu_impl(x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, relu, true,
-                        stats.has_value() ? *stats : at::Tensor());
+                        stats.has_value() ? *stats : at::Tensor(), nullptr, stats_b.has_value() ? *stats_b : at::Tensor());
 }
 
 // Can the BatchNorm (x, statistics rows `stats` from the producing conv's epilogue) leave its apply pass to the SubM conv
@@ -918,7 +938,8 @@ std::vector<at::Tensor> residual_block(const at::Tensor &x, const c10::optional<
                                        const std::vector<c10::optional<at::Tensor>> &cv2,
                                        const std::vector<c10::optional<at::Tensor>> &rb, int64_t n_out,
                                        const c10::optional<at::Tensor> &skip, bool want_stats,
-                                       const std::vector<c10::optional<at::Tensor>> &sc = {}) {
+                                       const std::vector<c10::optional<at::Tensor>> &sc = {},
+                                       const c10::optional<at::Tensor> &stats_in_b = c10::nullopt) {
     TORCH_CHECK(bn1.size() == 5 && bn2.size() == 5 && cv1.size() == 3 && cv2.size() == 3 && rb.size() == 5 &&
                 cv1[0].has_value() && cv2[0].has_value() && rb[0].has_value(), "doda residual_block: bad argument lists");
     // sc = {weight [1,1,1,Cin,Cout], packed forward, packed data-grad, identity table, identity table as the pair lists or
@@ -931,9 +952,10 @@ std::vector<at::Tensor> residual_block(const at::Tensor &x, const c10::optional<
     const at::Tensor &tbl = *rb[0];
     const at::Tensor st1 = stats_in.has_value() ? *stats_in : at::Tensor();
     PreArgs p1, p2;
-    const bool f1 = prologue_usable(x, st1, bn1, training, *cv1[0], tbl, n_out);
+    const bool f1 = !(stats_in_b.has_value() && stats_in_b->defined()) && prologue_usable(x, st1, bn1, training, *cv1[0], tbl, n_out);
     auto a = bn_relu_impl(x, bn1[0], bn1[1], bn1[2], bn1[3], bn1[4], training, momentum1, eps1, true,
-                          (identity || conv_skip) && training, st1, f1 ? &p1 : nullptr);
+                          (identity || conv_skip) && training, st1, f1 ? &p1 : nullptr,
+                          stats_in_b.has_value() ? *stats_in_b : at::Tensor());
 
     auto z1 = indice_conv_impl(a[0], *cv1[0], tbl, tbl, n_out, 2, cv1[1], cv1[2], c10::nullopt, rb[1], rb[2], rb[3], rb[4],
                                want_stats, f1 ? &p1 : nullptr);
@@ -994,11 +1016,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("pair_seg") = py::none());
     m.def("bn_relu", &bn_relu, "fused BatchNorm1d(+ReLU) with autograd", py::arg("x"), py::arg("weight"),
           py::arg("bias"), py::arg("running_mean"), py::arg("running_var"), py::arg("nbt"), py::arg("training"),
-          py::arg("momentum"), py::arg("eps"), py::arg("relu"), py::arg("stats") = py::none());
+          py::arg("momentum"), py::arg("eps"), py::arg("relu"), py::arg("stats") = py::none(), py::arg("stats_b") = py::none());
     m.def("bn_relu_pass", &bn_relu_pass, "fused BatchNorm1d(+ReLU) returning (y, alias of x) for residual blocks",
           py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("running_mean"), py::arg("running_var"),
           py::arg("nbt"), py::arg("training"), py::arg("momentum"), py::arg("eps"), py::arg("relu"),
-          py::arg("stats") = py::none());
+          py::arg("stats") = py::none(), py::arg("stats_b") = py::none());
     m.def("indice_conv_stats", [](const at::Tensor &features, const at::Tensor &weight, const at::Tensor &fwd_tbl,
                                   const at::Tensor &bwd_tbl, int64_t n_out, int64_t bwd_layout,
                                   const c10::optional<at::Tensor> &pk_fwd, const c10::optional<at::Tensor> &pk_bwd,
@@ -1019,15 +1041,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                                const std::vector<c10::optional<at::Tensor>> &cv2,
                                const std::vector<c10::optional<at::Tensor>> &rb, int64_t n_out,
                                const c10::optional<at::Tensor> &skip, bool want_stats,
-                               const std::vector<c10::optional<at::Tensor>> &sc) {
+                               const std::vector<c10::optional<at::Tensor>> &sc, const c10::optional<at::Tensor> &stats_in_b) {
         auto r = residual_block(x, stats_in, bn1, bn2, training, momentum1, eps1, momentum2, eps2, cv1, cv2, rb, n_out, skip,
-                                want_stats, sc);
+                                want_stats, sc, stats_in_b);
         return std::make_pair(r[0], r[1].defined() ? c10::optional<at::Tensor>(r[1]) : c10::nullopt);
     }, "BatchNorm -> ReLU -> SubM conv -> BatchNorm -> ReLU -> SubM conv (+ skip) in one call",
           py::arg("x"), py::arg("stats_in"), py::arg("bn1"), py::arg("bn2"), py::arg("training"), py::arg("momentum1"),
           py::arg("eps1"), py::arg("momentum2"), py::arg("eps2"), py::arg("cv1"), py::arg("cv2"), py::arg("rb"),
           py::arg("n_out"), py::arg("skip"), py::arg("want_stats"),
-          py::arg("sc") = std::vector<c10::optional<at::Tensor>>());
+          py::arg("sc") = std::vector<c10::optional<at::Tensor>>(), py::arg("stats_in_b") = py::none());
     m.def("set_bn_fusion", [](bool on) { g_bn_fusion = on; }, "BatchNorm statistics in the conv epilogues (default on)");
     m.def("set_bn_prologue", [](bool on) { g_bn_prologue = on; },
           "BatchNorm apply(+ReLU) in the consuming conv's prologue inside residual_block (default off)");

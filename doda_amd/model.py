@@ -54,6 +54,8 @@ FAST_BLOCKS = _os.environ.get("DODA_FAST_BLOCKS", "1") == "1"
 # gradient, taken with its row stride, no copy — is summed inside the BatchNorm's backward kernel: 12 accumulation
 # kernels per step less.  DODA_SKIP_FUSION=0: off.
 SKIP_IN_BLOCK = SKIP_VIA_BN = _os.environ.get("DODA_SKIP_FUSION", "1") == "1"
+# The concatenation's BatchNorm takes the statistics rows of its two halves (conv epilogues) instead of sweeping the new tensor
+CAT_STATS = _os.environ.get("DODA_CAT_STATS", "1") == "1"
 
 
 def _subm3(cin, cout, key):
@@ -179,9 +181,12 @@ class ResidualBlock(SparseModule):
             rb = [data.tbl, None, None, None, None]
         st = input.__dict__.get("_doda_stats")
         stats_in = st[1] if (st is not None and st[0] is feats and st[2] == feats._version) else None
+        stats_in_b = None
+        if isinstance(stats_in, tuple):   # the input is a channel concatenation: statistics rows of its two halves
+            stats_in, stats_in_b = stats_in
         want_stats = training and Fsp.BN_FUSION and n_out > Fsp.STATS_MIN_ROWS
         y, stats = ext.residual_block(feats, stats_in, l1, l2, training, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps,
-                                      [w1, pk1[0], pk1[1]], [w2, pk2[0], pk2[1]], rb, n_out, skip, want_stats, sc)
+                                      [w1, pk1[0], pk1[1]], [w2, pk2[0], pk2[1]], rb, n_out, skip, want_stats, sc, stats_in_b)
         out = spconv.SparseConvTensor(y, data.outids, data.out_spatial_shape, input.batch_size)
         out.indice_dict = input.indice_dict
         out.grid = input.grid
@@ -236,14 +241,24 @@ class UBlock(nn.Module):
                 hook()
         out = self.blocks(input)
         if len(self.nPlanes) > 1:
+            st_a = out.__dict__.get("_doda_stats")
+            src = out.features                        # (what the level's statistics rows belong to)
             down = self._down_with_skip(out) if SKIP_VIA_BN else None
             if down is not None:
                 skip_feats, down = down
             else:
                 skip_feats = _shallow(out).features
-                down = self.conv(out)
+                down = self.conv(out)                 # (re-binds out.features)
             dec = self.deconv(self.u(down))
             out.features = torch.cat((skip_feats, dec.features), dim=1)
+            # BatchNorm statistics are per channel: the concatenation's are its halves' — the rows the two producing convs
+            # accumulated in their epilogues — so the first BatchNorm of blocks_tail needs no sweep over the new tensor
+            st_b = dec.__dict__.get("_doda_stats")
+            out.__dict__.pop("_doda_stats", None)
+            if (CAT_STATS and st_a is not None and st_b is not None and st_a[0] is src and st_a[2] == src._version
+                    and st_b[0] is dec.features and st_b[2] == dec.features._version
+                    and torch.is_tensor(st_a[1]) and torch.is_tensor(st_b[1])):
+                out._doda_stats = (out.features, (st_a[1], st_b[1]), out.features._version)
             out = self.blocks_tail(out)
         return out
 

@@ -93,11 +93,14 @@ def batch_norm_relu(features, bn, relu, passthrough=False, stats=None):
         running_mean, running_var = _running_stats(bn)   # DSNorm: the current domain's pair
     if _ext is not None:
         par = bn._parameters
+        stats_b = None
+        if isinstance(stats, tuple):   # features = channel concatenation [a | b]: the statistics rows of its two halves
+            stats, stats_b = stats
         if passthrough:
             return _ext.bn_relu_pass(features, par["weight"], par["bias"], running_mean, running_var,
-                                     bn._buffers["num_batches_tracked"], bn.training, bn.momentum, bn.eps, relu, stats)
+                                     bn._buffers["num_batches_tracked"], bn.training, bn.momentum, bn.eps, relu, stats, stats_b)
         return _ext.bn_relu(features, par["weight"], par["bias"], running_mean, running_var,
-                            bn._buffers["num_batches_tracked"], bn.training, bn.momentum, bn.eps, relu, stats)
+                            bn._buffers["num_batches_tracked"], bn.training, bn.momentum, bn.eps, relu, stats, stats_b)
     if passthrough:
         return _BNReLU.apply(features, bn.weight, bn.bias, running_mean, running_var,
                              bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, relu), features

@@ -448,6 +448,11 @@ int doda_bn_relu_bwd_add_ld(const void *x, const void *dy, int32_t m, int32_t c,
                             const float *save_mean, const float *save_invstd, const float *gamma,
                             const float *beta, int32_t relu, const void *add, int32_t add_ld, void *dx,
                             float *dgamma, float *dbeta, void *ws, size_t ws_bytes, doda_stream_t stream);
+/* ABI 6.  The apply half alone: y = relu?((x - mean) * invstd * gamma + beta) with given per-channel vectors (e.g. from two
+ * doda_bn_fwd_final calls over the two halves of a channel concatenation, whose statistics rows come from the two convs
+ * that produced the halves — reference model/unet_block.py:93 followed by :23). */
+int doda_bn_relu_apply(const void *x, int32_t m, int32_t c, int32_t elem_bytes, const float *mean, const float *invstd,
+                       const float *gamma, const float *beta, int32_t relu, void *y, doda_stream_t stream);
 /* ABI 6.  The reduction half of doda_bn_relu_fwd_stats alone (training mode): save_mean / save_invstd [c] from the
  * partial rows, running statistics and num_batches_tracked updated (any of the three may be NULL) — for a BatchNorm whose
  * apply pass rides in the consuming convolution's prologue (doda_conv_epilogue.pre_*). */

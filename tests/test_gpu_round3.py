@@ -820,3 +820,43 @@ def test_skip_connections_through_the_batchnorm_alias(native_lib):
             assert num / den < tol, (dt, num / den)
     finally:
         M.SKIP_VIA_BN = M.SKIP_IN_BLOCK = True
+
+
+def test_concatenation_batchnorm_from_the_halves_epilogue_statistics(native_lib):
+    """model.CAT_STATS: the BatchNorm that follows a U-Net level's torch.cat (reference model/unet_block.py:93 -> :23)
+    takes the statistics rows the two producing convs accumulated in their epilogues (statistics are per channel) instead
+    of sweeping the concatenated tensor.  Against the standalone sweep: same loss and running statistics up to the
+    summation order of the sums (fp32: 1e-5; bf16: the usual rounding noise), in the one-call and the module-by-module
+    block, which stay BIT-equal to each other."""
+    _ext_or_skip()
+    from doda_amd import model as M
+    from doda_amd.scene import make_batch
+    d = dev()
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in make_batch(2, 30000, 29).items()}
+    cfg = M.default_cfg()
+
+    def run(on, dt, fast=True, skip_in_block=True):
+        M.CAT_STATS = on
+        M.FAST_BLOCKS = fast
+        M.SKIP_IN_BLOCK = skip_in_block
+        torch.manual_seed(0)
+        net = M.SparseConvNet(cfg).to(d).train()
+        loss = M.cross_entropy(M.voxelize_and_run(cfg, net, bd, d, feature_dtype=dt), bd["labels"])
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), [p.grad.float().clone() for p in net.parameters()], [b.float().clone() for b in net.buffers()]
+    try:
+        for dt, tol_l, tol_g in ((torch.float32, 1e-5, 1e-4), (torch.bfloat16, 5e-3, 5e-2)):
+            a, b = run(True, dt), run(False, dt)
+            assert abs(float(a[0]) - float(b[0])) <= tol_l * abs(float(b[0]))
+            for p, q in zip(a[2], b[2]):
+                assert rel_err(p.cpu(), q.cpu()) < max(tol_l * 10, 1e-4)
+            num = sum(float(((p - q) ** 2).sum()) for p, q in zip(a[1], b[1])) ** 0.5
+            den = sum(float((q ** 2).sum()) for q in b[1]) ** 0.5
+            assert num / den < tol_g, (dt, num / den)
+        # (the module-by-module block sums its 1x1 skip's gradient by autograd: compare without that fusion)
+        a, b = run(True, torch.bfloat16, True, False), run(True, torch.bfloat16, False, False)
+        assert torch.equal(a[0], b[0]) and all(torch.equal(p, q) for p, q in zip(a[1], b[1]))
+        assert all(torch.equal(p, q) for p, q in zip(a[2], b[2]))
+    finally:
+        M.CAT_STATS = M.FAST_BLOCKS = M.SKIP_IN_BLOCK = True
