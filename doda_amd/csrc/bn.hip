@@ -1093,12 +1093,24 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_fused_bwd(const typename T::elem 
     }
 }
 
-inline bool fused_ok(int rows, int c) {
-    // OFF by default: measured in the U-Net step (same box, alternating runs) 7.7-7.8 ms against 6.45-6.54 ms — a
-    // 256-workgroup apply sweep is far below the HBM rate the 4096-block one reaches, and more workgroups multiply the
-    // redundant partial reads; DODA_BN_FUSED_FINAL=1 switches it on (kept for the parity tests and small tensors)
+constexpr long long BN_FUSED_SMALL_ELEMS = 2500000;   // m * c up to which the one-launch form is the default (levels 3-4: 35-46k x 48, 8-11k x 64)
+inline bool fused_ok(int rows, int c, int m) {
+    // For LARGE tensors off by default: measured in the U-Net step (same box, alternating runs) 7.7-7.8 ms against
+    // 6.45-6.54 ms — a 256-workgroup apply sweep is far below the HBM rate the 4096-block one reaches, and more workgroups
+    // multiply the redundant partial reads; DODA_BN_FUSED_FINAL=1 switches it on everywhere (parity tests).
+    // SMALL tensors (levels 3-4 of the U-Net; the levels below take the one-launch bn_small_*):
+    // both launches are launch-floor kernels (5 + 5 us) and the sweep is a few workgroups — one launch (round 3,
+    // DODA_BN_FUSED_SMALL=0 switches that off).
     static const bool on = getenv("DODA_BN_FUSED_FINAL") && getenv("DODA_BN_FUSED_FINAL")[0] == '1';
-    return on && c <= BN_FUSED_MAX_C && c / 4 <= BN_BLOCK && (long long)rows * 2 * c * 4 <= BN_FUSED_MAX_PARTIAL_BYTES;
+    // DODA_BN_FUSED_SMALL: 0 = off, 1 / unset = the default threshold, larger values = that many elements
+    static const long long small_elems = [] {
+        const char *e = getenv("DODA_BN_FUSED_SMALL");
+        if (!e) return BN_FUSED_SMALL_ELEMS;
+        const long long v = atoll(e);
+        return v == 1 ? BN_FUSED_SMALL_ELEMS : v;
+    }();
+    const bool want = on || (long long)m * c <= small_elems;
+    return want && c <= BN_FUSED_MAX_C && c / 4 <= BN_BLOCK && (long long)rows * 2 * c * 4 <= BN_FUSED_MAX_PARTIAL_BYTES;
 }
 
 Geo make_geo(int c) {
@@ -1277,7 +1289,7 @@ static int run_fwd_stats(const void *x_, int m, int c, const float *stats, int r
                          void *y_, float *mean, float *invstd, hipStream_t s) {
     typedef typename T::elem elem;
     const Geo g = make_geo(c);
-    if (fused_ok(rows, c)) {      // final + apply in one launch: few partial rows
+    if (fused_ok(rows, c, m)) {      // final + apply in one launch: few partial rows
         const long long nfr = (long long)m * g.nf;
         const int grid = (int)((nfr + BN_BLOCK - 1) / BN_BLOCK < BN_FUSED_BLOCKS ? (nfr + BN_BLOCK - 1) / BN_BLOCK : BN_FUSED_BLOCKS);
         hipLaunchKernelGGL((bn_fused_fwd<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, nfr, g.nf, g.rpb, stats, rows,
@@ -1306,7 +1318,7 @@ static int run_bwd_stats(const void *x_, const void *dy_, int m, int c, const fl
     typedef typename T::elem elem;
     const Geo g = make_geo(c);
     if (add_ld == c || !add_) add_ld = 0;   // dense
-    if (!add_ld && fused_ok(rows, c)) {      // final + apply in one launch: few partial rows (opt-in; dense `add` only)
+    if (!add_ld && fused_ok(rows, c, m)) {      // final + apply in one launch: few partial rows (opt-in; dense `add` only)
         const long long nfr = (long long)m * g.nf;
         const int grid = (int)((nfr + BN_BLOCK - 1) / BN_BLOCK < BN_FUSED_BLOCKS ? (nfr + BN_BLOCK - 1) / BN_BLOCK : BN_FUSED_BLOCKS);
         hipLaunchKernelGGL((bn_fused_bwd<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, (const elem *)dy_, nfr, g.nf,

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 var=$1; shift; pat="${*:-add copy Cat bn_bwd}"
 out=gpurun_out/envab_$var; rm -rf $out; mkdir -p $out
-for on in 1 0 1 0; do
+for on in ${ENVAB_VALUES:-1 0 1 0}; do
   env $var=$on timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $out/p$on -o k -- python bench.py --no-cpu-baseline --fp32-steps 0 --kernel-reps 5 --steps 60 > $out/bench_$on.json 2> $out/p$on.err
   cp $out/p$on/k_kernel_stats.csv $out/${on}_kernel_stats.csv 2>/dev/null
   python - <<PY
