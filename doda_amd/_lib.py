@@ -98,6 +98,7 @@ _SIGNATURES = {
     "doda_bn_relu_bwd_totals": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                         c_vp, c_vp, c_vp, c_vp]),
     "doda_spconv_set_stats_finish": (None, [c_i32]),
+    "doda_spconv_get_stats_finish": (c_i32, []),
     "doda_spconv_prologue_ok": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),
     "doda_bn_relu_bwd_stats_ld": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                           c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -60,6 +60,7 @@ def collate_device(items, device, batch_size=None, voxel_mode=4, full_scale=(128
         spatial_shape = np.array([full_scale[0]] * 3, dtype=np.int64)
     voxel_locs, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(locs, batch_size, voxel_mode)
     out = {"locs": locs, "voxel_locs": voxel_locs, "p2v_map": p2v_map, "v2p_map": v2p_map,
+           "v2p_map_t": v2p_map[:, 1:].t().contiguous(),   # gather-table form for the fused head's backward (doda_amd.model)
            "locs_float": locs_float, "feats": locs_float.clone(), "labels": labels,
            "offsets": torch.tensor(offsets, dtype=torch.int32), "spatial_shape": spatial_shape, "id": ids,
            "mix_idx": mix_idx, "tar_tail_splits": tar_tail_splits}

@@ -1107,6 +1107,7 @@ bool arm(EpiArgs &ep, int rows, unsigned n_wg, hipStream_t s) {
 }  // namespace doda_fin
 
 extern "C" void doda_spconv_set_stats_finish(int32_t on) { doda_fin::set_enabled(on != 0); }
+extern "C" int32_t doda_spconv_get_stats_finish(void) { return doda_fin::enabled() ? 1 : 0; }
 
 // ---- gather with epilogue options (residual add, BatchNorm statistics) ------------------------------
 extern "C" void doda_spconv_set_wlds_kernel(int32_t on) { doda_wlds::set_enabled(on != 0); }

@@ -122,7 +122,7 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
         ep.stats = (float *)stats.data_ptr();
         ep.stats_rows_h = &stats_rows;
         // the conv kernel's last workgroup sums the rows itself when it can (ABI 5): the BatchNorm then gets totals
-        if (nc <= 256) {
+        if (nc <= 256 && doda_spconv_get_stats_finish()) {   // (off by default: no allocation then — ~80 per step)
             totals = at::empty({1, 2, nc}, x.options().dtype(at::kDouble));
             ep.totals = (double *)totals.data_ptr();
             ep.finished_h = &finished;

@@ -372,7 +372,7 @@ class SparseConvNet(nn.Module):
                 mod.weight.data.fill_(1.0)
                 mod.bias.data.fill_(0.0)
 
-    def forward(self, input, input_map, return_mid_feat=False, v2p_map=None):
+    def forward(self, input, input_map, return_mid_feat=False, v2p_map=None, v2p_map_t=None):
         if input.features.is_cuda and input.indices.shape[0] > 0:
             # all 13 rulebooks up front (+ their pair lists when a bf16 backward pass will follow)
             spconv.ops.build_pyramid(input, len(self.unet.nPlanes), with_pairs=(
@@ -385,7 +385,8 @@ class SparseConvNet(nn.Module):
                  and input_map.dtype == torch.int32 and 0 < v2p_map.shape[1] - 1 <= 27
                  and feats.shape[1] % 4 == 0 and self.linear.out_features % 4 == 0)
         if fused:  # voxel->point gather + Linear as one gather-GEMM over the p2v table
-            v2p_t = v2p_map[:, 1:].t().contiguous()
+            v2p_t = v2p_map_t if (v2p_map_t is not None and v2p_map_t.shape == (v2p_map.shape[1] - 1, v2p_map.shape[0])
+                                  and v2p_map_t.is_contiguous()) else v2p_map[:, 1:].t().contiguous()
             return _PointLinear.apply(feats, self.linear.weight, self.linear.bias, input_map, v2p_t)
         point_feats = feats[input_map.long()]  # voxel -> point
         scores = self.linear(point_feats.to(self.linear.weight.dtype))
@@ -563,5 +564,6 @@ def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fus
         inp = spconv.SparseConvTensor(voxel_feats.to(feature_dtype), voxel_coords.int(),
                                       batch["spatial_shape"], batch_size)
     if fused_head:
-        return model(inp, p2v, v2p_map=v2p)
+        v2p_t = batch.get("v2p_map_t")
+        return model(inp, p2v, v2p_map=v2p, v2p_map_t=v2p_t.to(device, non_blocking=True) if v2p_t is not None else None)
     return model(inp, p2v)

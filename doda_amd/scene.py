@@ -130,7 +130,10 @@ def make_batch(n_scenes=4, target_voxels=150000, seed=1000, voxel_scale=50, full
     labels = torch.cat(labels, 0).long()
     spatial_shape = np.clip((locs.max(0)[0][1:] + 1).numpy(), full_scale[0], None)
     voxel_locs, p2v_map, v2p_map = ops.voxelize_idx_host(locs, n_scenes, voxel_mode)
+    # (v2p_map_t: the voxel -> point table transposed to the gather-table form [maxActive, M] the fused head's backward
+    # reads — a property of the batch, produced by the loader next to the maps themselves)
     return {"locs": locs, "voxel_locs": voxel_locs, "p2v_map": p2v_map, "v2p_map": v2p_map,
+            "v2p_map_t": v2p_map[:, 1:].t().contiguous(),
             "locs_float": locs_float, "feats": locs_float.clone(), "labels": labels,
             "offsets": torch.tensor(offsets, dtype=torch.int32), "spatial_shape": spatial_shape,
             "id": list(range(n_scenes))}

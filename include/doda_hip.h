@@ -271,6 +271,7 @@ int32_t doda_spconv_prologue_ok(int32_t kc, int32_t nc, int32_t K, int32_t elem_
 /* Switch: 1 = finish statistics in the conv kernels, 0 = never (finished_h always 0).  Default 0 (DODA_STATS_FINISH=1
  * turns it on): on MI355X the end-of-workgroup protocol costs more than the BatchNorm's own reduction launch. */
 void doda_spconv_set_stats_finish(int32_t on);
+int32_t doda_spconv_get_stats_finish(void);   /* ABI 6: the switch's state (a caller need not allocate `totals` when it is 0) */
 /* ABI 3.  Tile-local form of a SubM gather table ("tilebook") for the LDS-staged convolution kernel:
  * per tile of doda_tilebook_tile() consecutive output rows, the sorted list of DISTINCT input rows the
  * tile's K x tile table entries reference and, per entry, its position in that list.  The kernel loads
