@@ -156,6 +156,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<O
 //         loads and the barrier lengthens it: level-1 16 -> 16 27.3 -> 38.9 us without overflow tiles (the apply launch
 //         costs 11 us), 28.5 -> 49.7 us with the bench scene's six tiles without a list, whose gathered operands are
 //         normalised 12 x per row in a serial chain (a tail the whole grid waits for); 32 channels +56 us at 601k rows.
+//         (Later in the round the tiles without a list got their table slice staged in LDS and pipelined gathers: the
+//         prologue kernel 49.7 -> 40.6 us on the bench scene — break-even with 28.5 + 11 us for conv + apply launch.)
 //         Kept as an opt-in (DODA_BN_PROLOGUE=1) with its parity tests.
 template <int MODE, bool OUT32, bool STATS, bool PRE = false>
 __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, unsigned x_bytes,
@@ -290,9 +292,28 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                 if constexpr (PRE) rr[k] = pre_apply8(rr[k], pv, ep.pre_relu);
                 if (k * 256 + tid < PPR * CAP) reinterpret_cast<u32x4 *>(rows_s)[PPR + k * 256 + tid] = rr[k];
             }
-        } else if (tt + L < cnt) {
-            load_list(tile + L, tid, rid);
-            U = tb.ucount[tile + L];
+        } else {
+            // A tile WITHOUT a list (more distinct neighbour rows than the kernel stages: 6 of the bench scene's 2349).  It
+            // used to walk the dense table with two dependent round trips per pair of units (table entries -> rows): 14 in
+            // series, a tail the whole grid waited for (+1.2 us on the level-1 layer; with the BatchNorm prologue +10 us).
+            // Now its 27 x 256 table entries are fetched ONCE, coalesced (thread = row, 27 loads in flight), into the LDS
+            // the rows would have used, and the unit loop gathers rows two units ahead from indices it reads from LDS.
+            static_assert((CAP + 1) * RB >= TB_K * TB_T * 4, "the table slice fits the row buffer");
+            int te[TB_K];
+            unsigned ldv = (unsigned)ld;
+            asm volatile("" : "+s"(ldv));   // (laundered: otherwise its 27 multiples are hoisted out of the tile loop)
+#pragma unroll
+            for (int o = 0; o < TB_K; ++o) {
+                const unsigned voff = (unsigned)(t0 + tid) < (unsigned)n_out ? ((unsigned)o * ldv + (unsigned)(t0 + tid)) * 4u : OOB;
+                te[o] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_t, voff, 0, 0);
+            }
+            if (tt + L < cnt) {
+                load_list(tile + L, tid, rid);
+                U = tb.ucount[tile + L];
+            }
+            int *tab_s = reinterpret_cast<int *>(rows_s);
+#pragma unroll
+            for (int o = 0; o < TB_K; ++o) tab_s[o * TB_T + tid] = (unsigned)(t0 + tid) < (unsigned)n_out ? te[o] : -1;
         }
         if constexpr (PRE) {
             if (!staged && ep.pre_out) {   // a tile without a list: its own rows, normalised, straight to pre_out
@@ -371,47 +392,40 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
-                // overflow tile: same units, operands gathered from global memory through the dense table; the
-                // table entries of two units, then their rows (straight-line code, counted waits).  (ld
-                // laundered: otherwise its 27 multiples are hoisted out of the tile loop.)
-                unsigned ldv = (unsigned)ld;
-                asm volatile("" : "+s"(ldv));
+                // tile without a list: same units; the table slice sits in LDS (phase A), indices two units ahead, rows one
+                // unit ahead of the MFMAs (absent neighbour / row past n_out: -1 -> out-of-range load -> zeros)
+                const int *tab_s = reinterpret_cast<const int *>(rows_s) + wid * 64 + i;
                 PreVec pvh;   // PRE: the vectors of the operand piece this lane gathers (piece `half`, not the staging piece)
                 if constexpr (PRE) pre_vec(pvh, half / 2u);
+                auto ldi = [&](int u, int (&d)[S]) {
+                    const int osel = WIDE ? u : 2 * u + (g >> 1);
 #pragma unroll
-                for (int u0 = 0; u0 < NU; u0 += 2) {
-                    unsigned go[2][S];
+                    for (int s = 0; s < S; ++s) d[s] = osel < TB_K ? tab_s[osel * TB_T + s * 16] : -1;
+                };
+                auto ldx = [&](const int (&d)[S], u32x4 (&xr)[S]) {
 #pragma unroll
-                    for (int du = 0; du < 2; ++du) {
-                        const int osel = WIDE ? u0 + du : 2 * (u0 + du) + (g >> 1);
+                    for (int s = 0; s < S; ++s)
+                        xr[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, d[s] >= 0 ? (unsigned)d[s] * (unsigned)RB + half : OOB, 0, 0);
+                };
+                int ix[3][S];
+                u32x4 xo[2][S];
+                ldi(0, ix[0]);
+                ldi(1, ix[1]);
+                ldx(ix[0], xo[0]);
 #pragma unroll
-                        for (int s = 0; s < S; ++s) {
-                            const int t = row0 + s * 16 + i;
-                            const unsigned voff = (osel < TB_K && t < n_out) ? ((unsigned)osel * ldv + (unsigned)t) * 4u : OOB;
-                            go[du][s] = __builtin_amdgcn_raw_buffer_load_b32(rs_t, voff, 0, 0);
+                for (int u = 0; u < NU; ++u) {
+                    if (u + 2 < NU) ldi(u + 2, ix[(u + 2) % 3]);
+                    if (u + 1 < NU) ldx(ix[(u + 1) % 3], xo[(u + 1) & 1]);
+                    const u32x4 wu = loadw(u);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        u32x4 xv = xo[u & 1][s];
+                        if constexpr (PRE) {   // an absent neighbour stays zero
+                            const u32x4 z = pre_apply8(xv, pvh, ep.pre_relu);
+                            xv = ix[u % 3][s] >= 0 ? z : (u32x4){0u, 0u, 0u, 0u};
                         }
-                    }
-#pragma unroll
-                    for (int du = 0; du < 2; ++du) {
-                        const int osel = WIDE ? u0 + du : 2 * (u0 + du) + (g >> 1);
-                        if (u0 + du >= NU) break;
-                        u32x4 xa[S];
-#pragma unroll
-                        for (int s = 0; s < S; ++s) {
-                            const int t = row0 + s * 16 + i;
-                            const bool present = osel < TB_K && t < n_out && (int)go[du][s] >= 0;   // out-of-range table reads return 0
-                            xa[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, present ? go[du][s] * (unsigned)RB + half : OOB, 0, 0);
-                            if constexpr (PRE) {   // an absent neighbour stays zero
-                                const u32x4 z = pre_apply8(xa[s], pvh, ep.pre_relu);
-                                xa[s] = present ? z : (u32x4){0u, 0u, 0u, 0u};
-                            }
-                        }
-                        const u32x4 wu = loadw(u0 + du);
-#pragma unroll
-                        for (int s = 0; s < S; ++s) {
-                            if constexpr (MODE == 2) mma_f32_k16(acc[s][0], wu, xa[s]);
-                            else mma_bf16_k32(acc[s][0], wu, xa[s]);
-                        }
+                        if constexpr (MODE == 2) mma_f32_k16(acc[s][0], wu, xv);
+                        else mma_bf16_k32(acc[s][0], wu, xv);
                     }
                 }
             }
