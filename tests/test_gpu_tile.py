@@ -46,10 +46,25 @@ def _scene_table(m, seed=0, batch=2, shape=(80, 70, 60)):
     return idx, ops.rulebook_subm(idx, list(shape), batch, 3)
 
 
-@pytest.mark.parametrize("m", [40000, 1000, 256, 255])
+def _far_apart_table(n=300000):
+    """Every tile references two clusters of rows ~200k rows apart (span above the builder's 131072-bit bitmap: the hash +
+    sort form), ~570 distinct rows per tile; some entries absent."""
+    t = torch.arange(n, dtype=torch.int64)
+    tbl = torch.empty(27, n, dtype=torch.int64)
+    for o in range(27):
+        tbl[o] = (t + o) % n if o < 13 else (t + 200000 + o) % n
+    g = torch.Generator().manual_seed(3)
+    tbl[torch.rand(27, n, generator=g) < 0.3] = -1
+    tbl[13] = t   # the centre tap is always present
+    return tbl.int().to(dev())
+
+
+@pytest.mark.parametrize("m", [40000, 1000, 256, 255, -1])
 def test_tilebook_is_a_lossless_encoding(native_lib, m):
+    """m > 0: scene tables (rows of a tile within a few thousand row numbers: the builder's bitmap form); m = -1: a table
+    whose tiles reference two far-apart clusters (the hash + bitonic-sort form).  Same format, same checks."""
     ext = _ext_or_skip()
-    _, tbl = _scene_table(m, seed=m)
+    tbl = _far_apart_table() if m < 0 else _scene_table(m, seed=m)[1]
     n = tbl.shape[1]
     t = ext.with_tilebook(tbl)
     assert ext.has_tilebook(t) and torch.equal(t, tbl)
