@@ -431,6 +431,26 @@ __device__ __forceinline__ f32x4 block_sum4(f32x4 v, float (*lds)[4]) {  // 256 
     return t;
 }
 
+// both sums through ONE LDS exchange (the small kernels are launch-floor kernels: every barrier pair counts)
+__device__ __forceinline__ void block_sum4x2(f32x4 &a, f32x4 &b, float (*lds)[8]) {  // 256 threads, fixed order
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] += __shfl_xor(a[q], d, 64); b[q] += __shfl_xor(b[q], d, 64); }
+    }
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lds[wid][q] = a[q]; lds[wid][4 + q] = b[q]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        a[q] = (lds[0][q] + lds[1][q]) + (lds[2][q] + lds[3][q]);
+        b[q] = (lds[0][4 + q] + lds[1][4 + q]) + (lds[2][4 + q] + lds[3][4 + q]);
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(BN_BLOCK) void bn_small_fwd(const typename T::elem *__restrict__ x, int m,
                                                          int c, float eps, float momentum,
@@ -442,7 +462,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_fwd(const typename T::elem 
                                                          typename T::elem *__restrict__ y,
                                                          float *__restrict__ mean,
                                                          float *__restrict__ invstd) {
-    __shared__ float lds[4][4];
+    __shared__ float lds[4][8];
     const int f = blockIdx.x;
     // Every global read of the kernel is issued up front and independently (rows past m re-read row
     // m-1 and are masked): a dependent round trip to L2/HBM costs 2-3 us here and the old form had
@@ -474,8 +494,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_fwd(const typename T::elem 
         s1 += v * w;
         s2 += v * v * w;
     }
-    s1 = block_sum4(s1, lds);
-    s2 = block_sum4(s2, lds);
+    block_sum4x2(s1, s2, lds);
     f32x4 mu, is;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -522,7 +541,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd(const typename T::elem 
                                                          float *__restrict__ dgamma,
                                                          float *__restrict__ dbeta,
                                                          const typename T::elem *__restrict__ add, int add_ld = 0) {
-    __shared__ float lds[4][4];
+    __shared__ float lds[4][8];
     const int f = blockIdx.x;
     const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + f * 4);
     const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + f * 4);
@@ -551,8 +570,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd(const typename T::elem 
         s1 += dz[i] * w;
         s2 += dz[i] * xh[i] * w;
     }
-    s1 = block_sum4(s1, lds);
-    s2 = block_sum4(s2, lds);
+    block_sum4x2(s1, s2, lds);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { dbeta[f * 4 + q] = s1[q]; dgamma[f * 4 + q] = s2[q]; }
