@@ -1095,7 +1095,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               char *p = (char *)const_cast<void *>(tb) + nt * UMAX * 4 + nt * K * T * 2 + nt * 4;
               at::Tensor over = at::from_blob(p, {2}, tbl.options()).cpu();
               return std::make_tuple(nt, (int64_t)over[0].item<int32_t>(), (int64_t)over[1].item<int32_t>());
-          });
+          }, py::call_guard<py::gil_scoped_release>());   // (called on the rulebook thread: its read-back must not hold the GIL)
     m.def("set_tile_kernel", [](bool on) { doda_spconv_set_tile_kernel(on ? 1 : 0); });
     m.def("pending_wgrads", []() { std::lock_guard<std::mutex> lock(g_wq_mu); return (int64_t)g_wq.size(); });
     m.def("set_defer_wgrad", [](bool on) { g_defer_wgrad = on; },
