@@ -1066,6 +1066,27 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("indices"), py::arg("shape"), py::arg("batch"), py::arg("n_levels"), py::arg("pairs_min_rows") = -1,
           py::arg("tile_min_rows") = -1, py::arg("tile_levels") = 2,
           py::call_guard<py::gil_scoped_release>());   // its size read-backs block: let other Python threads run
+    m.def("build_pyramid_probe", [](const at::Tensor &indices, std::vector<int64_t> shape, int64_t batch, int64_t n_levels,
+                                    int64_t pairs_min_rows, int64_t tile_min_rows, int64_t tile_levels) {
+              // build_pyramid + the finest tilebook's overflow counters (tiles, above the 64-byte capacity, above the list)
+              // in ONE call without the GIL: the rulebook thread's read-back does not stall the issuing thread
+              auto levels = build_pyramid(indices, shape, batch, n_levels, pairs_min_rows, tile_min_rows, tile_levels);
+              int64_t nt = -1, o64 = 0, o32 = 0;
+              if (!levels.empty()) {
+                  const at::Tensor &tbl = std::get<0>(levels[0]);
+                  const void *tb = tilebook_behind(tbl, tbl.dim() == 2 ? tbl.size(1) : 0);
+                  if (tb) {
+                      const int64_t T = doda_tilebook_tile(), K = tbl.size(0), UMAX = doda_tilebook_umax();
+                      nt = (tbl.size(1) + T - 1) / T;
+                      char *p = (char *)const_cast<void *>(tb) + nt * UMAX * 4 + nt * K * T * 2 + nt * 4;
+                      at::Tensor over = at::from_blob(p, {2}, tbl.options()).cpu();
+                      o64 = over[0].item<int32_t>();
+                      o32 = over[1].item<int32_t>();
+                  }
+              }
+              return std::make_tuple(levels, nt, o64, o32);
+          }, py::arg("indices"), py::arg("shape"), py::arg("batch"), py::arg("n_levels"), py::arg("pairs_min_rows") = -1,
+          py::arg("tile_min_rows") = -1, py::arg("tile_levels") = 2, py::call_guard<py::gil_scoped_release>());
     m.def("with_tilebook", [](const at::Tensor &tbl) {
               TORCH_CHECK(tbl.is_cuda() && tbl.scalar_type() == at::kInt && tbl.dim() == 2, "doda with_tilebook: int32 [K, M] table");
               at::Tensor out = table_with_tilebook(tbl.size(0), tbl.size(1), tbl.options());

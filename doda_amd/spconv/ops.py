@@ -96,12 +96,11 @@ def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", firs
         if tiles_on and _tile_state["skip"] > 0:
             _tile_state["skip"] -= 1
             tiles_on = False
-        levels = _ext.build_pyramid(indices, [int(v) for v in shape], int(tensor.batch_size), int(n_levels),
-                                    PAIRS_MIN_ROWS if with_pairs else -1,
-                                    TILE_MIN_ROWS if tiles_on else -1, n_tile_levels)
-        if tiles_on and _ext.has_tilebook(levels[0][0]):
-            # the builds are complete (the pyramid's size read-backs came after them on this stream): 8 bytes back
-            nt, over64, over32 = _ext.tilebook_overflow(levels[0][0])
+        # (one call without the GIL: the builds, their six size read-backs and the tilebook's overflow counters)
+        levels, nt, over64, over32 = _ext.build_pyramid_probe(indices, [int(v) for v in shape], int(tensor.batch_size),
+                                                              int(n_levels), PAIRS_MIN_ROWS if with_pairs else -1,
+                                                              TILE_MIN_ROWS if tiles_on else -1, n_tile_levels)
+        if tiles_on and nt >= 0:
             _tile_state["last"] = (nt, over64, over32)
             if over32 > TILE_OVERFLOW_MAX * nt:
                 _tile_state["skip"] = TILE_BACKOFF

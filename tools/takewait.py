@@ -23,6 +23,7 @@ wp, wt = True, tile_levels_for(torch.bfloat16)
 pf = PyramidPrefetcher(d, 7)
 pend = [pf.submit(bd, wp, wt, resident=True, now=True)]
 acc = [0.0, 0.0, 0.0, 0.0]
+iv = []
 
 
 def step(rec):
@@ -39,6 +40,7 @@ def step(rec):
     opt.step()
     f = time.perf_counter()
     if rec:
+        iv.append(((f - a) * 1e3, (b - a) * 1e3, (c - b) * 1e3, (e - c) * 1e3, (f - e) * 1e3, len(iv)))
         acc[0] += b - a; acc[1] += c - b; acc[2] += e - c; acc[3] += f - e
 
 
@@ -49,4 +51,10 @@ torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / steps * 1e3
 print("switch interval %.4f s: wall %.2f ms/step | wait for the pyramid %.3f ms, take + submit %.3f ms, forward issue %.2f ms, backward + optimizer issue %.2f ms"
       % (sys.getswitchinterval(), wall, acc[0] / steps * 1e3, acc[1] / steps * 1e3, acc[2] / steps * 1e3, acc[3] / steps * 1e3))
+import gc
+print("gc counts", gc.get_count(), "collections per generation", [g["collections"] for g in gc.get_stats()])
+iv.sort()
+print("per-step issue interval ms: min %.2f  p10 %.2f  median %.2f  p90 %.2f  max %.2f" % (iv[0][0], iv[len(iv) // 10][0], iv[len(iv) // 2][0], iv[9 * len(iv) // 10][0], iv[-1][0]))
+for r in iv[-8:]:
+    print("   slow step %3d: total %.2f = wait %.2f + take %.2f + forward %.2f + backward/opt %.2f" % (r[5], r[0], r[1], r[2], r[3], r[4]))
 pend[0].result(); pf.shutdown()
