@@ -108,6 +108,9 @@ _SIGNATURES = {
     "doda_bn_fwd_final": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "doda_bn_set_chain": (None, [c_i32]),
     "doda_bn_chain_errors": (C.c_int64, []),
+    "doda_cast_colsum_blocks": (c_i32, [C.c_int64, c_i32]),
+    "doda_cast_colsum_f32_bf16": (c_i32, [c_vp, C.c_int64, c_i32, c_vp, c_vp, c_i32, c_vp]),
+    "doda_pad_channels": (c_i32, [c_vp, C.c_int64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "doda_sgd_multi_desc_bytes": (c_sz, [c_i32]),
     "doda_sgd_multi": (c_i32, [c_vp, c_i32, C.c_double, C.c_double, C.c_double, C.c_double, c_i32, c_i32, c_vp,
                                c_sz, c_vp]),

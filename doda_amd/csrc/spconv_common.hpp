@@ -69,6 +69,7 @@ struct EpiArgs {   // plain data, shared across translation units
     const float *pre_mean, *pre_invstd, *pre_gamma, *pre_beta;   // [kc] each
     int pre_relu;
     void *pre_out;           // [n_in, kc] normalised rows (bf16) or null
+    int res_bcast;           // ABI 6: `res` is ONE row [nc] added to every output row (a bias): conv_fast only
 };
 
 constexpr unsigned FIN_GROUP = 32;         // workgroups per first-level ticket

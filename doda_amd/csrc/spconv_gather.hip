@@ -696,12 +696,14 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
             const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * (unsigned)nc + col) * OSZ : OOB;
             if (res) {   // y = conv + res (residual add of the block fused into the store; res has y's dtype)
                 const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, y_bytes, 0x00020000);
+                // (res_bcast: one row for every output row — the Linear head's bias, reference model/unet.py:64)
+                const unsigned voff_r = ep.res_bcast ? (voff != OOB ? col * OSZ : OOB) : voff;
                 if (OUT32 || sizeof(elem) == 4) {
-                    const f32x4 r4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, voff, 0, 0));
+                    const f32x4 r4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, voff_r, 0, 0));
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[s][nb][q] += r4[q];
                 } else {
-                    const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rs_r, voff, 0, 0);
+                    const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rs_r, voff_r, 0, 0);
                     acc[s][nb][0] += __uint_as_float(r2[0] << 16);
                     acc[s][nb][1] += __uint_as_float(r2[0] & 0xffff0000u);
                     acc[s][nb][2] += __uint_as_float(r2[1] << 16);
@@ -880,8 +882,9 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
             hipLaunchKernelGGL((pack_weights<T>), dim3(div_up(total, 256)), dim3(256), 0, s, w, K, kc,
                                nc, n_chunk, NB, wl & 3, (frag *)ws);
     }
+    if (ep.res_bcast && !fast) return DODA_ERR_UNSUPPORTED;   // (the broadcast residual lives in conv_fast's epilogue)
     // A tilebook of this table and rows of 32 / 64 bytes: the LDS-staged tile kernel (spconv_tile.hip)
-    {
+    if (!ep.res_bcast) {
         const int tmode = pair ? 0 : (wide && kc == 32) ? 1 : (fast && sizeof(elem) == 4 && kc == 16) ? 2 : -1;
         if (tmode >= 0 && tilebook && K == TB_K && tilebook_rows == n_out && doda_tile::enabled()) {
             const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
@@ -895,7 +898,7 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     }
     if (ep.pre_mean) return DODA_ERR_UNSUPPORTED;   // BatchNorm prologue: tile kernels only (doda_spconv_prologue_ok)
     // 48 -> 48 channels on a mid-size level: the layer's fragments in LDS, one workgroup per CU (spconv_wlds.hip)
-    if (wide && kc == 48 && nc == 48 && K == 27 && !out32 && n_out >= 8192 && n_out <= 262144 && doda_wlds::enabled()) {
+    if (!ep.res_bcast && wide && kc == 48 && nc == 48 && K == 27 && !out32 && n_out >= 8192 && n_out <= 262144 && doda_wlds::enabled()) {
         const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
         const unsigned yb = (unsigned)((size_t)n_out * nc * sizeof(elem));
         return doda_wlds::launch_conv48(x_, xb, wp, tbl, (unsigned)((size_t)K * ld * 4), ld, n_out, y_, yb, res, ep, n_part, s);
@@ -1138,6 +1141,7 @@ extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, in
     doda_fin::last_finished = 0;
     if (epi) {
         res = epi->residual;
+        ep.res_bcast = (res && epi->residual_bcast) ? 1 : 0;
         if (epi->stats) {
             if (!epi->stats_rows_h) return DODA_ERR_INVALID;
             ep.stats = epi->stats;

@@ -297,9 +297,21 @@ class _PointLinear(Function):
     @staticmethod
     def forward(ctx, feats, weight, bias, p2v, v2p_t):
         n = p2v.shape[0]
-        scores = _ops.spconv_gather(feats.contiguous(), weight.view(1, *weight.shape), p2v.view(1, n),
-                                    n, 1, weight.shape[0], out_f32=True)
-        if bias is not None:
+        fused_bias = (bias is not None and bias.dtype == torch.float32 and bias.is_cuda and feats.shape[1] % 4 == 0
+                      and weight.shape[0] % 4 == 0)
+        # (the bias rides in the gather kernel's store as a broadcast residual row: no separate pass over the scores)
+        scores = None
+        if fused_bias:
+            try:
+                scores = _ops.spconv_gather(feats.contiguous(), weight.view(1, *weight.shape), p2v.view(1, n), n, 1,
+                                            weight.shape[0], out_f32=True, residual=bias.detach().contiguous(),
+                                            residual_bcast=True)
+            except _ops.DodaNativeError:   # (a shape the dense-table fast kernel does not take)
+                fused_bias = False
+        if scores is None:
+            scores = _ops.spconv_gather(feats.contiguous(), weight.view(1, *weight.shape), p2v.view(1, n),
+                                        n, 1, weight.shape[0], out_f32=True)
+        if bias is not None and not fused_bias:
             scores += bias
         ctx.save_for_backward(feats, weight, p2v, v2p_t)
         ctx.has_bias = bias is not None
@@ -309,15 +321,22 @@ class _PointLinear(Function):
     def backward(ctx, d_scores):
         feats, weight, p2v, v2p_t = ctx.saved_tensors
         n = p2v.shape[0]
-        dy = d_scores.contiguous().to(feats.dtype)
         d_feats = d_w = d_b = None
+        if (d_scores.is_cuda and d_scores.dtype == torch.float32 and feats.dtype == torch.bfloat16 and d_scores.dim() == 2
+                and d_scores.shape[1] <= 64 and d_scores.shape[0] > 0):
+            # bf16 operand of the two gather-GEMMs below and the column sums (d_bias) in ONE pass over the fp32 gradient
+            dy, colsum = _ops.cast_colsum(d_scores.contiguous())
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                d_b = colsum
+        else:
+            dy = d_scores.contiguous().to(feats.dtype)
         if ctx.needs_input_grad[0]:
             k = v2p_t.shape[0]
             w_rep = weight.unsqueeze(0).expand(k, *weight.shape).contiguous()
             d_feats = _ops.spconv_gather(dy, w_rep, v2p_t, feats.shape[0], 0, weight.shape[1])
         if ctx.needs_input_grad[1]:
             d_w = _ops.spconv_wgrad(feats.contiguous(), dy, p2v.view(1, n), n)[0].t().to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and d_b is None:
             d_b = d_scores.sum(0)
         return d_feats, d_w, d_b, None, None
 

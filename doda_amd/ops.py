@@ -272,7 +272,7 @@ class _ConvEpilogue(C.Structure):   # doda_conv_epilogue (include/doda_hip.h, AB
                 ("bn_beta", C.c_void_p), ("bn_relu", C.c_int32), ("tilebook_rows", C.c_int32),
                 ("tilebook", C.c_void_p), ("totals", C.c_void_p), ("finished_h", C.POINTER(C.c_int32)),
                 ("pre_mean", C.c_void_p), ("pre_invstd", C.c_void_p), ("pre_gamma", C.c_void_p), ("pre_beta", C.c_void_p),
-                ("pre_relu", C.c_int32), ("reserved6", C.c_int32), ("pre_out", C.c_void_p)]
+                ("pre_relu", C.c_int32), ("residual_bcast", C.c_int32), ("pre_out", C.c_void_p)]
 
 
 def tilebook_build(tbl, n_rows=None):
@@ -317,7 +317,7 @@ def spconv_bwd_tile(dy, x, w, tbl, tilebook, packed=None, dw_out=None):
 
 
 def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, residual=None, tilebook=None,
-                  want_stats=False, bn=None, out=None, want_totals=False, pre=None):
+                  want_stats=False, bn=None, out=None, want_totals=False, pre=None, residual_bcast=False):
     """y[t] = sum_o x[tbl[o][t]] @ B_o (see doda_hip.h).  x: [n_in,kc] f32|bf16; w: fp32 weights
     viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2), or `packed`: the fragment-packed buffer
     produced by PackPlan for this (weight, layout, dtype).  Returns y [n_out, nc] in x.dtype (or
@@ -350,12 +350,14 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
     ydt = torch.float32 if (x.dtype == torch.float32 or out_f32) else torch.bfloat16
     if residual is not None:
         _need_cuda(residual)
-        if residual.dtype != ydt or tuple(residual.shape) != (n_out, nc) or not residual.is_contiguous():
-            raise RuntimeError("residual must be a contiguous [n_out, nc] tensor in the output dtype")
-    if tilebook is not None or want_stats or out is not None or pre is not None:   # epilogue-struct entry point
+        want = (nc,) if residual_bcast else (n_out, nc)
+        if residual.dtype != ydt or tuple(residual.shape) != want or not residual.is_contiguous():
+            raise RuntimeError("residual must be a contiguous [n_out, nc] tensor (or [nc] with residual_bcast) in the output dtype")
+    if tilebook is not None or want_stats or out is not None or pre is not None or residual_bcast:   # epilogue-struct entry point
         y = out if out is not None else torch.empty((n_out, nc), dtype=ydt, device=x.device)
         ep = _ConvEpilogue()
         ep.residual = _p(residual) if residual is not None else None
+        ep.residual_bcast = int(bool(residual_bcast and residual is not None))
         if tilebook is not None:
             ep.tilebook = _p(tilebook)
             ep.tilebook_rows = int(getattr(tilebook, "_doda_rows", n_out))
@@ -739,6 +741,28 @@ def bn_relu_bwd_totals(x, dy, totals, save_mean, save_invstd, gamma, beta, relu,
                                         _p(beta), int(bool(relu)), _p(add) if add is not None else None, _p(dx),
                                         _p(dgamma), _p(dbeta), _stream()), "doda_bn_relu_bwd_totals")
     return dx, dgamma, dbeta
+
+
+def cast_colsum(x):
+    """(x.bfloat16(), x.sum(0)) of a device fp32 [n, c <= 64] matrix in one pass (doda_cast_colsum_f32_bf16)."""
+    _feat_ok(x, "x")
+    n, c = x.shape
+    y = torch.empty((n, c), dtype=torch.bfloat16, device=x.device)
+    nb = int(lib().doda_cast_colsum_blocks(n, c))
+    if x.dtype != torch.float32 or nb == 0:
+        raise RuntimeError("cast_colsum: fp32 [n, c <= 64]")
+    partial = torch.empty((nb, c), dtype=torch.float32, device=x.device)
+    check(lib().doda_cast_colsum_f32_bf16(_p(x), n, c, _p(y), _p(partial), nb, _stream()), "doda_cast_colsum_f32_bf16")
+    return y, partial.sum(0)
+
+
+def pad_channels(x, c_out):
+    """x [n, c_in] (fp32 / bf16, contiguous) zero-padded to c_out channels in one kernel (doda_pad_channels)."""
+    _feat_ok(x, "x")
+    n, c_in = x.shape
+    y = torch.empty((n, c_out), dtype=x.dtype, device=x.device)
+    check(lib().doda_pad_channels(_p(x), n, c_in, c_out, _esz(x), _p(y), _stream()), "doda_pad_channels")
+    return y
 
 
 # ------------------------------------------------------------------------------------------

@@ -290,7 +290,10 @@ class SparseConvolution(SparseModule):
                 # rulebook's tilebook (forward 69 -> 34 us, weight gradient 85 -> ~31 us at 600k voxels) instead of the
                 # 8-byte-row generic paths, for one extra 19 MB tensor
                 extra = 16 - self.in_channels
-            features = nn.functional.pad(features, (0, extra))
+            if features.is_cuda and not features.requires_grad and features.is_contiguous() and features.shape[0] > 0:
+                features = _nops.pad_channels(features, self.in_channels + extra)   # one kernel (torch: fill + strided copy)
+            else:
+                features = nn.functional.pad(features, (0, extra))
             weight = nn.functional.pad(self.weight, (0, 0, 0, extra))
         else:
             packed = self._packed(features, input.indice_dict)

@@ -261,7 +261,8 @@ typedef struct doda_conv_epilogue {
      * float [kc] each.  Supported where doda_spconv_prologue_ok() says so; otherwise DODA_ERR_UNSUPPORTED. */
     const float *pre_mean, *pre_invstd, *pre_gamma, *pre_beta;
     int32_t pre_relu;
-    int32_t reserved6;
+    int32_t residual_bcast;   /* ABI 6: `residual` is ONE row [nc] (dtype of y) added to every output row — a bias (the Linear
+                               * head of reference model/unet.py:64 as a gather-GEMM); dense-table kernels only */
     void *pre_out;
 } doda_conv_epilogue;
 /* ABI 6.  1 when doda_spconv_gather_ex takes a BatchNorm prologue for this call shape (bf16 SubM K = 27 layers of 16 or
@@ -533,6 +534,19 @@ int doda_cross_entropy_fwd(const float *logits, const int64_t *labels, int32_t n
 int doda_cross_entropy_bwd(const float *logits, const int64_t *labels, const float *lse, const float *out,
                            const float *grad, int32_t n, int32_t c, int64_t ignore_index, float *dlogits,
                            doda_stream_t stream);
+
+/* ABI 6.  Glue of the head and the input layer (csrc/glue.hip).
+ * doda_cast_colsum_f32_bf16: y = bf16(x) (round to nearest even, as torch's cast) and partial[b][c] = sum of the rows
+ *   workgroup b swept — the Linear head's backward (reference model/unet.py:64) needs the score gradient as a bf16 GEMM
+ *   operand AND summed over the points (d_bias): one pass instead of a cast and a reduce kernel.  c <= 64; `partial`:
+ *   float [doda_cast_colsum_blocks(n, c)][c]; the caller adds the rows (fixed order: deterministic).
+ * doda_pad_channels: y[r, :c_in] = x[r, :], y[r, c_in:c_out] = 0 (the xyz input layer's rows padded to 4 / 16 channels,
+ *   spconv/conv.py): torch's constant_pad_nd = a fill + a strided copy. */
+int32_t doda_cast_colsum_blocks(int64_t n, int32_t c);
+int doda_cast_colsum_f32_bf16(const float *x, int64_t n, int32_t c, uint16_t *y, float *partial, int32_t n_blocks,
+                              doda_stream_t stream);
+int doda_pad_channels(const void *x, int64_t n, int32_t c_in, int32_t c_out, int32_t elem_bytes, void *y,
+                      doda_stream_t stream);
 
 /* ---- optimizer step -------------------------------------------------------------------------------
  * SGD over all parameter tensors of a network in one launch (replaces the five multi-tensor launches of

@@ -866,3 +866,48 @@ def test_concatenation_batchnorm_from_the_halves_epilogue_statistics(native_lib)
         assert all(torch.equal(p, q) for p, q in zip(a[2], b[2]))
     finally:
         M.CAT_STATS = M.FAST_BLOCKS = M.SKIP_IN_BLOCK = True
+
+
+def test_head_and_input_glue_kernels(native_lib):
+    """csrc/glue.hip + the broadcast residual of the gather kernel (ABI 6): cast_colsum = (x.bfloat16(), x.sum(0)) with the
+    cast BIT-equal to torch's; pad_channels = F.pad bit for bit (fp32 and bf16); the Linear head as a gather-GEMM with its
+    bias in the kernel's store = the same call + a separate add, bit for bit, and F.linear to 1e-5; its backward through
+    cast_colsum = torch's cast / sum to fp32 summation order."""
+    from doda_amd import ops
+    from doda_amd.model import _PointLinear
+    d = dev()
+    torch.manual_seed(5)
+    for n, c in ((100003, 20), (777, 64), (5, 4)):
+        x = torch.randn(n, c, device=d) * 3
+        y, s = ops.cast_colsum(x)
+        assert torch.equal(y, x.bfloat16())
+        assert rel_err(s.cpu(), x.double().sum(0).cpu()) < 1e-5
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(30001, 3, device=d).to(dt)
+        for c_out in (4, 16):
+            assert torch.equal(ops.pad_channels(x, c_out), torch.nn.functional.pad(x, (0, c_out - 3)))
+    # head: 50k voxels, 70k points, 16 -> 20
+    m, n = 50000, 70000
+    feats = torch.randn(m, 16, device=d).bfloat16().requires_grad_(True)
+    lin = torch.nn.Linear(16, 20).to(d)
+    p2v = torch.randint(0, m, (n,), device=d, dtype=torch.int32)
+    order = torch.argsort(p2v.long(), stable=True)
+    counts = torch.bincount(p2v.long(), minlength=m)
+    k = int(counts.max())
+    v2p_t = torch.full((k, m), -1, dtype=torch.int32, device=d)
+    start = torch.cumsum(counts, 0) - counts
+    rank = torch.arange(n, device=d) - start[p2v.long()[order]]
+    v2p_t[rank, p2v.long()[order]] = order.int()
+    scores = _PointLinear.apply(feats, lin.weight, lin.bias, p2v, v2p_t.contiguous())
+    plain = ops.spconv_gather(feats.detach(), lin.weight.detach().view(1, 20, 16), p2v.view(1, n), n, 1, 20, out_f32=True)
+    assert torch.equal(scores.detach(), plain + lin.bias.detach())
+    # (bf16 features: the kernel multiplies by the bf16-rounded weights, fp32 accumulation)
+    ref = torch.nn.functional.linear(feats.detach().double()[p2v.long()], lin.weight.detach().bfloat16().double(), lin.bias.detach().double())
+    assert rel_err(scores.detach().cpu(), ref.cpu()) < 1e-5
+    g = torch.randn(n, 20, device=d)
+    scores.backward(g)
+    assert rel_err(lin.bias.grad.cpu(), g.double().sum(0).cpu()) < 1e-5
+    gw = (g.bfloat16().double().t() @ feats.detach().double()[p2v.long()])
+    assert rel_err(lin.weight.grad.cpu(), gw.cpu()) < 1e-4
+    gf = torch.zeros(m, 16, dtype=torch.float64, device=d).index_add_(0, p2v.long(), g.bfloat16().double() @ lin.weight.detach().bfloat16().double())
+    assert rel_err(feats.grad.float().cpu(), gf.cpu()) < 2e-2
