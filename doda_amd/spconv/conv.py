@@ -118,11 +118,17 @@ class _Plan:
 
 
 def _repack_all(device, esz):
-    mods = [m for m in _MODULES if m.weight.device == device and m.weight.dtype == torch.float32
-            and m.weight.is_contiguous()
-            and m.weight.shape[0] * m.weight.shape[1] * m.weight.shape[2] <= 27]
-    mods.sort(key=id)
-    sig = tuple((id(m), m.weight.data_ptr()) for m in mods)
+    # (once per forward pass over all 71 conv modules: one dictionary look-up per module instead of a handful of
+    # nn.Module.__getattr__ calls each)
+    cand = []
+    for m in _MODULES:
+        w = m._parameters.get("weight")
+        if (w is not None and w.device == device and w.dtype == torch.float32 and w.is_contiguous()
+                and w.shape[0] * w.shape[1] * w.shape[2] <= 27):
+            cand.append((id(m), m, w))
+    cand.sort(key=lambda t: t[0])
+    mods = [t[1] for t in cand]
+    sig = tuple((t[0], t[2].data_ptr()) for t in cand)
     cached = _PLANS.get((device, esz))
     if cached is None or cached.sig != sig:
         entries = []
@@ -136,7 +142,7 @@ def _repack_all(device, esz):
             m._doda_packed[esz] = (cached, k, m._parameters["weight"], m.weight.data_ptr())
     cached.plan.run()
     cached.gen = _GEN[0]
-    cached.versions = tuple(m.weight._version for m in mods)
+    cached.versions = tuple(t[2]._version for t in cand)
     return cached
 
 
