@@ -279,6 +279,31 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> export_pairs(const at::Tensor &tb
     return {pairs, num, ws.narrow(0, 0, K * nt).view({K, nt})};
 }
 
+// One int32 from the device to the host WITHOUT a spinning wait: copy into pinned memory, then sleep on an event created
+// with hipEventBlockingSync.  Tensor::item() waits in hipStreamSynchronize, which spins by default: the rulebook thread
+// makes six such waits per step (~1.5 ms of a core) next to the issuing thread, which is what paces the step on a busy
+// host.  DODA_SPIN_READBACK=1 restores item().
+bool read_back_blocking(const void *dev_ptr, int32_t *out, int n, void *st) {   // n <= 16; false: the caller spins
+    static const bool spin = getenv("DODA_SPIN_READBACK") && getenv("DODA_SPIN_READBACK")[0] == '1';
+    if (spin) return false;
+    struct Slot { int32_t *host = nullptr; hipEvent_t ev = nullptr; };
+    static thread_local Slot slot;
+    if (!slot.host) {
+        TORCH_CHECK(hipHostMalloc((void **)&slot.host, 64, hipHostMallocDefault) == hipSuccess, "doda: hipHostMalloc");
+        TORCH_CHECK(hipEventCreateWithFlags(&slot.ev, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess, "doda: hipEventCreate");
+    }
+    TORCH_CHECK(hipMemcpyAsync(slot.host, dev_ptr, (size_t)n * 4, hipMemcpyDeviceToHost, (hipStream_t)st) == hipSuccess, "doda: hipMemcpyAsync");
+    TORCH_CHECK(hipEventRecord(slot.ev, (hipStream_t)st) == hipSuccess, "doda: hipEventRecord");
+    TORCH_CHECK(hipEventSynchronize(slot.ev) == hipSuccess, "doda: hipEventSynchronize");
+    for (int k = 0; k < n; ++k) out[k] = slot.host[k];
+    return true;
+}
+int32_t read_back_i32(const at::Tensor &t, void *st) {
+    int32_t v = 0;
+    if (read_back_blocking(t.data_ptr(), &v, 1, st)) return v;
+    return t.item<int32_t>();
+}
+
 // with_pairs: also export every rulebook's pair lists (SubM: [2,27,M] from nbr; k2s2: [2,8,M] from par_off)
 // for the pair-list weight gradient — on the same (side) stream, off the critical path.
 typedef std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, std::vector<int64_t>, at::Tensor, at::Tensor,
@@ -319,7 +344,7 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
                                          (int32_t *)parent.data_ptr(), (int32_t *)off.data_ptr(),
                                          (int32_t *)out_idx.data_ptr(), (int32_t *)count.data_ptr(), ws.data_ptr(),
                                          (size_t)ws.numel(), st), "doda_rulebook_down2_assign");
-        const int32_t m_out = count.item<int32_t>();   // the level's one size read-back
+        const int32_t m_out = read_back_i32(count, st);   // the level's one size read-back
         at::Tensor child = at::empty({8, m_out}, iopt), par_off = at::empty({8, m}, iopt);
         check(doda_rulebook_down2_tables((const int32_t *)parent.data_ptr(), (const int32_t *)off.data_ptr(), m, m_out,
                                          (int32_t *)child.data_ptr(), m_out, (int32_t *)par_off.data_ptr(), m, st),
@@ -1079,9 +1104,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                       const int64_t T = doda_tilebook_tile(), K = tbl.size(0), UMAX = doda_tilebook_umax();
                       nt = (tbl.size(1) + T - 1) / T;
                       char *p = (char *)const_cast<void *>(tb) + nt * UMAX * 4 + nt * K * T * 2 + nt * 4;
-                      at::Tensor over = at::from_blob(p, {2}, tbl.options()).cpu();
-                      o64 = over[0].item<int32_t>();
-                      o32 = over[1].item<int32_t>();
+                      int32_t ov[2] = {0, 0};
+                      if (!read_back_blocking(p, ov, 2, stream_of(tbl))) {
+                          at::Tensor over = at::from_blob(p, {2}, tbl.options()).cpu();
+                          ov[0] = over[0].item<int32_t>();
+                          ov[1] = over[1].item<int32_t>();
+                      }
+                      o64 = ov[0];
+                      o32 = ov[1];
                   }
               }
               return std::make_tuple(levels, nt, o64, o32);
