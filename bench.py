@@ -188,26 +188,30 @@ def _subm16_times(idx, shape, nb, dtype, reps):
             "fwd_bwd": {"cold": gate(True), "warm": gate(False)}, "b_f": b_f}
 
 
+PROFILE_ROUND = "r04"   # in-step / PMC evidence quoted by the bench line must come from THIS round's profiles or be absent
+# the roofline kernel's instantiation as rocprofv3 prints it (template arguments up to the ones that name the epilogue),
+# shared by the live measurement's label and the look-up in the committed kernel statistics
+ROOF_KERNEL = {"bf16": "conv_tile<0, false, true", "f32": "conv_fast<doda_spconv::PF32,"}
+
+
 def in_step_average(dtype):
-    """AverageNs of the roofline kernel's in-step instantiation from the committed rocprofv3 --kernel-trace --stats
-    summary of `python bench.py` (profiles/r03_*_kernel_stats.csv; a counter/trace pass cannot run inside this
-    process).  Returns (microseconds, file) or (None, None)."""
+    """AverageNs of the roofline kernel's in-step instantiation from THIS round's committed rocprofv3 --kernel-trace
+    --stats summary of `python bench.py` (profiles/<PROFILE_ROUND>_*_kernel_stats.csv; a counter/trace pass cannot run
+    inside this process).  Matches on the instantiation prefix ROOF_KERNEL[dtype] (a new trailing template parameter
+    must not silently send the look-up to an older round's file).  Returns (microseconds, file,
+    kernel name in the file) or (None, None, None) — never a figure from an earlier round."""
     import csv
-    prof = os.path.join(ROOT, "profiles")
-    for rnd in ("r03", "r02"):
-        path = os.path.join(prof, "%s_%s_kernel_stats.csv" % (rnd, "bf16" if dtype == "bf16" else "f32"))
-        if not os.path.exists(path):
-            continue
-        want = "conv_tile<0, false, true>" if dtype == "bf16" else "::PF32,"
-        try:
-            with open(path) as f:
-                rows = [r for r in csv.DictReader(f) if want in r["Name"]]
-            if rows:   # (fp32: the statistics instantiation with the largest total time = the level-1 layers)
-                top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
-                return float(top["AverageNs"]) / 1e3, "profiles/" + os.path.basename(path)
-        except (OSError, KeyError, ValueError):
-            pass
-    return None, None
+    path = os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (PROFILE_ROUND, "bf16" if dtype == "bf16" else "f32"))
+    want = ROOF_KERNEL["bf16" if dtype == "bf16" else "f32"]
+    try:
+        with open(path) as f:
+            rows = [r for r in csv.DictReader(f) if want in r["Name"]]
+        if rows:   # (several matches: the instantiation with the largest total time = the level-1 layers)
+            top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+            return float(top["AverageNs"]) / 1e3, "profiles/" + os.path.basename(path), top["Name"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None, None
 
 
 def kernel_roofline(batch_dev, dtype, reps, gate_scene=None):
@@ -232,14 +236,21 @@ def kernel_roofline(batch_dev, dtype, reps, gate_scene=None):
     step_cold = big["fwd"]["step_cold"]
     b_step = big["fwd"]["algorithmic_bytes"]["step"]
     if big["tile_kernel"]:
-        kname = "conv_tile<0,false,true> (LDS-staged over the tilebook; BatchNorm statistics + residual add in the epilogue: the instantiation the step launches)"
+        kname = ROOF_KERNEL["bf16"] + ", ...> (LDS-staged over the tilebook; BatchNorm statistics + residual add in the epilogue: the instantiation the step launches)"
     else:
-        kname = ("conv_fast<PF32,1,2,3,STATS>" if dtype == "f32" else "conv_fast<PBF16P,1,2,3,STATS>") + " (statistics + residual epilogue)"
+        kname = (ROOF_KERNEL["f32"] + " ..., STATS>" if dtype == "f32" else "conv_fast<PBF16P,1,2,3,STATS>") + " (statistics + residual epilogue)"
     traffic, traffic_src = pmc_traffic(dtype)
-    in_step_us, in_step_src = in_step_average(dtype)
+    in_step_us, in_step_src, in_step_name = in_step_average(dtype)
+    if in_step_us is not None and not (kname.startswith(ROOF_KERNEL["bf16" if dtype == "bf16" else "f32"])
+                                       and ROOF_KERNEL["bf16" if dtype == "bf16" else "f32"] in in_step_name):
+        in_step_us = in_step_src = in_step_name = None       # the profile describes another kernel than the live figure
+    # strict SURVEY 8d bytes of the forward gather (B_f: x + y + weights + 8P; the fused residual operand NOT counted)
+    b_8d = big["b_f"]
     roof = {"kernel": "%s, SubMConv3d 16->16 fwd gather, M=%d, P=%d" % (kname, m, pairs_total),
             "M": m, "P": pairs_total, "bound": "hbm", "achieved": step_cold["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": step_cold["frac_of_hbm_peak"], "measured": "cold (operands cycled through %d buffer sets, %d MB)" % (
+            "frac": step_cold["frac_of_hbm_peak"],
+            "frac_8d": b_8d / (step_cold["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_8d": b_8d,
+            "measured": "cold (operands cycled through %d buffer sets, %d MB)" % (
                 big["buffer_sets"], big["buffer_sets"] * big["bytes_per_set"] >> 20),
             "frac_cold": step_cold["frac_of_hbm_peak"], "frac_warm": big["fwd"]["step_warm"]["frac_of_hbm_peak"],
             "frac_plain_cold": big["fwd"]["plain_cold"]["frac_of_hbm_peak"],
@@ -247,7 +258,9 @@ def kernel_roofline(batch_dev, dtype, reps, gate_scene=None):
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": b_step, "avg_launch_us": step_cold["us"],
             "in_step_rocprof_avg_us": in_step_us, "in_step_rocprof_source": in_step_src,
+            "in_step_rocprof_kernel": in_step_name,
             "in_step_frac": (b_step / (in_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if in_step_us else None,
+            "in_step_frac_8d": (b_8d / (in_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if in_step_us else None,
             "detail": out}
     return roof, pairs_total / max(m, 1)
 
@@ -293,15 +306,16 @@ def step_algorithmic_bytes(net, batch_dev, dtype):
 
 def pmc_traffic(dtype):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
-    (tools/profile_r03.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of the same kernel — round 3: the
-    statistics + residual instantiation the step launches — on the same 4 x 150k-voxel batch).  Counters are in KiB; FETCH_SIZE is doubled as
+    of THIS round (tools/profile_round4.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of the same kernel — the
+    statistics + residual instantiation the step launches — on the same 4 x 150k-voxel batch; no file of this round:
+    null).  Counters are in KiB; FETCH_SIZE is doubled as
     MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950 (check: the doubled value,
     86.5 MB, sits 2.5 % above the compulsory x + table bytes, 84.4 MB; WRITE_SIZE equals the output
     bytes exactly).  A counter pass cannot run inside this process, hence the file."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     try:
         d, path = None, None
-        for rnd in ("r03", "r02", "r01"):   # newest committed pass that holds this dtype
+        for rnd in (PROFILE_ROUND,):   # this round's pass only
             cand = os.path.join(prof, "%s_pmc_traffic_raw.json" % rnd)
             if os.path.exists(cand):
                 with open(cand) as f:
@@ -331,28 +345,41 @@ def voxelize_legs(batch, batch_dev, reps=20):
     from doda_amd import ops
     locs, nb = batch["locs"], int(batch["offsets"].numel() - 1)
     n = locs.shape[0]
-    vl, _, v2p = ops.voxelize_idx_host(locs, nb, 4)   # warm-up (first-touch page faults of the allocator)
-    t1 = float("inf")
-    for _ in range(3):
-        t0 = time.perf_counter()
-        ops.voxelize_idx_host(locs, nb, 4)
-        t1 = min(t1, time.perf_counter() - t0)
-    workers = max(1, min(8, (os.cpu_count() or 1)))
-    copies = [locs.clone() for _ in range(workers)]
-    with ThreadPoolExecutor(workers) as ex:   # (the C entry point releases the GIL)
-        list(ex.map(lambda c: ops.voxelize_idx_host(c, nb, 4), copies))
-        t0 = time.perf_counter()
-        list(ex.map(lambda c: ops.voxelize_idx_host(c, nb, 4), copies))
-        tw = time.perf_counter() - t0
+    # ONE torch thread for the host legs: the wrapper's three output allocations are torch.zeros calls, and with the
+    # process's default intra-op pool (128 threads on the GPU box, a shared host) every one of them was a fork/join
+    # of that pool — r03's "1 thread" figure (0.195 s) timed the pool, not doda_voxelize_idx_h (25 ms)
+    thr_before = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        vl, _, v2p = ops.voxelize_idx_host(locs, nb, 4)   # warm-up (first-touch page faults of the allocator)
+        t1 = float("inf")
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ops.voxelize_idx_host(locs, nb, 4)
+            t1 = min(t1, time.perf_counter() - t0)
+        workers = max(1, min(8, (os.cpu_count() or 1)))
+        copies = [locs.clone() for _ in range(workers)]
+        with ThreadPoolExecutor(workers) as ex:   # (the C entry point releases the GIL)
+            list(ex.map(lambda c: ops.voxelize_idx_host(c, nb, 4), copies))
+            t0 = time.perf_counter()
+            list(ex.map(lambda c: ops.voxelize_idx_host(c, nb, 4), copies))
+            tw = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(thr_before)
     locs_dev = batch_dev["locs"]
     t_dev = _timed(lambda: ops.voxelize_idx_device(locs_dev, nb, 4), reps)
     m, width = vl.shape[0], v2p.shape[1]
+    # the two kernels alone: output sizes handed in (a loader that knows an upper bound needs no read-back)
+    t_k = _timed(lambda: ops.voxelize_idx_device(locs_dev, nb, 4, sizes=(m, width - 1)), reps)
     nbytes = 36 * n + (32 + 4 * width) * m
     return {"points": n, "voxels": m, "host_1_thread": {"seconds": t1, "points_per_s": n / t1},
             "host_workers": {"workers": workers, "seconds": tw, "points_per_s": workers * n / tw},
             "device": {"us": t_dev * 1e6, "points_per_s": n / t_dev, "algorithmic_bytes": nbytes,
                        "GBs": nbytes / t_dev / 1e9, "frac_of_hbm_peak": nbytes / t_dev / 1e9 / HBM_PEAK_GBS,
-                       "note": "assign + fill kernels incl. the D2H read-back of the output sizes"},
+                       "note": "assign + fill kernels incl. the D2H read-back of the output sizes",
+                       "kernels_only": {"us": t_k * 1e6, "GBs": nbytes / t_k / 1e9,
+                                        "frac_of_hbm_peak": nbytes / t_k / 1e9 / HBM_PEAK_GBS,
+                                        "note": "output sizes passed in: no read-back between assign and fill"}},
             "kind": "port", "note": "host = doda_voxelize_idx_h (restatement of voxelize.cpp:61-155; the reference's own "
                                     "translation unit does not build here)"}
 

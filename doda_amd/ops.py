@@ -74,8 +74,10 @@ def voxelize_idx_host(coords, batch_size, mode=4):
     return out_coords, input_map, out_map
 
 
-def voxelize_idx_device(coords, batch_size, mode=4):
-    """Device version of voxelize_idx (same results); coords int64 device [N,3|4]."""
+def voxelize_idx_device(coords, batch_size, mode=4, sizes=None):
+    """Device version of voxelize_idx (same results); coords int64 device [N,3|4].
+    sizes = (n_voxels, max_active) known to the caller (a previous call on the same points): the D2H read-back of the
+    two output sizes between the assign and the fill kernel is skipped."""
     _need_cuda(coords)
     if coords.dtype != torch.int64 or coords.dim() != 2:
         raise RuntimeError("voxelize_idx_device: coords must be int64 [N,3|4]")
@@ -88,7 +90,10 @@ def voxelize_idx_device(coords, batch_size, mode=4):
     ws = _ws(nbytes, dev)
     check(lib().doda_voxelize_idx_assign(_p(coords), n, ncol, int(mode), _p(input_map), _p(counts),
                                          _p(ws), ws.numel(), _stream()), "doda_voxelize_idx_assign")
-    m, max_active = (int(v) for v in counts.tolist())  # one D2H sync: sizes of the outputs
+    if sizes is not None:
+        m, max_active = int(sizes[0]), int(sizes[1])
+    else:
+        m, max_active = (int(v) for v in counts.tolist())  # one D2H sync: sizes of the outputs
     max_active = max(max_active, 1)
     out_coords = torch.zeros((m, ncol), dtype=torch.int64, device=dev)
     out_map = torch.zeros((m, max_active + 1), dtype=torch.int32, device=dev)

@@ -1,0 +1,220 @@
+"""Round-4 GPU tests: the default kernels in the regime the bench runs them in.
+
+conv_tile launches min(round8(tiles), 768) persistent workgroups (512 for 64-byte rows) and wgrad_dma16
+min(round8(tiles), 256); the step selects wgrad_dma16 only for rulebooks of >= 262 144 rows.  Every earlier
+kernel-level parity test stayed at <= 157 tiles, i.e. ONE tile per workgroup: the next-tile list prefetch, the
+cross-tile statistics accumulators and the two-buffer DMA-ahead pipeline with accumulators carried across tiles
+never ran under an oracle comparison.  Here: >= 300 k rows (>= 1172 tiles: >= 2 tiles per conv_tile workgroup,
+>= 4 per wgrad_dma16 workgroup), a ragged last tile, and a block of shuffled rows whose tiles reference more distinct
+rows than a tilebook lists (tiles "without a list", served from the dense table inside the kernels) — all against
+oracle.indice_conv / indice_conv_backward on ORACLE-built pair lists (reference semantics:
+model/unet_block.py:26,29; cfgs/scannet/spconv.yaml:27), plus one BASELINE-config-2-size step (4 x 150 k voxels).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def _ext_or_skip():
+    from doda_amd._ext import ext
+    if ext is None:
+        pytest.skip("compiled extension not built")
+    return ext
+
+
+_SCENE = {}
+
+
+def _big_scene(oracle):
+    """Two synthetic ScanNet-shaped scenes (doda_amd.scene, the bench's generator) of ~160 k voxels each in their
+    natural first-touch order, with one block of 4096 consecutive rows shuffled among themselves: the 16 tiles of that
+    block reference ~1800 distinct rows each (> TB_UMAX = 1024) and lose their lists.  Returns (idx int32 [n,4], shape,
+    batch, oracle pairs, oracle pair counts); cached for the module (the oracle rulebook takes ~3 s)."""
+    if "v" not in _SCENE:
+        from doda_amd.scene import make_batch
+        b = make_batch(2, 160000, 4242)
+        idx = b["voxel_locs"].int().numpy().copy()
+        shape = [int(s) for s in b["spatial_shape"]]
+        n = idx.shape[0]
+        assert n >= 300000 and n % 256 != 0, n                    # >= 1172 tiles, ragged last tile
+        lo = (n // 3) // 256 * 256 + 128                          # (the block straddles tile boundaries)
+        perm = np.random.default_rng(5).permutation(4096)
+        idx[lo:lo + 4096] = idx[lo:lo + 4096][perm]
+        idx = np.ascontiguousarray(idx)
+        pairs, pn = oracle.indice_pairs_subm(idx, 2, shape, 3)
+        _SCENE["v"] = (idx, shape, 2, pairs, pn)
+    return _SCENE["v"]
+
+
+def _hip_rulebook(idx, shape, batch, pairs, pn):
+    from doda_amd import ops
+    d = dev()
+    n = idx.shape[0]
+    tbl = ops.rulebook_subm(torch.from_numpy(idx).to(d), shape, batch, 3)
+    hip_pairs, hip_pn = ops.rulebook_pairs(tbl, n, flip=True)
+    assert np.array_equal(hip_pn.cpu().numpy(), pn) and np.array_equal(hip_pairs.cpu().numpy(), pairs)
+    tb = ops.tilebook_build(tbl)
+    assert tb is not None
+    n_over = tb[-8:].view(torch.int32).cpu().tolist()             # tiles above 960 / above 1024 distinct rows
+    assert n_over[1] >= 8, n_over                                  # tiles WITHOUT a list are in the launch
+    nt = (n + 255) // 256
+    assert nt >= 1172 and n_over[1] < nt // 20
+    return tbl, tb
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (32, 16), (16, 32)])
+def test_tile_kernels_multi_tile_regime_vs_oracle(native_lib, oracle, cin, cout):
+    """conv_tile MODE 0 (32-byte rows) and MODE 1 (64-byte rows), forward (layout 0) and data gradient (layout 2), at
+    >= 2 tiles per persistent workgroup: plain, with the fused residual, and with the statistics epilogue (the sum of
+    the per-workgroup rows against the fp64 column sums of the ORACLE's output).  Operands bf16-representable: every
+    product is exact in fp32, only the summation order differs — 1e-4 on fp32 outputs (north_star), one bf16 rounding
+    step on bf16 outputs."""
+    from doda_amd import ops
+    d = dev()
+    idx, shape, batch, pairs, pn = _big_scene(oracle)
+    n = idx.shape[0]
+    tbl, tb = _hip_rulebook(idx, shape, batch, pairs, pn)
+    g = torch.Generator().manual_seed(1000 * cin + cout)
+    x = torch.randn(n, cin, generator=g).bfloat16()
+    dy = torch.randn(n, cout, generator=g).bfloat16()
+    w = (torch.randn(3, 3, 3, cin, cout, generator=g) * 0.1).bfloat16().float()
+    ref_y = oracle.indice_conv(x.double(), w.double(), pairs, pn, n, False, True)
+    ref_dx, _ = oracle.indice_conv_backward(x.double(), w.double(), dy.double(), pairs, pn, False, True)
+    xd, dyd, wd = x.to(d), dy.to(d), w.to(d).view(27, cin, cout)
+
+    for inp, layout, nc, ref in ((xd, 0, cout, ref_y), (dyd, 2, cin, ref_dx)):
+        scale = float(ref.abs().max())
+        y32 = ops.spconv_gather(inp, wd, tbl, n, layout, nc, out_f32=True, tilebook=tb)
+        assert rel_err(y32.cpu(), ref) < 1e-4, (layout, "fp32 out")
+        yb = ops.spconv_gather(inp, wd, tbl, n, layout, nc, tilebook=tb)
+        assert yb.dtype == torch.bfloat16
+        tol = 2.0 ** -7 * ref.abs() + 1e-5 * scale                # the fp64 result rounded once (+ last-bit noise)
+        assert bool(((yb.float().cpu().double() - ref).abs() <= tol).all()), (layout, "bf16 out")
+        # residual + statistics epilogue, the instantiation the step launches
+        res = torch.randn(n, nc, generator=g).bfloat16()
+        yr, st = ops.spconv_gather(inp, wd, tbl, n, layout, nc, tilebook=tb, residual=res.to(d), want_stats=True)
+        want = ref + res.double()
+        tol = 2.0 ** -7 * want.abs() + 1e-5 * float(want.abs().max())
+        assert bool(((yr.float().cpu().double() - want).abs() <= tol).all()), (layout, "residual")
+        assert 2 <= st.shape[0] <= 768                             # one row per persistent workgroup
+        # contract (include/doda_hip.h, doda_conv_epilogue.stats): sums over y AS STORED (conv + residual, after the
+        # bf16 rounding), accumulated across all tiles of a workgroup: against fp64 column sums of the stored tensor,
+        # and against the oracle's values (which differ from the stored ones by one rounding per element)
+        tot = st.double().sum(0).cpu()
+        yf = yr.double().cpu()
+        assert rel_err(tot[0], yf.sum(0)) < 1e-5 and rel_err(tot[1], (yf * yf).sum(0)) < 1e-5, layout
+        assert rel_err(tot[1], (want * want).sum(0)) < 2e-3 and rel_err(tot[0], want.sum(0)) < 2e-2, layout
+        ys, st2 = ops.spconv_gather(inp, wd, tbl, n, layout, nc, tilebook=tb, want_stats=True)
+        tot2, yf2 = st2.double().sum(0).cpu(), ys.double().cpu()
+        assert rel_err(tot2[0], yf2.sum(0)) < 1e-5 and rel_err(tot2[1], (yf2 * yf2).sum(0)) < 1e-5, layout
+        assert rel_err(tot2[1], (ref * ref).sum(0)) < 2e-3, layout
+        # repeatable bit for bit (fixed-order reductions; no atomics on floats)
+        yr2, st3 = ops.spconv_gather(inp, wd, tbl, n, layout, nc, tilebook=tb, residual=res.to(d), want_stats=True)
+        assert torch.equal(yr, yr2) and torch.equal(st, st3)
+
+
+def test_wgrad_dma16_in_the_regime_the_step_selects_it(native_lib, oracle):
+    """wgrad_dma16 the way the step passes its jobs — table + tilebook + PAIR LISTS present, so that the >= 262 144-row
+    gate of classify() (csrc/spconv_wgrad.hip) is what picks the kernel —, four layers of one rulebook in one call, one
+    of them accumulating into an existing gradient: against oracle.indice_conv_backward on the oracle's pair lists.
+    That the LDS-staged kernel (and not the pair-list kernel) ran: bit-equal to the same call without pair lists (which
+    can only take the tile kernel), and NOT bit-equal to the call without a tilebook."""
+    from doda_amd import ops
+    d = dev()
+    idx, shape, batch, pairs, pn = _big_scene(oracle)
+    n = idx.shape[0]
+    assert n >= 262144
+    tbl, tb = _hip_rulebook(idx, shape, batch, pairs, pn)
+    pr, num, seg = ops.rulebook_pairs(tbl, n, flip=True, pad=False, with_seg=True)
+    g = torch.Generator().manual_seed(77)
+    xs = [torch.randn(n, 16, generator=g).bfloat16() for _ in range(4)]
+    dys = [torch.randn(n, 16, generator=g).bfloat16() for _ in range(4)]
+    w0 = torch.zeros(3, 3, 3, 16, 16, dtype=torch.float64)
+    refs = [oracle.indice_conv_backward(x.double(), w0, dy.double(), pairs, pn, False, True)[1] for x, dy in zip(xs, dys)]
+    base = torch.randn(27, 16, 16, generator=g)
+    plist = (pr[0], pr[1], num, seg)
+
+    def jobs(with_pairs, with_tb, acc):
+        out = []
+        for k in range(4):
+            out.append((xs[k].to(d), dys[k].to(d), tbl, n, plist if with_pairs else None,
+                        acc if k == 2 else None, tb if with_tb else None))
+        return out
+    acc = base.clone().to(d)
+    got = ops.spconv_wgrad_multi(jobs(True, True, acc))
+    for k in range(4):
+        val = got[k].cpu() - (base if k == 2 else 0)
+        assert rel_err(val.reshape(refs[k].shape), refs[k]) < 1e-4, k
+    acc2 = base.clone().to(d)
+    tile_only = ops.spconv_wgrad_multi(jobs(False, True, acc2))
+    assert all(torch.equal(a, b) for a, b in zip(got, tile_only))
+    acc3 = base.clone().to(d)
+    pairs_only = ops.spconv_wgrad_multi(jobs(True, False, acc3))
+    assert not all(torch.equal(a, b) for a, b in zip(got, pairs_only))     # another kernel, another summation order
+    for k in range(4):
+        val = pairs_only[k].cpu() - (base if k == 2 else 0)
+        assert rel_err(val.reshape(refs[k].shape), refs[k]) < 1e-4, k
+
+
+def _config2_step(dtype, tiled, batch_dev, n_steps=1):
+    """bench.py's step (deferred weight gradients -> doda_spconv_wgrad_multi, FusedSGD left out: one step's loss and
+    gradients) on a resident batch, tilebooks + wgrad_dma16 on or off."""
+    from doda_amd import spconv
+    from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
+    from doda_amd.spconv import functional as Fsp
+    from tests.util import deterministic_init
+    d = dev()
+    cfg = default_cfg()
+    old = spconv.ops.TILE_KERNEL
+    assert Fsp.set_deferred_wgrad(True)
+    try:
+        spconv.ops.TILE_KERNEL = tiled
+        net = deterministic_init(SparseConvNet(cfg), seed=3).to(d).train()
+        net.zero_grad(set_to_none=True)
+        loss = cross_entropy(voxelize_and_run(cfg, net, batch_dev, d, feature_dtype=dtype), batch_dev["labels"],
+                             ignore_index=255)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        assert all(v is not None for v in grads.values())
+        return float(loss.detach()), grads
+    finally:
+        spconv.ops.TILE_KERNEL = old
+        Fsp.set_deferred_wgrad(False)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_config2_size_step_tile_path_vs_dense_table_path(native_lib, dtype, monkeypatch):
+    """BASELINE config 2 at full size (4 scenes x ~150 k voxels, cfgs/scannet/spconv.yaml:16-27): the step with
+    tilebooks (conv_tile at 3+ tiles per workgroup, wgrad_dma16 selected by the row gate) against the same step on the
+    dense gather tables — loss and every parameter gradient within the tolerances of
+    tests/test_gpu_tile.py::test_unet_step_with_and_without_tilebooks."""
+    _ext_or_skip()
+    from doda_amd.scene import make_batch
+    import doda_amd.model as dmodel
+    d = dev()
+    batch = make_batch(4, 150000, 1000)
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    assert bd["voxel_locs"].shape[0] >= 4 * 140000
+    if dtype == torch.float32 and dmodel.tile_levels_for(dtype) == 0:
+        monkeypatch.setattr(dmodel, "tile_levels_for", lambda dt: 1)          # fp32 tile path: opt in
+    l0, g0 = _config2_step(dtype, False, bd)
+    l1, g1 = _config2_step(dtype, True, bd)
+    assert np.isfinite(l0) and np.isfinite(l1)
+    tol = (2e-2, 0.1) if dtype == torch.bfloat16 else (1e-4, 2e-2)
+    assert abs(l0 - l1) < tol[0] * abs(l0), (l0, l1)
+    for k, a in g0.items():
+        b = g1[k]
+        assert (a.float() - b.float()).norm().item() <= tol[1] * a.float().norm().item() + 1e-6, k
