@@ -46,30 +46,12 @@ _SIGNATURES = {
     "doda_spconv_pack_desc_bytes": (c_sz, []),
     "doda_spconv_pack_plan_h": (c_i32, [c_vp, c_i32, c_vp, C.POINTER(c_i32)]),
     "doda_spconv_pack_multi": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
-    "doda_spconv_gather_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
-                                       c_i32, c_vp, c_sz, c_vp]),
-    "doda_spconv_gather_add_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp,
-                                           c_i32, c_vp, c_sz, c_vp]),
-    "doda_spconv_gather_add_bf16": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp,
-                                            c_i32, c_i32, c_vp, c_sz, c_vp]),
-    "doda_spconv_wgrad_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
-    "doda_spconv_wgrad_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
-                                      c_vp, c_sz, c_vp]),
-    "doda_spconv_wgrad_pairs_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
-    "doda_spconv_wgrad_pairs_bf16": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
-                                             c_i32, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "doda_rulebook_pairs_tile": (c_i32, []),
     "doda_spconv_wgrad_multi_workspace_bytes": (c_sz, [c_vp, c_i32]),
     "doda_spconv_wgrad_multi_desc_bytes": (c_sz, [c_i32]),
     "doda_spconv_wgrad_multi": (c_i32, [c_vp, c_i32, c_vp, c_sz, c_vp, c_sz, c_vp]),
-    "doda_spconv_gather_bf16": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
-                                        c_i32, c_i32, c_vp, c_sz, c_vp]),
-    "doda_spconv_wgrad_bf16": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp,
-                                       c_vp, c_sz, c_vp]),
     "doda_maxpool_fwd_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "doda_maxpool_bwd_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    "doda_bn_relu_bwd_add": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp,
-                                     c_vp, c_vp, c_vp, c_sz, c_vp]),
     "doda_cross_entropy_workspace_bytes": (c_sz, [c_i32]),
     "doda_cross_entropy_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, C.c_int64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "doda_cross_entropy_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, C.c_int64, c_vp, c_vp]),
@@ -77,37 +59,19 @@ _SIGNATURES = {
     "doda_tilebook_umax": (c_i32, []),
     "doda_tilebook_bytes": (c_sz, [c_i32, c_i32]),
     "doda_tilebook_build": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
-    "doda_spconv_set_tile_kernel": (None, [c_i32]),
-    "doda_spconv_set_wlds_kernel": (None, [c_i32]),
-    "doda_spconv_set_dma_kernel": (None, [c_i32]),
-    "doda_spconv_set_wdma_kernel": (None, [c_i32]),
-    "doda_debug_dma_stamps": (c_i32, [c_vp]),
-    "doda_debug_wdma_stamps": (c_i32, [c_vp]),
-    "doda_spconv_bwd_tile_workspace_bytes": (c_sz, []),
-    "doda_spconv_bwd_tile_bf16": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp,
-                                          c_sz, c_vp, c_vp]),
+    "doda_set_option": (c_i32, [c_i32, c_i32]),
+    "doda_get_option": (c_i32, [c_i32]),
     "doda_spconv_stats_capacity": (c_sz, [c_i32]),
     "doda_spconv_gather_ex": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32,
                                       c_i32, c_vp, c_sz, c_vp, c_vp]),
     "doda_bn_relu_fwd_stats": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp,
                                        c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "doda_bn_relu_bwd_stats": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
-                                       c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "doda_bn_relu_fwd_totals": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
-                                        c_i32, c_vp, c_vp, c_vp, c_vp]),
-    "doda_bn_relu_bwd_totals": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
-                                        c_vp, c_vp, c_vp, c_vp]),
-    "doda_spconv_set_stats_finish": (None, [c_i32]),
-    "doda_spconv_get_stats_finish": (c_i32, []),
-    "doda_spconv_prologue_ok": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),
-    "doda_bn_relu_bwd_stats_ld": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                           c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "doda_bn_relu_bwd_add_ld": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp,
+    "doda_bn_relu_bwd_add": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp,
                                         c_vp, c_vp, c_vp, c_sz, c_vp]),
     "doda_bn_relu_apply": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "doda_bn_fwd_final": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "doda_bn_set_chain": (None, [c_i32]),
-    "doda_bn_chain_errors": (C.c_int64, []),
     "doda_cast_colsum_blocks": (c_i32, [C.c_int64, c_i32]),
     "doda_cast_colsum_f32_bf16": (c_i32, [c_vp, C.c_int64, c_i32, c_vp, c_vp, c_i32, c_vp]),
     "doda_pad_channels": (c_i32, [c_vp, C.c_int64, c_i32, c_i32, c_i32, c_vp, c_vp]),
@@ -127,7 +91,8 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-ABI_VERSION = 6   # include/doda_hip.h DODA_ABI_VERSION
+OPT_TILE_KERNEL, OPT_WLDS_KERNEL, OPT_WDMA_KERNEL = 1, 2, 3   # doda_set_option / doda_get_option
+ABI_VERSION = 7   # include/doda_hip.h DODA_ABI_VERSION
 
 _lib = None
 

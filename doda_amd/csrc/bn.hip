@@ -17,8 +17,6 @@
 // results are run-to-run deterministic.  Algorithmic bytes: fwd 3 passes, bwd 5 passes of M*C*s.
 #include "common.hpp"
 #include <stdlib.h>
-#include <map>
-#include <mutex>
 #include <utility>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -725,222 +723,6 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_final_stats(const float *__re
     bwd_final_body(blockIdx.x, stats, rows, m, c, invstd, gamma, dgamma, dbeta, coef);
 }
 
-// ---- final and apply CHAINED inside one launch (round 3) ----------------------------------------------------------
-// The two launches above are dependent and tiny: the `final` one is c/4 workgroups chasing two memory round trips
-// (5-6.5 us), and the host pays a second launch (3.5 us of an issuing thread that is as busy as the GPU) — 75 times per
-// U-Net step.  Here ONE grid holds both: its first c/4 workgroups are the `final` kernel; when one is done it makes its
-// vectors visible device-wide (release fence) and counts up a flag; every other workgroup is an `apply` workgroup that
-// waits — one lane polling, the rest parked at the barrier — until the flag reaches the launch's target, then acquires
-// and sweeps.  Workgroups are dispatched in index order, so the ones everybody waits for are always resident first.
-// The flag only ever counts UP (one per (device, stream), launches of a stream do not overlap; the host hands every
-// launch the value it will have when its own c/4 workgroups are through): nothing to reset, nothing to zero per launch.
-// The wait is bounded (~0.2 s): a launch whose producers died reports through the flag's error word instead of
-// hanging the queue.
-struct ChainFlag { unsigned *flag; unsigned target; };
-constexpr int BN_CHAIN_MAX_C = 256;      // channels whose vectors fit the apply workgroups' LDS copies
-
-__device__ __forceinline__ void chain_publish(const ChainFlag &cf) {
-    __syncthreads();                                  // (thread 0 wrote the vectors; the others left fwd/bwd_final_body early)
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(cf.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-__device__ __forceinline__ void chain_wait(const ChainFlag &cf) {
-    if (threadIdx.x == 0) {
-        int spins = 0;
-        while ((int)(__hip_atomic_load(cf.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - cf.target) < 0) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1 << 21)) {                // producers lost: do not hang the queue, flag the launch
-                __hip_atomic_fetch_add(cf.flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    // (no acquire fence: it would invalidate the XCD's L2 once per wave — measured +60 us per launch.  The few vectors the
-    // producers wrote are read with device-coherent loads instead: chain_load)
-}
-// device-coherent (L2-bypassing) load of a per-channel vector element written by another workgroup of this launch
-__device__ __forceinline__ float chain_load(const float *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <class T>
-__global__ __launch_bounds__(BN_BLOCK) void bn_fwd_chain(const float *__restrict__ stats, int rows, int m, int c, float eps,
-                                                         float momentum, float *__restrict__ mean, float *__restrict__ invstd,
-                                                         float *__restrict__ running_mean, float *__restrict__ running_var,
-                                                         long long *__restrict__ nbt, const ChainFlag cf,
-                                                         const typename T::elem *__restrict__ x, long long n_frag, int nf,
-                                                         const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
-                                                         typename T::elem *__restrict__ y) {
-    if ((int)blockIdx.x < nf) {
-        fwd_final_body(blockIdx.x, stats, rows, m, c, eps, momentum, mean, invstd, running_mean, running_var, nbt);
-        chain_publish(cf);
-        return;
-    }
-    __shared__ __attribute__((aligned(16))) float v_mu[BN_CHAIN_MAX_C], v_is[BN_CHAIN_MAX_C];
-    chain_wait(cf);
-    for (int ch = threadIdx.x; ch < c; ch += BN_BLOCK) {
-        v_mu[ch] = chain_load(mean + ch);
-        v_is[ch] = chain_load(invstd + ch);
-    }
-    __syncthreads();
-    const long long nb = gridDim.x - nf;
-    for (long long e = (long long)(blockIdx.x - nf) * BN_BLOCK + threadIdx.x; e < n_frag; e += nb * BN_BLOCK) {
-        const int f = (int)(e % nf);
-        const f32x4 v = T::load4(x + e * 4);
-        const f32x4 mu = *reinterpret_cast<const f32x4 *>(v_mu + f * 4);
-        const f32x4 is = *reinterpret_cast<const f32x4 *>(v_is + f * 4);
-        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
-        const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + f * 4);
-        f32x4 o = (v - mu) * is * ga + be;
-        if (relu) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = o[q] > 0.f ? o[q] : 0.f;
-        }
-        T::store4(y + e * 4, o);
-    }
-}
-
-template <class T>
-__global__ __launch_bounds__(BN_BLOCK) void bn_bwd_chain(const float *__restrict__ stats, int rows, int m, int c,
-                                                         const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                         float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                         float *__restrict__ coef, const ChainFlag cf,
-                                                         const typename T::elem *__restrict__ x,
-                                                         const typename T::elem *__restrict__ dy, long long n_frag, int nf,
-                                                         int relu, typename T::elem *__restrict__ dx,
-                                                         const typename T::elem *__restrict__ add) {
-    if ((int)blockIdx.x < nf) {
-        bwd_final_body(blockIdx.x, stats, rows, m, c, invstd, gamma, dgamma, dbeta, coef);
-        chain_publish(cf);
-        return;
-    }
-    __shared__ __attribute__((aligned(16))) float v_co[3 * BN_CHAIN_MAX_C];
-    chain_wait(cf);
-    for (int ch = threadIdx.x; ch < 3 * c; ch += BN_BLOCK) v_co[ch] = chain_load(coef + ch);   // (mean / invstd: an earlier launch's)
-    __syncthreads();
-    const long long nb = gridDim.x - nf;
-    for (long long e = (long long)(blockIdx.x - nf) * BN_BLOCK + threadIdx.x; e < n_frag; e += nb * BN_BLOCK) {
-        const int f = (int)(e % nf);
-        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + f * 4);
-        const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + f * 4);
-        const f32x4 xh = (T::load4(x + e * 4) - mu) * is;
-        f32x4 dz = T::load4(dy + e * 4);
-        if (relu) {
-            const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
-            const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + f * 4);
-            const f32x4 yv = xh * ga + be;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dz[q] = yv[q] > 0.f ? dz[q] : 0.f;
-        }
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(v_co + f * 4);
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(v_co + c + f * 4);
-        const f32x4 d = *reinterpret_cast<const f32x4 *>(v_co + 2 * c + f * 4);
-        f32x4 o = a * (dz - b - xh * d);
-        if (add) o += T::load4(add + e * 4);
-        T::store4(dx + e * 4, o);
-    }
-}
-
-// ---- apply passes fed by TOTALS (round 3: the conv kernel's last workgroup summed the partial rows, spconv_common.hpp
-// stats_finish) ---------------------------------------------------------------------------------------------------
-// The first c threads of every workgroup turn the two totals of their channel into the per-channel vectors (the
-// arithmetic of bn_fwd_final_stats / bn_bwd_final_stats, fp64) and park them in LDS; the sweep is bn_apply /
-// bn_bwd_apply with the vectors read from LDS instead of L1.  Workgroup 0 publishes what later kernels need.
-constexpr int BN_TOT_MAX_C = 256;
-
-template <class T>
-__global__ __launch_bounds__(BN_BLOCK) void bn_apply_tot(const typename T::elem *__restrict__ x, long long n_frag, int nf,
-                                                         const double *__restrict__ totals, int m, float eps, float momentum,
-                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                         float *__restrict__ mean, float *__restrict__ invstd,
-                                                         float *__restrict__ running_mean, float *__restrict__ running_var,
-                                                         long long *__restrict__ nbt, int relu,
-                                                         typename T::elem *__restrict__ y) {
-    __shared__ __attribute__((aligned(16))) float v_mu[BN_TOT_MAX_C], v_a[BN_TOT_MAX_C];
-    const int c = nf * 4;
-    for (int ch = threadIdx.x; ch < c; ch += BN_BLOCK) {
-        const double d = totals[ch] / m;
-        double var = totals[c + ch] / m - d * d;
-        if (var < 0.0) var = 0.0;
-        const float mu = (float)d, is = (float)(1.0 / sqrt(var + (double)eps));
-        v_mu[ch] = mu;
-        v_a[ch] = is;
-        if (blockIdx.x == 0) {
-            mean[ch] = mu;
-            invstd[ch] = is;
-            if (running_mean) {
-                const double unbiased = m > 1 ? var * (double)m / (double)(m - 1) : var;
-                running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * d);
-                running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unbiased);
-            }
-            if (ch == 0 && nbt) *nbt = *nbt + 1;
-        }
-    }
-    __syncthreads();
-    for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < n_frag; e += (long long)gridDim.x * BN_BLOCK) {
-        const int f = (int)(e % nf);
-        const f32x4 v = T::load4(x + e * 4);
-        const f32x4 mu = *reinterpret_cast<const f32x4 *>(v_mu + f * 4);
-        const f32x4 is = *reinterpret_cast<const f32x4 *>(v_a + f * 4);
-        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
-        const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + f * 4);
-        f32x4 o = (v - mu) * is * ga + be;     // (the expression of bn_apply: same rounding)
-        if (relu) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = o[q] > 0.f ? o[q] : 0.f;
-        }
-        T::store4(y + e * 4, o);
-    }
-}
-
-template <class T>
-__global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_tot(const typename T::elem *__restrict__ x,
-                                                             const typename T::elem *__restrict__ dy, long long n_frag,
-                                                             int nf, const double *__restrict__ totals, int m,
-                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                             int relu, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                             typename T::elem *__restrict__ dx,
-                                                             const typename T::elem *__restrict__ add) {
-    __shared__ __attribute__((aligned(16))) float v_a[BN_TOT_MAX_C], v_b[BN_TOT_MAX_C], v_d[BN_TOT_MAX_C];
-    const int c = nf * 4;
-    for (int ch = threadIdx.x; ch < c; ch += BN_BLOCK) {
-        const double s1 = totals[ch], s2 = totals[c + ch];
-        v_a[ch] = gamma[ch] * invstd[ch];
-        v_b[ch] = (float)(s1 / m);
-        v_d[ch] = (float)(s2 / m);
-        if (blockIdx.x == 0) {
-            dbeta[ch] = (float)s1;
-            dgamma[ch] = (float)s2;
-        }
-    }
-    __syncthreads();
-    for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < n_frag; e += (long long)gridDim.x * BN_BLOCK) {
-        const int f = (int)(e % nf);
-        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + f * 4);
-        const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + f * 4);
-        const f32x4 xh = (T::load4(x + e * 4) - mu) * is;
-        f32x4 dz = T::load4(dy + e * 4);
-        if (relu) {
-            const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + f * 4);
-            const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + f * 4);
-            const f32x4 yv = xh * ga + be;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dz[q] = yv[q] > 0.f ? dz[q] : 0.f;
-        }
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(v_a + f * 4);
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(v_b + f * 4);
-        const f32x4 d = *reinterpret_cast<const f32x4 *>(v_d + f * 4);
-        f32x4 o = a * (dz - b - xh * d);
-        if (add) o += T::load4(add + e * 4);
-        T::store4(dx + e * 4, o);
-    }
-}
-
 // ---- final + apply in ONE launch (round 3) ----------------------------------------------------------
 // The `final` kernels above are four to twelve blocks chasing L2 round trips: 6-7 us each, 75 of them per U-Net
 // step.  When the conv epilogue delivers few partial rows (the persistent tile kernels write ONE per workgroup:
@@ -1200,33 +982,6 @@ int run_bwd(const void *x_, const void *dy_, int m, int c, const float *mean, co
     return doda_check_launch();
 }
 
-// one counting flag per (device, stream); word 1 counts launches whose wait gave up
-// OFF by default (DODA_BN_CHAIN=1 / doda_bn_set_chain(1)): measured in the U-Net step (tools/hostab.py ... chain, profiles/
-// r03_bn_chain_ab.txt) the chained launch saves 0.12 ms of issue time per step but its kernels run 1.6 us longer than the two
-// separate ones together (the waiting workgroups hold their CUs while the side stream builds rulebooks): 6.3-6.5 ms against
-// 6.1-6.2 ms whenever the GPU paces the step.
-bool g_bn_chain = getenv("DODA_BN_CHAIN") && getenv("DODA_BN_CHAIN")[0] == '1';
-struct ChainState { unsigned *flag; unsigned count; };
-std::mutex g_chain_mu;
-std::map<std::pair<int, hipStream_t>, ChainState> g_chain;
-bool chain_next(hipStream_t s, int nf, ChainFlag *out) {
-    if (!g_bn_chain) return false;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    std::lock_guard<std::mutex> lk(g_chain_mu);
-    auto it = g_chain.find({dev, s});
-    if (it == g_chain.end()) {
-        unsigned *p = nullptr;      // never freed: a handful per process
-        if (hipMalloc((void **)&p, 256) != hipSuccess) return false;
-        if (hipMemsetAsync(p, 0, 256, s) != hipSuccess) return false;
-        it = g_chain.emplace(std::make_pair(dev, s), ChainState{p, 0u}).first;
-    }
-    it->second.count += (unsigned)nf;
-    out->flag = it->second.flag;
-    out->target = it->second.count;
-    return true;
-}
-
 bool bn_args_bad(int m, int c, int elem_bytes) {
     return m <= 0 || c <= 0 || (c % 4) != 0 || c > 1024 || (elem_bytes != 2 && elem_bytes != 4);
 }
@@ -1275,7 +1030,7 @@ extern "C" int doda_bn_relu_bwd(const void *x, const void *dy, int32_t m, int32_
 // dx = BN backward + add: `add` ([m, c], dtype of x) is a second gradient of the same x — in a
 // pre-activation residual block x feeds both the BatchNorm and the skip connection — so the
 // gradient accumulation rides in the apply pass instead of a separate elementwise kernel.
-extern "C" int doda_bn_relu_bwd_add_ld(const void *x, const void *dy, int32_t m, int32_t c,
+extern "C" int doda_bn_relu_bwd_add(const void *x, const void *dy, int32_t m, int32_t c,
                                        int32_t elem_bytes, const float *save_mean,
                                        const float *save_invstd, const float *gamma, const float *beta,
                                        int32_t relu, const void *add, int32_t add_ld, void *dx, float *dgamma,
@@ -1291,15 +1046,6 @@ extern "C" int doda_bn_relu_bwd_add_ld(const void *x, const void *dy, int32_t m,
     return run_bwd<BF16>(x, dy, m, c, save_mean, save_invstd, gamma, beta, relu, dx, dgamma, dbeta, ws,
                          ws_bytes, add, as_stream(stream), add_ld);
 }
-extern "C" int doda_bn_relu_bwd_add(const void *x, const void *dy, int32_t m, int32_t c,
-                                    int32_t elem_bytes, const float *save_mean,
-                                    const float *save_invstd, const float *gamma, const float *beta,
-                                    int32_t relu, const void *add, void *dx, float *dgamma, float *dbeta,
-                                    void *ws, size_t ws_bytes, doda_stream_t stream) {
-    return doda_bn_relu_bwd_add_ld(x, dy, m, c, elem_bytes, save_mean, save_invstd, gamma, beta, relu, add, c, dx, dgamma,
-                                   dbeta, ws, ws_bytes, stream);
-}
-
 // ---- BatchNorm(+ReLU) over statistics that a conv epilogue accumulated ------------------------------
 template <class T>
 static int run_fwd_stats(const void *x_, int m, int c, const float *stats, int rows, float eps, float momentum,
@@ -1315,13 +1061,6 @@ static int run_fwd_stats(const void *x_, int m, int c, const float *stats, int r
         return doda_check_launch();
     }
     const long long n_frag = (long long)m * g.nf;
-    const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
-    ChainFlag cf;
-    if (c <= BN_CHAIN_MAX_C && chain_next(s, g.nf, &cf)) {      // both passes in one launch: the first c/4 workgroups are the `final` kernel
-        hipLaunchKernelGGL((bn_fwd_chain<T>), dim3(g.nf + grid), dim3(BN_BLOCK), 0, s, stats, rows, m, c, eps, momentum, mean,
-                           invstd, rm, rv, nbt, cf, (const elem *)x_, n_frag, g.nf, gamma, beta, relu, (elem *)y_);
-        return doda_check_launch();
-    }
     hipLaunchKernelGGL(bn_fwd_final_stats, dim3(c / 4), dim3(BN_BLOCK), 0, s, stats, rows, m, c, eps, momentum, mean,
                        invstd, rm, rv, nbt);
     launch_apply<T>((const elem *)x_, n_frag, g.nf, mean, invstd, gamma, beta, relu, (elem *)y_, s);
@@ -1344,36 +1083,11 @@ static int run_bwd_stats(const void *x_, const void *dy_, int m, int c, const fl
         return doda_check_launch();
     }
     const long long n_frag = (long long)m * g.nf;
-    const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
-    ChainFlag cf;
-    if (!add_ld && c <= BN_CHAIN_MAX_C && chain_next(s, g.nf, &cf)) {
-        hipLaunchKernelGGL((bn_bwd_chain<T>), dim3(g.nf + grid), dim3(BN_BLOCK), 0, s, stats, rows, m, c, mean, invstd, gamma,
-                           beta, dgamma, dbeta, coef, cf, (const elem *)x_, (const elem *)dy_, n_frag, g.nf, relu,
-                           (elem *)dx_, (const elem *)add_);
-        return doda_check_launch();
-    }
     hipLaunchKernelGGL(bn_bwd_final_stats, dim3(c / 4), dim3(BN_BLOCK), 0, s, stats, rows, m, c, invstd, gamma, dgamma,
                        dbeta, coef);
     launch_bwd_apply<T>((const elem *)x_, (const elem *)dy_, n_frag, g.nf, c, mean, invstd, gamma, beta, relu, coef,
                         (elem *)dx_, (const elem *)add_, add_ld, s);
     return doda_check_launch();
-}
-
-extern "C" void doda_bn_set_chain(int32_t on) { g_bn_chain = on != 0; }
-// launches (on any stream of the current device) whose apply workgroups gave up waiting for their statistics: 0 unless a
-// kernel died.  Synchronises the device.
-extern "C" int64_t doda_bn_chain_errors(void) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
-    std::lock_guard<std::mutex> lk(g_chain_mu);
-    int64_t total = 0;
-    for (auto &kv : g_chain) {
-        if (kv.first.first != dev) continue;
-        unsigned w = 0;
-        if (hipMemcpy(&w, kv.second.flag + 1, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        total += w;
-    }
-    return total;
 }
 
 extern "C" int doda_bn_relu_fwd_stats(const void *x, int32_t m, int32_t c, int32_t elem_bytes, const float *stats,
@@ -1419,71 +1133,7 @@ extern "C" int doda_bn_fwd_final(const float *stats, int32_t stats_rows, int32_t
     return doda_check_launch();
 }
 
-template <class T>
-static int run_fwd_totals(const void *x_, int m, int c, const double *totals, float eps, float momentum, const float *gamma,
-                          const float *beta, float *rm, float *rv, long long *nbt, int relu, void *y_, float *mean,
-                          float *invstd, hipStream_t s) {
-    typedef typename T::elem elem;
-    const Geo g = make_geo(c);
-    const long long n_frag = (long long)m * g.nf;
-    const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
-    hipLaunchKernelGGL((bn_apply_tot<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, n_frag, g.nf, totals, m, eps,
-                       momentum, gamma, beta, mean, invstd, rm, rv, nbt, relu, (elem *)y_);
-    return doda_check_launch();
-}
-
-template <class T>
-static int run_bwd_totals(const void *x_, const void *dy_, int m, int c, const double *totals, const float *mean,
-                          const float *invstd, const float *gamma, const float *beta, int relu, const void *add_, void *dx_,
-                          float *dgamma, float *dbeta, hipStream_t s) {
-    typedef typename T::elem elem;
-    const Geo g = make_geo(c);
-    const long long n_frag = (long long)m * g.nf;
-    const int grid = (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
-    hipLaunchKernelGGL((bn_bwd_apply_tot<T>), dim3(grid), dim3(BN_BLOCK), 0, s, (const elem *)x_, (const elem *)dy_, n_frag,
-                       g.nf, totals, m, mean, invstd, gamma, beta, relu, dgamma, dbeta, (elem *)dx_, (const elem *)add_);
-    return doda_check_launch();
-}
-
-extern "C" int doda_bn_relu_fwd_totals(const void *x, int32_t m, int32_t c, int32_t elem_bytes, const double *totals,
-                                       float eps, float momentum, const float *gamma, const float *beta,
-                                       float *running_mean, float *running_var, int64_t *num_batches_tracked, int32_t relu,
-                                       void *y, float *save_mean, float *save_invstd, doda_stream_t stream) {
-    if (m == 0) return DODA_OK;
-    if (bn_args_bad(m, c, elem_bytes) || c > BN_TOT_MAX_C) return DODA_ERR_UNSUPPORTED;
-    if (!x || !y || !totals || !gamma || !beta || !save_mean || !save_invstd || (!running_mean != !running_var))
-        return DODA_ERR_INVALID;
-    if (elem_bytes == 4)
-        return run_fwd_totals<F32>(x, m, c, totals, eps, momentum, gamma, beta, running_mean, running_var,
-                                   (long long *)num_batches_tracked, relu, y, save_mean, save_invstd, as_stream(stream));
-    return run_fwd_totals<BF16>(x, m, c, totals, eps, momentum, gamma, beta, running_mean, running_var,
-                                (long long *)num_batches_tracked, relu, y, save_mean, save_invstd, as_stream(stream));
-}
-
-extern "C" int doda_bn_relu_bwd_totals(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
-                                       const double *totals, const float *save_mean, const float *save_invstd,
-                                       const float *gamma, const float *beta, int32_t relu, const void *add, void *dx,
-                                       float *dgamma, float *dbeta, doda_stream_t stream) {
-    if (m == 0) return DODA_OK;
-    if (bn_args_bad(m, c, elem_bytes) || c > BN_TOT_MAX_C) return DODA_ERR_UNSUPPORTED;
-    if (!x || !dy || !dx || !totals || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta)
-        return DODA_ERR_INVALID;
-    if (elem_bytes == 4)
-        return run_bwd_totals<F32>(x, dy, m, c, totals, save_mean, save_invstd, gamma, beta, relu, add, dx, dgamma, dbeta,
-                                   as_stream(stream));
-    return run_bwd_totals<BF16>(x, dy, m, c, totals, save_mean, save_invstd, gamma, beta, relu, add, dx, dgamma, dbeta,
-                                as_stream(stream));
-}
-
 extern "C" int doda_bn_relu_bwd_stats(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
-                                      const float *stats, int32_t stats_rows, const float *save_mean,
-                                      const float *save_invstd, const float *gamma, const float *beta, int32_t relu,
-                                      const void *add, void *dx, float *dgamma, float *dbeta, float *coef_ws,
-                                      doda_stream_t stream) {
-    return doda_bn_relu_bwd_stats_ld(x, dy, m, c, elem_bytes, stats, stats_rows, save_mean, save_invstd, gamma, beta, relu,
-                                     add, c, dx, dgamma, dbeta, coef_ws, stream);
-}
-extern "C" int doda_bn_relu_bwd_stats_ld(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
                                          const float *stats, int32_t stats_rows, const float *save_mean,
                                          const float *save_invstd, const float *gamma, const float *beta, int32_t relu,
                                          const void *add, int32_t add_ld, void *dx, float *dgamma, float *dbeta,

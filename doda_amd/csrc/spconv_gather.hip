@@ -26,9 +26,8 @@
 #include "common.hpp"
 #include "tilebook.hpp"
 #include "spconv_common.hpp"
+#include "wgrad_pairs.hpp"
 #include <stdlib.h>
-#include <map>
-#include <mutex>
 #include <utility>
 
 namespace {
@@ -776,12 +775,11 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                         a2 = (a2 + sred[1][nb][1][g]) + (sred[2][nb][1][g] + sred[3][nb][1][g]);
                     }
                     float *dst = ep.stats + (long long)part * 2 * nc + col;
-                    stats_store4(dst, a1);
-                    stats_store4(dst + nc, a2);
+                    *reinterpret_cast<f32x4 *>(dst) = a1;
+                    *reinterpret_cast<f32x4 *>(dst + nc) = a2;
                 }
             }
         }
-        stats_finish<SPLIT>(ep, nc);
     }
 }
 
@@ -791,8 +789,7 @@ int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_byt
                 const void *res, const EpiArgs &ep_in, int *n_part, hipStream_t s) {
     const dim3 grid(div_up(n_out, (SPLIT ? 1 : 4) * 16 * S) * div_up(NB, NBW)), block(256);
     if (n_part) *n_part = div_up(n_out, (SPLIT ? 1 : 4) * 16 * S);
-    EpiArgs ep = ep_in;
-    if (ep.stats) doda_fin::arm(ep, div_up(n_out, (SPLIT ? 1 : 4) * 16 * S), grid.x, s);
+    const EpiArgs &ep = ep_in;
     // Ring depth.  Re-measured after the EXEC-masked gathers and the wide / pair units went in: with
     // every load hitting L1 (ablation) the kernel time did not move, i.e. the unit loop is paced by
     // instruction issue and by how many waves a SIMD can interleave, not by memory latency.  Depth 8
@@ -846,7 +843,7 @@ template <class T>
 int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tbl, int ld, int K,
                int n_out, void *y_, int wl, void *ws, size_t ws_bytes, long long n_in, bool out32,
                const void *res, hipStream_t s,
-               const EpiArgs &ep = EpiArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
+               const EpiArgs &ep = EpiArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0},
                int *n_part = nullptr, const void *tilebook = nullptr, int tilebook_rows = 0) {
     typedef typename T::elem elem;
     typedef typename T::frag frag;
@@ -889,14 +886,10 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
         if (tmode >= 0 && tilebook && K == TB_K && tilebook_rows == n_out && doda_tile::enabled()) {
             const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
             const unsigned yb = (unsigned)((size_t)n_out * nc * (out32 ? 4 : sizeof(elem)));
-            // 16 -> 16 with bf16 outputs (the level-1 block convolutions, both directions): the LDS-DMA pipeline
-            if (tmode == 0 && !out32 && nc == 16 && doda_dma::enabled() && !ep.pre_mean)
-                return doda_dma::launch_conv16(x_, xb, wp, (unsigned)need, tbl, ld, n_out, tilebook, y_, yb, res, ep, n_part, s);
             return doda_tile::launch_conv_tile(tmode, out32 || sizeof(elem) == 4, x_, xb, wp, (unsigned)need, nc, NB, tbl, ld,
                                                n_out, tilebook, y_, yb, res, ep, n_part, s);
         }
     }
-    if (ep.pre_mean) return DODA_ERR_UNSUPPORTED;   // BatchNorm prologue: tile kernels only (doda_spconv_prologue_ok)
     // 48 -> 48 channels on a mid-size level: the layer's fragments in LDS, one workgroup per CU (spconv_wlds.hip)
     if (!ep.res_bcast && wide && kc == 48 && nc == 48 && K == 27 && !out32 && n_out >= 8192 && n_out <= 262144 && doda_wlds::enabled()) {
         const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
@@ -978,12 +971,6 @@ bool bad_args(const void *x, int kc, const float *w, int nc, const int32_t *tbl,
 }
 }  // namespace
 
-// pair-packed W[K-1-o]^T fragments of a 16 -> 16 layer (the data-grad operand) for spconv_tile.hip
-void doda_tile::pack_pair_layout2(const float *w, void *out, hipStream_t s) {
-    hipLaunchKernelGGL(pack_weights_wide, dim3(div_up((long long)TB_K * 32, 256)), dim3(256), 0, s, w, TB_K, 16, 16, 1, 1, 2,
-                       (u32x4_t *)out, 1);
-}
-
 extern "C" size_t doda_spconv_gather_workspace_bytes(int32_t K, int32_t kc, int32_t nc,
                                                      int32_t elem_bytes) {
     if (K <= 0 || kc <= 0 || nc <= 0) return 0;
@@ -1025,105 +1012,26 @@ extern "C" int doda_spconv_pack_multi(const void *descs_dev, const int32_t *blk_
     return doda_check_launch();
 }
 
-extern "C" int doda_spconv_gather_f32(const float *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
-                                      const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
-                                      float *y, int32_t w_layout, void *ws, size_t ws_bytes,
-                                      doda_stream_t stream) {
-    int st;
-    if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
-    return run_gather<F32>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, false, nullptr,
-                           as_stream(stream));
-}
-
-extern "C" int doda_spconv_gather_add_f32(const float *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
-                                          const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
-                                          const float *res, float *y, int32_t w_layout, void *ws,
-                                          size_t ws_bytes, doda_stream_t stream) {
-    int st;
-    if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
-    if (!res) return DODA_ERR_INVALID;
-    return run_gather<F32>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, false, res,
-                           as_stream(stream));
-}
-
-extern "C" int doda_spconv_gather_bf16(const uint16_t *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
-                                       const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
-                                       void *y, int32_t y_is_f32, int32_t w_layout, void *ws,
-                                       size_t ws_bytes, doda_stream_t stream) {
-    int st;
-    if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
-    return run_gather<BF16>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, y_is_f32 != 0,
-                            nullptr, as_stream(stream));
-}
-
-extern "C" int doda_spconv_gather_add_bf16(const uint16_t *x, int32_t n_in, int32_t kc, const float *w,
-                                           int32_t nc, const int32_t *tbl, int32_t ld, int32_t K,
-                                           int32_t n_out, const void *res, void *y, int32_t y_is_f32,
-                                           int32_t w_layout, void *ws, size_t ws_bytes,
-                                           doda_stream_t stream) {
-    int st;
-    if (bad_args(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, &st)) return st;
-    if (!res) return DODA_ERR_INVALID;
-    return run_gather<BF16>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, y_is_f32 != 0,
-                            res, as_stream(stream));
-}
-
-// ---- in-kernel finish of the epilogue statistics (spconv_common.hpp: EpiArgs.totals) ----------------
-namespace doda_fin {
-namespace {
-// OFF by default: measured on MI355X (profiles/r03_stats_finish_ab.txt) the end-of-workgroup protocol — drain the
-// write-through stores, one or two memory-side atomics — costs 3-7 us per workgroup: +6 us on the persistent tile kernels
-// (what the separate `final` launch costs) and +25..55 us on conv_fast's thousands of short workgroups.
-bool g_on = getenv("DODA_STATS_FINISH") && getenv("DODA_STATS_FINISH")[0] == '1';
-std::mutex g_mu;
-std::map<std::pair<int, hipStream_t>, unsigned *> g_tickets;
-}  // namespace
-thread_local int last_finished = 0;
-bool enabled() { return g_on; }
-void set_enabled(bool on) { g_on = on; }
-unsigned *ticket_for(hipStream_t s) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_tickets.find({dev, s});
-    if (it != g_tickets.end()) return it->second;
-    unsigned *p = nullptr;   // root + FIN_MAX_GROUPS group counters, one 256-byte line each; never freed (a handful per process)
-    const size_t bytes = (size_t)(1 + FIN_MAX_GROUPS) * FIN_STRIDE * sizeof(unsigned);
-    if (hipMalloc((void **)&p, bytes) != hipSuccess) return nullptr;
-    if (hipMemsetAsync(p, 0, bytes, s) != hipSuccess) return nullptr;
-    g_tickets[{dev, s}] = p;
-    return p;
-}
-bool arm(EpiArgs &ep, int rows, unsigned n_wg, hipStream_t s) {
-    last_finished = 0;
-    if (!ep.totals) return false;
-    unsigned *t = (g_on && n_wg <= FIN_GROUP * FIN_MAX_GROUPS) ? ticket_for(s) : nullptr;
-    if (!t) {
-        ep.totals = nullptr;
-        return false;
-    }
-    ep.ticket = t;
-    ep.fin_rows = rows;
-    last_finished = 1;
-    return true;
-}
-}  // namespace doda_fin
-
-extern "C" void doda_spconv_set_stats_finish(int32_t on) { doda_fin::set_enabled(on != 0); }
-extern "C" int32_t doda_spconv_get_stats_finish(void) { return doda_fin::enabled() ? 1 : 0; }
-
 // ---- gather with epilogue options (residual add, BatchNorm statistics) ------------------------------
-extern "C" void doda_spconv_set_wlds_kernel(int32_t on) { doda_wlds::set_enabled(on != 0); }
+// A/B switches of the kernel selection (measurements and parity tests; every option defaults to 1)
+extern "C" int doda_set_option(int32_t option, int32_t value) {
+    switch (option) {
+    case DODA_OPT_TILE_KERNEL: doda_tile::set_enabled(value != 0); return DODA_OK;
+    case DODA_OPT_WLDS_KERNEL: doda_wlds::set_enabled(value != 0); return DODA_OK;
+    case DODA_OPT_WDMA_KERNEL: doda_wdma::set_enabled(value != 0); return DODA_OK;
+    default: return DODA_ERR_INVALID;
+    }
+}
+extern "C" int32_t doda_get_option(int32_t option) {
+    switch (option) {
+    case DODA_OPT_TILE_KERNEL: return doda_tile::enabled() ? 1 : 0;
+    case DODA_OPT_WLDS_KERNEL: return doda_wlds::enabled() ? 1 : 0;
+    case DODA_OPT_WDMA_KERNEL: return doda_wdma::enabled() ? 1 : 0;
+    default: return -1;
+    }
+}
 
 extern "C" size_t doda_spconv_stats_capacity(int32_t n_out) { return n_out > 0 ? (size_t)div_up(n_out, 16) : 1; }
-
-extern "C" int32_t doda_spconv_prologue_ok(int32_t kc, int32_t nc, int32_t K, int32_t elem_bytes, int32_t y_is_f32,
-                                           int32_t n_in, int32_t n_out, int32_t has_tilebook) {
-    if (elem_bytes != 2 || y_is_f32 || K != TB_K || !has_tilebook || n_in != n_out || n_out <= 0 || nc <= 0 || nc % 4) return 0;
-    if (!doda_tile::enabled()) return 0;
-    if ((size_t)n_out * nc * 4 >= 0x7fffffffull || (size_t)n_in * kc * 2 >= 0x7ffffff0ull) return 0;
-    return (kc == 16 || kc == 32) ? 1 : 0;   // conv_tile MODE 0 / MODE 1
-}
 
 extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, int32_t elem_bytes, const float *w,
                                      int32_t nc, const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, void *y,
@@ -1135,20 +1043,15 @@ extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, in
         if (st == DODA_OK && epi && epi->stats_rows_h) *epi->stats_rows_h = 0;
         return st;
     }
-    EpiArgs ep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    EpiArgs ep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     const void *res = nullptr;
     int n_part = 0;
-    doda_fin::last_finished = 0;
     if (epi) {
         res = epi->residual;
         ep.res_bcast = (res && epi->residual_bcast) ? 1 : 0;
         if (epi->stats) {
             if (!epi->stats_rows_h) return DODA_ERR_INVALID;
             ep.stats = epi->stats;
-            if (epi->totals) {
-                if (!epi->finished_h || ((uintptr_t)epi->totals & 7)) return DODA_ERR_INVALID;
-                ep.totals = epi->totals;
-            }
             if (epi->bn_x) {
                 if (!epi->bn_mean || !epi->bn_invstd || !epi->bn_gamma || !epi->bn_beta) return DODA_ERR_INVALID;
                 ep.bn_x = epi->bn_x;
@@ -1157,25 +1060,14 @@ extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, in
                 ep.bn_relu = epi->bn_relu;
             }
         }
-        if (epi->pre_mean) {   // ABI 6: BatchNorm(+ReLU) prologue
-            if (!epi->pre_invstd || !epi->pre_gamma || !epi->pre_beta || ((uintptr_t)epi->pre_out & 15)) return DODA_ERR_INVALID;
-            if (!doda_spconv_prologue_ok(kc, nc, K, elem_bytes, y_is_f32, n_in, n_out, epi->tilebook != nullptr) ||
-                epi->tilebook_rows != n_out)
-                return DODA_ERR_UNSUPPORTED;
-            ep.pre_mean = epi->pre_mean; ep.pre_invstd = epi->pre_invstd;
-            ep.pre_gamma = epi->pre_gamma; ep.pre_beta = epi->pre_beta;
-            ep.pre_relu = epi->pre_relu;
-            ep.pre_out = epi->pre_out;
-        }
     }
     if (elem_bytes == 4)
         st = run_gather<F32>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, false, res,
-                             as_stream(stream), ep, &n_part);
+                             as_stream(stream), ep, &n_part, epi ? epi->tilebook : nullptr, epi ? epi->tilebook_rows : 0);
     else
         st = run_gather<BF16>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, y_is_f32 != 0, res,
                               as_stream(stream), ep, &n_part, epi ? epi->tilebook : nullptr,
                               epi ? epi->tilebook_rows : 0);
     if (st == DODA_OK && epi && epi->stats_rows_h) *epi->stats_rows_h = n_part;
-    if (epi && epi->finished_h) *epi->finished_h = (st == DODA_OK && ep.totals) ? doda_fin::last_finished : 0;
     return st;
 }

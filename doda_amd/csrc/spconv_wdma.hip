@@ -7,7 +7,7 @@
 // global memory: 12.4 pairs per voxel x 64 B = 0.8 KB of texture-path traffic per voxel against 137 B of operands
 // (PMC: GRBM_TA_BUSY 93 %); cold it runs at 57 us per level-1 layer.  Here a tile of 256 output rows t is staged
 // ONCE in LDS — the ~2.5 x 256 distinct x rows its table entries reference (LDS-DMA through the tilebook's list, as the
-// forward kernel of spconv_dma.hip stages them; pieces past the list's end are not issued) and its 256 dy rows — and
+// round-3 conv_dma16 experiment staged them; pieces past the list's end are not issued) and its 256 dy rows — and
 // every (offset, 32-row k-step) is served from there.  BOTH operands reach MFMA k-order through ds_read_b64_tr_b16:
 //   * dy (dense: rows t0 .. t0+255) with contiguous addresses (conflict-free);
 //   * the gathered x rows with PER-LANE addresses built from the tile's local indices: lane 4q + c of a 16-lane group
@@ -44,13 +44,6 @@ constexpr int WD_MAX_UNITS = (WD_UNITS + WD_WAVES - 1) / WD_WAVES;   // 4
 constexpr int WD_MAX_JOBS = 16;
 static_assert(WD_BUF_BYTES % 16 == 0 && 2 * WD_BUF_BYTES + 64 <= 160 * 1024, "two tile buffers per CU");
 static_assert(WD_UNITS * 256 * 4 <= WD_BUF_BYTES, "the final exchange re-uses ONE tile buffer (the other may be a DMA target)");
-
-// phase time stamps of one workgroup (DODA_DMA_DBG bit 7; tools/wdmastamps.py): [wave 0 | wave 5][item][phase]
-__device__ unsigned long long g_wd_stamps[2 * 16 * 8];
-__device__ __forceinline__ void wd_stamp(int dbg, int wid, int item, int phase) {
-    if ((dbg & 128) && blockIdx.x == 8 && (wid == 0 || wid == 5) && item < 16 && (threadIdx.x & 63) == 0)
-        g_wd_stamps[((wid ? 1 : 0) * 16 + item) * 8 + phase] = __builtin_amdgcn_s_memtime();
-}
 
 struct WdJob { const void *x, *dy; float *part; };    // part: [groups][27][256] of this layer
 struct WdJobs { int n; WdJob j[WD_MAX_JOBS]; };
@@ -97,7 +90,7 @@ __device__ __forceinline__ bf16x8 wd_pack_hi16(const f32x4 &d0, const f32x4 &d1)
 }
 
 __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned feat_bytes, const int32_t *__restrict__ tbl,
-                                                    int ld, int n, const TileBookView tb, const int dbg) {
+                                                    int ld, int n, const TileBookView tb) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WD_BUF_BYTES];
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, i = lane & 15, g = lane >> 4;
@@ -193,15 +186,7 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
         const unsigned short *lidx_s = reinterpret_cast<const unsigned short *>(buf + WD_ROWS_BYTES);
         const unsigned dy_base = rows_base + (unsigned)(WD_ROWS_BYTES + WD_LIDX_BYTES);
         const unsigned short *xg = reinterpret_cast<const unsigned short *>(jobs.j[qc.job].x);
-        wd_stamp(dbg, wid, item, 2);
         issue_list(q2, lnew);        // first thing: it has the whole tile to land (lnew held list(item): dead)
-        const bool early = (dbg & 256) != 0;      // (measurement) the next item's DMA at once instead of between the first steps
-        if (early) {
-            issue_rows(q1, item + 1, 0, lnext);
-            issue_rows(q1, item + 1, 1, lnext);
-            issue_strip(q1, item + 1);
-            issue_dy(q1, item + 1);
-        }
         // ---- dy fragments of the wave's four k-steps (every unit of wave w covers the half h = w & 1 of the tile):
         // channel i of rows 32 ks + 8 g + 0..7 ----
         const int q4 = i >> 2, c4 = i & 3, hw = wid & 1;
@@ -213,7 +198,6 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
             bt[kk] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bt[0]), "+v"(bt[1]), "+v"(bt[2]), "+v"(bt[3]) : : "memory");
-        wd_stamp(dbg, wid, item, 3);
         // (overflow path below) lane (i, g) reads the half g & 1 of the row of output row 32 ks + 8 (i >> 2) + 4 (g >> 1) + (i & 3)
         const int rl = 8 * (i >> 2) + 4 * (g >> 1) + (i & 3);
         const unsigned hsel = (unsigned)(g & 1);
@@ -231,7 +215,6 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
             const unsigned lane_off = rows_base + (unsigned)c4 * 8u;
             const unsigned sh = (unsigned)(g >> 1) * 16u;                 // entry 2 (ks & 1) + (g >> 1) of the strip position
             const bool tail_unit = wid + WD_WAVES * (WD_MAX_UNITS - 1) < WD_UNITS;   // the waves that own a unit 48 .. 53
-            wd_stamp(dbg, wid, item, 4);
 #pragma unroll
             for (int mp = 0; mp < WD_MAX_UNITS / 2; ++mp) {
                 unsigned ra[8], rb[8];
@@ -265,12 +248,10 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
                         const int gs = mp * 8 + st, m = gs >> 2, kk = gs & 3;
                         // the next item's DMA: in the FIRST steps of the tile (two buffers: it needs the rest of the tile to
                         // land), odd and even waves on alternating steps
-                        if (!early) {
-                            if (gs == (wid & 1)) issue_rows(q1, item + 1, 0, lnext);
-                            if (gs == 2 + (wid & 1)) issue_rows(q1, item + 1, 1, lnext);
-                            if (gs == 4 + (wid & 1)) issue_strip(q1, item + 1);
-                            if (gs == 6 + (wid & 1)) issue_dy(q1, item + 1);
-                        }
+                        if (gs == (wid & 1)) issue_rows(q1, item + 1, 0, lnext);
+                        if (gs == 2 + (wid & 1)) issue_rows(q1, item + 1, 1, lnext);
+                        if (gs == 4 + (wid & 1)) issue_strip(q1, item + 1);
+                        if (gs == 6 + (wid & 1)) issue_dy(q1, item + 1);
                         if (st + 2 < last) { xl[(st + 2) % 3] = wd_tr_b64<TAG>(ra[st + 2]); xh[(st + 2) % 3] = wd_tr_b64<TAG>(rb[st + 2]); }
                         // LDS returns in order: everything but the reads of the steps after this one has landed
                         const int newer = st + 2 < last ? 4 : 2 * (last - 1 - st);
@@ -335,7 +316,6 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
                     if (mm == m) acc[mm] += part;      // (static indices: acc[] stays in registers)
             }
         }
-        wd_stamp(dbg, wid, item, 5);
     };
 
     // the layer's partial: units -> LDS, halves added, one [27][256] block per workgroup
@@ -363,26 +343,22 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
-    bool nl_cur = __builtin_amdgcn_readfirstlane((int)la[0]) == -2 && !(dbg & 64);      // tile 0 has no list
+    bool nl_cur = __builtin_amdgcn_readfirstlane((int)la[0]) == -2;      // tile 0 has no list
     for (int item = 0; item < n_items; item += 2) {
         // everything issued so far has landed: DMA(item), list(item+1)
-        wd_stamp(dbg, wid, item, 0);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(lb) : : "memory");
-        wd_stamp(dbg, wid, item, 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         {
-            const bool nl_next = __builtin_amdgcn_readfirstlane((int)lb[0]) == -2 && !(dbg & 64);
+            const bool nl_next = __builtin_amdgcn_readfirstlane((int)lb[0]) == -2;
             body(item, nl_cur, lb, la);
             nl_cur = nl_next;
         }
         if ((item + 1) % nt_w == 0) flush(item / nt_w, item & 1);
         if (item + 1 >= n_items) break;
-        wd_stamp(dbg, wid, item + 1, 0);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(la) : : "memory");
-        wd_stamp(dbg, wid, item + 1, 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         {
-            const bool nl_next = __builtin_amdgcn_readfirstlane((int)la[0]) == -2 && !(dbg & 64);
+            const bool nl_next = __builtin_amdgcn_readfirstlane((int)la[0]) == -2;
             body(item + 1, nl_cur, la, lb);
             nl_cur = nl_next;
         }
@@ -454,8 +430,7 @@ int launch(const void *const *x, const void *const *dy, float *const *dw, const 
             jobs.j[k] = WdJob{x[first + k], dy[first + k], p};
             rj.j[k] = WdRJob{p, dw[first + k], accumulate[first + k], 0};
         }
-        static const int dbg = getenv("DODA_DMA_DBG") ? atoi(getenv("DODA_DMA_DBG")) : 0;   // ablation switches (measurements only)
-        hipLaunchKernelGGL(wgrad_dma16, dim3(groups), dim3(1024), 0, s, jobs, (unsigned)((size_t)n_rows * 32), tbl, ld, n_rows, tb, dbg);
+        hipLaunchKernelGGL(wgrad_dma16, dim3(groups), dim3(1024), 0, s, jobs, (unsigned)((size_t)n_rows * 32), tbl, ld, n_rows, tb);
         hipLaunchKernelGGL(wgrad_dma_reduce, dim3(TB_K * 256 / 32, nj), dim3(512), 0, s, rj, groups);
     }
     return doda_check_launch();
@@ -463,10 +438,3 @@ int launch(const void *const *x, const void *const *dy, float *const *dw, const 
 
 }  // namespace doda_wdma
 
-extern "C" void doda_spconv_set_wdma_kernel(int32_t on) { doda_wdma::set_enabled(on != 0); }
-
-// measurement aid: kernel 0 = conv_dma16 (spconv_dma.hip), 1 = wgrad_dma16
-extern "C" int doda_debug_wdma_stamps(unsigned long long *dst_h) {
-    return hipMemcpyFromSymbol(dst_h, HIP_SYMBOL(g_wd_stamps), sizeof(unsigned long long) * 2 * 16 * 8) == hipSuccess ? DODA_OK
-                                                                                                                   : DODA_ERR_LAUNCH;
-}

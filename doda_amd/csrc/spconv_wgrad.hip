@@ -265,17 +265,6 @@ __device__ __forceinline__ void wgrad_body(const typename T::elem *__restrict__ 
     }
 }
 
-template <class T, int TA, int TB, int OGW, bool VOK>
-__global__ __launch_bounds__(256) void wgrad_kernel(const typename T::elem *__restrict__ a, int ca,
-                                                    const typename T::elem *__restrict__ b, int cb,
-                                                    const int32_t *__restrict__ tbl, int ld, int K,
-                                                    int n_rows, int rows_per_chunk, int n_tag,
-                                                    int n_tbg, int n_og, float *__restrict__ partial) {
-    // contiguous items per XCD
-    wgrad_body<T, TA, TB, OGW, VOK>(a, ca, b, cb, tbl, ld, K, n_rows, rows_per_chunk, n_tag, n_tbg, n_og,
-                                    partial, xcd_work_item(blockIdx.x, gridDim.x));
-}
-
 // ---- many layers in one launch --------------------------------------------------------------
 // The weight gradients of a network are independent of the rest of the backward pass.  Queued and
 // launched together (one launch per kernel variant, one reduce launch), the 71 x 2 launches of a U-Net
@@ -365,39 +354,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float *__restrict__ pa
     }
 }
 
-// float4 flavour for n_elem % 4 == 0: LANES chunk lanes per element quad (1 = a thread walks all R
-// chunks itself).  The launcher picks LANES from (n_elem, R) only, so the summation order of a given
-// layer shape is fixed.  Coarse levels have few chunks and many elements (27 x 112 x 112): the
-// 16-lane kernel above spends its time on 20k nearly idle blocks there.
-template <int LANES>
-__global__ __launch_bounds__(256) void wgrad_reduce4(const float4 *__restrict__ partial, int R,
-                                                     long long n_quad, float4 *__restrict__ dw) {
-    constexpr int EPB = 256 / LANES;
-    __shared__ float4 part[LANES][EPB];
-    const int el = threadIdx.x % EPB, rl = threadIdx.x / EPB;
-    const long long q = (long long)blockIdx.x * EPB + el;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q < n_quad)
-        for (int r = rl; r < R; r += LANES) {
-            const float4 v = partial[(long long)r * n_quad + q];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-    if (LANES == 1) {
-        if (q < n_quad) dw[q] = s;
-        return;
-    }
-    part[rl][el] = s;
-    __syncthreads();
-    if (rl == 0 && q < n_quad) {
-        float4 t = part[0][el];
-#pragma unroll 4
-        for (int r = 1; r < LANES; ++r) {
-            const float4 v = part[r][el];
-            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-        }
-        dw[q] = t;
-    }
-}
 
 struct Plan {
     int TA, TB, OGW, n_og, n_tag, n_tbg, R, rows_per_chunk;
@@ -448,78 +404,6 @@ Plan make_plan(int K, int ca, int cb, int n_rows, int elem_bytes, bool multi = f
     return p;
 }
 
-template <class T>
-int run_wgrad(const void *a_, int ca, const void *b_, int cb, const int32_t *tbl, int ld, int K,
-              int n_rows, float *dw, void *ws, size_t ws_bytes, hipStream_t s) {
-    typedef typename T::elem elem;
-    const elem *a = (const elem *)a_, *b = (const elem *)b_;
-    const long long n_elem = (long long)K * ca * cb;
-    const Plan p = make_plan(K, ca, cb, n_rows, (int)sizeof(elem));
-    if (ws_bytes < (size_t)p.R * n_elem * 4) return DODA_ERR_WORKSPACE;
-    // a single row chunk needs no reduction: the kernel writes dw itself
-    float *partial = p.R == 1 ? dw : (float *)ws;
-    // 16-byte row vectors need 16-byte aligned rows in both operands
-    const int vec_ok = ((size_t)ca * sizeof(elem) % 16 == 0) && ((size_t)cb * sizeof(elem) % 16 == 0) &&
-                       ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0);
-    const dim3 grid(p.R * p.n_tag * p.n_tbg * p.n_og), block(256);
-#define GO(TA, TB, OG)                                                                             \
-    do {                                                                                           \
-        if (vec_ok)                                                                                \
-            hipLaunchKernelGGL((wgrad_kernel<T, TA, TB, OG, true>), grid, block, 0, s, a, ca, b, cb, tbl, \
-                               ld, K, n_rows, p.rows_per_chunk, p.n_tag, p.n_tbg, p.n_og, partial); \
-        else                                                                                       \
-            hipLaunchKernelGGL((wgrad_kernel<T, TA, TB, OG, false>), grid, block, 0, s, a, ca, b, cb, tbl, \
-                               ld, K, n_rows, p.rows_per_chunk, p.n_tag, p.n_tbg, p.n_og, partial); \
-    } while (0)
-    if (p.OGW == 2) {
-        if (p.TA == 3 && p.TB == 3) GO(3, 3, 2);
-        else if (p.TA == 1 && p.TB == 1) GO(1, 1, 2);
-        else if (p.TA == 2 && p.TB == 1) GO(2, 1, 2);
-        else if (p.TA == 1 && p.TB == 2) GO(1, 2, 2);
-        else GO(2, 2, 2);
-    } else if (p.OGW == 4 && p.TA == 1 && p.TB == 1) GO(1, 1, 4);
-    else if (p.OGW == 4 && p.TA == 2 && p.TB == 1) GO(2, 1, 4);
-    else if (p.OGW == 4 && p.TA == 1 && p.TB == 2) GO(1, 2, 4);
-    else if (p.TA == 1 && p.TB == 1) GO(1, 1, 7);
-    else if (p.TA == 2 && p.TB == 1) GO(2, 1, 7);
-    else if (p.TA == 1 && p.TB == 2) GO(1, 2, 7);
-    else GO(2, 2, 4);
-#undef GO
-    int st = doda_check_launch();
-    if (st != DODA_OK) return st;
-    if (p.R == 1) return DODA_OK;
-    if (n_elem % 4 == 0 && (uintptr_t)dw % 16 == 0) {
-        const long long n_quad = n_elem / 4;
-        // fewest chunk lanes that still give >= 512 blocks, never more lanes than chunks need
-        int lanes = 1;
-        while (lanes < 64 && lanes < p.R && n_quad * lanes / 256 < 512) lanes *= 4;
-        const dim3 grid(div_up(n_quad, 256 / lanes));
-        const float4 *src = (const float4 *)partial;
-        float4 *dst = (float4 *)dw;
-        if (lanes == 1) hipLaunchKernelGGL(wgrad_reduce4<1>, grid, dim3(256), 0, s, src, p.R, n_quad, dst);
-        else if (lanes == 4) hipLaunchKernelGGL(wgrad_reduce4<4>, grid, dim3(256), 0, s, src, p.R, n_quad, dst);
-        else if (lanes == 16) hipLaunchKernelGGL(wgrad_reduce4<16>, grid, dim3(256), 0, s, src, p.R, n_quad, dst);
-        else hipLaunchKernelGGL(wgrad_reduce4<64>, grid, dim3(256), 0, s, src, p.R, n_quad, dst);
-        return doda_check_launch();
-    }
-    hipLaunchKernelGGL(wgrad_reduce, dim3(div_up(n_elem, 16)), dim3(256), 0, s, partial, p.R,
-                       n_elem, dw);
-    return doda_check_launch();
-}
-
-int check_args(const void *a, int ca, const void *b, int cb, const int32_t *tbl, int ld, int K,
-               int n_rows, float *dw, void *ws, hipStream_t s, bool *done) {
-    *done = true;
-    if (ca <= 0 || cb <= 0 || K <= 0 || n_rows < 0 || ld < n_rows || !dw) return DODA_ERR_INVALID;
-    if (K > 4 * MAX_OGW) return DODA_ERR_UNSUPPORTED;
-    if (n_rows == 0) {
-        hipMemsetAsync(dw, 0, (size_t)K * ca * cb * 4, s);
-        return DODA_OK;
-    }
-    if (!a || !b || !tbl || !ws) return DODA_ERR_INVALID;
-    *done = false;
-    return DODA_OK;
-}
 // ---- host side of the many-layer launch -------------------------------------------------------
 struct JobPlan {
     Plan p;
@@ -787,73 +671,4 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
                                jobs_h[k].dw, (jobs_h[k].flags & DODA_WGRAD_ACCUMULATE) ? 1 : 0);
         }
     return doda_check_launch();
-}
-
-// ---- pair-list kernel, single layer ------------------------------------------------------------
-static doda_wgrad_job pairs_job(const uint16_t *a, int32_t n_a, int32_t ca, const uint16_t *b, int32_t n_b,
-                                int32_t cb, const int32_t *pin, const int32_t *pout, const int32_t *pnum,
-                                int32_t ld, int32_t K, float *dw, int32_t accumulate,
-                                const int32_t *seg = nullptr, int32_t seg_nt = 0) {
-    doda_wgrad_job j;
-    memset(&j, 0, sizeof(j));
-    j.a = a; j.b = b; j.dw = dw;
-    j.ca = ca; j.cb = cb; j.ld = ld; j.K = K; j.n_rows = n_b; j.elem_bytes = 2;
-    j.pair_in = pin; j.pair_out = pout; j.pair_num = pnum; j.pair_ld = ld; j.n_a = n_a;
-    j.flags = accumulate ? DODA_WGRAD_ACCUMULATE : 0;
-    j.pair_seg = seg;
-    j.pair_seg_nt = seg_nt;
-    return j;
-}
-
-extern "C" size_t doda_spconv_wgrad_pairs_workspace_bytes(int32_t K, int32_t ca, int32_t cb, int32_t ld) {
-    if (K <= 0 || ca <= 0 || cb <= 0 || ld <= 0) return 256;
-    doda_wgrad_job j = pairs_job(nullptr, ld, ca, nullptr, ld, cb, nullptr, nullptr, nullptr, ld, K, nullptr, 1);
-    return doda_pairs::partial_bytes(j) + doda_spconv_wgrad_multi_desc_bytes(1);
-}
-
-extern "C" int doda_spconv_wgrad_pairs_bf16(const uint16_t *a, int32_t n_a, int32_t ca, const uint16_t *b,
-                                            int32_t n_b, int32_t cb, const int32_t *pair_in,
-                                            const int32_t *pair_out, const int32_t *pair_num,
-                                            const int32_t *pair_seg, int32_t seg_nt, int32_t ld, int32_t K,
-                                            float *dw, int32_t accumulate, void *ws, size_t ws_bytes,
-                                            doda_stream_t stream) {
-    if (!a || !b || !dw || !ws || K <= 0 || ca <= 0 || cb <= 0 || n_b < 0 || ld < 0) return DODA_ERR_INVALID;
-    hipStream_t s = as_stream(stream);
-    if (n_b == 0 || ld == 0) {
-        if (!accumulate) hipMemsetAsync(dw, 0, (size_t)K * ca * cb * 4, s);
-        return DODA_OK;
-    }
-    const doda_wgrad_job j = pairs_job(a, n_a, ca, b, n_b, cb, pair_in, pair_out, pair_num, ld, K, dw, accumulate,
-                                       pair_seg, seg_nt);
-    if (!doda_pairs::eligible(j)) return DODA_ERR_UNSUPPORTED;
-    const size_t pbytes = doda_pairs::partial_bytes(j);
-    const size_t dbytes = doda_spconv_wgrad_multi_desc_bytes(1);
-    if (ws_bytes < pbytes + dbytes) return DODA_ERR_WORKSPACE;
-    // the tail of the workspace receives the device descriptors
-    return doda_spconv_wgrad_multi(&j, 1, ws, pbytes, (char *)ws + pbytes, dbytes, stream);
-}
-
-extern "C" size_t doda_spconv_wgrad_workspace_bytes(int32_t K, int32_t ca, int32_t cb,
-                                                    int32_t n_rows) {
-    if (K <= 0 || ca <= 0 || cb <= 0) return 0;
-    const Plan p2 = make_plan(K, ca, cb, n_rows, 2), p4 = make_plan(K, ca, cb, n_rows, 4);
-    return align_up((size_t)(p2.R > p4.R ? p2.R : p4.R) * K * ca * cb * 4, 256);
-}
-
-extern "C" int doda_spconv_wgrad_f32(const float *a, int32_t ca, const float *b, int32_t cb,
-                                     const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows,
-                                     float *dw, void *ws, size_t ws_bytes, doda_stream_t stream) {
-    bool done;
-    const int st = check_args(a, ca, b, cb, tbl, ld, K, n_rows, dw, ws, as_stream(stream), &done);
-    if (done) return st;
-    return run_wgrad<F32>(a, ca, b, cb, tbl, ld, K, n_rows, dw, ws, ws_bytes, as_stream(stream));
-}
-
-extern "C" int doda_spconv_wgrad_bf16(const uint16_t *a, int32_t ca, const uint16_t *b, int32_t cb,
-                                      const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows,
-                                      float *dw, void *ws, size_t ws_bytes, doda_stream_t stream) {
-    bool done;
-    const int st = check_args(a, ca, b, cb, tbl, ld, K, n_rows, dw, ws, as_stream(stream), &done);
-    if (done) return st;
-    return run_wgrad<BF16>(a, ca, b, cb, tbl, ld, K, n_rows, dw, ws, ws_bytes, as_stream(stream));
 }

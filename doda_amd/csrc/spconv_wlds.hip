@@ -73,8 +73,8 @@ __device__ __forceinline__ void wlds_epilogue(f32x4 (&acc)[S], int row0, int i, 
 #pragma unroll
             for (int w = 1; w < 8; ++w) { a1 += sred[w][0][g]; a2 += sred[w][1][g]; }
             float *dst = ep.stats + (long long)part * 2 * WCH + col;
-            stats_store4(dst, a1);
-            stats_store4(dst + WCH, a2);
+            *reinterpret_cast<f32x4 *>(dst) = a1;
+            *reinterpret_cast<f32x4 *>(dst + WCH) = a2;
         }
         __syncthreads();   // sred is reused by the next channel block / tile
     }
@@ -180,7 +180,6 @@ __global__ __launch_bounds__(512) void conv_wlds48(const unsigned short *__restr
         for (int nb = 0; nb < WNB; ++nb)
             wlds_epilogue<S, STATS>(acc[nb], row0, i, g, wid, nb, n_out, rs_y, res, y_bytes, ep, tile, sred);
     }
-    if constexpr (STATS) stats_finish(ep, WCH);
 }
 
 }  // namespace
@@ -194,8 +193,7 @@ int doda_wlds::launch_conv48(const void *x, unsigned x_bytes, const void *wp, co
     const int n_tiles = (n_out + 255) / 256;
     const int grid = n_tiles < 256 ? n_tiles : 256;
     if (n_part) *n_part = n_tiles;
-    EpiArgs ep = ep_in;
-    if (ep.stats) doda_fin::arm(ep, n_tiles, (unsigned)grid, s);
+    const EpiArgs &ep = ep_in;
     static bool attr_done = false;
     if (!attr_done) {   // more than 64 KB of dynamic LDS needs the opt-in
         if (hipFuncSetAttribute((const void *)conv_wlds48<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES) != hipSuccess ||

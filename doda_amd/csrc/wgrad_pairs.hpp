@@ -35,6 +35,7 @@ size_t desc_bytes_per_job();
 // LDS-staged weight gradient over a tilebook (spconv_wdma.hip): bf16 16 -> 16 layers sharing one table
 namespace doda_wdma {
 bool enabled();
+void set_enabled(bool on);
 int max_jobs();
 size_t partial_bytes(int n_rows);      // workspace per layer
 int launch(const void *const *x, const void *const *dy, float *const *dw, const int *accumulate, int n_layers,

@@ -13,6 +13,7 @@
 #include <torch/csrc/autograd/graph_task.h>
 #include <torch/csrc/autograd/saved_variable.h>
 #include <c10/hip/HIPGuard.h>
+#include <unordered_map>
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 
@@ -51,17 +52,6 @@ struct GatherEpi {
     at::Tensor stats;
 };
 
-// BatchNorm(+ReLU) whose apply pass rides in the consuming conv's PROLOGUE (ABI 6, doda_conv_epilogue.pre_*): the
-// BatchNorm op runs its reduction only and hands these to the conv, which reads the BatchNorm's INPUT x, normalises
-// the rows while staging them, and writes the BatchNorm's output z (the tensor the autograd graph knows as the conv's
-// input, saved for the weight gradient) as a side output.
-struct PreArgs {
-    bool active = false;
-    at::Tensor x, mean, invstd, gamma, beta;
-    bool relu = false;
-};
-bool g_bn_prologue = false;   // measured slower than the apply launch it removes (csrc/spconv_tile.hip, PRE): opt-in
-
 // A SubM table allocated by table_with_tilebook() carries its tilebook (doda_tilebook_build) in the same
 // storage, 256-byte aligned behind the K x ld entries: the table tensor is the one handle every layer of
 // the rulebook already passes around (forward, data-grad, saved for backward), so the tilebook reaches
@@ -95,10 +85,8 @@ void build_tilebook(const at::Tensor &tbl, void *st) {
 // y[t] = sum_o x[tbl[o][t]] . B_o   (include/doda_hip.h: doda_spconv_gather_ex)
 at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
                   const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32,
-                  const c10::optional<at::Tensor> &residual = c10::nullopt, GatherEpi *epi = nullptr,
-                  const PreArgs *pre = nullptr) {
-    // with a prologue x_in is the (still unwritten) normalised tensor: the kernel reads pre->x and writes x_in
-    const at::Tensor x = (pre && pre->active) ? pre->x : x_in.contiguous();
+                  const c10::optional<at::Tensor> &residual = c10::nullopt, GatherEpi *epi = nullptr) {
+    const at::Tensor x = x_in.contiguous();
     TORCH_CHECK(x.is_cuda() && x.dim() == 2 && tbl.is_cuda() && tbl.dim() == 2, "doda gather: bad inputs");
     const int esz = elem_bytes(x);
     const int64_t K = tbl.size(0), ld = tbl.size(1), kc = x.size(1);
@@ -113,20 +101,14 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
     }
     doda_conv_epilogue ep;
     memset(&ep, 0, sizeof(ep));
-    int32_t stats_rows = 0, finished = 0;
-    at::Tensor stats, totals;
+    int32_t stats_rows = 0;
+    at::Tensor stats;
     ep.residual = res.defined() ? res.data_ptr() : nullptr;
     bool with_stats = epi && epi->want && n_out > 0;
     if (with_stats) {
         stats = at::empty({(int64_t)doda_spconv_stats_capacity((int32_t)n_out), 2, nc}, x.options().dtype(at::kFloat));
         ep.stats = (float *)stats.data_ptr();
         ep.stats_rows_h = &stats_rows;
-        // the conv kernel's last workgroup sums the rows itself when it can (ABI 5): the BatchNorm then gets totals
-        if (nc <= 256 && doda_spconv_get_stats_finish()) {   // (off by default: no allocation then — ~80 per step)
-            totals = at::empty({1, 2, nc}, x.options().dtype(at::kDouble));
-            ep.totals = (double *)totals.data_ptr();
-            ep.finished_h = &finished;
-        }
         if (epi->bn_x.defined()) {
             TORCH_CHECK(epi->bn_x.scalar_type() == y.scalar_type() && epi->bn_x.is_contiguous() &&
                         epi->bn_x.size(0) == n_out && epi->bn_x.size(1) == nc, "doda gather: bn_x must match the output");
@@ -140,16 +122,6 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
     }
     ep.tilebook = tilebook_behind(tbl, n_out);
     ep.tilebook_rows = ep.tilebook ? (int32_t)n_out : 0;
-    if (pre && pre->active) {
-        TORCH_CHECK(x_in.is_contiguous() && x_in.sizes() == x.sizes() && x_in.scalar_type() == x.scalar_type(),
-                    "doda gather: the prologue's output must be shaped like its input");
-        ep.pre_mean = (const float *)pre->mean.data_ptr();
-        ep.pre_invstd = (const float *)pre->invstd.data_ptr();
-        ep.pre_gamma = (const float *)pre->gamma.data_ptr();
-        ep.pre_beta = (const float *)pre->beta.data_ptr();
-        ep.pre_relu = pre->relu ? 1 : 0;
-        ep.pre_out = x_in.data_ptr();
-    }
     const void *wptr;
     void *ws = nullptr;
     size_t ws_bytes = 0;
@@ -180,8 +152,6 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
             with_stats = false;
             ep.stats = nullptr;
             ep.stats_rows_h = nullptr;
-            ep.totals = nullptr;
-            ep.finished_h = nullptr;
             ep.bn_x = nullptr;
             use_packed = packed.has_value() && packed->defined();
             continue;
@@ -189,10 +159,7 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
         check(status, "doda_spconv_gather");
         break;
     }
-    if (epi) {
-        if (with_stats && finished) epi->stats = totals;      // double [1, 2, nc]: already summed over all rows
-        else epi->stats = (with_stats && stats_rows > 0) ? stats.narrow(0, 0, stats_rows) : at::Tensor();
-    }
+    if (epi) epi->stats = (with_stats && stats_rows > 0) ? stats.narrow(0, 0, stats_rows) : at::Tensor();
     return y;
 }
 
@@ -216,48 +183,26 @@ at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tenso
     const int esz = elem_bytes(a);
     const int64_t K = tbl.size(0), ld = tbl.size(1), ca = a.size(1), cb = b.size(1);
     at::Tensor dw = at::empty({K, ca, cb}, a.options().dtype(at::kFloat));
+    // one job of the multi-layer entry point (ABI 7: the only weight-gradient entry point); the library picks the
+    // kernel: LDS-staged over the tilebook, pair lists, or the gather table
+    doda_wgrad_job j;
+    memset(&j, 0, sizeof(j));
+    j.a = a.data_ptr(); j.b = b.data_ptr(); j.tbl = (const int32_t *)tbl.data_ptr(); j.dw = (float *)dw.data_ptr();
+    j.ca = (int32_t)ca; j.cb = (int32_t)cb; j.ld = (int32_t)ld; j.K = (int32_t)K; j.n_rows = (int32_t)n_rows;
+    j.elem_bytes = esz; j.n_a = (int32_t)a.size(0);
+    j.tilebook = tilebook_behind(tbl, n_rows);
     if (pairs_usable(a, b, pl)) {
-        const size_t wsb = doda_spconv_wgrad_pairs_workspace_bytes((int)K, (int)ca, (int)cb, (int)pl.ld());
-        at::Tensor ws = at::empty({(int64_t)wsb}, a.options().dtype(at::kByte));
-        const int status = doda_spconv_wgrad_pairs_bf16(
-            (const uint16_t *)a.data_ptr(), (int)a.size(0), (int)ca, (const uint16_t *)b.data_ptr(), (int)b.size(0),
-            (int)cb, (const int32_t *)pl.in.data_ptr(), (const int32_t *)pl.out.data_ptr(),
-            pl.num.defined() ? (const int32_t *)pl.num.data_ptr() : nullptr,
-            pl.seg.defined() ? (const int32_t *)pl.seg.data_ptr() : nullptr,
-            pl.seg.defined() ? (int)pl.seg.size(1) : 0, (int)pl.ld(), (int)K,
-            (float *)dw.data_ptr(), 0, ws.data_ptr(), wsb, stream_of(a));
-        if (status != DODA_ERR_UNSUPPORTED) {
-            check(status, "doda_spconv_wgrad_pairs");
-            return dw;
-        }
+        j.pair_in = (const int32_t *)pl.in.data_ptr();
+        j.pair_out = (const int32_t *)pl.out.data_ptr();
+        j.pair_num = pl.num.defined() ? (const int32_t *)pl.num.data_ptr() : nullptr;
+        j.pair_ld = (int32_t)pl.ld();
+        j.pair_seg = pl.seg.defined() ? (const int32_t *)pl.seg.data_ptr() : nullptr;
+        j.pair_seg_nt = pl.seg.defined() ? (int32_t)pl.seg.size(1) : 0;
     }
-    if (esz == 2 && ca % 16 == 0 && cb % 16 == 0 && n_rows > 0) {
-        // job form: carries the row count of `a` (range check of the MFMA-transpose kernel)
-        doda_wgrad_job j;
-        memset(&j, 0, sizeof(j));
-        j.a = a.data_ptr(); j.b = b.data_ptr(); j.tbl = (const int32_t *)tbl.data_ptr(); j.dw = (float *)dw.data_ptr();
-        j.ca = (int32_t)ca; j.cb = (int32_t)cb; j.ld = (int32_t)ld; j.K = (int32_t)K; j.n_rows = (int32_t)n_rows;
-        j.elem_bytes = 2; j.n_a = (int32_t)a.size(0);
-        j.tilebook = tilebook_behind(tbl, n_rows);   // LDS-staged kernel when the table carries its tilebook (16 -> 16)
-        const size_t wsb = doda_spconv_wgrad_multi_workspace_bytes(&j, 1), dsb = doda_spconv_wgrad_multi_desc_bytes(1);
-        at::Tensor ws = at::empty({(int64_t)wsb}, a.options().dtype(at::kByte));
-        at::Tensor desc = at::empty({(int64_t)dsb}, a.options().dtype(at::kByte));
-        check(doda_spconv_wgrad_multi(&j, 1, ws.data_ptr(), wsb, desc.data_ptr(), dsb, stream_of(a)),
-              "doda_spconv_wgrad_multi");
-        return dw;
-    }
-    const size_t wsb = doda_spconv_wgrad_workspace_bytes((int)K, (int)ca, (int)cb, (int)n_rows);
-    at::Tensor ws = at::empty({(int64_t)(wsb > 256 ? wsb : 256)}, a.options().dtype(at::kByte));
-    int status;
-    if (esz == 4)
-        status = doda_spconv_wgrad_f32((const float *)a.data_ptr(), (int)ca, (const float *)b.data_ptr(), (int)cb,
-                                       (const int32_t *)tbl.data_ptr(), (int)ld, (int)K, (int)n_rows,
-                                       (float *)dw.data_ptr(), ws.data_ptr(), (size_t)ws.numel(), stream_of(a));
-    else
-        status = doda_spconv_wgrad_bf16((const uint16_t *)a.data_ptr(), (int)ca, (const uint16_t *)b.data_ptr(),
-                                        (int)cb, (const int32_t *)tbl.data_ptr(), (int)ld, (int)K, (int)n_rows,
-                                        (float *)dw.data_ptr(), ws.data_ptr(), (size_t)ws.numel(), stream_of(a));
-    check(status, "doda_spconv_wgrad");
+    const size_t wsb = doda_spconv_wgrad_multi_workspace_bytes(&j, 1), dsb = doda_spconv_wgrad_multi_desc_bytes(1);
+    at::Tensor ws = at::empty({(int64_t)wsb}, a.options().dtype(at::kByte));
+    at::Tensor desc = at::empty({(int64_t)dsb}, a.options().dtype(at::kByte));
+    check(doda_spconv_wgrad_multi(&j, 1, ws.data_ptr(), wsb, desc.data_ptr(), dsb, stream_of(a)), "doda_spconv_wgrad_multi");
     return dw;
 }
 
@@ -283,14 +228,22 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> export_pairs(const at::Tensor &tb
 // with hipEventBlockingSync.  Tensor::item() waits in hipStreamSynchronize, which spins by default: the rulebook thread
 // makes six such waits per step (~1.5 ms of a core) next to the issuing thread, which is what paces the step on a busy
 // host.  DODA_SPIN_READBACK=1 restores item().
-bool read_back_blocking(const void *dev_ptr, int32_t *out, int n, void *st) {   // n <= 16; false: the caller spins
+bool read_back_blocking(const void *dev_ptr, int32_t *out, int n, void *st, int dev) {   // n <= 16; st: a stream of device `dev`; false: the caller spins
     static const bool spin = getenv("DODA_SPIN_READBACK") && getenv("DODA_SPIN_READBACK")[0] == '1';
     if (spin) return false;
-    struct Slot { int32_t *host = nullptr; hipEvent_t ev = nullptr; };
+    struct Slot { int32_t *host = nullptr; hipEvent_t ev = nullptr; int dev = -1; };
     static thread_local Slot slot;
-    if (!slot.host) {
+    // the event belongs to the device it was created on: a thread that later builds a pyramid on another device gets a
+    // new one under that device's guard (recording a foreign-device event on the stream fails); the pinned buffer is shared
+    const int cur = dev;
+    c10::hip::HIPGuard dev_guard((c10::DeviceIndex)dev);
+    if (!slot.host)
         TORCH_CHECK(hipHostMalloc((void **)&slot.host, 64, hipHostMallocDefault) == hipSuccess, "doda: hipHostMalloc");
+    if (!slot.ev || slot.dev != cur) {
+        if (slot.ev) (void)hipEventDestroy(slot.ev);
+        slot.ev = nullptr;
         TORCH_CHECK(hipEventCreateWithFlags(&slot.ev, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess, "doda: hipEventCreate");
+        slot.dev = cur;
     }
     TORCH_CHECK(hipMemcpyAsync(slot.host, dev_ptr, (size_t)n * 4, hipMemcpyDeviceToHost, (hipStream_t)st) == hipSuccess, "doda: hipMemcpyAsync");
     TORCH_CHECK(hipEventRecord(slot.ev, (hipStream_t)st) == hipSuccess, "doda: hipEventRecord");
@@ -300,7 +253,7 @@ bool read_back_blocking(const void *dev_ptr, int32_t *out, int n, void *st) {   
 }
 int32_t read_back_i32(const at::Tensor &t, void *st) {
     int32_t v = 0;
-    if (read_back_blocking(t.data_ptr(), &v, 1, st)) return v;
+    if (read_back_blocking(t.data_ptr(), &v, 1, st, (int)t.device().index())) return v;
     return t.item<int32_t>();
 }
 
@@ -374,6 +327,59 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
 // its gradient on the spot).  AccumulateGrad hooks do not see these gradients, so torch DDP must not be
 // combined with deferral (doda_amd.dist reduces gradients itself).  If a backward pass aborts, its
 // queued jobs are dropped when the next pass starts (different graph-task id).
+// ---- gradient homes (doda_amd.dist.GradAllReduce) -------------------------------------------------------------
+// Data-parallel training all-reduces the gradients in a few flat buckets (reference tool/train.py:360-361: DDP's
+// bucket views).  A parameter may be given a HOME: a view of its bucket.  The kernels that produce the parameter's
+// gradient — the deferred weight-gradient launch for conv weights, the BatchNorm backward for gamma / beta — then write
+// straight into the home and .grad becomes an alias of it: the reducer finds every byte in place (no torch.cat before
+// the collective, no copy back after it).  A home is used only for the FIRST gradient of a parameter in an optimizer
+// step (.grad undefined, and for BatchNorm not handed out yet in this backward pass); anything else — a second
+// backward pass, a shared module — takes the ordinary path and is accumulated by autograd / DODA_WGRAD_ACCUMULATE.
+struct GradHome {
+    c10::weak_intrusive_ptr<c10::TensorImpl> owner;
+    at::Tensor view;
+    int task = -2;       // graph task that last took it (BatchNorm nodes)
+    GradHome(const at::Tensor &param, const at::Tensor &v)
+        : owner(c10::weak_intrusive_ptr<c10::TensorImpl>(param.getIntrusivePtr())), view(v) {}
+};
+std::mutex g_home_mu;
+std::unordered_map<c10::TensorImpl *, GradHome> g_homes;
+
+void set_grad_home(const at::Tensor &param, const c10::optional<at::Tensor> &view) {
+    std::lock_guard<std::mutex> lock(g_home_mu);
+    c10::TensorImpl *key = param.unsafeGetTensorImpl();
+    if (!view.has_value() || !view->defined()) {
+        g_homes.erase(key);
+        return;
+    }
+    TORCH_CHECK(view->sizes() == param.sizes() && view->scalar_type() == param.scalar_type() && view->device() == param.device() &&
+                view->is_contiguous() && !view->requires_grad(), "doda set_grad_home: the view must be a contiguous tensor shaped like the parameter");
+    g_homes.erase(key);
+    g_homes.emplace(key, GradHome(param, *view));
+}
+void clear_grad_homes() {
+    std::lock_guard<std::mutex> lock(g_home_mu);
+    g_homes.clear();
+}
+// an alias of the parameter's home, or undefined.  task >= 0: not twice within one graph task.
+at::Tensor take_grad_home(const at::Tensor &param, int task = -1) {
+    if (!param.defined() || param.grad().defined()) return at::Tensor();
+    std::lock_guard<std::mutex> lock(g_home_mu);
+    if (g_homes.empty()) return at::Tensor();
+    auto it = g_homes.find(param.unsafeGetTensorImpl());
+    if (it == g_homes.end()) return at::Tensor();
+    auto alive = it->second.owner.lock();
+    if (!alive || alive.get() != param.unsafeGetTensorImpl()) {   // the parameter died and its address was reused
+        g_homes.erase(it);
+        return at::Tensor();
+    }
+    if (task >= 0) {
+        if (it->second.task == task) return at::Tensor();
+        it->second.task = task;
+    }
+    return it->second.view.alias();
+}
+
 struct PendingWgrad {
     at::Tensor a, b, tbl, weight;
     PairLists pl;
@@ -399,7 +405,9 @@ void issue_wgrads(std::vector<PendingWgrad> &q, const c10::hip::HIPStream &st) {
             flags = DODA_WGRAD_ACCUMULATE;
         } else {
             TORCH_CHECK(!target.defined(), "doda deferred wgrad: existing .grad of a conv weight is not a contiguous fp32 tensor");
-            target = fresh[k] = at::empty(p.weight.sizes(), p.weight.options());
+            target = take_grad_home(p.weight);     // the reducer's bucket view, when the weight has one
+            if (!target.defined()) target = at::empty(p.weight.sizes(), p.weight.options());
+            fresh[k] = target;
         }
         doda_wgrad_job j;
         memset(&j, 0, sizeof(j));
@@ -606,7 +614,7 @@ std::vector<at::Tensor> indice_conv_impl(const at::Tensor &features, const at::T
                        const c10::optional<at::Tensor> &pk_fwd, const c10::optional<at::Tensor> &pk_bwd,
                        const c10::optional<at::Tensor> &residual, const c10::optional<at::Tensor> &pair_in,
                        const c10::optional<at::Tensor> &pair_out, const c10::optional<at::Tensor> &pair_num,
-                       const c10::optional<at::Tensor> &pair_seg, bool want_stats, const PreArgs *pre = nullptr) {
+                       const c10::optional<at::Tensor> &pair_seg, bool want_stats) {
     const at::Tensor res = residual.has_value() ? *residual : at::Tensor();
     const bool need_grad = at::GradMode::is_enabled() &&
                            (features.requires_grad() || weight.requires_grad() || (res.defined() && res.requires_grad()));
@@ -616,7 +624,7 @@ std::vector<at::Tensor> indice_conv_impl(const at::Tensor &features, const at::T
     epi.want = want_stats;
     {
         at::AutoDispatchBelowADInplaceOrView guard;
-        y = gather(features, weight.reshape({K, cin, cout}), pk_fwd, fwd_tbl, n_out, 0, cout, false, residual, &epi, pre);
+        y = gather(features, weight.reshape({K, cin, cout}), pk_fwd, fwd_tbl, n_out, 0, cout, false, residual, &epi);
     }
     // the BatchNorm that produced `features` (if it was the last fused BatchNorm and its output is this tensor)
     std::shared_ptr<BNLink> link;
@@ -667,7 +675,7 @@ at::Tensor indice_conv(const at::Tensor &features, const at::Tensor &weight, con
                             pair_out, pair_num, pair_seg, false)[0];
 }
 
-// The second gradient of a BatchNorm's input as the backward kernels take it (doda_bn_relu_bwd_*_ld): dense, or — without
+// The second gradient of a BatchNorm's input as the backward kernels take it (doda_bn_relu_bwd_stats / _bwd_add, `add_ld`): dense, or — without
 // a copy — a column slice of a wider matrix whose rows lie `ld` elements apart: what torch.cat's backward hands to the
 // skip connection of a U-Net level (reference model/unet_block.py:93).
 at::Tensor add_operand(const at::Tensor &e, int64_t m, int64_t c, int64_t &ld) {
@@ -704,6 +712,14 @@ struct BNNode : public torch::autograd::Node {
         const at::Tensor dy = grads[0].contiguous();
         at::Tensor dx, dg, db;
         at::Tensor stats;
+        // gamma / beta gradients straight into the reducer's bucket views when the parameters have homes (fp32 leaves
+        // whose .grad is still undefined; at most once per backward pass): AccumulateGrad then binds the alias as .grad
+        auto grad_out = [&](const at::Tensor &param, int64_t c) {
+            at::Tensor h;
+            if (param.is_leaf() && param.scalar_type() == at::kFloat && param.numel() == c)
+                h = take_grad_home(param, torch::autograd::get_current_graph_task_id());
+            return h.defined() ? h : at::empty({c}, x.options().dtype(at::kFloat));
+        };
         if (link) {
             if (training && link->stats.defined() && link->dz.defined() &&
                 link->dz.unsafeGetTensorImpl() == grads[0].unsafeGetTensorImpl() &&
@@ -713,29 +729,15 @@ struct BNNode : public torch::autograd::Node {
             link->stats.reset();
             link->dz.reset();
         }
-        if (stats.defined() && stats.scalar_type() == at::kDouble) {   // totals: one launch
-            const int64_t m = x.size(0), c = x.size(1);
-            const at::Tensor add = extra.defined() ? extra.contiguous() : at::Tensor();
-            dx = at::empty_like(x);
-            dg = at::empty({c}, x.options().dtype(at::kFloat));
-            db = at::empty({c}, x.options().dtype(at::kFloat));
-            check(doda_bn_relu_bwd_totals(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
-                                          (const double *)stats.data_ptr(), (const float *)mean.data_ptr(),
-                                          (const float *)invstd.data_ptr(), (const float *)weight.data_ptr(),
-                                          (const float *)bias.data_ptr(), relu ? 1 : 0,
-                                          add.defined() ? add.data_ptr() : nullptr, dx.data_ptr(), (float *)dg.data_ptr(),
-                                          (float *)db.data_ptr(), stream_of(x)),
-                  "doda_bn_relu_bwd_totals");
-            extra = at::Tensor();
-        } else if (stats.defined()) {
+        if (stats.defined()) {
             const int64_t m = x.size(0), c = x.size(1);
             int64_t add_ld = c;
             const at::Tensor add = extra.defined() ? add_operand(extra, m, c, add_ld) : at::Tensor();
             dx = at::empty_like(x);
-            dg = at::empty({c}, x.options().dtype(at::kFloat));
-            db = at::empty({c}, x.options().dtype(at::kFloat));
+            dg = grad_out(weight, c);
+            db = grad_out(bias, c);
             at::Tensor coef = at::empty({3 * c}, x.options().dtype(at::kFloat));
-            check(doda_bn_relu_bwd_stats_ld(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
+            check(doda_bn_relu_bwd_stats(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
                                             (const float *)stats.data_ptr(), (int)stats.size(0),
                                             (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(),
                                             (const float *)weight.data_ptr(), (const float *)bias.data_ptr(), relu ? 1 : 0,
@@ -749,11 +751,11 @@ struct BNNode : public torch::autograd::Node {
             int64_t add_ld = c;
             const at::Tensor add = add_operand(extra, m, c, add_ld);
             dx = at::empty_like(x);
-            dg = at::empty({c}, x.options().dtype(at::kFloat));
-            db = at::empty({c}, x.options().dtype(at::kFloat));
+            dg = grad_out(weight, c);
+            db = grad_out(bias, c);
             const size_t wsb = doda_bn_workspace_bytes((int)m, (int)c);
             at::Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
-            check(doda_bn_relu_bwd_add_ld(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
+            check(doda_bn_relu_bwd_add(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
                                           (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(),
                                           (const float *)weight.data_ptr(), (const float *)bias.data_ptr(),
                                           relu ? 1 : 0, add.data_ptr(), (int)add_ld, dx.data_ptr(), (float *)dg.data_ptr(),
@@ -763,8 +765,8 @@ struct BNNode : public torch::autograd::Node {
         } else if (training) {
             const int64_t m = x.size(0), c = x.size(1);
             dx = at::empty_like(x);
-            dg = at::empty({c}, x.options().dtype(at::kFloat));
-            db = at::empty({c}, x.options().dtype(at::kFloat));
+            dg = grad_out(weight, c);
+            db = grad_out(bias, c);
             const size_t wsb = doda_bn_workspace_bytes((int)m, (int)c);
             at::Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
             check(doda_bn_relu_bwd(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
@@ -803,7 +805,7 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
                                      const at::Tensor &running_mean, const at::Tensor &running_var,
                                      const at::Tensor &nbt, bool training, double momentum, double eps,
                                      bool relu, bool passthrough, const at::Tensor &stats = at::Tensor(),
-                                     PreArgs *defer = nullptr, const at::Tensor &stats_b = at::Tensor()) {
+                                     const at::Tensor &stats_b = at::Tensor()) {
     const bool need_grad = at::GradMode::is_enabled() &&
                            (x_in.requires_grad() || weight.requires_grad() || bias.requires_grad());
     at::Tensor x, y, mean, invstd, xp;
@@ -821,7 +823,7 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
             mean = running_mean.to(at::kFloat).contiguous();
             invstd = at::rsqrt(running_var.to(at::kFloat) + eps).contiguous();
         }
-        if (training && stats.defined() && stats_b.defined() && !defer && m > BN_SMALL_ROWS && stats.dim() == 3 &&
+        if (training && stats.defined() && stats_b.defined() && m > BN_SMALL_ROWS && stats.dim() == 3 &&
             stats_b.dim() == 3 && stats.size(2) + stats_b.size(2) == c && stats.scalar_type() == at::kFloat &&
             stats_b.scalar_type() == at::kFloat && stats.is_contiguous() && stats_b.is_contiguous() && stats.size(2) % 4 == 0) {
             // x is a channel concatenation [a | b] (the U-Net level's skip + upsampled features): BatchNorm statistics are
@@ -840,26 +842,6 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
             check(doda_bn_relu_apply(x.data_ptr(), (int)m, (int)c, esz, mp, ip, (const float *)weight.data_ptr(),
                                      (const float *)bias.data_ptr(), relu ? 1 : 0, y.data_ptr(), stream_of(x)),
                   "doda_bn_relu_apply");
-        } else if (defer) {
-            // reduction only: the consuming conv's prologue applies the BatchNorm and writes y (the caller checked
-            // prologue_usable(): training, float statistics rows of a conv epilogue, m > BN_SMALL_ROWS)
-            check(doda_bn_fwd_final((const float *)stats.data_ptr(), (int)stats.size(0), (int)m, (int)c, (float)eps,
-                                    (float)momentum, (float *)running_mean.data_ptr(), (float *)running_var.data_ptr(),
-                                    nbt.defined() ? (int64_t *)nbt.data_ptr() : nullptr, (float *)mean.data_ptr(),
-                                    (float *)invstd.data_ptr(), stream_of(x)), "doda_bn_fwd_final");
-            defer->active = true;
-            defer->x = x;
-            defer->mean = mean; defer->invstd = invstd;
-            defer->gamma = weight.detach(); defer->beta = bias.detach();
-            defer->relu = relu;
-        } else if (training && stats.defined() && m > BN_SMALL_ROWS && stats.dim() == 3 && stats.size(0) == 1 && stats.size(2) == c &&
-            c <= 256 && stats.scalar_type() == at::kDouble && stats.is_contiguous()) {
-            check(doda_bn_relu_fwd_totals(x.data_ptr(), (int)m, (int)c, esz, (const double *)stats.data_ptr(), (float)eps,
-                                          (float)momentum, (const float *)weight.data_ptr(), (const float *)bias.data_ptr(),
-                                          (float *)running_mean.data_ptr(), (float *)running_var.data_ptr(),
-                                          nbt.defined() ? (int64_t *)nbt.data_ptr() : nullptr, relu ? 1 : 0, y.data_ptr(),
-                                          (float *)mean.data_ptr(), (float *)invstd.data_ptr(), stream_of(x)),
-                  "doda_bn_relu_fwd_totals");
         } else if (training && stats.defined() && m > BN_SMALL_ROWS && stats.dim() == 3 && stats.size(2) == c &&
             stats.scalar_type() == at::kFloat && stats.is_contiguous()) {
             check(doda_bn_relu_fwd_stats(x.data_ptr(), (int)m, (int)c, esz, (const float *)stats.data_ptr(),
@@ -915,7 +897,7 @@ at::Tensor bn_relu(const at::Tensor &x, const at::Tensor &weight, const at::Tens
                    bool training, double momentum, double eps, bool relu, const c10::optional<at::Tensor> &stats,
                    const c10::optional<at::Tensor> &stats_b) {
     return bn_relu_impl(x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, relu, false,
-                        stats.has_value() ? *stats : at::Tensor(), nullptr, stats_b.has_value() ? *stats_b : at::Tensor())[0];
+                        stats.has_value() ? *stats : at::Tensor(), stats_b.has_value() ? *stats_b : at::Tensor())[0];
 }
 
 // (y, x_alias): use x_alias wherever the block needs x again (its gradient is summed inside this op's backward)
@@ -924,25 +906,7 @@ std::vector<at::Tensor> bn_relu_pass(const at::Tensor &x, const at::Tensor &weig
                                      const at::Tensor &nbt, bool training, double momentum, double eps, bool relu,
                                      const c10::optional<at::Tensor> &stats, const c10::optional<at::Tensor> &stats_b) {
     return bn_relu_impl(x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, relu, true,
-                        stats.has_value() ? *stats : at::Tensor(), nullptr, stats_b.has_value() ? *stats_b : at::Tensor());
-}
-
-// Can the BatchNorm (x, statistics rows `stats` from the producing conv's epilogue) leave its apply pass to the SubM conv
-// (weight w over table tbl) that consumes it?  Training mode, bf16 rows, float statistics rows, more rows than the
-// one-launch BatchNorm handles, fp32 affine parameters and running statistics, and a kernel that takes the prologue.
-bool prologue_usable(const at::Tensor &x, const at::Tensor &stats, const std::vector<at::Tensor> &bn, bool training,
-                     const at::Tensor &w, const at::Tensor &tbl, int64_t n_out) {
-    if (!g_bn_prologue || !training || !stats.defined() || !x.defined() || x.dim() != 2) return false;
-    const int64_t m = x.size(0), c = x.size(1);
-    if (m <= BN_SMALL_ROWS || m != n_out || x.scalar_type() != at::kBFloat16 || !x.is_contiguous() || !x.is_cuda()) return false;
-    if (stats.dim() != 3 || stats.size(2) != c || stats.scalar_type() != at::kFloat || !stats.is_contiguous() ||
-        stats.size(0) < 1)
-        return false;
-    for (int k = 0; k < 4; ++k)
-        if (!bn[k].defined() || bn[k].scalar_type() != at::kFloat || !bn[k].is_contiguous() || bn[k].numel() != c) return false;
-    if (w.dim() != 5 || w.size(3) != c || tbl.dim() != 2) return false;
-    return doda_spconv_prologue_ok((int32_t)c, (int32_t)w.size(4), (int32_t)tbl.size(0), 2, 0, (int32_t)m, (int32_t)n_out,
-                                   tilebook_behind(tbl, n_out) != nullptr) != 0;
+                        stats.has_value() ? *stats : at::Tensor(), stats_b.has_value() ? *stats_b : at::Tensor());
 }
 
 // ---- a whole pre-activation residual block in ONE extension call ------------------------------------
@@ -976,24 +940,18 @@ std::vector<at::Tensor> residual_block(const at::Tensor &x, const c10::optional<
     const bool identity = !conv_skip && !(skip.has_value() && skip->defined());
     const at::Tensor &tbl = *rb[0];
     const at::Tensor st1 = stats_in.has_value() ? *stats_in : at::Tensor();
-    PreArgs p1, p2;
-    const bool f1 = !(stats_in_b.has_value() && stats_in_b->defined()) && prologue_usable(x, st1, bn1, training, *cv1[0], tbl, n_out);
     auto a = bn_relu_impl(x, bn1[0], bn1[1], bn1[2], bn1[3], bn1[4], training, momentum1, eps1, true,
-                          (identity || conv_skip) && training, st1, f1 ? &p1 : nullptr,
-                          stats_in_b.has_value() ? *stats_in_b : at::Tensor());
+                          (identity || conv_skip) && training, st1, stats_in_b.has_value() ? *stats_in_b : at::Tensor());
 
     auto z1 = indice_conv_impl(a[0], *cv1[0], tbl, tbl, n_out, 2, cv1[1], cv1[2], c10::nullopt, rb[1], rb[2], rb[3], rb[4],
-                               want_stats, f1 ? &p1 : nullptr);
+                               want_stats);
     at::Tensor skip_feats;   // (after conv1: the conv that follows a BatchNorm op picks up its statistics link)
     if (conv_skip)
         skip_feats = indice_conv_impl(training ? a[1] : x, *sc[0], *sc[3], *sc[3], x.size(0), 1, sc[1], sc[2], c10::nullopt,
                                       sc[4], sc[4], c10::nullopt, c10::nullopt, false)[0];
-    const bool f2 = prologue_usable(z1[0], z1[1], bn2, training, *cv2[0], tbl, n_out);
-    auto y2 = bn_relu_impl(z1[0], bn2[0], bn2[1], bn2[2], bn2[3], bn2[4], training, momentum2, eps2, true, false, z1[1],
-                           f2 ? &p2 : nullptr);
+    auto y2 = bn_relu_impl(z1[0], bn2[0], bn2[1], bn2[2], bn2[3], bn2[4], training, momentum2, eps2, true, false, z1[1]);
     const at::Tensor res = conv_skip ? skip_feats : identity ? (training ? a[1] : x) : *skip;
-    return indice_conv_impl(y2[0], *cv2[0], tbl, tbl, n_out, 2, cv2[1], cv2[2], res, rb[1], rb[2], rb[3], rb[4], want_stats,
-                            f2 ? &p2 : nullptr);
+    return indice_conv_impl(y2[0], *cv2[0], tbl, tbl, n_out, 2, cv2[1], cv2[2], res, rb[1], rb[2], rb[3], rb[4], want_stats);
 }
 
 }  // namespace
@@ -1076,9 +1034,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("n_out"), py::arg("skip"), py::arg("want_stats"),
           py::arg("sc") = std::vector<c10::optional<at::Tensor>>(), py::arg("stats_in_b") = py::none());
     m.def("set_bn_fusion", [](bool on) { g_bn_fusion = on; }, "BatchNorm statistics in the conv epilogues (default on)");
-    m.def("set_bn_prologue", [](bool on) { g_bn_prologue = on; },
-          "BatchNorm apply(+ReLU) in the consuming conv's prologue inside residual_block (default off)");
-    m.def("get_bn_prologue", []() { return g_bn_prologue; });
     m.def("gather", [](const at::Tensor &x, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
                        const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32) {
         return gather(x, w, packed, tbl, n_out, layout, nc, out_f32);
@@ -1105,7 +1060,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                       nt = (tbl.size(1) + T - 1) / T;
                       char *p = (char *)const_cast<void *>(tb) + nt * UMAX * 4 + nt * K * T * 2 + nt * 4;
                       int32_t ov[2] = {0, 0};
-                      if (!read_back_blocking(p, ov, 2, stream_of(tbl))) {
+                      if (!read_back_blocking(p, ov, 2, stream_of(tbl), (int)tbl.device().index())) {
                           at::Tensor over = at::from_blob(p, {2}, tbl.options()).cpu();
                           ov[0] = over[0].item<int32_t>();
                           ov[1] = over[1].item<int32_t>();
@@ -1147,12 +1102,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               at::Tensor over = at::from_blob(p, {2}, tbl.options()).cpu();
               return std::make_tuple(nt, (int64_t)over[0].item<int32_t>(), (int64_t)over[1].item<int32_t>());
           }, py::call_guard<py::gil_scoped_release>());   // (called on the rulebook thread: its read-back must not hold the GIL)
-    m.def("set_tile_kernel", [](bool on) { doda_spconv_set_tile_kernel(on ? 1 : 0); });
+    m.def("set_tile_kernel", [](bool on) { doda_set_option(DODA_OPT_TILE_KERNEL, on ? 1 : 0); });
     m.def("pending_wgrads", []() { std::lock_guard<std::mutex> lock(g_wq_mu); return (int64_t)g_wq.size(); });
     m.def("set_defer_wgrad", [](bool on) { g_defer_wgrad = on; },
           "queue conv weight gradients during backward and issue them in one multi-layer call at its end");
     m.def("get_defer_wgrad", []() { return g_defer_wgrad; });
     m.def("flush_wgrads", &flush_wgrads);
+    m.def("set_grad_home", &set_grad_home, "view of a flat gradient bucket that receives the parameter's gradient in place (None: forget)");
+    m.def("clear_grad_homes", &clear_grad_homes);
     m.def("set_wgrad_split", [](bool on) { g_wq_split = on; if (!on) g_ev_early_valid = false; },
           "issue the wide layers' weight gradients first and record an event behind them (GradAllReduce)");
     m.def("wait_wide_wgrads", [](int64_t stream) {

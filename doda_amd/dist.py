@@ -75,6 +75,34 @@ def _flat_broadcast(tensors, src=0):
                 off += t.numel()
 
 
+class _Bucket:
+    """One flat gradient buffer and the views its parameters' gradients live in."""
+
+    def __init__(self, params):
+        self.params = params
+        n = sum(p.numel() for p in params)
+        self.flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+        self.views, off = [], 0
+        for p in params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def gather_in_place(self):
+        """Every parameter's gradient INTO its view, .grad re-bound to the view.  A gradient the producing kernel already
+        wrote there (doda_amd's conv weight gradients and BatchNorm gamma / beta, through the extension's gradient
+        homes) costs nothing; a stray one (another producer, an accumulated second pass that left its home) is copied;
+        a missing one counts as zeros, so every rank sends the same message whatever its batch touched."""
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
+                v.copy_(g)
+            else:
+                continue
+            p.grad = v
+
+
 class GradAllReduce:
     """Gradient averaging after the backward pass.  Replaces DistributedDataParallel
     (tool/train.py:360-361) when weight gradients are deferred to the end of backward
@@ -85,11 +113,14 @@ class GradAllReduce:
       rank 0, as DDP does at wrap time; `sync_buffers()` repeats the buffer broadcast on demand (DDP's
       broadcast_buffers=True does it every forward; call it before evaluation / checkpointing — the
       running statistics of rank-local batches otherwise drift apart, which only matters there);
-    * reduce(): the FIXED parameter list (a missing gradient counts as zeros, so every rank sends the
-      same message sizes whatever its batch touched) is cut into buckets of ~`bucket_mb` MB; bucket k's
-      all-reduce (RCCL ring over xGMI, per-link bound) is asynchronous and overlaps the flattening copy
-      of bucket k+1 and the copy-back of bucket k-1.  With world size 1 everything is a no-op unless
-      `force` (or DODA_DIST_FORCE=1) asks for the collectives anyway (process group of one rank)."""
+    * gradients live IN the buckets (round 4; DDP's gradient_as_bucket_view): the FIXED parameter list is cut into
+      persistent flat buffers of ~`bucket_mb` MB and every parameter gets a view of its bucket as its gradient's home
+      (extension: set_grad_home) — the deferred weight-gradient launch and the BatchNorm backward kernels write there
+      directly and .grad is an alias of the view, so reduce() issues the all-reduce on the flat buffer in place: no
+      torch.cat before it, no split / copy-back after it (the r3 form moved all 30 MB twice per step);
+    * reduce(): bucket k's all-reduce (RCCL ring over xGMI, per-link bound; ReduceOp.AVG where the backend has it) is
+      asynchronous.  With world size 1 everything is a no-op unless `force` (or DODA_DIST_FORCE=1) asks for the
+      collectives anyway (process group of one rank)."""
 
     def __init__(self, module, bucket_mb=8.0, broadcast_buffers=True, overlap=True, force=None):
         self.module = module
@@ -100,34 +131,55 @@ class GradAllReduce:
         # the collectives run when there is someone to talk to, or when forced on an initialised group of one
         self.active = dist.is_initialized() and (self.world > 1 or bool(force))
         # (overlap) conv weights of the 16- / 32-channel levels: their gradients are the LAST kernels of a step
-        # (the pair-list launches of the deferred flush) and 2 of the 30 MB; everything else is reduced on a
+        # (the tile / pair-list launches of the deferred flush) and 2 of the 30 MB; everything else is reduced on a
         # side stream while those kernels run.  Static rule on the weight shape: identical on every rank.
         self._split = False
+        self._ext = None
         narrow = []
-        if overlap and self.active and self.params and self.params[0].is_cuda:
-            try:
-                from ._ext import ext as _ext
-            except Exception:
-                _ext = None
-            if _ext is not None and hasattr(_ext, "set_wgrad_split"):
-                narrow = [p for p in self.params if p.dim() == 5 and p.shape[3] <= 32 and p.shape[4] <= 32]
-                if narrow and len(narrow) < len(self.params):
-                    self._split, self._ext = True, _ext
-                    from .streams import independent_stream
-                    self._side = independent_stream(self.params[0].device, tag="allreduce")
-                    _ext.set_wgrad_split(True)
+        try:
+            from ._ext import ext as _ext
+        except Exception:
+            _ext = None
+        on_gpu = bool(self.params) and self.params[0].is_cuda
+        if overlap and self.active and on_gpu and _ext is not None and hasattr(_ext, "set_wgrad_split"):
+            narrow = [p for p in self.params if p.dim() == 5 and p.shape[3] <= 32 and p.shape[4] <= 32]
+            if narrow and len(narrow) < len(self.params):
+                self._split = True
+                from .streams import independent_stream
+                self._side = independent_stream(self.params[0].device, tag="allreduce")
+                _ext.set_wgrad_split(True)
         narrow_ids = {id(p) for p in narrow} if self._split else set()
-        self.buckets = self._cut([p for p in self.params if id(p) not in narrow_ids], bucket_mb)
-        self.late_buckets = self._cut([p for p in self.params if id(p) in narrow_ids], bucket_mb)
+        self.buckets, self.late_buckets = [], []
         if self.active:
+            self.buckets = [_Bucket(b) for b in self._cut([p for p in self.params if id(p) not in narrow_ids], bucket_mb)]
+            self.late_buckets = [_Bucket(b) for b in self._cut([p for p in self.params if id(p) in narrow_ids], bucket_mb)]
+            if on_gpu and _ext is not None and hasattr(_ext, "set_grad_home"):
+                self._ext = _ext
+                for b in self.buckets + self.late_buckets:
+                    for p, v in zip(b.params, b.views):
+                        _ext.set_grad_home(p, v)
             _flat_broadcast(self.params)
             if broadcast_buffers:
                 self.sync_buffers()
+        # SUM + scale where the backend has no averaging reduction (gloo)
+        self._avg = self.active and dist.get_backend() == "nccl" and hasattr(dist.ReduceOp, "AVG")
+
+    def close(self):
+        """Forget the gradient homes (the parameters' next gradients are ordinary tensors again)."""
+        if self._ext is not None:
+            for b in self.buckets + self.late_buckets:
+                for p in b.params:
+                    self._ext.set_grad_home(p, None)
+            self._ext = None
 
     @staticmethod
     def _cut(params, bucket_mb):
+        """Consecutive parameters of one dtype, ~bucket_mb MB each."""
         buckets, cur, cur_bytes, limit = [], [], 0, int(bucket_mb * (1 << 20))
         for p in params:
+            if cur and p.dtype != cur[0].dtype:
+                buckets.append(cur)
+                cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += p.numel() * p.element_size()
             if cur_bytes >= limit:
@@ -144,37 +196,29 @@ class GradAllReduce:
             if bufs:
                 _flat_broadcast(bufs)
 
-    @staticmethod
-    def _start(buckets):
+    def _start(self, buckets):
         pending = []
-        for bucket in buckets:
-            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
-            pending.append((bucket, flat, dist.all_reduce(flat, async_op=True)))
+        for b in buckets:
+            b.gather_in_place()
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            pending.append((b, dist.all_reduce(b.flat, op=op, async_op=True)))
         return pending
 
     def _finish(self, pending):
-        inv = 1.0 / self.world
-        for bucket, flat, work in pending:
+        for b, work in pending:
             work.wait()
-            flat.mul_(inv)
-            views = [t.view_as(p) for t, p in zip(flat.split([p.numel() for p in bucket]), bucket)]
-            have = [(p.grad, v) for p, v in zip(bucket, views) if p.grad is not None]
-            if have:
-                torch._foreach_copy_([g for g, _ in have], [v for _, v in have])
-            for p, v in zip(bucket, views):
-                if p.grad is None:
-                    p.grad = v.clone()
+            if not self._avg:
+                b.flat.mul_(1.0 / self.world)
 
     def reduce(self):
         """Call between loss.backward() and optimizer.step()."""
         if not self.active:
             return
         main = torch.cuda.current_stream() if self._split else None
-        if self._split and self._ext.wait_wide_wgrads(self._side.cuda_stream):
+        if self._split and self._ext_wait():
             # the side stream now waits for the wide layers' weight gradients only (and for everything backward
             # put on the stream before them); the narrow layers' kernels keep running on the main stream
-            # (gradients stay alive until the next zero_grad, which the main stream reaches after it has
-            # joined the side stream: no allocator hand-over needed)
+            # (the buckets are persistent: no allocator hand-over between the streams)
             with torch.cuda.stream(self._side):
                 early = self._start(self.buckets)
             late = self._start(self.late_buckets)
@@ -184,3 +228,7 @@ class GradAllReduce:
             main.wait_stream(self._side)
             return
         self._finish(self._start(self.buckets + self.late_buckets))
+
+    def _ext_wait(self):
+        from ._ext import ext as _ext
+        return _ext.wait_wide_wgrads(self._side.cuda_stream)

@@ -271,13 +271,11 @@ def _feat_ok(x, name):
         raise RuntimeError("%s must be a contiguous [rows, channels] tensor" % name)
 
 
-class _ConvEpilogue(C.Structure):   # doda_conv_epilogue (include/doda_hip.h, ABI 6)
+class _ConvEpilogue(C.Structure):   # doda_conv_epilogue (include/doda_hip.h, ABI 7)
     _fields_ = [("residual", C.c_void_p), ("stats", C.c_void_p), ("stats_rows_h", C.POINTER(C.c_int32)),
                 ("bn_x", C.c_void_p), ("bn_mean", C.c_void_p), ("bn_invstd", C.c_void_p), ("bn_gamma", C.c_void_p),
                 ("bn_beta", C.c_void_p), ("bn_relu", C.c_int32), ("tilebook_rows", C.c_int32),
-                ("tilebook", C.c_void_p), ("totals", C.c_void_p), ("finished_h", C.POINTER(C.c_int32)),
-                ("pre_mean", C.c_void_p), ("pre_invstd", C.c_void_p), ("pre_gamma", C.c_void_p), ("pre_beta", C.c_void_p),
-                ("pre_relu", C.c_int32), ("residual_bcast", C.c_int32), ("pre_out", C.c_void_p)]
+                ("tilebook", C.c_void_p), ("residual_bcast", C.c_int32)]
 
 
 def tilebook_build(tbl, n_rows=None):
@@ -295,49 +293,21 @@ def tilebook_build(tbl, n_rows=None):
     return tb
 
 
-def spconv_bwd_tile(dy, x, w, tbl, tilebook, packed=None, dw_out=None):
-    """Fused SubM backward of a bf16 16 -> 16, K = 27 layer (doda_spconv_bwd_tile_bf16): returns (dx, dw) with
-    dx = data gradient [n,16] bf16 and dw = weight gradient fp32 [27,16,16].  w: the layer's fp32 weight viewed
-    [27,16,16] ([K][Cin][Cout], what a w_layout-2 gather call takes) or `packed` = its layout-2 fragment buffer;
-    dw_out: accumulate into this tensor instead of returning a fresh one."""
-    _need_cuda(dy, x, tbl, tilebook)
-    n = dy.shape[0]
-    if (dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or tuple(dy.shape) != (n, 16) or tuple(x.shape) != (n, 16)
-            or tbl.shape[0] != 27 or not dy.is_contiguous() or not x.is_contiguous()):
-        raise RuntimeError("spconv_bwd_tile: contiguous bf16 [n,16] dy and x, 27-offset table")
-    dx = torch.empty_like(dy)
-    dw = dw_out if dw_out is not None else torch.empty((27, 16, 16), dtype=torch.float32, device=dy.device)
-    ws = _ws(lib().doda_spconv_bwd_tile_workspace_bytes(), dy.device)
-    if packed is not None:
-        w_ptr, is_packed = _p(packed), 1
-    else:
-        w = w.contiguous()
-        if w.dtype != torch.float32 or w.numel() != 27 * 256:
-            raise RuntimeError("spconv_bwd_tile: weight must be float32 [27,16,16]")
-        w_ptr, is_packed = _p(w), 0
-    check(lib().doda_spconv_bwd_tile_bf16(_p(dy), _p(x), n, w_ptr, is_packed, _p(tbl), tbl.shape[1], _p(tilebook), _p(dx),
-                                          _p(dw), int(dw_out is not None), _p(ws), ws.numel(), None, _stream()),
-          "doda_spconv_bwd_tile_bf16")
-    return dx, dw
-
-
 def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, residual=None, tilebook=None,
-                  want_stats=False, bn=None, out=None, want_totals=False, pre=None, residual_bcast=False):
-    """y[t] = sum_o x[tbl[o][t]] @ B_o (see doda_hip.h).  x: [n_in,kc] f32|bf16; w: fp32 weights
-    viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2), or `packed`: the fragment-packed buffer
-    produced by PackPlan for this (weight, layout, dtype).  Returns y [n_out, nc] in x.dtype (or
+                  want_stats=False, bn=None, out=None, residual_bcast=False):
+    """y[t] = sum_o x[tbl[o][t]] @ B_o (doda_spconv_gather_ex, the one gather entry point of ABI 7).  x: [n_in,kc]
+    f32|bf16; w: fp32 weights viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2), or `packed`: the
+    fragment-packed buffer produced by PackPlan for this (weight, layout, dtype).  Returns y [n_out, nc] in x.dtype (or
     float32 when out_f32); with `residual` ([n_out, nc], dtype of y) returns conv + residual.
     want_stats: returns (y, stats [rows, 2, nc] fp32): the BatchNorm partial sums of the epilogue
     (doda_conv_epilogue.stats) — (sum y, sum y^2), or with bn = (bn_x, mean, invstd, gamma, beta, relu) the
-    BatchNorm-backward sums of a data-grad call.  out: write into this tensor instead of allocating.
-    want_totals (with want_stats): returns (y, stats, totals) — totals: float64 [2, nc], the rows summed by the conv
-    kernel's last workgroup (doda_conv_epilogue.totals), or None when that kernel does not finish in place.
-    pre = (mean, invstd, gamma, beta, relu, z_out): BatchNorm(+ReLU) prologue on the gathered rows (ABI 6,
-    doda_conv_epilogue.pre_*); z_out ([n_in, kc] bf16 or None) receives the normalised rows."""
+    BatchNorm-backward sums of a data-grad call.  out: write into this tensor instead of allocating."""
     _feat_ok(x, "x")
     _need_cuda(tbl)
     K, ld = tbl.shape
     kc = x.shape[1]
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("spconv_gather: unsupported feature dtype %s" % x.dtype)
     esz = 4 if x.dtype == torch.float32 else 2
     if packed is not None:
         need = lib().doda_spconv_gather_workspace_bytes(K, kc, nc, esz)
@@ -358,69 +328,25 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
         want = (nc,) if residual_bcast else (n_out, nc)
         if residual.dtype != ydt or tuple(residual.shape) != want or not residual.is_contiguous():
             raise RuntimeError("residual must be a contiguous [n_out, nc] tensor (or [nc] with residual_bcast) in the output dtype")
-    if tilebook is not None or want_stats or out is not None or pre is not None or residual_bcast:   # epilogue-struct entry point
-        y = out if out is not None else torch.empty((n_out, nc), dtype=ydt, device=x.device)
-        ep = _ConvEpilogue()
-        ep.residual = _p(residual) if residual is not None else None
-        ep.residual_bcast = int(bool(residual_bcast and residual is not None))
-        if tilebook is not None:
-            ep.tilebook = _p(tilebook)
-            ep.tilebook_rows = int(getattr(tilebook, "_doda_rows", n_out))
-        stats, rows = None, C.c_int32(0)
-        if want_stats:
-            stats = torch.empty((int(lib().doda_spconv_stats_capacity(n_out)), 2, nc), dtype=torch.float32, device=x.device)
-            ep.stats, ep.stats_rows_h = _p(stats), C.pointer(rows)
-            if bn is not None:
-                bx, mean, invstd, gamma, beta, relu = bn
-                ep.bn_x, ep.bn_mean, ep.bn_invstd, ep.bn_gamma, ep.bn_beta = _p(bx), _p(mean), _p(invstd), _p(gamma), _p(beta)
-                ep.bn_relu = int(bool(relu))
-        if pre is not None:
-            pm, pi, pg, pb, prelu, zout = pre
-            _need_cuda(pm, pi, pg, pb)
-            ep.pre_mean, ep.pre_invstd, ep.pre_gamma, ep.pre_beta = _p(pm), _p(pi), _p(pg), _p(pb)
-            ep.pre_relu = int(bool(prelu))
-            if zout is not None:
-                if zout.dtype != x.dtype or tuple(zout.shape) != tuple(x.shape) or not zout.is_contiguous():
-                    raise RuntimeError("pre: z_out must be a contiguous tensor shaped like x")
-                ep.pre_out = _p(zout)
-        totals, fin = None, C.c_int32(0)
-        if want_stats and want_totals:
-            totals = torch.empty((2, nc), dtype=torch.float64, device=x.device)
-            ep.totals, ep.finished_h = _p(totals), C.pointer(fin)
-        check(lib().doda_spconv_gather_ex(_p(x), x.shape[0], kc, esz, w_ptr, nc, _p(tbl), ld, K, n_out, _p(y),
-                                          int(bool(out_f32)), layout, ws_ptr, ws_n, C.byref(ep), _stream()),
-              "doda_spconv_gather_ex")
-        if want_stats and want_totals:
-            return y, stats[:rows.value], (totals if fin.value else None)
-        return (y, stats[:rows.value]) if want_stats else y
-    if x.dtype == torch.float32:
-        y = torch.empty((n_out, nc), dtype=torch.float32, device=x.device)
-        if residual is None:
-            check(lib().doda_spconv_gather_f32(_p(x), x.shape[0], kc, w_ptr, nc, _p(tbl), ld, K, n_out,
-                                               _p(y), layout, ws_ptr, ws_n, _stream()),
-                  "doda_spconv_gather_f32")
-        else:
-            check(lib().doda_spconv_gather_add_f32(_p(x), x.shape[0], kc, w_ptr, nc, _p(tbl), ld, K, n_out,
-                                                   _p(residual), _p(y), layout, ws_ptr, ws_n, _stream()),
-                  "doda_spconv_gather_add_f32")
-    elif x.dtype == torch.bfloat16:
-        y = torch.empty((n_out, nc), dtype=ydt, device=x.device)
-        if residual is None:
-            check(lib().doda_spconv_gather_bf16(_p(x), x.shape[0], kc, w_ptr, nc, _p(tbl), ld, K, n_out,
-                                                _p(y), int(bool(out_f32)), layout, ws_ptr, ws_n, _stream()),
-                  "doda_spconv_gather_bf16")
-        else:
-            check(lib().doda_spconv_gather_add_bf16(_p(x), x.shape[0], kc, w_ptr, nc, _p(tbl), ld, K, n_out,
-                                                    _p(residual), _p(y), int(bool(out_f32)), layout, ws_ptr,
-                                                    ws_n, _stream()), "doda_spconv_gather_add_bf16")
-    else:
-        raise RuntimeError("spconv_gather: unsupported feature dtype %s" % x.dtype)
-    return y
-
-
-def spconv_prologue_ok(kc, nc, K, elem_bytes, out_f32, n_in, n_out, has_tilebook):
-    """Does doda_spconv_gather_ex take a BatchNorm prologue (pre=...) for this call shape?"""
-    return bool(lib().doda_spconv_prologue_ok(kc, nc, K, elem_bytes, int(bool(out_f32)), n_in, n_out, int(bool(has_tilebook))))
+    y = out if out is not None else torch.empty((n_out, nc), dtype=ydt, device=x.device)
+    ep = _ConvEpilogue()
+    ep.residual = _p(residual) if residual is not None else None
+    ep.residual_bcast = int(bool(residual_bcast and residual is not None))
+    if tilebook is not None:
+        ep.tilebook = _p(tilebook)
+        ep.tilebook_rows = int(getattr(tilebook, "_doda_rows", n_out))
+    stats, rows = None, C.c_int32(0)
+    if want_stats:
+        stats = torch.empty((int(lib().doda_spconv_stats_capacity(n_out)), 2, nc), dtype=torch.float32, device=x.device)
+        ep.stats, ep.stats_rows_h = _p(stats), C.pointer(rows)
+        if bn is not None:
+            bx, mean, invstd, gamma, beta, relu = bn
+            ep.bn_x, ep.bn_mean, ep.bn_invstd, ep.bn_gamma, ep.bn_beta = _p(bx), _p(mean), _p(invstd), _p(gamma), _p(beta)
+            ep.bn_relu = int(bool(relu))
+    check(lib().doda_spconv_gather_ex(_p(x), x.shape[0], kc, esz, w_ptr, nc, _p(tbl), ld, K, n_out, _p(y),
+                                      int(bool(out_f32)), layout, ws_ptr, ws_n, C.byref(ep), _stream()),
+          "doda_spconv_gather_ex")
+    return (y, stats[:rows.value]) if want_stats else y
 
 
 def bn_fwd_final(stats, m, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
@@ -554,52 +480,28 @@ def spconv_wgrad_multi(jobs):
 
 
 def spconv_wgrad(a, b, tbl, n_rows):
-    """dw[o] = sum_t a[tbl[o][t]]^T b[t]  ->  float32 [K, ca, cb]."""
+    """dw[o] = sum_t a[tbl[o][t]]^T b[t]  ->  float32 [K, ca, cb] (one job of doda_spconv_wgrad_multi)."""
     _feat_ok(a, "a")
     _feat_ok(b, "b")
     _need_cuda(tbl)
-    if a.dtype != b.dtype:
-        raise RuntimeError("spconv_wgrad: a and b must share a dtype")
-    K, ld = tbl.shape
-    ca, cb = a.shape[1], b.shape[1]
-    if a.dtype == torch.bfloat16 and ca % 16 == 0 and cb % 16 == 0 and n_rows > 0:
-        # the job form carries the row count of `a`, which the MFMA-transpose kernel's range check needs
-        return spconv_wgrad_multi([(a, b, tbl, n_rows)])[0]
-    dw = torch.empty((K, ca, cb), dtype=torch.float32, device=a.device)
-    ws = _ws(lib().doda_spconv_wgrad_workspace_bytes(K, ca, cb, n_rows), a.device)
-    if a.dtype == torch.float32:
-        fn, name = lib().doda_spconv_wgrad_f32, "doda_spconv_wgrad_f32"
-    elif a.dtype == torch.bfloat16:
-        fn, name = lib().doda_spconv_wgrad_bf16, "doda_spconv_wgrad_bf16"
-    else:
-        raise RuntimeError("spconv_wgrad: unsupported dtype %s" % a.dtype)
-    check(fn(_p(a), ca, _p(b), cb, _p(tbl), ld, K, n_rows, _p(dw), _p(ws), ws.numel(), _stream()),
-          name)
-    return dw
+    if a.dtype != b.dtype or a.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("spconv_wgrad: a and b must share a dtype (float32 or bfloat16)")
+    if n_rows == 0:
+        return torch.zeros((tbl.shape[0], a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
+    return spconv_wgrad_multi([(a, b, tbl, n_rows)])[0]
 
 
 def spconv_wgrad_pairs(a, b, pair_in, pair_out, pair_num, pair_seg=None, accumulate_into=None):
-    """dw[o] (+)= sum_{p < pair_num[o]} a[pair_in[o,p]]^T b[pair_out[o,p]] -> float32 [K, ca, cb]
-    (doda_spconv_wgrad_pairs_bf16: bf16 operands, channel counts multiples of 16).  pair_num None: every
-    list is full (the identity list of a 1x1 convolution).  pair_seg: the lists' segment prefix int32
-    [K, nt] (third result of rulebook_pairs; required whenever pair_num is given)."""
+    """dw[o] (+)= sum_{p < pair_num[o]} a[pair_in[o,p]]^T b[pair_out[o,p]] -> float32 [K, ca, cb]: one pair-list job
+    of doda_spconv_wgrad_multi (bf16 operands, channel counts multiples of 16).  pair_num None: every list is full
+    (the identity list of a 1x1 convolution).  pair_seg: the lists' segment prefix int32 [K, nt] (third result of
+    rulebook_pairs; required whenever pair_num is given)."""
     _feat_ok(a, "a")
     _feat_ok(b, "b")
     _need_cuda(pair_in, pair_out)
-    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
-        raise RuntimeError("spconv_wgrad_pairs: bf16 operands only")
-    K, ld = pair_in.shape
-    ldp = pair_in.stride(0) if K > 1 else ld
-    ca, cb = a.shape[1], b.shape[1]
-    dw = accumulate_into if accumulate_into is not None else \
-        torch.empty((K, ca, cb), dtype=torch.float32, device=a.device)
-    ws = _ws(lib().doda_spconv_wgrad_pairs_workspace_bytes(K, ca, cb, ldp), a.device)
-    check(lib().doda_spconv_wgrad_pairs_bf16(_p(a), a.shape[0], ca, _p(b), b.shape[0], cb, _p(pair_in), _p(pair_out),
-                                             _p(pair_num), _p(pair_seg),
-                                             0 if pair_seg is None else pair_seg.shape[1], ldp, K, _p(dw),
-                                             int(accumulate_into is not None),
-                                             _p(ws), ws.numel(), _stream()), "doda_spconv_wgrad_pairs_bf16")
-    return dw
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or a.shape[1] % 16 or b.shape[1] % 16:
+        raise RuntimeError("spconv_wgrad_pairs: bf16 operands with channel counts that are multiples of 16")
+    return spconv_wgrad_multi([(a, b, None, b.shape[0], (pair_in, pair_out, pair_num, pair_seg), accumulate_into)])[0]
 
 
 def maxpool_fwd(x, tbl, n_out):
@@ -676,7 +578,7 @@ def _add_ld(add, m, c, what):
 
 
 def bn_relu_bwd_add(x, dy, save_mean, save_invstd, gamma, beta, relu, add):
-    """bn_relu_bwd with a second gradient of x summed into dx inside the apply pass (doda_bn_relu_bwd_add_ld); `add`
+    """bn_relu_bwd with a second gradient of x summed into dx inside the apply pass (doda_bn_relu_bwd_add); `add`
     may be a column slice of a wider matrix (e.g. g[:, :c] of torch.cat's gradient): no copy is made."""
     _feat_ok(x, "x")
     _feat_ok(dy, "dy")
@@ -686,15 +588,15 @@ def bn_relu_bwd_add(x, dy, save_mean, save_invstd, gamma, beta, relu, add):
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
     ws = _ws(lib().doda_bn_workspace_bytes(m, c), x.device)
-    check(lib().doda_bn_relu_bwd_add_ld(_p(x), _p(dy), m, c, _esz(x), _p(save_mean), _p(save_invstd), _p(gamma), _p(beta),
+    check(lib().doda_bn_relu_bwd_add(_p(x), _p(dy), m, c, _esz(x), _p(save_mean), _p(save_invstd), _p(gamma), _p(beta),
                                         int(bool(relu)), ap, ld, _p(dx), _p(dgamma), _p(dbeta), _p(ws), ws.numel(),
-                                        _stream()), "doda_bn_relu_bwd_add_ld")
+                                        _stream()), "doda_bn_relu_bwd_add")
     return dx, dgamma, dbeta
 
 
 def bn_relu_bwd_stats(x, dy, stats, save_mean, save_invstd, gamma, beta, relu, add=None):
     """BatchNorm(+ReLU) backward over the (sum dz, sum dz * xhat) rows of a data-grad conv epilogue
-    (doda_bn_relu_bwd_stats_ld); add as in bn_relu_bwd_add.  -> (dx [+ add], dgamma, dbeta)."""
+    (doda_bn_relu_bwd_stats); add as in bn_relu_bwd_add.  -> (dx [+ add], dgamma, dbeta)."""
     _feat_ok(x, "x")
     _feat_ok(dy, "dy")
     _need_cuda(stats)
@@ -704,47 +606,9 @@ def bn_relu_bwd_stats(x, dy, stats, save_mean, save_invstd, gamma, beta, relu, a
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
     coef = torch.empty(3 * c, dtype=torch.float32, device=x.device)
-    check(lib().doda_bn_relu_bwd_stats_ld(_p(x), _p(dy), m, c, _esz(x), _p(stats), stats.shape[0], _p(save_mean),
+    check(lib().doda_bn_relu_bwd_stats(_p(x), _p(dy), m, c, _esz(x), _p(stats), stats.shape[0], _p(save_mean),
                                           _p(save_invstd), _p(gamma), _p(beta), int(bool(relu)), ap, ld, _p(dx), _p(dgamma),
-                                          _p(dbeta), _p(coef), _stream()), "doda_bn_relu_bwd_stats_ld")
-    return dx, dgamma, dbeta
-
-
-def bn_relu_fwd_totals(x, totals, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None):
-    """Training-mode BatchNorm(+ReLU) from the totals of a conv epilogue (doda_bn_relu_fwd_totals): one launch.
-    -> (y, save_mean, save_invstd)."""
-    _feat_ok(x, "x")
-    _need_cuda(totals)
-    m, c = x.shape
-    if totals.dtype != torch.float64 or totals.numel() != 2 * c or not totals.is_contiguous():
-        raise RuntimeError("totals must be a contiguous float64 [2, c] tensor")
-    y = torch.empty_like(x)
-    save_mean = torch.empty(c, dtype=torch.float32, device=x.device)
-    save_invstd = torch.empty(c, dtype=torch.float32, device=x.device)
-    check(lib().doda_bn_relu_fwd_totals(_p(x), m, c, _esz(x), _p(totals), float(eps), float(momentum), _p(gamma), _p(beta),
-                                        _p(running_mean) if running_mean is not None else None,
-                                        _p(running_var) if running_var is not None else None,
-                                        _p(num_batches_tracked) if num_batches_tracked is not None else None,
-                                        int(bool(relu)), _p(y), _p(save_mean), _p(save_invstd), _stream()),
-          "doda_bn_relu_fwd_totals")
-    return y, save_mean, save_invstd
-
-
-def bn_relu_bwd_totals(x, dy, totals, save_mean, save_invstd, gamma, beta, relu, add=None):
-    """BatchNorm(+ReLU) backward from the totals (sum dz, sum dz * xhat) of a data-grad conv epilogue
-    (doda_bn_relu_bwd_totals): one launch.  -> (dx [+ add], dgamma, dbeta)."""
-    _feat_ok(x, "x")
-    _feat_ok(dy, "dy")
-    _need_cuda(totals)
-    m, c = x.shape
-    if totals.dtype != torch.float64 or totals.numel() != 2 * c or not totals.is_contiguous():
-        raise RuntimeError("totals must be a contiguous float64 [2, c] tensor")
-    dx = torch.empty_like(x)
-    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
-    check(lib().doda_bn_relu_bwd_totals(_p(x), _p(dy), m, c, _esz(x), _p(totals), _p(save_mean), _p(save_invstd), _p(gamma),
-                                        _p(beta), int(bool(relu)), _p(add) if add is not None else None, _p(dx),
-                                        _p(dgamma), _p(dbeta), _stream()), "doda_bn_relu_bwd_totals")
+                                          _p(dbeta), _p(coef), _stream()), "doda_bn_relu_bwd_stats")
     return dx, dgamma, dbeta
 
 

@@ -5,7 +5,9 @@
     voxelization(feats, map_rule, mode=4)         -> [M,C]      differentiable w.r.t. feats
     point_recover(feats, map_rule, nPoint)        -> [nPoint,C] differentiable w.r.t. feats
     ballquery_batch_p(coords, batch_idxs, batch_offsets, radius, meanActive) -> (idx int32 [total], start_len int32 [n,2])
-    knn(xyz, query_xyz, batch_idxs, query_batch_offsets, k) -> idx int32 [n,k]
+    knn / knn_batch(xyz, query_xyz, batch_idxs, query_batch_offsets, k) -> idx int32 [n,k]
+plus `.apply` aliases under the reference's class names (Voxelization_Idx, Voxelization, PointRecover, BallQueryBatchP,
+KNNBatch).
 
 Names, positional argument order, dtypes and return tuples are the reference's (its callers: dataset/dataset.py:182,
 model/unet.py:88, model/unet.py:136-141); the bodies are this repository's.  The two differentiable ops are ONE
@@ -81,6 +83,9 @@ def ballquery_batch_p(coords, batch_idxs, batch_offsets, radius, meanActive):
         if not (t.is_cuda and t.is_contiguous()):
             raise AssertionError("ballquery_batch_p: device-resident contiguous tensors expected")
     n = coords.shape[0]
+    if n == 0:
+        return (torch.zeros(0, dtype=torch.int32, device=coords.device),
+                torch.zeros((0, 2), dtype=torch.int32, device=coords.device))
     cap = int(meanActive)
     total = None
     while total is None or total > n * cap:
@@ -102,3 +107,24 @@ def knn(xyz, query_xyz, batch_idxs, query_batch_offsets, k):
     idx = torch.zeros((n, k), dtype=torch.int32, device=xyz.device)
     _ops.knn_batch(xyz, query_xyz, batch_idxs, query_batch_offsets, idx, n, m, k)
     return idx
+
+
+knn_batch = knn   # the reference's name for it (pointgroup_ops.py:380)
+
+
+class _ApplyAlias:
+    """`Name.apply(...)` for code written against the reference's Function classes (pointgroup_ops.py:13,44,80,117,349):
+    the same plain functions behind the class names."""
+
+    def __init__(self, fn):
+        self.apply = fn
+
+    def __call__(self, *args, **kwargs):
+        return self.apply(*args, **kwargs)
+
+
+Voxelization_Idx = _ApplyAlias(voxelization_idx)
+Voxelization = _ApplyAlias(voxelization)
+PointRecover = _ApplyAlias(point_recover)
+BallQueryBatchP = _ApplyAlias(ballquery_batch_p)
+KNNBatch = _ApplyAlias(knn)

@@ -38,7 +38,7 @@ class IndiceData:
 
     def wgrad_lists(self, inverse=False):
         """(pair_in [K,ld], pair_out [K,ld], pair_num [K], seg [K,nt]) of the pair-list weight gradient
-        (doda_spconv_wgrad_pairs_bf16): list o pairs the row of the conv INPUT with the row of the conv
+        (doda_spconv_wgrad_multi's pair-list kernel): list o pairs the row of the conv INPUT with the row of the conv
         OUTPUT under offset o, in ascending input row; seg is the lists' per-256-row prefix.  Exported
         once per rulebook (doda_rulebook_pairs without the -1 fill)."""
         if self._wpairs is None:

@@ -132,26 +132,6 @@ def set_bn_fusion(on):
     return BN_FUSION
 
 
-# BatchNorm apply(+ReLU) in the consuming convolution's PROLOGUE (ABI 6): inside a
-# residual block issued as one extension call, a training-mode BatchNorm whose statistics came from the producing
-# conv's epilogue runs its reduction launch only; the tile kernel normalises each distinct row while staging it in LDS
-# and writes the normalised tensor as a side output.  Bit-equal to the two-launch form, and measured SLOWER than it on
-# MI355X (the transform lengthens the tile kernels' per-tile latency chain: +11.6 us per level-1 layer against the 11 us
-# apply launch it removes, +21 us with the scene's overflow tiles; profiles/r03_bn_prologue.txt): OFF by default,
-# DODA_BN_PROLOGUE=1 turns it on.
-BN_PROLOGUE = os.environ.get("DODA_BN_PROLOGUE", "0") == "1" and _ext is not None and hasattr(_ext, "set_bn_prologue")
-if _ext is not None and hasattr(_ext, "set_bn_prologue"):
-    _ext.set_bn_prologue(BN_PROLOGUE)
-
-
-def set_bn_prologue(on):
-    global BN_PROLOGUE
-    BN_PROLOGUE = bool(on) and _ext is not None and hasattr(_ext, "set_bn_prologue")
-    if _ext is not None and hasattr(_ext, "set_bn_prologue"):
-        _ext.set_bn_prologue(BN_PROLOGUE)
-    return BN_PROLOGUE
-
-
 def _conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residual=None, pairs=None,
           want_stats=False):
     """residual: optional [n_out, Cout] tensor in the output dtype; returns conv + residual with the
@@ -173,7 +153,7 @@ def _conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residua
     return (y, None) if want_stats else y
 
 
-# The pair-list weight gradient (doda_spconv_wgrad_pairs_bf16) needs the rulebook's pair lists (exported
+# The pair-list weight gradient (a pair-list job of doda_spconv_wgrad_multi) needs the rulebook's pair lists (exported
 # once per rulebook on the rulebook stream); DODA_WGRAD_PAIRS=0 keeps every layer on the gather-table kernel.
 WGRAD_PAIRS = os.environ.get("DODA_WGRAD_PAIRS", "1") == "1"
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DODA_ABI_VERSION 6
+#define DODA_ABI_VERSION 7
 
 #define DODA_OK 0
 #define DODA_ERR_INVALID (-1)        /* bad argument (null pointer, negative size, bad mode) */
@@ -193,29 +193,16 @@ size_t doda_spconv_pack_desc_bytes(void);
 int doda_spconv_pack_plan_h(void *descs_h, int32_t n_desc, int32_t *blk_end_h, int32_t *total_blocks);
 int doda_spconv_pack_multi(const void *descs_dev, const int32_t *blk_end_dev, int32_t n_desc,
                            int32_t total_blocks, doda_stream_t stream);
-int doda_spconv_gather_f32(const float *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
-                           const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, float *y,
-                           int32_t w_layout, void *ws, size_t ws_bytes, doda_stream_t stream);
+
 /* bf16 feature storage (BASELINE config 2): x / y are bf16 bit patterns; weights arrive fp32 and
  * are rounded to bf16 by the pre-pack; fp32 accumulate; y rounded to bf16 (RNE) once, or kept
- * fp32 when y_is_f32 (y then points to float [n_out, nc]; used by the point head's logits). */
-int doda_spconv_gather_bf16(const uint16_t *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
-                            const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, void *y,
-                            int32_t y_is_f32, int32_t w_layout, void *ws, size_t ws_bytes,
-                            doda_stream_t stream);
-
-/* Same with the block's residual add fused into the store:  y = (sum_o x[tbl[o][t]] . B_o) + res,
- * res: [n_out, nc] in the dtype of y (fp32 when y_is_f32).  Replaces the `output.features +=
- * identity.features` of the reference's ResidualBlock (model/unet_block.py:36) when the caller
- * owns the block; the sum is taken in fp32 before the single rounding of y. */
-int doda_spconv_gather_add_f32(const float *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
-                               const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
-                               const float *res, float *y, int32_t w_layout, void *ws,
-                               size_t ws_bytes, doda_stream_t stream);
-int doda_spconv_gather_add_bf16(const uint16_t *x, int32_t n_in, int32_t kc, const float *w, int32_t nc,
-                                const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out,
-                                const void *res, void *y, int32_t y_is_f32, int32_t w_layout,
-                                void *ws, size_t ws_bytes, doda_stream_t stream);
+ * fp32 when y_is_f32 (y then points to float [n_out, nc]; used by the point head's logits).
+ *
+ * ABI 7: doda_spconv_gather_ex is the ONE gather entry point (epi == NULL: the plain convolution); the per-dtype
+ * doda_spconv_gather_{f32,bf16} / _gather_add_* of ABI <= 6 were its special cases and are gone.  With `residual`
+ * y = (sum_o x[tbl[o][t]] . B_o) + res, res: [n_out, nc] in the dtype of y — the `output.features +=
+ * identity.features` of the reference's ResidualBlock (model/unet_block.py:36); the sum is taken in fp32 before the
+ * single rounding of y. */
 
 /* Gather with epilogue options: the conv fused with its neighbours in the layer graph (reference
  * model/unet_block.py:23-37,46-49,67-79: BatchNorm1d -> ReLU -> conv [-> + identity]).
@@ -243,36 +230,9 @@ typedef struct doda_conv_epilogue {
     int32_t bn_relu;
     int32_t tilebook_rows;   /* ABI 3: rows the tilebook was built for (must equal n_out) */
     const void *tilebook;    /* ABI 3: doda_tilebook_build of `tbl`, or NULL */
-    /* ABI 5: in-kernel finish of the statistics.  With `totals` (device, double [2][nc], 8-byte aligned) the last
-     * workgroup of the conv kernel to retire sums the partial rows — fixed order, fp64 — into totals[0][c] / totals[1][c]
-     * (the two sums over ALL rows), and *finished_h (HOST, required with totals) receives 1; hand the totals to
-     * doda_bn_relu_fwd_totals / doda_bn_relu_bwd_totals and the BatchNorm needs no reduction launch of its own.
-     * *finished_h == 0: this kernel does not finish in place (or doda_spconv_set_stats_finish(0)); use the rows. */
-    double *totals;
-    int32_t *finished_h;
-    /* ABI 6: BatchNorm(+ReLU) PROLOGUE — the BN -> ReLU -> conv triple of reference model/unet_block.py:23-30,46-49 in one
-     * launch.  With pre_mean set, every gathered input row goes through
-     *     z = (x - pre_mean) * pre_invstd * pre_gamma + pre_beta,  z = z > 0 ? z : 0 (pre_relu),  rounded to bf16
-     * (doda_bn_relu_fwd's arithmetic, operation for operation: the results are bit-equal to BatchNorm launch + conv
-     * launch) on its way to the matrix core: the tile kernels transform each DISTINCT row once while staging it in LDS.
-     * Absent neighbours stay zero.  pre_out ([n_in, kc] bf16, optional, 16-byte aligned) receives the normalised rows —
-     * written by the workgroup whose output rows they are (SubM: input row t = output row t) — for the weight
-     * gradient, which needs z as its gathered operand; the BatchNorm's own apply launch disappears.
-     * float [kc] each.  Supported where doda_spconv_prologue_ok() says so; otherwise DODA_ERR_UNSUPPORTED. */
-    const float *pre_mean, *pre_invstd, *pre_gamma, *pre_beta;
-    int32_t pre_relu;
     int32_t residual_bcast;   /* ABI 6: `residual` is ONE row [nc] (dtype of y) added to every output row — a bias (the Linear
                                * head of reference model/unet.py:64 as a gather-GEMM); dense-table kernels only */
-    void *pre_out;
 } doda_conv_epilogue;
-/* ABI 6.  1 when doda_spconv_gather_ex takes a BatchNorm prologue for this call shape (bf16 SubM K = 27 layers of 16 or
- * 32 input channels over a tilebook, bf16 output, n_in == n_out), else 0.  Depends on the A/B switches in force. */
-int32_t doda_spconv_prologue_ok(int32_t kc, int32_t nc, int32_t K, int32_t elem_bytes, int32_t y_is_f32, int32_t n_in,
-                                int32_t n_out, int32_t has_tilebook);
-/* Switch: 1 = finish statistics in the conv kernels, 0 = never (finished_h always 0).  Default 0 (DODA_STATS_FINISH=1
- * turns it on): on MI355X the end-of-workgroup protocol costs more than the BatchNorm's own reduction launch. */
-void doda_spconv_set_stats_finish(int32_t on);
-int32_t doda_spconv_get_stats_finish(void);   /* ABI 6: the switch's state (a caller need not allocate `totals` when it is 0) */
 /* ABI 3.  Tile-local form of a SubM gather table ("tilebook") for the LDS-staged convolution kernel:
  * per tile of doda_tilebook_tile() consecutive output rows, the sorted list of DISTINCT input rows the
  * tile's K x tile table entries reference and, per entry, its position in that list.  The kernel loads
@@ -291,67 +251,34 @@ int32_t doda_tilebook_umax(void);   /* list capacity per tile; layout: ulist int
 size_t doda_tilebook_bytes(int32_t n_rows, int32_t K);
 int doda_tilebook_build(const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, void *tilebook,
                         size_t tilebook_bytes, doda_stream_t stream);
-/* Fused SubM backward of a bf16 16 -> 16, K = 27 layer over the rulebook's tilebook (spconv
- * indice_conv_backward, reference call sites model/unet_block.py:26,29 through autograd): ONE staging of
- * dy's neighbourhood serves both gradients,
- *     dx[s]  = sum_o dy[tbl[o][s]] . W[26-o]^T        (bf16 [n_rows,16]; epilogue statistics as gather_ex)
- *     dw[o]  (+)= sum_s x[s]^T . dy[tbl[26-o][s]]     (fp32 [27][16][16]; `accumulate` adds into dw)
- * which equals the separate data-grad (w_layout 2) and weight-gradient calls up to summation order.
- * `w`: fp32 [27][16][16] stored [K][Cout][Cin] exactly as a w_layout-2 gather call receives it, or with
- * w_packed != 0 the fragment-packed buffer doda_spconv_pack_multi wrote for (layout 2, bf16).
- * Deterministic: persistent workgroups write one partial each, a second launch sums them in order. */
-size_t doda_spconv_bwd_tile_workspace_bytes(void);
-int doda_spconv_bwd_tile_bf16(const uint16_t *dy, const uint16_t *x, int32_t n_rows, const float *w,
-                              int32_t w_packed, const int32_t *tbl, int32_t ld, const void *tilebook,
-                              void *dx, float *dw, int32_t accumulate, void *ws, size_t ws_bytes,
-                              const doda_conv_epilogue *epi, doda_stream_t stream);
-/* A/B switch for measurements: 0 = ignore tilebooks (dense-table kernels only).  Default 1. */
-void doda_spconv_set_tile_kernel(int32_t on);
-/* A/B switch: 0 = the 48 -> 48 channel layers stay on the streaming-weights kernel instead of the weights-in-LDS
- * one.  Default 1. */
-void doda_spconv_set_wlds_kernel(int32_t on);
-/* A/B switch: 1 = the bf16 16 -> 16 layers with a tilebook take the one-workgroup-per-CU LDS-DMA pipeline
- * (spconv_dma.hip) instead of the three-workgroups-per-CU tile kernel.  Default 0 (it measured no faster). */
-void doda_spconv_set_dma_kernel(int32_t on);
-/* Measurement aid (tools/dmastamps.py): shader-clock stamps of the pipeline phases of one conv_dma16 workgroup, recorded
- * when DODA_DMA_DBG=128 is set in the environment; dst_h: host array of 2 * 16 * 8 uint64. */
-int doda_debug_dma_stamps(unsigned long long *dst_h);
-int doda_debug_wdma_stamps(unsigned long long *dst_h);   /* the same for wgrad_dma16 */
-/* A/B switch: 0 = weight-gradient jobs ignore their tilebook (pair-list / gather-table kernels).  Default 1. */
-void doda_spconv_set_wdma_kernel(int32_t on);
+/* ABI 7.  A/B switches of the kernel selection (measurements and parity tests; all default to 1; they replace the
+ * doda_spconv_set_*_kernel functions of ABI <= 6).  doda_set_option returns DODA_ERR_INVALID for an unknown option,
+ * doda_get_option -1. */
+#define DODA_OPT_TILE_KERNEL 1   /* 0: ignore tilebooks in doda_spconv_gather_ex (dense-table kernels only) */
+#define DODA_OPT_WLDS_KERNEL 2   /* 0: the 48 -> 48 channel layers stay on the streaming-weights kernel */
+#define DODA_OPT_WDMA_KERNEL 3   /* 0: weight-gradient jobs ignore their tilebook (pair-list / gather-table kernels) */
+int doda_set_option(int32_t option, int32_t value);
+int32_t doda_get_option(int32_t option);
 size_t doda_spconv_stats_capacity(int32_t n_out);
 int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, int32_t elem_bytes, const float *w,
                           int32_t nc, const int32_t *tbl, int32_t ld, int32_t K, int32_t n_out, void *y,
                           int32_t y_is_f32, int32_t w_layout, void *ws, size_t ws_bytes,
                           const doda_conv_epilogue *epi, doda_stream_t stream);
 
-/* dw[o][i][j] = sum_t a[tbl[o][t], i] * b[t, j],  a: [*, ca], b: [n_rows, cb], dw: fp32
- * [K][ca][cb].  Two deterministic stages inside one call (per-row-chunk partials in ws, then a
- * fixed-order reduce); K <= 28. */
-size_t doda_spconv_wgrad_workspace_bytes(int32_t K, int32_t ca, int32_t cb, int32_t n_rows);
-int doda_spconv_wgrad_f32(const float *a, int32_t ca, const float *b, int32_t cb,
-                          const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, float *dw,
-                          void *ws, size_t ws_bytes, doda_stream_t stream);
-int doda_spconv_wgrad_bf16(const uint16_t *a, int32_t ca, const uint16_t *b, int32_t cb,
-                           const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, float *dw,
-                           void *ws, size_t ws_bytes, doda_stream_t stream);
-
-/* The same contraction over spconv-format PAIR LISTS (offset-major lists of present pairs only):
- *   dw[o][i][j] (+)= sum_{p < pair_num[o]} a[pair_in[o*ld + p], i] * b[pair_out[o*ld + p], j]
- * pair_num (device) and pair_seg [K][seg_nt] come from doda_rulebook_pairs: pair_seg[o][t] = number of
- * pairs of list o whose `in` row lies below tile t (256 rows per tile).  A workgroup takes one range of
- * `in` rows and walks, one offset per wave, the matching segment of every list: all offsets of a row
- * range touch the same neighbourhood of rows, so a and b stream from HBM once.  pair_num == NULL and
- * pair_seg == NULL with K == 1: the list holds exactly ld pairs in row order (the 1x1 convolution, both
- * lists = 0..n-1).  bf16, ca % 16 == 0, cb % 16 == 0.
- * Rows are brought into MFMA k-order by a one-hot MFMA instead of an LDS round trip;
- * per-chunk partials in ws, fixed-order reduce: deterministic. */
-size_t doda_spconv_wgrad_pairs_workspace_bytes(int32_t K, int32_t ca, int32_t cb, int32_t ld);
-int doda_spconv_wgrad_pairs_bf16(const uint16_t *a, int32_t n_a, int32_t ca, const uint16_t *b,
-                                 int32_t n_b, int32_t cb, const int32_t *pair_in,
-                                 const int32_t *pair_out, const int32_t *pair_num,
-                                 const int32_t *pair_seg, int32_t seg_nt, int32_t ld, int32_t K, float *dw,
-                                 int32_t accumulate, void *ws, size_t ws_bytes, doda_stream_t stream);
+/* Weight gradient  dw[o][i][j] = sum_t a[tbl[o][t], i] * b[t, j],  a: [*, ca], b: [n_rows, cb], dw: fp32 [K][ca][cb]
+ * (spconv indice_conv_backward's per-offset `Xg^T . dYg`).  ABI 7: doda_spconv_wgrad_multi is the ONE entry point (a
+ * single layer is a call with one job); the per-dtype single-layer calls and doda_spconv_wgrad_pairs_bf16 of ABI <= 6
+ * were its special cases and are gone.  Three kernels behind a job, chosen by the library:
+ *   gather table : every dtype and channel count, K <= 28; per-row-chunk partials, fixed-order reduce;
+ *   pair lists   : bf16, ca % 16 == 0, cb % 16 == 0, spconv-format lists of PRESENT pairs only
+ *                  dw[o] (+)= sum_{p < pair_num[o]} a[pair_in[o*ld + p]]^T b[pair_out[o*ld + p]]; pair_num (device) and
+ *                  pair_seg [K][seg_nt] come from doda_rulebook_pairs (pair_seg[o][t] = pairs of list o whose `in` row
+ *                  lies below tile t, 256 rows per tile).  A workgroup takes one range of `in` rows and walks, one
+ *                  offset per wave, the matching segment of every list: a and b stream from HBM once.  pair_num ==
+ *                  NULL and pair_seg == NULL with K == 1: the list holds exactly ld pairs in row order (the 1x1
+ *                  convolution).  Rows reach MFMA k-order through a one-hot MFMA, no LDS round trip;
+ *   tilebook     : bf16, ca == cb == 16, K == 27, rulebooks of >= 262 144 rows: LDS-staged (see `tilebook` below).
+ * All deterministic (per-chunk / per-workgroup partials in ws, fixed-order reduce). */
 
 /* Weight gradients of MANY layers in one call (one launch per kernel variant + one reduce launch
  * instead of two launches per layer; the coarse levels' small grids run concurrently).  The weight
@@ -369,7 +296,7 @@ typedef struct doda_wgrad_job {
     /* ABI 2.  Optional spconv-format pair lists of the same rulebook (doda_rulebook_pairs):
      * list o = pairs p < pair_num[o] of (a row pair_in[o*pair_ld+p], b row pair_out[o*pair_ld+p]).
      * bf16 jobs with ca % 16 == 0 and cb % 16 == 0 then run the pair kernel (only PRESENT pairs are
-     * walked; see doda_spconv_wgrad_pairs_bf16); other jobs use tbl. */
+     * walked); other jobs use tbl. */
     const int32_t *pair_in, *pair_out, *pair_num;   /* pair_num NULL (K == 1): the list holds pair_ld pairs */
     int32_t pair_ld;      /* leading dimension of pair_in / pair_out */
     int32_t n_a;          /* rows of a (bounds the hardware range check of the pair kernel) */
@@ -418,13 +345,17 @@ int doda_bn_relu_bwd(const void *x, const void *dy, int32_t m, int32_t c, int32_
                      const float *save_mean, const float *save_invstd, const float *gamma,
                      const float *beta, int32_t relu, void *dx, float *dgamma, float *dbeta,
                      void *ws, size_t ws_bytes, doda_stream_t stream);
-/* Same, plus a second gradient of x summed into dx: dx = BN-backward(dy) + add (add: [m, c], dtype of x).
+/* Same, plus a second gradient of x summed into dx: dx = BN-backward(dy) + add (dtype of x).
  * In a pre-activation residual block (model/unet_block.py:23-37) x feeds both the first BatchNorm and
- * the skip connection; autograd would add the two gradients with an extra elementwise pass. */
+ * the skip connection; autograd would add the two gradients with an extra elementwise pass.
+ * ABI 7: `add` is ROW-STRIDED — row r of the second gradient starts at add + r * add_ld elements (add_ld >= c, a
+ * multiple of 4; `add` aligned to 4 elements; add_ld == c: dense) — a column slice of a wider matrix, i.e. the gradient
+ * torch.cat's backward hands to one of its inputs (the U-Net's skip connection, reference model/unet_block.py:93): no
+ * copy into a dense matrix, no separate accumulation kernel. */
 int doda_bn_relu_bwd_add(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
                          const float *save_mean, const float *save_invstd, const float *gamma,
-                         const float *beta, int32_t relu, const void *add, void *dx, float *dgamma,
-                         float *dbeta, void *ws, size_t ws_bytes, doda_stream_t stream);
+                         const float *beta, int32_t relu, const void *add, int32_t add_ld, void *dx,
+                         float *dgamma, float *dbeta, void *ws, size_t ws_bytes, doda_stream_t stream);
 
 /* BatchNorm(+ReLU) whose statistics pass already happened in a conv epilogue (doda_spconv_gather_ex):
  * `stats` = [stats_rows][2][c] partial sums.  Forward: (sum x, sum x^2) -> mean / invstd / running
@@ -437,58 +368,22 @@ int doda_bn_relu_fwd_stats(const void *x, int32_t m, int32_t c, int32_t elem_byt
                            const float *beta, float *running_mean, float *running_var,
                            int64_t *num_batches_tracked, int32_t relu, void *y, float *save_mean,
                            float *save_invstd, doda_stream_t stream);
-/* ABI 6.  doda_bn_relu_bwd_stats / doda_bn_relu_bwd_add with a ROW-STRIDED `add` operand: row r of the second gradient
- * starts at add + r * add_ld elements (add_ld >= c, a multiple of 4; `add` aligned to 4 elements) — a column slice of a
- * wider matrix, i.e. the gradient torch.cat's backward hands to one of its inputs (the U-Net's skip connection,
- * reference model/unet_block.py:93): no copy into a dense matrix, no separate accumulation kernel. */
-int doda_bn_relu_bwd_stats_ld(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
-                              const float *stats, int32_t stats_rows, const float *save_mean,
-                              const float *save_invstd, const float *gamma, const float *beta, int32_t relu,
-                              const void *add, int32_t add_ld, void *dx, float *dgamma, float *dbeta,
-                              float *coef_ws, doda_stream_t stream);
-int doda_bn_relu_bwd_add_ld(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
-                            const float *save_mean, const float *save_invstd, const float *gamma,
-                            const float *beta, int32_t relu, const void *add, int32_t add_ld, void *dx,
-                            float *dgamma, float *dbeta, void *ws, size_t ws_bytes, doda_stream_t stream);
+int doda_bn_relu_bwd_stats(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
+                           const float *stats, int32_t stats_rows, const float *save_mean,
+                           const float *save_invstd, const float *gamma, const float *beta, int32_t relu,
+                           const void *add, int32_t add_ld, void *dx, float *dgamma, float *dbeta,
+                           float *coef_ws, doda_stream_t stream);   /* add / add_ld as doda_bn_relu_bwd_add; add may be NULL */
 /* ABI 6.  The apply half alone: y = relu?((x - mean) * invstd * gamma + beta) with given per-channel vectors (e.g. from two
  * doda_bn_fwd_final calls over the two halves of a channel concatenation, whose statistics rows come from the two convs
  * that produced the halves — reference model/unet_block.py:93 followed by :23). */
 int doda_bn_relu_apply(const void *x, int32_t m, int32_t c, int32_t elem_bytes, const float *mean, const float *invstd,
                        const float *gamma, const float *beta, int32_t relu, void *y, doda_stream_t stream);
 /* ABI 6.  The reduction half of doda_bn_relu_fwd_stats alone (training mode): save_mean / save_invstd [c] from the
- * partial rows, running statistics and num_batches_tracked updated (any of the three may be NULL) — for a BatchNorm whose
- * apply pass rides in the consuming convolution's prologue (doda_conv_epilogue.pre_*). */
+ * partial rows, running statistics and num_batches_tracked updated (any of the three may be NULL) — with
+ * doda_bn_relu_apply: the BatchNorm after a channel concatenation, fed by the statistics rows of its two halves. */
 int doda_bn_fwd_final(const float *stats, int32_t stats_rows, int32_t m, int32_t c, float eps, float momentum,
                       float *running_mean, float *running_var, int64_t *num_batches_tracked, float *save_mean,
                       float *save_invstd, doda_stream_t stream);
-int doda_bn_relu_bwd_stats(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
-                           const float *stats, int32_t stats_rows, const float *save_mean,
-                           const float *save_invstd, const float *gamma, const float *beta, int32_t relu,
-                           const void *add, void *dx, float *dgamma, float *dbeta, float *coef_ws,
-                           doda_stream_t stream);
-
-/* ABI 5.  doda_bn_relu_fwd_stats / _bwd_stats can run their two passes — the reduction of the partial rows and the apply
- * sweep — as ONE launch: the grid's first c/4 workgroups reduce and publish, the others wait on a device flag and then
- * sweep (csrc/bn.hip bn_fwd_chain).  Off by default (it saves issue time but not GPU time on MI355X); doda_bn_set_chain(1)
- * or DODA_BN_CHAIN=1 turns it on;
- * doda_bn_chain_errors() synchronises the device and returns how many launches gave up waiting (0 unless a kernel
- * died; -1 on a runtime error). */
-void doda_bn_set_chain(int32_t on);
-int64_t doda_bn_chain_errors(void);
-
-/* ABI 5.  Same with the statistics already summed over all rows by the conv kernel itself
- * (doda_conv_epilogue.totals: double [2][c]): ONE launch per direction.  Every workgroup of the apply pass derives the
- * per-channel vectors from the totals (fp64, as the `final` kernels do); workgroup 0 also writes save_mean /
- * save_invstd, the running statistics and num_batches_tracked (forward) or dgamma / dbeta (backward). */
-int doda_bn_relu_fwd_totals(const void *x, int32_t m, int32_t c, int32_t elem_bytes, const double *totals, float eps,
-                            float momentum, const float *gamma, const float *beta, float *running_mean,
-                            float *running_var, int64_t *num_batches_tracked, int32_t relu, void *y, float *save_mean,
-                            float *save_invstd, doda_stream_t stream);
-int doda_bn_relu_bwd_totals(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
-                            const double *totals, const float *save_mean, const float *save_invstd, const float *gamma,
-                            const float *beta, int32_t relu, const void *add, void *dx, float *dgamma, float *dbeta,
-                            doda_stream_t stream);
-
 /* ------------------------------------------------------------------------------------------
  * Neighbour queries
  * ---------------------------------------------------------------------------------------- */

@@ -100,10 +100,6 @@ def test_headline_kernels_vs_oracle_on_oracle_pairs(native_lib, oracle, cin, cou
     # element-wise: a bf16 output is the fp64 result rounded once (ties / last-bit summation noise: one step)
     tol = 2.0 ** -7 * ref_y.abs() + 1e-5 * float(ref_y.abs().max())
     assert bool(((yb.float().cpu().double() - ref_y).abs() <= tol).all())
-    if cin == 16 and cout == 16:
-        dx2, dw = ops.spconv_bwd_tile(dyd, xd, wd, tbl, tb)
-        assert rel_err(dx2.float().cpu(), ref_dx) < 2.0 ** -7
-        assert rel_err(dw.cpu().reshape(ref_dw.shape), ref_dw) < 1e-4
     # the weight-gradient kernels of the training path on the same oracle lists
     pr, num, seg = ops.rulebook_pairs(tbl, n, flip=True, pad=False, with_seg=True)
     dw_pairs = ops.spconv_wgrad_pairs(xd, dyd, pr[0], pr[1], num, seg)
@@ -118,57 +114,6 @@ def test_headline_kernels_vs_oracle_on_oracle_pairs(native_lib, oracle, cin, cou
         assert rel_err((outs[1].cpu() - base).reshape(ref_dw2.shape), ref_dw2) < 1e-4
         again = ops.spconv_wgrad_multi([(xd, dyd, tbl, n, None, None, tb)])[0]
         assert torch.equal(again, outs[0])                                  # deterministic
-
-
-@pytest.mark.parametrize("m,layout", [(40000, 0), (40000, 2), (777, 0), (70000, 0)])
-def test_dma_pipeline_kernel_matches_oracle_and_tile_kernel(native_lib, m, layout):
-    """conv_dma16 (spconv_dma.hip; off by default, doda_spconv_set_dma_kernel): the hand-counted LDS-DMA pipeline
-    against the fp64 definition over the table and against conv_tile — plain, with residual, and with the statistics
-    epilogue in both forms (every vmcnt constant of the pipeline is exercised by the 3 .. 35 tiles per workgroup)."""
-    from doda_amd import ops
-    from doda_amd._lib import lib
-    d = dev()
-    shape, batch = [80, 70, 60], 2
-    idx = torch.from_numpy(_raster_scene(5 + m, m, batch, shape)).to(d)
-    tbl = ops.rulebook_subm(idx, shape, batch, 3)
-    n = tbl.shape[1]
-    torch.manual_seed(m + layout)
-    x = torch.randn(n, 16, device=d).bfloat16()
-    res = torch.randn(n, 16, device=d).bfloat16()
-    bnx = torch.randn(n, 16, device=d).bfloat16()
-    w = (torch.randn(27, 16, 16, device=d) * 0.1).bfloat16().float()
-    tb = ops.tilebook_build(tbl)
-    bn = (bnx, torch.randn(16, device=d) * 0.1, torch.rand(16, device=d) + 0.5, torch.rand(16, device=d) + 0.5,
-          torch.randn(16, device=d) * 0.1, True)
-    t = tbl.cpu().long()
-    ref = torch.zeros(n, 16, dtype=torch.float64)
-    for o in range(27):
-        b = w.double().cpu()[o] if layout == 0 else w.double().cpu()[26 - o].t()
-        sel = t[o] >= 0
-        ref[sel] += x.double().cpu()[t[o][sel]] @ b
-
-    def run():
-        a = ops.spconv_gather(x, w, tbl, n, layout, 16, tilebook=tb)
-        b_, sb = ops.spconv_gather(x, w, tbl, n, layout, 16, tilebook=tb, residual=res, want_stats=True)
-        c, sc = ops.spconv_gather(x, w, tbl, n, layout, 16, tilebook=tb, want_stats=True, bn=bn)
-        torch.cuda.synchronize()
-        return a, b_, sb.sum(0), c, sc.sum(0)
-    try:
-        lib().doda_spconv_set_dma_kernel(1)
-        got = run()
-        again = run()
-    finally:
-        lib().doda_spconv_set_dma_kernel(0)
-    want = run()
-    assert rel_err(got[0].float().cpu(), ref) < 2.0 ** -7
-    assert rel_err(got[1].float().cpu(), ref + res.double().cpu()) < 2.0 ** -7
-    for g_, w_, a_ in zip(got, want, again):
-        assert torch.equal(g_, a_)                                            # repeatable bit for bit
-        if g_.dtype == torch.bfloat16:                                         # same sums, maybe another order: one rounding step
-            assert (g_ != w_).float().mean().item() < 0.02
-            assert ((g_.float() - w_.float()).abs() <= 2.0 ** -7 * w_.float().abs() + 1e-6).all()
-        else:
-            assert rel_err(g_.cpu(), w_.cpu()) < 1e-4
 
 
 @pytest.mark.parametrize("n,kind", [(255, "scene"), (300, "scene"), (3001, "scene"), (2000, "random")])
@@ -528,138 +473,6 @@ def test_bn_final_and_apply_in_one_launch_opt_in(native_lib):
     assert " passed" in r.stdout
 
 
-# ------------------------------------------------------------------ statistics finished inside the conv kernels (ABI 5)
-@pytest.mark.parametrize("cin,cout,m,tile", [(16, 16, 40000, True), (32, 32, 30000, True), (48, 48, 12000, False),
-                                             (64, 64, 9000, False), (16, 32, 6000, False), (32, 16, 300, True),
-                                             (96, 96, 5000, False)])
-def test_conv_kernels_finish_their_statistics(native_lib, cin, cout, m, tile):
-    """doda_conv_epilogue.totals: the last workgroup of conv_tile / conv_fast / conv_wlds48 to retire sums the partial
-    rows of the launch (write-through stores, device-scope ticket).  The totals must equal the fp64 sum of the rows the
-    same call returns, in both forms of the epilogue (forward sums; data-grad sums against a BatchNorm input), on every
-    repetition (the ticket re-arms itself) and on a second stream (one ticket per stream)."""
-    from doda_amd import ops
-    d = dev()
-    shape, batch = [80, 70, 60], 2
-    idx = torch.from_numpy(_raster_scene(11 + m, m, batch, shape)).to(d)
-    tbl = ops.rulebook_subm(idx, shape, batch, 3)
-    n = tbl.shape[1]
-    torch.manual_seed(m)
-    x = torch.randn(n, cin, device=d).bfloat16()
-    w = (torch.randn(27, cin, cout, device=d) * 0.1).bfloat16().float()
-    bnx = torch.randn(n, cout, device=d).bfloat16()
-    bn = (bnx, torch.randn(cout, device=d) * 0.1, torch.rand(cout, device=d) + 0.5, torch.rand(cout, device=d) + 0.5,
-          torch.randn(cout, device=d) * 0.1, True)
-    tb = ops.tilebook_build(tbl) if tile else None
-
-    def check(stream_ctx):
-        with stream_ctx:
-            for rep in range(6):
-                for bn_arg in (None, bn):
-                    y, rows, tot = ops.spconv_gather(x, w, tbl, n, 0, cout, tilebook=tb, want_stats=True, bn=bn_arg,
-                                                     want_totals=True)
-                    assert tot is not None, "this kernel is expected to finish its statistics in place"
-                    torch.cuda.current_stream().synchronize()
-                    want = rows.double().sum(0)
-                    assert rows.shape[0] >= 1
-                    err = (tot - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
-                    assert err < 1e-12, (rep, bn_arg is not None, err)
-                    y2, rows2 = ops.spconv_gather(x, w, tbl, n, 0, cout, tilebook=tb, want_stats=True, bn=bn_arg)
-                    assert torch.equal(y, y2) and torch.equal(rows, rows2)      # the finish changes nothing else
-    import contextlib
-    from doda_amd._lib import lib
-    try:
-        lib().doda_spconv_set_stats_finish(1)        # (off by default: it measured slower than the separate reduction)
-        check(contextlib.nullcontext())
-        side = torch.cuda.Stream(device=d)
-        side.wait_stream(torch.cuda.current_stream())
-        check(torch.cuda.stream(side))
-        torch.cuda.current_stream().wait_stream(side)
-    finally:
-        lib().doda_spconv_set_stats_finish(0)
-    # switched off: rows only
-    _, _, tot = ops.spconv_gather(x, w, tbl, n, 0, cout, tilebook=tb, want_stats=True, want_totals=True)
-    assert tot is None
-
-
-@pytest.mark.parametrize("c,m,dt", [(16, 50000, torch.bfloat16), (48, 9001, torch.bfloat16), (32, 20000, torch.float32),
-                                    (112, 5000, torch.bfloat16)])
-def test_batchnorm_from_totals(native_lib, c, m, dt):
-    """doda_bn_relu_fwd_totals / doda_bn_relu_bwd_totals (one launch per direction) against the fp64 definition of
-    training-mode BatchNorm1d + ReLU (reference model/unet_block.py:23-30) and its backward, fed by exact totals."""
-    from doda_amd import ops
-    d = dev()
-    torch.manual_seed(c + m)
-    x = (torch.randn(m, c, device=d) * 1.7 + 0.3).to(dt)
-    gamma = torch.rand(c, device=d) + 0.5
-    beta = torch.randn(c, device=d) * 0.2
-    rm, rv = torch.randn(c, device=d) * 0.1, torch.rand(c, device=d) + 0.5
-    rm0, rv0 = rm.clone(), rv.clone()
-    nbt = torch.zeros((), dtype=torch.long, device=d)
-    xd = x.double()
-    totals = torch.stack([xd.sum(0), (xd * xd).sum(0)]).contiguous()
-    y, mean, invstd = ops.bn_relu_fwd_totals(x, totals, gamma, beta, rm, rv, 0.1, 1e-4, True, nbt)
-    mu, var = xd.mean(0), xd.var(0, unbiased=False)
-    xh = (xd - mu) / torch.sqrt(var + 1e-4)
-    ref = torch.relu(xh * gamma.double() + beta.double())
-    tol = 2.0 ** -7 if dt == torch.bfloat16 else 1e-5
-    assert rel_err(y.float().cpu(), ref.cpu()) < tol
-    assert rel_err(mean.cpu(), mu.cpu()) < 1e-6 and rel_err(invstd.cpu(), (1 / torch.sqrt(var + 1e-4)).cpu()) < 1e-6
-    assert rel_err(rm.cpu(), (0.9 * rm0.double() + 0.1 * mu).cpu()) < 1e-6
-    assert rel_err(rv.cpu(), (0.9 * rv0.double() + 0.1 * xd.var(0, unbiased=True)).cpu()) < 1e-6
-    assert int(nbt.item()) == 1
-    # backward: dz = dy * [y > 0]; totals (sum dz, sum dz * xhat) with the kernel's own fp32 xhat
-    dy = torch.randn(m, c, device=d).to(dt)
-    add = torch.randn(m, c, device=d).to(dt)
-    xh32 = (x.float() - mean) * invstd
-    mask = (xh32 * gamma + beta) > 0
-    dz = dy.float() * mask
-    tot_b = torch.stack([dz.double().sum(0), (dz * xh32).double().sum(0)]).contiguous()
-    dx, dg, db = ops.bn_relu_bwd_totals(x, dy, tot_b, mean, invstd, gamma, beta, True, add=add)
-    a = (gamma * invstd).double()
-    ref_dx = a * (dz.double() - tot_b[0] / m - xh32.double() * (tot_b[1] / m)) + add.double()
-    assert rel_err(dx.float().cpu(), ref_dx.cpu()) < tol
-    assert rel_err(db.cpu(), tot_b[0].cpu()) < 1e-6 and rel_err(dg.cpu(), tot_b[1].cpu()) < 1e-6
-
-
-def test_step_with_and_without_in_kernel_finish(native_lib):
-    """The whole training step (model.voxelize_and_run -> loss -> backward) with the statistics finished inside the conv
-    kernels against the same step with the separate `final` launches: same loss, same gradients up to the fp64
-    summation order of identical fp32 rows."""
-    _ext_or_skip()
-    from doda_amd._lib import lib
-    from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
-    from doda_amd.scene import make_batch
-    d = dev()
-    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in make_batch(2, 30000, 7).items()}
-    cfg = default_cfg()
-
-    import doda_amd.model as M
-
-    def run(on):
-        lib().doda_spconv_set_stats_finish(1 if on else 0)
-        # (the concatenation's BatchNorm takes float statistics ROWS of its halves; with totals it falls back to its own
-        # sweep — a different, equally valid rounding of the same sums: compare like with like)
-        M.CAT_STATS = False
-        torch.manual_seed(0)
-        net = SparseConvNet(cfg).to(d).train()
-        loss = cross_entropy(voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.bfloat16), bd["labels"])
-        loss.backward()
-        torch.cuda.synchronize()
-        return loss.item(), [p.grad.float().cpu() for p in net.parameters()], [b.float().cpu() for b in net.buffers()]
-    try:
-        l1, g1, b1 = run(True)
-        l0, g0, b0 = run(False)
-    finally:
-        lib().doda_spconv_set_stats_finish(0)
-        M.CAT_STATS = True
-    assert abs(l1 - l0) <= 2e-3 * abs(l0)
-    num = sum(float(((a - b) ** 2).sum()) for a, b in zip(g1, g0)) ** 0.5
-    den = sum(float((b ** 2).sum()) for b in g0) ** 0.5
-    assert num / den < 2e-2, num / den
-    for a, b in zip(b1, b0):
-        assert rel_err(a, b) < 1e-3
-
-
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 def test_residual_block_in_one_call_is_the_same_step(native_lib, dt):
     """model.ResidualBlock through ext.residual_block (one extension call per block) issues the same native ops in the
@@ -701,41 +514,6 @@ def test_residual_block_in_one_call_is_the_same_step(native_lib, dt):
     assert all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
     assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
     assert torch.equal(a[3], b[3])
-
-
-def test_batchnorm_passes_chained_in_one_launch(native_lib):
-    """doda_bn_relu_fwd_stats / _bwd_stats as ONE launch (bn_fwd_chain / bn_bwd_chain: the grid's first workgroups reduce
-    the partial rows and publish, the rest wait on a device flag, then sweep) against the two dependent launches: the
-    same arithmetic, so loss, gradients and BatchNorm buffers of a training step are BIT-equal; nobody gave up waiting."""
-    _ext_or_skip()
-    from doda_amd._lib import lib
-    from doda_amd import model as M
-    from doda_amd.scene import make_batch
-    d = dev()
-    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in make_batch(2, 40000, 13).items()}
-    cfg = M.default_cfg()
-
-    def run(on):
-        lib().doda_bn_set_chain(1 if on else 0)
-        torch.manual_seed(0)
-        net = M.SparseConvNet(cfg).to(d).train()
-        losses = []
-        for _ in range(3):
-            net.zero_grad(set_to_none=True)
-            loss = M.cross_entropy(M.voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.bfloat16), bd["labels"])
-            loss.backward()
-            losses.append(loss.detach().clone())
-        torch.cuda.synchronize()
-        return losses, [p.grad.clone() for p in net.parameters()], [b.clone() for b in net.buffers()]
-    try:
-        a = run(True)
-        b = run(False)
-    finally:
-        lib().doda_bn_set_chain(0)      # (the default: it saves issue time, not GPU time)
-    assert all(torch.equal(x, y) for x, y in zip(a[0], b[0]))
-    assert all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
-    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
-    assert lib().doda_bn_chain_errors() == 0
 
 
 def test_one_call_block_yields_to_hooks(native_lib):

@@ -143,59 +143,6 @@ def _oracle_wgrad(x, dy, tbl):
     return dw
 
 
-@pytest.mark.parametrize("m", [40000, 3001, 256])
-def test_fused_backward_tile_kernel(native_lib, m):
-    """doda_spconv_bwd_tile_bf16: dx against the oracle data gradient and the dense-table kernel, dw against
-    the oracle weight gradient on the same bf16 operands (1e-4: exact products, summation order only); an
-    accumulate call adds exactly."""
-    from doda_amd import ops
-    d = dev()
-    _, tbl = _scene_table(m, seed=7 + m)
-    n = tbl.shape[1]
-    torch.manual_seed(m)
-    x = torch.randn(n, 16, device=d).bfloat16()
-    dy = torch.randn(n, 16, device=d).bfloat16()
-    w = (torch.randn(27, 16, 16, device=d) * 0.1).bfloat16().float()    # [K][Cin][Cout]
-    tb = ops.tilebook_build(tbl)
-    dx, dw = ops.spconv_bwd_tile(dy, x, w, tbl, tb)
-    dx_ref = _oracle_conv(dy, w, tbl, 2)
-    assert rel_err(dx.float().cpu(), dx_ref) < 2.0 ** -7
-    dx_dense = ops.spconv_gather(dy, w, tbl, n, 2, 16)
-    assert (dx != dx_dense).float().mean().item() < 0.02
-    dw_ref = _oracle_wgrad(x, dy, tbl)
-    assert rel_err(dw.cpu(), dw_ref) < 1e-4
-    plan = ops.PackPlan([(w, 27, 16, 16, 2, 2)], d)
-    plan.run()
-    acc = dw.clone()
-    dx2, _ = ops.spconv_bwd_tile(dy, x, None, tbl, tb, packed=plan.outputs[0], dw_out=acc)
-    assert torch.equal(dx2, dx)
-    assert rel_err(acc.cpu(), 2 * dw_ref) < 1e-4
-
-
-def test_fused_backward_overflow_tiles(native_lib):
-    from doda_amd import ops
-    d = dev()
-    n = 2000
-    g = torch.Generator().manual_seed(9)
-    # a symmetric table is not required by the kernel's definition: dx and dw follow the table as given
-    tbl = torch.randint(0, n, (27, n), generator=g, dtype=torch.int32)
-    tbl[torch.rand(27, n, generator=g) < 0.5] = -1
-    tbl = tbl.to(d)
-    x = torch.randn(n, 16, device=d).bfloat16()
-    dy = torch.randn(n, 16, device=d).bfloat16()
-    w = (torch.randn(27, 16, 16, device=d) * 0.1).bfloat16().float()
-    tb = ops.tilebook_build(tbl)
-    dx, dw = ops.spconv_bwd_tile(dy, x, w, tbl, tb)
-    assert rel_err(dx.float().cpu(), _oracle_conv(dy, w, tbl, 2)) < 2.0 ** -7
-    # dw[o] = sum_s x[s]^T dy[tbl[26-o][s]]
-    t = tbl.cpu().long()
-    ref = torch.zeros(27, 16, 16, dtype=torch.float64)
-    for o in range(27):
-        sel = t[26 - o] >= 0
-        ref[o] = x.double().cpu()[sel].t() @ dy.double().cpu()[t[26 - o][sel]]
-    assert rel_err(dw.cpu(), ref) < 1e-4
-
-
 @pytest.mark.parametrize("m,nc,layout", [(40000, 16, 0), (40000, 16, 2), (9000, 32, 2), (300, 48, 0)])
 def test_tile_kernel_fp32_features(native_lib, m, nc, layout):
     """fp32 features (the reference's precision), 16 input channels: 64-byte rows through the same staging; 1e-4
@@ -372,13 +319,13 @@ def test_weights_in_lds_kernel_48_channels(native_lib, m, layout):
     ref = _oracle_conv(x, wk, tbl, layout)
     res = torch.randn(n, 48, device=d).bfloat16()
     try:
-        lib().doda_spconv_set_wlds_kernel(0)
+        lib().doda_set_option(2, 0)   # DODA_OPT_WLDS_KERNEL
         y_stream = ops.spconv_gather(x, wk, tbl, n, layout, 48)
-        lib().doda_spconv_set_wlds_kernel(1)
+        lib().doda_set_option(2, 1)
         y = ops.spconv_gather(x, wk, tbl, n, layout, 48)
         y_res = ops.spconv_gather(x, wk, tbl, n, layout, 48, residual=res)
     finally:
-        lib().doda_spconv_set_wlds_kernel(1)
+        lib().doda_set_option(2, 1)
     assert rel_err(y.float().cpu(), ref) < 2.0 ** -7
     assert (y != y_stream).float().mean().item() < 0.02
     assert rel_err(y_res.float().cpu(), ref + res.double().cpu()) < 2.0 ** -7

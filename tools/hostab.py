@@ -1,6 +1,6 @@
 """In-process A/B of a host-side switch on a small scene (the step is then paced by the issuing thread alone):
-alternating blocks of steps with a switch (model.FAST_BLOCKS, or the chained BatchNorm launches) on / off; prints the host issue time per step of each block.
-tools/hostab.py [voxels] [steps] [rounds] [blocks|chain]"""
+alternating blocks of steps with a switch (model.FAST_BLOCKS) on / off; prints the host issue time per step of each block.
+tools/hostab.py [voxels] [steps] [rounds] [blocks]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +12,7 @@ pin_to_device_numa(0)
 vox = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-SWITCH = sys.argv[4] if len(sys.argv) > 4 else "blocks"     # blocks: model.FAST_BLOCKS; chain: doda_bn_set_chain
+SWITCH = sys.argv[4] if len(sys.argv) > 4 else "blocks"     # blocks: model.FAST_BLOCKS
 from doda_amd._lib import lib
 d = torch.device("cuda:0")
 cfg = M.default_cfg(); torch.manual_seed(0)
@@ -45,8 +45,6 @@ for r in range(rounds):
     for fast in (True, False):
         if SWITCH == "blocks":
             M.FAST_BLOCKS = fast
-        elif SWITCH == "chain":
-            lib().doda_bn_set_chain(1 if fast else 0)
         for _ in range(3):
             step()
         torch.cuda.synchronize()

@@ -59,7 +59,6 @@ def main():
         gy = torch.randn(m, 16, device=d).bfloat16()
         plan2 = ops.PackPlan([(w, 27, 16, 16, 2, 2)], d)
         plan2.run()
-        out["bwd_tile_us"] = timed(lambda: ops.spconv_bwd_tile(gy, x, None, data.tbl, tb, packed=plan2.outputs[0]))
         out["dgrad_tile_us"] = timed(lambda: ops.spconv_gather(gy, None, data.tbl, m, 2, 16, packed=plan2.outputs[0], tilebook=tb))
         pairs = data.wgrad_lists()
         jobs = [(x, gy, data.tbl, m, pairs)] * 8
@@ -90,10 +89,10 @@ def main():
         out["tile_stats_res_cold_us"] = timed(lambda: stats(True))
     if a.kc == 48 and a.nc == 48:
         from doda_amd._lib import lib as _l
-        _l().doda_spconv_set_wlds_kernel(0)
+        _l().doda_set_option(2, 0)
         out["stream_weights_us"] = timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, 48, packed=pk))
         out["stream_weights_cold_us"] = timed(lambda: cold(False))
-        _l().doda_spconv_set_wlds_kernel(1)
+        _l().doda_set_option(2, 1)
         out["weights_in_lds_us"] = timed(lambda: ops.spconv_gather(x, None, data.tbl, m, 0, 48, packed=pk))
         out["weights_in_lds_cold_us"] = timed(lambda: cold(False))
     y0 = ops.spconv_gather(x, None, data.tbl, m, 0, a.nc, packed=pk, out_f32=True)
