@@ -497,6 +497,8 @@ def main():
         if prefetch is not None:
             pending[0].result()
             prefetch.shutdown()
+            if prefetch.gated:   # (A/B aid: steps whose build started without the coarse-phase event)
+                sys.stderr.write("[bench] gated prefetch: %d of %d builds ungated (timeouts)\n" % (prefetch.gate_timeouts, steps + warmup))
         return dt, float(loss.detach()), net
 
     elapsed, final_loss, net = run_training(args.dtype, args.steps, args.warmup)

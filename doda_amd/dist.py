@@ -92,6 +92,7 @@ class _Bucket:
         wrote there (doda_amd's conv weight gradients and BatchNorm gamma / beta, through the extension's gradient
         homes) costs nothing; a stray one (another producer, an accumulated second pass that left its home) is copied;
         a missing one counts as zeros, so every rank sends the same message whatever its batch touched."""
+        moved = 0
         for p, v in zip(self.params, self.views):
             g = p.grad
             if g is None:
@@ -101,6 +102,8 @@ class _Bucket:
             else:
                 continue
             p.grad = v
+            moved += 1
+        return moved
 
 
 class GradAllReduce:
@@ -135,6 +138,7 @@ class GradAllReduce:
         # side stream while those kernels run.  Static rule on the weight shape: identical on every rank.
         self._split = False
         self._ext = None
+        self.last_moved = 0
         narrow = []
         try:
             from ._ext import ext as _ext
@@ -172,6 +176,12 @@ class GradAllReduce:
                     self._ext.set_grad_home(p, None)
             self._ext = None
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     @staticmethod
     def _cut(params, bucket_mb):
         """Consecutive parameters of one dtype, ~bucket_mb MB each."""
@@ -199,7 +209,7 @@ class GradAllReduce:
     def _start(self, buckets):
         pending = []
         for b in buckets:
-            b.gather_in_place()
+            self.last_moved += b.gather_in_place()   # (diagnostic: gradients that were NOT produced in their bucket)
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             pending.append((b, dist.all_reduce(b.flat, op=op, async_op=True)))
         return pending
@@ -214,6 +224,7 @@ class GradAllReduce:
         """Call between loss.backward() and optimizer.step()."""
         if not self.active:
             return
+        self.last_moved = 0
         main = torch.cuda.current_stream() if self._split else None
         if self._split and self._ext_wait():
             # the side stream now waits for the wide layers' weight gradients only (and for everything backward

@@ -236,7 +236,7 @@ class UBlock(nn.Module):
                 for r in range(block_reps)))
 
     def forward(self, input):
-        if self.level == COARSE_LEVEL and _coarse_hooks:
+        if self.level == COARSE_LEVEL and _coarse_hooks and self.training and torch.is_grad_enabled():   # (training steps only)
             for hook in list(_coarse_hooks):   # the step enters its coarse levels: few rows, most CUs idle from here on
                 hook()
         out = self.blocks(input)
@@ -475,6 +475,7 @@ class PyramidPrefetcher:
         self.gated = bool(gated)
         self._gate = None            # (threading.Event, torch.cuda.Event) of the build waiting for this step's coarse phase
         self._lock = threading.Lock()
+        self.gate_timeouts = 0       # builds that started WITHOUT the coarse-phase event (steps longer than the wait)
         if self.gated:
             _coarse_hooks.append(self._open_gate)
 
@@ -514,6 +515,14 @@ class PyramidPrefetcher:
             # wait (host side) until the main thread has recorded the coarse-phase event of the step in flight; a step
             # that never gets there (evaluation of a shallow model, an exception) must not hold the pipeline: time out
             opened = gate[0].wait(timeout=0.05)
+            if not opened:
+                # the step in flight did not reach its coarse levels in time (first iterations, evaluation, a profiler
+                # run): this build goes ungated; the stale gate is withdrawn so that nobody records an event for it, and
+                # the count tells an A/B reader how many of its steps were NOT gated
+                with self._lock:
+                    if self._gate is gate:
+                        self._gate = None
+                    self.gate_timeouts += 1
         with torch.cuda.stream(self.stream):
             if gate is not None and opened:
                 self.stream.wait_event(gate[1])
