@@ -66,13 +66,16 @@ __device__ __forceinline__ f32x4 epi_unpack(const u32x2 &v) {
                    __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
 }
 
+// Statistics (round 4): every lane keeps its own running (sum, sum of squares / sum dz * xhat) of the four channels it
+// stores, across ALL tiles of the persistent workgroup (lst[0], lst[1]); the reduction over the 16 rows of a lane group
+// (DPP), the four waves (LDS) and the store of the workgroup's ONE partial row happen once, at the end of the kernel
+// (stats_flush).  Round 3 reduced per tile: 32 DPP operations, an LDS exchange and two barriers in every tile's
+// epilogue — on the tile loop's critical path.  Fixed order whatever the timing: deterministic.
 template <int S, bool OUT32, bool STATS>
-__device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<OUT32> &pre, int row0, int i, int g, int wid,
+__device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<OUT32> &pre, int row0, int i, int g,
                                               int nb0, int nc, int n_out, __amdgpu_buffer_rsrc_t rs_y,
-                                              const void *__restrict__ res, const EpiArgs &ep, int part,
-                                              f32x4 *wg_acc = nullptr) {
+                                              const void *__restrict__ res, const EpiArgs &ep, f32x4 (&lst)[2]) {
     constexpr unsigned OSZ = OUT32 ? 4u : 2u;
-    __shared__ f32x4 sred[STATS ? 4 : 1][2][4];
     const unsigned col = (unsigned)(nb0 * 16 + 4 * g);
     f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -115,23 +118,27 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<O
             __builtin_amdgcn_raw_buffer_store_b64(packed_out, rs_y, voff, 0, 0);
     }
     if constexpr (STATS) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { st1[q] = row_sum16(st1[q]); st2[q] = row_sum16(st2[q]); }
-        if (i == 15) { sred[wid][0][g] = st1; sred[wid][1][g] = st2; }
-        __syncthreads();
-        if (wid == 0 && i == 15 && col < (unsigned)nc) {
-            const f32x4 a1 = (sred[0][0][g] + sred[1][0][g]) + (sred[2][0][g] + sred[3][0][g]);
-            const f32x4 a2 = (sred[0][1][g] + sred[1][1][g]) + (sred[2][1][g] + sred[3][1][g]);
-            if (wg_acc) {     // persistent caller: one partial row per WORKGROUP, summed over its tiles here (LDS, this lane only)
-                wg_acc[(nb0 * 2 + 0) * 4 + g] += a1;
-                wg_acc[(nb0 * 2 + 1) * 4 + g] += a2;
-            } else {
-                float *dst = ep.stats + (long long)part * 2 * nc + col;
-                *reinterpret_cast<f32x4 *>(dst) = a1;
-                *reinterpret_cast<f32x4 *>(dst + nc) = a2;
-            }
-        }
+        lst[0] += st1;
+        lst[1] += st2;
     }
+}
+
+// the workgroup's partial row of channel block nb0 from the lanes' running sums (all 256 threads call it)
+__device__ __forceinline__ void stats_flush(f32x4 (&lst)[2], int i, int g, int wid, int nb0, int nc, float *__restrict__ stats_row) {
+    __shared__ f32x4 sred[4][2][4];
+    f32x4 st1 = lst[0], st2 = lst[1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { st1[q] = row_sum16(st1[q]); st2[q] = row_sum16(st2[q]); }
+    if (i == 15) { sred[wid][0][g] = st1; sred[wid][1][g] = st2; }
+    __syncthreads();
+    const int col = nb0 * 16 + 4 * g;
+    if (wid == 0 && i == 15 && col < nc) {
+        const f32x4 a1 = (sred[0][0][g] + sred[1][0][g]) + (sred[2][0][g] + sred[3][0][g]);
+        const f32x4 a2 = (sred[0][1][g] + sred[1][1][g]) + (sred[2][1][g] + sred[3][1][g]);
+        *reinterpret_cast<f32x4 *>(stats_row + col) = a1;
+        *reinterpret_cast<f32x4 *>(stats_row + nc + col) = a2;
+    }
+    __syncthreads();   // sred is reused by the next channel block
 }
 
 // PERSISTENT: 3 workgroups per CU (LDS footprint), XCD (blockIdx & 7) walks its own contiguous range of
@@ -157,18 +164,17 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
     constexpr int RB = WIDE ? 64 : 32;                         // bytes per staged row
     constexpr int PPR = RB / 16;                               // 16-byte pieces per row
     constexpr int CAP = WIDE ? TB_CAP64 : TB_UMAX;             // distinct rows this kernel stages (LDS budget)
-    constexpr int NRL = (PPR * CAP + 255) / 256;               // row loads per thread
+    constexpr int NLJ = PPR;                                   // 16-byte list loads per thread (one per pass of 256 / PPR entries)
+    constexpr int NRL = 4 * NLJ;                               // row loads per thread
     constexpr int NLI = (TB_K * TB_T * 2 / 16 + 255) / 256;   // 16-byte pieces of the index strip per thread
     __shared__ __attribute__((aligned(16))) unsigned char rows_s[(CAP + 1) * RB];   // slot 0: the zero row
     __shared__ __attribute__((aligned(16))) unsigned short lidx_s[TB_K * TB_T];
-    // BatchNorm statistics: ONE partial row per persistent workgroup (its tiles summed in LDS by the lanes that used to
-    // write a row per tile): <= 768 rows instead of one per 256 output rows, few enough for the BatchNorm's apply pass
-    // to reduce them itself (bn.hip bn_fused_*: the separate `final` launch disappears)
-    constexpr int MAXNB = 8;
-    __shared__ f32x4 wg_acc[STATS ? MAXNB * 2 * 4 : 1];
-    if constexpr (STATS) {
-        if (threadIdx.x < MAXNB * 2 * 4) wg_acc[threadIdx.x] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    // BatchNorm statistics: ONE partial row per persistent workgroup (<= 768 rows instead of one per 256 output rows),
+    // accumulated per lane across the workgroup's tiles and reduced once at the end (tile_epilogue / stats_flush)
+    constexpr int MAXNB = 2;      // channel blocks with statistics (16 / 32 output channels: every tilebook layer of the U-Net)
+    f32x4 lst[STATS ? MAXNB : 1][2];
+#pragma unroll
+    for (int b = 0; b < (STATS ? MAXNB : 1); ++b) lst[b][0] = lst[b][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int tid0 = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
@@ -184,12 +190,18 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
     // piece h = 16 bytes: PPR consecutive lanes take the pieces of one list entry (a wave reads 32 or 16
     // consecutive entries per instruction).  Entries past the count are -1: their row offset is out
     // of range and loads zeros — no lane is masked, no branch.
+    // Round 4: the list is read with 16-byte loads.  Its storage order (tb_upos) keeps entries e0, e0 + 256, e0 + 512,
+    // e0 + 768 in one 16-byte group, so a thread takes the groups e0 = j * (256 / PPR) + tid / PPR, j < PPR: 2 or 4 list
+    // instructions per thread instead of 8 or 15 four-byte ones (the tile kernels are paced by the number of
+    // vector-memory instructions a CU's texture path retires); rid[4 j + k] = entry e0 + 256 k.
+    auto entry_of = [&](int j, int k, int tid) { return j * (256 / PPR) + tid / PPR + 256 * k; };
     auto load_list = [&](int tile, int tid, unsigned (&rid)[NRL]) {
-        const int32_t *ul = tb.ulist + (size_t)tile * TB_UMAX;
+        const u32x4 *ul4 = reinterpret_cast<const u32x4 *>(tb.ulist + (size_t)tile * TB_UMAX);
 #pragma unroll
-        for (int k = 0; k < NRL; ++k) {
-            const int e = (k * 256 + tid) / PPR;
-            rid[k] = e < CAP ? (unsigned)ul[tb_upos(e)] : 0xffffffffu;
+        for (int j = 0; j < NLJ; ++j) {
+            const u32x4 v = ul4[j * (256 / PPR) + tid / PPR];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rid[4 * j + k] = entry_of(j, k, tid) < CAP ? v[k] : 0xffffffffu;
         }
     };
     unsigned rid[NRL];
@@ -243,8 +255,10 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
             }
             if (tid < PPR) reinterpret_cast<u32x4 *>(rows_s)[tid] = (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int k = 0; k < NRL; ++k)
-                if (k * 256 + tid < PPR * CAP) reinterpret_cast<u32x4 *>(rows_s)[PPR + k * 256 + tid] = rr[k];
+            for (int k = 0; k < NRL; ++k) {
+                const int e = entry_of(k >> 2, k & 3, tid);
+                if (e < CAP) reinterpret_cast<u32x4 *>(rows_s)[PPR + e * PPR + (tid & (PPR - 1))] = rr[k];
+            }
         } else {
             // A tile WITHOUT a list (more distinct neighbour rows than the kernel stages: 6 of the bench scene's 2349).  It
             // used to walk the dense table with two dependent round trips per pair of units (table entries -> rows): 14 in
@@ -348,24 +362,17 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                     }
                 }
             }
-            tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, wid, nb0, nc, n_out, rs_y, res, ep, tile, STATS ? wg_acc : nullptr);
-            if (STATS && nb0 + 1 < NB) __syncthreads();   // the statistics scratch is reused by the next channel block
+            // (statistics: static register index — NB <= MAXNB is checked by the launcher)
+            if (nb0 == 0) tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[0]);
+            else tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[STATS ? MAXNB - 1 : 0]);
         }
         __syncthreads();   // the next tile overwrites the staged rows
     }
     if constexpr (STATS) {   // the workgroup's partial row (zeros when it had no tile)
-        __syncthreads();
         const int lane = tid0 & 63, i = lane & 15, g = lane >> 4;
-        if (wid == 0 && i == 15) {
-            for (int nb0 = 0; nb0 < NB && nb0 < MAXNB; ++nb0) {
-                const int col = nb0 * 16 + 4 * g;
-                if (col < nc) {
-                    float *dst = ep.stats + (long long)blockIdx.x * 2 * nc + col;
-                    *reinterpret_cast<f32x4 *>(dst) = wg_acc[(nb0 * 2 + 0) * 4 + g];
-                    *reinterpret_cast<f32x4 *>(dst + nc) = wg_acc[(nb0 * 2 + 1) * 4 + g];
-                }
-            }
-        }
+        float *row = ep.stats + (long long)blockIdx.x * 2 * nc;
+        stats_flush(lst[0], i, g, wid, 0, nc, row);
+        if (NB > 1) stats_flush(lst[MAXNB - 1], i, g, wid, 1, nc, row);
     }
 }
 
@@ -386,7 +393,7 @@ int doda_tile::launch_conv_tile(int mode, bool out32, const void *x, unsigned xb
     const int max_groups = mode == 0 ? BT_MAX_GROUPS : BT_MAX_GROUPS * 2 / 3;
     if (groups > max_groups) groups = max_groups;
     const dim3 grid(groups), block(256);
-    if (NB > 8 && ep_in.stats) return DODA_ERR_UNSUPPORTED;   // (the per-workgroup statistics accumulators hold 8 channel blocks)
+    if (NB > 2 && ep_in.stats) return DODA_ERR_UNSUPPORTED;   // (the lanes' statistics accumulators hold 2 channel blocks: the caller takes the dense-table kernel)
     if (n_part) *n_part = groups;      // one statistics row per persistent workgroup
     const EpiArgs &ep = ep_in;
 #define GT(M, O32, ST)                                                                             \

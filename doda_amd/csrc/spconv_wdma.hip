@@ -45,7 +45,10 @@ constexpr int WD_MAX_JOBS = 16;
 static_assert(WD_BUF_BYTES % 16 == 0 && 2 * WD_BUF_BYTES + 64 <= 160 * 1024, "two tile buffers per CU");
 static_assert(WD_UNITS * 256 * 4 <= WD_BUF_BYTES, "the final exchange re-uses ONE tile buffer (the other may be a DMA target)");
 
-struct WdJob { const void *x, *dy; float *part; };    // part: [groups][27][256] of this layer
+// One 16 x 16 channel block of a layer: x / dy point at the block's first channel, rows lie x_stride / dy_stride BYTES apart
+// (32 for a 16-channel tensor; 64 for a 16-channel half of a 32-channel one: round 4 — a 32 -> 16 layer is two blocks over
+// the halves of x, each staged through the same 32-byte LDS rows).  part: [groups][27][256] of this block.
+struct WdJob { const void *x, *dy; float *part; unsigned x_stride, dy_stride; };
 struct WdJobs { int n; WdJob j[WD_MAX_JOBS]; };
 
 __device__ __forceinline__ u32x4 wd_rsrc(const void *p, unsigned bytes) {
@@ -89,7 +92,7 @@ __device__ __forceinline__ bf16x8 wd_pack_hi16(const f32x4 &d0, const f32x4 &d1)
     return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned feat_bytes, const int32_t *__restrict__ tbl,
+__global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int32_t *__restrict__ tbl,
                                                     int ld, int n, const TileBookView tb) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WD_BUF_BYTES];
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,13 +138,14 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
     };
     auto issue_rows = [&](const Where &q, int item, int k, const u32x2 &rid) {      // k = 0, 1
         const unsigned buf = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
-        const u32x4 rs_x = wd_rsrc(jobs.j[q.job].x, feat_bytes);
+        const unsigned xs = jobs.j[q.job].x_stride;
+        const u32x4 rs_x = wd_rsrc(jobs.j[q.job].x, (unsigned)n * xs - (xs - 32u));
         // The list is sorted with the absent entries (negative) at its end, and a piece covers 32 consecutive entries: a
         // piece whose FIRST entry is absent stages nothing any local index points at — not issued (40 % of the pieces at
         // ~600 distinct rows per tile; every wait in this kernel is vmcnt(0), so counts may differ between waves).  Inside
         // the last used piece an absent entry's row offset is out of range and lands as zeros.
         if (!q.ok || __builtin_amdgcn_readfirstlane((int)rid[k]) < 0) return;
-        wd_dma16(buf + 32u + (unsigned)(((kb + k) * 8 + w8) * 1024), rid[k] * 32u + src_half, rs_x);
+        wd_dma16(buf + 32u + (unsigned)(((kb + k) * 8 + w8) * 1024), rid[k] * xs + src_half, rs_x);
     };
     auto issue_strip = [&](const Where &q, int item) {
         const unsigned buf = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
@@ -151,10 +155,11 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
     auto issue_dy = [&](const Where &q, int item) {
         if (wid < 8) {      // (wave-uniform; every wait in this kernel is vmcnt(0), so waves need not issue equal counts)
             const unsigned buf = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
-            const u32x4 rs_dy = wd_rsrc(jobs.j[q.job].dy, feat_bytes);
+            const unsigned ds = jobs.j[q.job].dy_stride;
+            const u32x4 rs_dy = wd_rsrc(jobs.j[q.job].dy, (unsigned)n * ds - (ds - 32u));
             // rows past n: out of range -> zeros
             wd_dma16(buf + (unsigned)(WD_ROWS_BYTES + WD_LIDX_BYTES) + (unsigned)(wid * 1024),
-                     q.ok ? (q.tile * (unsigned)TB_T + (unsigned)(wid * 32 + (lane >> 1))) * 32u + (unsigned)(lane & 1) * 16u : OOB, rs_dy);
+                     q.ok ? (q.tile * (unsigned)TB_T + (unsigned)(wid * 32 + (lane >> 1))) * ds + (unsigned)(lane & 1) * 16u : OOB, rs_dy);
         }
     };
 
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     v[kk] = (u32x4){0u, 0u, 0u, 0u};
-                    if (gi[kk] >= 0) v[kk] = *reinterpret_cast<const u32x4 *>(xg + (size_t)gi[kk] * 16 + hsel * 8);
+                    if (gi[kk] >= 0) v[kk] = *reinterpret_cast<const u32x4 *>(xg + (size_t)gi[kk] * (jobs.j[qc.job].x_stride >> 1) + hsel * 8);
                 }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
@@ -369,7 +374,8 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, unsigned 
 
 // dw[job][e] (+)= sum over workgroups of part[job][wg][e], fixed order.  One workgroup per 32 outputs and layer; its 16
 // lane groups take every 16th partial, eight loads in flight each, combined in a fixed tree through LDS.
-struct WdRJob { const float *part; float *dw; int accumulate, pad; };
+// e = (o, ci, co) of the 16 x 16 block lands at dw[o * ldo + ci * ldc + co] (dw already points at the block's corner)
+struct WdRJob { const float *part; float *dw; int accumulate, ldo, ldc, pad; };
 struct WdRJobs { WdRJob j[WD_MAX_JOBS]; };
 
 __global__ __launch_bounds__(512) void wgrad_dma_reduce(const WdRJobs jobs, int n_part) {
@@ -392,7 +398,8 @@ __global__ __launch_bounds__(512) void wgrad_dma_reduce(const WdRJobs jobs, int 
         float v = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) v += red[q][jx];
-        d.dw[e] = d.accumulate ? d.dw[e] + v : v;
+        float *dst = d.dw + (size_t)(e >> 8) * d.ldo + (size_t)((e >> 4) & 15) * d.ldc + (e & 15);
+        *dst = d.accumulate ? *dst + v : v;
     }
 }
 
@@ -413,24 +420,25 @@ int groups_for(int n_rows) {
 size_t partial_bytes(int n_rows) { return (size_t)groups_for(n_rows) * TB_K * 256 * sizeof(float); }
 int max_jobs() { return WD_MAX_JOBS; }
 
-// x[k], dy[k], dw[k]: the layers (all over the same table / tilebook, n_rows rows, bf16 [n_rows,16]); part: n x partial_bytes
-int launch(const void *const *x, const void *const *dy, float *const *dw, const int *accumulate, int n_layers,
-           const int32_t *tbl, int ld, int n_rows, const void *tilebook, void *part, hipStream_t s) {
+// blocks[k]: one 16 x 16 channel block of a layer (all over the same table / tilebook, n_rows rows); part: n x partial_bytes
+int launch(const Block *blocks, int n_blocks, const int32_t *tbl, int ld, int n_rows, const void *tilebook, void *part,
+           hipStream_t s) {
     const TileBookView tb = tilebook_view(const_cast<void *>(tilebook), n_rows);
     const int groups = groups_for(n_rows);
-    for (int first = 0; first < n_layers; first += WD_MAX_JOBS) {
-        const int nj = n_layers - first < WD_MAX_JOBS ? n_layers - first : WD_MAX_JOBS;
+    for (int first = 0; first < n_blocks; first += WD_MAX_JOBS) {
+        const int nj = n_blocks - first < WD_MAX_JOBS ? n_blocks - first : WD_MAX_JOBS;
         WdJobs jobs;
         WdRJobs rj;
         ::memset(&jobs, 0, sizeof(jobs));
         ::memset(&rj, 0, sizeof(rj));
         jobs.n = nj;
         for (int k = 0; k < nj; ++k) {
+            const Block &b = blocks[first + k];
             float *p = (float *)((char *)part + (size_t)(first + k) * partial_bytes(n_rows));
-            jobs.j[k] = WdJob{x[first + k], dy[first + k], p};
-            rj.j[k] = WdRJob{p, dw[first + k], accumulate[first + k], 0};
+            jobs.j[k] = WdJob{b.x, b.dy, p, (unsigned)b.x_stride, (unsigned)b.dy_stride};
+            rj.j[k] = WdRJob{p, b.dw, b.accumulate, b.ldo, b.ldc, 0};
         }
-        hipLaunchKernelGGL(wgrad_dma16, dim3(groups), dim3(1024), 0, s, jobs, (unsigned)((size_t)n_rows * 32), tbl, ld, n_rows, tb);
+        hipLaunchKernelGGL(wgrad_dma16, dim3(groups), dim3(1024), 0, s, jobs, tbl, ld, n_rows, tb);
         hipLaunchKernelGGL(wgrad_dma_reduce, dim3(TB_K * 256 / 32, nj), dim3(512), 0, s, rj, groups);
     }
     return doda_check_launch();

@@ -467,9 +467,11 @@ enum { J_SKIP = 0, J_ZERO = 1, J_DENSE = 2, J_PAIRS = 3, J_TILE = 4 };
 static int classify(const doda_wgrad_job &j) {
     if (j.n_rows == 0 && j.dw && j.K > 0 && j.ca > 0 && j.cb > 0)
         return (j.flags & DODA_WGRAD_ACCUMULATE) ? J_SKIP : J_ZERO;
-    // a tilebook of the job's table: the LDS-staged kernel (bf16 16 -> 16, K = 27)
-    if (j.tilebook && j.tbl && j.elem_bytes == 2 && j.ca == 16 && j.cb == 16 && j.K == 27 && j.n_rows > 0 && j.a && j.b && j.dw &&
-        j.n_a == j.n_rows && j.ld >= j.n_rows && (size_t)j.n_rows * 32 < 0x7ffffff0ull && (size_t)j.K * j.ld * 4 < 0xffffffffull &&
+    // a tilebook of the job's table: the LDS-staged kernel (bf16, K = 27; 16 -> 16, and — round 4 — 16 / 32 channels on
+    // either side as 16 x 16 channel blocks over row-strided halves)
+    if (j.tilebook && j.tbl && j.elem_bytes == 2 && (j.ca == 16 || j.ca == 32) && (j.cb == 16 || j.cb == 32) && j.K == 27 &&
+        j.n_rows > 0 && j.a && j.b && j.dw &&
+        j.n_a == j.n_rows && j.ld >= j.n_rows && (size_t)j.n_rows * 64 < 0x7ffffff0ull && (size_t)j.K * j.ld * 4 < 0xffffffffull &&
         !(((uintptr_t)j.a | (uintptr_t)j.b | (uintptr_t)j.tilebook) & 15) && doda_wdma::enabled() &&
         // four tiles per workgroup and more: below, the per-layer exchange + reduce of the persistent schedule cost more
         // than the staging saves (one 150k-voxel scene: 20.5 us against 13 us for the pair lists; 600k voxels: 41 / 57)
@@ -481,6 +483,8 @@ static int classify(const doda_wgrad_job &j) {
     return J_DENSE;
 }
 
+static size_t tile_blocks(const doda_wgrad_job &j) { return (size_t)(j.ca / 16) * (j.cb / 16); }
+
 static bool dense_needs_partial(const JobPlan &jp, const doda_wgrad_job &j) {
     return jp.p.R > 1 || (j.flags & DODA_WGRAD_ACCUMULATE);
 }
@@ -491,7 +495,7 @@ extern "C" size_t doda_spconv_wgrad_multi_workspace_bytes(const doda_wgrad_job *
     for (int k = 0; k < n_jobs; ++k) {
         const int cls = classify(jobs_h[k]);
         if (cls == J_PAIRS) { total += doda_pairs::partial_bytes(jobs_h[k]); continue; }
-        if (cls == J_TILE) { total += align_up(doda_wdma::partial_bytes(jobs_h[k].n_rows), 256); continue; }
+        if (cls == J_TILE) { total += tile_blocks(jobs_h[k]) * align_up(doda_wdma::partial_bytes(jobs_h[k].n_rows), 256); continue; }
         if (cls != J_DENSE) continue;
         JobPlan jp;
         if (!plan_job(jobs_h[k], &jp)) continue;
@@ -536,48 +540,33 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
         const int st = doda_pairs::prepare(jobs_h, pair_jobs.data(), (int)pair_jobs.size(), (char *)ws, &off, &prep);
         if (st != DODA_OK) return st;
     }
-    // tile jobs: one launch per rulebook (jobs sharing table + tilebook), partials behind everything else
-    std::vector<size_t> tile_off(tile_jobs.size());
-    for (size_t q = 0; q < tile_jobs.size(); ++q) {
-        tile_off[q] = off;
-        off += align_up(doda_wdma::partial_bytes(jobs_h[tile_jobs[q]].n_rows), 256);
-    }
-    if (ws_bytes < off) return DODA_ERR_WORKSPACE;
+    // tile jobs: one launch per rulebook (jobs sharing table + tilebook): their 16 x 16 channel blocks in queue order, the
+    // blocks' partials contiguous behind everything else
     {
         std::vector<char> done(tile_jobs.size(), 0);
         for (size_t q = 0; q < tile_jobs.size(); ++q) {
             if (done[q]) continue;
             const doda_wgrad_job &j0 = jobs_h[tile_jobs[q]];
-            std::vector<const void *> xs, dys;
-            std::vector<float *> dws;
-            std::vector<int> accs;
-            // the group's partials must be contiguous: members are taken in queue order and re-based on the first one
-            std::vector<size_t> members;
+            std::vector<doda_wdma::Block> blocks;
             for (size_t r = q; r < tile_jobs.size(); ++r) {
                 const doda_wgrad_job &j = jobs_h[tile_jobs[r]];
                 if (done[r] || j.tilebook != j0.tilebook || j.tbl != j0.tbl || j.n_rows != j0.n_rows || j.ld != j0.ld) continue;
-                members.push_back(r);
+                done[r] = 1;
+                for (int ci = 0; ci < j.ca; ci += 16)
+                    for (int co = 0; co < j.cb; co += 16)
+                        blocks.push_back(doda_wdma::Block{(const char *)j.a + ci * 2, (const char *)j.b + co * 2,
+                                                          j.dw + (size_t)ci * j.cb + co, j.ca * 2, j.cb * 2, j.ca * j.cb, j.cb,
+                                                          (j.flags & DODA_WGRAD_ACCUMULATE) ? 1 : 0});
             }
-            // contiguity: partial slots of equal size were carved in queue order, so members r0 < r1 < ... are NOT
-            // necessarily adjacent; launch runs of adjacent members
-            size_t m0 = 0;
-            while (m0 < members.size()) {
-                size_t m1 = m0 + 1;
-                while (m1 < members.size() && members[m1] == members[m1 - 1] + 1) ++m1;
-                xs.clear(); dys.clear(); dws.clear(); accs.clear();
-                for (size_t m = m0; m < m1; ++m) {
-                    const doda_wgrad_job &j = jobs_h[tile_jobs[members[m]]];
-                    xs.push_back(j.a); dys.push_back(j.b); dws.push_back(j.dw);
-                    accs.push_back((j.flags & DODA_WGRAD_ACCUMULATE) ? 1 : 0);
-                    done[members[m]] = 1;
-                }
-                const int st = doda_wdma::launch(xs.data(), dys.data(), dws.data(), accs.data(), (int)xs.size(), j0.tbl, j0.ld,
-                                                 j0.n_rows, j0.tilebook, (char *)ws + tile_off[members[m0]], s);
-                if (st != DODA_OK) return st;
-                m0 = m1;
-            }
+            const size_t bytes = blocks.size() * align_up(doda_wdma::partial_bytes(j0.n_rows), 256);
+            if (ws_bytes < off + bytes) return DODA_ERR_WORKSPACE;
+            const int st = doda_wdma::launch(blocks.data(), (int)blocks.size(), j0.tbl, j0.ld, j0.n_rows, j0.tilebook,
+                                             (char *)ws + off, s);
+            if (st != DODA_OK) return st;
+            off += bytes;
         }
     }
+    if (ws_bytes < off) return DODA_ERR_WORKSPACE;
 
     // dense descriptors grouped by kernel variant, then the reductions
     std::vector<WJob> wj;

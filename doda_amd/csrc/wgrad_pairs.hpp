@@ -37,7 +37,10 @@ namespace doda_wdma {
 bool enabled();
 void set_enabled(bool on);
 int max_jobs();
-size_t partial_bytes(int n_rows);      // workspace per layer
-int launch(const void *const *x, const void *const *dy, float *const *dw, const int *accumulate, int n_layers,
-           const int32_t *tbl, int ld, int n_rows, const void *tilebook, void *part, hipStream_t s);
+size_t partial_bytes(int n_rows);      // workspace per 16 x 16 channel block
+// One 16 x 16 channel block of a layer's weight gradient: x / dy point at the block's first channel (bf16), rows x_stride /
+// dy_stride bytes apart; the block's corner in the layer's dw [27][ca][cb] and its strides (ldo = ca * cb, ldc = cb).
+struct Block { const void *x, *dy; float *dw; int x_stride, dy_stride, ldo, ldc, accumulate; };
+int launch(const Block *blocks, int n_blocks, const int32_t *tbl, int ld, int n_rows, const void *tilebook, void *part,
+           hipStream_t s);
 }  // namespace doda_wdma

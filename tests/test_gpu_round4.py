@@ -168,6 +168,45 @@ def test_wgrad_dma16_in_the_regime_the_step_selects_it(native_lib, oracle):
         assert rel_err(val.reshape(refs[k].shape), refs[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("ca,cb,big", [(32, 16, True), (16, 32, True), (32, 32, False), (32, 16, False)])
+def test_wgrad_over_the_tilebook_for_32_channel_sides(native_lib, oracle, ca, cb, big):
+    """Round 4: layers with 32 channels on either side run the LDS-staged weight gradient as 16 x 16 channel blocks over
+    row-strided halves of x / dy (doda_wdma::Block) — the level-1 32 -> 16 layer of the U-Net (model/unet_block.py:83-88,
+    blocks_tail) no longer needs the rulebook's pair lists.  Against oracle.indice_conv_backward on oracle-built pairs, at
+    the row count where the step selects the kernel (big) and on a small ragged scene; with an accumulate job; and
+    bit-equal on a second call (fixed-order reduce)."""
+    from doda_amd import ops
+    d = dev()
+    if big:
+        idx, shape, batch, pairs, pn = _big_scene(oracle)
+        tbl, tb = _hip_rulebook(idx, shape, batch, pairs, pn)
+    else:
+        from tests.util import surface_voxels
+        shape, batch = [40, 36, 30], 1
+        idx = surface_voxels(3001, 3001, batch, shape)
+        key = ((idx[:, 0].astype(np.int64) * shape[0] + idx[:, 1]) * shape[1] + idx[:, 2]) * shape[2] + idx[:, 3]
+        idx = np.ascontiguousarray(idx[np.argsort(key, kind="stable")].astype(np.int32))
+        pairs, pn = oracle.indice_pairs_subm(idx, batch, shape, 3)
+        tbl = ops.rulebook_subm(torch.from_numpy(idx).to(d), shape, batch, 3)
+        tb = ops.tilebook_build(tbl)
+    n = idx.shape[0]
+    g = torch.Generator().manual_seed(100 * ca + cb)
+    x = torch.randn(n, ca, generator=g).bfloat16()
+    dy = torch.randn(n, cb, generator=g).bfloat16()
+    ref = oracle.indice_conv_backward(x.double(), torch.zeros(3, 3, 3, ca, cb, dtype=torch.float64), dy.double(), pairs, pn,
+                                      False, True)[1]
+    base = torch.randn(27, ca, cb, generator=g)
+    acc = base.clone().to(d)
+    xd, dyd = x.to(d), dy.to(d)
+    got = ops.spconv_wgrad_multi([(xd, dyd, tbl, n, None, None, tb), (xd, dyd, tbl, n, None, acc, tb)])
+    assert rel_err(got[0].cpu().reshape(ref.shape), ref) < 1e-4
+    assert rel_err((got[1].cpu() - base).reshape(ref.shape), ref) < 1e-4
+    again = ops.spconv_wgrad_multi([(xd, dyd, tbl, n, None, None, tb)])[0]
+    assert torch.equal(again, got[0])
+    dense = ops.spconv_wgrad_multi([(xd, dyd, tbl, n)])[0]              # the gather-table kernel: another summation order
+    assert rel_err(dense.cpu().reshape(ref.shape), ref) < 1e-4 and not torch.equal(dense, got[0])
+
+
 def _config2_step(dtype, tiled, batch_dev, n_steps=1):
     """bench.py's step (deferred weight gradients -> doda_spconv_wgrad_multi, FusedSGD left out: one step's loss and
     gradients) on a resident batch, tilebooks + wgrad_dma16 on or off."""
