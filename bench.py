@@ -106,7 +106,8 @@ def _subm16_times(idx, shape, nb, dtype, reps):
     plan = ops.PackPlan([(w, 27, 16, 16, 0, s), (w, 27, 16, 16, 2, s)], dev)
     plan.run()
     pk_f, pk_d = plan.outputs
-    use_tile = dtype == "bf16" and spconv.ops.TILE_KERNEL
+    from doda_amd.model import tile_levels_for
+    use_tile = spconv.ops.TILE_KERNEL and tile_levels_for(tdt) > 0
     use_pairs = dtype == "bf16" and spconv.functional.WGRAD_PAIRS
     # one buffer set = everything one fwd + dgrad + wgrad of a layer touches
     per_set = 3 * s * m * 16 + (73 * m if use_tile else 108 * m)
@@ -158,7 +159,8 @@ def _subm16_times(idx, shape, nb, dtype, reps):
         return (st.x, st.gy, st.tbl, m, st.pairs if use_pairs else None, None, st.tb if use_wtile else None)
     jobs_warm = [job(sets[0]) for _ in range(n_layers)]
     jobs_cold = [job(sets[j % n_sets]) for j in range(n_layers)]
-    wg_kernel = ("wgrad_dma16 (LDS-staged over the tilebook)" if use_wtile else
+    wg_kernel = ("wgrad_tile_f32 (LDS-staged over the tilebook, exact fp32 MFMA)" if (use_wtile and dtype == "f32") else
+                 "wgrad_dma16 (LDS-staged over the tilebook)" if use_wtile else
                  "wgrad_pairs_kernel<1,1> (pair lists)" if use_pairs else "wgrad_multi_kernel (gather table)")
 
     t = {}
@@ -191,7 +193,7 @@ def _subm16_times(idx, shape, nb, dtype, reps):
 PROFILE_ROUND = "r04"   # in-step / PMC evidence quoted by the bench line must come from THIS round's profiles or be absent
 # the roofline kernel's instantiation as rocprofv3 prints it (template arguments up to the ones that name the epilogue),
 # shared by the live measurement's label and the look-up in the committed kernel statistics
-ROOF_KERNEL = {"bf16": "conv_tile<0, false, true", "f32": "conv_fast<doda_spconv::PF32,"}
+ROOF_KERNEL = {"bf16": "conv_tile<0, false, true", "f32": "conv_tile<2, true, true", "f32_dense": "::PF32,"}
 
 
 def in_step_average(dtype):
@@ -202,7 +204,8 @@ def in_step_average(dtype):
     kernel name in the file) or (None, None, None) — never a figure from an earlier round."""
     import csv
     path = os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (PROFILE_ROUND, "bf16" if dtype == "bf16" else "f32"))
-    want = ROOF_KERNEL["bf16" if dtype == "bf16" else "f32"]
+    from doda_amd.model import tile_levels_for
+    want = ROOF_KERNEL["bf16" if dtype == "bf16" else ("f32" if tile_levels_for(torch.float32) > 0 else "f32_dense")]
     try:
         with open(path) as f:
             rows = [r for r in csv.DictReader(f) if want in r["Name"]]
@@ -235,14 +238,14 @@ def kernel_roofline(batch_dev, dtype, reps, gate_scene=None):
     m, pairs_total = big["M"], big["P"]
     step_cold = big["fwd"]["step_cold"]
     b_step = big["fwd"]["algorithmic_bytes"]["step"]
+    rk = ROOF_KERNEL["bf16" if dtype == "bf16" else ("f32" if big["tile_kernel"] else "f32_dense")]
     if big["tile_kernel"]:
-        kname = ROOF_KERNEL["bf16"] + ", ...> (LDS-staged over the tilebook; BatchNorm statistics + residual add in the epilogue: the instantiation the step launches)"
+        kname = rk + ", ...> (LDS-staged over the tilebook; BatchNorm statistics + residual add in the epilogue: the instantiation the step launches)"
     else:
-        kname = (ROOF_KERNEL["f32"] + " ..., STATS>" if dtype == "f32" else "conv_fast<PBF16P,1,2,3,STATS>") + " (statistics + residual epilogue)"
+        kname = ("conv_fast<PF32, ..., STATS> [" + rk + "]" if dtype == "f32" else "conv_fast<PBF16P,1,2,3,STATS>") + " (statistics + residual epilogue)"
     traffic, traffic_src = pmc_traffic(dtype)
     in_step_us, in_step_src, in_step_name = in_step_average(dtype)
-    if in_step_us is not None and not (kname.startswith(ROOF_KERNEL["bf16" if dtype == "bf16" else "f32"])
-                                       and ROOF_KERNEL["bf16" if dtype == "bf16" else "f32"] in in_step_name):
+    if in_step_us is not None and not (rk in kname and rk in in_step_name):
         in_step_us = in_step_src = in_step_name = None       # the profile describes another kernel than the live figure
     # strict SURVEY 8d bytes of the forward gather (B_f: x + y + weights + 8P; the fused residual operand NOT counted)
     b_8d = big["b_f"]

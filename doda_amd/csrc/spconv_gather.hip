@@ -882,7 +882,11 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     if (ep.res_bcast && !fast) return DODA_ERR_UNSUPPORTED;   // (the broadcast residual lives in conv_fast's epilogue)
     // A tilebook of this table and rows of 32 / 64 bytes: the LDS-staged tile kernel (spconv_tile.hip)
     if (!ep.res_bcast) {
-        const int tmode = pair ? 0 : (wide && kc == 32) ? 1 : (fast && sizeof(elem) == 4 && kc == 16) ? 2 : -1;
+        // (fp32 rows: the tile kernel's fp32 mode is bound by the fp32 matrix rate like the dense-table kernel and measured
+        // within a few percent of it; DODA_F32_CONV_TILE=0 keeps fp32 forward / data-grad calls on conv_fast even when the
+        // table carries a tilebook — the fp32 weight gradient uses the tilebook either way)
+        static const bool f32_tile = !(getenv("DODA_F32_CONV_TILE") && getenv("DODA_F32_CONV_TILE")[0] == '0');
+        const int tmode = pair ? 0 : (wide && kc == 32) ? 1 : (fast && sizeof(elem) == 4 && kc == 16 && f32_tile) ? 2 : -1;
         if (tmode >= 0 && tilebook && K == TB_K && tilebook_rows == n_out && doda_tile::enabled()) {
             const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
             const unsigned yb = (unsigned)((size_t)n_out * nc * (out32 ? 4 : sizeof(elem)));

@@ -318,6 +318,11 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                 lr[0] = loadl(0);
                 lr[1] = loadl(1);
                 fetch(lr[0], xa[0]);
+                // (MODE 2, fp32: skipping the MFMAs of (offset, 16-row subtile) slots without a present neighbour — ~45 % of
+                // them on a surface scene — was built twice (round 3: per-subtile test inside the unit; round 4: wave-uniform
+                // presence masks from ballots, operand reads unconditional, one branch per slot) and measured SLOWER both
+                // times: 88 / 154 us against 84 us dense at level 1 — 108 branches per wave and tile between MFMA groups
+                // and 250 VGPRs cost more than the skipped matrix work; the dense loop stays)
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     if (u + 2 < NU) lr[(u + 2) % 3] = loadl(u + 2);

@@ -403,6 +403,12 @@ __global__ __launch_bounds__(512) void wgrad_dma_reduce(const WdRJobs jobs, int 
     }
 }
 
+// (Round 4 built the fp32 counterpart — wgrad_tile_f32: x rows, index strip and dy rows staged in LDS, the next tile held in
+// registers during the multiply, rows as the k dimension of v_mfma_f32_16x16x4_f32, k-steps without a present neighbour
+// skipped — parity-green against the oracle and SLOWER than the gather-table kernel: 132-143 us against 110 us per level-1
+// layer (8 layers per call).  The fp32 matrix rate (1/16 of bf16) puts 53 us of MFMA issue under a dense layer, 4-byte LDS
+// operand reads (one per lane and k-step: 4.6 k LDS instructions per tile) another ~45 us, and sixteen waves leaving a
+// barrier together run the two phases one after the other.  Removed)
 bool g_use_wdma = !(getenv("DODA_NO_WDMA") && getenv("DODA_NO_WDMA")[0] == '1');
 
 }  // namespace

@@ -469,8 +469,8 @@ static int classify(const doda_wgrad_job &j) {
         return (j.flags & DODA_WGRAD_ACCUMULATE) ? J_SKIP : J_ZERO;
     // a tilebook of the job's table: the LDS-staged kernel (bf16, K = 27; 16 -> 16, and — round 4 — 16 / 32 channels on
     // either side as 16 x 16 channel blocks over row-strided halves)
-    if (j.tilebook && j.tbl && j.elem_bytes == 2 && (j.ca == 16 || j.ca == 32) && (j.cb == 16 || j.cb == 32) && j.K == 27 &&
-        j.n_rows > 0 && j.a && j.b && j.dw &&
+    if (j.tilebook && j.tbl && j.elem_bytes == 2 && (j.ca == 16 || j.ca == 32) && (j.cb == 16 || j.cb == 32) &&
+        j.K == 27 && j.n_rows > 0 && j.a && j.b && j.dw &&
         j.n_a == j.n_rows && j.ld >= j.n_rows && (size_t)j.n_rows * 64 < 0x7ffffff0ull && (size_t)j.K * j.ld * 4 < 0xffffffffull &&
         !(((uintptr_t)j.a | (uintptr_t)j.b | (uintptr_t)j.tilebook) & 15) && doda_wdma::enabled() &&
         // four tiles per workgroup and more: below, the per-layer exchange + reduce of the persistent schedule cost more
@@ -552,10 +552,11 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
                 const doda_wgrad_job &j = jobs_h[tile_jobs[r]];
                 if (done[r] || j.tilebook != j0.tilebook || j.tbl != j0.tbl || j.n_rows != j0.n_rows || j.ld != j0.ld) continue;
                 done[r] = 1;
+                const int es = 2;
                 for (int ci = 0; ci < j.ca; ci += 16)
                     for (int co = 0; co < j.cb; co += 16)
-                        blocks.push_back(doda_wdma::Block{(const char *)j.a + ci * 2, (const char *)j.b + co * 2,
-                                                          j.dw + (size_t)ci * j.cb + co, j.ca * 2, j.cb * 2, j.ca * j.cb, j.cb,
+                        blocks.push_back(doda_wdma::Block{(const char *)j.a + ci * es, (const char *)j.b + co * es,
+                                                          j.dw + (size_t)ci * j.cb + co, j.ca * es, j.cb * es, j.ca * j.cb, j.cb,
                                                           (j.flags & DODA_WGRAD_ACCUMULATE) ? 1 : 0});
             }
             const size_t bytes = blocks.size() * align_up(doda_wdma::partial_bytes(j0.n_rows), 256);

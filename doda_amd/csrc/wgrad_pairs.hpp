@@ -32,7 +32,7 @@ size_t desc_bytes_per_job();
 
 }  // namespace doda_pairs
 
-// LDS-staged weight gradient over a tilebook (spconv_wdma.hip): bf16 16 -> 16 layers sharing one table
+// LDS-staged weight gradient over a tilebook (spconv_wdma.hip): bf16 layers of 16 / 32 channels sharing one table
 namespace doda_wdma {
 bool enabled();
 void set_enabled(bool on);

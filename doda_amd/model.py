@@ -415,11 +415,17 @@ class SparseConvNet(nn.Module):
 _PYR_STREAMS = {}
 
 
+F32_TILES = _os.environ.get("DODA_F32_TILES", "0") == "1"
+
+
 def tile_levels_for(dtype):
-    """Levels whose SubM rulebook gets a tilebook: the two finest for bf16 (rows of 32 / 64 bytes).  The tile kernel
-    also takes fp32 16-channel rows, but that layer is bound by the fp32 matrix rate (83.7 us against 86.3 us for the
-    dense-table kernel at level 1), which does not pay for the tilebook build: off by default."""
-    return 2 if dtype == torch.bfloat16 else 0
+    """Levels whose SubM rulebook gets a tilebook: the two finest for bf16 (rows of 32 / 64 bytes).  The tile kernel also
+    takes fp32 16-channel rows (DODA_F32_TILES=1: level 1), but fp32 layers are bound by the fp32 matrix rate, 1/16 of
+    bf16: measured in round 4 the fp32 step takes 12.2 ms with the tilebook against 11.9 ms on the dense-table kernels
+    (conv_tile MODE 2 96 us against conv_fast 97 us per level-1 layer, and the tilebook build on top): off by default."""
+    if dtype == torch.bfloat16:
+        return 2
+    return 1 if (dtype == torch.float32 and F32_TILES) else 0
 
 
 def _prebuild_pyramid(voxel_coords, spatial_shape, batch_size, n_levels, device, with_pairs=False, with_tiles=None):

@@ -28,7 +28,7 @@ s = 4 if dt == "f32" else 2
 plan = ops.PackPlan([(w, 27, c, c, 0, s), (w, 27, c, c, 2, s)], dev); plan.run()
 pairs = sub.wgrad_lists() if which == "wgradp" else None
 res = torch.randn(m, c, device=dev).to(tdt)
-tb = ops.tilebook_build(sub.tbl) if (dt == "bf16" and c == 16 and os.environ.get("DODA_NO_TILE", "0") != "1") else None   # fp32 stays on conv_fast
+tb = ops.tilebook_build(sub.tbl) if (c == 16 and os.environ.get("DODA_NO_TILE", "0") != "1") else None
 for _ in range(reps):
     if which == "fwd": ops.spconv_gather(x, None, sub.tbl, m, 0, c, packed=plan.outputs[0], tilebook=tb)
     elif which == "dgrad": ops.spconv_gather(gy, None, sub.tbl, m, 2, c, packed=plan.outputs[1], tilebook=tb)
