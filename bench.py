@@ -155,10 +155,18 @@ def _subm16_times(idx, shape, nb, dtype, reps):
     # the LDS-staged tile kernel when it is enabled, else the pair-list kernel)
     use_wtile = use_tile and os.environ.get("DODA_NO_WDMA", "0") != "1"
 
-    def job(st):
-        return (st.x, st.gy, st.tbl, m, st.pairs if use_pairs else None, None, st.tb if use_wtile else None)
+    def job(st, rb=None):
+        rb = st if rb is None else rb      # the set whose rulebook (table, pair lists, tilebook) the layer uses
+        return (st.x, st.gy, rb.tbl, m, rb.pairs if use_pairs else None, None, rb.tb if use_wtile else None)
     jobs_warm = [job(sets[0]) for _ in range(n_layers)]
-    jobs_cold = [job(sets[j % n_sets]) for j in range(n_layers)]
+    # cold: as in the step, the layers of one call share ONE rulebook (the deferred flush issues a level's layers together)
+    # and differ in their operands; consecutive calls take the next rulebook copy, so nothing of a call is cache-resident
+    jobs_cold = [[job(sets[(c + j) % n_sets], sets[c]) for j in range(n_layers)] for c in range(n_sets)]
+    kc = [0]
+
+    def wgrad_cold():
+        kc[0] = (kc[0] + 1) % n_sets
+        ops.spconv_wgrad_multi(jobs_cold[kc[0]])
     wg_kernel = ("wgrad_tile_f32 (LDS-staged over the tilebook, exact fp32 MFMA)" if (use_wtile and dtype == "f32") else
                  "wgrad_dma16 (LDS-staged over the tilebook)" if use_wtile else
                  "wgrad_pairs_kernel<1,1> (pair lists)" if use_pairs else "wgrad_multi_kernel (gather table)")
@@ -169,7 +177,7 @@ def _subm16_times(idx, shape, nb, dtype, reps):
             for step in (False, True):
                 t[(name, cold, step)] = _timed(lambda: fn(cold, step), reps)
     t_w = {False: _timed(lambda: ops.spconv_wgrad_multi(jobs_warm), max(5, reps // 4), per=n_layers),
-           True: _timed(lambda: ops.spconv_wgrad_multi(jobs_cold), max(5, reps // 4), per=n_layers)}
+           True: _timed(wgrad_cold, max(5, reps // 4), per=n_layers)}
 
     def rec(sec, nbytes):
         return {"us": sec * 1e6, "GBs": nbytes / sec / 1e9, "frac_of_hbm_peak": nbytes / sec / 1e9 / HBM_PEAK_GBS}

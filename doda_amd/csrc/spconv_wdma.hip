@@ -22,8 +22,8 @@
 // of tile j, each wave at a different step (the waves leave the barrier together, and sixteen waves queueing on the CU's
 // texture path at the same instant stall each other instead of overlapping with the matrix work).
 // The 54 units (offset, half of the tile's k-steps) are dealt to the 16 waves; accumulators stay in registers across
-// all tiles of a layer; per layer and workgroup one partial [27][16][16] is written (256 partials instead of the 768
-// a three-workgroups-per-CU schedule would produce), summed in a fixed order by wgrad_dma_reduce: deterministic.
+// all tiles a workgroup has of a 16 x 16 channel block; per (workgroup, block it touches) one partial [27][16][16] is written
+// (block-major chunks: see the schedule in the kernel), summed in a fixed order by wgrad_dma_reduce: deterministic.
 #include "common.hpp"
 #include "tilebook.hpp"
 #include "spconv_common.hpp"
@@ -48,7 +48,7 @@ static_assert(WD_UNITS * 256 * 4 <= WD_BUF_BYTES, "the final exchange re-uses ON
 // One 16 x 16 channel block of a layer: x / dy point at the block's first channel, rows lie x_stride / dy_stride BYTES apart
 // (32 for a 16-channel tensor; 64 for a 16-channel half of a 32-channel one: round 4 — a 32 -> 16 layer is two blocks over
 // the halves of x, each staged through the same 32-byte LDS rows).  part: [groups][27][256] of this block.
-struct WdJob { const void *x, *dy; float *part; unsigned x_stride, dy_stride; };
+struct WdJob { const void *x, *dy; float *part; unsigned x_stride, dy_stride; int first_rank, pad; };   // first_rank: see the schedule
 struct WdJobs { int n; WdJob j[WD_MAX_JOBS]; };
 
 __device__ __forceinline__ u32x4 wd_rsrc(const void *p, unsigned bytes) {
@@ -100,20 +100,17 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
     const u32x4 rs_ul = wd_rsrc(tb.ulist, (unsigned)tb.nt * (unsigned)TB_UMAX * 4u);
     const u32x4 rs_li = wd_rsrc(tb.lidx, (unsigned)tb.nt * (unsigned)(TB_K * TB_T * 2));
 
-    // persistent schedule: XCD (blockIdx & 7) owns one contiguous range of tiles, its L workgroups stride it
-    const int L = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int qn = tb.nt >> 3, rn = tb.nt & 7;
-    const int lo = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
-    const int cnt = qn + (xcd < rn ? 1 : 0);
-    const int nt_w = slot < cnt ? (cnt - slot + L - 1) / L : 0;      // tiles of this workgroup (per layer)
-    const int n_items = nt_w * jobs.n;                               // (layer, tile) items, layer-major
-    if (nt_w == 0) {   // more workgroups than tiles: this one still owns a partial per layer
-        for (int job = 0; job < jobs.n; ++job) {
-            float *dst = jobs.j[job].part + (size_t)blockIdx.x * (TB_K * 256);
-            for (int e = tid; e < TB_K * 256; e += 1024) dst[e] = 0.f;
-        }
-        return;
-    }
+    // Persistent schedule (round 4: BLOCK-major).  The (block, tile) items of the launch, block-major, are cut into gridDim.x
+    // contiguous chunks; workgroup rank r = (XCD, slot) takes chunk r, so an XCD owns one contiguous stretch of the list
+    // (adjacent tiles share most of their neighbour rows: L2 reuse) and a workgroup sees at most two or three blocks: it
+    // writes ONE partial per block it touches — (gridDim.x + blocks) partials per launch.  Round 3 let every workgroup
+    // walk every block of the launch over its own strided tiles: blocks x gridDim.x partials (76 MB written and read
+    // again at level 1 with 11 blocks, a flush of four barriers per block and workgroup).
+    const int G = gridDim.x, nt = tb.nt;
+    const int rank = (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+    const long long N = (long long)jobs.n * nt;
+    const int start = (int)((long long)rank * N / G), n_items = (int)((long long)(rank + 1) * N / G) - start;
+    if (n_items == 0) return;     // (more workgroups than items: no partial slot was counted for this one)
 
     if (tid < 4) reinterpret_cast<u32x4 *>(smem + (tid >> 1) * WD_BUF_BYTES)[tid & 1] = (u32x4){0u, 0u, 0u, 0u};   // zero rows
 
@@ -127,8 +124,9 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
     auto where = [&](int item) {     // (one scalar division per item, not per piece)
         Where q;
         q.ok = item < n_items;
-        q.job = q.ok ? item / nt_w : 0;
-        q.tile = (unsigned)(lo + slot + (q.ok ? item - q.job * nt_w : 0) * L);
+        const int gid = start + (q.ok ? item : 0);
+        q.job = gid / nt;
+        q.tile = (unsigned)(gid - q.job * nt);
         return q;
     };
     auto issue_list = [&](const Where &q, u32x2 &rid) {
@@ -325,7 +323,7 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
 
     // the layer's partial: units -> LDS, halves added, one [27][256] block per workgroup
     // (exchange through the buffer the last tile was read from: the other one is the target of the next item's DMA)
-    auto flush = [&](int job, int bufsel) {
+    auto flush = [&](int job, int bufsel, int last_gid) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done reading the buffer
         float *ex = reinterpret_cast<float *>(smem + bufsel * WD_BUF_BYTES);
 #pragma unroll
@@ -338,7 +336,10 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
             acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        float *dst = jobs.j[job].part + (size_t)blockIdx.x * (TB_K * 256);
+        // partial slot inside the block: consecutive ranks share a block when every rank has items (N >= G); with fewer items
+        // than workgroups every non-empty rank holds exactly one tile and the tile's index is the slot
+        const int pslot = N >= G ? rank - jobs.j[job].first_rank : last_gid - job * nt;
+        float *dst = jobs.j[job].part + (size_t)pslot * (TB_K * 256);
         for (int e = tid; e < TB_K * 256; e += 1024) {
             const int o = e >> 8, c = e & 255;
             dst[e] = ex[(2 * o) * 256 + c] + ex[(2 * o + 1) * 256 + c];
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
             body(item, nl_cur, lb, la);
             nl_cur = nl_next;
         }
-        if ((item + 1) % nt_w == 0) flush(item / nt_w, item & 1);
+        if (item + 1 == n_items || (start + item + 1) % nt == 0) flush((start + item) / nt, item & 1, start + item);   // the block's last tile here
         if (item + 1 >= n_items) break;
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(la) : : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
             body(item + 1, nl_cur, la, lb);
             nl_cur = nl_next;
         }
-        if ((item + 2) % nt_w == 0) flush((item + 1) / nt_w, (item + 1) & 1);
+        if (item + 2 == n_items || (start + item + 2) % nt == 0) flush((start + item + 1) / nt, (item + 1) & 1, start + item + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -375,12 +376,13 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
 // dw[job][e] (+)= sum over workgroups of part[job][wg][e], fixed order.  One workgroup per 32 outputs and layer; its 16
 // lane groups take every 16th partial, eight loads in flight each, combined in a fixed tree through LDS.
 // e = (o, ci, co) of the 16 x 16 block lands at dw[o * ldo + ci * ldc + co] (dw already points at the block's corner)
-struct WdRJob { const float *part; float *dw; int accumulate, ldo, ldc, pad; };
+struct WdRJob { const float *part; float *dw; int accumulate, ldo, ldc, n_part; };   // n_part: partials of this block
 struct WdRJobs { WdRJob j[WD_MAX_JOBS]; };
 
-__global__ __launch_bounds__(512) void wgrad_dma_reduce(const WdRJobs jobs, int n_part) {
+__global__ __launch_bounds__(512) void wgrad_dma_reduce(const WdRJobs jobs) {
     __shared__ float red[16][32];
     const WdRJob d = jobs.j[blockIdx.y];
+    const int n_part = d.n_part;
     const int jx = threadIdx.x & 31, p = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + jx;
     float a[8];
@@ -430,7 +432,8 @@ int max_jobs() { return WD_MAX_JOBS; }
 int launch(const Block *blocks, int n_blocks, const int32_t *tbl, int ld, int n_rows, const void *tilebook, void *part,
            hipStream_t s) {
     const TileBookView tb = tilebook_view(const_cast<void *>(tilebook), n_rows);
-    const int groups = groups_for(n_rows);
+    const int groups = groups_for(n_rows), nt = tb.nt;
+    size_t used = 0;      // partial slots handed out so far (bytes)
     for (int first = 0; first < n_blocks; first += WD_MAX_JOBS) {
         const int nj = n_blocks - first < WD_MAX_JOBS ? n_blocks - first : WD_MAX_JOBS;
         WdJobs jobs;
@@ -438,14 +441,30 @@ int launch(const Block *blocks, int n_blocks, const int32_t *tbl, int ld, int n_
         ::memset(&jobs, 0, sizeof(jobs));
         ::memset(&rj, 0, sizeof(rj));
         jobs.n = nj;
+        // which ranks touch which block (the kernel's chunking, restated): first rank and count per block
+        int first_rank[WD_MAX_JOBS], count[WD_MAX_JOBS];
+        for (int k = 0; k < nj; ++k) { first_rank[k] = -1; count[k] = 0; }
+        const long long N = (long long)nj * nt;
+        if (N >= groups) {
+            for (int r = 0; r < groups; ++r) {
+                const long long st = (long long)r * N / groups, en = (long long)(r + 1) * N / groups;
+                for (long long b = st / nt; b <= (en - 1) / nt; ++b) {
+                    if (first_rank[b] < 0) first_rank[b] = r;
+                    ++count[b];
+                }
+            }
+        } else {      // fewer items than workgroups: one tile per non-empty rank, slot = tile index
+            for (int k = 0; k < nj; ++k) { first_rank[k] = 0; count[k] = nt; }
+        }
         for (int k = 0; k < nj; ++k) {
             const Block &b = blocks[first + k];
-            float *p = (float *)((char *)part + (size_t)(first + k) * partial_bytes(n_rows));
-            jobs.j[k] = WdJob{b.x, b.dy, p, (unsigned)b.x_stride, (unsigned)b.dy_stride};
-            rj.j[k] = WdRJob{p, b.dw, b.accumulate, b.ldo, b.ldc, 0};
+            float *p = (float *)((char *)part + used);
+            used += (size_t)count[k] * TB_K * 256 * sizeof(float);
+            jobs.j[k] = WdJob{b.x, b.dy, p, (unsigned)b.x_stride, (unsigned)b.dy_stride, first_rank[k], 0};
+            rj.j[k] = WdRJob{p, b.dw, b.accumulate, b.ldo, b.ldc, count[k]};
         }
         hipLaunchKernelGGL(wgrad_dma16, dim3(groups), dim3(1024), 0, s, jobs, tbl, ld, n_rows, tb);
-        hipLaunchKernelGGL(wgrad_dma_reduce, dim3(TB_K * 256 / 32, nj), dim3(512), 0, s, rj, groups);
+        hipLaunchKernelGGL(wgrad_dma_reduce, dim3(TB_K * 256 / 32, nj), dim3(512), 0, s, rj);
     }
     return doda_check_launch();
 }

@@ -464,6 +464,13 @@ Staging g_staging;
 // job classes of a multi call
 enum { J_SKIP = 0, J_ZERO = 1, J_DENSE = 2, J_PAIRS = 3, J_TILE = 4 };
 
+// rows from which a rulebook's tile jobs take the LDS-staged kernel even when pair lists are at hand (measurement aid:
+// DODA_WDMA_MIN_ROWS)
+static int wdma_min_rows() {
+    static const int v = getenv("DODA_WDMA_MIN_ROWS") ? atoi(getenv("DODA_WDMA_MIN_ROWS")) : 32768;
+    return v;
+}
+
 static int classify(const doda_wgrad_job &j) {
     if (j.n_rows == 0 && j.dw && j.K > 0 && j.ca > 0 && j.cb > 0)
         return (j.flags & DODA_WGRAD_ACCUMULATE) ? J_SKIP : J_ZERO;
@@ -473,9 +480,11 @@ static int classify(const doda_wgrad_job &j) {
         j.K == 27 && j.n_rows > 0 && j.a && j.b && j.dw &&
         j.n_a == j.n_rows && j.ld >= j.n_rows && (size_t)j.n_rows * 64 < 0x7ffffff0ull && (size_t)j.K * j.ld * 4 < 0xffffffffull &&
         !(((uintptr_t)j.a | (uintptr_t)j.b | (uintptr_t)j.tilebook) & 15) && doda_wdma::enabled() &&
-        // four tiles per workgroup and more: below, the per-layer exchange + reduce of the persistent schedule cost more
-        // than the staging saves (one 150k-voxel scene: 20.5 us against 13 us for the pair lists; 600k voxels: 41 / 57)
-        (j.n_rows >= 4 * 256 * 256 || !doda_pairs::eligible(j)))
+        // round 4 (block-major chunks: one or two partials per workgroup whatever the number of layers): faster than the pair
+        // lists from ~40 k rows up — 8 layers per call: 601 k rows 21.3 / 43.3 us per layer, 152 k rows 7.2 / 13.0, level 2
+        // (154 k rows, 32 -> 32 as four blocks) 21.3 / 23.7, 37 k rows 10.3 / 10.1 (tools/wl2.py).  Round 3's schedule (every
+        // workgroup walked every layer: a flush per layer and workgroup) lost below 262 k rows.
+        (j.n_rows >= wdma_min_rows() || !doda_pairs::eligible(j)))
         return J_TILE;
     // DODA_WGRAD_NO_PAIRS=1 keeps every job on the gather-table kernel (A/B measurements)
     static const bool no_pairs = getenv("DODA_WGRAD_NO_PAIRS") && getenv("DODA_WGRAD_NO_PAIRS")[0] == '1';

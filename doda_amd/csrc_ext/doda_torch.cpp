@@ -286,11 +286,10 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
         if (tiled) build_tilebook(nbr, st);
         at::Tensor sp, sn, sh, dp, dn, dh;
         const bool with_pairs = pairs_min_rows >= 0 && m >= pairs_min_rows;
-        // (round 4) a SubM rulebook with a tilebook and >= 262 144 rows needs no pair lists: every bf16 layer of 16 / 32
-        // channels on either side takes the LDS-staged weight gradient over the tilebook (csrc/spconv_wgrad.hip classify();
-        // a layer it does not take falls back to the gather table) — the export was 60 % of the pair-list kernels' time
-        // on the rulebook stream for ONE layer of the U-Net (level 1, 32 -> 16)
-        const bool subm_pairs = with_pairs && !(tiled && m >= 4 * 256 * 256);
+        // (round 4) a SubM rulebook with a tilebook needs no pair lists: every bf16 layer of 16 / 32 channels on either side
+        // takes the LDS-staged weight gradient over the tilebook (csrc/spconv_wgrad.hip classify(): from 32 768 rows, the
+        // smallest rulebook that gets a tilebook; a layer it does not take falls back to the gather table)
+        const bool subm_pairs = with_pairs && !tiled;
         if (subm_pairs) std::tie(sp, sn, sh) = export_pairs(nbr, m, true, st);
         if (lvl == n_levels - 1) {
             out.emplace_back(nbr, at::Tensor(), at::Tensor(), at::Tensor(), std::vector<int64_t>(), sp, sn, sh, dp, dn, dh);

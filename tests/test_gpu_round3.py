@@ -112,8 +112,13 @@ def test_headline_kernels_vs_oracle_on_oracle_pairs(native_lib, oracle, cin, cou
         outs = ops.spconv_wgrad_multi([(xd, dyd, tbl, n, None, None, tb), (x2.to(d), dyd, tbl, n, None, acc, tb)])
         assert rel_err(outs[0].cpu().reshape(ref_dw.shape), ref_dw) < 1e-4
         assert rel_err((outs[1].cpu() - base).reshape(ref_dw2.shape), ref_dw2) < 1e-4
-        again = ops.spconv_wgrad_multi([(xd, dyd, tbl, n, None, None, tb)])[0]
-        assert torch.equal(again, outs[0])                                  # deterministic
+        # deterministic: the same call again is bit-equal (the workgroups' chunks depend on the number of channel blocks in
+        # a launch, so a call with other jobs agrees to rounding only)
+        acc_b = base.clone().to(d)
+        again = ops.spconv_wgrad_multi([(xd, dyd, tbl, n, None, None, tb), (x2.to(d), dyd, tbl, n, None, acc_b, tb)])
+        assert torch.equal(again[0], outs[0]) and torch.equal(again[1], outs[1])
+        alone = ops.spconv_wgrad_multi([(xd, dyd, tbl, n, None, None, tb)])[0]
+        assert rel_err(alone.cpu(), outs[0].cpu()) < 1e-5
 
 
 @pytest.mark.parametrize("n,kind", [(255, "scene"), (300, "scene"), (3001, "scene"), (2000, "random")])

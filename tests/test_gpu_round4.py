@@ -201,8 +201,13 @@ def test_wgrad_over_the_tilebook_for_32_channel_sides(native_lib, oracle, ca, cb
     got = ops.spconv_wgrad_multi([(xd, dyd, tbl, n, None, None, tb), (xd, dyd, tbl, n, None, acc, tb)])
     assert rel_err(got[0].cpu().reshape(ref.shape), ref) < 1e-4
     assert rel_err((got[1].cpu() - base).reshape(ref.shape), ref) < 1e-4
-    again = ops.spconv_wgrad_multi([(xd, dyd, tbl, n, None, None, tb)])[0]
-    assert torch.equal(again, got[0])
+    # bit-equal when the same call is repeated (fixed-order reduce; the workgroups' chunks — hence the summation order —
+    # depend on how many channel blocks a launch holds, so a call with other jobs agrees to rounding only)
+    acc2 = base.clone().to(d)
+    again = ops.spconv_wgrad_multi([(xd, dyd, tbl, n, None, None, tb), (xd, dyd, tbl, n, None, acc2, tb)])
+    assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])
+    alone = ops.spconv_wgrad_multi([(xd, dyd, tbl, n, None, None, tb)])[0]
+    assert rel_err(alone.cpu(), got[0].cpu()) < 1e-5
     dense = ops.spconv_wgrad_multi([(xd, dyd, tbl, n)])[0]              # the gather-table kernel: another summation order
     assert rel_err(dense.cpu().reshape(ref.shape), ref) < 1e-4 and not torch.equal(dense, got[0])
 

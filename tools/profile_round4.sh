@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-3 artifacts on the GPU box: default bench line, rocprofv3 kernel stats of the same step (bf16 + fp32), and
+# Round-4 artifacts on the GPU box: default bench line, rocprofv3 kernel stats of the same step (bf16 + fp32), and
 # FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs, kernel-trace only) for the roofline kernel in the form the step
 # launches it (conv_tile<0,false,true>: statistics + residual) and for the tile weight gradient (wgrad_dma16).
-# usage: tools/profile_r03.sh [tag]   -> gpurun_out/<tag>/
+# usage: tools/profile_r04.sh [tag]   -> gpurun_out/<tag>/
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-tag=${1:-r03}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
+tag=${1:-r04}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
 timeout 900 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $out/prof_bf16 -o k -- python bench.py --no-cpu-baseline --fp32-steps 0 --kernel-reps 5 > $out/bench_bf16_under_rocprof.json 2> $out/prof_bf16.err
 timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $out/prof_f32 -o k -- python bench.py --dtype f32 --no-cpu-baseline --steps 40 --warmup 10 --kernel-reps 5 > $out/bench_f32_under_rocprof.json 2> $out/prof_f32.err
