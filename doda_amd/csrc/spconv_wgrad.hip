@@ -474,11 +474,11 @@ static int wdma_min_rows() {
 static int classify(const doda_wgrad_job &j) {
     if (j.n_rows == 0 && j.dw && j.K > 0 && j.ca > 0 && j.cb > 0)
         return (j.flags & DODA_WGRAD_ACCUMULATE) ? J_SKIP : J_ZERO;
-    // a tilebook of the job's table: the LDS-staged kernel (bf16, K = 27; 16 -> 16, and — round 4 — 16 / 32 channels on
-    // either side as 16 x 16 channel blocks over row-strided halves)
-    if (j.tilebook && j.tbl && j.elem_bytes == 2 && (j.ca == 16 || j.ca == 32) && (j.cb == 16 || j.cb == 32) &&
+    // a tilebook of the job's table: the LDS-staged kernel (bf16, K = 27; 16 -> 16, and — round 4 — 16 .. 64 channels on
+    // either side as 16 x 16 channel blocks over row-strided slices)
+    if (j.tilebook && j.tbl && j.elem_bytes == 2 && j.ca % 16 == 0 && j.ca <= 64 && j.cb % 16 == 0 && j.cb <= 64 &&
         j.K == 27 && j.n_rows > 0 && j.a && j.b && j.dw &&
-        j.n_a == j.n_rows && j.ld >= j.n_rows && (size_t)j.n_rows * 64 < 0x7ffffff0ull && (size_t)j.K * j.ld * 4 < 0xffffffffull &&
+        j.n_a == j.n_rows && j.ld >= j.n_rows && (size_t)j.n_rows * 128 < 0x7ffffff0ull && (size_t)j.K * j.ld * 4 < 0xffffffffull &&
         !(((uintptr_t)j.a | (uintptr_t)j.b | (uintptr_t)j.tilebook) & 15) && doda_wdma::enabled() &&
         // round 4 (block-major chunks: one or two partials per workgroup whatever the number of layers): faster than the pair
         // lists from ~40 k rows up — 8 layers per call: 601 k rows 21.3 / 43.3 us per layer, 152 k rows 7.2 / 13.0, level 2

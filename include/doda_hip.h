@@ -277,7 +277,8 @@ int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, int32_t elem_
  *                  offset per wave, the matching segment of every list: a and b stream from HBM once.  pair_num ==
  *                  NULL and pair_seg == NULL with K == 1: the list holds exactly ld pairs in row order (the 1x1
  *                  convolution).  Rows reach MFMA k-order through a one-hot MFMA, no LDS round trip;
- *   tilebook     : bf16, ca == cb == 16, K == 27, rulebooks of >= 262 144 rows: LDS-staged (see `tilebook` below).
+ *   tilebook     : bf16, ca and cb multiples of 16 up to 64, K == 27, rulebooks of >= 32 768 rows: LDS-staged, as 16 x 16
+ *                  channel blocks over row-strided slices of a and b (see `tilebook` below).
  * All deterministic (per-chunk / per-workgroup partials in ws, fixed-order reduce). */
 
 /* Weight gradients of MANY layers in one call (one launch per kernel variant + one reduce launch
@@ -305,9 +306,12 @@ typedef struct doda_wgrad_job {
     const int32_t *pair_seg;     /* [K][pair_seg_nt] segment prefix of the lists (see doda_rulebook_pairs), with */
     int32_t pair_seg_nt;         /* pair_num; both NULL / 0 for the full identity lists of a 1x1 convolution   */
     int32_t reserved2;
-    /* ABI 4.  Optional tilebook of `tbl` (doda_tilebook_build, built for n_rows rows): bf16 jobs with ca == cb == 16 and
-     * K == 27 then run the LDS-staged kernel (spconv_wdma.hip: the tile's distinct a rows and its b rows are staged once
-     * per 256 rows by LDS-DMA instead of being gathered per pair); jobs of one call that share a tilebook share a launch. */
+    /* ABI 4.  Optional tilebook of `tbl` (doda_tilebook_build, built for n_rows rows): bf16 jobs with K == 27 and 16 .. 64
+     * channels on either side (ABI 7; ABI <= 6: ca == cb == 16) then run the LDS-staged kernel (spconv_wdma.hip: per 16 x 16
+     * channel block the tile's distinct a rows and its b rows are staged once per 256 rows by LDS-DMA instead of being
+     * gathered per pair); jobs of one call that share a tilebook share a launch, and the SUMMATION ORDER of a job depends on
+     * the other tile jobs of its call (workgroups take contiguous chunks of the call's (block, tile) list): results are
+     * deterministic per call, equal across call shapes to fp32 rounding. */
     const void *tilebook;
 } doda_wgrad_job;
 #define DODA_WGRAD_ACCUMULATE 1   /* dw += result (second backward pass into an existing .grad) */

@@ -168,7 +168,7 @@ def test_wgrad_dma16_in_the_regime_the_step_selects_it(native_lib, oracle):
         assert rel_err(val.reshape(refs[k].shape), refs[k]) < 1e-4, k
 
 
-@pytest.mark.parametrize("ca,cb,big", [(32, 16, True), (16, 32, True), (32, 32, False), (32, 16, False)])
+@pytest.mark.parametrize("ca,cb,big", [(32, 16, True), (16, 32, True), (32, 32, False), (32, 16, False), (64, 32, False)])
 def test_wgrad_over_the_tilebook_for_32_channel_sides(native_lib, oracle, ca, cb, big):
     """Round 4: layers with 32 channels on either side run the LDS-staged weight gradient as 16 x 16 channel blocks over
     row-strided halves of x / dy (doda_wdma::Block) — the level-1 32 -> 16 layer of the U-Net (model/unet_block.py:83-88,
