@@ -13,6 +13,7 @@
 // All kernels are HBM/L2-latency-bound integer work: one lane per voxel, coalesced reads of the
 // int4 coordinate rows, coalesced table writes (tbl[o][t] with t across lanes).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -89,6 +90,77 @@ __global__ __launch_bounds__(256) void subm_probe(const int4 *__restrict__ indic
         nbr[(long long)o * ld + t] = v;
         if (v >= 0) nbr[(long long)(K3 - 1 - o) * ld + v] = t;
     }
+}
+
+// ---- direct-address grid (round 4) ---------------------------------------------------------------
+// For grids of up to DODA_RULEBOOK_GRID_MAX_CELLS cells (a batch of 2 cm ScanNet scenes: 16.5 M cells = 66 MB of int32)
+// the cell -> row map is a plain array: grid[cell] = row or -1.  A probe is ONE 4-byte read instead of 1.3 eight-byte
+// hash reads, and the three z-neighbours of a (dx, dy) pair are adjacent words: the 13 probes of a voxel touch ~5
+// 64-byte sectors instead of ~17 — the hash probe ran at the fabric's random-sector rate.  The caller
+// opts in by handing over a workspace with room for the grid behind the hash workspace (doda_hip.h); larger grids
+// (1 cm scenes: 2^34 cells) keep the hash.  Same results: first-touch (lowest row) wins a cell, as hash_insert_min.
+constexpr long long GRID_MAX_CELLS = 1ll << 26;
+
+__device__ __forceinline__ bool in_grid(const int4 c, int batch, const GridDesc g) {
+    return (unsigned)c.x < (unsigned)batch && (unsigned)c.y < (unsigned)g.X && (unsigned)c.z < (unsigned)g.Y && (unsigned)c.w < (unsigned)g.Z;
+}
+
+__global__ __launch_bounds__(256) void subm_grid_insert(const int4 *__restrict__ indices, int m, int batch, GridDesc g,
+                                                        int32_t *__restrict__ grid, int32_t *__restrict__ nbr, int ld,
+                                                        int first_fill, int k3) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const int4 c = indices[t];
+    if (in_grid(c, batch, g)) atomicMin((unsigned *)grid + (long long)cell_id(c.x, c.y, c.z, c.w, g), (unsigned)t);
+    for (int o = first_fill; o < k3; ++o) nbr[(long long)o * ld + t] = -1;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void subm_grid_probe(const int4 *__restrict__ indices, int m, int batch, GridDesc g,
+                                                       const int32_t *__restrict__ grid, int32_t *__restrict__ nbr, int ld) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const int4 c = indices[t];  // (b, x, y, z)
+    constexpr int R = KS / 2, K3 = KS * KS * KS, NP = K3 / 2;
+    nbr[(long long)NP * ld + t] = t;   // centre
+    const bool own_ok = in_grid(c, batch, g);
+    int v[NP];
+#pragma unroll
+    for (int o = 0; o < NP; ++o) {
+        const int k0 = o / (KS * KS), k1 = (o / KS) % KS, k2 = o % KS;
+        const int x = c.y + k0 - R, y = c.z + k1 - R, z = c.w + k2 - R;
+        const bool inb = own_ok && x >= 0 && x < g.X && y >= 0 && y < g.Y && z >= 0 && z < g.Z;
+        v[o] = inb ? grid[(long long)cell_id(c.x, x, y, z, g)] : -1;
+    }
+#pragma unroll
+    for (int o = 0; o < NP; ++o) {
+        nbr[(long long)o * ld + t] = v[o];
+        if (v[o] >= 0) nbr[(long long)(K3 - 1 - o) * ld + v[o]] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void down2_grid_insert(const int4 *__restrict__ indices, int m, int batch, GridDesc go,
+                                                         int32_t *__restrict__ grid, int32_t *__restrict__ off) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int4 c = indices[j];
+    off[j] = ((c.y & 1) * 2 + (c.z & 1)) * 2 + (c.w & 1);
+    const int4 q = make_int4(c.x, c.y >> 1, c.z >> 1, c.w >> 1);
+    if (c.y < 0 || c.z < 0 || c.w < 0 || !in_grid(q, batch, go)) return;
+    atomicMin((unsigned *)grid + (long long)cell_id(q.x, q.y, q.z, q.w, go), (unsigned)j);
+}
+
+__global__ __launch_bounds__(256) void down2_grid_first(const int4 *__restrict__ indices, int m, int batch, GridDesc go,
+                                                        const int32_t *__restrict__ grid, int32_t *__restrict__ firstj,
+                                                        int32_t *__restrict__ flag) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int4 c = indices[j];
+    const int4 q = make_int4(c.x, c.y >> 1, c.z >> 1, c.w >> 1);
+    int f = -1;
+    if (!(c.y < 0 || c.z < 0 || c.w < 0) && in_grid(q, batch, go)) f = grid[(long long)cell_id(q.x, q.y, q.z, q.w, go)];
+    firstj[j] = f;
+    flag[j] = (f == j) ? 1 : 0;
 }
 
 // ---- Down2 (kernel 2, stride 2, pad 0) ------------------------------------------------------
@@ -381,6 +453,16 @@ bool grid_fmt(int batch, int X, int Y, int Z, unsigned long long max_value, Hash
 }
 }  // namespace
 
+// the direct-address grid behind the hash workspace, or null (no room / grid too large / switched off)
+static int32_t *dense_grid(void *ws, size_t ws_bytes, size_t hash_total, int batch, const GridDesc g) {
+    static const bool off = getenv("DODA_RULEBOOK_GRID") && getenv("DODA_RULEBOOK_GRID")[0] == '0';
+    if (off || batch <= 0 || g.X <= 0 || g.Y <= 0 || g.Z <= 0) return nullptr;
+    const long double cells = (long double)batch * g.X * g.Y * g.Z;
+    if (cells > (long double)GRID_MAX_CELLS) return nullptr;
+    const size_t at = align_up(hash_total, 256), need = at + (size_t)cells * 4;
+    return ws_bytes >= need ? (int32_t *)((char *)ws + at) : nullptr;
+}
+
 extern "C" size_t doda_rulebook_workspace_bytes(int32_t m) { return carve(nullptr, m).total; }
 
 extern "C" int doda_rulebook_subm(const int32_t *indices, int32_t m, const int32_t *shape_h,
@@ -401,6 +483,15 @@ extern "C" int doda_rulebook_subm(const int32_t *indices, int32_t m, const int32
         // identity table
         hipLaunchKernelGGL((subm_probe<1>), dim3(grid), dim3(256), 0, s, (const int4 *)indices, m,
                            g, w.tab, w.cap - 1, hf, nbr, ld);
+        return doda_check_launch();
+    }
+    int32_t *dgrid = dense_grid(ws, ws_bytes, w.total, batch, g);
+    if (dgrid) {      // direct-address grid: the caller's workspace has room for it (and the grid is small enough)
+        hipMemsetAsync(dgrid, 0xFF, (size_t)batch * g.X * g.Y * g.Z * 4, s);
+        hipLaunchKernelGGL(subm_grid_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, (int)batch, g, dgrid,
+                           nbr, ld, 14, 27);
+        hipLaunchKernelGGL((subm_grid_probe<3>), dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, (int)batch, g, dgrid,
+                           nbr, ld);
         return doda_check_launch();
     }
     hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
@@ -433,11 +524,19 @@ extern "C" int doda_rulebook_down2_assign(const int32_t *indices, int32_t m,
     const RbWs w = carve(ws, m);
     if (ws_bytes < w.total) return DODA_ERR_WORKSPACE;
     const int grid = div_up(m, 256);
-    hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
-    hipLaunchKernelGGL(down2_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, go,
-                       w.tab, w.cap - 1, hf, off);
-    hipLaunchKernelGGL(down2_first, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, go,
-                       w.tab, w.cap - 1, hf, w.a /*firstj*/, w.b /*flag*/);
+    int32_t *dgrid = dense_grid(ws, ws_bytes, w.total, batch, go);
+    if (dgrid) {
+        hipMemsetAsync(dgrid, 0xFF, (size_t)batch * go.X * go.Y * go.Z * 4, s);
+        hipLaunchKernelGGL(down2_grid_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, (int)batch, go, dgrid, off);
+        hipLaunchKernelGGL(down2_grid_first, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, (int)batch, go, dgrid,
+                           w.a /*firstj*/, w.b /*flag*/);
+    } else {
+        hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
+        hipLaunchKernelGGL(down2_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, go,
+                           w.tab, w.cap - 1, hf, off);
+        hipLaunchKernelGGL(down2_first, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, go,
+                           w.tab, w.cap - 1, hf, w.a /*firstj*/, w.b /*flag*/);
+    }
     int st = exclusive_scan_i32(w.b, w.c /*rank*/, m, counts_out, w.scan, s);
     if (st != DODA_OK) return st;
     hipLaunchKernelGGL(down2_finalize, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, w.a,

@@ -274,7 +274,11 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
     for (int64_t lvl = 0; lvl < n_levels; ++lvl) {
         const int32_t m = (int32_t)indices.size(0);
         int32_t shp[3] = {(int32_t)shape[0], (int32_t)shape[1], (int32_t)shape[2]};
-        const size_t wsb = doda_rulebook_workspace_bytes(m);
+        size_t wsb = doda_rulebook_workspace_bytes(m);
+        {   // room for the direct-address grid behind it (doda_hip.h: grids of <= 2^26 cells; larger ones keep the hash)
+            const long double cells = (long double)batch * shape[0] * shape[1] * shape[2];
+            if (m > 0 && cells > 0 && cells <= (long double)(1ll << 26)) wsb = (wsb + 255) / 256 * 256 + (size_t)cells * 4;
+        }
         at::Tensor ws = at::empty({(int64_t)(wsb > 256 ? wsb : 256)}, iopt.dtype(at::kByte));
         // tilebooks for the finest `tile_levels` levels: DODA's 16- and 32-channel bf16 layers (2) or the 16-channel
         // fp32 layers (1) — rows of 32 or 64 bytes, what the tile kernel stages

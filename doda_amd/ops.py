@@ -154,6 +154,19 @@ def _check_indices(indices):
     return indices.contiguous()
 
 
+RULEBOOK_GRID_MAX_CELLS = 1 << 26
+
+
+def _rulebook_ws(m, batch_size, shape3, device):
+    """Workspace of a rulebook build: doda_rulebook_workspace_bytes(m), plus — for grids of up to 2^26 cells — room for the
+    direct-address grid behind it (include/doda_hip.h: the build then replaces the hash table by a plain cell -> row array)."""
+    nbytes = lib().doda_rulebook_workspace_bytes(m)
+    cells = int(batch_size) * int(shape3[0]) * int(shape3[1]) * int(shape3[2])
+    if m > 0 and 0 < cells <= RULEBOOK_GRID_MAX_CELLS:
+        nbytes = (nbytes + 255) // 256 * 256 + 4 * cells
+    return _ws(nbytes, device)
+
+
 def rulebook_subm(indices, spatial_shape, batch_size, ksize=3):
     """Gather table int32 [ksize^3, M] of a SubMConv3d (nbr[o][t] = input row or -1)."""
     indices = _check_indices(indices)
@@ -161,7 +174,7 @@ def rulebook_subm(indices, spatial_shape, batch_size, ksize=3):
     shape_c, _ = _shape3(spatial_shape)
     K = ksize ** 3
     nbr = torch.empty((K, m), dtype=torch.int32, device=indices.device)
-    ws = _ws(lib().doda_rulebook_workspace_bytes(m), indices.device)
+    ws = _rulebook_ws(m, batch_size, _shape3(spatial_shape)[1], indices.device)
     check(lib().doda_rulebook_subm(_p(indices), m, shape_c, int(batch_size), int(ksize), _p(nbr), m,
                                    _p(ws), ws.numel(), _stream()), "doda_rulebook_subm")
     return nbr
@@ -179,7 +192,7 @@ def rulebook_down2(indices, spatial_shape, batch_size):
     off = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
     out_idx_full = torch.empty((max(m, 1), 4), dtype=torch.int32, device=dev)
     count = torch.empty(1, dtype=torch.int32, device=dev)   # always written by the scan
-    ws = _ws(lib().doda_rulebook_workspace_bytes(m), dev)
+    ws = _rulebook_ws(m, batch_size, out_shape, dev)
     check(lib().doda_rulebook_down2_assign(_p(indices), m, shape_c, int(batch_size), _p(parent),
                                            _p(off), _p(out_idx_full), _p(count), _p(ws), ws.numel(),
                                            _stream()), "doda_rulebook_down2_assign")

@@ -262,3 +262,57 @@ def test_config2_size_step_tile_path_vs_dense_table_path(native_lib, dtype, monk
     for k, a in g0.items():
         b = g1[k]
         assert (a.float() - b.float()).norm().item() <= tol[1] * a.float().norm().item() + 1e-6, k
+
+
+@pytest.mark.parametrize("kind,m,shape,batch", [("surface", 30000, [80, 70, 60], 2), ("random", 5000, [33, 21, 47], 3),
+                                                 ("bench", 150000, None, 1)])
+def test_rulebook_direct_address_grid_equals_the_hash_build(native_lib, oracle, kind, m, shape, batch):
+    """Round 4: doda_rulebook_subm / doda_rulebook_down2_assign with room for a direct-address grid in the workspace
+    (include/doda_hip.h) against the same calls on the minimum workspace (64-bit hash table): SubM tables, k2 s2 parents /
+    offsets / first-touch output rows / count bit-equal, and the SubM table equal to the oracle's pair lists."""
+    import ctypes as C
+    from doda_amd import ops
+    from doda_amd._lib import lib, check
+    from tests.util import random_voxels, surface_voxels
+    d = dev()
+    if kind == "bench":
+        from doda_amd.scene import make_batch
+        b = make_batch(1, m, 77)
+        idx, shape, batch = b["voxel_locs"].int().numpy(), [int(v) for v in b["spatial_shape"]], 1
+    else:
+        idx = (surface_voxels if kind == "surface" else random_voxels)(5, m, batch, shape)
+    n = idx.shape[0]
+    ind = torch.from_numpy(np.ascontiguousarray(idx)).to(d)
+    shape_c = (C.c_int32 * 3)(*shape)
+    stream = torch.cuda.current_stream().cuda_stream
+    base = lib().doda_rulebook_workspace_bytes(n)
+
+    def build(with_grid, coarse):
+        shp = [(v - 2) // 2 + 1 for v in shape] if coarse else shape
+        cells = batch * shp[0] * shp[1] * shp[2]
+        nbytes = (base + 255) // 256 * 256 + 4 * cells if with_grid else base
+        return torch.empty(nbytes, dtype=torch.uint8, device=d)
+
+    tables = []
+    for with_grid in (False, True):
+        ws = build(with_grid, False)
+        nbr = torch.empty((27, n), dtype=torch.int32, device=d)
+        check(lib().doda_rulebook_subm(ind.data_ptr(), n, shape_c, batch, 3, nbr.data_ptr(), n, ws.data_ptr(), ws.numel(), stream),
+              "doda_rulebook_subm")
+        ws2 = build(with_grid, True)
+        parent = torch.empty(n, dtype=torch.int32, device=d)
+        off = torch.empty(n, dtype=torch.int32, device=d)
+        out_idx = torch.zeros((n, 4), dtype=torch.int32, device=d)
+        count = torch.zeros(1, dtype=torch.int32, device=d)
+        check(lib().doda_rulebook_down2_assign(ind.data_ptr(), n, shape_c, batch, parent.data_ptr(), off.data_ptr(),
+                                               out_idx.data_ptr(), count.data_ptr(), ws2.data_ptr(), ws2.numel(), stream),
+              "doda_rulebook_down2_assign")
+        torch.cuda.synchronize()
+        mo = int(count.item())
+        tables.append((nbr.cpu(), parent.cpu(), off.cpu(), out_idx[:mo].cpu(), mo))
+    for a, b_ in zip(tables[0][:4], tables[1][:4]):
+        assert torch.equal(a, b_)
+    assert tables[0][4] == tables[1][4] > 0
+    pairs, pn = oracle.indice_pairs_subm(np.ascontiguousarray(idx), batch, shape, 3)
+    hp, hn = ops.rulebook_pairs(tables[1][0].to(d), n, flip=True)
+    assert np.array_equal(hn.cpu().numpy(), pn) and np.array_equal(hp.cpu().numpy(), pairs)

@@ -20,6 +20,11 @@ wp, wt = True, tile_levels_for(torch.bfloat16)
 
 
 def run(mode):
+    if mode.startswith("inline"):
+        return run_inline(mode)
+    if mode.startswith("dummy"):
+        _, n, big = mode.split("_")
+        return run_dummy(int(n), int(big))
     pf = PyramidPrefetcher(d, 7, gated=(mode == "gated")) if mode != "reuse" else PyramidPrefetcher(d, 7, gated=False)
     pend = [pf.submit(bd, wp, wt, resident=True, now=True)]
     fixed = PyramidPrefetcher.take(pf.submit(bd, wp, wt, resident=True, now=True), d) if mode == "reuse" else None
@@ -57,9 +62,84 @@ def run(mode):
     return dt
 
 
-res = {"start": [], "gated": [], "reuse": []}
+def run_dummy(n_launch, big):
+    """reuse mode + n_launch tiny (or `big`-element) fill kernels on an independent side stream per step: what do side-stream
+    LAUNCHES cost the step, apart from their work?"""
+    from doda_amd.streams import independent_stream
+    side = independent_stream(d, tag="rulebooks")
+    pf = PyramidPrefetcher(d, 7, gated=False)
+    fixed = PyramidPrefetcher.take(pf.submit(bd, wp, wt, resident=True, now=True), d)
+    buf = torch.empty(max(big, 64), dtype=torch.int32, device=d)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.stream(side):
+            for _ in range(n_launch):
+                buf.fill_(1)
+        loss = cross_entropy(voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.bfloat16, inputs_ready=True, pyramid=fixed), bd["labels"])
+        loss.backward()
+        opt.step()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    pf.shutdown()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def run_inline(mode):
+    """The NEXT batch's pyramid built by the ISSUING thread itself on the side stream — no second thread in the HIP runtime;
+    inline_start: at the top of the step (its six size read-backs block the issuing thread while the main stream still has
+    the previous step's tail queued), inline_mid: between forward and backward."""
+    from doda_amd.streams import independent_stream
+    side = independent_stream(d, tag="rulebooks")
+
+    def build():
+        with torch.cuda.stream(side):
+            idx32 = bd["voxel_locs"].int()
+            probe = spconv.SparseConvTensor(None, idx32, bd["spatial_shape"], 4)
+            spconv.ops.build_pyramid(probe, 7, with_pairs=wp, with_tiles=wt)
+            ev = torch.cuda.Event(); ev.record(side)
+        return idx32, probe.indice_dict, ev
+    nxt = [build()]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        idx32, book, ev = nxt[0]
+        main = torch.cuda.current_stream(d)
+        main.wait_event(ev)
+        idx32.record_stream(main)
+        for data in book.values():
+            for t in vars(data).values():
+                for u in (t if isinstance(t, tuple) else (t,)):
+                    if torch.is_tensor(u) and u.is_cuda:
+                        u.record_stream(main)
+        if mode == "inline_start":
+            nxt[0] = build()
+        loss = cross_entropy(voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.bfloat16, inputs_ready=True, pyramid=(idx32, book)), bd["labels"])
+        if mode == "inline_mid":
+            nxt[0] = build()
+        loss.backward()
+        opt.step()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+MODES = ("start", "inline_start", "inline_mid", "reuse") if os.environ.get("ABGATE_INLINE") == "1" else ("start", "gated", "reuse")
+if os.environ.get("ABGATE_DUMMY") == "1":
+    MODES = ("reuse", "dummy_90_64", "dummy_45_64", "dummy_10_25000000", "start")
+res = {m: [] for m in MODES}
 for r in range(rounds):
-    for mode in ("start", "gated", "reuse"):
+    for mode in MODES:
         res[mode].append(run(mode))
 for k, v in res.items():
     print(k, " ".join("%.2f" % x for x in v), "| median %.2f" % sorted(v)[len(v) // 2])
