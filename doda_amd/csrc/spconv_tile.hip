@@ -78,6 +78,20 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<O
     constexpr unsigned OSZ = OUT32 ? 4u : 2u;
     const unsigned col = (unsigned)(nb0 * 16 + 4 * g);
     f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+    // the BatchNorm vectors of the lane's four channels: ONCE per tile (inside the row loop the stores to y between them kept
+    // hipcc from hoisting the loads: sixteen L1 round trips per lane and tile in the data-gradient epilogue)
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, ga = mu, be = mu;
+    if constexpr (STATS) {
+        if (ep.bn_x) {
+            const unsigned cc = col < (unsigned)nc ? col : 0u;
+            mu = *reinterpret_cast<const f32x4 *>(ep.bn_mean + cc);
+            is = *reinterpret_cast<const f32x4 *>(ep.bn_invstd + cc);
+            if (ep.bn_relu) {
+                ga = *reinterpret_cast<const f32x4 *>(ep.bn_gamma + cc);
+                be = *reinterpret_cast<const f32x4 *>(ep.bn_beta + cc);
+            }
+        }
+    }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const unsigned t = (unsigned)(row0 + s * 16 + i);
@@ -94,13 +108,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<O
             if constexpr (!OUT32) v = epi_unpack(packed_out);
             if (ep.bn_x) {
                 const f32x4 xr = epi_unpack(pre.bnx[s]);
-                const unsigned cc = col < (unsigned)nc ? col : 0u;
-                const f32x4 mu = *reinterpret_cast<const f32x4 *>(ep.bn_mean + cc);
-                const f32x4 is = *reinterpret_cast<const f32x4 *>(ep.bn_invstd + cc);
                 const f32x4 xh = (xr - mu) * is;
                 if (ep.bn_relu) {
-                    const f32x4 ga = *reinterpret_cast<const f32x4 *>(ep.bn_gamma + cc);
-                    const f32x4 be = *reinterpret_cast<const f32x4 *>(ep.bn_beta + cc);
                     const f32x4 yv = xh * ga + be;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = yv[q] > 0.f ? v[q] : 0.f;
