@@ -887,7 +887,9 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
         // table carries a tilebook — the fp32 weight gradient uses the tilebook either way)
         static const bool f32_tile = !(getenv("DODA_F32_CONV_TILE") && getenv("DODA_F32_CONV_TILE")[0] == '0');
         const int tmode = pair ? 0 : (wide && kc == 32) ? 1 : (fast && sizeof(elem) == 4 && kc == 16 && f32_tile) ? 2 : -1;
-        if (tmode >= 0 && tilebook && K == TB_K && tilebook_rows == n_out && doda_tile::enabled()) {
+        // (statistics: the tile kernels' per-lane accumulators hold up to two channel blocks)
+        const bool stats_fit = !ep.stats || NB <= 2;
+        if (tmode >= 0 && tilebook && K == TB_K && tilebook_rows == n_out && doda_tile::enabled() && stats_fit) {
             const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
             const unsigned yb = (unsigned)((size_t)n_out * nc * (out32 ? 4 : sizeof(elem)));
             return doda_tile::launch_conv_tile(tmode, out32 || sizeof(elem) == 4, x_, xb, wp, (unsigned)need, nc, NB, tbl, ld,

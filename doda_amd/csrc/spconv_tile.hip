@@ -7,6 +7,21 @@
 #include "tilebook.hpp"
 #include "spconv_common.hpp"
 
+#ifdef DODA_TILE_STAMPS
+// Measurement build only (tools/tilestamps.py compiles its own copy of the library with -DDODA_TILE_STAMPS): wave 0 of every
+// workgroup records the 100 MHz wall clock at six points of each of its first eight tiles.
+__device__ unsigned long long doda_tile_stamp_buf[768 * 8 * 8];
+extern "C" int doda_debug_tile_stamps(void *host_out, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(doda_tile_stamp_buf), bytes);
+}
+#define TILE_STAMP(k)                                                                                      \
+    do {                                                                                                   \
+        if (tid0 == 0 && stamp_it < 8) doda_tile_stamp_buf[(blockIdx.x * 8 + stamp_it) * 8 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define TILE_STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -38,7 +53,9 @@ namespace {
 template <bool OUT32> struct EpiPre { u32x4 res[4], bnx[4]; };   // four channels of a row: fp32 ...
 template <> struct EpiPre<false> { u32x2 res[4], bnx[4]; };        // ... or bf16
 
-template <int S, bool OUT32, bool STATS>
+// ALWAYS: issue every load whatever the call's operands (an absent operand: out-of-range offset, zeros, no traffic) — the
+// pipelined kernel needs the same instruction sequence on every path (conv_tile16)
+template <int S, bool OUT32, bool STATS, bool ALWAYS = false>
 __device__ __forceinline__ void epi_prefetch(EpiPre<OUT32> &pre, int row0, int i, int g, int nb0, int nc, int n_out,
                                              unsigned y_bytes, const void *__restrict__ res, const EpiArgs &ep) {
     constexpr unsigned OSZ = OUT32 ? 4u : 2u;
@@ -49,6 +66,16 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<OUT32> &pre, int row0, int i
     for (int s = 0; s < S; ++s) {
         const unsigned t = (unsigned)(row0 + s * 16 + i);
         const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * (unsigned)nc + col) * OSZ : OOB;
+        if constexpr (ALWAYS) {
+            const unsigned vr = res ? voff : OOB, vb = ep.bn_x ? voff : OOB;
+            if constexpr (OUT32) pre.res[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, vr, 0, 0);
+            else pre.res[s] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr, 0, 0);
+            if constexpr (STATS) {
+                if constexpr (OUT32) pre.bnx[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, vb, 0, 0);
+                else pre.bnx[s] = __builtin_amdgcn_raw_buffer_load_b64(rs_b, vb, 0, 0);
+            }
+            continue;
+        }
         if (res) {
             if constexpr (OUT32) pre.res[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, voff, 0, 0);
             else pre.res[s] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, voff, 0, 0);
@@ -71,10 +98,11 @@ __device__ __forceinline__ f32x4 epi_unpack(const u32x2 &v) {
 // (DPP), the four waves (LDS) and the store of the workgroup's ONE partial row happen once, at the end of the kernel
 // (stats_flush).  Round 3 reduced per tile: 32 DPP operations, an LDS exchange and two barriers in every tile's
 // epilogue — on the tile loop's critical path.  Fixed order whatever the timing: deterministic.
-template <int S, bool OUT32, bool STATS>
+template <int S, bool OUT32, bool STATS, bool BNLDS = false>
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<OUT32> &pre, int row0, int i, int g,
                                               int nb0, int nc, int n_out, __amdgpu_buffer_rsrc_t rs_y,
-                                              const void *__restrict__ res, const EpiArgs &ep, f32x4 (&lst)[2]) {
+                                              const void *__restrict__ res, const EpiArgs &ep, f32x4 (&lst)[2],
+                                              const f32x4 (*bnv_lds)[4] = nullptr) {
     constexpr unsigned OSZ = OUT32 ? 4u : 2u;
     const unsigned col = (unsigned)(nb0 * 16 + 4 * g);
     f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
@@ -82,7 +110,12 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<O
     // hipcc from hoisting the loads: sixteen L1 round trips per lane and tile in the data-gradient epilogue)
     f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, ga = mu, be = mu;
     if constexpr (STATS) {
-        if (ep.bn_x) {
+        if (BNLDS && ep.bn_x) {   // conv_tile16: the vectors sit in LDS (a global load here would queue behind the
+            mu = bnv_lds[0][g];      // next tile's prefetched rows)
+            is = bnv_lds[1][g];
+            ga = bnv_lds[2][g];
+            be = bnv_lds[3][g];
+        } else if (!BNLDS && ep.bn_x) {
             const unsigned cc = col < (unsigned)nc ? col : 0u;
             mu = *reinterpret_cast<const f32x4 *>(ep.bn_mean + cc);
             is = *reinterpret_cast<const f32x4 *>(ep.bn_invstd + cc);
@@ -161,8 +194,8 @@ __device__ __forceinline__ void stats_flush(f32x4 (&lst)[2], int i, int g, int w
 //         workgroups per CU, which still keeps ~70 KB of row loads in flight per CU).
 // MODE 2: fp32, 16 input channels (64-byte rows staged exactly as MODE 1; four v_mfma_f32_16x16x4_f32 per unit and
 //         subtile — the reference's precision; MFMA-bound at ~53 us for the level-1 layer instead of 80 us).
-template <int MODE, bool OUT32, bool STATS>
-__global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, unsigned x_bytes,
+template <int MODE, bool OUT32, bool STATS, int MAXNB>
+__global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *__restrict__ x, unsigned x_bytes,
                                                  const void *__restrict__ wp, unsigned wp_bytes, int nc, int NB,
                                                  const int32_t *__restrict__ tbl, int ld, int n_out,
                                                  const TileBookView tb, void *__restrict__ y, unsigned y_bytes,
@@ -172,15 +205,19 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
     constexpr int S = 4, NU = WIDE ? TB_K : (TB_K + 1) / 2;
     constexpr int RB = WIDE ? 64 : 32;                         // bytes per staged row
     constexpr int PPR = RB / 16;                               // 16-byte pieces per row
-    constexpr int CAP = WIDE ? TB_CAP64 : TB_UMAX;             // distinct rows this kernel stages (LDS budget)
+    constexpr int CAP = WIDE ? TB_CAP64 : TB_LMAX;             // distinct rows this kernel stages (LDS budget; 10-bit local indices)
     constexpr int NLJ = PPR;                                   // 16-byte list loads per thread (one per pass of 256 / PPR entries)
     constexpr int NRL = 4 * NLJ;                               // row loads per thread
-    constexpr int NLI = (TB_K * TB_T * 2 / 16 + 255) / 256;   // 16-byte pieces of the index strip per thread
+    constexpr int NLP = TB_LIDX_BYTES / 16;                    // 16-byte pieces of the index strip (576)
+    constexpr int NLI = (NLP + 255) / 256;                     // ... per thread
     __shared__ __attribute__((aligned(16))) unsigned char rows_s[(CAP + 1) * RB];   // slot 0: the zero row
-    __shared__ __attribute__((aligned(16))) unsigned short lidx_s[TB_K * TB_T];
+    __shared__ __attribute__((aligned(16))) unsigned lidx_s[TB_T * TB_LW];   // nine words per output row (tilebook.hpp)
     // BatchNorm statistics: ONE partial row per persistent workgroup (<= 768 rows instead of one per 256 output rows),
     // accumulated per lane across the workgroup's tiles and reduced once at the end (tile_epilogue / stats_flush)
-    constexpr int MAXNB = 2;      // channel blocks with statistics (16 / 32 output channels: every tilebook layer of the U-Net)
+    // channel blocks with statistics: MAXNB = 1 or 2 (up to 32 output channels: every tilebook layer of the U-Net; the
+    // dispatcher sends anything else to the dense-table kernel).  A template parameter: the second block's accumulators
+    // cost the 16 -> 16 kernel (MAXNB = 1) registers it needs for its third wave per SIMD
+    static_assert(MAXNB == 1 || MAXNB == 2, "statistics of one or two channel blocks");
     f32x4 lst[STATS ? MAXNB : 1][2];
 #pragma unroll
     for (int b = 0; b < (STATS ? MAXNB : 1); ++b) lst[b][0] = lst[b][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -210,7 +247,9 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
         for (int j = 0; j < NLJ; ++j) {
             const u32x4 v = ul4[j * (256 / PPR) + tid / PPR];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rid[4 * j + k] = entry_of(j, k, tid) < CAP ? v[k] : 0xffffffffu;
+            for (int k = 0; k < 4; ++k) rid[4 * j + k] = v[k];   // (entries >= CAP: loaded, never written to LDS — a select
+                                                                  // here made the wave wait for the NEXT tile's list before it
+                                                                  // could park the current tile's rows)
         }
     };
     unsigned rid[NRL];
@@ -219,8 +258,15 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
         load_list(lo + slot, tid0, rid);
         U = tb.ucount[lo + slot];
     }
+#ifdef DODA_TILE_STAMPS
+    int stamp_it = -1;
+#endif
     for (int tt = slot; tt < cnt; tt += L) {
         const int tile = lo + tt, t0 = tile * TB_T;
+#ifdef DODA_TILE_STAMPS
+        ++stamp_it;
+#endif
+        TILE_STAMP(0);
         // every address below depends only on the lane; laundering the lane id once per tile keeps hipcc from
         // hoisting them out of the tile loop into ~100 long-lived registers
         int tid = tid0;
@@ -247,11 +293,11 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
             for (int k = 0; k < NRL; ++k)
                 rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, rid[k] * (unsigned)RB + (unsigned)(tid & (PPR - 1)) * 16u, 0, 0);
             u32x4 li4[NLI];
-            const u32x4 *li = reinterpret_cast<const u32x4 *>(tb.lidx + (size_t)tile * TB_K * TB_T);
+            const u32x4 *li = reinterpret_cast<const u32x4 *>(tb.lidx + (size_t)tile * (TB_T * TB_LW));
 #pragma unroll
             for (int k = 0; k < NLI; ++k) {
                 const int e = k * 256 + tid;
-                li4[k] = li[e < TB_K * TB_T * 2 / 16 ? e : 0];
+                li4[k] = li[e < NLP ? e : 0];
             }
             if (tt + L < cnt) {
                 load_list(tile + L, tid, rid);
@@ -260,7 +306,7 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
 #pragma unroll
             for (int k = 0; k < NLI; ++k) {
                 const int e = k * 256 + tid;
-                if (e < TB_K * TB_T * 2 / 16) reinterpret_cast<u32x4 *>(lidx_s)[e] = li4[k];
+                if (e < NLP) reinterpret_cast<u32x4 *>(lidx_s)[e] = li4[k];
             }
             if (tid < PPR) reinterpret_cast<u32x4 *>(rows_s)[tid] = (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
@@ -291,7 +337,9 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
 #pragma unroll
             for (int o = 0; o < TB_K; ++o) tab_s[o * TB_T + tid] = (unsigned)(t0 + tid) < (unsigned)n_out ? te[o] : -1;
         }
+        TILE_STAMP(1);
         __syncthreads();
+        TILE_STAMP(2);
 
         for (int nb0 = 0; nb0 < NB; ++nb0) {
             if (nb0 > 0) {
@@ -307,26 +355,34 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                 // local indices two units ahead, operand rows one unit ahead of the MFMAs (the scheduling
                 // barriers keep hipcc from sinking the reads next to their use, which left one LDS round trip
                 // exposed per MFMA)
-                const unsigned short *my = lidx_s + wid * 64 + i * 4;
-                auto loadl = [&](int u) {
-                    const int osel = WIDE ? u : 2 * u + (g >> 1);
-                    u32x2 v = {0u, 0u};   // offset 27 of the last pair: the zero row
-                    if (osel < TB_K) v = *reinterpret_cast<const u32x2 *>(my + osel * TB_T);
-                    return v;
+                // the lane's four rows (one per subtile) keep their nine index words 16 rows = 144 words apart; unit u needs
+                // offset u (64-byte rows) or offset 2u + (g >> 1) (32-byte rows: a pair of offsets per MFMA, offset 27 of the
+                // last pair = absent): word osel / 3, bits 10 (osel % 3) .. +9.  For the pairs the two candidates are compile-time
+                // constants selected by the lane's half (osel = 27 -> the always-zero bits 30-31 of word 8)
+                const unsigned *my = lidx_s + (wid * 64 + i) * TB_LW;
+                const bool hi_off = !WIDE && (g >> 1);
+                auto word_of = [&](int u) { return WIDE ? u / 3 : (hi_off ? ((2 * u + 1) < TB_K ? (2 * u + 1) / 3 : TB_LW - 1) : (2 * u) / 3); };
+                auto shift_of = [&](int u) {
+                    return WIDE ? 10u * (unsigned)(u % 3)
+                                : (hi_off ? ((2 * u + 1) < TB_K ? 10u * (unsigned)((2 * u + 1) % 3) : 30u) : 10u * (unsigned)((2 * u) % 3));
                 };
-                auto fetch = [&](const u32x2 &l, u32x4 (&xa)[S]) {
-                    xa[0] = *reinterpret_cast<const u32x4 *>(rows_s + (l[0] & 0xffffu) * (unsigned)RB + half);
-                    xa[1] = *reinterpret_cast<const u32x4 *>(rows_s + (l[0] >> 16) * (unsigned)RB + half);
-                    xa[2] = *reinterpret_cast<const u32x4 *>(rows_s + (l[1] & 0xffffu) * (unsigned)RB + half);
-                    xa[3] = *reinterpret_cast<const u32x4 *>(rows_s + (l[1] >> 16) * (unsigned)RB + half);
+                auto loadl = [&](int u) {
+                    const unsigned *p = my + word_of(u);
+                    return (u32x4){p[0], p[16 * TB_LW], p[32 * TB_LW], p[48 * TB_LW]};
+                };
+                auto fetch = [&](int u, const u32x4 &l, u32x4 (&xa)[S]) {
+                    const unsigned sh = shift_of(u);
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+                        xa[s] = *reinterpret_cast<const u32x4 *>(rows_s + ((__builtin_amdgcn_ubfe(l[s], sh, 10u) * (unsigned)RB) | half));
                 };
                 u32x4 xa[2][S], wr[4];
-                u32x2 lr[3];
+                u32x4 lr[2];   // (two in flight: unit u + 1's words are consumed before unit u + 3's overwrite them)
 #pragma unroll
                 for (int u = 0; u < 3; ++u) wr[u] = loadw(u);
                 lr[0] = loadl(0);
                 lr[1] = loadl(1);
-                fetch(lr[0], xa[0]);
+                fetch(0, lr[0], xa[0]);
                 // (MODE 2, fp32: skipping the MFMAs of (offset, 16-row subtile) slots without a present neighbour — ~45 % of
                 // them on a surface scene — was built twice (round 3: per-subtile test inside the unit; round 4: wave-uniform
                 // presence masks from ballots, operand reads unconditional, one branch per slot) and measured SLOWER both
@@ -334,8 +390,8 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                 // and 250 VGPRs cost more than the skipped matrix work; the dense loop stays)
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    if (u + 2 < NU) lr[(u + 2) % 3] = loadl(u + 2);
-                    if (u + 1 < NU) fetch(lr[(u + 1) % 3], xa[(u + 1) & 1]);
+                    if (u + 1 < NU) fetch(u + 1, lr[(u + 1) & 1], xa[(u + 1) & 1]);
+                    if (u + 2 < NU) lr[u & 1] = loadl(u + 2);
                     if (u + 3 < NU) wr[(u + 3) & 3] = loadw(u + 3);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -376,21 +432,266 @@ __global__ __launch_bounds__(256) void conv_tile(const void *__restrict__ x, uns
                     }
                 }
             }
+            TILE_STAMP(3);
             // (statistics: static register index — NB <= MAXNB is checked by the launcher)
             if (nb0 == 0) tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[0]);
             else tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[STATS ? MAXNB - 1 : 0]);
         }
+        TILE_STAMP(4);
         __syncthreads();   // the next tile overwrites the staged rows
+        TILE_STAMP(5);
     }
     if constexpr (STATS) {   // the workgroup's partial row (zeros when it had no tile)
         const int lane = tid0 & 63, i = lane & 15, g = lane >> 4;
         float *row = ep.stats + (long long)blockIdx.x * 2 * nc;
         stats_flush(lst[0], i, g, wid, 0, nc, row);
-        if (NB > 1) stats_flush(lst[MAXNB - 1], i, g, wid, 1, nc, row);
+        if (MAXNB > 1 && NB > 1) stats_flush(lst[MAXNB - 1], i, g, wid, 1, nc, row);
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_tile16 (round 4): the 16 -> 16 channel layer (MODE 0, one channel block) as a SOFTWARE PIPELINE across tiles.
+// Wall-clock stamps inside conv_tile (tools/tilestamps.py, level-1 layer, 2349 tiles over 768 workgroups) showed where
+// its 28 us go: every tile WAITS 2.1-2.5 us for its rows (one HBM round trip, exposed: the three workgroups of a CU
+// start together and stay in step, so they wait together and then contend for the SIMDs together — units 1.35 us
+// alone, 2.5-3.0 us in company), the first tile 4.2 us (list, then rows), and 45 workgroups run a fourth tile alone
+// (4 us).  Here a workgroup requests the NEXT tile's rows and index strip (into registers: 8 + 3 x 16 bytes per
+// thread) as soon as the current tile's are parked in LDS, so the round trip runs under the multiply phase and the
+// epilogue; the 14 weight fragments stay in registers for the kernel's lifetime (the streamed loads would queue
+// behind the prefetch: vmcnt retires in order), which leaves NO vector-memory wait inside the unit loop.  ~230 VGPRs:
+// two workgroups per CU (512 persistent workgroups) — each hides its own latency instead of relying on the third.
+// Same arithmetic, same order of operations per output element as conv_tile<0, ...>: results are bit-identical.
+template <bool OUT32, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv_tile16(const void *__restrict__ x, unsigned x_bytes,
+                                                      const void *__restrict__ wp, unsigned wp_bytes, int nc,
+                                                      const int32_t *__restrict__ tbl, int ld, int n_out,
+                                                      const TileBookView tb, void *__restrict__ y, unsigned y_bytes,
+                                                      const void *__restrict__ res, const EpiArgs ep) {
+    constexpr int S = 4, NU = (TB_K + 1) / 2, RB = 32, PPR = 2, CAP = TB_LMAX, NLJ = PPR, NRL = 4 * NLJ;
+    constexpr int NLP = TB_LIDX_BYTES / 16, NLI = (NLP + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char rows_s[(CAP + 1) * RB];   // slot 0: the zero row
+    __shared__ __attribute__((aligned(16))) unsigned lidx_s[TB_T * TB_LW];
+    __shared__ f32x4 bnv_s[4][4];   // BatchNorm mean / invstd / gamma / beta of the 16 output channels (data-gradient epilogue)
+    f32x4 lst[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (STATS) {
+        if (ep.bn_x && tid < 64) {
+            const int v = tid >> 4, c = tid & 15;
+            const float *src = v == 0 ? ep.bn_mean : v == 1 ? ep.bn_invstd : v == 2 ? ep.bn_gamma : ep.bn_beta;
+            reinterpret_cast<float *>(bnv_s)[v * 16 + c] = (src && c < nc) ? src[c] : 0.f;
+        }
+        // (visible to every wave after the first tile's barrier)
+    }
+    const int lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, wp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void *)tbl, 0, (unsigned)TB_K * (unsigned)ld * 4u, 0x00020000);
+
+    const int L = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int qn = tb.nt >> 3, rn = tb.nt & 7;
+    const int lo = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
+    const int cnt = qn + (xcd < rn ? 1 : 0);
+    const unsigned half = (unsigned)(g & 1) * 16u;
+
+    // the kernel's weights: 14 pair fragments (pair packing [o][32 slots] x 16 B; offset 27 lies past the buffer: zeros)
+    u32x4 wr[NU];
+    {
+        const unsigned lane_w = (unsigned)(g >> 1) * 512u + (unsigned)((g & 1) * 16 + i) * 16u;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) wr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)u * 1024u + lane_w, 0, 0);
+    }
+
+    // Lists and strips are read through buffer descriptors: a request for "no tile" (tile < 0) is an out-of-range offset —
+    // zeros, no memory traffic — so EVERY iteration issues the same number of vector-memory instructions in the same
+    // order and hipcc's wait counts stay exact (a conditional request made it wait for vmcnt(0) before the epilogue:
+    // for the next tile's rows)
+    const __amdgpu_buffer_rsrc_t rs_ul = __builtin_amdgcn_make_buffer_rsrc((void *)tb.ulist, 0, (unsigned)tb.nt * (unsigned)(TB_UMAX * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_li = __builtin_amdgcn_make_buffer_rsrc((void *)tb.lidx, 0, (unsigned)tb.nt * (unsigned)TB_LIDX_BYTES, 0x00020000);
+    auto entry_of = [&](int j, int k) { return j * (256 / PPR) + tid / PPR + 256 * k; };
+    const __amdgpu_buffer_rsrc_t rs_uc = __builtin_amdgcn_make_buffer_rsrc((void *)tb.ucount, 0, (unsigned)tb.nt * 4u, 0x00020000);
+    auto load_list = [&](int tile, unsigned (&rid)[NRL]) {
+        const unsigned base = tile >= 0 ? (unsigned)tile * (unsigned)(TB_UMAX * 4) : OOB;
+#pragma unroll
+        for (int j = 0; j < NLJ; ++j) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_ul, base + (unsigned)(j * (256 / PPR) + tid / PPR) * 16u, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rid[4 * j + k] = v[k];
+        }
+    };
+    // count, rows (through their list) and index strip of a tile -> registers; `none`: all-ones (every request out of range;
+    // count 0).  The count goes FIRST: the tile loop carries it across its back edge (a register copy = a wait for that
+    // load), and in-order vmcnt must not make that a wait for the rows
+    auto request = [&](int tile, unsigned none, const unsigned (&rid)[NRL], u32x4 (&rr)[NRL], u32x4 (&li4)[NLI], unsigned &count) {
+        count = __builtin_amdgcn_raw_buffer_load_b32(rs_uc, none ? OOB : (unsigned)tile * 4u, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NRL; ++k) {
+            const unsigned r = rid[k] | none;   // (a list entry of -1 / -2 is out of range by itself)
+            rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, r < 0x04000000u ? r * (unsigned)RB + (unsigned)(tid & (PPR - 1)) * 16u : OOB, 0, 0);
+        }
+        const unsigned base = none ? OOB : (unsigned)tile * (unsigned)TB_LIDX_BYTES;
+#pragma unroll
+        for (int k = 0; k < NLI; ++k) {
+            const int e = k * 256 + tid;
+            li4[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_li, base + (unsigned)(e < NLP ? e : 0) * 16u, 0, 0);
+        }
+    };
+
+    unsigned rid[NRL];
+    u32x4 rr[NRL], li4[NLI];
+    unsigned U = 0;   // (per lane, the same value in every lane)
+    load_list(slot < cnt ? lo + slot : -1, rid);
+    // the first list is needed now anyway: waiting for EVERYTHING requested so far tells hipcc's wait-count pass that the
+    // weight fragments have arrived — otherwise every unit of every tile waits "for its fragment", i.e. (in-order vmcnt)
+    // for the next tile's rows, and the pipeline is gone
+    // (an empty asm that "rewrites" the fragments and the list: the loads cannot sink below it, hipcc waits for them in front
+    // of it — vmcnt(0) —, and every later use depends on it)
+    asm volatile("" : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2]), "+v"(wr[3]), "+v"(wr[4]), "+v"(wr[5]), "+v"(wr[6]), "+v"(wr[7]),
+                      "+v"(wr[8]), "+v"(wr[9]), "+v"(wr[10]), "+v"(wr[11]), "+v"(wr[12]), "+v"(wr[13]),
+                      "+v"(rid[0]), "+v"(rid[1]), "+v"(rid[2]), "+v"(rid[3]), "+v"(rid[4]), "+v"(rid[5]), "+v"(rid[6]), "+v"(rid[7]));
+    static_assert(NU == 14 && NRL == 8, "operand list of the asm above");
+    if (slot >= cnt) return;   // (no tile, no statistics row: the launcher never starts such a workgroup)
+    request(lo + slot, 0u, rid, rr, li4, U);
+    load_list(slot + L < cnt ? lo + slot + L : -1, rid);
+    // four stores to nowhere: the tile loop ends in the epilogue's four stores, and with the same tail of vector-memory
+    // instructions on the way INTO the loop the wait counts at its top are exact (without them hipcc assumes the fewest —
+    // none — and makes every tile wait for the previous tile's stores to be acknowledged)
+    __builtin_amdgcn_sched_barrier(0);   // (they stay BEHIND the loads above)
+#pragma unroll
+    for (int k = 0; k < S; ++k) __builtin_amdgcn_raw_buffer_store_b32((unsigned)k, rs_y, OOB + 16u * (unsigned)k, 0, 0);   // (distinct: not merged)
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef DODA_TILE_STAMPS
+    const int tid0 = tid;
+    int stamp_it = -1;
+#endif
+    for (int tt = slot; tt < cnt; tt += L) {
+        const int tile = lo + tt, t0 = tile * TB_T;
+#ifdef DODA_TILE_STAMPS
+        ++stamp_it;
+#endif
+        TILE_STAMP(0);
+        const bool staged = __builtin_amdgcn_readfirstlane(U) <= (unsigned)CAP;
+        const int row0 = t0 + wid * 64;
+        // ---- park this tile's rows and strip (requested one tile ago) ----
+        if (staged) {
+#pragma unroll
+            for (int k = 0; k < NLI; ++k) {
+                const int e = k * 256 + tid;
+                if (e < NLP) reinterpret_cast<u32x4 *>(lidx_s)[e] = li4[k];
+            }
+            if (tid < PPR) reinterpret_cast<u32x4 *>(rows_s)[tid] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < NRL; ++k) {
+                const int e = entry_of(k >> 2, k & 3);
+                if (e < CAP) reinterpret_cast<u32x4 *>(rows_s)[PPR + e * PPR + (tid & (PPR - 1))] = rr[k];
+            }
+        } else {
+            // a tile without a list: its 27 x 256 table entries, coalesced, into the LDS the rows would have used (conv_tile)
+            static_assert((CAP + 1) * RB >= TB_K * TB_T * 4, "the table slice fits the row buffer");
+            int te[TB_K];
+#pragma unroll
+            for (int o = 0; o < TB_K; ++o) {
+                const unsigned voff = (unsigned)(t0 + tid) < (unsigned)n_out ? ((unsigned)o * (unsigned)ld + (unsigned)(t0 + tid)) * 4u : OOB;
+                te[o] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_t, voff, 0, 0);
+            }
+            int *tab_s = reinterpret_cast<int *>(rows_s);
+#pragma unroll
+            for (int o = 0; o < TB_K; ++o) tab_s[o * TB_T + tid] = (unsigned)(t0 + tid) < (unsigned)n_out ? te[o] : -1;
+        }
+        TILE_STAMP(1);
+        __syncthreads();
+        TILE_STAMP(2);
+
+        // ---- requests, in the order their data is needed (vmcnt retires in order): this tile's epilogue operands, the NEXT
+        //      tile's rows and strip (its list arrived during the previous tile), the list after that ----
+        EpiPre<OUT32> pre;
+        epi_prefetch<S, OUT32, STATS, true>(pre, row0, i, g, 0, nc, n_out, y_bytes, res, ep);
+        unsigned Unext;
+        request(tile + L, tt + L < cnt ? 0u : 0xffffffffu, rid, rr, li4, Unext);
+        load_list(tt + 2 * L < cnt ? tile + 2 * L : -1, rid);
+
+        // ---- multiply phase: no vector-memory wait inside ----
+        f32x4 acc[S][1];
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (staged) {
+            const unsigned *my = lidx_s + (wid * 64 + i) * TB_LW;
+            const bool hi_off = g >> 1;
+            auto word_of = [&](int u) { return hi_off ? ((2 * u + 1) < TB_K ? (2 * u + 1) / 3 : TB_LW - 1) : (2 * u) / 3; };
+            auto shift_of = [&](int u) {
+                return hi_off ? ((2 * u + 1) < TB_K ? 10u * (unsigned)((2 * u + 1) % 3) : 30u) : 10u * (unsigned)((2 * u) % 3);
+            };
+            auto loadl = [&](int u) {
+                const unsigned *p = my + word_of(u);
+                return (u32x4){p[0], p[16 * TB_LW], p[32 * TB_LW], p[48 * TB_LW]};
+            };
+            auto fetch = [&](int u, const u32x4 &l, u32x4 (&xa)[S]) {
+                const unsigned sh = shift_of(u);
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    xa[s] = *reinterpret_cast<const u32x4 *>(rows_s + ((__builtin_amdgcn_ubfe(l[s], sh, 10u) * (unsigned)RB) | half));
+            };
+            u32x4 xa[2][S], lr[2];
+            lr[0] = loadl(0);
+            lr[1] = loadl(1);
+            fetch(0, lr[0], xa[0]);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (u + 1 < NU) fetch(u + 1, lr[(u + 1) & 1], xa[(u + 1) & 1]);
+                if (u + 2 < NU) lr[u & 1] = loadl(u + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < S; ++s) mma_bf16_k32(acc[s][0], wr[u], xa[u & 1][s]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            const int *tab_s = reinterpret_cast<const int *>(rows_s) + wid * 64 + i;
+            auto ldi = [&](int u, int (&d)[S]) {
+                const int osel = 2 * u + (g >> 1);
+#pragma unroll
+                for (int s = 0; s < S; ++s) d[s] = osel < TB_K ? tab_s[osel * TB_T + s * 16] : -1;
+            };
+            auto ldx = [&](const int (&d)[S], u32x4 (&xr)[S]) {
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    xr[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, d[s] >= 0 ? (unsigned)d[s] * (unsigned)RB + half : OOB, 0, 0);
+            };
+            int ix[3][S];
+            u32x4 xo[2][S];
+            ldi(0, ix[0]);
+            ldi(1, ix[1]);
+            ldx(ix[0], xo[0]);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (u + 2 < NU) ldi(u + 2, ix[(u + 2) % 3]);
+                if (u + 1 < NU) ldx(ix[(u + 1) % 3], xo[(u + 1) & 1]);
+#pragma unroll
+                for (int s = 0; s < S; ++s) mma_bf16_k32(acc[s][0], wr[u], xo[u & 1][s]);
+            }
+        }
+        TILE_STAMP(3);
+        tile_epilogue<S, OUT32, STATS, true>(acc, pre, row0, i, g, 0, nc, n_out, rs_y, res, ep, lst, bnv_s);
+        U = Unext;
+        TILE_STAMP(4);
+        __syncthreads();   // the next tile overwrites the staged rows
+        TILE_STAMP(5);
+    }
+    if constexpr (STATS) stats_flush(lst, i, g, wid, 0, nc, ep.stats + (long long)blockIdx.x * 2 * nc);
+}
+
 constexpr int BT_MAX_GROUPS = 768;   // 3 workgroups per CU x 256 CUs
+constexpr int T16_MAX_GROUPS = 512;  // conv_tile16: 2 workgroups per CU
+// conv_tile16 pays off from the point where conv_tile's workgroups run more than one tile each (a single tile per
+// workgroup has nothing to prefetch, and three shallow workgroups per CU then beat two)
+int tile16_min_tiles() {
+    static const int v = [] {
+        const char *e = getenv("DODA_TILE16_MIN_TILES");
+        const int m = e && *e ? atoi(e) : BT_MAX_GROUPS + 1;
+        return m < T16_MAX_GROUPS ? T16_MAX_GROUPS : m;   // (every one of its 512 workgroups must own a tile)
+    }();
+    return v;
+}
 
 bool g_use_tile = true;   // doda_set_option(DODA_OPT_TILE_KERNEL) (A/B measurements)
 
@@ -403,15 +704,32 @@ int doda_tile::launch_conv_tile(int mode, bool out32, const void *x, unsigned xb
                                 const int32_t *tbl, int ld, int n_out, const void *tilebook, void *y, unsigned yb,
                                 const void *res, const EpiArgs &ep_in, int *n_part, hipStream_t s) {
     const TileBookView tb = tilebook_view(const_cast<void *>(tilebook), n_out);
+    if (mode == 0 && NB == 1 && tb.nt >= tile16_min_tiles()) {
+        const int groups16 = T16_MAX_GROUPS;
+        if (n_part) *n_part = groups16;
+        const dim3 grid(groups16), block(256);
+        const EpiArgs &ep = ep_in;
+#define G16(O32, ST)                                                                               \
+    hipLaunchKernelGGL((conv_tile16<O32, ST>), grid, block, 0, s, x, xb, wp, wpb, nc, tbl, ld, n_out, tb, y, yb, res, ep)
+        if (out32) { if (ep.stats) G16(true, true); else G16(true, false); }
+        else { if (ep.stats) G16(false, true); else G16(false, false); }
+#undef G16
+        return doda_check_launch();
+    }
     int groups = (tb.nt + 7) / 8 * 8;   // persistent: 3 (64-byte rows: 2) workgroups per CU, a multiple of the 8 XCDs
     const int max_groups = mode == 0 ? BT_MAX_GROUPS : BT_MAX_GROUPS * 2 / 3;
     if (groups > max_groups) groups = max_groups;
     const dim3 grid(groups), block(256);
-    if (NB > 2 && ep_in.stats) return DODA_ERR_UNSUPPORTED;   // (the lanes' statistics accumulators hold 2 channel blocks: the caller takes the dense-table kernel)
+    if (NB > 2 && ep_in.stats) return DODA_ERR_UNSUPPORTED;   // (run_gather does not send such calls here)
+    const bool two = NB > 1 && ep_in.stats;                   // statistics of a second channel block
     if (n_part) *n_part = groups;      // one statistics row per persistent workgroup
     const EpiArgs &ep = ep_in;
+#define GT1(M, O32, ST, NBS)                                                                       \
+    hipLaunchKernelGGL((conv_tile<M, O32, ST, NBS>), grid, block, 0, s, x, xb, wp, wpb, nc, NB, tbl, ld, n_out, tb, y, yb, res, ep)
 #define GT(M, O32, ST)                                                                             \
-    hipLaunchKernelGGL((conv_tile<M, O32, ST>), grid, block, 0, s, x, xb, wp, wpb, nc, NB, tbl, ld, n_out, tb, y, yb, res, ep)
+    do {                                                                                           \
+        if (ST && two) GT1(M, O32, ST, 2); else GT1(M, O32, ST, 1);                                \
+    } while (0)
 #define GM(M)                                                                                      \
     do {                                                                                           \
         if (out32) { if (ep.stats) GT(M, true, true); else GT(M, true, false); }                   \
@@ -422,6 +740,7 @@ int doda_tile::launch_conv_tile(int mode, bool out32, const void *x, unsigned xb
     else GM(0);
 #undef GM
 #undef GT
+#undef GT1
     return doda_check_launch();
 }
 

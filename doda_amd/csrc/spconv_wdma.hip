@@ -36,9 +36,12 @@ namespace {
 
 constexpr int WD_WAVES = 16;
 constexpr int WD_ROWS_BYTES = (TB_UMAX + 1) * 32;     // slot 0: the shared zero row
-constexpr int WD_LIDX_BYTES = 16384;                  // 27 x 256 x 2 = 13824, rounded up to whole 1 KB DMA pieces
+constexpr int WD_LIDX_BYTES = TB_LIDX_BYTES;          // 256 rows x 9 packed words = 9216 = nine 1 KB DMA pieces (round 4; was 16 pieces)
 constexpr int WD_DY_BYTES = TB_T * 32;
-constexpr int WD_BUF_BYTES = WD_ROWS_BYTES + WD_LIDX_BYTES + WD_DY_BYTES;
+constexpr int WD_UNITS_BYTES = 2 * TB_K * 256 * 4;    // the per-block exchange of the units' accumulators re-uses a tile buffer
+constexpr int WD_BUF_BYTES = (WD_ROWS_BYTES + WD_LIDX_BYTES + WD_DY_BYTES) > WD_UNITS_BYTES ? (WD_ROWS_BYTES + WD_LIDX_BYTES + WD_DY_BYTES)
+                                                                                           : WD_UNITS_BYTES;
+static_assert(WD_LIDX_BYTES % 1024 == 0, "whole DMA pieces");
 constexpr int WD_UNITS = 2 * TB_K;                    // (offset, half of the k-steps)
 constexpr int WD_MAX_UNITS = (WD_UNITS + WD_WAVES - 1) / WD_WAVES;   // 4
 constexpr int WD_MAX_JOBS = 16;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, i = lane & 15, g = lane >> 4;
     const u32x4 rs_ul = wd_rsrc(tb.ulist, (unsigned)tb.nt * (unsigned)TB_UMAX * 4u);
-    const u32x4 rs_li = wd_rsrc(tb.lidx, (unsigned)tb.nt * (unsigned)(TB_K * TB_T * 2));
+    const u32x4 rs_li = wd_rsrc(tb.lidx, (unsigned)tb.nt * (unsigned)TB_LIDX_BYTES);
 
     // Persistent schedule (round 4: BLOCK-major).  The (block, tile) items of the launch, block-major, are cut into gridDim.x
     // contiguous chunks; workgroup rank r = (XCD, slot) takes chunk r, so an XCD owns one contiguous stretch of the list
@@ -147,8 +150,9 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
     };
     auto issue_strip = [&](const Where &q, int item) {
         const unsigned buf = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
-        wd_dma16(buf + (unsigned)WD_ROWS_BYTES + (unsigned)(wid * 1024),
-                 q.ok ? q.tile * (unsigned)(TB_K * TB_T * 2) + (unsigned)(wid * 64 + lane) * 16u : OOB, rs_li);
+        if (wid < WD_LIDX_BYTES / 1024)      // (wave-uniform: nine pieces)
+            wd_dma16(buf + (unsigned)WD_ROWS_BYTES + (unsigned)(wid * 1024),
+                     q.ok ? q.tile * (unsigned)TB_LIDX_BYTES + (unsigned)(wid * 64 + lane) * 16u : OOB, rs_li);
     };
     auto issue_dy = [&](const Where &q, int item) {
         if (wid < 8) {      // (wave-uniform; every wait in this kernel is vmcnt(0), so waves need not issue equal counts)
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
         const int t0 = (int)qc.tile * TB_T;
         const unsigned char *buf = smem + (item & 1) * WD_BUF_BYTES;
         const unsigned rows_base = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
-        const unsigned short *lidx_s = reinterpret_cast<const unsigned short *>(buf + WD_ROWS_BYTES);
+        const unsigned *lidx_s = reinterpret_cast<const unsigned *>(buf + WD_ROWS_BYTES);   // nine packed words per output row
         const unsigned dy_base = rows_base + (unsigned)(WD_ROWS_BYTES + WD_LIDX_BYTES);
         const unsigned short *xg = reinterpret_cast<const unsigned short *>(jobs.j[qc.job].x);
         issue_list(q2, lnew);        // first thing: it has the whole tile to land (lnew held list(item): dead)
@@ -216,7 +220,6 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
             // Two units (eight steps) at a time: their sixteen row addresses live in registers, the next pair's are computed
             // when these are spent (the wave budget is 128 VGPRs at 16 waves per workgroup).
             const unsigned lane_off = rows_base + (unsigned)c4 * 8u;
-            const unsigned sh = (unsigned)(g >> 1) * 16u;                 // entry 2 (ks & 1) + (g >> 1) of the strip position
             const bool tail_unit = wid + WD_WAVES * (WD_MAX_UNITS - 1) < WD_UNITS;   // the waves that own a unit 48 .. 53
 #pragma unroll
             for (int mp = 0; mp < WD_MAX_UNITS / 2; ++mp) {
@@ -227,14 +230,14 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
                     const int o = unit < WD_UNITS ? unit >> 1 : 0;      // (a unit past the end: any valid strip, result dropped)
 #pragma unroll
                     for (int kp = 0; kp < 2; ++kp) {
-                        // k-steps ks = 4 hw + 2 kp (+1): rows 32 ks + 8 g + q4 (+4) sit at strip position 8 (g & 1) + q4 (+4)
-                        // of the 64-row group ks >> 1 = 2 hw + kp
-                        const unsigned short *sp = lidx_s + o * TB_T + (2 * hw + kp) * 64 + (8 * (g & 1) + q4) * 4;
-                        const u32x2 v0 = *reinterpret_cast<const u32x2 *>(sp), v1 = *reinterpret_cast<const u32x2 *>(sp + 16);
-                        ra[mm * 4 + 2 * kp] = (__builtin_amdgcn_ubfe(v0[0], sh, 16u) << 5) + lane_off;
-                        ra[mm * 4 + 2 * kp + 1] = (__builtin_amdgcn_ubfe(v0[1], sh, 16u) << 5) + lane_off;
-                        rb[mm * 4 + 2 * kp] = (__builtin_amdgcn_ubfe(v1[0], sh, 16u) << 5) + lane_off;
-                        rb[mm * 4 + 2 * kp + 1] = (__builtin_amdgcn_ubfe(v1[1], sh, 16u) << 5) + lane_off;
+                        // k-steps ks = 4 hw + 2 kp (+1): the lane's operand rows are 32 ks + 8 g + q4 (+4) of the tile; their local
+                        // indices for offset o: bits 10 (o % 3) .. +9 of word o / 3 of the row's nine words (tilebook.hpp)
+                        const unsigned *sp = lidx_s + ((2 * hw + kp) * 64 + 8 * g + q4) * TB_LW + o / 3;
+                        const unsigned shb = 10u * (unsigned)(o % 3);
+                        ra[mm * 4 + 2 * kp] = (__builtin_amdgcn_ubfe(sp[0], shb, 10u) << 5) + lane_off;
+                        ra[mm * 4 + 2 * kp + 1] = (__builtin_amdgcn_ubfe(sp[32 * TB_LW], shb, 10u) << 5) + lane_off;
+                        rb[mm * 4 + 2 * kp] = (__builtin_amdgcn_ubfe(sp[4 * TB_LW], shb, 10u) << 5) + lane_off;
+                        rb[mm * 4 + 2 * kp + 1] = (__builtin_amdgcn_ubfe(sp[36 * TB_LW], shb, 10u) << 5) + lane_off;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
                 else run_pair(std::integral_constant<int, 1>{});      // the last pair of a wave without a fourth unit: four steps
             }
         } else {
-            // a tile without a list (more than TB_UMAX distinct rows; none at 2 cm): slices through the dense table
+            // a tile without a list (more than TB_LMAX distinct rows; none at 2 cm): slices through the dense table
             issue_rows(q1, item + 1, 0, lnext);
             issue_rows(q1, item + 1, 1, lnext);
             issue_strip(q1, item + 1);

@@ -76,10 +76,10 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
             if (tid == 0) {
                 v.ucount[tile] = U;
                 if (U > TB_CAP64) atomicAdd(&v.n_over[0], 1);
-                if (U > TB_UMAX) atomicAdd(&v.n_over[1], 1);
+                if (U > TB_LMAX) atomicAdd(&v.n_over[1], 1);
             }
             int32_t *ul = v.ulist + (size_t)tile * TB_UMAX;
-            if (U > TB_UMAX) {
+            if (U > TB_LMAX) {
                 for (int k = tid; k < TB_UMAX; k += 256) ul[k] = -2;
                 return;
             }
@@ -108,15 +108,22 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
                     ul[tb_upos(k++)] = lo + w * 32 + 8 * q + b;
                 }
             }
-            uint16_t *li = v.lidx + (size_t)tile * TB_K * TB_T + tb_pos(tid);
+            // the row's nine packed words (three 10-bit local indices each; tilebook.hpp)
+            uint32_t *li = v.lidx + ((size_t)tile * TB_T + tid) * TB_LW;
 #pragma unroll
-            for (int o = 0; o < TB_K; ++o) {
-                unsigned short r = 0;   // absent: LDS slot 0, the zero row
-                if (e[o] >= 0) {
-                    const unsigned d = (unsigned)(e[o] - lo), w = d >> 5;
-                    r = (unsigned short)(hrank[w] + __popc(htab[w] & ((1u << (d & 31u)) - 1u)) + 1);
+            for (int w3 = 0; w3 < TB_LW; ++w3) {
+                unsigned word = 0u;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int o = 3 * w3 + q;
+                    unsigned r = 0u;   // absent: LDS slot 0, the zero row
+                    if (e[o] >= 0) {
+                        const unsigned d = (unsigned)(e[o] - lo), w = d >> 5;
+                        r = (unsigned)(hrank[w] + __popc(htab[w] & ((1u << (d & 31u)) - 1u)) + 1);
+                    }
+                    word |= r << (10 * q);
                 }
-                li[o * TB_T] = r;
+                li[w3] = word;
             }
             return;
         }
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
 #pragma unroll
     for (int o = 0; o < TB_K; ++o) {
         if (e[o] < 0) continue;
-        if (*(volatile int *)&cnt > TB_UMAX) break;   // overflow: the count is all that is kept
+        if (*(volatile int *)&cnt > TB_LMAX) break;   // overflow: the count is all that is kept
         const unsigned key = (unsigned)e[o];
         unsigned slot = hash_mix(key) & (HCAP - 1);
         for (;;) {
@@ -145,10 +152,10 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
     if (tid == 0) {
         v.ucount[tile] = U;
         if (U > TB_CAP64) atomicAdd(&v.n_over[0], 1);
-        if (U > TB_UMAX) atomicAdd(&v.n_over[1], 1);
+        if (U > TB_LMAX) atomicAdd(&v.n_over[1], 1);
     }
     int32_t *ul = v.ulist + (size_t)tile * TB_UMAX;
-    if (U > TB_UMAX) {
+    if (U > TB_LMAX) {
         for (int k = tid; k < TB_UMAX; k += 256) ul[k] = -2;   // no list: every reader sees the marker in its own entries
         return;
     }
@@ -208,17 +215,23 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
         hrank[slot] = (unsigned short)k;
     }
     __syncthreads();
-    uint16_t *li = v.lidx + (size_t)tile * TB_K * TB_T + tb_pos(tid);
+    uint32_t *li = v.lidx + ((size_t)tile * TB_T + tid) * TB_LW;
 #pragma unroll
-    for (int o = 0; o < TB_K; ++o) {
-        unsigned short r = 0;   // absent: LDS slot 0, the zero row
-        if (e[o] >= 0) {
-            const unsigned key = (unsigned)e[o];
-            unsigned slot = hash_mix(key) & (HCAP - 1);
-            while (htab[slot] != key) slot = (slot + 1) & (HCAP - 1);
-            r = (unsigned short)(hrank[slot] + 1);
+    for (int w3 = 0; w3 < TB_LW; ++w3) {
+        unsigned word = 0u;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int o = 3 * w3 + q;
+            unsigned r = 0u;   // absent: LDS slot 0, the zero row
+            if (e[o] >= 0) {
+                const unsigned key = (unsigned)e[o];
+                unsigned slot = hash_mix(key) & (HCAP - 1);
+                while (htab[slot] != key) slot = (slot + 1) & (HCAP - 1);
+                r = (unsigned)(hrank[slot] + 1);
+            }
+            word |= r << (10 * q);
         }
-        li[o * TB_T] = r;
+        li[w3] = word;
     }
 }
 

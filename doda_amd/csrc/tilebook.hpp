@@ -8,27 +8,33 @@
 //   ulist [TB_UMAX]   int32   the distinct input rows, ascending (-1 past the count; every entry -2 when the tile
 //                             has more than TB_UMAX of them), stored in the order tb_upos() gives: the 16 bytes a
 //                             lane of the LDS-DMA kernel needs for its four row pieces are contiguous
-//   lidx  [K][TB_T]   uint16  1 + position of tbl[o][t] in ulist, or 0 when absent (LDS slot 0 = the zero row)
-//   ucount            int32   number of distinct rows (> TB_UMAX: the list is not kept)
+//   lidx  [TB_T][9]   uint32  round 4: per output row t nine words, word w = the local indices of offsets 3w, 3w+1, 3w+2 in
+//                             bits 0-9 / 10-19 / 20-29; a local index = 1 + position of tbl[o][t] in ulist, or 0 when absent
+//                             (LDS slot 0 = the zero row).  36 B per row (rounds 2-3: uint16 [K][TB_T] = 54 B per row: the
+//                             strip was the largest single item of the tile kernels' HBM traffic)
+//   ucount            int32   number of distinct rows (> TB_LMAX: the list is not kept)
 // plus, once per tilebook, n_over int32 [2]: tiles above TB_CAP64 / above TB_UMAX (the caller's safety valve:
 // voxel orders without locality overflow everywhere and are better served by the dense-table kernels).
 // A kernel stages at most its own capacity (what its LDS budget allows for its row size: tile_cap()) and
 // serves a tile above it from the dense table.
 // and the kernel loads each distinct row ONCE, coalesced, into LDS and serves all K gathers from there.
-// Inside a tile lidx is swizzled so that one 8-byte LDS read returns the four subtile entries of a lane:
-//   pos(r) = (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3).
+// Rows are stored in tile order (row t at words 9 t .. 9 t + 8): sixteen lanes reading one word of sixteen consecutive rows
+// hit sixteen different LDS banks (stride 9 words).
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
 
 constexpr int TB_T = 256;        // output rows per tile
 constexpr int TB_UMAX = 1024;    // list capacity per tile = the largest kernel capacity (32-byte rows)
-constexpr int TB_CAP64 = 960;    // kernel capacity for 64-byte rows (2 workgroups per CU) and for the fused backward
+constexpr int TB_LMAX = 1023;    // most distinct rows a tile may have and keep its list (local indices are 10 bits: 1 .. 1023)
+constexpr int TB_CAP64 = 960;    // kernel capacity for 64-byte rows (2 workgroups per CU)
 constexpr int TB_K = 27;
+constexpr int TB_LW = 9;         // 32-bit words of local indices per output row (three 10-bit indices each)
+constexpr int TB_LIDX_BYTES = TB_T * TB_LW * 4;   // 9216 per tile
 
 struct TileBookView {
     int32_t *ulist;     // [nt][TB_UMAX]
-    uint16_t *lidx;     // [nt][TB_K][TB_T]
+    uint32_t *lidx;     // [nt][TB_T][TB_LW]
     int32_t *ucount;    // [nt]
     int32_t *n_over;    // [2]
     int nt;
@@ -36,7 +42,7 @@ struct TileBookView {
 
 static inline size_t tilebook_bytes_for(long long n_rows) {
     const size_t nt = (size_t)((n_rows + TB_T - 1) / TB_T);
-    return nt * ((size_t)TB_UMAX * 4 + (size_t)TB_K * TB_T * 2 + 4) + 8;
+    return nt * ((size_t)TB_UMAX * 4 + (size_t)TB_LIDX_BYTES + 4) + 8;
 }
 
 static inline TileBookView tilebook_view(void *base, long long n_rows) {
@@ -45,8 +51,8 @@ static inline TileBookView tilebook_view(void *base, long long n_rows) {
     char *p = (char *)base;
     v.ulist = (int32_t *)p;
     p += (size_t)v.nt * TB_UMAX * 4;
-    v.lidx = (uint16_t *)p;
-    p += (size_t)v.nt * TB_K * TB_T * 2;
+    v.lidx = (uint32_t *)p;
+    p += (size_t)v.nt * TB_LIDX_BYTES;
     v.ucount = (int32_t *)p;
     p += (size_t)v.nt * 4;
     v.n_over = (int32_t *)p;
@@ -63,6 +69,8 @@ __host__ __device__
 static inline int tb_upos(int e) { return (((e >> 5) & 7) * 32 + (e & 31)) * 4 + (e >> 8); }
 static_assert(TB_UMAX == 1024, "tb_upos permutes exactly 1024 entries");
 
-#ifdef __HIPCC__
-__device__ __forceinline__ int tb_pos(int r) { return (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3); }
+// local index of offset o in a row's nine words
+#if defined(__HIPCC__)
+__host__ __device__
 #endif
+static inline unsigned tb_lidx_get(const uint32_t *row_words, int o) { return (row_words[o / 3] >> (10 * (o % 3))) & 0x3ffu; }

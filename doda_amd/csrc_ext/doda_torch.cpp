@@ -1066,7 +1066,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                   if (tb) {
                       const int64_t T = doda_tilebook_tile(), K = tbl.size(0), UMAX = doda_tilebook_umax();
                       nt = (tbl.size(1) + T - 1) / T;
-                      char *p = (char *)const_cast<void *>(tb) + nt * UMAX * 4 + nt * K * T * 2 + nt * 4;
+                      (void)K; (void)UMAX; (void)nt;
+                      char *p = (char *)const_cast<void *>(tb) + doda_tilebook_bytes((int32_t)tbl.size(1), (int32_t)tbl.size(0)) - 8;
                       int32_t ov[2] = {0, 0};
                       if (!read_back_blocking(p, ov, 2, stream_of(tbl), (int)tbl.device().index())) {
                           at::Tensor over = at::from_blob(p, {2}, tbl.options()).cpu();
@@ -1088,25 +1089,31 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               return out;
           }, "copy of a gather table with its tilebook (doda_tilebook_build) in the same storage");
     m.def("has_tilebook", [](const at::Tensor &tbl) { return tilebook_behind(tbl, tbl.dim() == 2 ? tbl.size(1) : 0) != nullptr; });
-    m.def("tilebook_parts", [](const at::Tensor &tbl) {   // (ulist [nt,UMAX] int32, lidx [nt,K,T] int16, ucount [nt] int32) views, for tests
+    m.def("tilebook_parts", [](const at::Tensor &tbl) {   // (ulist [nt,UMAX] int32, local indices [nt,K,T] int16 decoded, ucount [nt] int32), for tests
               const void *tb = tilebook_behind(tbl, tbl.size(1));
               TORCH_CHECK(tb, "doda tilebook_parts: no tilebook");
               const int64_t T = doda_tilebook_tile(), nt = (tbl.size(1) + T - 1) / T, K = tbl.size(0), UMAX = doda_tilebook_umax();
+              const int64_t LW = (K + 2) / 3;     // packed words per row: three 10-bit local indices each (csrc/tilebook.hpp)
               char *p = (char *)const_cast<void *>(tb);
-              auto o32 = tbl.options(), o16 = tbl.options().dtype(at::kShort);
+              auto o32 = tbl.options();
               // (stored in the DMA kernel's lane order, csrc/tilebook.hpp tb_upos: handed out in list order)
               at::Tensor order = at::empty({UMAX}, at::TensorOptions().dtype(at::kLong));
               for (int64_t e = 0; e < UMAX; ++e) order.data_ptr<int64_t>()[e] = (((e >> 5) & 7) * 32 + (e & 31)) * 4 + (e >> 8);
               at::Tensor ulist = at::from_blob(p, {nt, UMAX}, o32).index_select(1, order.to(tbl.device()));
-              at::Tensor lidx = at::from_blob(p + nt * UMAX * 4, {nt, K, T}, o16).clone();
-              at::Tensor ucount = at::from_blob(p + nt * UMAX * 4 + nt * K * T * 2, {nt}, o32).clone();
+              at::Tensor words = at::from_blob(p + nt * UMAX * 4, {nt, T, LW}, o32).to(at::kLong);
+              std::vector<at::Tensor> per_offset;
+              for (int64_t o = 0; o < K; ++o)
+                  per_offset.push_back(words.select(2, o / 3).bitwise_right_shift(10 * (o % 3)).bitwise_and(0x3ff));
+              at::Tensor lidx = at::stack(per_offset, 1).to(at::kShort);          // [nt, K, T]
+              at::Tensor ucount = at::from_blob(p + nt * UMAX * 4 + nt * T * LW * 4, {nt}, o32).clone();
               return std::make_tuple(ulist, lidx, ucount);
           });
     m.def("tilebook_overflow", [](const at::Tensor &tbl) {   // (tiles, tiles above the 64-byte-row capacity, above the list capacity); syncs
               const void *tb = tilebook_behind(tbl, tbl.size(1));
               TORCH_CHECK(tb, "doda tilebook_overflow: no tilebook");
               const int64_t T = doda_tilebook_tile(), nt = (tbl.size(1) + T - 1) / T, K = tbl.size(0), UMAX = doda_tilebook_umax();
-              char *p = (char *)const_cast<void *>(tb) + nt * UMAX * 4 + nt * K * T * 2 + nt * 4;
+              (void)K; (void)UMAX; (void)nt;
+              char *p = (char *)const_cast<void *>(tb) + doda_tilebook_bytes((int32_t)tbl.size(1), (int32_t)tbl.size(0)) - 8;
               at::Tensor over = at::from_blob(p, {2}, tbl.options()).cpu();
               return std::make_tuple(nt, (int64_t)over[0].item<int32_t>(), (int64_t)over[1].item<int32_t>());
           }, py::call_guard<py::gil_scoped_release>());   // (called on the rulebook thread: its read-back must not hold the GIL)

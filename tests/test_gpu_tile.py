@@ -72,16 +72,14 @@ def test_tilebook_is_a_lossless_encoding(native_lib, m):
     lidx = lidx.view(np.uint16)
     T, UMAX = lidx.shape[2], ulist.shape[1]
     tb = tbl.cpu().numpy()
-    r = np.arange(T)
-    pos = (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3)
     for tile in range(ulist.shape[0]):
         rows = np.arange(tile * T, min((tile + 1) * T, n))
         ent = np.full((27, T), -1, np.int64)
         ent[:, :len(rows)] = tb[:, rows]
         uniq = np.unique(ent[ent >= 0])
-        assert ucount[tile] == len(uniq) <= UMAX
+        assert ucount[tile] == len(uniq) <= UMAX - 1     # (10-bit local indices: at most 1023 distinct rows keep a list)
         assert np.array_equal(ulist[tile, :len(uniq)], uniq) and (ulist[tile, len(uniq):] == -1).all()
-        loc = lidx[tile][:, pos].astype(np.int64)          # un-swizzled [27, T]; 0 = absent, else 1 + position
+        loc = lidx[tile].astype(np.int64)                  # decoded [27, T]; 0 = absent, else 1 + position
         absent = loc == 0
         assert np.array_equal(absent, ent < 0)
         assert loc.max() <= len(uniq)
