@@ -110,7 +110,7 @@ def _subm16_times(idx, shape, nb, dtype, reps):
     use_tile = spconv.ops.TILE_KERNEL and tile_levels_for(tdt) > 0
     use_pairs = dtype == "bf16" and spconv.functional.WGRAD_PAIRS
     # one buffer set = everything one fwd + dgrad + wgrad of a layer touches
-    per_set = 3 * s * m * 16 + (52 * m if use_tile else 108 * m)
+    per_set = 3 * s * m * 16 + (56 * m if use_tile else 108 * m)
     n_sets = max(2, -(-COLD_BYTES // per_set) + 1)
 
     class Set:

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
     constexpr int NLP = TB_LIDX_BYTES / 16;                    // 16-byte pieces of the index strip (576)
     constexpr int NLI = (NLP + 255) / 256;                     // ... per thread
     __shared__ __attribute__((aligned(16))) unsigned char rows_s[(CAP + 1) * RB];   // slot 0: the zero row
-    __shared__ __attribute__((aligned(16))) unsigned lidx_s[TB_T * TB_LW];   // nine words per output row (tilebook.hpp)
+    __shared__ __attribute__((aligned(16))) unsigned lidx_s[TB_T * TB_LW];   // ten planes of 256 words (tilebook.hpp)
     // BatchNorm statistics: ONE partial row per persistent workgroup (<= 768 rows instead of one per 256 output rows),
     // accumulated per lane across the workgroup's tiles and reduced once at the end (tile_epilogue / stats_flush)
     // channel blocks with statistics: MAXNB = 1 or 2 (up to 32 output channels: every tilebook layer of the U-Net; the
@@ -355,34 +355,38 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
                 // local indices two units ahead, operand rows one unit ahead of the MFMAs (the scheduling
                 // barriers keep hipcc from sinking the reads next to their use, which left one LDS round trip
                 // exposed per MFMA)
-                // the lane's four rows (one per subtile) keep their nine index words 16 rows = 144 words apart; unit u needs
-                // offset u (64-byte rows) or offset 2u + (g >> 1) (32-byte rows: a pair of offsets per MFMA, offset 27 of the
-                // last pair = absent): word osel / 3, bits 10 (osel % 3) .. +9.  For the pairs the two candidates are compile-time
-                // constants selected by the lane's half (osel = 27 -> the always-zero bits 30-31 of word 8)
-                const unsigned *my = lidx_s + (wid * 64 + i) * TB_LW;
-                const bool hi_off = !WIDE && (g >> 1);
-                auto word_of = [&](int u) { return WIDE ? u / 3 : (hi_off ? ((2 * u + 1) < TB_K ? (2 * u + 1) / 3 : TB_LW - 1) : (2 * u) / 3); };
-                auto shift_of = [&](int u) {
-                    return WIDE ? 10u * (unsigned)(u % 3)
-                                : (hi_off ? ((2 * u + 1) < TB_K ? 10u * (unsigned)((2 * u + 1) % 3) : 30u) : 10u * (unsigned)((2 * u) % 3));
-                };
-                auto loadl = [&](int u) {
-                    const unsigned *p = my + word_of(u);
-                    return (u32x4){p[0], p[16 * TB_LW], p[32 * TB_LW], p[48 * TB_LW]};
-                };
-                auto fetch = [&](int u, const u32x4 &l, u32x4 (&xa)[S]) {
-                    const unsigned sh = shift_of(u);
+                // local indices (tilebook.hpp): plane 5 p + k of the strip holds, for the lane's four rows (adjacent words: one
+                // 16-byte read), the fields of the offsets 2 (3 k + q) + p.  Pair units take offsets 2 u and 2 u + 1: the lane's
+                // half of the pair picks the parity — a different plane, the same shift — so a word serves three units; the
+                // 64-byte-row kernels walk offsets 0, 1, 2, ...: two word streams (even / odd offsets), six units per word
+                const unsigned *my = lidx_s + wid * 64 + tb_lsigma(i) * 4 + ((!WIDE && (g >> 1)) ? 5 * TB_T : 0);
+                auto loadp = [&](int plane) { return *reinterpret_cast<const u32x4 *>(my + plane * TB_T); };
+                constexpr int NSTR = WIDE ? 2 : 1;       // word streams
+                u32x4 lw[NSTR][2];
+                auto word_of = [&](int u) -> const u32x4 & { return WIDE ? lw[u & 1][((u >> 1) / 3) & 1] : lw[0][(u / 3) & 1]; };
+                auto fetch = [&](int u, u32x4 (&xa)[S]) {
+                    const unsigned sh = WIDE ? 10u * (unsigned)((u >> 1) % 3) : 10u * (unsigned)(u % 3);
+                    const u32x4 &l = word_of(u);
 #pragma unroll
                     for (int s = 0; s < S; ++s)
                         xa[s] = *reinterpret_cast<const u32x4 *>(rows_s + ((__builtin_amdgcn_ubfe(l[s], sh, 10u) * (unsigned)RB) | half));
                 };
+                // the word after the one unit u starts: requested in the iteration in which unit u's word is first used
+                auto next_word = [&](int u) {
+                    if constexpr (WIDE) {
+                        const int p = u & 1, k = (u >> 1) / 3;
+                        if ((u >> 1) % 3 == 0 && 2 * (3 * (k + 1)) + p < TB_K) lw[p][(k + 1) & 1] = loadp(5 * p + k + 1);
+                    } else {
+                        const int k = u / 3;
+                        if (u % 3 == 0 && 3 * (k + 1) < NU) lw[0][(k + 1) & 1] = loadp(k + 1);
+                    }
+                };
                 u32x4 xa[2][S], wr[4];
-                u32x4 lr[2];   // (two in flight: unit u + 1's words are consumed before unit u + 3's overwrite them)
 #pragma unroll
                 for (int u = 0; u < 3; ++u) wr[u] = loadw(u);
-                lr[0] = loadl(0);
-                lr[1] = loadl(1);
-                fetch(0, lr[0], xa[0]);
+                lw[0][0] = loadp(0);
+                if constexpr (WIDE) lw[1][0] = loadp(5);
+                fetch(0, xa[0]);
                 // (MODE 2, fp32: skipping the MFMAs of (offset, 16-row subtile) slots without a present neighbour — ~45 % of
                 // them on a surface scene — was built twice (round 3: per-subtile test inside the unit; round 4: wave-uniform
                 // presence masks from ballots, operand reads unconditional, one branch per slot) and measured SLOWER both
@@ -390,8 +394,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
                 // and 250 VGPRs cost more than the skipped matrix work; the dense loop stays)
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    if (u + 1 < NU) fetch(u + 1, lr[(u + 1) & 1], xa[(u + 1) & 1]);
-                    if (u + 2 < NU) lr[u & 1] = loadl(u + 2);
+                    if (u + 1 < NU) fetch(u + 1, xa[(u + 1) & 1]);
+                    next_word(u);
                     if (u + 3 < NU) wr[(u + 3) & 3] = loadw(u + 3);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -616,30 +620,24 @@ __global__ __launch_bounds__(256, 2) void conv_tile16(const void *__restrict__ x
 #pragma unroll
         for (int s = 0; s < S; ++s) acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (staged) {
-            const unsigned *my = lidx_s + (wid * 64 + i) * TB_LW;
-            const bool hi_off = g >> 1;
-            auto word_of = [&](int u) { return hi_off ? ((2 * u + 1) < TB_K ? (2 * u + 1) / 3 : TB_LW - 1) : (2 * u) / 3; };
-            auto shift_of = [&](int u) {
-                return hi_off ? ((2 * u + 1) < TB_K ? 10u * (unsigned)((2 * u + 1) % 3) : 30u) : 10u * (unsigned)((2 * u) % 3);
-            };
-            auto loadl = [&](int u) {
-                const unsigned *p = my + word_of(u);
-                return (u32x4){p[0], p[16 * TB_LW], p[32 * TB_LW], p[48 * TB_LW]};
-            };
-            auto fetch = [&](int u, const u32x4 &l, u32x4 (&xa)[S]) {
-                const unsigned sh = shift_of(u);
+            // local indices: plane (5 x the lane's offset parity) + u / 3, bits 10 (u % 3) .. + 9 — one 16-byte read per three
+            // units for the lane's four rows (tilebook.hpp)
+            const unsigned *my = lidx_s + wid * 64 + tb_lsigma(i) * 4 + ((g >> 1) ? 5 * TB_T : 0);
+            auto loadp = [&](int k) { return *reinterpret_cast<const u32x4 *>(my + k * TB_T); };
+            u32x4 lw[2];
+            auto fetch = [&](int u, u32x4 (&xa)[S]) {
+                const u32x4 &l = lw[(u / 3) & 1];
 #pragma unroll
                 for (int s = 0; s < S; ++s)
-                    xa[s] = *reinterpret_cast<const u32x4 *>(rows_s + ((__builtin_amdgcn_ubfe(l[s], sh, 10u) * (unsigned)RB) | half));
+                    xa[s] = *reinterpret_cast<const u32x4 *>(rows_s + ((__builtin_amdgcn_ubfe(l[s], 10u * (unsigned)(u % 3), 10u) * (unsigned)RB) | half));
             };
-            u32x4 xa[2][S], lr[2];
-            lr[0] = loadl(0);
-            lr[1] = loadl(1);
-            fetch(0, lr[0], xa[0]);
+            u32x4 xa[2][S];
+            lw[0] = loadp(0);
+            fetch(0, xa[0]);
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-                if (u + 1 < NU) fetch(u + 1, lr[(u + 1) & 1], xa[(u + 1) & 1]);
-                if (u + 2 < NU) lr[u & 1] = loadl(u + 2);
+                if (u + 1 < NU) fetch(u + 1, xa[(u + 1) & 1]);
+                if (u % 3 == 0 && 3 * (u / 3 + 1) < NU) lw[(u / 3 + 1) & 1] = loadp(u / 3 + 1);   // (first used two units on)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < S; ++s) mma_bf16_k32(acc[s][0], wr[u], xa[u & 1][s]);

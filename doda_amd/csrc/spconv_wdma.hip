@@ -36,7 +36,7 @@ namespace {
 
 constexpr int WD_WAVES = 16;
 constexpr int WD_ROWS_BYTES = (TB_UMAX + 1) * 32;     // slot 0: the shared zero row
-constexpr int WD_LIDX_BYTES = TB_LIDX_BYTES;          // 256 rows x 9 packed words = 9216 = nine 1 KB DMA pieces (round 4; was 16 pieces)
+constexpr int WD_LIDX_BYTES = TB_LIDX_BYTES;          // ten planes x 256 packed words = 10240 = ten 1 KB DMA pieces (round 4; was 16 pieces)
 constexpr int WD_DY_BYTES = TB_T * 32;
 constexpr int WD_UNITS_BYTES = 2 * TB_K * 256 * 4;    // the per-block exchange of the units' accumulators re-uses a tile buffer
 constexpr int WD_BUF_BYTES = (WD_ROWS_BYTES + WD_LIDX_BYTES + WD_DY_BYTES) > WD_UNITS_BYTES ? (WD_ROWS_BYTES + WD_LIDX_BYTES + WD_DY_BYTES)
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
     };
     auto issue_strip = [&](const Where &q, int item) {
         const unsigned buf = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
-        if (wid < WD_LIDX_BYTES / 1024)      // (wave-uniform: nine pieces)
+        if (wid < WD_LIDX_BYTES / 1024)      // (wave-uniform: ten pieces)
             wd_dma16(buf + (unsigned)WD_ROWS_BYTES + (unsigned)(wid * 1024),
                      q.ok ? q.tile * (unsigned)TB_LIDX_BYTES + (unsigned)(wid * 64 + lane) * 16u : OOB, rs_li);
     };
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
         const int t0 = (int)qc.tile * TB_T;
         const unsigned char *buf = smem + (item & 1) * WD_BUF_BYTES;
         const unsigned rows_base = smem_base + (unsigned)(item & 1) * (unsigned)WD_BUF_BYTES;
-        const unsigned *lidx_s = reinterpret_cast<const unsigned *>(buf + WD_ROWS_BYTES);   // nine packed words per output row
+        const unsigned *lidx_s = reinterpret_cast<const unsigned *>(buf + WD_ROWS_BYTES);   // ten planes of packed local indices (tilebook.hpp)
         const unsigned dy_base = rows_base + (unsigned)(WD_ROWS_BYTES + WD_LIDX_BYTES);
         const unsigned short *xg = reinterpret_cast<const unsigned short *>(jobs.j[qc.job].x);
         issue_list(q2, lnew);        // first thing: it has the whole tile to land (lnew held list(item): dead)
@@ -231,13 +231,15 @@ __global__ __launch_bounds__(1024) void wgrad_dma16(const WdJobs jobs, const int
 #pragma unroll
                     for (int kp = 0; kp < 2; ++kp) {
                         // k-steps ks = 4 hw + 2 kp (+1): the lane's operand rows are 32 ks + 8 g + q4 (+4) of the tile; their local
-                        // indices for offset o: bits 10 (o % 3) .. +9 of word o / 3 of the row's nine words (tilebook.hpp)
-                        const unsigned *sp = lidx_s + ((2 * hw + kp) * 64 + 8 * g + q4) * TB_LW + o / 3;
-                        const unsigned shb = 10u * (unsigned)(o % 3);
+                        // indices for offset o: bits tb_lshift(o) .. +9 of their word in plane tb_lplane(o) (tilebook.hpp)
+                        // (plane tb_lplane(o), word tb_lpos(row): row r + 32 is two subtiles = 2 words on, row r + 4 — bit 2 of
+                        // the row, bit 3 of its slot — 32 words)
+                        const unsigned *sp = lidx_s + tb_lplane(o) * TB_T + tb_lpos((2 * hw + kp) * 64 + 8 * g + q4);
+                        const unsigned shb = tb_lshift(o);
                         ra[mm * 4 + 2 * kp] = (__builtin_amdgcn_ubfe(sp[0], shb, 10u) << 5) + lane_off;
-                        ra[mm * 4 + 2 * kp + 1] = (__builtin_amdgcn_ubfe(sp[32 * TB_LW], shb, 10u) << 5) + lane_off;
-                        rb[mm * 4 + 2 * kp] = (__builtin_amdgcn_ubfe(sp[4 * TB_LW], shb, 10u) << 5) + lane_off;
-                        rb[mm * 4 + 2 * kp + 1] = (__builtin_amdgcn_ubfe(sp[36 * TB_LW], shb, 10u) << 5) + lane_off;
+                        ra[mm * 4 + 2 * kp + 1] = (__builtin_amdgcn_ubfe(sp[2], shb, 10u) << 5) + lane_off;
+                        rb[mm * 4 + 2 * kp] = (__builtin_amdgcn_ubfe(sp[32], shb, 10u) << 5) + lane_off;
+                        rb[mm * 4 + 2 * kp + 1] = (__builtin_amdgcn_ubfe(sp[34], shb, 10u) << 5) + lane_off;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);

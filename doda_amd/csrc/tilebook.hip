@@ -108,22 +108,22 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
                     ul[tb_upos(k++)] = lo + w * 32 + 8 * q + b;
                 }
             }
-            // the row's nine packed words (three 10-bit local indices each; tilebook.hpp)
-            uint32_t *li = v.lidx + ((size_t)tile * TB_T + tid) * TB_LW;
+            // the row's ten packed words, one per plane (three 10-bit local indices each; tilebook.hpp)
+            uint32_t *li = v.lidx + (size_t)tile * (TB_T * TB_LW) + tb_lpos(tid);
 #pragma unroll
             for (int w3 = 0; w3 < TB_LW; ++w3) {
                 unsigned word = 0u;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    const int o = 3 * w3 + q;
-                    unsigned r = 0u;   // absent: LDS slot 0, the zero row
-                    if (e[o] >= 0) {
+                    const int oo = 2 * (3 * (w3 % 5) + q) + w3 / 5, o = oo < TB_K ? oo : 0;
+                    unsigned r = 0u;   // absent (or no such offset): LDS slot 0, the zero row
+                    if (oo < TB_K && e[o] >= 0) {
                         const unsigned d = (unsigned)(e[o] - lo), w = d >> 5;
                         r = (unsigned)(hrank[w] + __popc(htab[w] & ((1u << (d & 31u)) - 1u)) + 1);
                     }
                     word |= r << (10 * q);
                 }
-                li[w3] = word;
+                li[w3 * TB_T] = word;
             }
             return;
         }
@@ -215,15 +215,15 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
         hrank[slot] = (unsigned short)k;
     }
     __syncthreads();
-    uint32_t *li = v.lidx + ((size_t)tile * TB_T + tid) * TB_LW;
+    uint32_t *li = v.lidx + (size_t)tile * (TB_T * TB_LW) + tb_lpos(tid);
 #pragma unroll
     for (int w3 = 0; w3 < TB_LW; ++w3) {
         unsigned word = 0u;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const int o = 3 * w3 + q;
-            unsigned r = 0u;   // absent: LDS slot 0, the zero row
-            if (e[o] >= 0) {
+            const int oo = 2 * (3 * (w3 % 5) + q) + w3 / 5, o = oo < TB_K ? oo : 0;
+            unsigned r = 0u;   // absent (or no such offset): LDS slot 0, the zero row
+            if (oo < TB_K && e[o] >= 0) {
                 const unsigned key = (unsigned)e[o];
                 unsigned slot = hash_mix(key) & (HCAP - 1);
                 while (htab[slot] != key) slot = (slot + 1) & (HCAP - 1);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
             }
             word |= r << (10 * q);
         }
-        li[w3] = word;
+        li[w3 * TB_T] = word;
     }
 }
 

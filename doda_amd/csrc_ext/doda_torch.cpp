@@ -1093,17 +1093,20 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               const void *tb = tilebook_behind(tbl, tbl.size(1));
               TORCH_CHECK(tb, "doda tilebook_parts: no tilebook");
               const int64_t T = doda_tilebook_tile(), nt = (tbl.size(1) + T - 1) / T, K = tbl.size(0), UMAX = doda_tilebook_umax();
-              const int64_t LW = (K + 2) / 3;     // packed words per row: three 10-bit local indices each (csrc/tilebook.hpp)
+              TORCH_CHECK(K == 27 && T == 256, "doda tilebook_parts: layout of csrc/tilebook.hpp");
+              const int64_t LW = 10;              // planes of packed local indices (csrc/tilebook.hpp: tb_lplane / tb_lshift / tb_lpos)
               char *p = (char *)const_cast<void *>(tb);
               auto o32 = tbl.options();
               // (stored in the DMA kernel's lane order, csrc/tilebook.hpp tb_upos: handed out in list order)
               at::Tensor order = at::empty({UMAX}, at::TensorOptions().dtype(at::kLong));
               for (int64_t e = 0; e < UMAX; ++e) order.data_ptr<int64_t>()[e] = (((e >> 5) & 7) * 32 + (e & 31)) * 4 + (e >> 8);
               at::Tensor ulist = at::from_blob(p, {nt, UMAX}, o32).index_select(1, order.to(tbl.device()));
-              at::Tensor words = at::from_blob(p + nt * UMAX * 4, {nt, T, LW}, o32).to(at::kLong);
+              at::Tensor pos = at::empty({T}, at::TensorOptions().dtype(at::kLong));      // word of row t inside a plane
+              for (int64_t t = 0; t < T; ++t) pos.data_ptr<int64_t>()[t] = (t & 0xC0) | (((t & 3) | ((t & 4) << 1) | ((t & 8) >> 1)) << 2) | ((t >> 4) & 3);
+              at::Tensor words = at::from_blob(p + nt * UMAX * 4, {nt, LW, T}, o32).to(at::kLong).index_select(2, pos.to(tbl.device()));
               std::vector<at::Tensor> per_offset;
               for (int64_t o = 0; o < K; ++o)
-                  per_offset.push_back(words.select(2, o / 3).bitwise_right_shift(10 * (o % 3)).bitwise_and(0x3ff));
+                  per_offset.push_back(words.select(1, (o & 1) * 5 + (o >> 1) / 3).bitwise_right_shift(10 * ((o >> 1) % 3)).bitwise_and(0x3ff));
               at::Tensor lidx = at::stack(per_offset, 1).to(at::kShort);          // [nt, K, T]
               at::Tensor ucount = at::from_blob(p + nt * UMAX * 4 + nt * T * LW * 4, {nt}, o32).clone();
               return std::make_tuple(ulist, lidx, ucount);

@@ -251,12 +251,14 @@ typedef struct doda_conv_epilogue {
  * DODA_ERR_UNSUPPORTED); `tilebook` 16-byte aligned. */
 int32_t doda_tilebook_tile(void);
 int32_t doda_tilebook_umax(void);   /* list slots per tile (1024; a tile whose neighbourhood has more than 1023 distinct rows is
-                                     * an overflow tile).  Layout: ulist int32 [nt][umax]; lidx uint32 [nt][tile][9] — per output
-                                     * row nine words of three 10-bit local indices, offset o in word o/3 at bit 10*(o%3): 1 + the
-                                     * position of tbl[o][row] in ulist, 0 = no neighbour; ucount int32 [nt]; n_over int32 [2] (the last eight bytes) = tiles whose
-                                     * neighbourhood exceeds the 64-byte-row / 32-byte-row staging capacity (they are served from
-                                     * the dense table: a caller whose voxel order has no locality reads n_over and stops
-                                     * building tilebooks).  52 bytes per output row (ABI 7; 70 with the uint16 strip before) */
+                                     * an overflow tile).  Layout: ulist int32 [nt][umax]; lidx uint32 [nt][10][tile] — ten planes
+                                     * of packed 10-bit local indices (1 + the position of tbl[o][row] in ulist, 0 = no neighbour):
+                                     * offset o of row t is bits 10 ((o / 2) % 3) .. + 9 of word ((t & 0xC0) | (sigma(t & 15) << 2)
+                                     * | ((t >> 4) & 3)), sigma = bits 2 and 3 exchanged, of plane 5 (o & 1) + (o / 2) / 3; ucount int32 [nt]; n_over int32 [2] (the
+                                     * last eight bytes) = tiles whose neighbourhood exceeds the 64-byte-row / 32-byte-row staging
+                                     * capacity (they are served from the dense table: a caller whose voxel order has no locality
+                                     * reads n_over and stops building tilebooks).  56 bytes per output row (ABI 7; 70 with the
+                                     * uint16 strip before) */
 size_t doda_tilebook_bytes(int32_t n_rows, int32_t K);
 int doda_tilebook_build(const int32_t *tbl, int32_t ld, int32_t K, int32_t n_rows, void *tilebook,
                         size_t tilebook_bytes, doda_stream_t stream);
