@@ -98,8 +98,8 @@ __device__ __forceinline__ f32x4 epi_unpack(const u32x2 &v) {
 // (DPP), the four waves (LDS) and the store of the workgroup's ONE partial row happen once, at the end of the kernel
 // (stats_flush).  Round 3 reduced per tile: 32 DPP operations, an LDS exchange and two barriers in every tile's
 // epilogue — on the tile loop's critical path.  Fixed order whatever the timing: deterministic.
-template <int S, bool OUT32, bool STATS, bool BNLDS = false>
-__device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<OUT32> &pre, int row0, int i, int g,
+template <int S, bool OUT32, bool STATS, bool BNLDS = false, int B = 0, int NBA = 1>
+__device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][NBA], const EpiPre<OUT32> &pre, int row0, int i, int g,
                                               int nb0, int nc, int n_out, __amdgpu_buffer_rsrc_t rs_y,
                                               const void *__restrict__ res, const EpiArgs &ep, f32x4 (&lst)[2],
                                               const f32x4 (*bnv_lds)[4] = nullptr) {
@@ -129,7 +129,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][1], const EpiPre<O
     for (int s = 0; s < S; ++s) {
         const unsigned t = (unsigned)(row0 + s * 16 + i);
         const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * (unsigned)nc + col) * OSZ : OOB;
-        f32x4 a = acc[s][0];
+        f32x4 a = acc[s][B];
         if (res) a += epi_unpack(pre.res[s]);
         u32x2 packed_out = {0u, 0u};
         if constexpr (!OUT32) {
@@ -194,7 +194,10 @@ __device__ __forceinline__ void stats_flush(f32x4 (&lst)[2], int i, int g, int w
 //         workgroups per CU, which still keeps ~70 KB of row loads in flight per CU).
 // MODE 2: fp32, 16 input channels (64-byte rows staged exactly as MODE 1; four v_mfma_f32_16x16x4_f32 per unit and
 //         subtile — the reference's precision; MFMA-bound at ~53 us for the level-1 layer instead of 80 us).
-template <int MODE, bool OUT32, bool STATS, int MAXNB>
+// DUAL (64-byte rows, 32 output channels: the level-2 layers): both channel blocks in ONE pass over the units — every operand
+// row read out of LDS feeds two MFMAs.  (Stamps, level-2 rulebook of the bench batch, 600 tiles on 512 workgroups: two passes
+// took 8.4 us of a 14 us tile with the LDS array as the busiest unit.)
+template <int MODE, bool OUT32, bool STATS, int MAXNB, bool DUAL = false>
 __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *__restrict__ x, unsigned x_bytes,
                                                  const void *__restrict__ wp, unsigned wp_bytes, int nc, int NB,
                                                  const int32_t *__restrict__ tbl, int ld, int n_out,
@@ -202,6 +205,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
                                                  const void *__restrict__ res, const EpiArgs ep) {
     constexpr bool WIDE = MODE != 0;
     static_assert(MODE != 2 || OUT32, "fp32 features have fp32 outputs");
+    static_assert(!DUAL || (MODE == 1 && (MAXNB == 2 || !STATS)), "two channel blocks per pass: bf16, 64-byte rows");
+    constexpr int NBA = DUAL ? 2 : 1;                          // channel blocks per pass over the units
     constexpr int S = 4, NU = WIDE ? TB_K : (TB_K + 1) / 2;
     constexpr int RB = WIDE ? 64 : 32;                         // bytes per staged row
     constexpr int PPR = RB / 16;                               // 16-byte pieces per row
@@ -281,7 +286,9 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
         // pair packing [o][nb][32 slots], wide packing [o][nb][64 lanes]; 16 bytes per slot
         unsigned lane_w = WIDE ? (unsigned)lane * 16u
                                : (unsigned)(g >> 1) * (unsigned)NB * 512u + (unsigned)((g & 1) * 16 + i) * 16u;
-        auto loadw = [&](int u) { return __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)u * (unsigned)NB * 1024u + lane_w, 0, 0); };
+        auto loadw = [&](int u, int b = 0) {
+            return __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)u * (unsigned)NB * 1024u + lane_w + (unsigned)b * (WIDE ? 1024u : 512u), 0, 0);
+        };
         // the epilogue's operands of the first channel block travel with the rows
         EpiPre<OUT32> pre;
         epi_prefetch<S, OUT32, STATS>(pre, row0, i, g, 0, nc, n_out, y_bytes, res, ep);
@@ -341,16 +348,18 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
         __syncthreads();
         TILE_STAMP(2);
 
-        for (int nb0 = 0; nb0 < NB; ++nb0) {
+        for (int nb0 = 0; nb0 < NB; nb0 += NBA) {
             if (nb0 > 0) {
-                lane_w += WIDE ? 1024u : 512u;
+                lane_w += (WIDE ? 1024u : 512u) * (unsigned)NBA;
                 epi_prefetch<S, OUT32, STATS>(pre, row0, i, g, nb0, nc, n_out, y_bytes, res, ep);
             }
 
             // ---- phase B ----
-            f32x4 acc[S][1];
+            f32x4 acc[S][NBA];
 #pragma unroll
-            for (int s = 0; s < S; ++s) acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int b = 0; b < NBA; ++b) acc[s][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (staged) {
                 // local indices two units ahead, operand rows one unit ahead of the MFMAs (the scheduling
                 // barriers keep hipcc from sinking the reads next to their use, which left one LDS round trip
@@ -381,9 +390,11 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
                         if (u % 3 == 0 && 3 * (k + 1) < NU) lw[0][(k + 1) & 1] = loadp(k + 1);
                     }
                 };
-                u32x4 xa[2][S], wr[4];
+                u32x4 xa[2][S], wr[4][NBA];
 #pragma unroll
-                for (int u = 0; u < 3; ++u) wr[u] = loadw(u);
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int b = 0; b < NBA; ++b) wr[u][b] = loadw(u, b);
                 lw[0][0] = loadp(0);
                 if constexpr (WIDE) lw[1][0] = loadp(5);
                 fetch(0, xa[0]);
@@ -396,12 +407,18 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
                 for (int u = 0; u < NU; ++u) {
                     if (u + 1 < NU) fetch(u + 1, xa[(u + 1) & 1]);
                     next_word(u);
-                    if (u + 3 < NU) wr[(u + 3) & 3] = loadw(u + 3);
+                    if (u + 3 < NU) {
+#pragma unroll
+                        for (int b = 0; b < NBA; ++b) wr[(u + 3) & 3][b] = loadw(u + 3, b);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
-                        if constexpr (MODE == 2) mma_f32_k16(acc[s][0], wr[u & 3], xa[u & 1][s]);
-                        else mma_bf16_k32(acc[s][0], wr[u & 3], xa[u & 1][s]);
+#pragma unroll
+                        for (int b = 0; b < NBA; ++b) {
+                            if constexpr (MODE == 2) mma_f32_k16(acc[s][b], wr[u & 3][b], xa[u & 1][s]);
+                            else mma_bf16_k32(acc[s][b], wr[u & 3][b], xa[u & 1][s]);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -428,18 +445,32 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
                 for (int u = 0; u < NU; ++u) {
                     if (u + 2 < NU) ldi(u + 2, ix[(u + 2) % 3]);
                     if (u + 1 < NU) ldx(ix[(u + 1) % 3], xo[(u + 1) & 1]);
-                    const u32x4 wu = loadw(u);
+                    u32x4 wu[NBA];
+#pragma unroll
+                    for (int b = 0; b < NBA; ++b) wu[b] = loadw(u, b);
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
-                        if constexpr (MODE == 2) mma_f32_k16(acc[s][0], wu, xo[u & 1][s]);
-                        else mma_bf16_k32(acc[s][0], wu, xo[u & 1][s]);
+#pragma unroll
+                        for (int b = 0; b < NBA; ++b) {
+                            if constexpr (MODE == 2) mma_f32_k16(acc[s][b], wu[b], xo[u & 1][s]);
+                            else mma_bf16_k32(acc[s][b], wu[b], xo[u & 1][s]);
+                        }
                     }
                 }
             }
             TILE_STAMP(3);
             // (statistics: static register index — NB <= MAXNB is checked by the launcher)
-            if (nb0 == 0) tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[0]);
-            else tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[STATS ? MAXNB - 1 : 0]);
+            if constexpr (DUAL) {
+                // the second block's epilogue operands: requested now (the lines its rows share with the first block's are in
+                // the cache), consumed after the first block's epilogue
+                EpiPre<OUT32> pre1;
+                epi_prefetch<S, OUT32, STATS>(pre1, row0, i, g, nb0 + 1, nc, n_out, y_bytes, res, ep);
+                tile_epilogue<S, OUT32, STATS, false, 0, NBA>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[0]);
+                tile_epilogue<S, OUT32, STATS, false, 1, NBA>(acc, pre1, row0, i, g, nb0 + 1, nc, n_out, rs_y, res, ep, lst[STATS ? MAXNB - 1 : 0]);
+            } else {
+                if (nb0 == 0) tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[0]);
+                else tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[STATS ? MAXNB - 1 : 0]);
+            }
         }
         TILE_STAMP(4);
         __syncthreads();   // the next tile overwrites the staged rows
@@ -679,6 +710,10 @@ __global__ __launch_bounds__(256, 2) void conv_tile16(const void *__restrict__ x
 }
 
 constexpr int BT_MAX_GROUPS = 768;   // 3 workgroups per CU x 256 CUs
+bool dual_blocks() {   // (A/B: DODA_TILE_DUAL=0 keeps the 32-output-channel layers on one channel block per pass)
+    static const bool v = !(getenv("DODA_TILE_DUAL") && getenv("DODA_TILE_DUAL")[0] == '0');
+    return v;
+}
 constexpr int T16_MAX_GROUPS = 512;  // conv_tile16: 2 workgroups per CU
 // conv_tile16 pays off from the point where conv_tile's workgroups run more than one tile each (a single tile per
 // workgroup has nothing to prefetch, and three shallow workgroups per CU then beat two)
@@ -724,6 +759,8 @@ int doda_tile::launch_conv_tile(int mode, bool out32, const void *x, unsigned xb
     const EpiArgs &ep = ep_in;
 #define GT1(M, O32, ST, NBS)                                                                       \
     hipLaunchKernelGGL((conv_tile<M, O32, ST, NBS>), grid, block, 0, s, x, xb, wp, wpb, nc, NB, tbl, ld, n_out, tb, y, yb, res, ep)
+#define GTD(O32, ST)                                                                               \
+    hipLaunchKernelGGL((conv_tile<1, O32, ST, 2, true>), grid, block, 0, s, x, xb, wp, wpb, nc, NB, tbl, ld, n_out, tb, y, yb, res, ep)
 #define GT(M, O32, ST)                                                                             \
     do {                                                                                           \
         if (ST && two) GT1(M, O32, ST, 2); else GT1(M, O32, ST, 1);                                \
@@ -734,11 +771,16 @@ int doda_tile::launch_conv_tile(int mode, bool out32, const void *x, unsigned xb
         else { if (ep.stats) GT(M, false, true); else GT(M, false, false); }                       \
     } while (0)
     if (mode == 2) { if (ep.stats) GT(2, true, true); else GT(2, true, false); }
+    else if (mode == 1 && NB == 2 && dual_blocks()) {   // 32 output channels: both channel blocks in one pass
+        if (out32) { if (ep.stats) GTD(true, true); else GTD(true, false); }
+        else { if (ep.stats) GTD(false, true); else GTD(false, false); }
+    }
     else if (mode == 1) GM(1);
     else GM(0);
 #undef GM
 #undef GT
 #undef GT1
+#undef GTD
     return doda_check_launch();
 }
 

@@ -9,7 +9,7 @@ rotating buffer sets (cold) and prints, per round of tiles, the mean / p90 lengt
   units   2 -> 3         the unit loop
   epi     3 -> 4         epilogue
   bar2    4 -> 5         barrier at the end of the tile
-usage: tilestamps.py [n_scenes=4] [reps=6]
+usage: tilestamps.py [n_scenes=4] [reps=6] [l2]      (l2: the level-2 rulebook of the batch, 32 -> 32 channels: conv_tile<1>)
 """
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,16 +47,22 @@ def main():
     batch = make_batch(nsc, 150000, 1000)
     idx = batch["voxel_locs"].int().to(dev)
     shape = [int(s) for s in batch["spatial_shape"]]
-    sub = spconv.ops.build_subm(idx, nsc, shape, 3)
-    m = idx.shape[0]
-    w = torch.randn(27, 16, 16, device=dev) * 0.05
-    plan = ops.PackPlan([(w, 27, 16, 16, 0, 2)], dev)
+    l2 = "l2" in sys.argv[3:]
+    c = 32 if l2 else 16
+    if l2:
+        t = spconv.SparseConvTensor(None, idx, shape, nsc)
+        sub = spconv.ops.build_pyramid(t, 3, with_pairs=False, with_tiles=2)["subm2"]
+    else:
+        sub = spconv.ops.build_subm(idx, nsc, shape, 3)
+    m = sub.tbl.shape[1]
+    w = torch.randn(27, c, c, device=dev) * 0.05
+    plan = ops.PackPlan([(w, 27, c, c, 0, 2)], dev)
     plan.run()
     n_sets = 8
     sets = []
     for j in range(n_sets):
-        tbl = sub.tbl if j == 0 else sub.tbl.clone()
-        sets.append((torch.randn(m, 16, device=dev).bfloat16(), torch.randn(m, 16, device=dev).bfloat16(), tbl,
+        tbl = sub.tbl.clone()
+        sets.append((torch.randn(m, c, device=dev).bfloat16(), torch.randn(m, c, device=dev).bfloat16(), tbl,
                      ops.tilebook_build(tbl)))
     h = _lib.lib()
     fn = C.CDLL(lib_path).doda_debug_tile_stamps   # (same path: the handle doda_amd._lib holds)
@@ -68,7 +74,7 @@ def main():
         x, res, tbl, tb = sets[r % n_sets]
         torch.cuda.synchronize()
         ev[0].record()
-        ops.spconv_gather(x, None, tbl, m, 0, 16, packed=plan.outputs[0], tilebook=tb, residual=res, want_stats=True)
+        ops.spconv_gather(x, None, tbl, m, 0, c, packed=plan.outputs[0], tilebook=tb, residual=res, want_stats=True)
         ev[1].record()
         torch.cuda.synchronize()
         if r < reps - 2:
@@ -76,8 +82,8 @@ def main():
         assert fn(buf.ctypes.data, buf.nbytes) == 0
         st = buf.reshape(768, 8, 8).astype(np.int64)
         nt = (m + 255) // 256
-        groups = min(768, (nt + 7) // 8 * 8)
-        if h.doda_get_option(1) and nt >= int(os.environ.get("DODA_TILE16_MIN_TILES", "769")):
+        groups = min(512 if l2 else 768, (nt + 7) // 8 * 8)
+        if not l2 and h.doda_get_option(1) and nt >= int(os.environ.get("DODA_TILE16_MIN_TILES", "769")):
             groups = 512                                  # conv_tile16
         st = st[:groups]
         t0 = st[:, 0, 0].min()
