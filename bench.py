@@ -201,7 +201,7 @@ def _subm16_times(idx, shape, nb, dtype, reps):
 PROFILE_ROUND = "r04"   # in-step / PMC evidence quoted by the bench line must come from THIS round's profiles or be absent
 # the roofline kernel's instantiation as rocprofv3 prints it (template arguments up to the ones that name the epilogue),
 # shared by the live measurement's label and the look-up in the committed kernel statistics
-ROOF_KERNEL = {"bf16": "conv_tile<0, false, true", "f32": "conv_tile<2, true, true", "f32_dense": "::PF32,"}
+ROOF_KERNEL = {"bf16": "conv_tile16<false, true>", "f32": "conv_tile<2, true, true", "f32_dense": "::PF32,"}
 
 
 def in_step_average(dtype):
@@ -248,7 +248,8 @@ def kernel_roofline(batch_dev, dtype, reps, gate_scene=None):
     b_step = big["fwd"]["algorithmic_bytes"]["step"]
     rk = ROOF_KERNEL["bf16" if dtype == "bf16" else ("f32" if big["tile_kernel"] else "f32_dense")]
     if big["tile_kernel"]:
-        kname = rk + ", ...> (LDS-staged over the tilebook; BatchNorm statistics + residual add in the epilogue: the instantiation the step launches)"
+        kname = rk + (" (LDS-staged over the tilebook, software-pipelined across a workgroup's tiles;" if dtype == "bf16" else
+                      ", ...> (LDS-staged over the tilebook;") + " BatchNorm statistics + residual add in the epilogue: the instantiation the step launches)"
     else:
         kname = ("conv_fast<PF32, ..., STATS> [" + rk + "]" if dtype == "f32" else "conv_fast<PBF16P,1,2,3,STATS>") + " (statistics + residual epilogue)"
     traffic, traffic_src = pmc_traffic(dtype)
