@@ -61,6 +61,10 @@ struct EpiArgs {   // plain data, shared across translation units
 namespace doda_tile {
 bool enabled();   // doda_set_option(DODA_OPT_TILE_KERNEL)
 void set_enabled(bool on);
+bool pipeline_enabled();   // doda_set_option(DODA_OPT_TILE_PIPELINE): conv_tile16 for 16 -> 16 layers of many tiles
+void set_pipeline(bool on);
+bool dual_enabled();       // doda_set_option(DODA_OPT_TILE_DUAL): both channel blocks of a 32-output-channel layer in one pass
+void set_dual(bool on);
 // conv_tile over `tilebook` (doda_tilebook_build of tbl).  mode 0: bf16 16 channels, 1: bf16 32 channels, 2: fp32 16
 // channels; out32: fp32 output rows.  *n_part (if given) receives the number of statistics rows.
 int launch_conv_tile(int mode, bool out32, const void *x, unsigned x_bytes, const void *wp, unsigned wp_bytes, int nc, int NB,

@@ -1025,6 +1025,8 @@ extern "C" int doda_set_option(int32_t option, int32_t value) {
     case DODA_OPT_TILE_KERNEL: doda_tile::set_enabled(value != 0); return DODA_OK;
     case DODA_OPT_WLDS_KERNEL: doda_wlds::set_enabled(value != 0); return DODA_OK;
     case DODA_OPT_WDMA_KERNEL: doda_wdma::set_enabled(value != 0); return DODA_OK;
+    case DODA_OPT_TILE_PIPELINE: doda_tile::set_pipeline(value != 0); return DODA_OK;
+    case DODA_OPT_TILE_DUAL: doda_tile::set_dual(value != 0); return DODA_OK;
     default: return DODA_ERR_INVALID;
     }
 }
@@ -1033,6 +1035,8 @@ extern "C" int32_t doda_get_option(int32_t option) {
     case DODA_OPT_TILE_KERNEL: return doda_tile::enabled() ? 1 : 0;
     case DODA_OPT_WLDS_KERNEL: return doda_wlds::enabled() ? 1 : 0;
     case DODA_OPT_WDMA_KERNEL: return doda_wdma::enabled() ? 1 : 0;
+    case DODA_OPT_TILE_PIPELINE: return doda_tile::pipeline_enabled() ? 1 : 0;
+    case DODA_OPT_TILE_DUAL: return doda_tile::dual_enabled() ? 1 : 0;
     default: return -1;
     }
 }

@@ -710,10 +710,11 @@ __global__ __launch_bounds__(256, 2) void conv_tile16(const void *__restrict__ x
 }
 
 constexpr int BT_MAX_GROUPS = 768;   // 3 workgroups per CU x 256 CUs
-bool dual_blocks() {   // (A/B: DODA_TILE_DUAL=0 keeps the 32-output-channel layers on one channel block per pass)
-    static const bool v = !(getenv("DODA_TILE_DUAL") && getenv("DODA_TILE_DUAL")[0] == '0');
-    return v;
-}
+// (A/B switches: DODA_TILE_DUAL=0 / doda_set_option(DODA_OPT_TILE_DUAL, 0) keeps the 32-output-channel layers on one channel block
+// per pass; doda_set_option(DODA_OPT_TILE_PIPELINE, 0) keeps the 16 -> 16 layers on conv_tile)
+bool g_dual = !(getenv("DODA_TILE_DUAL") && getenv("DODA_TILE_DUAL")[0] == '0');
+bool g_pipeline = true;
+bool dual_blocks() { return g_dual; }
 constexpr int T16_MAX_GROUPS = 512;  // conv_tile16: 2 workgroups per CU
 // conv_tile16 pays off from the point where conv_tile's workgroups run more than one tile each (a single tile per
 // workgroup has nothing to prefetch, and three shallow workgroups per CU then beat two)
@@ -732,12 +733,16 @@ bool g_use_tile = true;   // doda_set_option(DODA_OPT_TILE_KERNEL) (A/B measurem
 
 bool doda_tile::enabled() { return g_use_tile; }
 void doda_tile::set_enabled(bool on) { g_use_tile = on; }
+bool doda_tile::pipeline_enabled() { return g_pipeline; }
+void doda_tile::set_pipeline(bool on) { g_pipeline = on; }
+bool doda_tile::dual_enabled() { return g_dual; }
+void doda_tile::set_dual(bool on) { g_dual = on; }
 
 int doda_tile::launch_conv_tile(int mode, bool out32, const void *x, unsigned xb, const void *wp, unsigned wpb, int nc, int NB,
                                 const int32_t *tbl, int ld, int n_out, const void *tilebook, void *y, unsigned yb,
                                 const void *res, const EpiArgs &ep_in, int *n_part, hipStream_t s) {
     const TileBookView tb = tilebook_view(const_cast<void *>(tilebook), n_out);
-    if (mode == 0 && NB == 1 && tb.nt >= tile16_min_tiles()) {
+    if (mode == 0 && NB == 1 && g_pipeline && tb.nt >= tile16_min_tiles()) {
         const int groups16 = T16_MAX_GROUPS;
         if (n_part) *n_part = groups16;
         const dim3 grid(groups16), block(256);

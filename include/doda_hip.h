@@ -268,6 +268,10 @@ int doda_tilebook_build(const int32_t *tbl, int32_t ld, int32_t K, int32_t n_row
 #define DODA_OPT_TILE_KERNEL 1   /* 0: ignore tilebooks in doda_spconv_gather_ex (dense-table kernels only) */
 #define DODA_OPT_WLDS_KERNEL 2   /* 0: the 48 -> 48 channel layers stay on the streaming-weights kernel */
 #define DODA_OPT_WDMA_KERNEL 3   /* 0: weight-gradient jobs ignore their tilebook (pair-list / gather-table kernels) */
+#define DODA_OPT_TILE_PIPELINE 4 /* 0: 16 -> 16 layers stay on conv_tile whatever the tile count (default 1: tables of >= 769 tiles —
+                                  * DODA_TILE16_MIN_TILES — take the cross-tile pipelined conv_tile16; results are bit-identical) */
+#define DODA_OPT_TILE_DUAL 5     /* 0: 32-output-channel tile layers take one channel block per pass over the units (default 1:
+                                  * both in one pass; results are bit-identical) */
 int doda_set_option(int32_t option, int32_t value);
 int32_t doda_get_option(int32_t option);
 size_t doda_spconv_stats_capacity(int32_t n_out);

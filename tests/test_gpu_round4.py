@@ -316,3 +316,39 @@ def test_rulebook_direct_address_grid_equals_the_hash_build(native_lib, oracle, 
     pairs, pn = oracle.indice_pairs_subm(np.ascontiguousarray(idx), batch, shape, 3)
     hp, hn = ops.rulebook_pairs(tables[1][0].to(d), n, flip=True)
     assert np.array_equal(hn.cpu().numpy(), pn) and np.array_equal(hp.cpu().numpy(), pairs)
+
+
+@pytest.mark.parametrize("cin,cout,option", [(16, 16, 4), (32, 32, 5)])
+def test_pipelined_and_dual_block_tile_kernels_equal_the_plain_tile_kernel_bit_for_bit(native_lib, oracle, cin, cout, option):
+    """conv_tile16 (16 -> 16, the next tile prefetched into registers: DODA_OPT_TILE_PIPELINE) and the dual-block pass of the
+    32-output-channel layers (DODA_OPT_TILE_DUAL) change WHEN operands are fetched and how many accumulators a pass keeps, not what
+    is summed in which order: outputs and per-column statistics totals must equal the plain conv_tile's exactly — forward and data
+    gradient, with residual + statistics (the step's instantiation), on a rulebook with tiles that lost their lists."""
+    from doda_amd import ops
+    from doda_amd._lib import lib
+    d = dev()
+    idx, shape, batch, pairs, pn = _big_scene(oracle)
+    n = idx.shape[0]
+    tbl, tb = _hip_rulebook(idx, shape, batch, pairs, pn)
+    g = torch.Generator().manual_seed(77 + option)
+    x = torch.randn(n, cin, generator=g).bfloat16().to(d)
+    dy = torch.randn(n, cout, generator=g).bfloat16().to(d)
+    w = (torch.randn(27, cin, cout, generator=g) * 0.1).to(d)
+    assert lib().doda_get_option(option) == 1
+    try:
+        for inp, layout, nc in ((x, 0, cout), (dy, 2, cin)):
+            res = torch.randn(n, nc, generator=g).bfloat16().to(d)
+            got = {}
+            for on in (1, 0):
+                assert lib().doda_set_option(option, on) == 0
+                y, st = ops.spconv_gather(inp, w, tbl, n, layout, nc, tilebook=tb, residual=res, want_stats=True)
+                yp = ops.spconv_gather(inp, w, tbl, n, layout, nc, tilebook=tb, out_f32=True)
+                got[on] = (y, st.double().sum(0).cpu(), yp, st.shape[0])
+            assert torch.equal(got[1][0], got[0][0]) and torch.equal(got[1][2], got[0][2]), (layout, "outputs")
+            # (the partial rows are per workgroup — 512 against 768 of them — so only their totals are comparable: fp32 partials
+            # summed in fp64 over different groupings of the same values)
+            assert rel_err(got[1][1], got[0][1]) < 1e-6, (layout, "statistics")
+            if option == 4:
+                assert got[1][3] == 512 and got[0][3] == 768
+    finally:
+        lib().doda_set_option(option, 1)
