@@ -32,15 +32,15 @@ namespace {
 // (tilebook.hpp) lists as ~2.2 x 256 DISTINCT input rows:
 //   phase A  every distinct row is loaded once, consecutive lanes covering consecutive list entries (runs
 //            of consecutive rows -> whole 128-byte lines), and parked in LDS next to the tile's local-index
-//            strip (27 x 256 uint16);
-//   phase B  per unit (a pair of offsets x 16 channels, or one offset x 32 channels) one 8-byte LDS read
-//            returns the lane's four local indices (one per 16-row subtile), four 16-byte LDS reads fetch
+//            strip (ten planes of packed 10-bit local indices, tilebook.hpp);
+//   phase B  per unit (a pair of offsets x 16 channels, or one offset x 32 channels) the lane's four local indices (one per
+//            16-row subtile) come out of a 16-byte LDS read that serves three units, four 16-byte LDS reads fetch
 //            the operand rows (an absent neighbour is the shared zero row: same address in every lane, a
 //            broadcast), four MFMAs accumulate.  The only vector-memory instruction in the loop is the
 //            streamed weight fragment (L1-resident).
-// Vector-memory instructions per 64 output rows (16 channels): ~9 rows + 8 list + 4 strip + 14 weights + 4
-// stores = 39 against 96.  A tile whose neighbourhood exceeds the kernel's capacity (1216 rows of 32 bytes, 960 of
-// 64 bytes; 0.05 % / 17 % of the tiles of a 1 cm scene, none at 2 cm) takes
+// Vector-memory instructions per wave and tile (16 channels): 8 rows + 2 list + 3 strip + 14 weights + 4 epilogue
+// operands + 4 stores = 35 against 96 per 64 rows.  A tile whose neighbourhood exceeds the kernel's capacity (1023 rows of 32
+// bytes — 10-bit local indices —, 960 of 64 bytes; a few percent / 17 % of the tiles of a 1 cm scene, none at 2 cm) takes
 // the same loop with the operands gathered from global memory through the dense table.
 // Same arithmetic as conv_fast up to the order in which offsets are paired (fixed (2u, 2u+1) here, pairs of
 // ACTIVE offsets there): fp32 accumulation, one bf16 rounding at the store.

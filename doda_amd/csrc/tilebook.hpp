@@ -1,5 +1,5 @@
 // Tile-local form of a SubM gather table ("tilebook"), shared by the builder (tilebook.hip) and the
-// LDS-staged convolution kernels (spconv_tile.hip: conv_tile, bwd_tile).
+// LDS-staged kernels (spconv_tile.hip: conv_tile, conv_tile16; spconv_wdma.hip: wgrad_dma16).
 //
 // The dense table tbl[K][M] makes every (offset, row) slot a vector-memory gather of its own: at level 1
 // of DODA's U-Net a 32-row wave issues 28 gather instructions at 37 % lane use, and the kernel is paced by
@@ -62,7 +62,7 @@ static inline TileBookView tilebook_view(void *base, long long n_rows) {
     return v;
 }
 
-// Storage position of list entry e.  The LDS-DMA kernel (spconv_dma.hip) moves a tile's rows with four DMA
+// Storage position of list entry e.  The LDS-DMA kernel (spconv_wdma.hip) moves a tile's rows with four DMA
 // instructions per wave; lane l of wave w stages, with instruction k, the row of entry (k*8 + w)*32 + (l >> 1).
 // Stored at (w*32 + (l >> 1))*4 + k, the four entries of a lane are ONE 16-byte load (8 list instructions per tile
 // instead of 40 four-byte ones: these kernels are paced by the number of vector-memory instructions per CU).
