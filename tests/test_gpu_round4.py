@@ -352,3 +352,46 @@ def test_pipelined_and_dual_block_tile_kernels_equal_the_plain_tile_kernel_bit_f
                 assert got[1][3] == 512 and got[0][3] == 768
     finally:
         lib().doda_set_option(option, 1)
+
+
+@pytest.mark.parametrize("tiles,ragged", [(769, 0), (770, 37), (1024, 0), (1025, 255), (1249, 1)])
+def test_pipelined_tile_kernel_at_the_edges_of_its_schedule(native_lib, oracle, tiles, ragged):
+    """conv_tile16's schedule has corners the two big-scene tests do not reach: workgroups with ONE tile next to workgroups
+    with two (769 tiles on 512 workgroups: 'no next tile' requests from the first iteration on), exact multiples of the grid,
+    a last tile of a single row / of 255 rows.  Truncated copies of the big scene's gather table (entries past the cut = absent)
+    are valid gather tables; the plain conv_tile — oracle-checked above — is the reference, bit for bit, forward with residual +
+    statistics and plain with fp32 output."""
+    from doda_amd import ops
+    from doda_amd._lib import lib
+    d = dev()
+    idx, shape, batch, pairs, pn = _big_scene(oracle)
+    tbl_full = ops.rulebook_subm(torch.from_numpy(idx).to(d), shape, batch, 3)
+    n = (tiles - 1) * 256 + (ragged if ragged else 256)
+    assert n <= tbl_full.shape[1]
+    tbl = tbl_full[:, :n].clone()
+    tbl[tbl >= n] = -1
+    tbl = tbl.contiguous()
+    tb = ops.tilebook_build(tbl)
+    assert tb is not None
+    g = torch.Generator().manual_seed(tiles)
+    x = torch.randn(n, 16, generator=g).bfloat16().to(d)
+    res = torch.randn(n, 16, generator=g).bfloat16().to(d)
+    w = (torch.randn(27, 16, 16, generator=g) * 0.1).to(d)
+    got = {}
+    try:
+        for on in (1, 0):
+            assert lib().doda_set_option(4, on) == 0
+            y, st = ops.spconv_gather(x, w, tbl, n, 0, 16, tilebook=tb, residual=res, want_stats=True)
+            yp = ops.spconv_gather(x, w, tbl, n, 0, 16, tilebook=tb, out_f32=True)
+            got[on] = (y, st.double().sum(0).cpu(), yp, st.shape[0])
+    finally:
+        lib().doda_set_option(4, 1)
+    assert got[1][3] == 512 and got[0][3] == min(768, (tiles + 7) // 8 * 8)
+    assert torch.equal(got[1][0], got[0][0]) and torch.equal(got[1][2], got[0][2])
+    assert rel_err(got[1][1], got[0][1]) < 1e-6
+    # and against the definition on a sample of rows (the truncated table is not an oracle rulebook: fp64 gather-sum here)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(n - min(n, 300), n), torch.randint(0, n, (400,), generator=g)]).to(d)
+    nb = tbl[:, rows].long()                                             # [27, r]
+    xr = torch.cat([x.double(), torch.zeros(1, 16, dtype=torch.float64, device=d)])[nb.clamp(min=-1)]   # -1 -> the zero row
+    want = torch.einsum("orc,ock->rk", xr, w.bfloat16().double())
+    assert rel_err(got[1][2][rows].cpu(), want.cpu()) < 1e-4
