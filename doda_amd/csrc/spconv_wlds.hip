@@ -19,13 +19,15 @@ constexpr int W_LDS_BYTES = WK * WNB * W_SLOTS * 16;   // 124 416
 bool g_use_wlds = true;
 
 // statistics / residual / store of one 16-column block held by 8 waves x S subtiles (cf. tile_epilogue)
+// Round 4: the residual / BatchNorm-input rows arrive as arguments — requested at the top of the tile, before the table and the
+// gathers (three channel blocks used to wait one after the other for their own loads at the END of the tile's chain) — and the
+// BatchNorm vectors come out of LDS (bnv: mean / invstd / gamma / beta x 48 channels, filled once per workgroup).
 template <int S, bool STATS>
-__device__ __forceinline__ void wlds_epilogue(f32x4 (&acc)[S], int row0, int i, int g, int wid, int nb, int n_out,
-                                              __amdgpu_buffer_rsrc_t rs_y, const void *__restrict__ res, unsigned y_bytes,
-                                              const EpiArgs &ep, int part, f32x4 (*sred)[2][4]) {
+__device__ __forceinline__ void wlds_epilogue(f32x4 (&acc)[S], const u32x2 (&pre_res)[S], const u32x2 (&pre_bnx)[S], int row0,
+                                              int i, int g, int wid, int nb, int n_out, __amdgpu_buffer_rsrc_t rs_y,
+                                              const void *__restrict__ res, const EpiArgs &ep, int part, f32x4 (*sred)[2][4],
+                                              const float (*bnv)[WCH]) {
     const unsigned col = (unsigned)(nb * 16 + 4 * g);
-    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)ep.bn_x, 0, y_bytes, 0x00020000);
     f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
     auto unpack = [](const u32x2 &v) {
         return (f32x4){__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u),
@@ -36,20 +38,20 @@ __device__ __forceinline__ void wlds_epilogue(f32x4 (&acc)[S], int row0, int i, 
         const unsigned t = (unsigned)(row0 + s * 16 + i);
         const unsigned voff = t < (unsigned)n_out ? (t * (unsigned)WCH + col) * 2u : OOB;
         f32x4 a = acc[s];
-        if (res) a += unpack(__builtin_amdgcn_raw_buffer_load_b64(rs_r, voff, 0, 0));
+        if (res) a += unpack(pre_res[s]);
         u32x2 packed_out;
         packed_out[0] = (unsigned)f2bf(a[0]) | ((unsigned)f2bf(a[1]) << 16);
         packed_out[1] = (unsigned)f2bf(a[2]) | ((unsigned)f2bf(a[3]) << 16);
         if constexpr (STATS) {
             f32x4 v = unpack(packed_out);
             if (ep.bn_x) {
-                const f32x4 xr = unpack(__builtin_amdgcn_raw_buffer_load_b64(rs_b, voff, 0, 0));
-                const f32x4 mu = *reinterpret_cast<const f32x4 *>(ep.bn_mean + col);
-                const f32x4 is = *reinterpret_cast<const f32x4 *>(ep.bn_invstd + col);
+                const f32x4 xr = unpack(pre_bnx[s]);
+                const f32x4 mu = *reinterpret_cast<const f32x4 *>(&bnv[0][col]);
+                const f32x4 is = *reinterpret_cast<const f32x4 *>(&bnv[1][col]);
                 const f32x4 xh = (xr - mu) * is;
                 if (ep.bn_relu) {
-                    const f32x4 ga = *reinterpret_cast<const f32x4 *>(ep.bn_gamma + col);
-                    const f32x4 be = *reinterpret_cast<const f32x4 *>(ep.bn_beta + col);
+                    const f32x4 ga = *reinterpret_cast<const f32x4 *>(&bnv[2][col]);
+                    const f32x4 be = *reinterpret_cast<const f32x4 *>(&bnv[3][col]);
                     const f32x4 yv = xh * ga + be;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = yv[q] > 0.f ? v[q] : 0.f;
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(512) void conv_wlds48(const unsigned short *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned char wl_raw[];
     u32x4 *wl = reinterpret_cast<u32x4 *>(wl_raw);                      // [27][3][96]
     __shared__ f32x4 sred[STATS ? 8 : 1][2][4];
+    __shared__ __attribute__((aligned(16))) float bnv[4][WCH];   // BatchNorm vectors of the data-gradient statistics epilogue
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
@@ -96,8 +99,30 @@ __global__ __launch_bounds__(512) void conv_wlds48(const unsigned short *__restr
     const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void *)tbl, 0, tbl_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, y_bytes, 0x00020000);
 
+    if constexpr (STATS) {
+        if (ep.bn_x && tid < 4 * WCH) {
+            const int v = tid / WCH, c = tid - v * WCH;
+            const float *src = v == 0 ? ep.bn_mean : v == 1 ? ep.bn_invstd : v == 2 ? ep.bn_gamma : ep.bn_beta;
+            bnv[v][c] = src ? src[c] : 0.f;
+        }
+    }
     // ---- the layer's fragments, once per workgroup.  Wide packing in global memory: [o][chunk 2][nb 3][lane 64];
     //      chunk 1 keeps lanes 0..31 (channels 32..47), lanes 32..63 would multiply zero padding ----
+    const int n_tiles = (n_out + TM - 1) / TM;
+    // gather-table entries of the wave's rows under every offset; the FIRST tile's are requested together with the fragments
+    // (they used to start their round trip after the fragments were parked and the workgroup had met at the barrier)
+    unsigned off[WK][S];
+    auto load_table = [&](int tile) {
+        const int row0 = tile * TM + wid * RW;
+#pragma unroll
+        for (int o = 0; o < WK; ++o)
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int t = row0 + s * 16 + i;
+                const unsigned voff = t < n_out ? ((unsigned)o * (unsigned)ld + (unsigned)t) * 4u : OOB;
+                off[o][s] = __builtin_amdgcn_raw_buffer_load_b32(rs_t, voff, 0, 0);
+            }
+    };
     {   // all loads first (16 per thread in flight), then the LDS writes: a rolled loop made 16 dependent round trips
         constexpr int NCP = (WK * WNB * W_SLOTS + 511) / 512;
         u32x4 tmp[NCP];
@@ -108,6 +133,7 @@ __global__ __launch_bounds__(512) void conv_wlds48(const unsigned short *__restr
             const int src = slot < 64 ? ((o * 2 + 0) * WNB + nb) * 64 + slot : ((o * 2 + 1) * WNB + nb) * 64 + (slot - 64);
             tmp[k] = wp[src];
         }
+        load_table((int)blockIdx.x);   // (a workgroup without a tile: every offset out of range)
 #pragma unroll
         for (int k = 0; k < NCP; ++k) {
             const int e = k * 512 + tid;
@@ -116,19 +142,26 @@ __global__ __launch_bounds__(512) void conv_wlds48(const unsigned short *__restr
     }
     __syncthreads();
 
-    const int n_tiles = (n_out + TM - 1) / TM;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int row0 = tile * TM + wid * RW;
+        // the epilogue's operands of all three channel blocks: requested now, consumed at the end of the tile
+        u32x2 pre_res[WNB][S], pre_bnx[WNB][S];
+        {
+            const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, y_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)ep.bn_x, 0, y_bytes, 0x00020000);
+#pragma unroll
+            for (int nb = 0; nb < WNB; ++nb)
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const unsigned t = (unsigned)(row0 + s * 16 + i);
+                    const unsigned voff = t < (unsigned)n_out ? (t * (unsigned)WCH + (unsigned)(nb * 16 + 4 * g)) * 2u : OOB;
+                    pre_res[nb][s] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, res ? voff : OOB, 0, 0);
+                    if constexpr (STATS) pre_bnx[nb][s] = __builtin_amdgcn_raw_buffer_load_b64(rs_b, ep.bn_x ? voff : OOB, 0, 0);
+                    else pre_bnx[nb][s] = (u32x2){0u, 0u};
+                }
+        }
         // byte offsets of the wave's rows under every offset (absent / past the end: out of range -> zeros)
-        unsigned off[WK][S];
-#pragma unroll
-        for (int o = 0; o < WK; ++o)
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int t = row0 + s * 16 + i;
-                const unsigned voff = t < n_out ? ((unsigned)o * (unsigned)ld + (unsigned)t) * 4u : OOB;
-                off[o][s] = __builtin_amdgcn_raw_buffer_load_b32(rs_t, voff, 0, 0);
-            }
+        if (tile != (int)blockIdx.x) load_table(tile);
 #pragma unroll
         for (int o = 0; o < WK; ++o)
 #pragma unroll
@@ -178,7 +211,7 @@ __global__ __launch_bounds__(512) void conv_wlds48(const unsigned short *__restr
         }
 #pragma unroll
         for (int nb = 0; nb < WNB; ++nb)
-            wlds_epilogue<S, STATS>(acc[nb], row0, i, g, wid, nb, n_out, rs_y, res, y_bytes, ep, tile, sred);
+            wlds_epilogue<S, STATS>(acc[nb], pre_res[nb], pre_bnx[nb], row0, i, g, wid, nb, n_out, rs_y, res, ep, tile, sred, bnv);
     }
 }
 
