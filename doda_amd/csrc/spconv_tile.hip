@@ -40,7 +40,7 @@ namespace {
 //            streamed weight fragment (L1-resident).
 // Vector-memory instructions per wave and tile (16 channels): 8 rows + 2 list + 3 strip + 14 weights + 4 epilogue
 // operands + 4 stores = 35 against 96 per 64 rows.  A tile whose neighbourhood exceeds the kernel's capacity (1023 rows of 32
-// bytes — 10-bit local indices —, 960 of 64 bytes; a few percent / 17 % of the tiles of a 1 cm scene, none at 2 cm) takes
+// bytes — 10-bit local indices —, 960 of 64 bytes: 0.2 % of the level-1 tiles of a 2 cm scene, most of a 1 cm scene's — such batches keep plain tables at that level) takes
 // the same loop with the operands gathered from global memory through the dense table.
 // Same arithmetic as conv_fast up to the order in which offsets are paired (fixed (2u, 2u+1) here, pairs of
 // ACTIVE offsets there): fp32 accumulation, one bf16 rounding at the store.
