@@ -436,8 +436,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # the issuing threads next to the GPU (2-socket host: 6.2 ms per step pinned to the GPU's NUMA node, 6.5-7.5 unpinned)
-    from doda_amd.host import pin_to_device_numa
+    from doda_amd.host import pin_to_device_numa, raise_issue_priority
     pinned = pin_to_device_numa(local_rank)
+    prio = raise_issue_priority()
 
     from doda_amd.build import build_native
     from doda_amd import _lib
@@ -548,6 +549,7 @@ def main():
                        "points_per_gpu": n_local, "pairs_per_voxel_subm1": round(ppv, 2),
                        "parallelism": "dp%d" % world, "n_classes": 20, "final_loss": final_loss,
                        "host_pinning": ("NUMA node %d (%d CPUs)" % (pinned["node"], pinned["cpus"])) if pinned else "none",
+                       "host_priority": prio or "unchanged",
                        "grad_sync": "deferred multi-layer wgrad + bucketed all-reduce" if deferred else "torch DDP",
                        "collectives": ("none (single process)" if not dist.is_initialized() else
                                        "%s (forced, 1 rank)" % dist.get_backend() if world == 1 else

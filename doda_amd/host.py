@@ -66,3 +66,23 @@ def pin_to_device_numa(device_index=0):
         return {"node": node, "cpus": len(target)}
     except (OSError, ValueError):
         return None
+
+
+def raise_issue_priority():
+    """Scheduling priority of the calling (kernel-issuing) thread.  A training step here is ~500 dependent launches whose issue
+    takes 4-5 ms of host time against ~5.5 ms of GPU time: on a host shared with other jobs every preemption of the issuing
+    thread is GPU idle time.  DODA_HOST_PRIO = "fifo" (SCHED_FIFO 10, needs CAP_SYS_NICE), "nice" (nice -15), "0"/"off" (nothing);
+    default: try nice.  Returns what was applied (a string) or None."""
+    mode = os.environ.get("DODA_HOST_PRIO", "nice").lower()
+    if mode in ("0", "off", "none", ""):
+        return None
+    try:
+        if mode == "fifo" and hasattr(os, "sched_setscheduler"):
+            os.sched_setscheduler(0, os.SCHED_FIFO, os.sched_param(10))
+            return "SCHED_FIFO 10"
+        cur = os.getpriority(os.PRIO_PROCESS, 0)
+        if cur > -15:
+            os.setpriority(os.PRIO_PROCESS, 0, -15)
+        return "nice %d" % os.getpriority(os.PRIO_PROCESS, 0)
+    except (OSError, PermissionError, AttributeError):
+        return None
