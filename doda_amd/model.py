@@ -418,13 +418,18 @@ _PYR_STREAMS = {}
 F32_TILES = _os.environ.get("DODA_F32_TILES", "0") == "1"
 
 
+# bf16 levels with a tilebook (DODA_TILE_LEVELS).  Levels 1-2 use it for the gathers AND the weight gradient; a level-3 tilebook
+# (48 channels: no tile gather kernel) would serve the weight gradient only.
+BF16_TILE_LEVELS = int(_os.environ.get("DODA_TILE_LEVELS", "2"))
+
+
 def tile_levels_for(dtype):
     """Levels whose SubM rulebook gets a tilebook: the two finest for bf16 (rows of 32 / 64 bytes).  The tile kernel also
     takes fp32 16-channel rows (DODA_F32_TILES=1: level 1), but fp32 layers are bound by the fp32 matrix rate, 1/16 of
     bf16: measured in round 4 the fp32 step takes 12.2 ms with the tilebook against 11.9 ms on the dense-table kernels
     (conv_tile MODE 2 96 us against conv_fast 97 us per level-1 layer, and the tilebook build on top): off by default."""
     if dtype == torch.bfloat16:
-        return 2
+        return BF16_TILE_LEVELS
     return 1 if (dtype == torch.float32 and F32_TILES) else 0
 
 
