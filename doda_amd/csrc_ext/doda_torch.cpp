@@ -1136,6 +1136,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               TORCH_CHECK(hipStreamWaitEvent((hipStream_t)stream, g_ev_early, 0) == hipSuccess, "doda: hipStreamWaitEvent");
               return true;
           }, "make `stream` wait for the wide layers' weight gradients of the last flush; false if there was no split flush");
+    m.def("clear_grads", [](const std::vector<at::Tensor> &params) {   // optimizer.zero_grad(set_to_none=True) in one call
+              for (const at::Tensor &p : params)
+                  if (p.defined() && p.grad().defined()) const_cast<at::Tensor &>(p).mutable_grad().reset();
+          }, "set .grad of every listed parameter to None (203 Python attribute stores per step otherwise)");
     m.def("sgd_step", &sgd_step, "torch.optim.SGD's update of all parameters in one launch",
           py::call_guard<py::gil_scoped_release>());
     m.def("abi_version", []() { return doda_abi_version(); });

@@ -29,6 +29,14 @@ class FusedSGD(torch.optim.SGD):
         super().add_param_group(param_group)
         self._doda_lists = {}
 
+    def zero_grad(self, set_to_none=True):
+        """torch's zero_grad(set_to_none=True) walks the parameters in Python (0.2 ms per step for the U-Net's 203); one
+        extension call does the same stores.  set_to_none=False (in-place zeroing) is torch's."""
+        if not set_to_none or _ext is None or not hasattr(_ext, "clear_grads"):
+            return super().zero_grad(set_to_none=set_to_none)
+        for group in self.param_groups:
+            _ext.clear_grads(group["params"])
+
     def _slow_lists(self, group):
         """(params, grads, buffers, first flags) of the parameters that have a gradient; creates the missing
         momentum buffers (torch: clone of the first gradient — here the kernel writes it, first flag set)."""
