@@ -22,6 +22,26 @@
 #include <vector>
 
 #include "../../include/doda_hip.h"
+#include <chrono>
+#include <cstdlib>
+
+// Host-side time of the extension's own entry points (DODA_HOST_TIMING=1; tools/hostcount.py prints it): where the issuing
+// thread spends a step — the step sits at the host / GPU crossover.
+namespace host_timing {
+struct Slot { const char *name; long long ns = 0, calls = 0; };
+static Slot g_slots[] = {{"residual_block"}, {"conv_backward"}, {"bn_backward"}, {"flush_wgrads"}, {"wgrad_multi (library)"}};
+static const bool g_on = getenv("DODA_HOST_TIMING") && getenv("DODA_HOST_TIMING")[0] == '1';
+struct Scope {
+    int k;
+    std::chrono::steady_clock::time_point t0;
+    explicit Scope(int k_) : k(k_) { if (g_on) t0 = std::chrono::steady_clock::now(); }
+    ~Scope() {
+        if (!g_on) return;
+        g_slots[k].ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        g_slots[k].calls += 1;
+    }
+};
+}  // namespace host_timing
 
 namespace {
 
@@ -396,6 +416,27 @@ struct PendingWgrad {
 std::mutex g_wq_mu;
 std::vector<PendingWgrad> g_wq;
 bool g_wq_callback = false, g_defer_wgrad = false;
+// (set_direct_grads, with set_defer_wgrad) parameter gradients of the extension's own nodes are written to .grad by the
+// nodes themselves — conv weights by the deferred launch, BatchNorm gamma / beta by the BatchNorm backward — and the nodes keep
+// NO autograd edge to those leaves: the engine then has 203 AccumulateGrad nodes less to schedule per U-Net step (~0.5 ms of
+// the issuing thread, which paces the step as much as the GPU does).  Same contract as the deferred weight gradient: no
+// AccumulateGrad hooks for these parameters, torch.autograd.grad(..., params) does not see them.
+bool g_direct_grads = false;
+
+inline bool direct_leaf(const at::Tensor &p) {
+    return g_direct_grads && g_defer_wgrad && p.defined() && p.requires_grad() && p.is_leaf() &&
+           p.scalar_type() == at::kFloat && p.is_contiguous();
+}
+// what AccumulateGrad does for a fresh, contiguous gradient: bind it, or add to an existing one
+inline void deposit_grad(const at::Tensor &param, const at::Tensor &g) {
+    at::Tensor &slot = const_cast<at::Tensor &>(param).mutable_grad();
+    if (!slot.defined()) {
+        slot = g.sizes() == param.sizes() ? g : g.reshape(param.sizes());
+    } else {
+        at::NoGradGuard no_grad;
+        slot.add_(g.reshape(slot.sizes()));
+    }
+}
 int g_wq_task = -2;
 c10::optional<c10::hip::HIPStream> g_wq_stream;
 
@@ -442,8 +483,11 @@ void issue_wgrads(std::vector<PendingWgrad> &q, const c10::hip::HIPStream &st) {
     const size_t wsb = doda_spconv_wgrad_multi_workspace_bytes(jobs.data(), (int32_t)jobs.size());
     const size_t dsb = doda_spconv_wgrad_multi_desc_bytes((int32_t)jobs.size());
     at::Tensor ws = at::empty({(int64_t)wsb}, opt), desc = at::empty({(int64_t)dsb}, opt);
-    check(doda_spconv_wgrad_multi(jobs.data(), (int32_t)jobs.size(), ws.data_ptr(), wsb, desc.data_ptr(), dsb,
-                                  (void *)st.stream()), "doda_spconv_wgrad_multi");
+    {
+        host_timing::Scope lib_scope(4);
+        check(doda_spconv_wgrad_multi(jobs.data(), (int32_t)jobs.size(), ws.data_ptr(), wsb, desc.data_ptr(), dsb,
+                                      (void *)st.stream()), "doda_spconv_wgrad_multi");
+    }
     for (size_t k = 0; k < q.size(); ++k)
         if (fresh[k].defined()) q[k].weight.mutable_grad() = fresh[k];
 }
@@ -477,6 +521,7 @@ inline bool narrow_weight(const at::Tensor &w) {   // [kD, kH, kW, Cin, Cout]
 }
 
 void flush_wgrads() {
+    host_timing::Scope host_scope(3);
     std::vector<PendingWgrad> q;
     c10::optional<c10::hip::HIPStream> st;
     {
@@ -574,8 +619,10 @@ struct ConvNode : public torch::autograd::Node {
     PairLists pl;
     std::shared_ptr<BNLink> bn;   // the BatchNorm in front of this conv, if linked
     int64_t n_out = 0, bwd_layout = 0;
+    bool direct_w = false;   // no edge to the weight: its gradient is deposited here (set_direct_grads)
 
     variable_list apply(variable_list &&grads) override {
+        host_timing::Scope host_scope(1);
         const at::Tensor features = features_.unpack(), weight = weight_.unpack();
         const int64_t cin = weight.size(-2), cout = weight.size(-1), K = fwd_tbl.size(0);
         variable_list out(3);
@@ -598,7 +645,10 @@ struct ConvNode : public torch::autograd::Node {
                 bn->dz_version = out[0]._version();
             }
         }
-        if (task_should_compute_output(1) && !try_defer_wgrad(features, dy, fwd_tbl, n_out, weight, pl))
+        if (direct_w) {
+            if (!try_defer_wgrad(features, dy, fwd_tbl, n_out, weight, pl))
+                deposit_grad(weight, wgrad(features, dy, fwd_tbl, n_out, pl).reshape(weight.sizes()).to(weight.scalar_type()));
+        } else if (task_should_compute_output(1) && !try_defer_wgrad(features, dy, fwd_tbl, n_out, weight, pl))
             out[1] = wgrad(features, dy, fwd_tbl, n_out, pl).reshape(weight.sizes()).to(weight.scalar_type());
         if (task_should_compute_output(2)) out[2] = grads[0];
         return out;
@@ -645,7 +695,14 @@ std::vector<at::Tensor> indice_conv_impl(const at::Tensor &features, const at::T
     if (need_grad) {
         auto node = std::shared_ptr<ConvNode>(new ConvNode(), torch::autograd::deleteNode);
         node->bn = link;
-        node->set_next_edges(torch::autograd::collect_next_edges(features, weight, res));
+        {
+            torch::autograd::edge_list edges = torch::autograd::collect_next_edges(features, weight, res);
+            if (direct_leaf(weight)) {
+                edges[1] = torch::autograd::Edge();
+                node->direct_w = true;
+            }
+            node->set_next_edges(std::move(edges));
+        }
         node->features_ = SavedVariable(features, false);
         node->weight_ = SavedVariable(weight, false);
         node->fwd_tbl = fwd_tbl;
@@ -707,8 +764,10 @@ struct BNNode : public torch::autograd::Node {
     at::Tensor mean, invstd;
     std::shared_ptr<BNLink> link;   // statistics may arrive from the consuming conv's data-grad epilogue
     bool training = true, relu = false;
+    bool direct_p = false;   // no edges to gamma / beta: their gradients are deposited here (set_direct_grads)
 
     variable_list apply(variable_list &&grads) override {
+        host_timing::Scope host_scope(2);
         const at::Tensor x = x_.unpack(), weight = weight_.unpack(), bias = bias_.unpack();
         variable_list out(3);
         at::Tensor extra;   // gradient of the pass-through alias
@@ -793,8 +852,13 @@ struct BNNode : public torch::autograd::Node {
         }
         if (extra.defined()) dx = dx + extra;
         if (task_should_compute_output(0)) out[0] = dx;
-        if (task_should_compute_output(1)) out[1] = dg.scalar_type() == weight.scalar_type() ? dg : dg.to(weight.scalar_type());
-        if (task_should_compute_output(2)) out[2] = db.scalar_type() == bias.scalar_type() ? db : db.to(bias.scalar_type());
+        if (direct_p) {
+            deposit_grad(weight, dg);
+            deposit_grad(bias, db);
+        } else {
+            if (task_should_compute_output(1)) out[1] = dg.scalar_type() == weight.scalar_type() ? dg : dg.to(weight.scalar_type());
+            if (task_should_compute_output(2)) out[2] = db.scalar_type() == bias.scalar_type() ? db : db.to(bias.scalar_type());
+        }
         return out;
     }
     void release_variables() override {
@@ -885,7 +949,15 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
             node->link = link;
             g_last_bn = link;
         }
-        node->set_next_edges(torch::autograd::collect_next_edges(x_in, weight, bias));
+        {
+            torch::autograd::edge_list edges = torch::autograd::collect_next_edges(x_in, weight, bias);
+            if (training && direct_leaf(weight) && direct_leaf(bias)) {
+                edges[1] = torch::autograd::Edge();
+                edges[2] = torch::autograd::Edge();
+                node->direct_p = true;
+            }
+            node->set_next_edges(std::move(edges));
+        }
         node->x_ = SavedVariable(x_in.is_contiguous() ? x_in : x, false);
         node->weight_ = SavedVariable(weight, false);
         node->bias_ = SavedVariable(bias, false);
@@ -937,6 +1009,7 @@ std::vector<at::Tensor> residual_block(const at::Tensor &x, const c10::optional<
                                        const c10::optional<at::Tensor> &skip, bool want_stats,
                                        const std::vector<c10::optional<at::Tensor>> &sc = {},
                                        const c10::optional<at::Tensor> &stats_in_b = c10::nullopt) {
+    host_timing::Scope host_scope(0);
     TORCH_CHECK(bn1.size() == 5 && bn2.size() == 5 && cv1.size() == 3 && cv2.size() == 3 && rb.size() == 5 &&
                 cv1[0].has_value() && cv2[0].has_value() && rb[0].has_value(), "doda residual_block: bad argument lists");
     // sc = {weight [1,1,1,Cin,Cout], packed forward, packed data-grad, identity table, identity table as the pair lists or
@@ -1125,6 +1198,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("set_defer_wgrad", [](bool on) { g_defer_wgrad = on; },
           "queue conv weight gradients during backward and issue them in one multi-layer call at its end");
     m.def("get_defer_wgrad", []() { return g_defer_wgrad; });
+    m.def("set_direct_grads", [](bool on) { g_direct_grads = on; },
+          "with set_defer_wgrad: the extension's nodes write parameter gradients to .grad themselves and keep no autograd edge to "
+          "the parameters (no AccumulateGrad nodes for them)");
+    m.def("get_direct_grads", []() { return g_direct_grads; });
     m.def("flush_wgrads", &flush_wgrads);
     m.def("set_grad_home", &set_grad_home, "view of a flat gradient bucket that receives the parameter's gradient in place (None: forget)");
     m.def("clear_grad_homes", &clear_grad_homes);
@@ -1136,6 +1213,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               TORCH_CHECK(hipStreamWaitEvent((hipStream_t)stream, g_ev_early, 0) == hipSuccess, "doda: hipStreamWaitEvent");
               return true;
           }, "make `stream` wait for the wide layers' weight gradients of the last flush; false if there was no split flush");
+    m.def("host_timing", []() {   // {name: (microseconds, calls)} since the last call; empty unless DODA_HOST_TIMING=1
+              py::dict d;
+              for (auto &sl : host_timing::g_slots) {
+                  d[py::str(sl.name)] = py::make_tuple(sl.ns / 1e3, sl.calls);
+                  sl.ns = 0; sl.calls = 0;
+              }
+              return d;
+          });
     m.def("clear_grads", [](const std::vector<at::Tensor> &params) {   // optimizer.zero_grad(set_to_none=True) in one call
               for (const at::Tensor &p : params)
                   if (p.defined() && p.grad().defined()) const_cast<at::Tensor &>(p).mutable_grad().reset();

@@ -33,12 +33,18 @@ def step():
 
 for _ in range(10): step()
 torch.cuda.synchronize()
+from doda_amd._ext import ext as _e
+if hasattr(_e, "host_timing"): _e.host_timing()        # (reset; DODA_HOST_TIMING=1 fills it)
 s0 = torch.cuda.memory_stats(d)["allocation.all.allocated"]
 n = 20; tf = tb = to = 0.0
 for _ in range(n):
     l, f, b, o = step(); tf += f; tb += b; to += o
 torch.cuda.synchronize()
 s1 = torch.cuda.memory_stats(d)["allocation.all.allocated"]
+if hasattr(_e, "host_timing"):
+    ht = _e.host_timing()
+    if any(v[1] for v in ht.values()):
+        print("extension entry points, host us per step: " + "; ".join("%s %.0f (%d calls)" % (k, v[0] / n, v[1] / n) for k, v in ht.items()))
 print("host per step (re-used pyramid): fwd %.2f ms, bwd %.2f ms, opt %.2f ms; allocator calls per step: %.0f" % (tf / n * 1e3, tb / n * 1e3, to / n * 1e3, (s1 - s0) / n))
 # autograd nodes of one step
 loss = M.cross_entropy(M.voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.bfloat16, inputs_ready=True, pyramid=pyr), bd["labels"])
