@@ -140,15 +140,34 @@ def _subm16_times(idx, shape, nb, dtype, reps):
             k[0] = (k[0] + 1) % n_sets
         return sets[k[0] if cold else 0]
 
+    # prepared calls (ops.GatherCall: one native call per launch, the host cost of the extension's call sites): the Python
+    # wrapper around doda_spconv_gather_ex takes longer than the 9 us kernels of one 150k scene on a busy host
+    calls = {}
+
+    def call(name, st, step):
+        key = (name, id(st), step)
+        c = calls.get(key)
+        if c is None:
+            if name == "fwd":
+                c = ops.GatherCall(st.x, None, st.tbl, m, 0, 16, packed=pk_f, tilebook=st.tb, out=st.y,
+                                   residual=st.res if step else None, want_stats=step)
+            else:
+                c = ops.GatherCall(st.gy, None, st.tbl, m, 2, 16, packed=pk_d, tilebook=st.tb, out=st.y, want_stats=step,
+                                   bn=(st.x, mean, invstd, gamma, beta, True) if step else None)
+            calls[key] = c
+            return
+        c.run()
+
+    for st_ in sets:                      # (every call exists before anything is timed)
+        for name_ in ("fwd", "dgrad"):
+            for step_ in (False, True):
+                call(name_, st_, step_)
+
     def fwd(cold, step):
-        st = nxt(cold)
-        ops.spconv_gather(st.x, None, st.tbl, m, 0, 16, packed=pk_f, tilebook=st.tb, out=st.y,
-                          residual=st.res if step else None, want_stats=step)
+        call("fwd", nxt(cold), step)
 
     def dgrad(cold, step):
-        st = nxt(cold)
-        ops.spconv_gather(st.gy, None, st.tbl, m, 2, 16, packed=pk_d, tilebook=st.tb, out=st.y, want_stats=step,
-                          bn=(st.x, mean, invstd, gamma, beta, True) if step else None)
+        call("dgrad", nxt(cold), step)
 
     n_layers = 8   # the 16 -> 16 block convolutions of level 1 share the rulebook and one multi-layer call
     # (a job carries the rulebook's pair lists AND its tilebook, as the model's deferred queue does; the library picks
@@ -158,15 +177,17 @@ def _subm16_times(idx, shape, nb, dtype, reps):
     def job(st, rb=None):
         rb = st if rb is None else rb      # the set whose rulebook (table, pair lists, tilebook) the layer uses
         return (st.x, st.gy, rb.tbl, m, rb.pairs if use_pairs else None, None, rb.tb if use_wtile else None)
-    jobs_warm = [job(sets[0]) for _ in range(n_layers)]
+    # (prepared calls, ops.WgradPlan: one native call per launch as in the extension's deferred flush — the Python wrapper's
+    # ~10 us per job paced this loop on busy hosts: 10.5 instead of 7.5 us per layer on one 150k scene, bimodal between runs)
+    plan_warm = ops.WgradPlan([job(sets[0]) for _ in range(n_layers)])
     # cold: as in the step, the layers of one call share ONE rulebook (the deferred flush issues a level's layers together)
     # and differ in their operands; consecutive calls take the next rulebook copy, so nothing of a call is cache-resident
-    jobs_cold = [[job(sets[(c + j) % n_sets], sets[c]) for j in range(n_layers)] for c in range(n_sets)]
+    plans_cold = [ops.WgradPlan([job(sets[(c + j) % n_sets], sets[c]) for j in range(n_layers)]) for c in range(n_sets)]
     kc = [0]
 
     def wgrad_cold():
         kc[0] = (kc[0] + 1) % n_sets
-        ops.spconv_wgrad_multi(jobs_cold[kc[0]])
+        plans_cold[kc[0]].run()
     wg_kernel = ("wgrad_tile_f32 (LDS-staged over the tilebook, exact fp32 MFMA)" if (use_wtile and dtype == "f32") else
                  "wgrad_dma16 (LDS-staged over the tilebook)" if use_wtile else
                  "wgrad_pairs_kernel<1,1> (pair lists)" if use_pairs else "wgrad_multi_kernel (gather table)")
@@ -176,7 +197,7 @@ def _subm16_times(idx, shape, nb, dtype, reps):
         for cold in (False, True):
             for step in (False, True):
                 t[(name, cold, step)] = _timed(lambda: fn(cold, step), reps)
-    t_w = {False: _timed(lambda: ops.spconv_wgrad_multi(jobs_warm), max(5, reps // 4), per=n_layers),
+    t_w = {False: _timed(plan_warm.run, max(5, reps // 4), per=n_layers),
            True: _timed(wgrad_cold, max(5, reps // 4), per=n_layers)}
 
     def rec(sec, nbytes):

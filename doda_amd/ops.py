@@ -306,8 +306,21 @@ def tilebook_build(tbl, n_rows=None):
     return tb
 
 
+class GatherCall:
+    """A doda_spconv_gather_ex call prepared once (same arguments as spconv_gather; `out` and, with want_stats, the statistics
+    buffer are created once and overwritten by every run) and launched by `run()` with ONE native call: the host cost of the
+    extension's call sites.  For timing loops over kernels shorter than the Python wrapper (one 150k-voxel scene: 9 us)."""
+
+    def __init__(self, *args, **kwargs):
+        self.result = spconv_gather(*args, _call=self, **kwargs)
+
+    def run(self):
+        check(lib().doda_spconv_gather_ex(*self._args), "doda_spconv_gather_ex")
+        return self.result
+
+
 def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, residual=None, tilebook=None,
-                  want_stats=False, bn=None, out=None, residual_bcast=False):
+                  want_stats=False, bn=None, out=None, residual_bcast=False, _call=None):
     """y[t] = sum_o x[tbl[o][t]] @ B_o (doda_spconv_gather_ex, the one gather entry point of ABI 7).  x: [n_in,kc]
     f32|bf16; w: fp32 weights viewed [K,kc,nc] (layout 0) or [K,nc,kc] (layouts 1,2), or `packed`: the
     fragment-packed buffer produced by PackPlan for this (weight, layout, dtype).  Returns y [n_out, nc] in x.dtype (or
@@ -356,9 +369,12 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
             bx, mean, invstd, gamma, beta, relu = bn
             ep.bn_x, ep.bn_mean, ep.bn_invstd, ep.bn_gamma, ep.bn_beta = _p(bx), _p(mean), _p(invstd), _p(gamma), _p(beta)
             ep.bn_relu = int(bool(relu))
-    check(lib().doda_spconv_gather_ex(_p(x), x.shape[0], kc, esz, w_ptr, nc, _p(tbl), ld, K, n_out, _p(y),
-                                      int(bool(out_f32)), layout, ws_ptr, ws_n, C.byref(ep), _stream()),
-          "doda_spconv_gather_ex")
+    call_args = (_p(x), x.shape[0], kc, esz, w_ptr, nc, _p(tbl), ld, K, n_out, _p(y),
+                 int(bool(out_f32)), layout, ws_ptr, ws_n, C.byref(ep), _stream())
+    check(lib().doda_spconv_gather_ex(*call_args), "doda_spconv_gather_ex")
+    if _call is not None:   # (GatherCall: everything the native call references stays alive with the object)
+        _call._args = call_args
+        _call._keep = (x, w, tbl, y, ep, rows, stats, residual, tilebook, bn, packed, ws if packed is None else None)
     return (y, stats[:rows.value]) if want_stats else y
 
 
@@ -427,7 +443,22 @@ class _WgradJob(C.Structure):   # doda_wgrad_job (include/doda_hip.h, ABI 2)
 WGRAD_ACCUMULATE = 1
 
 
-def spconv_wgrad_multi(jobs):
+class WgradPlan:
+    """A doda_spconv_wgrad_multi call prepared once (job descriptors, output tensors, workspace, descriptor buffer) and launched
+    by `run()` with ONE native call — what the extension's deferred flush costs the host per call.  spconv_wgrad_multi() builds the
+    same call in Python every time (~10 us per job): for timing loops over launches shorter than that (one 150k-voxel scene: 60 us
+    for eight layers) the wrapper, not the GPU, paces the loop on a busy host.  `outputs` = the dw tensors (overwritten by every run)."""
+
+    def __init__(self, jobs):
+        self.outputs = spconv_wgrad_multi(jobs, _plan=self)
+
+    def run(self):
+        check(lib().doda_spconv_wgrad_multi(C.addressof(self._arr), self._n, _p(self._ws), self._ws.numel(), _p(self._desc),
+                                            self._desc.numel(), _stream()), "doda_spconv_wgrad_multi")
+        return self.outputs
+
+
+def spconv_wgrad_multi(jobs, _plan=None):
     """Weight gradients of many layers in one native call (doda_spconv_wgrad_multi).
     jobs: list of (a [*,ca], b [n_rows,cb], tbl int32 [K,ld], n_rows[, pairs[, dw[, tilebook]]]); `tilebook` =
     tilebook_build(tbl) (bf16 16 -> 16, K = 27 jobs then take the LDS-staged kernel); `pairs` = None or
@@ -489,6 +520,8 @@ def spconv_wgrad_multi(jobs):
     desc = torch.empty(l.doda_spconv_wgrad_multi_desc_bytes(len(jobs)), dtype=torch.uint8, device=dev)
     check(l.doda_spconv_wgrad_multi(C.addressof(arr), len(jobs), _p(ws), ws.numel(), _p(desc), desc.numel(),
                                     _stream()), "doda_spconv_wgrad_multi")
+    if _plan is not None:   # (WgradPlan: everything the native call references stays alive with the plan)
+        _plan._arr, _plan._n, _plan._ws, _plan._desc, _plan._keep = arr, len(jobs), ws, desc, (keep, list(jobs))
     return outs
 
 
