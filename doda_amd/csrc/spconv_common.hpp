@@ -65,11 +65,18 @@ bool pipeline_enabled();   // doda_set_option(DODA_OPT_TILE_PIPELINE): conv_tile
 void set_pipeline(bool on);
 bool dual_enabled();       // doda_set_option(DODA_OPT_TILE_DUAL): both channel blocks of a 32-output-channel layer in one pass
 void set_dual(bool on);
+bool up_enabled();         // doda_set_option(DODA_OPT_CONV_UP): conv_up32 for one-source-per-row tables
+void set_up(bool on);
 // conv_tile over `tilebook` (doda_tilebook_build of tbl).  mode 0: bf16 16 channels, 1: bf16 32 channels, 2: fp32 16
 // channels; out32: fp32 output rows.  *n_part (if given) receives the number of statistics rows.
 int launch_conv_tile(int mode, bool out32, const void *x, unsigned x_bytes, const void *wp, unsigned wp_bytes, int nc, int NB,
                      const int32_t *tbl, int ld, int n_out, const void *tilebook, void *y, unsigned y_bytes, const void *res,
                      const EpiArgs &ep, int *n_part, hipStream_t s);
+// conv_up32: bf16, 32 input channels, K <= 8, a table with (about) one source row per output row (inverse convolution forward,
+// strided convolution data gradient); wp = wide-packed fragments [o][nb][64] x 16 B.  *n_part: statistics rows (one per 256 rows).
+int launch_conv_up32(bool out32, const void *x, unsigned x_bytes, const void *wp, unsigned wp_bytes, int nc, int NB, int K,
+                     const int32_t *tbl, int ld, int n_out, void *y, unsigned y_bytes, const void *res, const EpiArgs &ep,
+                     int *n_part, hipStream_t s);
 }  // namespace doda_tile
 
 namespace doda_wlds {

@@ -23,6 +23,7 @@
 //   * fp32: v_mfma_f32_16x16x4_f32 (exact fmaf chain); bf16: v_mfma_f32_16x16x16_bf16, fp32
 //     accumulate, one RNE rounding at the store.
 // Bound: HBM for table + feature bytes; MFMA only for the dense contraction.
+#include <cstdio>
 #include "common.hpp"
 #include "tilebook.hpp"
 #include "spconv_common.hpp"
@@ -862,6 +863,13 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     if (ep.stats && !fast) return DODA_ERR_UNSUPPORTED;   // the statistics ride in the fast kernel's epilogue only
     const int mode = pack_mode(K, kc, (int)sizeof(elem));
     const bool wide = fast && mode == 0x10, pair = fast && mode == 0x20;
+    {   // DODA_TRACE_GATHER=1: one line per call on stderr (which layer shapes reach which kernel: tools/gathermap.py)
+        static const bool trace = getenv("DODA_TRACE_GATHER") && getenv("DODA_TRACE_GATHER")[0] == '1';
+        if (trace)
+            fprintf(stderr, "doda_gather K=%d kc=%d nc=%d n_out=%d n_in=%lld layout=%d esz=%d out32=%d stats=%d bn=%d res=%d tilebook=%d\n",
+                    K, kc, nc, n_out, n_in, wl & 0xff, (int)sizeof(elem), (int)out32, ep.stats ? 1 : 0, ep.bn_x ? 1 : 0,
+                    res ? 1 : 0, tilebook ? 1 : 0);
+    }
     const int n_chunk = wide ? (kc + 31) / 32 : (kc + 15) / 16;
     const size_t need = pair ? (size_t)K * NB * 32 * 16 : (size_t)K * n_chunk * NB * 64 * (wide ? 16 : sizeof(frag));
     const void *wp;
@@ -880,6 +888,16 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
                                nc, n_chunk, NB, wl & 3, (frag *)ws);
     }
     if (ep.res_bcast && !fast) return DODA_ERR_UNSUPPORTED;   // (the broadcast residual lives in conv_fast's epilogue)
+    // K <= 8, 32 input channels, fewer input rows than output rows (the k2 s2 rulebook read from the fine side: one source row
+    // per output row): conv_up32 (spconv_tile.hip).  DODA_CONV_UP=0 / doda_set_option(DODA_OPT_CONV_UP, 0): conv_fast as before.
+    {
+        if (doda_tile::up_enabled() && wide && sizeof(elem) == 2 && kc == 32 && K <= 8 && K > 1 && n_in < (long long)n_out && nc % 16 == 0 &&
+            !ep.res_bcast && doda_tile::enabled()) {
+            const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
+            const unsigned yb = (unsigned)((size_t)n_out * nc * (out32 ? 4 : sizeof(elem)));
+            return doda_tile::launch_conv_up32(out32, x_, xb, wp, (unsigned)need, nc, NB, K, tbl, ld, n_out, y_, yb, res, ep, n_part, s);
+        }
+    }
     // A tilebook of this table and rows of 32 / 64 bytes: the LDS-staged tile kernel (spconv_tile.hip)
     if (!ep.res_bcast) {
         // (fp32 rows: the tile kernel's fp32 mode is bound by the fp32 matrix rate like the dense-table kernel and measured
@@ -1027,6 +1045,7 @@ extern "C" int doda_set_option(int32_t option, int32_t value) {
     case DODA_OPT_WDMA_KERNEL: doda_wdma::set_enabled(value != 0); return DODA_OK;
     case DODA_OPT_TILE_PIPELINE: doda_tile::set_pipeline(value != 0); return DODA_OK;
     case DODA_OPT_TILE_DUAL: doda_tile::set_dual(value != 0); return DODA_OK;
+    case DODA_OPT_CONV_UP: doda_tile::set_up(value != 0); return DODA_OK;
     default: return DODA_ERR_INVALID;
     }
 }
@@ -1037,6 +1056,7 @@ extern "C" int32_t doda_get_option(int32_t option) {
     case DODA_OPT_WDMA_KERNEL: return doda_wdma::enabled() ? 1 : 0;
     case DODA_OPT_TILE_PIPELINE: return doda_tile::pipeline_enabled() ? 1 : 0;
     case DODA_OPT_TILE_DUAL: return doda_tile::dual_enabled() ? 1 : 0;
+    case DODA_OPT_CONV_UP: return doda_tile::up_enabled() ? 1 : 0;
     default: return -1;
     }
 }

@@ -709,11 +709,93 @@ __global__ __launch_bounds__(256, 2) void conv_tile16(const void *__restrict__ x
     if constexpr (STATS) stats_flush(lst, i, g, wid, 0, nc, ep.stats + (long long)blockIdx.x * 2 * nc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_up32 (round 4): gathers whose table has (about) ONE source row per output row — the inverse convolution's forward
+// (reference model/unet_block.py:78: a fine voxel reads its coarse parent through the k2 s2 rulebook, roles swapped) and the
+// data gradient of the strided convolution (unet_block.py:70), 32 input channels.  conv_fast walks the K = 8 table offset by
+// offset: eight table loads and eight gathers per row, seven of them out of range — 52 us for the level-2 -> level-1 layer whose
+// bytes (48 MB) take 8 us.  Here lane l reads the eight table entries of row l once, the wave exchanges the (source row, offset)
+// codes through the LDS crossbar (ds_bpermute), every row's 64 bytes are gathered ONCE, and the eight weight matrices are applied
+// as eight MFMA passes whose operand is the row or zero (v_cndmask): matrix work nobody waits for.  Correct for ANY table: a row
+// with several sources takes one more pass per extra source (the dispatcher only sends tables with n_in < n_out here).
+// Epilogue = the tile kernels' (residual, fp32 output, BatchNorm statistics, one partial row per workgroup = per 256 rows).
+template <bool OUT32, bool STATS>
+__global__ __launch_bounds__(256) void conv_up32(const void *__restrict__ x, unsigned x_bytes, const void *__restrict__ wp,
+                                                 unsigned wp_bytes, int nc, int NB, int K, const int32_t *__restrict__ tbl, int ld,
+                                                 int n_out, void *__restrict__ y, unsigned y_bytes, const void *__restrict__ res,
+                                                 const EpiArgs ep) {
+    constexpr int S = 4, KMAX = 8;
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, wp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void *)tbl, 0, (unsigned)K * (unsigned)ld * 4u, 0x00020000);
+    const int row0 = (int)blockIdx.x * TB_T + wid * 64;
+    // the eight table entries of row (row0 + lane): -1 = no source under that offset
+    int te[KMAX];
+    {
+        const unsigned r = (unsigned)(row0 + lane);
+#pragma unroll
+        for (int o = 0; o < KMAX; ++o) {
+            const bool ok = o < K && r < (unsigned)n_out;
+            const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_t, ok ? ((unsigned)o * (unsigned)ld + r) * 4u : OOB, 0, 0);
+            te[o] = ok ? v : -1;
+        }
+    }
+    float *stats_row = STATS ? ep.stats + (long long)blockIdx.x * 2 * nc : nullptr;
+    for (int nb0 = 0; nb0 < NB; ++nb0) {
+        EpiPre<OUT32> pre;
+        epi_prefetch<S, OUT32, STATS>(pre, row0, i, g, nb0, nc, n_out, y_bytes, res, ep);
+        u32x4 wr[KMAX];   // the block's weight matrices ([o][nb][64 lanes] x 16 B)
+#pragma unroll
+        for (int o = 0; o < KMAX; ++o)
+            wr[o] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, o < K ? ((unsigned)(o * NB + nb0) * 64u + (unsigned)lane) * 16u : OOB, 0, 0);
+        f32x4 acc[S][1];
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < KMAX; ++j) {
+            // the j-th source of the lane's row as (row << 3 | offset), or -1
+            int code = -1, seen = 0;
+#pragma unroll
+            for (int o = 0; o < KMAX; ++o) {
+                const bool v = te[o] >= 0;
+                code = (v && seen == j) ? ((te[o] << 3) | o) : code;
+                seen += v ? 1 : 0;
+            }
+            if (__builtin_amdgcn_ballot_w64(code >= 0) == 0ull) break;   // (wave-uniform)
+            int cs[S];
+            u32x4 xr[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                cs[s] = __builtin_amdgcn_ds_bpermute((s * 16 + i) * 4, code);
+                xr[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, cs[s] >= 0 ? (unsigned)(cs[s] >> 3) * 64u + (unsigned)g * 16u : OOB, 0, 0);
+            }
+#pragma unroll
+            for (int o = 0; o < KMAX; ++o) {
+                if (__builtin_amdgcn_ballot_w64(code >= 0 && (code & 7) == o) == 0ull) continue;   // no row of the wave under this offset
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const bool mine = cs[s] >= 0 && (cs[s] & 7) == o;
+                    u32x4 b;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[q] = mine ? xr[s][q] : 0u;
+                    mma_bf16_k32(acc[s][0], wr[o], b);
+                }
+            }
+        }
+        f32x4 lst[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst);
+        if constexpr (STATS) stats_flush(lst, i, g, wid, nb0, nc, stats_row);
+    }
+}
+
 constexpr int BT_MAX_GROUPS = 768;   // 3 workgroups per CU x 256 CUs
 // (A/B switches: DODA_TILE_DUAL=0 / doda_set_option(DODA_OPT_TILE_DUAL, 0) keeps the 32-output-channel layers on one channel block
 // per pass; doda_set_option(DODA_OPT_TILE_PIPELINE, 0) keeps the 16 -> 16 layers on conv_tile)
 bool g_dual = !(getenv("DODA_TILE_DUAL") && getenv("DODA_TILE_DUAL")[0] == '0');
 bool g_pipeline = true;
+bool g_up = !(getenv("DODA_CONV_UP") && getenv("DODA_CONV_UP")[0] == '0');
 bool dual_blocks() { return g_dual; }
 constexpr int T16_MAX_GROUPS = 512;  // conv_tile16: 2 workgroups per CU
 // conv_tile16 pays off from the point where conv_tile's workgroups run more than one tile each (a single tile per
@@ -737,6 +819,21 @@ bool doda_tile::pipeline_enabled() { return g_pipeline; }
 void doda_tile::set_pipeline(bool on) { g_pipeline = on; }
 bool doda_tile::dual_enabled() { return g_dual; }
 void doda_tile::set_dual(bool on) { g_dual = on; }
+bool doda_tile::up_enabled() { return g_up; }
+void doda_tile::set_up(bool on) { g_up = on; }
+
+int doda_tile::launch_conv_up32(bool out32, const void *x, unsigned xb, const void *wp, unsigned wpb, int nc, int NB, int K,
+                                const int32_t *tbl, int ld, int n_out, void *y, unsigned yb, const void *res, const EpiArgs &ep,
+                                int *n_part, hipStream_t s) {
+    const int groups = (n_out + TB_T - 1) / TB_T;
+    if (n_part) *n_part = groups;
+    const dim3 grid(groups), block(256);
+#define GU(O32, ST) hipLaunchKernelGGL((conv_up32<O32, ST>), grid, block, 0, s, x, xb, wp, wpb, nc, NB, K, tbl, ld, n_out, y, yb, res, ep)
+    if (out32) { if (ep.stats) GU(true, true); else GU(true, false); }
+    else { if (ep.stats) GU(false, true); else GU(false, false); }
+#undef GU
+    return doda_check_launch();
+}
 
 int doda_tile::launch_conv_tile(int mode, bool out32, const void *x, unsigned xb, const void *wp, unsigned wpb, int nc, int NB,
                                 const int32_t *tbl, int ld, int n_out, const void *tilebook, void *y, unsigned yb,

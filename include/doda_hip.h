@@ -272,6 +272,9 @@ int doda_tilebook_build(const int32_t *tbl, int32_t ld, int32_t K, int32_t n_row
                                   * DODA_TILE16_MIN_TILES — take the cross-tile pipelined conv_tile16; results are bit-identical) */
 #define DODA_OPT_TILE_DUAL 5     /* 0: 32-output-channel tile layers take one channel block per pass over the units (default 1:
                                   * both in one pass; results are bit-identical) */
+#define DODA_OPT_CONV_UP 6       /* 0: K <= 8 gathers with 32 input channels and fewer input than output rows (inverse convolution
+                                  * forward, strided convolution data gradient) stay on the offset-by-offset kernel (default 1:
+                                  * conv_up32, one gather per output row) */
 int doda_set_option(int32_t option, int32_t value);
 int32_t doda_get_option(int32_t option);
 size_t doda_spconv_stats_capacity(int32_t n_out);

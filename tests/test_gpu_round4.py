@@ -395,3 +395,52 @@ def test_pipelined_tile_kernel_at_the_edges_of_its_schedule(native_lib, oracle, 
     xr = torch.cat([x.double(), torch.zeros(1, 16, dtype=torch.float64, device=d)])[nb.clamp(min=-1)]   # -1 -> the zero row
     want = torch.einsum("orc,ock->rk", xr, w.bfloat16().double())
     assert rel_err(got[1][2][rows].cpu(), want.cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("layout,nc", [(0, 16), (1, 16), (0, 32)])
+def test_conv_up32_one_gather_per_output_row(native_lib, oracle, layout, nc):
+    """conv_up32 (K = 8 tables read from the fine side: inverse convolution forward, strided convolution data gradient; 32
+    input channels): against conv_fast (DODA_OPT_CONV_UP off) bit for bit — a row has one source, so both kernels form the
+    same single MFMA product per row and add zeros otherwise — plain, fp32 output, and with residual + statistics; against
+    the fp64 definition on sampled rows; and, on a synthetic table whose rows have 0..8 sources (the extra passes of the
+    kernel), against conv_fast within the fp32 summation order."""
+    from doda_amd import ops
+    from doda_amd._lib import lib
+    d = dev()
+    idx, shape, batch, pairs, pn = _big_scene(oracle)
+    n = idx.shape[0]
+    _, child, par_off, _ = ops.rulebook_down2(torch.from_numpy(idx).to(d), shape, batch)
+    m_c = child.shape[1]
+    assert m_c < n and par_off.shape == (8, n)
+    g = torch.Generator().manual_seed(31 + layout + nc)
+    xc = torch.randn(m_c, 32, generator=g).bfloat16().to(d)
+    res = torch.randn(n, nc, generator=g).bfloat16().to(d)
+    w = (torch.randn(8, 32, nc, generator=g) * 0.1) if layout == 0 else (torch.randn(8, nc, 32, generator=g) * 0.1)
+    w = w.to(d)
+    # a table with several sources per row: every entry kept with probability 1/2 of a random table into the coarse rows
+    multi = torch.randint(0, m_c, (8, n), generator=g, dtype=torch.int32)
+    multi[torch.rand(8, n, generator=g) < 0.5] = -1
+    multi = multi.to(d)
+    got = {}
+    try:
+        for on in (1, 0):
+            assert lib().doda_set_option(6, on) == 0
+            y = ops.spconv_gather(xc, w, par_off, n, layout, nc)
+            y32 = ops.spconv_gather(xc, w, par_off, n, layout, nc, out_f32=True)
+            yr, st = ops.spconv_gather(xc, w, par_off, n, layout, nc, residual=res, want_stats=True)
+            ym = ops.spconv_gather(xc, w, multi, n, layout, nc, out_f32=True)
+            got[on] = (y, y32, yr, st.double().sum(0).cpu(), ym, st.shape[0])
+    finally:
+        lib().doda_set_option(6, 1)
+    assert got[1][5] == (n + 255) // 256
+    assert torch.equal(got[1][0], got[0][0]) and torch.equal(got[1][1], got[0][1]) and torch.equal(got[1][2], got[0][2])
+    assert rel_err(got[1][3], got[0][3]) < 1e-6
+    assert rel_err(got[1][4].cpu(), got[0][4].cpu()) < 1e-5
+    # fp64 definition on sampled rows (single-source table and the multi-source one)
+    rows = torch.cat([torch.arange(0, 512), torch.arange(n - 300, n), torch.randint(0, n, (600,), generator=g)]).to(d)
+    wd = w.bfloat16().double() if layout == 0 else w.bfloat16().double().transpose(1, 2)      # [8, 32, nc]
+    xz = torch.cat([xc.double(), torch.zeros(1, 32, dtype=torch.float64, device=d)])
+    for tbl_k, out in ((par_off, got[1][1]), (multi, got[1][4])):
+        nb = tbl_k[:, rows].long()
+        want = torch.einsum("orc,ock->rk", xz[nb], wd)
+        assert rel_err(out[rows].cpu(), want.cpu()) < 1e-4
