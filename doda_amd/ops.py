@@ -309,7 +309,8 @@ def tilebook_build(tbl, n_rows=None):
 class GatherCall:
     """A doda_spconv_gather_ex call prepared once (same arguments as spconv_gather; `out` and, with want_stats, the statistics
     buffer are created once and overwritten by every run) and launched by `run()` with ONE native call: the host cost of the
-    extension's call sites.  For timing loops over kernels shorter than the Python wrapper (one 150k-voxel scene: 9 us)."""
+    extension's call sites.  For timing loops over kernels shorter than the Python wrapper (one 150k-voxel scene: 9 us).
+    The call is bound to the stream that was current when the object was made and to the tensors it was made with."""
 
     def __init__(self, *args, **kwargs):
         self.result = spconv_gather(*args, _call=self, **kwargs)
@@ -447,7 +448,8 @@ class WgradPlan:
     """A doda_spconv_wgrad_multi call prepared once (job descriptors, output tensors, workspace, descriptor buffer) and launched
     by `run()` with ONE native call — what the extension's deferred flush costs the host per call.  spconv_wgrad_multi() builds the
     same call in Python every time (~10 us per job): for timing loops over launches shorter than that (one 150k-voxel scene: 60 us
-    for eight layers) the wrapper, not the GPU, paces the loop on a busy host.  `outputs` = the dw tensors (overwritten by every run)."""
+    for eight layers) the wrapper, not the GPU, paces the loop on a busy host.  `outputs` = the dw tensors (overwritten by every run).
+    Launches on torch's current stream at run() time; workspace and descriptor buffer belong to the plan (runs must be stream-ordered)."""
 
     def __init__(self, jobs):
         self.outputs = spconv_wgrad_multi(jobs, _plan=self)
