@@ -19,8 +19,12 @@ import torch
 from torch import nn
 from torch.autograd import Function
 
+from torch.nn.modules import module as _torch_module
+
 from . import ops as _ops
 from . import pointgroup_ops, spconv
+from .spconv import conv as _cv
+from .spconv import functional as Fsp
 from .spconv.modules import SparseModule
 
 
@@ -91,7 +95,6 @@ class ResidualBlock(SparseModule):
     def _plan(self):
         """The block's static operands for ext.residual_block — (generation, bn1 list, bn2 list, bn1, bn2, conv1, conv2, the six modules) —
         or False when the block is not the plain [BN, ReLU, SubM3, BN, ReLU, SubM3] of the reference."""
-        from .spconv import conv as _cv
         plan = self.__dict__.get("_doda_plan")
         if plan is not None and (plan is False or plan[0] == _cv._GEN[0]):
             return plan
@@ -118,7 +121,6 @@ class ResidualBlock(SparseModule):
         """The whole block as ONE extension call (csrc_ext residual_block: the same native ops and autograd nodes the
         module-by-module path issues, without the interpreter between them), or None when any precondition of that
         path does not hold — then the modules run one by one as before."""
-        from .spconv import functional as Fsp
         ext = Fsp._ext
         if ext is None or not Fsp._SERIAL or not hasattr(ext, "residual_block"):
             return None
@@ -127,7 +129,7 @@ class ResidualBlock(SparseModule):
             return None
         _, l1, l2, bn1, bn2, c1, c2, all_mods = plan
         # hooks registered since the plan was made (feature taps, profilers) must fire: module by module then
-        from torch.nn.modules import module as _mod
+        _mod = _torch_module   # (imported at module level: the function-level imports were ~5 us per block and step)
         if (_mod._global_forward_hooks or _mod._global_forward_pre_hooks or _mod._global_backward_hooks
                 or _mod._global_backward_pre_hooks or self.conv_branch._forward_hooks or self.conv_branch._forward_pre_hooks):
             return None
