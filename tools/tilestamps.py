@@ -86,6 +86,7 @@ def main():
         if not l2 and h.doda_get_option(1) and nt >= int(os.environ.get("DODA_TILE16_MIN_TILES", "769")):
             groups = 512                                  # conv_tile16
         st = st[:groups]
+        st = st[st[:, 0, 0] > 0]                          # (workgroups without a tile leave no stamps)
         t0 = st[:, 0, 0].min()
         print("rep %d: m %d tiles %d groups %d  event time %.1f us  stamp span %.1f us  start skew p50 %.2f p99 %.2f us" % (
             r, m, nt, groups, ev[0].elapsed_time(ev[1]) * 1e3, (st[:, :, 5].max() - t0) / 100.0,
