@@ -1,4 +1,4 @@
-import cProfile, pstats, io, os, sys, time
+import cProfile, pstats, io, os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from doda_amd import model as M, spconv

@@ -4,9 +4,8 @@ tile kernels' staging capacities.  usage: ucount.py [target_voxels=150000] [voxe
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from doda_amd import ops, spconv
+from doda_amd import spconv
 from doda_amd.scene import make_batch
-from doda_amd._ext import ext
 tv = int(sys.argv[1]) if len(sys.argv) > 1 else 150000
 vs = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 ns = int(sys.argv[3]) if len(sys.argv) > 3 else 1
