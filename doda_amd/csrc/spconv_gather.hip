@@ -905,8 +905,8 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
         // table carries a tilebook — the fp32 weight gradient uses the tilebook either way)
         static const bool f32_tile = !(getenv("DODA_F32_CONV_TILE") && getenv("DODA_F32_CONV_TILE")[0] == '0');
         const int tmode = pair ? 0 : (wide && kc == 32) ? 1 : (fast && sizeof(elem) == 4 && kc == 16 && f32_tile) ? 2 : -1;
-        // (statistics: the tile kernels' per-lane accumulators hold up to two channel blocks)
-        const bool stats_fit = !ep.stats || NB <= 2;
+        // (statistics: the tile kernels' per-lane accumulators hold up to two channel blocks, the dual-pass 64-byte-row kernel four)
+        const bool stats_fit = !ep.stats || NB <= 2 || (tmode == 1 && NB == 4 && doda_tile::dual_enabled());
         if (tmode >= 0 && tilebook && K == TB_K && tilebook_rows == n_out && doda_tile::enabled() && stats_fit) {
             const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
             const unsigned yb = (unsigned)((size_t)n_out * nc * (out32 ? 4 : sizeof(elem)));

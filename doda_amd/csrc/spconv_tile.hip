@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
                                                  const void *__restrict__ res, const EpiArgs ep) {
     constexpr bool WIDE = MODE != 0;
     static_assert(MODE != 2 || OUT32, "fp32 features have fp32 outputs");
-    static_assert(!DUAL || (MODE == 1 && (MAXNB == 2 || !STATS)), "two channel blocks per pass: bf16, 64-byte rows");
+    static_assert(!DUAL || (MODE == 1 && (MAXNB == 2 || MAXNB == 4 || !STATS)), "two channel blocks per pass: bf16, 64-byte rows");
+    static_assert(MAXNB != 4 || DUAL, "statistics of four channel blocks: two dual passes");
     constexpr int NBA = DUAL ? 2 : 1;                          // channel blocks per pass over the units
     constexpr int S = 4, NU = WIDE ? TB_K : (TB_K + 1) / 2;
     constexpr int RB = WIDE ? 64 : 32;                         // bytes per staged row
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
     // channel blocks with statistics: MAXNB = 1 or 2 (up to 32 output channels: every tilebook layer of the U-Net; the
     // dispatcher sends anything else to the dense-table kernel).  A template parameter: the second block's accumulators
     // cost the 16 -> 16 kernel (MAXNB = 1) registers it needs for its third wave per SIMD
-    static_assert(MAXNB == 1 || MAXNB == 2, "statistics of one or two channel blocks");
+    static_assert(MAXNB == 1 || MAXNB == 2 || MAXNB == 4, "statistics of one, two or (dual passes) four channel blocks");
     f32x4 lst[STATS ? MAXNB : 1][2];
 #pragma unroll
     for (int b = 0; b < (STATS ? MAXNB : 1); ++b) lst[b][0] = lst[b][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -465,8 +466,13 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
                 // the cache), consumed after the first block's epilogue
                 EpiPre<OUT32> pre1;
                 epi_prefetch<S, OUT32, STATS>(pre1, row0, i, g, nb0 + 1, nc, n_out, y_bytes, res, ep);
-                tile_epilogue<S, OUT32, STATS, false, 0, NBA>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[0]);
-                tile_epilogue<S, OUT32, STATS, false, 1, NBA>(acc, pre1, row0, i, g, nb0 + 1, nc, n_out, rs_y, res, ep, lst[STATS ? MAXNB - 1 : 0]);
+                if (MAXNB == 4 && nb0 == 2) {   // (the second dual pass of a 64-output-channel layer: blocks 2 and 3)
+                    tile_epilogue<S, OUT32, STATS, false, 0, NBA>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[STATS && MAXNB == 4 ? 2 : 0]);
+                    tile_epilogue<S, OUT32, STATS, false, 1, NBA>(acc, pre1, row0, i, g, nb0 + 1, nc, n_out, rs_y, res, ep, lst[STATS && MAXNB == 4 ? 3 : 0]);
+                } else {
+                    tile_epilogue<S, OUT32, STATS, false, 0, NBA>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[0]);
+                    tile_epilogue<S, OUT32, STATS, false, 1, NBA>(acc, pre1, row0, i, g, nb0 + 1, nc, n_out, rs_y, res, ep, lst[STATS && MAXNB > 1 ? 1 : 0]);
+                }
             } else {
                 if (nb0 == 0) tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[0]);
                 else tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst[STATS ? MAXNB - 1 : 0]);
@@ -480,7 +486,9 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
         const int lane = tid0 & 63, i = lane & 15, g = lane >> 4;
         float *row = ep.stats + (long long)blockIdx.x * 2 * nc;
         stats_flush(lst[0], i, g, wid, 0, nc, row);
-        if (MAXNB > 1 && NB > 1) stats_flush(lst[MAXNB - 1], i, g, wid, 1, nc, row);
+#pragma unroll
+        for (int b = 1; b < MAXNB; ++b)
+            if (b < NB) stats_flush(lst[b], i, g, wid, b, nc, row);
     }
 }
 
@@ -855,7 +863,7 @@ int doda_tile::launch_conv_tile(int mode, bool out32, const void *x, unsigned xb
     const int max_groups = mode == 0 ? BT_MAX_GROUPS : BT_MAX_GROUPS * 2 / 3;
     if (groups > max_groups) groups = max_groups;
     const dim3 grid(groups), block(256);
-    if (NB > 2 && ep_in.stats) return DODA_ERR_UNSUPPORTED;   // (run_gather does not send such calls here)
+    if (ep_in.stats && NB > 2 && !(mode == 1 && NB == 4 && dual_blocks())) return DODA_ERR_UNSUPPORTED;   // (run_gather does not send such calls here)
     const bool two = NB > 1 && ep_in.stats;                   // statistics of a second channel block
     if (n_part) *n_part = groups;      // one statistics row per persistent workgroup
     const EpiArgs &ep = ep_in;
@@ -876,6 +884,12 @@ int doda_tile::launch_conv_tile(int mode, bool out32, const void *x, unsigned xb
     else if (mode == 1 && NB == 2 && dual_blocks()) {   // 32 output channels: both channel blocks in one pass
         if (out32) { if (ep.stats) GTD(true, true); else GTD(true, false); }
         else { if (ep.stats) GTD(false, true); else GTD(false, false); }
+    }
+    else if (mode == 1 && NB == 4 && dual_blocks()) {   // 64 output channels: two dual passes (the 32 -> 64 data gradient of level 2)
+#define GTQ(O32, ST) hipLaunchKernelGGL((conv_tile<1, O32, ST, 4, true>), grid, block, 0, s, x, xb, wp, wpb, nc, NB, tbl, ld, n_out, tb, y, yb, res, ep)
+        if (out32) { if (ep.stats) GTQ(true, true); else GTD(true, false); }
+        else { if (ep.stats) GTQ(false, true); else GTD(false, false); }
+#undef GTQ
     }
     else if (mode == 1) GM(1);
     else GM(0);

@@ -444,3 +444,37 @@ def test_conv_up32_one_gather_per_output_row(native_lib, oracle, layout, nc):
         nb = tbl_k[:, rows].long()
         want = torch.einsum("orc,ock->rk", xz[nb], wd)
         assert rel_err(out[rows].cpu(), want.cpu()) < 1e-4
+
+
+def test_dual_pass_tile_kernel_with_four_channel_blocks_vs_oracle(native_lib, oracle):
+    """32 -> 64 channels over a tilebook (the data gradient of the level-2 decoder's 64 -> 32 layer has this shape): two dual
+    passes of conv_tile<1, ., ., 4, true>, statistics of four channel blocks per workgroup.  Against the oracle's forward on
+    bf16-representable operands (one bf16 rounding on the output), statistics totals against fp64 column sums of the stored
+    tensor, and against the dense-table kernel (DODA_OPT_TILE_DUAL off sends this shape to conv_fast)."""
+    from doda_amd import ops
+    from doda_amd._lib import lib
+    d = dev()
+    idx, shape, batch, pairs, pn = _big_scene(oracle)
+    n = idx.shape[0]
+    tbl, tb = _hip_rulebook(idx, shape, batch, pairs, pn)
+    g = torch.Generator().manual_seed(3264)
+    x = torch.randn(n, 32, generator=g).bfloat16()
+    w = (torch.randn(3, 3, 3, 32, 64, generator=g) * 0.1).bfloat16().float()
+    res = torch.randn(n, 64, generator=g).bfloat16()
+    ref = oracle.indice_conv(x.double(), w.double(), pairs, pn, n, False, True) + res.double()
+    xd, wd, rd = x.to(d), w.to(d).view(27, 32, 64), res.to(d)
+    got = {}
+    try:
+        for on in (1, 0):
+            assert lib().doda_set_option(5, on) == 0
+            y, st = ops.spconv_gather(xd, wd, tbl, n, 0, 64, tilebook=tb, residual=rd, want_stats=True)
+            got[on] = (y, st.double().sum(0).cpu(), st.shape[0])
+    finally:
+        lib().doda_set_option(5, 1)
+    assert got[1][2] == 512 and got[0][2] > 768          # the tile kernel's one row per workgroup / conv_fast's row per 256 rows
+    tol = 2.0 ** -7 * ref.abs() + 1e-5 * float(ref.abs().max())
+    for on in (1, 0):
+        y = got[on][0]
+        assert bool(((y.float().cpu().double() - ref).abs() <= tol).all()), on
+        yf = y.double().cpu()
+        assert rel_err(got[on][1][0], yf.sum(0)) < 1e-5 and rel_err(got[on][1][1], (yf * yf).sum(0)) < 1e-5, on
