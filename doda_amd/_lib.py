@@ -88,11 +88,14 @@ _SIGNATURES = {
     "doda_ballquery_workspace_bytes": (c_sz, [c_i32]),
     "doda_ballquery_batch_p": (c_i32, [c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                        C.POINTER(c_i32), c_vp, c_sz, c_vp]),
+    "doda_coarse_workgroups": (c_i32, []),
+    "doda_coarse_desc_bytes": (c_sz, [c_i32]),
+    "doda_coarse_run": (c_i32, [c_vp, c_i32, c_vp, c_sz, c_vp, C.c_uint32, C.POINTER(C.c_uint32), c_vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 OPT_TILE_KERNEL, OPT_WLDS_KERNEL, OPT_WDMA_KERNEL, OPT_TILE_PIPELINE, OPT_TILE_DUAL, OPT_CONV_UP = 1, 2, 3, 4, 5, 6   # doda_set_option / doda_get_option
-ABI_VERSION = 7   # include/doda_hip.h DODA_ABI_VERSION
+ABI_VERSION = 8   # include/doda_hip.h DODA_ABI_VERSION
 
 _lib = None
 

@@ -1,0 +1,545 @@
+// Coarse-level executor: the deep levels of DODA's SparseConv U-Net in ONE persistent launch per direction.
+//
+// Reference: model/unet_block.py:55-100 (UBlock recursion) over model/unet_block.py:9-37 (ResidualBlock:
+// BatchNorm1d -> ReLU -> SubMConv3d -> BatchNorm1d -> ReLU -> SubMConv3d + skip), the strided / inverse convolution pair
+// (:67-79) and the concatenation skip (:89-93).  At the U-Net's levels 5-7 a batch of four ScanNet scenes holds
+// ~1.9 k / 0.4 k / 0.1 k rows: every layer there is a launch-floor kernel (7.5 us for a convolution, 8-10 us for a
+// BatchNorm), ~110 launches forward + backward that also cost the issuing thread ~9 us each.
+//
+// MI355X-first design (numbers: tools/probe/xcdbar.hip, xcdgather.hip):
+//   * A device-side OP LIST (doda_cx_op, include/doda_hip.h) is walked by G persistent workgroups of 512 threads that sit
+//     on ONE XCD (observed placement: block b runs on XCD b % 8; the grid is 8 G blocks, those with b % 8 != 0 leave at
+//     once).  One XCD = one L2: a grid barrier over its 32 workgroups costs 1.1 us (one relaxed agent-scope counter,
+//     relaxed polls); over all 256 CUs it costs 4.1 us — more than the kernel boundary it replaces.
+//   * Correctness never depends on the placement: everything one workgroup writes for another goes out with sc1
+//     (write-through) stores, is drained (s_waitcnt vmcnt(0) in every wave) before the workgroup arrives at the barrier,
+//     and is read back with sc1 loads (L1 bypass) — the guide's placement-independent hand-off, no fences.
+//   * Op kinds: GEMM (gather-GEMM over a rulebook table: MFMA 16x16x32 bf16 on the library's pre-packed "wide" weight
+//     fragments; 16-row tiles; the offsets of a tile split over the waves of a workgroup and summed in a fixed order
+//     through LDS; epilogue: residual add, ReLU mask of the BatchNorm in front of the conv (backward), bf16 rounding,
+//     BatchNorm statistics partials of the stored values, coalesced 16-byte stores), BNFWD / BNBWD (each workgroup
+//     reduces the G partial rows itself — same rows, same order, fp64 — and sweeps the rows it owns), STATS.
+//   * Deterministic: static unit -> workgroup assignment, fixed summation orders.
+#include "common.hpp"
+#include "spconv_common.hpp"
+#include <mutex>
+#include <string.h>
+#include <stdlib.h>
+
+namespace {
+
+constexpr int CX_THREADS = 512;
+constexpr int CX_WAVES = 8;
+constexpr int CX_MAXC = 256;         // channels of any tensor an op touches
+constexpr int CX_MAXG = 64;          // workgroups (statistics rows) of a call
+constexpr int CX_SC1 = 16;           // aux bits of a raw buffer access: sc1 (agent scope: write-through store / L1-bypass load)
+constexpr unsigned CX_SPIN_LIMIT = 1u << 21;
+
+// LDS map (dynamic)
+constexpr int CX_RED_OFF = 0;                                   // f32x4 [8 waves][8 blocks][64 lanes]
+constexpr int CX_RED_BYTES = CX_WAVES * 8 * 64 * 16;            // 64 KB
+constexpr int CX_OUT_OFF = CX_RED_OFF + CX_RED_BYTES;           // bf16 [128 rows][c_out]
+constexpr int CX_OUT_BYTES = 128 * CX_MAXC * 2;                 // 64 KB
+constexpr int CX_IDX_OFF = CX_OUT_OFF + CX_OUT_BYTES;           // int [8 waves][27][16]
+constexpr int CX_IDX_BYTES = CX_WAVES * 27 * 16 * 4;            // 13.5 KB
+constexpr int CX_VEC_OFF = CX_IDX_OFF + CX_IDX_BYTES;           // float [6][CX_MAXC]
+constexpr int CX_VEC_BYTES = 6 * CX_MAXC * 4;
+constexpr int CX_LDS_BYTES = CX_VEC_OFF + CX_VEC_BYTES;         // ~148 KB
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t cx_rsrc(const void *p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, 0x7ffffff0, 0x00020000);   // (masking by the explicit OOB offset)
+}
+__device__ __forceinline__ float cx_bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+struct CxCtl {
+    unsigned *ctr, *err;
+    unsigned target;     // value the counter reaches when every workgroup has arrived at the NEXT barrier
+    int G;
+    bool dead;
+};
+
+// All workgroups of the call meet here.  Every wave first drains its own write-through stores.
+__device__ __forceinline__ void cx_barrier(CxCtl &c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    c.target += (unsigned)c.G;
+    if (threadIdx.x == 0 && !c.dead) {
+        __hip_atomic_fetch_add(c.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(c.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - c.target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > CX_SPIN_LIMIT) {   // a workgroup that never arrives must not hang the device: flag and fall through
+                __hip_atomic_store(c.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c.dead = true;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    // (one lane polled; the others learn of a time-out at the next barrier through the flag: not needed — a dead call's
+    // results are discarded by the host, it only has to terminate)
+}
+
+// 8 bf16 of a 16-byte chunk -> floats
+__device__ __forceinline__ void cx_unpack8(const u32x4 &v, float (&f)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f[2 * q] = __uint_as_float(v[q] << 16);
+        f[2 * q + 1] = __uint_as_float(v[q] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4 cx_pack8(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (unsigned)f2bf(f[2 * q]) | ((unsigned)f2bf(f[2 * q + 1]) << 16);
+    return v;
+}
+
+// ---- GEMM -------------------------------------------------------------------------------------------------------------
+// One pass over NBW channel blocks [nb0, nb0 + NBW) of the output.  Wave w: tile (w % tpw) of the unit, offset slice w / tpw.
+template <int NBW>
+__device__ __forceinline__ void cx_gemm_pass(const doda_cx_op &op, int me, int G, char *smem, int nb0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int n_out = op.rows, K = op.K, c_in = op.c_in, c_out = op.c_out;
+    const int CC = (c_in + 31) >> 5, NB = (c_out + 15) >> 4;
+    const int T = (n_out + 15) >> 4;
+    const bool identity = (op.flags & DODA_CX_F_IDENTITY) != 0;
+    const bool bwd = op.aux != nullptr;          // ReLU mask + backward statistics of the BatchNorm in front of the conv
+    const bool relu = (op.flags & DODA_CX_F_RELU) != 0;
+    // tiles per workgroup unit (power of two) x offset slices = 8 waves: as many slices as the offsets allow, fewer when
+    // there are enough tiles to give every workgroup a unit anyway
+    const int nsl_max = K >= 8 ? 8 : K >= 4 ? 4 : K >= 2 ? 2 : 1;
+    int tpw = CX_WAVES / nsl_max;
+    while (tpw < CX_WAVES && (T + 2 * tpw - 1) / (2 * tpw) >= G) tpw *= 2;
+    const int nsl = CX_WAVES / tpw;
+    const int n_units = (T + tpw - 1) / tpw;
+    const int t_in = wave & (tpw - 1), sl = wave / tpw;
+    const int o_lo = sl * K / nsl, o_hi = (sl + 1) * K / nsl;
+
+    const rsrc_t rs_x = cx_rsrc(op.x), rs_w = cx_rsrc(op.w), rs_y = cx_rsrc(op.y);
+    const rsrc_t rs_r = cx_rsrc(op.res ? op.res : op.x), rs_a = cx_rsrc(op.aux ? op.aux : op.x);
+    const unsigned x_pitch = (unsigned)op.x_ld * 2u;
+    f32x4 *red = reinterpret_cast<f32x4 *>(smem + CX_RED_OFF);
+    unsigned short *outt = reinterpret_cast<unsigned short *>(smem + CX_OUT_OFF);
+    int *myidx = reinterpret_cast<int *>(smem + CX_IDX_OFF) + wave * 27 * 16;
+    const float *vec = reinterpret_cast<const float *>(smem + CX_VEC_OFF);
+
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};   // statistics of channel block nb0 + wave (lanes r == 15)
+    for (int u = me; u < n_units; u += G) {
+        const int tile = u * tpw + t_in;
+        // this wave's slice of the table -> LDS (wave-private strip: 16 consecutive rows per offset, coalesced)
+        {
+            const int n_e = (o_hi - o_lo) * 16;
+            for (int e = lane; e < n_e; e += 64) {
+                const int oo = o_lo + (e >> 4), rr = tile * 16 + (e & 15);
+                int v = -1;
+                if (tile < T && rr < n_out) v = identity ? rr : op.tbl[(long long)oo * op.tbl_ld + rr];
+                myidx[e] = v;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        f32x4 acc[NBW];
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int o = o_lo; o < o_hi; ++o) {
+            const int id = myidx[(o - o_lo) * 16 + r];
+            if (__builtin_amdgcn_ballot_w64(id >= 0) == 0ull) continue;   // no row of the tile has this neighbour
+            const unsigned rowoff = (unsigned)id * x_pitch;
+            for (int cc = 0; cc < CC; ++cc) {
+                const int c0 = cc * 32 + g * 8;
+                const unsigned xo = (id >= 0 && c0 < c_in) ? rowoff + (unsigned)c0 * 2u : OOB;
+                const u32x4 xa = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xo, 0, CX_SC1);
+                const unsigned wbase = ((unsigned)((o * CC + cc) * NB + nb0) * 64u + (unsigned)lane) * 16u;
+                u32x4 wf[NBW];
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) wf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wbase + (unsigned)j * 1024u, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) mma_bf16_k32(acc[j], wf[j], xa);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) red[(wave * 8 + j) * 64 + lane] = acc[j];
+        __syncthreads();
+        // epilogue: wave j finishes channel block nb0 + j of every tile of the unit
+        if (wave < NBW) {
+            const int ch = (nb0 + wave) * 16 + g * 4;
+            for (int t = 0; t < tpw; ++t) {
+                f32x4 v = red[(t * 8 + wave) * 64 + lane];
+                for (int s = 1; s < nsl; ++s) v += red[((s * tpw + t) * 8 + wave) * 64 + lane];
+                const int row = (u * tpw + t) * 16 + r;
+                const bool ok = row < n_out;
+                if (op.res) {
+                    const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(rs_r, ok ? ((unsigned)row * (unsigned)op.res_ld + (unsigned)ch) * 2u : OOB, 0, CX_SC1);
+                    v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
+                    v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+                }
+                f32x4 xh = {0.f, 0.f, 0.f, 0.f};
+                if (bwd) {
+                    const u32x2 xr = __builtin_amdgcn_raw_buffer_load_b64(rs_a, ok ? ((unsigned)row * (unsigned)op.aux_ld + (unsigned)ch) * 2u : OOB, 0, CX_SC1);
+                    const float xv[4] = {__uint_as_float(xr[0] << 16), __uint_as_float(xr[0] & 0xffff0000u),
+                                         __uint_as_float(xr[1] << 16), __uint_as_float(xr[1] & 0xffff0000u)};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        xh[q] = (xv[q] - vec[ch + q]) * vec[CX_MAXC + ch + q];
+                        if (relu) {
+                            const float yv = xh[q] * vec[2 * CX_MAXC + ch + q] + vec[3 * CX_MAXC + ch + q];
+                            v[q] = yv > 0.f ? v[q] : 0.f;
+                        }
+                    }
+                    if (!ok) xh = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                unsigned short ob[4];
+                f32x4 vr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ob[q] = f2bf(v[q]); vr[q] = cx_bf2f(ob[q]); }
+                if (op.stats) {
+                    f32x4 a = vr, b = bwd ? vr * xh : vr * vr;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { a[q] = row_sum16(a[q]); b[q] = row_sum16(b[q]); }
+                    st1 += a; st2 += b;
+                }
+                u32x2 pk;
+                pk[0] = (unsigned)ob[0] | ((unsigned)ob[1] << 16);
+                pk[1] = (unsigned)ob[2] | ((unsigned)ob[3] << 16);
+                *reinterpret_cast<u32x2 *>(outt + (t * 16 + r) * c_out + ch) = pk;
+            }
+        }
+        __syncthreads();
+        {   // the unit's rows, channels of this pass, in 16-byte write-through stores
+            const int cprp = NBW * 2, rows_u = tpw * 16;
+            for (int i = threadIdx.x; i < rows_u * cprp; i += CX_THREADS) {
+                const int rr = i / cprp, ck = i - rr * cprp;
+                const int row = u * tpw * 16 + rr, chn = nb0 * 16 + ck * 8;
+                if (row < n_out) {
+                    const u32x4 d = *reinterpret_cast<const u32x4 *>(outt + rr * c_out + chn);
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, ((unsigned)row * (unsigned)op.y_ld + (unsigned)chn) * 2u, 0, CX_SC1);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (op.stats && wave < NBW && r == 15) {   // this workgroup's partial row (zeros when it had no unit)
+        const int ch = (nb0 + wave) * 16 + g * 4;
+        const rsrc_t rs_s = cx_rsrc(op.stats);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, st1), rs_s, ((unsigned)(me * 2 + 0) * (unsigned)c_out + (unsigned)ch) * 4u, 0, CX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, st2), rs_s, ((unsigned)(me * 2 + 1) * (unsigned)c_out + (unsigned)ch) * 4u, 0, CX_SC1);
+    }
+}
+
+__device__ __forceinline__ void cx_gemm(const doda_cx_op &op, int me, int G, char *smem) {
+    if (op.aux) {   // the BatchNorm in front of the conv (backward epilogue): its vectors -> LDS
+        float *vec = reinterpret_cast<float *>(smem + CX_VEC_OFF);
+        const int c = threadIdx.x;
+        if (c < op.c_out) {
+            vec[c] = op.mean[c];
+            vec[CX_MAXC + c] = op.invstd[c];
+            vec[2 * CX_MAXC + c] = op.gamma[c];
+            vec[3 * CX_MAXC + c] = op.beta[c];
+        }
+        __syncthreads();
+    }
+    const int NB = (op.c_out + 15) >> 4;
+#define CX_PASS(N, B0) cx_gemm_pass<N>(op, me, G, smem, B0)
+    switch (NB) {
+    case 1: CX_PASS(1, 0); break;
+    case 2: CX_PASS(2, 0); break;
+    case 3: CX_PASS(3, 0); break;
+    case 4: CX_PASS(4, 0); break;
+    case 5: CX_PASS(5, 0); break;
+    case 6: CX_PASS(6, 0); break;
+    case 7: CX_PASS(7, 0); break;
+    case 8: CX_PASS(8, 0); break;
+    case 10: CX_PASS(5, 0); CX_PASS(5, 5); break;
+    case 12: CX_PASS(6, 0); CX_PASS(6, 6); break;
+    case 14: CX_PASS(7, 0); CX_PASS(7, 7); break;
+    case 16: CX_PASS(8, 0); CX_PASS(8, 8); break;
+    default: break;   // (rejected on the host)
+    }
+#undef CX_PASS
+}
+
+// rows [r0, r1) this workgroup owns in the row-local ops
+__device__ __forceinline__ void cx_own_rows(int rows, int me, int G, int &r0, int &r1) {
+    const int per = (rows + G - 1) / G;
+    r0 = me * per < rows ? me * per : rows;
+    r1 = r0 + per < rows ? r0 + per : rows;
+}
+
+// ---- BatchNorm(+ReLU) forward: y = [relu]((x - mean) * invstd * gamma + beta) ------------------------------------------
+__device__ __forceinline__ void cx_bnfwd(const doda_cx_op &op, int me, int G, char *smem) {
+    float *vec = reinterpret_cast<float *>(smem + CX_VEC_OFF);
+    const int C = op.c_in, rows = op.rows, tid = threadIdx.x;
+    if (tid < C) {
+        float mu, is;
+        if (op.flags & DODA_CX_F_TRAINING) {
+            const int ca = op.c_split;
+            const float *sp = tid < ca ? op.stats : op.stats_b;
+            const int cw = tid < ca ? ca : C - ca, cl = tid < ca ? tid : tid - ca;
+            const rsrc_t rs_s = cx_rsrc(sp);
+            double s1 = 0.0, s2 = 0.0;
+            for (int p = 0; p < op.n_part; ++p) {
+                const float a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_s, ((unsigned)(p * 2) * (unsigned)cw + (unsigned)cl) * 4u, 0, CX_SC1));
+                const float b = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_s, ((unsigned)(p * 2 + 1) * (unsigned)cw + (unsigned)cl) * 4u, 0, CX_SC1));
+                s1 += (double)a;
+                s2 += (double)b;
+            }
+            const double d = s1 / rows;
+            double var = s2 / rows - d * d;
+            if (var < 0.0) var = 0.0;
+            mu = (float)d;
+            is = (float)(1.0 / sqrt(var + (double)op.eps));
+            if (me == 0) {
+                if (op.running_mean) {
+                    const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+                    const double mom = (double)op.momentum;
+                    op.running_mean[tid] = (float)((1.0 - mom) * (double)op.running_mean[tid] + mom * d);
+                    op.running_var[tid] = (float)((1.0 - mom) * (double)op.running_var[tid] + mom * unbiased);
+                }
+                if (tid == 0 && op.nbt) *op.nbt += 1;
+            }
+        } else {
+            mu = op.running_mean[tid];
+            is = 1.0f / sqrtf(op.running_var[tid] + op.eps);
+        }
+        if (me == 0 && op.mean) { op.mean[tid] = mu; op.invstd[tid] = is; }
+        vec[tid] = mu;
+        vec[CX_MAXC + tid] = is;
+        vec[2 * CX_MAXC + tid] = op.gamma[tid];
+        vec[3 * CX_MAXC + tid] = op.beta[tid];
+    }
+    __syncthreads();
+    int r0, r1;
+    cx_own_rows(rows, me, G, r0, r1);
+    const int cpr = C >> 3;
+    const bool relu = (op.flags & DODA_CX_F_RELU) != 0;
+    const rsrc_t rs_x = cx_rsrc(op.x), rs_y = cx_rsrc(op.y);
+    for (int i = tid; i < (r1 - r0) * cpr; i += CX_THREADS) {
+        const int rr = i / cpr, ck = i - rr * cpr, row = r0 + rr, c0 = ck * 8;
+        const u32x4 xv = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ((unsigned)row * (unsigned)op.x_ld + (unsigned)c0) * 2u, 0, CX_SC1);
+        float f[8];
+        cx_unpack8(xv, f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float o = (f[q] - vec[c0 + q]) * vec[CX_MAXC + c0 + q] * vec[2 * CX_MAXC + c0 + q] + vec[3 * CX_MAXC + c0 + q];
+            if (relu) o = o > 0.f ? o : 0.f;
+            f[q] = o;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(cx_pack8(f), rs_y, ((unsigned)row * (unsigned)op.y_ld + (unsigned)c0) * 2u, 0, CX_SC1);
+    }
+}
+
+// ---- BatchNorm backward apply: dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) + add -------------------
+// dz arrives with the ReLU mask applied (GEMM epilogue); stats = (sum dz, sum dz * xhat) partial rows.
+__device__ __forceinline__ void cx_bnbwd(const doda_cx_op &op, int me, int G, char *smem) {
+    float *vec = reinterpret_cast<float *>(smem + CX_VEC_OFF);
+    const int C = op.c_in, rows = op.rows, tid = threadIdx.x;
+    if (tid < C) {
+        const rsrc_t rs_s = cx_rsrc(op.stats);
+        double s1 = 0.0, s2 = 0.0;
+        for (int p = 0; p < op.n_part; ++p) {
+            const float a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_s, ((unsigned)(p * 2) * (unsigned)C + (unsigned)tid) * 4u, 0, CX_SC1));
+            const float b = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_s, ((unsigned)(p * 2 + 1) * (unsigned)C + (unsigned)tid) * 4u, 0, CX_SC1));
+            s1 += (double)a;
+            s2 += (double)b;
+        }
+        const float is = op.invstd[tid];
+        vec[tid] = op.mean[tid];
+        vec[CX_MAXC + tid] = is;
+        vec[2 * CX_MAXC + tid] = op.gamma[tid] * is;
+        vec[3 * CX_MAXC + tid] = (float)(s1 / rows);
+        vec[4 * CX_MAXC + tid] = (float)(s2 / rows);
+        if (me == 0 && op.dgamma) {
+            if (op.flags & DODA_CX_F_ACCUM) { op.dbeta[tid] += (float)s1; op.dgamma[tid] += (float)s2; }
+            else { op.dbeta[tid] = (float)s1; op.dgamma[tid] = (float)s2; }
+        }
+    }
+    __syncthreads();
+    int r0, r1;
+    cx_own_rows(rows, me, G, r0, r1);
+    const int cpr = C >> 3, csp = op.c_split;
+    const rsrc_t rs_z = cx_rsrc(op.x), rs_x = cx_rsrc(op.aux), rs_a = cx_rsrc(op.res ? op.res : op.x);
+    const rsrc_t rs_y = cx_rsrc(op.y), rs_y2 = cx_rsrc(op.y2 ? op.y2 : op.y);
+    for (int i = tid; i < (r1 - r0) * cpr; i += CX_THREADS) {
+        const int rr = i / cpr, ck = i - rr * cpr, row = r0 + rr, c0 = ck * 8;
+        const u32x4 zv = __builtin_amdgcn_raw_buffer_load_b128(rs_z, ((unsigned)row * (unsigned)op.x_ld + (unsigned)c0) * 2u, 0, CX_SC1);
+        const u32x4 xv = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ((unsigned)row * (unsigned)op.aux_ld + (unsigned)c0) * 2u, 0, CX_SC1);
+        u32x4 av = {0u, 0u, 0u, 0u};
+        if (op.res) av = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ((unsigned)row * (unsigned)op.res_ld + (unsigned)c0) * 2u, 0, CX_SC1);
+        float dz[8], x[8], ad[8];
+        cx_unpack8(zv, dz);
+        cx_unpack8(xv, x);
+        cx_unpack8(av, ad);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float xh = (x[q] - vec[c0 + q]) * vec[CX_MAXC + c0 + q];
+            float o = vec[2 * CX_MAXC + c0 + q] * (dz[q] - vec[3 * CX_MAXC + c0 + q] - xh * vec[4 * CX_MAXC + c0 + q]);
+            if (op.res) o += ad[q];
+            dz[q] = o;
+        }
+        if (c0 < csp) __builtin_amdgcn_raw_buffer_store_b128(cx_pack8(dz), rs_y, ((unsigned)row * (unsigned)op.y_ld + (unsigned)c0) * 2u, 0, CX_SC1);
+        else __builtin_amdgcn_raw_buffer_store_b128(cx_pack8(dz), rs_y2, ((unsigned)row * (unsigned)op.y2_ld + (unsigned)(c0 - csp)) * 2u, 0, CX_SC1);
+    }
+}
+
+// ---- (sum x, sum x^2) partial row of the rows this workgroup owns --------------------------------------------------------
+__device__ __forceinline__ void cx_stats(const doda_cx_op &op, int me, int G, char *smem) {
+    float *sred = reinterpret_cast<float *>(smem + CX_RED_OFF);
+    const int C = op.c_in, rows = op.rows, tid = threadIdx.x;
+    int r0, r1;
+    cx_own_rows(rows, me, G, r0, r1);
+    const int cpr = C >> 3, RL = CX_THREADS / cpr;
+    const int col = tid % cpr, rl = tid / cpr;
+    const rsrc_t rs_x = cx_rsrc(op.x);
+    if (rl < RL) {
+        float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int row = r0 + rl; row < r1; row += RL) {
+            const u32x4 xv = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ((unsigned)row * (unsigned)op.x_ld + (unsigned)col * 8u) * 2u, 0, CX_SC1);
+            float f[8];
+            cx_unpack8(xv, f);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { s1[q] += f[q]; s2[q] += f[q] * f[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sred[(rl * 2 + 0) * C + col * 8 + q] = s1[q];
+            sred[(rl * 2 + 1) * C + col * 8 + q] = s2[q];
+        }
+    }
+    __syncthreads();
+    const rsrc_t rs_s = cx_rsrc(op.stats);
+    for (int e = tid; e < 2 * C; e += CX_THREADS) {
+        float t = 0.f;
+        for (int k = 0; k < RL; ++k) t += sred[k * 2 * C + e];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), rs_s, ((unsigned)me * 2u * (unsigned)C + (unsigned)e) * 4u, 0, CX_SC1);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(CX_THREADS) void coarse_exec(const doda_cx_op *__restrict__ ops, int n_ops, unsigned *sync, unsigned sync_base,
+                                                          int G, int xcds) {
+    if ((int)(blockIdx.x & 7) >= xcds) return;
+    const int me = (int)(blockIdx.x >> 3) * xcds + (int)(blockIdx.x & 7);
+    if (me >= G) return;
+    extern __shared__ __attribute__((aligned(16))) char cx_smem[];
+    CxCtl ctl{sync, sync + 1, sync_base, G, false};
+    for (int i = 0; i < n_ops; ++i) {
+        const doda_cx_op &op = ops[i];
+        if (op.flags & DODA_CX_F_BARRIER) cx_barrier(ctl);
+        else __syncthreads();   // (the ops share LDS regions)
+        switch (op.kind) {
+        case DODA_CX_GEMM: cx_gemm(op, me, G, cx_smem); break;
+        case DODA_CX_BNFWD: cx_bnfwd(op, me, G, cx_smem); break;
+        case DODA_CX_BNBWD: cx_bnbwd(op, me, G, cx_smem); break;
+        case DODA_CX_STATS: cx_stats(op, me, G, cx_smem); break;
+        default: break;
+        }
+    }
+}
+
+// pinned staging ring for the op-list upload (as optim.hip: grow-only slots, reuse guarded by an event)
+struct Slot {
+    void *host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    int ev_dev = -1;
+    bool pending = false;
+};
+std::mutex g_mu;
+Slot g_slot[4];
+unsigned g_next = 0;
+bool g_attr_set = false;
+
+int env_int(const char *name, int dflt, int lo, int hi) {
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    const int v = atoi(e);
+    return v < lo ? lo : v > hi ? hi : v;
+}
+
+bool bad_channels(int c) { return c <= 0 || c > CX_MAXC || (c % 8) != 0; }
+
+}  // namespace
+
+extern "C" int32_t doda_coarse_workgroups(void) {
+    static const int g = env_int("DODA_CX_WGS", 32, 1, CX_MAXG);
+    return g;
+}
+
+extern "C" size_t doda_coarse_desc_bytes(int32_t n_ops) { return n_ops > 0 ? align_up((size_t)n_ops * sizeof(doda_cx_op), 256) : 0; }
+
+extern "C" int doda_coarse_run(const doda_cx_op *ops_h, int32_t n_ops, void *desc_dev, size_t desc_bytes, uint32_t *sync_dev,
+                               uint32_t sync_base, uint32_t *sync_next_h, doda_stream_t stream) {
+    if (sync_next_h) *sync_next_h = sync_base;
+    if (n_ops == 0) return DODA_OK;
+    if (n_ops < 0 || !ops_h || !desc_dev || !sync_dev) return DODA_ERR_INVALID;
+    const size_t need = doda_coarse_desc_bytes(n_ops);
+    if (desc_bytes < need) return DODA_ERR_WORKSPACE;
+    const int G = doda_coarse_workgroups();
+    static const int xcds = env_int("DODA_CX_XCDS", 1, 1, 8);
+    unsigned n_barriers = 0;
+    for (int k = 0; k < n_ops; ++k) {
+        const doda_cx_op &o = ops_h[k];
+        if (o.flags & DODA_CX_F_BARRIER) ++n_barriers;
+        if (o.rows < 0 || o.n_part != G) return DODA_ERR_INVALID;
+        switch (o.kind) {
+        case DODA_CX_GEMM: {
+            const int NB = (o.c_out + 15) / 16;
+            if (!o.x || !o.w || !o.y || (!o.tbl && !(o.flags & DODA_CX_F_IDENTITY))) return DODA_ERR_INVALID;
+            if (bad_channels(o.c_in) || bad_channels(o.c_out) || o.c_out % 16 != 0 || o.c_in < 32) return DODA_ERR_UNSUPPORTED;
+            if (!(NB <= 8 || NB == 10 || NB == 12 || NB == 14 || NB == 16)) return DODA_ERR_UNSUPPORTED;
+            if (o.K < 1 || o.K > 27 || ((o.flags & DODA_CX_F_IDENTITY) && o.K != 1)) return DODA_ERR_UNSUPPORTED;
+            if (o.x_ld < o.c_in || o.y_ld < o.c_out || o.x_ld % 8 || o.y_ld % 8 || (o.res && (o.res_ld < o.c_out || o.res_ld % 4)) ||
+                (o.aux && (o.aux_ld < o.c_out || o.aux_ld % 4 || !o.mean || !o.invstd || !o.gamma || !o.beta)))
+                return DODA_ERR_INVALID;
+            break;
+        }
+        case DODA_CX_BNFWD:
+            if (!o.x || !o.y || !o.gamma || !o.beta || bad_channels(o.c_in) || o.x_ld % 8 || o.y_ld % 8) return DODA_ERR_INVALID;
+            if ((o.flags & DODA_CX_F_TRAINING) ? (!o.stats || o.c_split <= 0 || o.c_split > o.c_in || (o.c_split < o.c_in && !o.stats_b) || !o.mean || !o.invstd)
+                                               : (!o.running_mean || !o.running_var))
+                return DODA_ERR_INVALID;
+            break;
+        case DODA_CX_BNBWD:
+            if (!o.x || !o.aux || !o.y || !o.stats || !o.mean || !o.invstd || !o.gamma || bad_channels(o.c_in) || o.x_ld % 8 || o.aux_ld % 8 ||
+                o.y_ld % 8 || (o.res && o.res_ld % 8) || o.c_split <= 0 || o.c_split > o.c_in || o.c_split % 8 ||
+                (o.c_split < o.c_in && (!o.y2 || o.y2_ld % 8)) || (o.dgamma && !o.dbeta))
+                return DODA_ERR_INVALID;
+            break;
+        case DODA_CX_STATS:
+            if (!o.x || !o.stats || bad_channels(o.c_in) || o.x_ld % 8) return DODA_ERR_INVALID;
+            break;
+        default: return DODA_ERR_INVALID;
+        }
+    }
+    hipStream_t s = as_stream(stream);
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (!g_attr_set) {
+            if (hipFuncSetAttribute((const void *)coarse_exec, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS_BYTES) != hipSuccess)
+                return DODA_ERR_LAUNCH;
+            g_attr_set = true;
+        }
+        Slot &sl = g_slot[g_next++ & 3u];
+        if (sl.pending) { (void)hipEventSynchronize(sl.ev); sl.pending = false; }
+        if (sl.cap < need) {
+            if (sl.host) (void)hipHostFree(sl.host);
+            sl.cap = align_up(need, 4096) * 2;
+            if (hipHostMalloc(&sl.host, sl.cap, hipHostMallocDefault) != hipSuccess) { sl.host = nullptr; sl.cap = 0; return DODA_ERR_NOMEM; }
+        }
+        int cur_dev = 0;
+        (void)hipGetDevice(&cur_dev);
+        if (sl.ev && sl.ev_dev != cur_dev) { (void)hipEventDestroy(sl.ev); sl.ev = nullptr; }
+        if (!sl.ev && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) return DODA_ERR_LAUNCH;
+        sl.ev_dev = cur_dev;
+        memcpy(sl.host, ops_h, (size_t)n_ops * sizeof(doda_cx_op));
+        if (hipMemcpyAsync(desc_dev, sl.host, (size_t)n_ops * sizeof(doda_cx_op), hipMemcpyHostToDevice, s) != hipSuccess) return DODA_ERR_LAUNCH;
+        (void)hipEventRecord(sl.ev, s);
+        sl.pending = true;
+    }
+    hipLaunchKernelGGL(coarse_exec, dim3((unsigned)(8 * ((G + xcds - 1) / xcds))), dim3(CX_THREADS), CX_LDS_BYTES, s, (const doda_cx_op *)desc_dev, n_ops,
+                       (unsigned *)sync_dev, (unsigned)sync_base, G, xcds);
+    if (sync_next_h) *sync_next_h = sync_base + n_barriers * (unsigned)G;
+    return doda_check_launch();
+}

@@ -765,3 +765,64 @@ def sgd_multi(params, grads, bufs, first, lr, momentum=0.0, dampening=0.0, weigh
     check(lib().doda_sgd_multi(C.cast(arr, C.c_void_p), n, float(lr), float(momentum), float(dampening),
                                float(weight_decay), int(bool(nesterov)), int(bool(maximize)), _p(desc), nbytes,
                                _stream()), "doda_sgd_multi")
+
+
+# ---- coarse-level executor (ABI 8, csrc/coarse.hip) ----------------------------------------------------
+CX_GEMM, CX_BNFWD, CX_BNBWD, CX_STATS = 1, 2, 3, 4
+CX_F_BARRIER, CX_F_IDENTITY, CX_F_RELU, CX_F_TRAINING, CX_F_ACCUM = 1, 2, 4, 8, 16
+
+
+class _CxOp(C.Structure):   # doda_cx_op
+    _fields_ = [("kind", C.c_int32), ("flags", C.c_int32), ("rows", C.c_int32), ("rows_in", C.c_int32),
+                ("c_in", C.c_int32), ("c_out", C.c_int32), ("K", C.c_int32), ("tbl_ld", C.c_int32),
+                ("x_ld", C.c_int32), ("y_ld", C.c_int32), ("res_ld", C.c_int32), ("aux_ld", C.c_int32),
+                ("y2_ld", C.c_int32), ("n_part", C.c_int32), ("c_split", C.c_int32), ("reserved", C.c_int32),
+                ("eps", C.c_float), ("momentum", C.c_float),
+                ("x", C.c_void_p), ("w", C.c_void_p), ("tbl", C.c_void_p), ("y", C.c_void_p), ("y2", C.c_void_p),
+                ("res", C.c_void_p), ("aux", C.c_void_p), ("stats", C.c_void_p), ("stats_b", C.c_void_p),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("nbt", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+
+
+_CX_SYNC = {}   # device -> [uint32 [2] tensor, counter value]
+
+
+def coarse_workgroups():
+    return int(lib().doda_coarse_workgroups())
+
+
+def coarse_error(device):
+    """True when a grid barrier of an earlier coarse_run on `device` timed out (synchronises)."""
+    st = _CX_SYNC.get(torch.device(device))
+    return bool(st is not None and int(st[0][1].item()) != 0)
+
+
+def coarse_run(ops, device):
+    """Run a list of executor ops (dicts keyed by the doda_cx_op field names; tensors for the pointer fields) in ONE
+    persistent launch (doda_coarse_run).  Tensor operands: bf16 feature matrices (row strides given by the caller in
+    `*_ld`), fp32 statistics / BatchNorm vectors, int32 tables.  The caller keeps every tensor alive until the stream has
+    passed the launch.  Used by the tests and tools; the training path builds its op lists in the C++ extension."""
+    device = torch.device(device)
+    n = len(ops)
+    arr = (_CxOp * n)()
+    ptr_fields = {"x", "w", "tbl", "y", "y2", "res", "aux", "stats", "stats_b", "gamma", "beta", "mean", "invstd",
+                  "running_mean", "running_var", "nbt", "dgamma", "dbeta"}
+    for k, o in enumerate(ops):
+        for name, v in o.items():
+            if name in ptr_fields:
+                if v is not None:
+                    _need_cuda(v)
+                setattr(arr[k], name, v.data_ptr() if v is not None else None)
+            else:
+                setattr(arr[k], name, v)
+        arr[k].n_part = coarse_workgroups()
+    st = _CX_SYNC.get(device)
+    if st is None:
+        st = _CX_SYNC[device] = [torch.zeros(2, dtype=torch.int32, device=device), 0]
+    nbytes = lib().doda_coarse_desc_bytes(n)
+    desc = _ws(nbytes, device)
+    nxt = C.c_uint32(0)
+    check(lib().doda_coarse_run(C.cast(arr, C.c_void_p), n, _p(desc), nbytes, _p(st[0]), st[1], C.byref(nxt), _stream()),
+          "doda_coarse_run")
+    st[1] = int(nxt.value)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DODA_ABI_VERSION 7
+#define DODA_ABI_VERSION 8
 
 #define DODA_OK 0
 #define DODA_ERR_INVALID (-1)        /* bad argument (null pointer, negative size, bad mode) */
@@ -486,6 +486,81 @@ size_t doda_sgd_multi_desc_bytes(int32_t n_tensors);
 int doda_sgd_multi(const doda_sgd_tensor *tensors_h, int32_t n_tensors, double lr, double momentum,
                    double dampening, double weight_decay, int32_t nesterov, int32_t maximize, void *desc_dev,
                    size_t desc_bytes, doda_stream_t stream);
+
+/* ---- ABI 8: coarse-level executor -----------------------------------------------------------------------
+ * The deep levels of DODA's U-Net in ONE persistent launch per direction (csrc/coarse.hip).  Replaces, for levels of a
+ * few thousand rows and fewer, the per-layer launches of reference model/unet_block.py:55-100 (UBlock: blocks -> strided
+ * conv -> UBlock -> inverse conv -> concatenation -> blocks_tail) with model/unet_block.py:9-37 inside (ResidualBlock:
+ * BatchNorm1d -> ReLU -> SubMConv3d, twice, + skip); the arithmetic per layer is that of doda_spconv_gather_ex (bf16
+ * features, fp32 accumulate, one rounding at the store) and doda_bn_relu_fwd / _bwd.
+ *
+ * The caller describes the work as a HOST array of ops; doda_coarse_workgroups() persistent workgroups on one XCD walk
+ * it in order, with a grid barrier in front of every op flagged DODA_CX_F_BARRIER (an op whose inputs an EARLIER op of
+ * the same call wrote needs the flag; independent neighbours may omit it).  All feature tensors are bf16 [rows, c] with a
+ * row stride in elements (`*_ld`: a column slice of a wider matrix — the halves of a concatenation — is addressed in
+ * place); channel counts are multiples of 8 (GEMM outputs: of 16), at most 256.  Statistics arrays hold
+ * doda_coarse_workgroups() rows of [2][c] floats (`n_part` must say so).
+ *
+ * DODA_CX_GEMM   y[t, :] = sum_o x[tbl[o][t], :] . B_o (+ res[t, :])   t < rows; `w` = the fragment-packed weights of
+ *                doda_spconv_pack_multi for (K, c_in, c_out, bf16) — "wide" order, c_in >= 32; tbl int32 [K][tbl_ld]
+ *                (or DODA_CX_F_IDENTITY: K = 1, row t reads row t: the 1x1 convolution).
+ *                aux == NULL (forward): stats[p] = (sum y, sum y^2) over the rows workgroup p stored, y as stored.
+ *                aux != NULL (data gradient; aux = input of the BatchNorm in FRONT of the conv, mean / invstd / gamma /
+ *                beta its vectors): y = dz = (sum ...) * [gamma * xhat + beta > 0] (the mask only with DODA_CX_F_RELU),
+ *                stats[p] = (sum dz, sum dz * xhat), xhat = (aux - mean) * invstd.   stats may be NULL.
+ * DODA_CX_BNFWD  y = [relu]((x - mean) * invstd * gamma + beta) over c_in channels.  DODA_CX_F_TRAINING: mean / invstd
+ *                from the partial rows `stats` (first c_split channels) and `stats_b` (the rest: x is a concatenation),
+ *                written to mean / invstd; running_mean / running_var / nbt updated when given.  Otherwise the running
+ *                statistics are used.
+ * DODA_CX_BNBWD  dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) (+ res): x = dz (masked), aux = the
+ *                BatchNorm's input, stats = the GEMM's backward statistics; columns < c_split go to y, the rest to y2
+ *                (the two halves of a concatenation's gradient as two dense tensors); dgamma / dbeta written (or, with
+ *                DODA_CX_F_ACCUM, added to) when given.
+ * DODA_CX_STATS  stats[p] = (sum x, sum x^2) over the rows workgroup p owns.
+ *
+ * sync: uint32 [2] device words owned by the caller across calls, zero at first use: [0] the barrier counter — the caller
+ * passes the value it holds (`sync_base`: 0, then what *sync_next_h returned) —, [1] set to 1 by a barrier that timed out
+ * (a workgroup never arrived: the results are garbage, the launch still terminates).  Calls sharing `sync` must be stream
+ * ordered.  desc_dev: doda_coarse_desc_bytes(n_ops) bytes of device scratch for the uploaded ops. */
+#define DODA_CX_GEMM 1
+#define DODA_CX_BNFWD 2
+#define DODA_CX_BNBWD 3
+#define DODA_CX_STATS 4
+#define DODA_CX_F_BARRIER 1
+#define DODA_CX_F_IDENTITY 2
+#define DODA_CX_F_RELU 4
+#define DODA_CX_F_TRAINING 8
+#define DODA_CX_F_ACCUM 16
+typedef struct doda_cx_op {
+    int32_t kind, flags;
+    int32_t rows;            /* output rows (GEMM) / rows of the tensor */
+    int32_t rows_in;         /* GEMM: rows of x */
+    int32_t c_in, c_out;     /* GEMM: channels of x / y; other kinds: c_in = channels */
+    int32_t K, tbl_ld;
+    int32_t x_ld, y_ld, res_ld, aux_ld, y2_ld;
+    int32_t n_part;          /* rows of every statistics array = doda_coarse_workgroups() */
+    int32_t c_split;
+    int32_t reserved;
+    float eps, momentum;
+    const void *x;
+    const void *w;
+    const int32_t *tbl;
+    void *y;
+    void *y2;
+    const void *res;
+    const void *aux;
+    float *stats;
+    const float *stats_b;
+    const float *gamma, *beta;
+    float *mean, *invstd;
+    float *running_mean, *running_var;
+    int64_t *nbt;
+    float *dgamma, *dbeta;
+} doda_cx_op;
+int32_t doda_coarse_workgroups(void);
+size_t doda_coarse_desc_bytes(int32_t n_ops);
+int doda_coarse_run(const doda_cx_op *ops_h, int32_t n_ops, void *desc_dev, size_t desc_bytes, uint32_t *sync_dev,
+                    uint32_t sync_base, uint32_t *sync_next_h, doda_stream_t stream);
 
 #ifdef __cplusplus
 }

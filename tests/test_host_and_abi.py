@@ -19,7 +19,7 @@ def test_header_symbols_all_exported(native_lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(native_lib, name), name
-    assert native_lib.doda_abi_version() == 7
+    assert native_lib.doda_abi_version() == 8
     assert len(declared) <= 60      # (the boundary a maintainer carries)
     assert native_lib.doda_strerror(-3).decode().startswith("cell id")
 
