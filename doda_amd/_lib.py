@@ -90,7 +90,7 @@ _SIGNATURES = {
                                        C.POINTER(c_i32), c_vp, c_sz, c_vp]),
     "doda_coarse_workgroups": (c_i32, []),
     "doda_coarse_desc_bytes": (c_sz, [c_i32]),
-    "doda_coarse_run": (c_i32, [c_vp, c_i32, c_vp, c_sz, c_vp, C.c_uint32, C.POINTER(C.c_uint32), c_vp]),
+    "doda_coarse_run": (c_i32, [c_vp, c_i32, c_vp, c_sz, c_vp, c_vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -417,13 +417,12 @@ __device__ __forceinline__ void cx_stats(const doda_cx_op &op, int me, int G, ch
     __syncthreads();
 }
 
-__global__ __launch_bounds__(CX_THREADS) void coarse_exec(const doda_cx_op *__restrict__ ops, int n_ops, unsigned *sync, unsigned sync_base,
-                                                          int G, int xcds) {
+__global__ __launch_bounds__(CX_THREADS) void coarse_exec(const doda_cx_op *__restrict__ ops, int n_ops, unsigned *sync, int G, int xcds) {
     if ((int)(blockIdx.x & 7) >= xcds) return;
     const int me = (int)(blockIdx.x >> 3) * xcds + (int)(blockIdx.x & 7);
     if (me >= G) return;
     extern __shared__ __attribute__((aligned(16))) char cx_smem[];
-    CxCtl ctl{sync, sync + 1, sync_base, G, false};
+    CxCtl ctl{sync, sync + 1, 0u, G, false};   // (the counter is zero at launch: the last workgroup out resets it, below)
     for (int i = 0; i < n_ops; ++i) {
         const doda_cx_op &op = ops[i];
         if (op.flags & DODA_CX_F_BARRIER) cx_barrier(ctl);
@@ -434,6 +433,16 @@ __global__ __launch_bounds__(CX_THREADS) void coarse_exec(const doda_cx_op *__re
         case DODA_CX_BNBWD: cx_bnbwd(op, me, G, cx_smem); break;
         case DODA_CX_STATS: cx_stats(op, me, G, cx_smem); break;
         default: break;
+        }
+    }
+    // the last workgroup to leave puts the barrier counter back to zero for the next launch (every workgroup is past its
+    // last barrier once it has counted itself out; a launch whose barrier timed out still ends with a clean counter)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)G - 1u) {
+            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -470,18 +479,15 @@ extern "C" int32_t doda_coarse_workgroups(void) {
 extern "C" size_t doda_coarse_desc_bytes(int32_t n_ops) { return n_ops > 0 ? align_up((size_t)n_ops * sizeof(doda_cx_op), 256) : 0; }
 
 extern "C" int doda_coarse_run(const doda_cx_op *ops_h, int32_t n_ops, void *desc_dev, size_t desc_bytes, uint32_t *sync_dev,
-                               uint32_t sync_base, uint32_t *sync_next_h, doda_stream_t stream) {
-    if (sync_next_h) *sync_next_h = sync_base;
+                               doda_stream_t stream) {
     if (n_ops == 0) return DODA_OK;
     if (n_ops < 0 || !ops_h || !desc_dev || !sync_dev) return DODA_ERR_INVALID;
     const size_t need = doda_coarse_desc_bytes(n_ops);
     if (desc_bytes < need) return DODA_ERR_WORKSPACE;
     const int G = doda_coarse_workgroups();
     static const int xcds = env_int("DODA_CX_XCDS", 1, 1, 8);
-    unsigned n_barriers = 0;
     for (int k = 0; k < n_ops; ++k) {
         const doda_cx_op &o = ops_h[k];
-        if (o.flags & DODA_CX_F_BARRIER) ++n_barriers;
         if (o.rows < 0 || o.n_part != G) return DODA_ERR_INVALID;
         switch (o.kind) {
         case DODA_CX_GEMM: {
@@ -539,7 +545,6 @@ extern "C" int doda_coarse_run(const doda_cx_op *ops_h, int32_t n_ops, void *des
         sl.pending = true;
     }
     hipLaunchKernelGGL(coarse_exec, dim3((unsigned)(8 * ((G + xcds - 1) / xcds))), dim3(CX_THREADS), CX_LDS_BYTES, s, (const doda_cx_op *)desc_dev, n_ops,
-                       (unsigned *)sync_dev, (unsigned)sync_base, G, xcds);
-    if (sync_next_h) *sync_next_h = sync_base + n_barriers * (unsigned)G;
+                       (unsigned *)sync_dev, G, xcds);
     return doda_check_launch();
 }

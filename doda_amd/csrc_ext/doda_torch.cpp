@@ -29,7 +29,8 @@
 // thread spends a step — the step sits at the host / GPU crossover.
 namespace host_timing {
 struct Slot { const char *name; long long ns = 0, calls = 0; };
-static Slot g_slots[] = {{"residual_block"}, {"conv_backward"}, {"bn_backward"}, {"flush_wgrads"}, {"wgrad_multi (library)"}};
+static Slot g_slots[] = {{"residual_block"}, {"conv_backward"}, {"bn_backward"}, {"flush_wgrads"}, {"wgrad_multi (library)"},
+                         {"coarse_backward"}, {"coarse_forward"}};
 static const bool g_on = getenv("DODA_HOST_TIMING") && getenv("DODA_HOST_TIMING")[0] == '1';
 struct Scope {
     int k;
@@ -1035,6 +1036,475 @@ std::vector<at::Tensor> residual_block(const at::Tensor &x, const c10::optional<
     return indice_conv_impl(y2[0], *cv2[0], tbl, tbl, n_out, 2, cv2[1], cv2[2], res, rb[1], rb[2], rb[3], rb[4], want_stats);
 }
 
+
+// ---- coarse-level executor glue (csrc/coarse.hip, doda_coarse_run) --------------------------------------------
+// reference model/unet_block.py:55-100: one UBlock subtree (blocks -> strided conv -> UBlock -> inverse conv ->
+// concatenation -> blocks_tail, ResidualBlocks of model/unet_block.py:9-37 inside) whose levels hold a few thousand rows
+// and fewer, as ONE persistent launch forward and ONE backward.  The Python side (doda_amd/model.py: UBlock._coarse_steps)
+// flattens the subtree into STEPS; this file expands them into executor ops, owns the intermediate tensors and the
+// autograd node.  No arithmetic here: every op is a kernel phase of libdoda_hip.so.
+//   step RB   (kind 0): tensors {subm table, bn1 x5, conv1 x3, bn2 x5, conv2 x3, skip conv x3 | None x3, identity table | None}
+//                       scalars {eps1, momentum1, eps2, momentum2}
+//   step DOWN (kind 1): tensors {child [8, m], par_off [8, n], bn x5, conv x3}        scalars {eps, momentum, m}
+//   step UP   (kind 2): tensors {par_off [8, n], child [8, m], bn x5, conv x3}        scalars {eps, momentum, n}
+// bn x5 = gamma, beta, running_mean, running_var, num_batches_tracked; conv x3 = weight, packed forward, packed data-grad.
+namespace coarse {
+
+typedef std::vector<c10::optional<at::Tensor>> TList;
+
+struct Arena {   // device scratch that is never handed out as a tensor: a few chunks instead of a hundred allocations
+    std::vector<at::Tensor> chunks;
+    char *cur = nullptr;
+    size_t left = 0;
+    at::TensorOptions opt;
+    void *alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes > left) {
+            const size_t sz = bytes > ((size_t)2 << 20) ? bytes : ((size_t)2 << 20);
+            chunks.push_back(at::empty({(int64_t)sz}, opt));
+            cur = (char *)chunks.back().data_ptr();
+            left = sz;
+        }
+        void *p = cur;
+        cur += bytes;
+        left -= bytes;
+        return p;
+    }
+    float *floats(size_t n) { return (float *)alloc(n * 4); }
+};
+
+struct Val {   // a bf16 [rows, c] matrix: dense, or a column slice of a wider one (ld > c)
+    void *p = nullptr;
+    int rows = 0, c = 0, ld = 0;
+    at::Tensor t;                 // the dense tensor holding it, when there is one (operands of the weight gradients)
+    float *stats = nullptr;       // (sum, sum of squares) partial rows of columns [0, c_split)
+    float *stats_b = nullptr;     // ... of columns [c_split, c): a concatenation
+    int c_split = 0;
+};
+
+struct BNP { at::Tensor gamma, beta, rm, rv, nbt; float eps = 0.f, mom = 0.f; };
+struct CVP { at::Tensor weight, pk_fwd, pk_bwd; };
+
+struct Layer {   // BatchNorm -> ReLU -> conv, as the backward pass needs it
+    BNP bn;
+    CVP cv;
+    Val x;                      // the BatchNorm's input
+    at::Tensor a;               // its output = the conv's input (dense: operand of the weight gradient)
+    float *mean = nullptr, *invstd = nullptr;
+    at::Tensor fwd_tbl, bwd_tbl;
+    int K = 0, n_in = 0, n_out = 0, c_in = 0, c_out = 0;
+};
+
+struct Step {
+    int kind = 0;
+    Layer l1, l2;               // RB: both; DOWN / UP: l1
+    bool has_skip = false;
+    CVP skip;
+    at::Tensor ident;           // identity table of the 1x1 skip conv (weight-gradient job)
+};
+
+inline BNP bn_of(const TList &t, size_t at_, double eps, double mom) {
+    BNP b;
+    b.gamma = *t[at_]; b.beta = *t[at_ + 1]; b.rm = *t[at_ + 2]; b.rv = *t[at_ + 3];
+    if (t[at_ + 4].has_value() && t[at_ + 4]->defined()) b.nbt = *t[at_ + 4];
+    b.eps = (float)eps; b.mom = (float)mom;
+    TORCH_CHECK(b.gamma.scalar_type() == at::kFloat && b.beta.scalar_type() == at::kFloat && b.rm.scalar_type() == at::kFloat &&
+                b.rv.scalar_type() == at::kFloat && b.gamma.is_contiguous() && b.beta.is_contiguous() && b.rm.is_contiguous() &&
+                b.rv.is_contiguous(), "doda coarse: BatchNorm vectors must be contiguous fp32");
+    return b;
+}
+inline CVP cv_of(const TList &t, size_t at_) {
+    CVP c;
+    TORCH_CHECK(t[at_].has_value() && t[at_ + 1].has_value() && t[at_ + 2].has_value(), "doda coarse: conv needs weight + packed copies");
+    c.weight = *t[at_]; c.pk_fwd = *t[at_ + 1]; c.pk_bwd = *t[at_ + 2];
+    return c;
+}
+
+struct SyncState { at::Tensor words; };
+std::mutex g_sync_mu;
+std::unordered_map<int, SyncState> g_sync;
+uint32_t *sync_words(const at::Tensor &like) {
+    std::lock_guard<std::mutex> lock(g_sync_mu);
+    SyncState &s = g_sync[(int)like.device().index()];
+    if (!s.words.defined()) s.words = at::zeros({4}, like.options().dtype(at::kInt));
+    return (uint32_t *)s.words.data_ptr();
+}
+
+struct Builder {
+    std::vector<doda_cx_op> ops;
+    Arena arena;
+    int G = 0;
+    at::TensorOptions bf;
+    bool first = true;
+
+    doda_cx_op &push(int kind, int flags) {
+        ops.emplace_back();
+        doda_cx_op &o = ops.back();
+        memset(&o, 0, sizeof(o));
+        o.kind = kind;
+        o.flags = flags;
+        o.n_part = G;
+        return o;
+    }
+    Val dense(int rows, int c, bool as_tensor) {
+        Val v;
+        v.rows = rows; v.c = c; v.ld = c;
+        if (as_tensor) { v.t = at::empty({rows, c}, bf); v.p = v.t.data_ptr(); }
+        else v.p = arena.alloc((size_t)rows * c * 2);
+        return v;
+    }
+    void run(const at::Tensor &like) {
+        if (ops.empty()) return;
+        const size_t nb = doda_coarse_desc_bytes((int32_t)ops.size());
+        void *desc = arena.alloc(nb);
+        check(doda_coarse_run(ops.data(), (int32_t)ops.size(), desc, nb, sync_words(like), stream_of(like)), "doda_coarse_run");
+    }
+
+    // ---- forward ----
+    void stats_of(Val &x) {   // a tensor that arrives without statistics (the executor's input)
+        x.stats = arena.floats((size_t)G * 2 * x.c);
+        x.stats_b = nullptr;
+        x.c_split = x.c;
+        doda_cx_op &o = push(DODA_CX_STATS, first ? 0 : DODA_CX_F_BARRIER);
+        o.rows = x.rows; o.c_in = x.c; o.x_ld = x.ld; o.x = x.p; o.stats = x.stats;
+        first = false;
+    }
+    void bn_fwd(Layer &L, bool training) {
+        Val &x = L.x;
+        if (training && !x.stats) stats_of(x);
+        L.a = at::empty({x.rows, x.c}, bf);
+        doda_cx_op &o = push(DODA_CX_BNFWD, (first ? 0 : DODA_CX_F_BARRIER) | DODA_CX_F_RELU | (training ? DODA_CX_F_TRAINING : 0));
+        first = false;
+        o.rows = x.rows; o.c_in = x.c; o.x_ld = x.ld; o.y_ld = x.c; o.x = x.p; o.y = L.a.data_ptr();
+        o.eps = L.bn.eps; o.momentum = L.bn.mom;
+        o.gamma = (const float *)L.bn.gamma.data_ptr(); o.beta = (const float *)L.bn.beta.data_ptr();
+        o.running_mean = (float *)L.bn.rm.data_ptr(); o.running_var = (float *)L.bn.rv.data_ptr();
+        if (training) {
+            L.mean = arena.floats(x.c); L.invstd = arena.floats(x.c);
+            o.mean = L.mean; o.invstd = L.invstd;
+            o.stats = x.stats; o.stats_b = x.stats_b; o.c_split = x.c_split > 0 ? x.c_split : x.c;
+            o.nbt = L.bn.nbt.defined() ? (int64_t *)L.bn.nbt.data_ptr() : nullptr;
+        } else {
+            // evaluation: the running statistics; backward (running statistics as constants) is not the executor's business
+            o.c_split = x.c;
+        }
+    }
+    // y = conv(L.a) (+ res), statistics of y when `want_stats`; `out` preset (p / ld) = where y goes
+    void gemm_fwd(Layer &L, const at::Tensor &tbl, bool identity, Val &out, const Val *res, bool want_stats, bool barrier) {
+        doda_cx_op &o = push(DODA_CX_GEMM, (barrier ? DODA_CX_F_BARRIER : 0) | (identity ? DODA_CX_F_IDENTITY : 0));
+        first = false;
+        o.rows = out.rows; o.rows_in = (int32_t)L.a.size(0); o.c_in = (int32_t)L.a.size(1); o.c_out = out.c;
+        o.K = identity ? 1 : (int32_t)tbl.size(0);
+        o.tbl = identity ? nullptr : (const int32_t *)tbl.data_ptr();
+        o.tbl_ld = identity ? out.rows : (int32_t)tbl.size(1);
+        o.x = L.a.data_ptr(); o.x_ld = (int32_t)L.a.size(1);
+        o.w = L.cv.pk_fwd.data_ptr();
+        o.y = out.p; o.y_ld = out.ld;
+        if (res) { o.res = res->p; o.res_ld = res->ld; }
+        if (want_stats) {
+            out.stats = arena.floats((size_t)G * 2 * out.c);
+            out.stats_b = nullptr;
+            out.c_split = out.c;
+            o.stats = out.stats;
+        }
+    }
+};
+
+struct CoarseNode : public torch::autograd::Node {
+    std::vector<Step> steps;
+    std::vector<at::Tensor> keep;      // arena chunks and tensors the saved pointers refer to
+    at::Tensor x_in;                   // (kept for its size / options)
+    int G = 0;
+
+    // gamma / beta gradient targets: the reducer's bucket views when the parameters have homes, existing .grad tensors
+    // (accumulate) or fresh tensors deposited afterwards
+    struct PGrad { at::Tensor param, buf; bool accum = false, fresh = false; };
+
+    variable_list apply(variable_list &&grads) override {
+        host_timing::Scope host_scope(5);
+        variable_list out(1);
+        if (!grads[0].defined()) return out;
+        at::Tensor g = grads[0].contiguous();
+        TORCH_CHECK(g.scalar_type() == at::kBFloat16, "doda coarse: gradient dtype");
+        Builder B;
+        B.G = G;
+        B.bf = g.options();
+        B.arena.opt = g.options().dtype(at::kByte);
+        const int task = torch::autograd::get_current_graph_task_id();
+        std::vector<PGrad> pgrads;
+        auto pgrad = [&](const at::Tensor &param, int64_t c, int &flags) -> float * {
+            PGrad pg;
+            pg.param = param;
+            at::Tensor cur = param.grad();
+            if (cur.defined() && cur.scalar_type() == at::kFloat && cur.is_contiguous() && cur.numel() == c) {
+                pg.buf = cur; pg.accum = true; flags |= DODA_CX_F_ACCUM;
+            } else {
+                at::Tensor h;
+                if (param.is_leaf() && param.scalar_type() == at::kFloat && param.numel() == c) h = take_grad_home(param, task);
+                pg.buf = h.defined() ? h : at::empty({c}, param.options().dtype(at::kFloat));
+                pg.fresh = true;
+            }
+            pgrads.push_back(pg);
+            return (float *)pg.buf.data_ptr();
+        };
+        struct WJob { at::Tensor a, b, tbl, weight; int64_t n_rows; };
+        std::vector<WJob> wjobs;
+        bool first = true;
+        // dz = data gradient of L's conv applied to `dy`, masked by L's ReLU; statistics for L's BatchNorm backward
+        auto gemm_bwd = [&](const Layer &L, const at::Tensor &dy, bool identity, float *&st, bool barrier) -> void * {
+            void *dz = B.arena.alloc((size_t)L.n_in * L.c_in * 2);
+            st = B.arena.floats((size_t)G * 2 * L.c_in);
+            doda_cx_op &o = B.push(DODA_CX_GEMM, (barrier && !first ? DODA_CX_F_BARRIER : 0) | DODA_CX_F_RELU | (identity ? DODA_CX_F_IDENTITY : 0));
+            first = false;
+            o.rows = L.n_in; o.rows_in = L.n_out; o.c_in = L.c_out; o.c_out = L.c_in;
+            o.K = identity ? 1 : (int32_t)L.bwd_tbl.size(0);
+            o.tbl = identity ? nullptr : (const int32_t *)L.bwd_tbl.data_ptr();
+            o.tbl_ld = identity ? L.n_in : (int32_t)L.bwd_tbl.size(1);
+            o.x = dy.data_ptr(); o.x_ld = L.c_out;
+            o.w = L.cv.pk_bwd.data_ptr();
+            o.y = dz; o.y_ld = L.c_in;
+            o.aux = L.x.p; o.aux_ld = L.x.ld;
+            o.mean = L.mean; o.invstd = L.invstd;
+            o.gamma = (const float *)L.bn.gamma.data_ptr(); o.beta = (const float *)L.bn.beta.data_ptr();
+            o.stats = st;
+            return dz;
+        };
+        // gradient of L's BatchNorm input from dz (+ add); a concatenated input splits into two dense tensors
+        auto bn_bwd = [&](const Layer &L, void *dz, float *st, const at::Tensor &add, at::Tensor &left, at::Tensor &right) {
+            int flags = DODA_CX_F_BARRIER;
+            const int c = L.c_in;
+            const int split = (L.x.c_split > 0 && L.x.c_split < c) ? L.x.c_split : c;
+            left = at::empty({L.n_in, split}, B.bf);
+            keep_alive.push_back(left);   // (every tensor an op points at stays alive until the launch is queued: a freed block
+            //                               could be handed out again by the next at::empty of this very pass)
+            if (split < c) { right = at::empty({L.n_in, c - split}, B.bf); keep_alive.push_back(right); }
+            float *dg = nullptr, *db = nullptr;
+            {
+                int f1 = 0, f2 = 0;
+                dg = pgrad(L.bn.gamma, c, f1);
+                db = pgrad(L.bn.beta, c, f2);
+                if ((f1 != 0) != (f2 != 0)) {   // one accumulates, the other does not: give both fresh buffers and add afterwards
+                    PGrad &pa = pgrads[pgrads.size() - 2], &pb = pgrads.back();
+                    if (pa.accum) { pa.buf = at::empty({c}, pa.param.options().dtype(at::kFloat)); pa.accum = false; pa.fresh = true; dg = (float *)pa.buf.data_ptr(); }
+                    if (pb.accum) { pb.buf = at::empty({c}, pb.param.options().dtype(at::kFloat)); pb.accum = false; pb.fresh = true; db = (float *)pb.buf.data_ptr(); }
+                } else if (f1) flags |= DODA_CX_F_ACCUM;
+            }
+            doda_cx_op &o = B.push(DODA_CX_BNBWD, flags);
+            o.rows = L.n_in; o.c_in = c; o.c_split = split;
+            o.x = dz; o.x_ld = c;
+            o.aux = L.x.p; o.aux_ld = L.x.ld;
+            if (add.defined()) { o.res = add.data_ptr(); o.res_ld = (int32_t)add.size(1); }
+            o.y = left.data_ptr(); o.y_ld = split;
+            if (split < c) { o.y2 = right.data_ptr(); o.y2_ld = c - split; }
+            o.stats = st;
+            o.mean = L.mean; o.invstd = L.invstd;
+            o.gamma = (const float *)L.bn.gamma.data_ptr();
+            o.dgamma = dg; o.dbeta = db;
+        };
+        std::vector<at::Tensor> skip_grads;
+        for (size_t si = steps.size(); si-- > 0;) {
+            const Step &S = steps[si];
+            if (S.kind == 0) {
+                float *st2 = nullptr, *st1 = nullptr;
+                void *dz2 = gemm_bwd(S.l2, g, false, st2, true);
+                at::Tensor gS;
+                if (S.has_skip) {   // data gradient of the 1x1 skip conv: no mask, no statistics; independent of dz2
+                    gS = at::empty({S.l1.n_in, S.l1.c_in}, B.bf);
+                    keep_alive.push_back(gS);
+                    doda_cx_op &o = B.push(DODA_CX_GEMM, DODA_CX_F_IDENTITY);
+                    o.rows = S.l1.n_in; o.rows_in = S.l1.n_in; o.c_in = S.l2.c_out; o.c_out = S.l1.c_in; o.K = 1; o.tbl_ld = S.l1.n_in;
+                    o.x = g.data_ptr(); o.x_ld = S.l2.c_out; o.w = S.skip.pk_bwd.data_ptr(); o.y = gS.data_ptr(); o.y_ld = S.l1.c_in;
+                }
+                at::Tensor g1, none;
+                bn_bwd(S.l2, dz2, st2, at::Tensor(), g1, none);
+                void *dz1 = gemm_bwd(S.l1, g1, false, st1, true);
+                at::Tensor left, right;
+                bn_bwd(S.l1, dz1, st1, S.has_skip ? gS : g, left, right);
+                wjobs.push_back({S.l2.a, g, S.l2.fwd_tbl, S.l2.cv.weight, S.l2.n_out});
+                wjobs.push_back({S.l1.a, g1, S.l1.fwd_tbl, S.l1.cv.weight, S.l1.n_out});
+                if (S.has_skip) wjobs.push_back({S.l1.x.t, g, S.ident, S.skip.weight, S.l1.n_in});
+                if (right.defined()) { skip_grads.push_back(left); g = right; }
+                else g = left;
+            } else {
+                float *st = nullptr;
+                void *dz = gemm_bwd(S.l1, g, false, st, true);
+                at::Tensor add, left, none;
+                if (S.kind == 1) {
+                    TORCH_CHECK(!skip_grads.empty(), "doda coarse: unbalanced down / up steps");
+                    add = skip_grads.back();
+                    skip_grads.pop_back();
+                }
+                bn_bwd(S.l1, dz, st, add, left, none);
+                wjobs.push_back({S.l1.a, g, S.l1.fwd_tbl, S.l1.cv.weight, S.l1.n_out});
+                g = left;
+            }
+        }
+        B.run(g);
+        // parameter gradients: the weight gradients join the step's deferred launch; gamma / beta are bound now
+        for (WJob &w : wjobs) {
+            if (!try_defer_wgrad(w.a, w.b, w.tbl, w.n_rows, w.weight, PairLists()))
+                deposit_grad(w.weight, wgrad(w.a, w.b, w.tbl, w.n_rows).reshape(w.weight.sizes()).to(w.weight.scalar_type()));
+        }
+        for (PGrad &pg : pgrads)
+            if (pg.fresh) deposit_grad(pg.param, pg.buf);
+        // (the arena of this pass must outlive the launch: the caching allocator re-uses a freed block only for work queued
+        // LATER on this stream, which is ordered behind the launch)
+        keep_alive.clear();
+        if (task_should_compute_output(0)) out[0] = g;
+        return out;
+    }
+    std::vector<at::Tensor> keep_alive;
+    void release_variables() override {
+        steps.clear();
+        keep.clear();
+        x_in.reset();
+    }
+    std::string name() const override { return "DodaCoarseUBlockBackward"; }
+};
+
+// Returns {y [n, c] bf16, statistics partial rows of y [G, 2, c] (training) or undefined}.
+std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optional<at::Tensor> &stats_in, const std::vector<int64_t> &kinds,
+                                      const std::vector<TList> &tensors, const std::vector<std::vector<double>> &scalars, bool training) {
+    host_timing::Scope host_scope(6);
+    TORCH_CHECK(x_in.is_cuda() && x_in.dim() == 2 && x_in.scalar_type() == at::kBFloat16 && x_in.size(0) >= 2,
+                "doda coarse_ublock: bf16 device features");
+    TORCH_CHECK(kinds.size() == tensors.size() && kinds.size() == scalars.size() && !kinds.empty(), "doda coarse_ublock: step lists");
+    const bool need_grad = at::GradMode::is_enabled() && x_in.requires_grad();
+    TORCH_CHECK(!need_grad || (training && g_direct_grads && g_defer_wgrad),
+                "doda coarse_ublock: a differentiable call needs training mode with deferred weight gradients and direct parameter gradients");
+    at::AutoDispatchBelowADInplaceOrView guard;
+    const at::Tensor x = x_in.contiguous();
+    Builder B;
+    B.G = doda_coarse_workgroups();
+    B.bf = x.options();
+    B.arena.opt = x.options().dtype(at::kByte);
+    std::vector<Step> steps(kinds.size());
+    Val cur;
+    cur.p = x.data_ptr(); cur.rows = (int)x.size(0); cur.c = (int)x.size(1); cur.ld = cur.c; cur.t = x;
+    at::Tensor stats_keep;
+    if (training && stats_in.has_value() && stats_in->defined() && stats_in->dim() == 3 && stats_in->size(0) == B.G &&
+        stats_in->size(2) == cur.c && stats_in->scalar_type() == at::kFloat && stats_in->is_contiguous()) {
+        stats_keep = *stats_in;
+        cur.stats = (float *)stats_keep.data_ptr();
+        cur.c_split = cur.c;
+    }
+    struct Skip { Val left; at::Tensor cat; };
+    std::vector<Skip> skips;
+    at::Tensor y_out, y_stats;
+    for (size_t si = 0; si < kinds.size(); ++si) {
+        Step &S = steps[si];
+        const TList &t = tensors[si];
+        const std::vector<double> &sc = scalars[si];
+        S.kind = (int)kinds[si];
+        const bool last = si + 1 == kinds.size();
+        if (S.kind == 0) {
+            TORCH_CHECK(t.size() == 21 && sc.size() == 4 && t[0].has_value(), "doda coarse_ublock: RB step");
+            const at::Tensor &tbl = *t[0];
+            const int n = cur.rows;
+            TORCH_CHECK(tbl.dim() == 2 && tbl.size(0) == 27 && tbl.size(1) == n && tbl.scalar_type() == at::kInt, "doda coarse_ublock: SubM table");
+            S.l1.bn = bn_of(t, 1, sc[0], sc[1]);
+            S.l1.cv = cv_of(t, 6);
+            S.l2.bn = bn_of(t, 9, sc[2], sc[3]);
+            S.l2.cv = cv_of(t, 14);
+            S.has_skip = t[17].has_value() && t[17]->defined();
+            const int cin = cur.c, cout = (int)S.l1.cv.weight.size(-1);
+            TORCH_CHECK(S.l1.cv.weight.size(-2) == cin && S.l2.cv.weight.size(-2) == cout && S.l2.cv.weight.size(-1) == cout &&
+                        (S.has_skip || cin == cout), "doda coarse_ublock: channel counts of a residual block");
+            S.l1.x = cur;
+            S.l1.fwd_tbl = S.l1.bwd_tbl = S.l2.fwd_tbl = S.l2.bwd_tbl = tbl;
+            S.l1.K = S.l2.K = 27;
+            S.l1.n_in = S.l1.n_out = S.l2.n_in = S.l2.n_out = n;
+            S.l1.c_in = cin; S.l1.c_out = cout; S.l2.c_in = cout; S.l2.c_out = cout;
+            B.bn_fwd(S.l1, training);
+            Val y1 = B.dense(n, cout, false);
+            B.gemm_fwd(S.l1, tbl, false, y1, nullptr, training, true);
+            Val skipv = cur;
+            if (S.has_skip) {   // 1x1 conv of the block's raw input (no barrier: nothing it reads was written since the last one)
+                S.skip = cv_of(t, 17);
+                TORCH_CHECK(t[20].has_value(), "doda coarse_ublock: identity table of the skip conv");
+                S.ident = *t[20];
+                TORCH_CHECK(cur.t.defined() && cur.ld == cur.c, "doda coarse_ublock: the skip conv's input must be dense");
+                skipv = B.dense(n, cout, false);
+                Layer sk;
+                sk.a = cur.t;
+                sk.cv = S.skip;
+                B.gemm_fwd(sk, at::Tensor(), true, skipv, nullptr, false, false);
+            }
+            S.l2.x = y1;
+            B.bn_fwd(S.l2, training);
+            // where the block's output goes: the left half of the concatenation when a strided conv follows
+            Val y;
+            if (!last && kinds[si + 1] == 1) {
+                at::Tensor cat = at::empty({n, 2 * cout}, B.bf);
+                y.p = cat.data_ptr(); y.rows = n; y.c = cout; y.ld = 2 * cout;
+                skips.push_back({Val(), cat});
+            } else {
+                y = B.dense(n, cout, last);
+                if (last) y_out = y.t;
+            }
+            if (last && training) {   // the caller may feed these rows to the next fused BatchNorm
+                y_stats = at::empty({B.G, 2, cout}, x.options().dtype(at::kFloat));
+            }
+            B.gemm_fwd(S.l2, tbl, false, y, &skipv, training, true);
+            if (last && training) {   // (gemm_fwd put the partial rows into the arena: point the op at the returned tensor instead)
+                B.ops.back().stats = (float *)y_stats.data_ptr();
+                y.stats = (float *)y_stats.data_ptr();
+            }
+            if (!last && kinds[si + 1] == 1) skips.back().left = y;
+            cur = y;
+        } else if (S.kind == 1 || S.kind == 2) {
+            TORCH_CHECK(t.size() == 10 && sc.size() == 3 && t[0].has_value() && t[1].has_value(), "doda coarse_ublock: down / up step");
+            S.l1.bn = bn_of(t, 2, sc[0], sc[1]);
+            S.l1.cv = cv_of(t, 7);
+            S.l1.fwd_tbl = *t[0];
+            S.l1.bwd_tbl = *t[1];
+            S.l1.K = 8;
+            const int n_out = (int)sc[2], cin = cur.c, cout = (int)S.l1.cv.weight.size(-1);
+            TORCH_CHECK(S.l1.fwd_tbl.size(0) == 8 && S.l1.fwd_tbl.size(1) == n_out && S.l1.bwd_tbl.size(0) == 8 && S.l1.bwd_tbl.size(1) == cur.rows &&
+                        S.l1.cv.weight.size(-2) == cin, "doda coarse_ublock: strided rulebook / channels");
+            S.l1.x = cur;
+            S.l1.n_in = cur.rows; S.l1.n_out = n_out; S.l1.c_in = cin; S.l1.c_out = cout;
+            B.bn_fwd(S.l1, training);
+            if (S.kind == 1) {
+                Val d = B.dense(n_out, cout, false);
+                B.gemm_fwd(S.l1, S.l1.fwd_tbl, false, d, nullptr, training, true);
+                cur = d;
+            } else {
+                TORCH_CHECK(!skips.empty(), "doda coarse_ublock: unbalanced down / up steps");
+                Skip sk = skips.back();
+                skips.pop_back();
+                TORCH_CHECK(sk.left.rows == n_out && sk.left.c == cout, "doda coarse_ublock: the inverse conv must restore the skipped level");
+                Val u;
+                u.p = (char *)sk.cat.data_ptr() + (size_t)cout * 2; u.rows = n_out; u.c = cout; u.ld = 2 * cout;
+                B.gemm_fwd(S.l1, S.l1.fwd_tbl, false, u, nullptr, training, true);
+                Val cat;
+                cat.p = sk.cat.data_ptr(); cat.rows = n_out; cat.c = 2 * cout; cat.ld = 2 * cout; cat.t = sk.cat;
+                cat.stats = sk.left.stats; cat.stats_b = u.stats; cat.c_split = cout;
+                cur = cat;
+            }
+        } else {
+            TORCH_CHECK(false, "doda coarse_ublock: unknown step kind");
+        }
+    }
+    TORCH_CHECK(y_out.defined() && skips.empty(), "doda coarse_ublock: the last step must be a residual block at the input's level");
+    B.run(x);
+    g_last_bn.reset();
+    if (need_grad) {
+        auto node = std::shared_ptr<CoarseNode>(new CoarseNode(), torch::autograd::deleteNode);
+        node->set_next_edges(torch::autograd::collect_next_edges(x_in));
+        node->steps = std::move(steps);
+        node->keep = B.arena.chunks;
+        if (stats_keep.defined()) node->keep.push_back(stats_keep);
+        node->keep.push_back(x);
+        node->x_in = x;
+        node->G = B.G;
+        torch::autograd::set_history(y_out, node);
+    }
+    return {y_out, y_stats};
+}
+
+}  // namespace coarse
+
 }  // namespace
 
 // ---- optimizer step: all parameters in one launch (doda_sgd_multi) ------------------------------------
@@ -1227,6 +1697,20 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           }, "set .grad of every listed parameter to None (203 Python attribute stores per step otherwise)");
     m.def("sgd_step", &sgd_step, "torch.optim.SGD's update of all parameters in one launch",
           py::call_guard<py::gil_scoped_release>());
+    m.def("coarse_ublock", [](const at::Tensor &x, const c10::optional<at::Tensor> &stats_in, const std::vector<int64_t> &kinds,
+                              const std::vector<std::vector<c10::optional<at::Tensor>>> &tensors,
+                              const std::vector<std::vector<double>> &scalars, bool training) {
+        auto r = coarse::coarse_ublock(x, stats_in, kinds, tensors, scalars, training);
+        return std::make_pair(r[0], r[1].defined() ? c10::optional<at::Tensor>(r[1]) : c10::nullopt);
+    }, "a U-Net subtree of coarse levels as one persistent launch per direction (doda_coarse_run)",
+          py::arg("x"), py::arg("stats_in"), py::arg("kinds"), py::arg("tensors"), py::arg("scalars"), py::arg("training"));
+    m.def("coarse_workgroups", []() { return (int64_t)doda_coarse_workgroups(); });
+    m.def("coarse_error", [](int64_t device) {   // a grid barrier of an earlier executor launch on `device` timed out (synchronises)
+        std::lock_guard<std::mutex> lock(coarse::g_sync_mu);
+        auto it = coarse::g_sync.find((int)device);
+        if (it == coarse::g_sync.end() || !it->second.words.defined()) return false;
+        return it->second.words.cpu()[1].item<int32_t>() != 0;
+    });
     m.def("abi_version", []() { return doda_abi_version(); });
     m.def("built_for_abi", []() { return (int)DODA_ABI_VERSION; });
 }

@@ -207,6 +207,39 @@ class VGGBlock(SparseModule):
         return self.conv_layers(input)
 
 
+# Coarse-level executor (csrc/coarse.hip): the UBlock subtree from level COARSE_EXEC_LEVEL down runs as ONE
+# persistent launch forward and ONE backward (bf16 features, compiled extension, training with deferred weight gradients and
+# direct parameter gradients, or any no-grad pass).  DODA_COARSE_EXEC=0: layer by layer as before.
+COARSE_EXEC = _os.environ.get("DODA_COARSE_EXEC", "1") == "1"
+COARSE_EXEC_LEVEL = int(_os.environ.get("DODA_COARSE_LEVEL", "5"))
+COARSE_MAX_ROWS = int(_os.environ.get("DODA_COARSE_MAX_ROWS", "16384"))   # above: the whole-chip per-layer kernels win
+
+
+def set_coarse_exec(on, level=None):
+    global COARSE_EXEC, COARSE_EXEC_LEVEL
+    COARSE_EXEC = bool(on)
+    if level is not None:
+        COARSE_EXEC_LEVEL = int(level)
+    return COARSE_EXEC
+
+
+def _bn_list(bn):
+    return [bn._parameters["weight"], bn._parameters["bias"], bn._buffers["running_mean"], bn._buffers["running_var"],
+            bn._buffers["num_batches_tracked"]]
+
+
+def _plain_bn(m):
+    return (type(m) is nn.BatchNorm1d and m.affine and m.track_running_stats and m.momentum is not None
+            and not (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks)
+            and m._parameters["weight"].dtype == torch.float32)
+
+
+def _plain_conv(m, cls, ksize):
+    return (type(m) is cls and m.bias is None and m.kernel_size == ksize and m._parameters["weight"].dtype == torch.float32
+            and m.in_channels % 16 == 0 and m.out_channels % 16 == 0 and m.in_channels >= 32
+            and not (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks))
+
+
 # Level at which the forward pass turns launch-floor bound (a few thousand rows and fewer): PyramidPrefetcher starts the
 # NEXT batch's rulebook kernels there instead of next to the level-1 convolutions (see PyramidPrefetcher.submit).
 COARSE_LEVEL = 4
@@ -237,10 +270,124 @@ class UBlock(nn.Module):
                 ("block%d" % r, block(c * (2 - r) if r < 2 else c, c, norm_fn, indice_key=subm_key))
                 for r in range(block_reps)))
 
+    # ---- the subtree as executor steps (csrc_ext coarse_ublock) ----
+    def _coarse_modules(self):
+        """Static part: [("rb", block) | ("down", seq, level) | ("up", seq, level)] in execution order, or False when a
+        module of the subtree is not the plain reference form (model/unet_block.py:9-37,55-100)."""
+        plan = self.__dict__.get("_doda_coarse")
+        if plan is not None:
+            return plan
+        steps, ok = [], [True]
+
+        def walk(ub):
+            for blk in ub.blocks._modules.values():
+                steps.append(("rb", blk, ub.level))
+            if len(ub.nPlanes) > 1:
+                steps.append(("down", ub.conv, ub.level))
+                walk(ub.u)
+                steps.append(("up", ub.deconv, ub.level))
+                for blk in ub.blocks_tail._modules.values():
+                    steps.append(("rb", blk, ub.level))
+
+        walk(self)
+        for kind, m, _ in steps:
+            if kind == "rb":
+                mods = list(m.conv_branch._modules.values()) if type(m) is ResidualBlock else []
+                sk = list(m.i_branch._modules.values()) if type(m) is ResidualBlock else []
+                good = (len(mods) == 6 and _plain_bn(mods[0]) and type(mods[1]) is nn.ReLU and _plain_conv(mods[2], spconv.SubMConv3d, [3, 3, 3])
+                        and _plain_bn(mods[3]) and type(mods[4]) is nn.ReLU and _plain_conv(mods[5], spconv.SubMConv3d, [3, 3, 3])
+                        and mods[2].indice_key == mods[5].indice_key and len(sk) == 1
+                        and (type(sk[0]) is nn.Identity or _plain_conv(sk[0], spconv.SubMConv3d, [1, 1, 1]))
+                        and not (m._forward_hooks or m._forward_pre_hooks or m.conv_branch._forward_hooks or m.i_branch._forward_hooks))
+            else:
+                mods = list(m._modules.values())
+                cls = spconv.SparseConv3d if kind == "down" else spconv.SparseInverseConv3d
+                good = (len(mods) == 3 and _plain_bn(mods[0]) and type(mods[1]) is nn.ReLU and _plain_conv(mods[2], cls, [2, 2, 2])
+                        and (kind == "up" or mods[2].stride == [2, 2, 2]) and not (m._forward_hooks or m._forward_pre_hooks))
+            ok[0] = ok[0] and good
+        plan = self.__dict__["_doda_coarse"] = steps if ok[0] else False
+        return plan
+
+    def _forward_coarse(self, input):
+        """The whole subtree in one executor call, or None when a precondition fails (then the modules run one by one)."""
+        ext = Fsp._ext
+        feats = input.features
+        if (ext is None or not Fsp._SERIAL or not hasattr(ext, "coarse_ublock") or not feats.is_cuda
+                or feats.dtype != torch.bfloat16 or feats.dim() != 2 or not (2 <= feats.shape[0] <= COARSE_MAX_ROWS)
+                or _torch_module._global_forward_hooks or _torch_module._global_forward_pre_hooks
+                or _torch_module._global_backward_hooks or _torch_module._global_backward_pre_hooks):
+            return None
+        plan = self._coarse_modules()
+        if plan is False:
+            return None
+        training = self.training
+        grad = torch.is_grad_enabled() and feats.requires_grad
+        if grad and not (training and ext.get_defer_wgrad() and ext.get_direct_grads()):
+            return None
+        idict = input.indice_dict
+        kinds, tensors, scalars = [], [], []
+        rows = {self.level: feats.shape[0]}
+        for kind, m, lvl in plan:
+            if kind == "rb":
+                mods = list(m.conv_branch._modules.values())
+                bn1, c1, bn2, c2 = mods[0], mods[2], mods[3], mods[5]
+                data = idict.get(c1.indice_key)
+                if (data is None or data.kind != "subm" or data.tbl.shape[1] != rows.get(lvl) or bn1.training != training
+                        or bn2.training != training):
+                    return None
+                pk1, pk2 = c1._packed(feats, idict), c2._packed(feats, idict)
+                if pk1 is None or pk2 is None:
+                    return None
+                sk = m.i_branch[0]
+                if type(sk) is nn.Identity:
+                    skt = [None, None, None, None]
+                else:
+                    pks = sk._packed(feats, idict)
+                    if pks is None:
+                        return None
+                    skt = [sk._parameters["weight"], pks[0], pks[1], _cv._identity_table(rows[lvl], feats.device)]
+                kinds.append(0)
+                tensors.append([data.tbl] + _bn_list(bn1) + [c1._parameters["weight"], pk1[0], pk1[1]] + _bn_list(bn2)
+                               + [c2._parameters["weight"], pk2[0], pk2[1]] + skt)
+                scalars.append([bn1.eps, bn1.momentum, bn2.eps, bn2.momentum])
+            else:
+                mods = list(m._modules.values())
+                bn, cv = mods[0], mods[2]
+                data = idict.get(cv.indice_key)
+                if data is None or data.kind != "down2" or bn.training != training or data.tbl_rev.shape[1] != rows.get(lvl):
+                    return None
+                pk = cv._packed(feats, idict)
+                if pk is None:
+                    return None
+                if kind == "down":
+                    rows[lvl + 1] = data.outids.shape[0]
+                    if rows[lvl + 1] < 2:
+                        return None
+                    kinds.append(1)
+                    tensors.append([data.tbl, data.tbl_rev] + _bn_list(bn) + [cv._parameters["weight"], pk[0], pk[1]])
+                    scalars.append([bn.eps, bn.momentum, rows[lvl + 1]])
+                else:
+                    kinds.append(2)
+                    tensors.append([data.tbl_rev, data.tbl] + _bn_list(bn) + [cv._parameters["weight"], pk[0], pk[1]])
+                    scalars.append([bn.eps, bn.momentum, rows[lvl]])
+        st = input.__dict__.get("_doda_stats")
+        stats_in = st[1] if (st is not None and st[0] is feats and st[2] == feats._version and torch.is_tensor(st[1])) else None
+        y, stats = ext.coarse_ublock(feats, stats_in, kinds, tensors, scalars, training)
+        out = spconv.SparseConvTensor(y, input.indices, input.spatial_shape, input.batch_size)
+        out.indice_dict = idict
+        out.grid = input.grid
+        if stats is not None:
+            out._doda_stats = (y, stats, y._version)
+        return out
+
     def forward(self, input):
         if self.level == COARSE_LEVEL and _coarse_hooks and self.training and torch.is_grad_enabled():   # (training steps only)
             for hook in list(_coarse_hooks):   # the step enters its coarse levels: few rows, most CUs idle from here on
                 hook()
+        if COARSE_EXEC and self.level == COARSE_EXEC_LEVEL:
+            out = self._forward_coarse(input)
+            if out is not None:
+                return out
         out = self.blocks(input)
         if len(self.nPlanes) > 1:
             st_a = out.__dict__.get("_doda_stats")

@@ -785,7 +785,7 @@ class _CxOp(C.Structure):   # doda_cx_op
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
 
 
-_CX_SYNC = {}   # device -> [uint32 [2] tensor, counter value]
+_CX_SYNC = {}   # device -> uint32 [4] tensor (barrier counter, time-out flag, exit counter)
 
 
 def coarse_workgroups():
@@ -795,7 +795,7 @@ def coarse_workgroups():
 def coarse_error(device):
     """True when a grid barrier of an earlier coarse_run on `device` timed out (synchronises)."""
     st = _CX_SYNC.get(torch.device(device))
-    return bool(st is not None and int(st[0][1].item()) != 0)
+    return bool(st is not None and int(st[1].item()) != 0)
 
 
 def coarse_run(ops, device):
@@ -819,10 +819,7 @@ def coarse_run(ops, device):
         arr[k].n_part = coarse_workgroups()
     st = _CX_SYNC.get(device)
     if st is None:
-        st = _CX_SYNC[device] = [torch.zeros(2, dtype=torch.int32, device=device), 0]
+        st = _CX_SYNC[device] = torch.zeros(4, dtype=torch.int32, device=device)
     nbytes = lib().doda_coarse_desc_bytes(n)
     desc = _ws(nbytes, device)
-    nxt = C.c_uint32(0)
-    check(lib().doda_coarse_run(C.cast(arr, C.c_void_p), n, _p(desc), nbytes, _p(st[0]), st[1], C.byref(nxt), _stream()),
-          "doda_coarse_run")
-    st[1] = int(nxt.value)
+    check(lib().doda_coarse_run(C.cast(arr, C.c_void_p), n, _p(desc), nbytes, _p(st), _stream()), "doda_coarse_run")

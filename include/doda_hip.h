@@ -518,10 +518,10 @@ int doda_sgd_multi(const doda_sgd_tensor *tensors_h, int32_t n_tensors, double l
  *                DODA_CX_F_ACCUM, added to) when given.
  * DODA_CX_STATS  stats[p] = (sum x, sum x^2) over the rows workgroup p owns.
  *
- * sync: uint32 [2] device words owned by the caller across calls, zero at first use: [0] the barrier counter — the caller
- * passes the value it holds (`sync_base`: 0, then what *sync_next_h returned) —, [1] set to 1 by a barrier that timed out
- * (a workgroup never arrived: the results are garbage, the launch still terminates).  Calls sharing `sync` must be stream
- * ordered.  desc_dev: doda_coarse_desc_bytes(n_ops) bytes of device scratch for the uploaded ops. */
+ * sync: uint32 [4] device words owned by the caller across calls, zeroed once before the first: [0] the barrier counter and
+ * [2] the exit counter (both back at zero when a launch has ended), [1] set to 1 by a barrier that timed out (a workgroup
+ * never arrived: the results are garbage, the launch still terminates and leaves the counters clean).  Calls sharing
+ * `sync` must be stream ordered.  desc_dev: doda_coarse_desc_bytes(n_ops) bytes of device scratch for the uploaded ops. */
 #define DODA_CX_GEMM 1
 #define DODA_CX_BNFWD 2
 #define DODA_CX_BNBWD 3
@@ -560,7 +560,7 @@ typedef struct doda_cx_op {
 int32_t doda_coarse_workgroups(void);
 size_t doda_coarse_desc_bytes(int32_t n_ops);
 int doda_coarse_run(const doda_cx_op *ops_h, int32_t n_ops, void *desc_dev, size_t desc_bytes, uint32_t *sync_dev,
-                    uint32_t sync_base, uint32_t *sync_next_h, doda_stream_t stream);
+                    doda_stream_t stream);
 
 #ifdef __cplusplus
 }
