@@ -36,15 +36,18 @@ constexpr int CX_SC1 = 16;           // aux bits of a raw buffer access: sc1 (ag
 constexpr unsigned CX_SPIN_LIMIT = 1u << 21;
 
 // LDS map (dynamic)
-constexpr int CX_RED_OFF = 0;                                   // f32x4 [8 waves][8 blocks][64 lanes]
-constexpr int CX_RED_BYTES = CX_WAVES * 8 * 64 * 16;            // 64 KB
-constexpr int CX_OUT_OFF = CX_RED_OFF + CX_RED_BYTES;           // bf16 [128 rows][c_out]
-constexpr int CX_OUT_BYTES = 128 * CX_MAXC * 2;                 // 64 KB
-constexpr int CX_IDX_OFF = CX_OUT_OFF + CX_OUT_BYTES;           // int [8 waves][27][16]
-constexpr int CX_IDX_BYTES = CX_WAVES * 27 * 16 * 4;            // 13.5 KB
+constexpr int CX_CHUNK_OFF = 0;                                 // a chunk of operands (<= 80 KB); after a unit's chunk loop:
+constexpr int CX_RED_BYTES = CX_WAVES * 8 * 64 * 16;            //   f32x4 [8 waves][8 blocks][64 lanes] partial accumulators (64 KB)
+constexpr int CX_OUT_BYTES = 128 * 128 * 2;                     //   + bf16 [128 rows][nbu * 16] output staging (32 KB)
+constexpr int CX_CHUNK_BYTES = CX_RED_BYTES + CX_OUT_BYTES;     // 96 KB
+constexpr int CX_IDX_OFF = CX_CHUNK_OFF + CX_CHUNK_BYTES;       // int [27][128]: the unit's slice of the table
+constexpr int CX_IDX_BYTES = 27 * 128 * 4;                      // 13.5 KB
 constexpr int CX_VEC_OFF = CX_IDX_OFF + CX_IDX_BYTES;           // float [6][CX_MAXC]
 constexpr int CX_VEC_BYTES = 6 * CX_MAXC * 4;
-constexpr int CX_LDS_BYTES = CX_VEC_OFF + CX_VEC_BYTES;         // ~148 KB
+constexpr int CX_WGST_OFF = CX_VEC_OFF + CX_VEC_BYTES;          // float [2][CX_MAXC]: this workgroup's statistics row of a GEMM
+constexpr int CX_WGST_BYTES = 2 * CX_MAXC * 4;
+constexpr int CX_RED_OFF = CX_CHUNK_OFF;                        // (row-local ops: scratch)
+constexpr int CX_LDS_BYTES = CX_WGST_OFF + CX_WGST_BYTES;       // ~118 KB
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t cx_rsrc(const void *p) {
@@ -97,78 +100,132 @@ __device__ __forceinline__ u32x4 cx_pack8(const float (&f)[8]) {
 }
 
 // ---- GEMM -------------------------------------------------------------------------------------------------------------
-// One pass over NBW channel blocks [nb0, nb0 + NBW) of the output.  Wave w: tile (w % tpw) of the unit, offset slice w / tpw.
-template <int NBW>
-__device__ __forceinline__ void cx_gemm_pass(const doda_cx_op &op, int me, int G, char *smem, int nb0) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// A workgroup UNIT = (tpw consecutive 16-row tiles) x (nbu consecutive 16-channel output blocks), all K offsets.  What a
+// single XCD's CU can ingest (~64 B/clk) is the bound here, and a load that is waited for one at a time costs a full L2 /
+// fabric round trip (~1.2 us): a first version whose waves each walked their own (offset, chunk) units — one gathered
+// operand + the weight fragments, wait, MFMAs — spent 1 ms per direction on levels 5-7.  So the operands travel in CHUNKS
+// of `oc` offsets: all 512 threads request a chunk's weight fragments (coalesced 16-byte pieces of the pre-packed buffer)
+// and gathered rows (already in MFMA operand order) into registers — TWO chunks in flight, up to 160 KB per CU —, park a
+// chunk in LDS, and the eight waves multiply it from there: wave = (tile t, slice s of the chunk's (offset, k-chunk)
+// units), the slices of a tile summed in a fixed order through LDS at the end.  The plan (tpw, nbu, oc) is chosen per op on
+// the host (plan_gemm) so that every workgroup gets a unit and no unit ingests more than it must: many tiles -> 64-row
+// units with every channel block (weights read once per 64 rows); few tiles -> the channel blocks spread over workgroups.
+constexpr int CX_LPT = 10;                        // 16-byte loads per thread and chunk (chunk <= 80 KB)
+constexpr int CX_CHUNK_ITEMS = CX_LPT * CX_THREADS;
+
+struct GemmPlan { int tpw, nbu, oc; };
+__host__ __device__ inline GemmPlan unpack_plan(int v) { return GemmPlan{v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff}; }
+inline int pack_plan(const GemmPlan &p) { return p.tpw | (p.nbu << 8) | (p.oc << 16); }
+
+template <int NBU>
+__device__ __forceinline__ void cx_gemm_units(const doda_cx_op &op, int me, int G, char *smem, const GemmPlan pl) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int n_out = op.rows, K = op.K, c_in = op.c_in, c_out = op.c_out;
-    const int CC = (c_in + 31) >> 5, NB = (c_out + 15) >> 4;
+    const int CC = (c_in + 31) >> 5, NB = c_out >> 4;
     const int T = (n_out + 15) >> 4;
     const bool identity = (op.flags & DODA_CX_F_IDENTITY) != 0;
     const bool bwd = op.aux != nullptr;          // ReLU mask + backward statistics of the BatchNorm in front of the conv
     const bool relu = (op.flags & DODA_CX_F_RELU) != 0;
-    // tiles per workgroup unit (power of two) x offset slices = 8 waves: as many slices as the offsets allow, fewer when
-    // there are enough tiles to give every workgroup a unit anyway
-    const int nsl_max = K >= 8 ? 8 : K >= 4 ? 4 : K >= 2 ? 2 : 1;
-    int tpw = CX_WAVES / nsl_max;
-    while (tpw < CX_WAVES && (T + 2 * tpw - 1) / (2 * tpw) >= G) tpw *= 2;
-    const int nsl = CX_WAVES / tpw;
-    const int n_units = (T + tpw - 1) / tpw;
-    const int t_in = wave & (tpw - 1), sl = wave / tpw;
-    const int o_lo = sl * K / nsl, o_hi = (sl + 1) * K / nsl;
+    const int tpw = pl.tpw, oc = pl.oc;
+    const int tsh = tpw == 1 ? 0 : tpw == 2 ? 1 : tpw == 4 ? 2 : 3;
+    const int nsl = CX_WAVES >> tsh;              // slices of a chunk's units per tile
+    const int MS = (T + tpw - 1) >> tsh, NS = (NB + NBU - 1) / NBU;
+    const int n_units = MS * NS;
+    const int NCH = (K + oc - 1) / oc;
+    const int t_in = wave & (tpw - 1), sl = wave >> tsh;
+    const int rows_u = tpw * 16;
 
     const rsrc_t rs_x = cx_rsrc(op.x), rs_w = cx_rsrc(op.w), rs_y = cx_rsrc(op.y);
     const rsrc_t rs_r = cx_rsrc(op.res ? op.res : op.x), rs_a = cx_rsrc(op.aux ? op.aux : op.x);
     const unsigned x_pitch = (unsigned)op.x_ld * 2u;
-    f32x4 *red = reinterpret_cast<f32x4 *>(smem + CX_RED_OFF);
-    unsigned short *outt = reinterpret_cast<unsigned short *>(smem + CX_OUT_OFF);
-    int *myidx = reinterpret_cast<int *>(smem + CX_IDX_OFF) + wave * 27 * 16;
+    u32x4 *cbuf = reinterpret_cast<u32x4 *>(smem + CX_CHUNK_OFF);
+    f32x4 *red = reinterpret_cast<f32x4 *>(smem + CX_CHUNK_OFF);                        // (after the chunk loop)
+    unsigned short *outt = reinterpret_cast<unsigned short *>(smem + CX_CHUNK_OFF + CX_RED_BYTES);
+    int *strip = reinterpret_cast<int *>(smem + CX_IDX_OFF);
     const float *vec = reinterpret_cast<const float *>(smem + CX_VEC_OFF);
+    float *wgst = reinterpret_cast<float *>(smem + CX_WGST_OFF);
 
-    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};   // statistics of channel block nb0 + wave (lanes r == 15)
+    const int nWf = oc * CC * NBU, nAf = oc * tpw * CC;      // 1 KB fragments of a chunk: weights, then gathered rows
     for (int u = me; u < n_units; u += G) {
-        const int tile = u * tpw + t_in;
-        // this wave's slice of the table -> LDS (wave-private strip: 16 consecutive rows per offset, coalesced)
-        {
-            const int n_e = (o_hi - o_lo) * 16;
-            for (int e = lane; e < n_e; e += 64) {
-                const int oo = o_lo + (e >> 4), rr = tile * 16 + (e & 15);
-                int v = -1;
-                if (tile < T && rr < n_out) v = identity ? rr : op.tbl[(long long)oo * op.tbl_ld + rr];
-                myidx[e] = v;
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const int mg = u / NS, ng = u - mg * NS;
+        const int tile0 = mg * tpw, nb0 = ng * NBU;
+        __syncthreads();                                       // (strip / chunk buffer of the previous unit are done with)
+        for (int e = tid; e < K * rows_u; e += CX_THREADS) {   // the unit's slice of the table
+            const int o = e / rows_u, rr = e - o * rows_u, row = tile0 * 16 + rr;
+            int v = -1;
+            if (row < n_out) v = identity ? row : op.tbl[(long long)o * op.tbl_ld + row];
+            strip[e] = v;
         }
-        f32x4 acc[NBW];
+        __syncthreads();
+        // request chunk c into R: fragment f = q * 8 + wave of the chunk (wave-uniform), one 16-byte piece per lane
+        auto issue = [&](int c, u32x4 (&R)[CX_LPT]) {
+            const int o0 = c * oc;
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int o = o_lo; o < o_hi; ++o) {
-            const int id = myidx[(o - o_lo) * 16 + r];
-            if (__builtin_amdgcn_ballot_w64(id >= 0) == 0ull) continue;   // no row of the tile has this neighbour
-            const unsigned rowoff = (unsigned)id * x_pitch;
-            for (int cc = 0; cc < CC; ++cc) {
-                const int c0 = cc * 32 + g * 8;
-                const unsigned xo = (id >= 0 && c0 < c_in) ? rowoff + (unsigned)c0 * 2u : OOB;
-                const u32x4 xa = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xo, 0, CX_SC1);
-                const unsigned wbase = ((unsigned)((o * CC + cc) * NB + nb0) * 64u + (unsigned)lane) * 16u;
-                u32x4 wf[NBW];
+            for (int q = 0; q < CX_LPT; ++q) {
+                const int f = q * CX_WAVES + wave;
+                if (c < NCH && f < nWf) {
+                    const int j = f % NBU, f2 = f / NBU, cc = f2 % CC, o = o0 + f2 / CC;
+                    const bool ok = o < K && nb0 + j < NB;
+                    R[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, ok ? ((unsigned)((o * CC + cc) * NB + nb0 + j) * 64u + (unsigned)lane) * 16u : OOB, 0, 0);
+                } else if (c < NCH && f < nWf + nAf) {
+                    const int fa = f - nWf, cc = fa % CC, f2 = fa / CC, t = f2 & (tpw - 1), o = o0 + (f2 >> tsh);
+                    const int id = o < K ? strip[o * rows_u + t * 16 + r] : -1;
+                    const int c0 = cc * 32 + g * 8;
+                    R[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (id >= 0 && c0 < c_in) ? (unsigned)id * x_pitch + (unsigned)c0 * 2u : OOB, 0, CX_SC1);
+                }
+            }
+        };
+        auto park = [&](u32x4 (&R)[CX_LPT]) {
 #pragma unroll
-                for (int j = 0; j < NBW; ++j) wf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wbase + (unsigned)j * 1024u, 0, 0);
+            for (int q = 0; q < CX_LPT; ++q) {
+                const int f = q * CX_WAVES + wave;
+                if (f < nWf + nAf) cbuf[f * 64 + lane] = R[q];
+            }
+        };
+        f32x4 acc[NBU];
 #pragma unroll
-                for (int j = 0; j < NBW; ++j) mma_bf16_k32(acc[j], wf[j], xa);
+        for (int j = 0; j < NBU; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto multiply = [&](int c) {
+            const int n_o = (c + 1) * oc <= K ? oc : K - c * oc;
+            for (int uu = sl; uu < n_o * CC; uu += nsl) {
+                const int o_l = uu / CC, cc = uu - o_l * CC;
+                const u32x4 xa = cbuf[(nWf + (o_l * tpw + t_in) * CC + cc) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < NBU; ++j) mma_bf16_k32(acc[j], cbuf[((o_l * CC + cc) * NBU + j) * 64 + lane], xa);
+            }
+        };
+        u32x4 Ra[CX_LPT], Rb[CX_LPT];
+        issue(0, Ra);
+        issue(1, Rb);
+        for (int c = 0; c < NCH; c += 2) {
+            __syncthreads();            // every wave is done with the chunk in LDS
+            park(Ra);
+            issue(c + 2, Ra);
+            __syncthreads();
+            multiply(c);
+            if (c + 1 < NCH) {
+                __syncthreads();
+                park(Rb);
+                issue(c + 3, Rb);
+                __syncthreads();
+                multiply(c + 1);
             }
         }
+        __syncthreads();                // the chunk buffer becomes the reduction / output staging area
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) red[(wave * 8 + j) * 64 + lane] = acc[j];
+        for (int j = 0; j < NBU; ++j) red[(wave * 8 + j) * 64 + lane] = acc[j];
         __syncthreads();
         // epilogue: wave j finishes channel block nb0 + j of every tile of the unit
-        if (wave < NBW) {
+        const int nbu_here = NB - nb0 < NBU ? NB - nb0 : NBU;
+        if (wave < nbu_here) {
             const int ch = (nb0 + wave) * 16 + g * 4;
+            f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
             for (int t = 0; t < tpw; ++t) {
                 f32x4 v = red[(t * 8 + wave) * 64 + lane];
-                for (int s = 1; s < nsl; ++s) v += red[((s * tpw + t) * 8 + wave) * 64 + lane];
-                const int row = (u * tpw + t) * 16 + r;
+                for (int s2 = 1; s2 < nsl; ++s2) v += red[((s2 * tpw + t) * 8 + wave) * 64 + lane];
+                const int row = (tile0 + t) * 16 + r;
                 const bool ok = row < n_out;
                 if (op.res) {
                     const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(rs_r, ok ? ((unsigned)row * (unsigned)op.res_ld + (unsigned)ch) * 2u : OOB, 0, CX_SC1);
@@ -188,7 +245,6 @@ __device__ __forceinline__ void cx_gemm_pass(const doda_cx_op &op, int me, int G
                             v[q] = yv > 0.f ? v[q] : 0.f;
                         }
                     }
-                    if (!ok) xh = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
                 unsigned short ob[4];
                 f32x4 vr;
@@ -203,61 +259,60 @@ __device__ __forceinline__ void cx_gemm_pass(const doda_cx_op &op, int me, int G
                 u32x2 pk;
                 pk[0] = (unsigned)ob[0] | ((unsigned)ob[1] << 16);
                 pk[1] = (unsigned)ob[2] | ((unsigned)ob[3] << 16);
-                *reinterpret_cast<u32x2 *>(outt + (t * 16 + r) * c_out + ch) = pk;
+                *reinterpret_cast<u32x2 *>(outt + (t * 16 + r) * (NBU * 16) + wave * 16 + g * 4) = pk;
+            }
+            if (op.stats && r == 15) {   // one writer per channel and unit, units in program order: deterministic
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { wgst[ch + q] += st1[q]; wgst[CX_MAXC + ch + q] += st2[q]; }
             }
         }
         __syncthreads();
-        {   // the unit's rows, channels of this pass, in 16-byte write-through stores
-            const int cprp = NBW * 2, rows_u = tpw * 16;
-            for (int i = threadIdx.x; i < rows_u * cprp; i += CX_THREADS) {
-                const int rr = i / cprp, ck = i - rr * cprp;
-                const int row = u * tpw * 16 + rr, chn = nb0 * 16 + ck * 8;
+        {   // the unit's rows x channel blocks in 16-byte write-through stores
+            const int cpr = nbu_here * 2;
+            for (int i = tid; i < rows_u * cpr; i += CX_THREADS) {
+                const int rr = i / cpr, ck = i - rr * cpr;
+                const int row = tile0 * 16 + rr;
                 if (row < n_out) {
-                    const u32x4 d = *reinterpret_cast<const u32x4 *>(outt + rr * c_out + chn);
-                    __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, ((unsigned)row * (unsigned)op.y_ld + (unsigned)chn) * 2u, 0, CX_SC1);
+                    const u32x4 d = *reinterpret_cast<const u32x4 *>(outt + rr * (NBU * 16) + ck * 8);
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, ((unsigned)row * (unsigned)op.y_ld + (unsigned)(nb0 * 16 + ck * 8)) * 2u, 0, CX_SC1);
                 }
             }
         }
-        __syncthreads();
-    }
-    if (op.stats && wave < NBW && r == 15) {   // this workgroup's partial row (zeros when it had no unit)
-        const int ch = (nb0 + wave) * 16 + g * 4;
-        const rsrc_t rs_s = cx_rsrc(op.stats);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, st1), rs_s, ((unsigned)(me * 2 + 0) * (unsigned)c_out + (unsigned)ch) * 4u, 0, CX_SC1);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, st2), rs_s, ((unsigned)(me * 2 + 1) * (unsigned)c_out + (unsigned)ch) * 4u, 0, CX_SC1);
     }
 }
 
 __device__ __forceinline__ void cx_gemm(const doda_cx_op &op, int me, int G, char *smem) {
-    if (op.aux) {   // the BatchNorm in front of the conv (backward epilogue): its vectors -> LDS
-        float *vec = reinterpret_cast<float *>(smem + CX_VEC_OFF);
-        const int c = threadIdx.x;
-        if (c < op.c_out) {
-            vec[c] = op.mean[c];
-            vec[CX_MAXC + c] = op.invstd[c];
-            vec[2 * CX_MAXC + c] = op.gamma[c];
-            vec[3 * CX_MAXC + c] = op.beta[c];
+    float *vec = reinterpret_cast<float *>(smem + CX_VEC_OFF);
+    float *wgst = reinterpret_cast<float *>(smem + CX_WGST_OFF);
+    const int c = threadIdx.x;
+    if (c < CX_MAXC) { wgst[c] = 0.f; wgst[CX_MAXC + c] = 0.f; }
+    if (op.aux && c < op.c_out) {   // the BatchNorm in front of the conv (backward epilogue): its vectors -> LDS
+        vec[c] = op.mean[c];
+        vec[CX_MAXC + c] = op.invstd[c];
+        vec[2 * CX_MAXC + c] = op.gamma[c];
+        vec[3 * CX_MAXC + c] = op.beta[c];
+    }
+    __syncthreads();
+    const GemmPlan pl = unpack_plan(op.reserved);
+    switch (pl.nbu) {
+    case 1: cx_gemm_units<1>(op, me, G, smem, pl); break;
+    case 2: cx_gemm_units<2>(op, me, G, smem, pl); break;
+    case 3: cx_gemm_units<3>(op, me, G, smem, pl); break;
+    case 4: cx_gemm_units<4>(op, me, G, smem, pl); break;
+    case 5: cx_gemm_units<5>(op, me, G, smem, pl); break;
+    case 6: cx_gemm_units<6>(op, me, G, smem, pl); break;
+    case 7: cx_gemm_units<7>(op, me, G, smem, pl); break;
+    case 8: cx_gemm_units<8>(op, me, G, smem, pl); break;
+    default: break;
+    }
+    __syncthreads();
+    if (op.stats) {   // this workgroup's partial row: what it accumulated over its units, zeros elsewhere
+        const rsrc_t rs_s = cx_rsrc(op.stats);
+        for (int e = threadIdx.x; e < 2 * op.c_out; e += CX_THREADS) {
+            const int h = e >= op.c_out ? 1 : 0, ch = e - h * op.c_out;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wgst[h * CX_MAXC + ch]), rs_s, ((unsigned)(me * 2 + h) * (unsigned)op.c_out + (unsigned)ch) * 4u, 0, CX_SC1);
         }
-        __syncthreads();
     }
-    const int NB = (op.c_out + 15) >> 4;
-#define CX_PASS(N, B0) cx_gemm_pass<N>(op, me, G, smem, B0)
-    switch (NB) {
-    case 1: CX_PASS(1, 0); break;
-    case 2: CX_PASS(2, 0); break;
-    case 3: CX_PASS(3, 0); break;
-    case 4: CX_PASS(4, 0); break;
-    case 5: CX_PASS(5, 0); break;
-    case 6: CX_PASS(6, 0); break;
-    case 7: CX_PASS(7, 0); break;
-    case 8: CX_PASS(8, 0); break;
-    case 10: CX_PASS(5, 0); CX_PASS(5, 5); break;
-    case 12: CX_PASS(6, 0); CX_PASS(6, 6); break;
-    case 14: CX_PASS(7, 0); CX_PASS(7, 7); break;
-    case 16: CX_PASS(8, 0); CX_PASS(8, 8); break;
-    default: break;   // (rejected on the host)
-    }
-#undef CX_PASS
 }
 
 // rows [r0, r1) this workgroup owns in the row-local ops
@@ -469,6 +524,26 @@ int env_int(const char *name, int dflt, int lo, int hi) {
 
 bool bad_channels(int c) { return c <= 0 || c > CX_MAXC || (c % 8) != 0; }
 
+// (tpw, nbu, oc) of a GEMM op: see cx_gemm_units.  Cost of a candidate = rounds of units x KB a unit ingests (its share of
+// the weight fragments + the rows it gathers, about half of the table's slots being present) + a fixed per-unit part.
+GemmPlan plan_gemm(const doda_cx_op &o, int G) {
+    const int K = o.K, CC = (o.c_in + 31) / 32, NB = o.c_out / 16, T = (o.rows + 15) / 16;
+    GemmPlan best{1, NB < 8 ? NB : 8, 1};
+    double best_cost = 1e30;
+    for (int tpw = 1; tpw <= 8; tpw *= 2)
+        for (int nbu = 1; nbu <= 8 && nbu <= NB; ++nbu) {
+            if (CC * (nbu + tpw) > CX_CHUNK_ITEMS / 64) continue;          // one offset must fit a chunk
+            const int units = ((T + tpw - 1) / tpw) * ((NB + nbu - 1) / nbu);
+            const int rounds = (units + G - 1) / G;
+            const double kb = (double)K * CC * (nbu + 0.5 * tpw) + 48.0;
+            const double cost = rounds * kb;
+            if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && tpw > best.tpw)) { best_cost = cost; best.tpw = tpw; best.nbu = nbu; }
+        }
+    int oc = (CX_CHUNK_ITEMS / 64) / (CC * (best.nbu + best.tpw));
+    best.oc = oc < 1 ? 1 : oc > K ? K : oc;
+    return best;
+}
+
 }  // namespace
 
 extern "C" int32_t doda_coarse_workgroups(void) {
@@ -494,7 +569,7 @@ extern "C" int doda_coarse_run(const doda_cx_op *ops_h, int32_t n_ops, void *des
             const int NB = (o.c_out + 15) / 16;
             if (!o.x || !o.w || !o.y || (!o.tbl && !(o.flags & DODA_CX_F_IDENTITY))) return DODA_ERR_INVALID;
             if (bad_channels(o.c_in) || bad_channels(o.c_out) || o.c_out % 16 != 0 || o.c_in < 32) return DODA_ERR_UNSUPPORTED;
-            if (!(NB <= 8 || NB == 10 || NB == 12 || NB == 14 || NB == 16)) return DODA_ERR_UNSUPPORTED;
+            (void)NB;
             if (o.K < 1 || o.K > 27 || ((o.flags & DODA_CX_F_IDENTITY) && o.K != 1)) return DODA_ERR_UNSUPPORTED;
             if (o.x_ld < o.c_in || o.y_ld < o.c_out || o.x_ld % 8 || o.y_ld % 8 || (o.res && (o.res_ld < o.c_out || o.res_ld % 4)) ||
                 (o.aux && (o.aux_ld < o.c_out || o.aux_ld % 4 || !o.mean || !o.invstd || !o.gamma || !o.beta)))
@@ -540,6 +615,10 @@ extern "C" int doda_coarse_run(const doda_cx_op *ops_h, int32_t n_ops, void *des
         if (!sl.ev && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) return DODA_ERR_LAUNCH;
         sl.ev_dev = cur_dev;
         memcpy(sl.host, ops_h, (size_t)n_ops * sizeof(doda_cx_op));
+        for (int k = 0; k < n_ops; ++k) {
+            doda_cx_op &o = ((doda_cx_op *)sl.host)[k];
+            if (o.kind == DODA_CX_GEMM) o.reserved = pack_plan(plan_gemm(o, G));
+        }
         if (hipMemcpyAsync(desc_dev, sl.host, (size_t)n_ops * sizeof(doda_cx_op), hipMemcpyHostToDevice, s) != hipSuccess) return DODA_ERR_LAUNCH;
         (void)hipEventRecord(sl.ev, s);
         sl.pending = true;
