@@ -46,14 +46,28 @@ constexpr int CX_VEC_OFF = CX_IDX_OFF + CX_IDX_BYTES;           // float [6][CX_
 constexpr int CX_VEC_BYTES = 6 * CX_MAXC * 4;
 constexpr int CX_WGST_OFF = CX_VEC_OFF + CX_VEC_BYTES;          // float [2][CX_MAXC]: this workgroup's statistics row of a GEMM
 constexpr int CX_WGST_BYTES = 2 * CX_MAXC * 4;
+constexpr int CX_DEC_OFF = CX_WGST_OFF + CX_WGST_BYTES;         // int [CX_LPT * 8]: what fragment f of a chunk is (cx_gemm)
+constexpr int CX_DEC_BYTES = 512;
+constexpr int CX_EPI_OFF = CX_DEC_OFF + CX_DEC_BYTES;         // bf16 [128 rows][nbu * 16]: the unit's tile of the epilogue operand
+constexpr int CX_EPI_BYTES = 128 * 128 * 2;                     //   (forward: residual; data gradient: the BatchNorm's input) 32 KB
 constexpr int CX_RED_OFF = CX_CHUNK_OFF;                        // (row-local ops: scratch)
-constexpr int CX_LDS_BYTES = CX_WGST_OFF + CX_WGST_BYTES;       // ~118 KB
+constexpr int CX_LDS_BYTES = CX_EPI_OFF + CX_EPI_BYTES;         // ~150 KB
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t cx_rsrc(const void *p) {
     return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, 0x7ffffff0, 0x00020000);   // (masking by the explicit OOB offset)
 }
 __device__ __forceinline__ float cx_bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// debug stamps (tools/cxstamps.py): workgroup 0, thread 0 appends (label << 56 | 100 MHz wall clock) to a caller-provided buffer
+__device__ unsigned long long *g_cx_stamps = nullptr;
+__device__ __forceinline__ void cx_stamp(int me, unsigned label) {
+    unsigned long long *b = g_cx_stamps;
+    if (b && me == 0 && threadIdx.x == 0) {
+        const unsigned long long k = b[0];
+        if (k < 4000) { b[1 + k] = ((unsigned long long)label << 56) | (__builtin_amdgcn_s_memrealtime() & 0x00ffffffffffffffull); b[0] = k + 1; }
+    }
+}
 
 struct CxCtl {
     unsigned *ctr, *err;
@@ -110,15 +124,18 @@ __device__ __forceinline__ u32x4 cx_pack8(const float (&f)[8]) {
 // units), the slices of a tile summed in a fixed order through LDS at the end.  The plan (tpw, nbu, oc) is chosen per op on
 // the host (plan_gemm) so that every workgroup gets a unit and no unit ingests more than it must: many tiles -> 64-row
 // units with every channel block (weights read once per 64 rows); few tiles -> the channel blocks spread over workgroups.
-constexpr int CX_LPT = 10;                        // 16-byte loads per thread and chunk (chunk <= 80 KB)
+constexpr int CX_LPT = 8;                         // 16-byte loads per thread and chunk (chunk <= 64 KB)
 constexpr int CX_CHUNK_ITEMS = CX_LPT * CX_THREADS;
 
 struct GemmPlan { int tpw, nbu, oc; };
 __host__ __device__ inline GemmPlan unpack_plan(int v) { return GemmPlan{v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff}; }
 inline int pack_plan(const GemmPlan &p) { return p.tpw | (p.nbu << 8) | (p.oc << 16); }
 
-template <int NBU>
+// (ONE instantiation with the block count at run time: eight template instances made the kernel 171 KB of code against a
+// 64 KB instruction cache, and every op began with ~2.5 us of instruction fetch)
+constexpr int NBU_MAX = 8;
 __device__ __forceinline__ void cx_gemm_units(const doda_cx_op &op, int me, int G, char *smem, const GemmPlan pl) {
+    const int NBU = pl.nbu;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -146,79 +163,127 @@ __device__ __forceinline__ void cx_gemm_units(const doda_cx_op &op, int me, int 
     int *strip = reinterpret_cast<int *>(smem + CX_IDX_OFF);
     const float *vec = reinterpret_cast<const float *>(smem + CX_VEC_OFF);
     float *wgst = reinterpret_cast<float *>(smem + CX_WGST_OFF);
+    unsigned short *epit = reinterpret_cast<unsigned short *>(smem + CX_EPI_OFF);
 
-    const int nWf = oc * CC * NBU, nAf = oc * tpw * CC;      // 1 KB fragments of a chunk: weights, then gathered rows
+    const int nWf = oc * CC * NBU;                            // 1 KB fragments of a chunk: weights [oc][CC][NBU], then gathered rows [oc][tpw][CC]
+    int dec[CX_LPT];
+#pragma unroll
+    for (int q = 0; q < CX_LPT; ++q) dec[q] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(smem + CX_DEC_OFF)[q * CX_WAVES + wave]);
     for (int u = me; u < n_units; u += G) {
-        const int mg = u / NS, ng = u - mg * NS;
+        const int mg = NS == 1 ? u : u / NS, ng = u - mg * NS;
         const int tile0 = mg * tpw, nb0 = ng * NBU;
-        __syncthreads();                                       // (strip / chunk buffer of the previous unit are done with)
-        for (int e = tid; e < K * rows_u; e += CX_THREADS) {   // the unit's slice of the table
-            const int o = e / rows_u, rr = e - o * rows_u, row = tile0 * 16 + rr;
-            int v = -1;
-            if (row < n_out) v = identity ? row : op.tbl[(long long)o * op.tbl_ld + row];
-            strip[e] = v;
-        }
-        __syncthreads();
-        // request chunk c into R: fragment f = q * 8 + wave of the chunk (wave-uniform), one 16-byte piece per lane
+        // request chunk c into R: fragment q * 8 + wave of the chunk (wave-uniform), one 16-byte piece per lane.  dec[q] says
+        // what the fragment is — weights (offset in chunk << 16 | k-chunk << 8 | block), bit 30: gathered rows (offset in chunk
+        // << 16 | k-chunk << 8 | tile), -1: nothing — decoded once per op into LDS (cx_gemm).  STRAIGHT-LINE code: one
+        // unconditional load per q with a selected descriptor and offset (nothing to fetch = out-of-range offset), so the
+        // nine table reads and the nine requests go out back to back; with a branch per q every request waited for its own
+        // LDS read (1.8 us to issue 18 loads).
         auto issue = [&](int c, u32x4 (&R)[CX_LPT]) {
             const int o0 = c * oc;
+            int id[CX_LPT];
 #pragma unroll
             for (int q = 0; q < CX_LPT; ++q) {
-                const int f = q * CX_WAVES + wave;
-                if (c < NCH && f < nWf) {
-                    const int j = f % NBU, f2 = f / NBU, cc = f2 % CC, o = o0 + f2 / CC;
-                    const bool ok = o < K && nb0 + j < NB;
-                    R[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, ok ? ((unsigned)((o * CC + cc) * NB + nb0 + j) * 64u + (unsigned)lane) * 16u : OOB, 0, 0);
-                } else if (c < NCH && f < nWf + nAf) {
-                    const int fa = f - nWf, cc = fa % CC, f2 = fa / CC, t = f2 & (tpw - 1), o = o0 + (f2 >> tsh);
-                    const int id = o < K ? strip[o * rows_u + t * 16 + r] : -1;
-                    const int c0 = cc * 32 + g * 8;
-                    R[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (id >= 0 && c0 < c_in) ? (unsigned)id * x_pitch + (unsigned)c0 * 2u : OOB, 0, CX_SC1);
-                }
+                const int dq = __builtin_amdgcn_readfirstlane(dec[q]), o = o0 + ((dq >> 16) & 0xff), t = dq & (tpw - 1);
+                id[q] = strip[(o < K ? o : K - 1) * rows_u + t * 16 + r];
+            }
+#pragma unroll
+            for (int q = 0; q < CX_LPT; ++q) {
+                // (readfirstlane: the fragment kind must be PROVABLY wave-uniform where it selects the buffer descriptor — kept in a
+                // VGPR the select became a waterfall loop per request: 5 us per chunk with no memory traffic at all)
+                const int dq = __builtin_amdgcn_readfirstlane(dec[q]), lo = dq & 0xff, cc = (dq >> 8) & 0xff, o = o0 + ((dq >> 16) & 0xff);
+                const bool live = dq >= 0 && c < NCH && o < K, is_a = (dq & 0x40000000) != 0;
+                const int c0 = cc * 32 + g * 8;
+                const unsigned w_off = ((unsigned)((o * CC + cc) * NB + nb0 + lo) * 64u + (unsigned)lane) * 16u;
+                const unsigned a_off = (unsigned)id[q] * x_pitch + (unsigned)c0 * 2u;
+                const bool ok = live && (is_a ? (id[q] >= 0 && c0 < c_in) : (nb0 + lo < NB));
+                const unsigned off = ok ? (is_a ? a_off : w_off) : OOB;
+                R[q] = __builtin_amdgcn_raw_buffer_load_b128(is_a ? rs_x : rs_w, off, 0, CX_SC1);
             }
         };
         auto park = [&](u32x4 (&R)[CX_LPT]) {
 #pragma unroll
             for (int q = 0; q < CX_LPT; ++q) {
-                const int f = q * CX_WAVES + wave;
-                if (f < nWf + nAf) cbuf[f * 64 + lane] = R[q];
-            }
-        };
-        f32x4 acc[NBU];
-#pragma unroll
-        for (int j = 0; j < NBU; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        auto multiply = [&](int c) {
-            const int n_o = (c + 1) * oc <= K ? oc : K - c * oc;
-            for (int uu = sl; uu < n_o * CC; uu += nsl) {
-                const int o_l = uu / CC, cc = uu - o_l * CC;
-                const u32x4 xa = cbuf[(nWf + (o_l * tpw + t_in) * CC + cc) * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < NBU; ++j) mma_bf16_k32(acc[j], cbuf[((o_l * CC + cc) * NBU + j) * 64 + lane], xa);
+                cbuf[(q * CX_WAVES + wave) * 64 + lane] = R[q];   // (unconditional: a branch per piece made hipcc wait vmcnt(0) — for
+                //                                                    the NEWER chunk in flight as well — before every write)
             }
         };
         u32x4 Ra[CX_LPT], Rb[CX_LPT];
-        issue(0, Ra);
-        issue(1, Rb);
-        for (int c = 0; c < NCH; c += 2) {
-            __syncthreads();            // every wave is done with the chunk in LDS
-            park(Ra);
+        cx_stamp(me, 10);
+        // the epilogue's operand tile (residual rows, or the BatchNorm input of a data-gradient call): requested now, read
+        // from LDS when the accumulators are ready
+        const int nbu_here = NB - nb0 < NBU ? NB - nb0 : NBU;
+        const bool has_epi = op.res != nullptr || bwd;
+        const int epi_ld = bwd ? op.aux_ld : op.res_ld;
+        u32x4 ev[4];
+        if (has_epi) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = q * CX_THREADS + tid, cpr = nbu_here * 2;
+                const int rr = i / cpr, ck = i - rr * cpr, row = tile0 * 16 + rr;
+                const bool ok = rr < rows_u && row < n_out;
+                ev[q] = __builtin_amdgcn_raw_buffer_load_b128(bwd ? rs_a : rs_r, ok ? ((unsigned)row * (unsigned)epi_ld + (unsigned)(nb0 * 16 + ck * 8)) * 2u : OOB, 0, CX_SC1);
+            }
+        }
+        __syncthreads();                                       // (strip / chunk buffer of the previous unit are done with)
+        for (int e = tid; e < K * rows_u; e += CX_THREADS) {   // the unit's slice of the table
+            const int o = e >> (4 + tsh), rr = e & (rows_u - 1), row = tile0 * 16 + rr;
+            int v = -1;
+            if (row < n_out) v = identity ? row : op.tbl[(long long)o * op.tbl_ld + row];
+            strip[e] = v;
+        }
+        __syncthreads();
+        cx_stamp(me, 11);
+        f32x4 acc[NBU_MAX];
+#pragma unroll
+        for (int j = 0; j < NBU_MAX; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto multiply = [&](int c) {
+            const int n_o = (c + 1) * oc <= K ? oc : K - c * oc;
+            int o_l = 0, cc = sl;
+            for (int uu = sl; uu < n_o * CC; uu += nsl, cc += nsl) {
+                while (cc >= CC) { cc -= CC; ++o_l; }
+                const u32x4 xa = cbuf[(nWf + (o_l * tpw + t_in) * CC + cc) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < NBU_MAX; ++j)
+                    if (j < NBU) mma_bf16_k32(acc[j], cbuf[((o_l * CC + cc) * NBU + j) * 64 + lane], xa);
+            }
+        };
+        // chunk c is multiplied from LDS while chunks c + 1 and c + 2 are in flight (the loop starts two chunks early: its
+        // first two trips only request)
+        for (int c = -2; c < NCH; c += 2) {
+            if (c >= 0) {
+                __syncthreads();        // every wave is done with the chunk in LDS
+                park(Ra);
+            }
             issue(c + 2, Ra);
-            __syncthreads();
-            multiply(c);
-            if (c + 1 < NCH) {
+            if (c >= 0) {
+                __syncthreads();
+                multiply(c);
+            }
+            if (c + 1 >= 0 && c + 1 < NCH) {
                 __syncthreads();
                 park(Rb);
-                issue(c + 3, Rb);
+            }
+            issue(c + 3, Rb);
+            if (c == -2 && has_epi) {   // (the epilogue operand tile: parked once the first two chunks are on their way)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = q * CX_THREADS + tid, cpr = nbu_here * 2;
+                    const int rr = i / cpr, ck = i - rr * cpr;
+                    if (rr < rows_u) *reinterpret_cast<u32x4 *>(epit + rr * (NBU * 16) + ck * 8) = ev[q];
+                }
+            }
+            if (c + 1 >= 0 && c + 1 < NCH) {
                 __syncthreads();
                 multiply(c + 1);
             }
         }
         __syncthreads();                // the chunk buffer becomes the reduction / output staging area
+        cx_stamp(me, 16);
 #pragma unroll
-        for (int j = 0; j < NBU; ++j) red[(wave * 8 + j) * 64 + lane] = acc[j];
+        for (int j = 0; j < NBU_MAX; ++j)
+            if (j < NBU) red[(wave * 8 + j) * 64 + lane] = acc[j];
         __syncthreads();
         // epilogue: wave j finishes channel block nb0 + j of every tile of the unit
-        const int nbu_here = NB - nb0 < NBU ? NB - nb0 : NBU;
         if (wave < nbu_here) {
             const int ch = (nb0 + wave) * 16 + g * 4;
             f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
@@ -227,14 +292,16 @@ __device__ __forceinline__ void cx_gemm_units(const doda_cx_op &op, int me, int 
                 for (int s2 = 1; s2 < nsl; ++s2) v += red[((s2 * tpw + t) * 8 + wave) * 64 + lane];
                 const int row = (tile0 + t) * 16 + r;
                 const bool ok = row < n_out;
+                (void)ok;
+                const u32x2 et = has_epi ? *reinterpret_cast<const u32x2 *>(epit + (t * 16 + r) * (NBU * 16) + wave * 16 + g * 4) : (u32x2){0u, 0u};
                 if (op.res) {
-                    const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(rs_r, ok ? ((unsigned)row * (unsigned)op.res_ld + (unsigned)ch) * 2u : OOB, 0, CX_SC1);
+                    const u32x2 rr = et;
                     v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
                     v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
                 }
                 f32x4 xh = {0.f, 0.f, 0.f, 0.f};
                 if (bwd) {
-                    const u32x2 xr = __builtin_amdgcn_raw_buffer_load_b64(rs_a, ok ? ((unsigned)row * (unsigned)op.aux_ld + (unsigned)ch) * 2u : OOB, 0, CX_SC1);
+                    const u32x2 xr = et;
                     const float xv[4] = {__uint_as_float(xr[0] << 16), __uint_as_float(xr[0] & 0xffff0000u),
                                          __uint_as_float(xr[1] << 16), __uint_as_float(xr[1] & 0xffff0000u)};
 #pragma unroll
@@ -267,6 +334,7 @@ __device__ __forceinline__ void cx_gemm_units(const doda_cx_op &op, int me, int 
             }
         }
         __syncthreads();
+        cx_stamp(me, 17);
         {   // the unit's rows x channel blocks in 16-byte write-through stores
             const int cpr = nbu_here * 2;
             for (int i = tid; i < rows_u * cpr; i += CX_THREADS) {
@@ -292,19 +360,18 @@ __device__ __forceinline__ void cx_gemm(const doda_cx_op &op, int me, int G, cha
         vec[2 * CX_MAXC + c] = op.gamma[c];
         vec[3 * CX_MAXC + c] = op.beta[c];
     }
-    __syncthreads();
+    cx_stamp(me, 20);
     const GemmPlan pl = unpack_plan(op.reserved);
-    switch (pl.nbu) {
-    case 1: cx_gemm_units<1>(op, me, G, smem, pl); break;
-    case 2: cx_gemm_units<2>(op, me, G, smem, pl); break;
-    case 3: cx_gemm_units<3>(op, me, G, smem, pl); break;
-    case 4: cx_gemm_units<4>(op, me, G, smem, pl); break;
-    case 5: cx_gemm_units<5>(op, me, G, smem, pl); break;
-    case 6: cx_gemm_units<6>(op, me, G, smem, pl); break;
-    case 7: cx_gemm_units<7>(op, me, G, smem, pl); break;
-    case 8: cx_gemm_units<8>(op, me, G, smem, pl); break;
-    default: break;
+    if (c < CX_LPT * CX_WAVES) {   // fragment c of a chunk: weights [oc][CC][nbu], then gathered rows [oc][tpw][CC]
+        const int CC = (op.c_in + 31) >> 5, nWf = pl.oc * CC * pl.nbu, nAf = pl.oc * pl.tpw * CC;
+        int d = -1;
+        if (c < nWf) { const int j = c % pl.nbu, f2 = c / pl.nbu; d = ((f2 / CC) << 16) | ((f2 % CC) << 8) | j; }
+        else if (c < nWf + nAf) { const int fa = c - nWf, f2 = fa / CC; d = 0x40000000 | ((f2 / pl.tpw) << 16) | ((fa % CC) << 8) | (f2 % pl.tpw); }
+        reinterpret_cast<int *>(smem + CX_DEC_OFF)[c] = d;
     }
+    __syncthreads();
+    cx_stamp(me, 21);
+    if (pl.nbu >= 1 && pl.nbu <= NBU_MAX) cx_gemm_units(op, me, G, smem, pl);
     __syncthreads();
     if (op.stats) {   // this workgroup's partial row: what it accumulated over its units, zeros elsewhere
         const rsrc_t rs_s = cx_rsrc(op.stats);
@@ -313,6 +380,15 @@ __device__ __forceinline__ void cx_gemm(const doda_cx_op &op, int me, int G, cha
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wgst[h * CX_MAXC + ch]), rs_s, ((unsigned)(me * 2 + h) * (unsigned)op.c_out + (unsigned)ch) * 4u, 0, CX_SC1);
         }
     }
+}
+
+// The G partial rows [G][2][cw] of a statistics array, columns [0, cw) -> LDS `dst` (same layout) with every thread
+// requesting 16-byte pieces at once: ONE round trip (a loop of dependent 4-byte loads cost 64 of them: 10 us per op).
+__device__ __forceinline__ void cx_fetch_partials(const float *sp, int n_part, int cw, float *dst) {
+    const rsrc_t rs = cx_rsrc(sp);
+    const int n16 = (n_part * 2 * cw) >> 2;
+    for (int i = threadIdx.x; i < n16; i += CX_THREADS)
+        reinterpret_cast<u32x4 *>(dst)[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)i * 16u, 0, CX_SC1);
 }
 
 // rows [r0, r1) this workgroup owns in the row-local ops
@@ -326,19 +402,28 @@ __device__ __forceinline__ void cx_own_rows(int rows, int me, int G, int &r0, in
 __device__ __forceinline__ void cx_bnfwd(const doda_cx_op &op, int me, int G, char *smem) {
     float *vec = reinterpret_cast<float *>(smem + CX_VEC_OFF);
     const int C = op.c_in, rows = op.rows, tid = threadIdx.x;
+    float *part = reinterpret_cast<float *>(smem + CX_RED_OFF);   // [G][2][ca] then [G][2][cb]
+    const bool training = (op.flags & DODA_CX_F_TRAINING) != 0;
+    const int ca = op.c_split;
+    if (training) {
+        cx_fetch_partials(op.stats, op.n_part, ca, part);
+        if (ca < C) cx_fetch_partials(op.stats_b, op.n_part, C - ca, part + op.n_part * 2 * ca);
+    }
+    float g_ = 0.f, b_ = 0.f, rm_ = 0.f, rv_ = 0.f;
+    if (tid < C) {   // (requested before the partial rows are waited for)
+        g_ = op.gamma[tid]; b_ = op.beta[tid];
+        if (op.running_mean && (me == 0 || !training)) { rm_ = op.running_mean[tid]; rv_ = op.running_var[tid]; }
+    }
+    __syncthreads();
     if (tid < C) {
         float mu, is;
-        if (op.flags & DODA_CX_F_TRAINING) {
-            const int ca = op.c_split;
-            const float *sp = tid < ca ? op.stats : op.stats_b;
+        if (training) {
+            const float *sp = tid < ca ? part : part + op.n_part * 2 * ca;
             const int cw = tid < ca ? ca : C - ca, cl = tid < ca ? tid : tid - ca;
-            const rsrc_t rs_s = cx_rsrc(sp);
             double s1 = 0.0, s2 = 0.0;
             for (int p = 0; p < op.n_part; ++p) {
-                const float a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_s, ((unsigned)(p * 2) * (unsigned)cw + (unsigned)cl) * 4u, 0, CX_SC1));
-                const float b = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_s, ((unsigned)(p * 2 + 1) * (unsigned)cw + (unsigned)cl) * 4u, 0, CX_SC1));
-                s1 += (double)a;
-                s2 += (double)b;
+                s1 += (double)sp[(p * 2) * cw + cl];
+                s2 += (double)sp[(p * 2 + 1) * cw + cl];
             }
             const double d = s1 / rows;
             double var = s2 / rows - d * d;
@@ -349,20 +434,20 @@ __device__ __forceinline__ void cx_bnfwd(const doda_cx_op &op, int me, int G, ch
                 if (op.running_mean) {
                     const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
                     const double mom = (double)op.momentum;
-                    op.running_mean[tid] = (float)((1.0 - mom) * (double)op.running_mean[tid] + mom * d);
-                    op.running_var[tid] = (float)((1.0 - mom) * (double)op.running_var[tid] + mom * unbiased);
+                    op.running_mean[tid] = (float)((1.0 - mom) * (double)rm_ + mom * d);
+                    op.running_var[tid] = (float)((1.0 - mom) * (double)rv_ + mom * unbiased);
                 }
                 if (tid == 0 && op.nbt) *op.nbt += 1;
             }
         } else {
-            mu = op.running_mean[tid];
-            is = 1.0f / sqrtf(op.running_var[tid] + op.eps);
+            mu = rm_;
+            is = 1.0f / sqrtf(rv_ + op.eps);
         }
         if (me == 0 && op.mean) { op.mean[tid] = mu; op.invstd[tid] = is; }
         vec[tid] = mu;
         vec[CX_MAXC + tid] = is;
-        vec[2 * CX_MAXC + tid] = op.gamma[tid];
-        vec[3 * CX_MAXC + tid] = op.beta[tid];
+        vec[2 * CX_MAXC + tid] = g_;
+        vec[3 * CX_MAXC + tid] = b_;
     }
     __syncthreads();
     int r0, r1;
@@ -390,25 +475,26 @@ __device__ __forceinline__ void cx_bnfwd(const doda_cx_op &op, int me, int G, ch
 __device__ __forceinline__ void cx_bnbwd(const doda_cx_op &op, int me, int G, char *smem) {
     float *vec = reinterpret_cast<float *>(smem + CX_VEC_OFF);
     const int C = op.c_in, rows = op.rows, tid = threadIdx.x;
+    float *part = reinterpret_cast<float *>(smem + CX_RED_OFF);
+    cx_fetch_partials(op.stats, op.n_part, C, part);
+    float is_ = 0.f, mu_ = 0.f, ga_ = 0.f, dg_ = 0.f, db_ = 0.f;
     if (tid < C) {
-        const rsrc_t rs_s = cx_rsrc(op.stats);
+        is_ = op.invstd[tid]; mu_ = op.mean[tid]; ga_ = op.gamma[tid];
+        if (me == 0 && op.dgamma && (op.flags & DODA_CX_F_ACCUM)) { dg_ = op.dgamma[tid]; db_ = op.dbeta[tid]; }
+    }
+    __syncthreads();
+    if (tid < C) {
         double s1 = 0.0, s2 = 0.0;
         for (int p = 0; p < op.n_part; ++p) {
-            const float a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_s, ((unsigned)(p * 2) * (unsigned)C + (unsigned)tid) * 4u, 0, CX_SC1));
-            const float b = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_s, ((unsigned)(p * 2 + 1) * (unsigned)C + (unsigned)tid) * 4u, 0, CX_SC1));
-            s1 += (double)a;
-            s2 += (double)b;
+            s1 += (double)part[(p * 2) * C + tid];
+            s2 += (double)part[(p * 2 + 1) * C + tid];
         }
-        const float is = op.invstd[tid];
-        vec[tid] = op.mean[tid];
-        vec[CX_MAXC + tid] = is;
-        vec[2 * CX_MAXC + tid] = op.gamma[tid] * is;
+        vec[tid] = mu_;
+        vec[CX_MAXC + tid] = is_;
+        vec[2 * CX_MAXC + tid] = ga_ * is_;
         vec[3 * CX_MAXC + tid] = (float)(s1 / rows);
         vec[4 * CX_MAXC + tid] = (float)(s2 / rows);
-        if (me == 0 && op.dgamma) {
-            if (op.flags & DODA_CX_F_ACCUM) { op.dbeta[tid] += (float)s1; op.dgamma[tid] += (float)s2; }
-            else { op.dbeta[tid] = (float)s1; op.dgamma[tid] = (float)s2; }
-        }
+        if (me == 0 && op.dgamma) { op.dbeta[tid] = db_ + (float)s1; op.dgamma[tid] = dg_ + (float)s2; }
     }
     __syncthreads();
     int r0, r1;
@@ -478,10 +564,25 @@ __global__ __launch_bounds__(CX_THREADS) void coarse_exec(const doda_cx_op *__re
     if (me >= G) return;
     extern __shared__ __attribute__((aligned(16))) char cx_smem[];
     CxCtl ctl{sync, sync + 1, 0u, G, false};   // (the counter is zero at launch: the last workgroup out resets it, below)
+    // The op in hand lives in REGISTERS (wave-uniform values): read through a reference to global memory, every field access
+    // inside a loop was a vector load followed by s_waitcnt vmcnt(0) — which also drained the operand chunks in flight (a
+    // chunk round cost 5 us with no memory traffic of its own).  The next op's 216 bytes are requested while this one runs and
+    // handed over through LDS.
+    __shared__ int opbuf[2][64];
+    constexpr int OPW = (int)(sizeof(doda_cx_op) / 4);
+    if (threadIdx.x < OPW) opbuf[0][threadIdx.x] = reinterpret_cast<const int *>(ops)[threadIdx.x];
     for (int i = 0; i < n_ops; ++i) {
-        const doda_cx_op &op = ops[i];
+        int nxt = 0;
+        if (threadIdx.x < OPW && i + 1 < n_ops) nxt = reinterpret_cast<const int *>(ops + i + 1)[threadIdx.x];
+        __syncthreads();
+        struct alignas(8) { int w[OPW]; } raw;
+#pragma unroll
+        for (int k = 0; k < OPW; ++k) raw.w[k] = __builtin_amdgcn_readfirstlane(opbuf[i & 1][k]);
+        doda_cx_op op;
+        __builtin_memcpy(&op, &raw, sizeof(op));
+        cx_stamp(me, 1);
         if (op.flags & DODA_CX_F_BARRIER) cx_barrier(ctl);
-        else __syncthreads();   // (the ops share LDS regions)
+        cx_stamp(me, 2);
         switch (op.kind) {
         case DODA_CX_GEMM: cx_gemm(op, me, G, cx_smem); break;
         case DODA_CX_BNFWD: cx_bnfwd(op, me, G, cx_smem); break;
@@ -489,6 +590,8 @@ __global__ __launch_bounds__(CX_THREADS) void coarse_exec(const doda_cx_op *__re
         case DODA_CX_STATS: cx_stats(op, me, G, cx_smem); break;
         default: break;
         }
+        cx_stamp(me, 3);
+        if (threadIdx.x < OPW) opbuf[(i + 1) & 1][threadIdx.x] = nxt;
     }
     // the last workgroup to leave puts the barrier counter back to zero for the next launch (every workgroup is past its
     // last barrier once it has counted itself out; a launch whose barrier timed out still ends with a clean counter)
@@ -545,6 +648,12 @@ GemmPlan plan_gemm(const doda_cx_op &o, int G) {
 }
 
 }  // namespace
+
+// debug: where a launch spends its time (tools/cxstamps.py).  buf_dev: uint64 [4001] device words, [0] = 0 before a launch; NULL: off.
+extern "C" int doda_coarse_debug_stamps(void *buf_dev) {
+    unsigned long long *p = (unsigned long long *)buf_dev;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_cx_stamps), &p, sizeof(p)) == hipSuccess ? DODA_OK : DODA_ERR_LAUNCH;
+}
 
 extern "C" int32_t doda_coarse_workgroups(void) {
     static const int g = env_int("DODA_CX_WGS", 32, 1, CX_MAXG);

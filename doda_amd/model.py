@@ -209,8 +209,11 @@ class VGGBlock(SparseModule):
 
 # Coarse-level executor (csrc/coarse.hip): the UBlock subtree from level COARSE_EXEC_LEVEL down runs as ONE
 # persistent launch forward and ONE backward (bf16 features, compiled extension, training with deferred weight gradients and
-# direct parameter gradients, or any no-grad pass).  DODA_COARSE_EXEC=0: layer by layer as before.
-COARSE_EXEC = _os.environ.get("DODA_COARSE_EXEC", "1") == "1"
+# direct parameter gradients, or any no-grad pass).  Built, parity-tested against the per-layer path and fp32
+# (tests/test_gpu_coarse.py) and MEASURED SLOWER on MI355X (2 x ~1.1 ms per step for levels 5-7 against
+# ~1.0 ms for the ~110 launches it replaces — one XCD has 1/8 of the chip's loads in flight, and a grid barrier over more XCDs
+# costs more than the kernel boundary it saves), so it is OPT-IN: DODA_COARSE_EXEC=1 / set_coarse_exec(True).
+COARSE_EXEC = _os.environ.get("DODA_COARSE_EXEC", "0") == "1"
 COARSE_EXEC_LEVEL = int(_os.environ.get("DODA_COARSE_LEVEL", "5"))
 COARSE_MAX_ROWS = int(_os.environ.get("DODA_COARSE_MAX_ROWS", "16384"))   # above: the whole-chip per-layer kernels win
 

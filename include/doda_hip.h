@@ -558,6 +558,8 @@ typedef struct doda_cx_op {
     float *dgamma, *dbeta;
 } doda_cx_op;
 int32_t doda_coarse_workgroups(void);
+int doda_coarse_debug_stamps(void *buf_dev);   /* debug aid (tools/cxstamps.py): uint64 [4001] device words that workgroup 0 fills with
+                                                * (label << 56 | 100 MHz clock) at the phase boundaries of later launches; NULL: off */
 size_t doda_coarse_desc_bytes(int32_t n_ops);
 int doda_coarse_run(const doda_cx_op *ops_h, int32_t n_ops, void *desc_dev, size_t desc_bytes, uint32_t *sync_dev,
                     doda_stream_t stream);
