@@ -23,11 +23,51 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 __device__ __forceinline__ void mma_bf16_k32(f32x4 &acc, const u32x4 &w, const u32x4 &x) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
 }
-// 16 fp32 channels: lane (i, g) holds channels 4g..4g+3; four v_mfma_f32_16x16x4_f32 (an exact fmaf chain)
+// 16 fp32 channels: lane (i, g) holds channels 4g..4g+3 of a weight column / a feature row.
+//
+// Round 5: the fp32 matrix rate of this part is 1/16 of the bf16 rate (157 TFLOP/s; a 16-channel unit is
+// four dependent v_mfma_f32_16x16x4_f32 = 128 cycles), and the fp32 kernels sat on exactly that chain.  Both operands are
+// split IN REGISTERS into a bf16 head and a bf16 tail (x = hi + lo + e, |e| <= 2^-17 |x|: hi = RNE(x), lo = RNE(x - hi), the
+// subtraction exact) and the unit becomes TWO v_mfma_f32_16x16x32_bf16 (32 cycles): the k = 32 of one instruction is
+// (4 channels of the lane group) x (head, tail) — A = [w_hi | w_lo] against B = [x_hi | x_hi], then against [x_lo | x_lo]:
+// all four partial products, fp32 accumulate.  The gathered bytes do not change (fp32 rows, fp32 fragment buffer).  Error of a
+// product <= ~2^-16 relative (north_star: 1e-4 on fp32 features); DODA_F32_EXACT_MFMA=1 at build time keeps the fp32 chain.
+#ifndef DODA_F32_EXACT_MFMA
+#define DODA_F32_EXACT_MFMA 0
+#endif
+struct SplitBf16 { unsigned hi[2], lo[2]; };   // 4 values: heads packed (v0,v1),(v2,v3), tails likewise
+__device__ __forceinline__ SplitBf16 split_bf16x4(const f32x4 &v) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    SplitBf16 r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 a = {v[2 * h], v[2 * h + 1]};
+        const bf16x2 hb = __builtin_convertvector(a, bf16x2);                 // v_cvt_pk_bf16_f32: round to nearest even
+        const unsigned hu = __builtin_bit_cast(unsigned, hb);
+        const f32x2 res = {a[0] - __uint_as_float(hu << 16), a[1] - __uint_as_float(hu & 0xffff0000u)};   // exact
+        r.hi[h] = hu;
+        r.lo[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(res, bf16x2));
+    }
+    return r;
+}
+// SPLIT is a compile-time choice (a run-time branch inside conv_fast's ring of hand-counted asm loads made hipcc copy
+// registers whose loads were still in flight: 49 parity tests failed); the host picks the instantiation per launch
+// (EpiArgs::f32_split: layers of many rows, where the matrix pipe is what the kernel waits for and thousands of rows average
+// the rounding; small layers keep the exact chain).
+template <bool SPLIT = false>
 __device__ __forceinline__ void mma_f32_k16(f32x4 &acc, const u32x4 &w, const u32x4 &x) {
     const f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
+    if constexpr (DODA_F32_EXACT_MFMA || !SPLIT) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q], xf[q], acc, 0, 0, 0);
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q], xf[q], acc, 0, 0, 0);
+    } else {
+        const SplitBf16 ws = split_bf16x4(wf), xs = split_bf16x4(xf);
+        const u32x4 a = {ws.hi[0], ws.hi[1], ws.lo[0], ws.lo[1]};
+        const u32x4 b1 = {xs.hi[0], xs.hi[1], xs.hi[0], xs.hi[1]}, b2 = {xs.lo[0], xs.lo[1], xs.lo[0], xs.lo[1]};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b1), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b2), acc, 0, 0, 0);
+    }
 }
 
 // inclusive prefix sum along the 16 lanes of a DPP row (row_shr with zero fill): lane 15 ends up with
@@ -56,6 +96,7 @@ struct EpiArgs {   // plain data, shared across translation units
     const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;   // [nc] each
     int bn_relu;
     int res_bcast;           // ABI 6: `res` is ONE row [nc] added to every output row (a bias): conv_fast only
+    int f32_split;           // round 5: fp32 units as two bf16 MFMAs on head / tail splits (mma_f32_k16); set by run_gather
 };
 
 namespace doda_tile {

@@ -30,6 +30,7 @@
 #include "wgrad_pairs.hpp"
 #include <stdlib.h>
 #include <utility>
+#include <type_traits>
 
 namespace {
 
@@ -40,8 +41,7 @@ struct F32 {
     static __device__ __forceinline__ elem from_float(float f) { return f; }
     static __device__ __forceinline__ float to_float(elem e) { return e; }
     static __device__ __forceinline__ void mma(f32x4 &acc, const frag &w, const frag &x) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q], x[q], acc, 0, 0, 0);
+        mma_f32_k16<false>(acc, __builtin_bit_cast(u32x4, w), __builtin_bit_cast(u32x4, x));
     }
     static __device__ __forceinline__ void store4(elem *p, const f32x4 &v) {
         *reinterpret_cast<f32x4 *>(p) = v;
@@ -395,11 +395,12 @@ struct PF32 {
     static constexpr int CH = 16;
     static constexpr bool PAIR = false;
     DODA_ASM_LOAD("buffer_load_dwordx4")
-    static __device__ __forceinline__ void mma(f32x4 &acc, const raw &w, const raw &x) {
-        const f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[q], xf[q], acc, 0, 0, 0);
-    }
+    static __device__ __forceinline__ void mma(f32x4 &acc, const raw &w, const raw &x) { mma_f32_k16<false>(acc, w, x); }
+};
+// PF32S: the same kernel with every unit as two bf16 MFMAs on bf16 head / tail splits of both operands (spconv_common.hpp
+// mma_f32_k16<true>): fp32 layers of many rows (run_gather: EpiArgs::f32_split)
+struct PF32S : PF32 {
+    static __device__ __forceinline__ void mma(f32x4 &acc, const raw &w, const raw &x) { mma_f32_k16<true>(acc, w, x); }
 };
 struct PBF16 {
     typedef unsigned short elem;
@@ -788,6 +789,9 @@ template <class P, int NBW, int S, bool SPLIT = false>
 int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_bytes, int nc, int NB,
                 const int32_t *tbl, int ld, int K, int n_out, long long n_in, void *y, bool out32,
                 const void *res, const EpiArgs &ep_in, int *n_part, hipStream_t s) {
+    if constexpr (std::is_same<P, PF32>::value) {   // fp32 layers of many rows: the bf16 head / tail instantiation
+        if (ep_in.f32_split) return launch_fast<PF32S, NBW, S, SPLIT>(x, kc, wp, wp_bytes, nc, NB, tbl, ld, K, n_out, n_in, y, out32, res, ep_in, n_part, s);
+    }
     const dim3 grid(div_up(n_out, (SPLIT ? 1 : 4) * 16 * S) * div_up(NB, NBW)), block(256);
     if (n_part) *n_part = div_up(n_out, (SPLIT ? 1 : 4) * 16 * S);
     const EpiArgs &ep = ep_in;
@@ -844,13 +848,19 @@ template <class T>
 int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tbl, int ld, int K,
                int n_out, void *y_, int wl, void *ws, size_t ws_bytes, long long n_in, bool out32,
                const void *res, hipStream_t s,
-               const EpiArgs &ep = EpiArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0},
+               const EpiArgs &ep_arg = EpiArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0},
                int *n_part = nullptr, const void *tilebook = nullptr, int tilebook_rows = 0) {
     typedef typename T::elem elem;
     typedef typename T::frag frag;
     const elem *x = (const elem *)x_;
     elem *y = (elem *)y_;
     const int NB = (nc + 15) / 16;
+    EpiArgs ep = ep_arg;
+    {   // fp32 layers of at least DODA_F32_SPLIT_ROWS output rows (default 65536; 0: all, -1: none) multiply bf16 head / tail
+        // splits of both operands (spconv_common.hpp mma_f32_k16): the bench batch's levels 1-2, not the deep levels
+        static const long long min_rows = [] { const char *e = getenv("DODA_F32_SPLIT_ROWS"); return e && *e ? atoll(e) : 65536ll; }();
+        ep.f32_split = (sizeof(elem) == 4 && min_rows >= 0 && (long long)n_out >= min_rows) ? 1 : 0;
+    }
     // all rows the table may reference must sit inside the 2 GB buffer window of the fast path
     const bool x_rows_bytes_ok = n_in > 0 && (size_t)n_in * kc * sizeof(elem) < 0x7ffffff0ull;
     const size_t va = 4 * sizeof(elem);  // vector access granule
@@ -1073,7 +1083,7 @@ extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, in
         if (st == DODA_OK && epi && epi->stats_rows_h) *epi->stats_rows_h = 0;
         return st;
     }
-    EpiArgs ep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    EpiArgs ep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     const void *res = nullptr;
     int n_part = 0;
     if (epi) {

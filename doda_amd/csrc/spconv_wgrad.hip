@@ -47,6 +47,42 @@ struct F32 {
     }
 };
 
+// F32S (round 5): fp32 operands, every 16 rows as TWO v_mfma_f32_16x16x32_bf16 on bf16 head / tail splits made in registers
+// (x = hi + lo + e, |e| <= 2^-17 |x|): the k = 32 of an instruction is (4 rows of the lane group) x (head, tail) —
+// A = [a_hi | a_lo] against B = [b_hi | b_hi], then against [b_lo | b_lo]: all four partial products, fp32 accumulate.  The
+// fp32 matrix rate of this part is 1/16 of bf16 and four v_mfma_f32_16x16x4_f32 per 16 rows were the largest item of the
+// fp32 step (4.8 of 13.8 ms of kernels); same LDS reads (one float per lane, row and operand), same bytes.  Used for layers
+// of many rows (plan_job); small layers keep the exact chain.
+struct F32S : F32 {
+    static constexpr int KSTEPS = RT / 16;
+    struct kfrag { unsigned hi[2], lo[2]; };
+    template <int STRIDE>
+    static __device__ __forceinline__ void frags(const elem *tile, int g, int i, int col0, kfrag (&out)[KSTEPS]) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = tile[(ks * 16 + 4 * g + q) * STRIDE + col0 + i];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x2 a = {v[2 * h], v[2 * h + 1]};
+                const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));   // round to nearest even
+                const f32x2 res = {a[0] - __uint_as_float(hu << 16), a[1] - __uint_as_float(hu & 0xffff0000u)};   // exact
+                out[ks].hi[h] = hu;
+                out[ks].lo[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(res, bf16x2));
+            }
+        }
+    }
+    static __device__ __forceinline__ f32x4 mma(const kfrag &a, const kfrag &b, f32x4 c) {
+        const u32x4 av = {a.hi[0], a.hi[1], a.lo[0], a.lo[1]};
+        const u32x4 b1 = {b.hi[0], b.hi[1], b.hi[0], b.hi[1]}, b2 = {b.lo[0], b.lo[1], b.lo[0], b.lo[1]};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b1), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b2), c, 0, 0, 0);
+    }
+};
+
 struct BF16 {
     typedef unsigned short elem;
     typedef s16x4 frag;
@@ -408,6 +444,7 @@ Plan make_plan(int K, int ca, int cb, int n_rows, int elem_bytes, bool multi = f
 struct JobPlan {
     Plan p;
     int esz, vok, key;
+    int split;         // fp32 job multiplied as bf16 head / tail splits (F32S)
     size_t ws_off;     // partials of this job inside the workspace (unused when R == 1)
     long long n_elem;
 };
@@ -420,7 +457,12 @@ bool plan_job(const doda_wgrad_job &j, JobPlan *out) {
     out->vok = ((size_t)j.ca * j.elem_bytes % 16 == 0) && ((size_t)j.cb * j.elem_bytes % 16 == 0) &&
                ((uintptr_t)j.a % 16 == 0) && ((uintptr_t)j.b % 16 == 0);
     out->p = make_plan(j.K, j.ca, j.cb, j.n_rows, j.elem_bytes, true);
-    out->key = (((j.elem_bytes * 4 + out->p.TA) * 4 + out->p.TB) * 8 + out->p.OGW) * 2 + out->vok;
+    {   // fp32 jobs of at least DODA_F32_WGRAD_SPLIT_ROWS rows (default 0: all of them — a weight gradient is a sum over
+        // thousands of rows, and one instantiation for every fp32 job keeps the layers of a step in shared launches; -1: none)
+        static const long long min_rows = [] { const char *e = getenv("DODA_F32_WGRAD_SPLIT_ROWS"); return e && *e ? atoll(e) : 0ll; }();
+        out->split = (j.elem_bytes == 4 && min_rows >= 0 && (long long)j.n_rows >= min_rows) ? 1 : 0;
+    }
+    out->key = ((((j.elem_bytes * 4 + out->p.TA) * 4 + out->p.TB) * 8 + out->p.OGW) * 2 + out->vok) * 2 + out->split;
     out->n_elem = (long long)j.K * j.ca * j.cb;
     return true;
 }
@@ -646,7 +688,8 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
     const WJob *wj_dev = (const WJob *)desc_dev;
     for (const Group &g : groups) {
         const JobPlan &jp = plans[g.rep];
-        if (jp.esz == 4) launch_multi_variant<F32>(jp.p, jp.vok, g.blocks, wj_dev + g.first, g.count, s);
+        if (jp.esz == 4 && jp.split) launch_multi_variant<F32S>(jp.p, jp.vok, g.blocks, wj_dev + g.first, g.count, s);
+        else if (jp.esz == 4) launch_multi_variant<F32>(jp.p, jp.vok, g.blocks, wj_dev + g.first, g.count, s);
         else launch_multi_variant<BF16>(jp.p, jp.vok, g.blocks, wj_dev + g.first, g.count, s);
     }
     int st = doda_check_launch();

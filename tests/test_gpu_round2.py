@@ -562,7 +562,14 @@ def test_full_size_tail_layer_properties(native_lib, dtype):
     # identity on the centre offset
     wi = torch.zeros(27, cin, cout, device=d)
     wi[13, :cout, :] = torch.eye(cout, device=d)
-    assert torch.equal(ops.spconv_gather(x1, wi, tbl, m, 0, cout), x1[:, :cout].contiguous())
+    yi = ops.spconv_gather(x1, wi, tbl, m, 0, cout)
+    if dtype == torch.float32:
+        # (round 5: fp32 layers of >= 65536 rows multiply bf16 head + tail splits of both operands — x = hi + lo + e with
+        # |e| <= 2^-17 |x| — so the identity kernel copies to 2^-16 relative, per element, instead of bit for bit;
+        # DODA_F32_SPLIT_ROWS=-1 restores the exact fp32 MFMA chain)
+        assert float(((yi - x1[:, :cout]).abs() / x1[:, :cout].abs().clamp_min(1e-30)).max()) <= 2.0 ** -16
+    else:
+        assert torch.equal(yi, x1[:, :cout].contiguous())
     y1 = ops.spconv_gather(x1, w, tbl, m, 0, cout).float()
     y2 = ops.spconv_gather(x2, w, tbl, m, 0, cout).float()
     if dtype == torch.float32:   # linearity (exact inputs; bf16 would round x1 + x2)
