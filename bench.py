@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--kernel-reps", type=int, default=50)
     p.add_argument("--fp32-steps", type=int, default=40,
                    help="timed steps of the fp32 sub-record (reference precision); 0 = skip")
+    p.add_argument("--no-train-entry", action="store_true",
+                   help="skip the train_entry sub-record (python -m doda_amd.train on fresh batches, 1 rank and 2 gloo ranks on this GPU)")
+    p.add_argument("--train-entry-scenes", type=int, default=640, help="scenes per run of the train_entry sub-record (4 per iteration)")
     p.add_argument("--prefetch", type=int, default=1,
                    help="1: rulebooks of the next batch are built on a helper thread during the step; 0: in line")
     return p.parse_args()
@@ -448,6 +451,48 @@ def cpu_baseline(args, batch=None, batch_dev=None):
     return out
 
 
+def train_entry(args):
+    """The TRAINING ENTRY POINT on fresh batches (north_star states its scaling target on tool/train.py):
+    `python -m doda_amd.train` as a subprocess — its own loader (dataset resident in HBM, augmentation + collate + rulebooks
+    of batch k+1 on helper threads / side streams while step k is issued: doda_amd/loader.py), meters, LR schedule,
+    optimizer — one rank, then two ranks sharing this GPU over gloo (the collective path at world size 2; RCCL cannot put
+    two ranks on one device).  Steady-state ms per iteration from the trainer's own clock (device drained on both sides)."""
+    import subprocess
+    import tempfile
+    out = {}
+    root = tempfile.mkdtemp(prefix="doda_train_entry_")
+    base = ["-m", "doda_amd.train", "--cfg_file", "doda_amd/cfgs/synthetic/spconv.yaml", "--dtype", args.dtype, "--batch_size"]
+    tail = ["--synthetic_voxels", str(args.voxels), "--synthetic_base", "8", "--epochs", "1", "--print_freq", "100000",
+            "--output_root", root, "--scene_cache", os.path.join(root, "scenes"), "--ckpt_save_freq", "1000",
+            "--set", "EVALUATION.evaluate", "False"]
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    runs = (("one_rank", [sys.executable] + base + [str(args.scenes), "--synthetic_scenes", str(args.train_entry_scenes),
+                          "--timing_json", os.path.join(root, "t1.json")] + tail, env, "t1.json"),
+            ("two_ranks_gloo_one_gpu", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                        "--master-addr", "127.0.0.1", "--master-port", "29631"] + base +
+             [str(2 * args.scenes), "--synthetic_scenes", str(2 * args.train_entry_scenes), "--launcher", "pytorch",
+              "--timing_json", os.path.join(root, "t2.json")] + tail, dict(env, DODA_DIST_BACKEND="gloo"), "t2.json"))
+    try:
+        for name, cmd, e, js in runs:
+            try:
+                r = subprocess.run(cmd, cwd=here, env=e, capture_output=True, text=True, timeout=420)
+                with open(os.path.join(root, js)) as f:
+                    t = json.load(f)
+                out[name] = {"ms_per_iter": t["ms_per_iter"], "iterations": t["iterations"], "world": t["world"],
+                             "scenes_per_rank": t["batch_size_per_gpu"],
+                             "voxels_per_s_whole_job": None,
+                             "feeder_ms_per_batch": [t.get("feeder_wait_for_workers_ms"), t.get("feeder_collate_and_rulebooks_ms")]}
+            except Exception as ex:   # noqa: BLE001  (a sub-record must not take the bench line with it)
+                out[name] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+    finally:
+        import shutil
+        shutil.rmtree(root, ignore_errors=True)
+    return out
+
+
 def main():
     args = parse()
     from doda_amd import dist as ddist
@@ -482,6 +527,8 @@ def main():
     from doda_amd import spconv
     deferred = Fsp.set_deferred_wgrad(True)
     labels = batch_dev["labels"]
+
+    gate_info = {}
 
     def run_training(dtype_name, steps, warmup):
         """`warmup` untimed + `steps` timed training steps with a fresh network; returns
@@ -532,6 +579,7 @@ def main():
             pending[0].result()
             prefetch.shutdown()
             if prefetch.gated:   # (A/B aid: steps whose build started without the coarse-phase event)
+                gate_info[dtype_name] = {"gate_timeouts": prefetch.gate_timeouts, "builds": steps + warmup}
                 sys.stderr.write("[bench] gated prefetch: %d of %d builds ungated (timeouts)\n" % (prefetch.gate_timeouts, steps + warmup))
         return dt, float(loss.detach()), net
 
@@ -577,6 +625,7 @@ def main():
                                        "%s, %d ranks" % (dist.get_backend(), world)),
                        "rulebooks": "13 per step, built for the next batch on a helper thread + side stream "
                                     "during the step" if args.prefetch else "13 per step, built in line",
+                       "prefetch_gate": gate_info.get(args.dtype, "off"),
                        "rulebook_parity": "bit-exact vs this repo's restatement of spconv-1.2's CPU algorithm; "
                                           "spconv is not vendored by the reference: orderings unpinned"},
             "roofline": roof,
@@ -600,6 +649,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, batch, batch_dev)
             roof["detail"]["voxelize_idx_device"] = line["cpu_baseline"]["voxelize_idx"]["device"]
+        if world == 1 and not args.no_train_entry and not dist.is_initialized():
+            del batch_dev, net           # (the subprocesses share this GPU)
+            torch.cuda.empty_cache()
+            te = train_entry(args)
+            for rec in te.values():
+                if "ms_per_iter" in rec:
+                    rec["voxels_per_s_whole_job"] = m_local / args.scenes * rec["scenes_per_rank"] * rec["world"] / (rec["ms_per_iter"] * 1e-3)
+                    rec["vs_resident_batch_step"] = rec["ms_per_iter"] / (elapsed / args.steps * 1e3)
+            line["train_entry"] = te
         print(json.dumps(line), flush=True)
     ddist.barrier()
     if dist.is_initialized():

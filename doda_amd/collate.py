@@ -71,3 +71,20 @@ def collate_device(items, device, batch_size=None, voxel_mode=4, full_scale=(128
         ratio = ratio + r
     out["tar_splits_class_ratio"] = ratio
     return out
+
+
+def collate_device_concat(hb, device, voxel_mode=4):
+    """The batch dictionary from a host-side concatenation (doda_amd.loader.host_collate, run in the DataLoader workers like
+    the reference's collate_fn): three uploads, the widening to the reference's dtypes and `voxelization_idx` on the device.
+    Same keys and values as collate_device on the same scenes."""
+    device = torch.device(device)
+    locs = hb["locs32"].to(device, non_blocking=True).to(torch.int64)
+    locs_float = hb["locs_float"].to(device, non_blocking=True)
+    labels = hb["labels32"].to(device, non_blocking=True).to(torch.int64)
+    batch_size = hb["offsets"].numel() - 1
+    voxel_locs, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(locs, batch_size, voxel_mode)
+    return {"locs": locs, "voxel_locs": voxel_locs, "p2v_map": p2v_map, "v2p_map": v2p_map,
+            "v2p_map_t": v2p_map[:, 1:].t().contiguous(),
+            "locs_float": locs_float, "feats": locs_float.clone(), "labels": labels,
+            "offsets": hb["offsets"], "spatial_shape": hb["spatial_shape"], "id": hb["id"],
+            "mix_idx": [], "tar_tail_splits": [], "selected_idx": [], "mask1": [], "mask2": [], "tar_splits_class_ratio": []}

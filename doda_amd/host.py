@@ -71,9 +71,10 @@ def pin_to_device_numa(device_index=0):
 def raise_issue_priority():
     """Scheduling priority of the calling (kernel-issuing) thread.  A training step here is ~500 dependent launches whose issue
     takes 4-5 ms of host time against ~5.5 ms of GPU time: on a host shared with other jobs every preemption of the issuing
-    thread is GPU idle time.  DODA_HOST_PRIO = "fifo" (SCHED_FIFO 10, needs CAP_SYS_NICE), "nice" (nice -15), "0"/"off" (nothing);
-    default: try nice.  Returns what was applied (a string) or None."""
-    mode = os.environ.get("DODA_HOST_PRIO", "nice").lower()
+    thread is GPU idle time.  OPT-IN (a benchmark must not boost itself over a shared host's other jobs by default):
+    DODA_HOST_PRIO = "fifo" (SCHED_FIFO 10, needs CAP_SYS_NICE) or "nice" (nice -15); unset / "0" / "off": nothing.
+    Returns what was applied (a string) or None."""
+    mode = os.environ.get("DODA_HOST_PRIO", "off").lower()
     if mode in ("0", "off", "none", ""):
         return None
     try:

@@ -63,11 +63,20 @@ def build_parser():
     p.add_argument("--pin_memory", action="store_true", default=False)
     p.add_argument("--synthetic_scenes", type=int, default=32, help="scenes per epoch of the synthetic loader")
     p.add_argument("--synthetic_voxels", type=int, default=150000, help="active voxels per synthetic scene")
+    p.add_argument("--synthetic_base", type=int, default=16, help="procedural base scenes per split (samples = augmented base scenes)")
+    p.add_argument("--scene_cache", type=str, default=None, help="directory of the base scenes (default: /dev/shm/doda_amd_scenes_<uid>)")
+    p.add_argument("--host_loader", action="store_true", default=False,
+                   help="DataLoader worker processes + uploads per batch (reference dataset/__init__.py:62-75) instead of the "
+                        "dataset resident in HBM with the augmentation on the device (doda_amd.loader.DeviceScenes)")
+    p.add_argument("--inline_loader", action="store_true", default=False,
+                   help="generate and collate every batch in the training loop's own thread (the pre-round-5 loader)")
     p.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="feature storage dtype")
     p.add_argument("--self_train", action="store_true", default=False,
                    help="tool/st.py step: a source pass and a target pass per optimizer step")
     p.add_argument("--output_root", type=str, default=None, help="default: <cfg root>/output")
     p.add_argument("--max_iters", type=int, default=None, help="stop after this many iterations (smoke runs)")
+    p.add_argument("--timing_warmup", type=int, default=10, help="iterations of an epoch before its steady-state clock starts")
+    p.add_argument("--timing_json", type=str, default=None, help="write {iterations, seconds, ms_per_iter, voxels_per_s} here at exit")
     p.add_argument("--set", dest="set_cfgs", default=None, nargs=argparse.REMAINDER,
                    help="set extra config keys if needed")
     return p
@@ -293,6 +302,8 @@ class Trainer:
         self.n_levels = len(net.unet.nPlanes)
         self.prefetch = PyramidPrefetcher(device, self.n_levels) if device.type == "cuda" else None
         self.iters_done = 0
+        self._loaders = {}
+        self.step_times = []      # (iterations, seconds) of the steady part of every epoch (see train_epoch)
 
     # one forward + backward of one batch; `domain`: None | "source" | "target" (DSNorm statistics)
     def _pass(self, batch, pyramid, domain, weight=1.0):
@@ -307,9 +318,47 @@ class Trainer:
         (loss * weight if weight != 1.0 else loss).backward()
         return loss, scores.detach().argmax(1), labels
 
+    def _loader(self, split):
+        """(iterable of host / device batches, object with set_epoch) per split, made once: the dataset resident in HBM
+        (default) or a persistent DataLoader with worker processes (--host_loader; reference dataset/__init__.py:62-75)."""
+        from . import dist as ddist
+        from .loader import DeviceScenes, host_loader, synthetic_dataset
+        if split not in self._loaders:
+            if self.rank == 0:
+                ds = synthetic_dataset(self.cfg, self.args, split)      # (generates missing base scenes)
+            ddist.barrier()
+            if self.rank != 0:
+                ds = synthetic_dataset(self.cfg, self.args, split)
+            seed = self.args.manual_seed or 0
+            if self.args.host_loader:
+                self._loaders[split] = host_loader(ds, self.args.batch_size, self.rank, self.world, self.args.workers,
+                                                   shuffle=split != "val", seed=seed)
+            else:
+                dsc = DeviceScenes(ds.paths, ds.length, ds.voxel_scale, ds.seed + seed, self.args.batch_size, self.rank, self.world,
+                                   self.device, augment=ds.augment, shuffle=split != "val",
+                                   full_scale0=self.cfg.DATA_CONFIG.DATA_PROCESSOR.get("full_scale", [128, 512])[0])
+                self._loaders[split] = (dsc, dsc)
+        return self._loaders[split]
+
     def _batches(self, epoch, split):
-        """(batch, prebuilt rulebooks) with the rulebooks of batch k+1 in flight while batch k is used."""
+        """(batch, prebuilt rulebooks): worker processes produce the scenes, a feeder thread collates them on the device and
+        builds their rulebooks two batches ahead (doda_amd.loader); --inline_loader: everything in this thread, as before."""
         from .model import PyramidPrefetcher
+        if not self.args.inline_loader and self.device.type == "cuda":
+            from .loader import DeviceFeeder
+            dl, sampler = self._loader(split)
+            sampler.set_epoch(epoch)
+            feeder = DeviceFeeder(iter(dl), self.device, prefetcher=self.prefetch, with_pairs=self.with_pairs,
+                                  with_tiles=self.with_tiles, voxel_mode=self.cfg.DATA_CONFIG.DATA_PROCESSOR.voxel_mode,
+                                  full_scale=self.cfg.DATA_CONFIG.DATA_PROCESSOR.get("full_scale", [128, 512]))
+            try:
+                for pair in feeder:
+                    yield pair
+            finally:
+                feeder.close()
+                if feeder.batches:
+                    self.feeder_ms = (1e3 * feeder.wait_host_s / feeder.batches, 1e3 * feeder.collate_s / feeder.batches)
+            return
         it = make_loader(self.cfg, self.args, self.device, self.rank, self.world, epoch, split)
         nxt = next(it, None)
         fut = self.prefetch.submit(nxt, self.with_pairs, self.with_tiles, now=True) if (nxt is not None and self.prefetch) else None
@@ -326,7 +375,12 @@ class Trainer:
         n_iter = max(1, args.synthetic_scenes // (args.batch_size * self.world))
         target = self._batches(epoch, "target") if args.self_train else None
         t0 = time.time()
+        warm = min(getattr(args, "timing_warmup", 10), max(0, n_iter - 2))
+        t_steady = None
         for i, (batch, pyramid) in enumerate(self._batches(epoch, "train")):
+            if i == warm:   # steady-state clock: from here to the end of the epoch, device drained on both sides
+                torch.cuda.synchronize(self.device)
+                t_steady = (time.time(), i)
             lr = adjust_lr(cfg.OPTIMIZATION, self.optimizer, None, total_epochs, n_iter, epoch, i)
             self.optimizer.zero_grad(set_to_none=True)
             if args.self_train:   # tool/st.py:136-198: source pass, then target pass, ONE optimizer step
@@ -350,6 +404,12 @@ class Trainer:
                     epoch + 1, total_epochs, i + 1, n_iter, (time.time() - t0) / (i + 1), l, allacc, lr))
             if args.max_iters is not None and self.iters_done >= args.max_iters:
                 break
+        if t_steady is not None:
+            torch.cuda.synchronize(self.device)
+            done = i + 1 - t_steady[1]
+            if done > 0:
+                self.step_times.append((done, time.time() - t_steady[0]))
+                self.log("Steady state: %d iterations, %.3f ms per iteration" % (done, 1e3 * self.step_times[-1][1] / done))
         meters.all_reduce()
         l, miou, macc, allacc, _ = meters.read()
         self.log("Train result at epoch [%d/%d]: mIoU/mAcc/allAcc %.4f/%.4f/%.4f." % (epoch + 1, total_epochs, miou, macc, allacc))
@@ -447,6 +507,16 @@ def main(argv=None):
             break
     if trainer.prefetch is not None:
         trainer.prefetch.shutdown()
+    if args.timing_json and rank == 0 and trainer.step_times:
+        import json
+        its = sum(t[0] for t in trainer.step_times)
+        sec = sum(t[1] for t in trainer.step_times)
+        with open(args.timing_json, "w") as f:
+            json.dump({"iterations": its, "seconds": sec, "ms_per_iter": 1e3 * sec / its, "world": world,
+                       "batch_size_per_gpu": args.batch_size, "workers": args.workers, "dtype": args.dtype,
+                       "voxels_per_scene": args.synthetic_voxels,
+                       "feeder_wait_for_workers_ms": getattr(trainer, "feeder_ms", (None, None))[0],
+                       "feeder_collate_and_rulebooks_ms": getattr(trainer, "feeder_ms", (None, None))[1]}, f)
     ddist.barrier()
 
 
