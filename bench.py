@@ -529,6 +529,7 @@ def main():
     labels = batch_dev["labels"]
 
     gate_info = {}
+    sync_info = {}
 
     def run_training(dtype_name, steps, warmup):
         """`warmup` untimed + `steps` timed training steps with a fresh network; returns
@@ -552,6 +553,8 @@ def main():
 
         def step():
             opt.zero_grad(set_to_none=True)
+            if reducer is not None:
+                reducer.arm()       # (the exchange of the deep levels' gradients starts inside this step's backward pass)
             pyramid = None
             if prefetch is not None:
                 pyramid = PyramidPrefetcher.take(pending[0], dev)
@@ -567,6 +570,13 @@ def main():
 
         for _ in range(warmup):
             step()
+        if reducer is not None and reducer.active and warmup > 0:   # (one extra untimed step with event timing: where the exchange starts)
+            reducer.time_window = True
+            step()
+            sync_info[dtype_name] = {"early_start_to_end_of_backward_ms": reducer.overlap_window_ms(),
+                                     "early_bucket_MB": sum(b.flat.numel() for b in reducer.buckets) * 4 / 1e6,
+                                     "late_bucket_MB": sum(b.flat.numel() for b in reducer.late_buckets) * 4 / 1e6}
+            reducer.time_window = False
         ddist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -626,6 +636,7 @@ def main():
                        "rulebooks": "13 per step, built for the next batch on a helper thread + side stream "
                                     "during the step" if args.prefetch else "13 per step, built in line",
                        "prefetch_gate": gate_info.get(args.dtype, "off"),
+                       "grad_exchange": sync_info.get(args.dtype, "no process group"),
                        "rulebook_parity": "bit-exact vs this repo's restatement of spconv-1.2's CPU algorithm; "
                                           "spconv is not vendored by the reference: orderings unpinned"},
             "roofline": roof,

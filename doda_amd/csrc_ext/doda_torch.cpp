@@ -554,6 +554,35 @@ void flush_wgrads() {
     issue_in_rounds(narrow, *st);
 }
 
+// Early flush (data-parallel overlap): issue every job queued SO FAR — called from a tensor hook when the
+// backward pass leaves the deep levels, whose layers carry 28 of the 30 MB of gradients — on the backward pass's own stream,
+// and record the event the reducer's side stream waits for.  The engine callback stays registered: jobs queued afterwards
+// (the encoder of levels 1-2) are issued by the ordinary flush when backward ends.  Returns the number of jobs issued.
+int64_t flush_wgrads_early() {
+    std::vector<PendingWgrad> q;
+    c10::optional<c10::hip::HIPStream> st;
+    {
+        std::lock_guard<std::mutex> lock(g_wq_mu);
+        q.swap(g_wq);
+        st = g_wq_stream;
+    }
+    if (q.empty() || !st) return 0;
+    const int64_t n = (int64_t)q.size();
+    issue_in_rounds(q, *st);
+    if (g_ev_early && g_ev_early_dev != (int)st->device_index()) {
+        hipEventDestroy(g_ev_early);
+        g_ev_early = nullptr;
+    }
+    if (!g_ev_early) {
+        c10::hip::HIPGuard dev_guard(st->device_index());
+        TORCH_CHECK(hipEventCreateWithFlags(&g_ev_early, hipEventDisableTiming) == hipSuccess, "doda: hipEventCreate");
+        g_ev_early_dev = (int)st->device_index();
+    }
+    TORCH_CHECK(hipEventRecord(g_ev_early, st->stream()) == hipSuccess, "doda: hipEventRecord");
+    g_ev_early_valid = true;
+    return n;
+}
+
 // true when the job was queued (the caller then returns no gradient for the weight)
 bool try_defer_wgrad(const at::Tensor &features, const at::Tensor &dy, const at::Tensor &tbl, int64_t n_rows,
                      const at::Tensor &weight, const PairLists &pl) {
@@ -1672,7 +1701,28 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           "with set_defer_wgrad: the extension's nodes write parameter gradients to .grad themselves and keep no autograd edge to "
           "the parameters (no AccumulateGrad nodes for them)");
     m.def("get_direct_grads", []() { return g_direct_grads; });
+    m.def("grads_into_views", [](const std::vector<at::Tensor> &params, const std::vector<at::Tensor> &views) {
+              // GradAllReduce's per-step pass over its parameters (doda_amd/dist.py _Bucket.gather_in_place) in one call: a
+              // gradient already living in its bucket view costs a pointer compare; a stray one is copied in, a missing one
+              // zero-filled; .grad is re-bound to the view.  Returns how many were NOT in place.  (281 parameters x ~1.5 us of
+              // Python per step sat in front of the collectives on a host-bound step.)
+              TORCH_CHECK(params.size() == views.size(), "doda grads_into_views: list lengths differ");
+              at::NoGradGuard no_grad;
+              int64_t moved = 0;
+              for (size_t k = 0; k < params.size(); ++k) {
+                  at::Tensor &slot = const_cast<at::Tensor &>(params[k]).mutable_grad();
+                  const at::Tensor &v = views[k];
+                  if (!slot.defined()) const_cast<at::Tensor &>(v).zero_();
+                  else if (slot.data_ptr() != v.data_ptr() || slot.strides() != v.strides()) const_cast<at::Tensor &>(v).copy_(slot);
+                  else continue;
+                  slot = v;
+                  ++moved;
+              }
+              return moved;
+          }, "re-home every parameter's gradient in its bucket view (copy / zero-fill only where it is not there already)");
     m.def("flush_wgrads", &flush_wgrads);
+    m.def("flush_wgrads_early", &flush_wgrads_early,
+          "issue the weight-gradient jobs queued so far (mid-backward) and record the event wait_wide_wgrads() waits for");
     m.def("set_grad_home", &set_grad_home, "view of a flat gradient bucket that receives the parameter's gradient in place (None: forget)");
     m.def("clear_grad_homes", &clear_grad_homes);
     m.def("set_wgrad_split", [](bool on) { g_wq_split = on; if (!on) g_ev_early_valid = false; },

@@ -92,6 +92,13 @@ class _Bucket:
         wrote there (doda_amd's conv weight gradients and BatchNorm gamma / beta, through the extension's gradient
         homes) costs nothing; a stray one (another producer, an accumulated second pass that left its home) is copied;
         a missing one counts as zeros, so every rank sends the same message whatever its batch touched."""
+        if self.params and self.params[0].is_cuda:
+            try:
+                from ._ext import ext as _ext
+            except Exception:
+                _ext = None
+            if _ext is not None and hasattr(_ext, "grads_into_views"):
+                return int(_ext.grads_into_views(self.params, self.views))   # (the same pass without the interpreter)
         moved = 0
         for p, v in zip(self.params, self.views):
             g = p.grad
@@ -140,6 +147,11 @@ class GradAllReduce:
         self._ext = None
         self.last_moved = 0
         narrow = []
+        self.armed = False          # arm(): the NEXT backward pass is the last one before reduce()
+        self.time_window = False    # measurement aid: time from the early start to the end of backward (overlap_window_ms)
+        self._ev_early = self._ev_done = None
+        self._early_pending = None
+        self._early_mode = False
         try:
             from ._ext import ext as _ext
         except Exception:
@@ -147,6 +159,20 @@ class GradAllReduce:
         on_gpu = bool(self.params) and self.params[0].is_cuda
         if overlap and self.active and on_gpu and _ext is not None and hasattr(_ext, "set_wgrad_split"):
             narrow = [p for p in self.params if p.dim() == 5 and p.shape[3] <= 32 and p.shape[4] <= 32]
+            # (round 5) a U-Net: the LATE set is instead what the backward pass produces last — the encoder of levels 1-2
+            # (input conv, blocks and strided conv of the two finest levels: 0.2 of the 30 MB); everything else is complete
+            # when backward leaves level 3 and its exchange starts THERE, under the level-2 / level-1 backward kernels
+            # (model.py fires `start_early` from a tensor hook; reference: DDP's bucket hooks, tool/train.py:360-361)
+            late_prefixes = ("input_conv.", "unet.blocks.", "unet.conv.", "unet.u.blocks.", "unet.u.conv.")
+            named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+            enc = [p for n, p in named if n.startswith(late_prefixes)]
+            # OPT-IN (DODA_EARLY_ALLREDUCE=1): measured under a forced one-rank RCCL group the mid-backward flush + collective
+            # issue cost the host-bound step 0.8-1.0 ms (6.8-7.0 against 5.7-6.0 ms with the end-of-backward split below),
+            # more than the 0.35-0.7 ms an 8-GPU ring would expose
+            if (os.environ.get("DODA_EARLY_ALLREDUCE", "0") == "1" and hasattr(_ext, "flush_wgrads_early") and enc
+                    and len(enc) < len(named) and any(n.startswith("unet.u.u.") for n, _ in named)):
+                narrow = enc
+                self._early_mode = True
             if narrow and len(narrow) < len(self.params):
                 self._split = True
                 from .streams import independent_stream
@@ -220,9 +246,58 @@ class GradAllReduce:
             if not self._avg:
                 b.flat.mul_(1.0 / self.world)
 
+    def arm(self):
+        """The next backward pass is the last before reduce(): its tensor hook (doda_amd.model) may start the exchange early.
+        (tool/st.py runs two backward passes per optimizer step: only the second may.)"""
+        self.armed = bool(self.active and self._split and self._early_mode)
+        if self.armed:
+            from . import model as _model
+            _model.set_early_exchange(self._on_deep_levels_done)
+        return self.armed
+
+    def overlap_window_ms(self):
+        """Main-stream time between the early start of the deep levels' all-reduce and the end of the backward pass of the
+        last reduced step (time_window = True): what the exchange has to hide in.  Synchronises."""
+        if self._ev_early is None or self._ev_done is None:
+            return None
+        self._ev_done.synchronize()
+        return self._ev_early.elapsed_time(self._ev_done)
+
+    def _on_deep_levels_done(self):
+        """Fired inside backward when the gradient of level 3's input exists: every layer of levels >= 3 and the whole decoder
+        have run.  Issues their queued weight gradients now (main stream) and starts the all-reduce of their buckets on the
+        side stream behind that launch."""
+        if not self.armed or self._early_pending is not None:
+            return
+        self.armed = False
+        from ._ext import ext as _ext
+        self.last_moved = 0
+        _ext.flush_wgrads_early()
+        if self.time_window:
+            self._ev_early = torch.cuda.Event(enable_timing=True)
+            self._ev_early.record()
+        if _ext.wait_wide_wgrads(self._side.cuda_stream):
+            with torch.cuda.stream(self._side):
+                self._early_pending = self._start(self.buckets)
+
     def reduce(self):
         """Call between loss.backward() and optimizer.step()."""
         if not self.active:
+            return
+        self.armed = False
+        if self._early_pending is not None:     # the deep levels' buckets have been travelling since mid-backward
+            main = torch.cuda.current_stream()
+            if self.time_window and self._ev_early is not None:
+                self._ev_done = torch.cuda.Event(enable_timing=True)
+                self._ev_done.record()
+            early, self._early_pending = self._early_pending, None
+            late = self._start(self.late_buckets)
+            with torch.cuda.stream(self._side):
+                self._finish(early)
+            self._finish(late)
+            main.wait_stream(self._side)
+            from ._ext import ext as _ext
+            _ext.wait_wide_wgrads(self._side.cuda_stream)   # (consume the split flush's event of this pass, if any)
             return
         self.last_moved = 0
         main = torch.cuda.current_stream() if self._split else None

@@ -243,6 +243,16 @@ def _plain_conv(m, cls, ksize):
             and not (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks))
 
 
+# Early gradient exchange (doda_amd.dist.GradAllReduce.arm): a callback fired from a tensor hook when the backward pass has
+# produced the gradient of level EARLY_LEVEL's input — every deeper layer and the whole decoder are done by then.
+EARLY_LEVEL = 3
+_early_exchange = [None]
+
+
+def set_early_exchange(fn):
+    _early_exchange[0] = fn
+
+
 # Level at which the forward pass turns launch-floor bound (a few thousand rows and fewer): PyramidPrefetcher starts the
 # NEXT batch's rulebook kernels there instead of next to the level-1 convolutions (see PyramidPrefetcher.submit).
 COARSE_LEVEL = 4
@@ -387,6 +397,12 @@ class UBlock(nn.Module):
         if self.level == COARSE_LEVEL and _coarse_hooks and self.training and torch.is_grad_enabled():   # (training steps only)
             for hook in list(_coarse_hooks):   # the step enters its coarse levels: few rows, most CUs idle from here on
                 hook()
+        if (self.level == EARLY_LEVEL and _early_exchange[0] is not None and self.training and torch.is_grad_enabled()
+                and input.features.requires_grad):
+            def _fire(g, fn=_early_exchange[0]):
+                fn()
+                return g
+            input.features.register_hook(_fire)
         if COARSE_EXEC and self.level == COARSE_EXEC_LEVEL:
             out = self._forward_coarse(input)
             if out is not None:

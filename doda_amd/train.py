@@ -388,8 +388,12 @@ class Trainer:
                 loss, preds, labels = self._pass(batch, pyramid, "source",
                                                  st.get("SRC", Config()).get("loss_weight", 1.0))
                 tb, tp = next(target)
+                if self.reducer is not None:
+                    self.reducer.arm()      # (the second backward pass completes the gradients: its hook may start the exchange)
                 self._pass(tb, tp, "target", st.get("TAR", Config()).get("loss_weight", 1.0))
             else:
+                if self.reducer is not None:
+                    self.reducer.arm()
                 loss, preds, labels = self._pass(batch, pyramid, "source")
             if self.reducer is not None:
                 self.reducer.reduce()

@@ -24,7 +24,7 @@ def _free_port():
 def _worker(rank, world, port, dtype_name, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
-                          LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                          LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", DODA_EARLY_ALLREDUCE="1")
         import torch.distributed as dist
         from doda_amd import dist as ddist
         from doda_amd.dsnorm import DSNorm, set_ds_source, set_ds_target
@@ -55,24 +55,36 @@ def _worker(rank, world, port, dtype_name, q):
                for r in range(world)]
         state = {k: v.clone() for k, v in net.state_dict().items()}
 
-        def grads_of(r, self_train):
-            """gradient of rank r's step, computed locally with the buffers reset (deterministic kernels)"""
+        def grads_of(r, self_train, arm=False):
+            """gradient of rank r's step, computed locally with the buffers reset (deterministic kernels).  arm: the LAST
+            backward pass may start the exchange of the deep levels' buckets from its tensor hook (GradAllReduce.arm)."""
             net.load_state_dict(state)
             net.zero_grad(set_to_none=True)
             net.apply(set_ds_source)
+            if arm and not self_train:
+                assert red.arm()
             cross_entropy(voxelize_and_run(cfg, net, batches[r], dev, feature_dtype=dtype), batches[r]["labels"]).backward()
             if self_train:                           # tool/st.py:162-168: target pass, DSNorm target statistics
                 net.apply(set_ds_target)
+                if arm:
+                    assert red._early_pending is None    # (the first pass must NOT have started anything)
+                    assert red.arm()
                 (cross_entropy(voxelize_and_run(cfg, net, tgt[r], dev, feature_dtype=dtype), tgt[r]["labels"]) * 0.5).backward()
+            if arm:
+                assert red._early_pending is not None and len(red._early_pending) == len(red.buckets)
+                return None
             torch.cuda.synchronize()
             return [p.grad.detach().clone() for p in net.parameters()]
 
         worst = 0.0
-        for self_train in (False, True):
+        assert red._early_mode and sum(p.numel() for b in red.late_buckets for p in b.params) < 0.05 * sum(p.numel() for p in net.parameters())
+        for self_train, arm in ((False, False), (True, False), (False, True), (True, True)):
             want = [sum(g) / world for g in zip(*[grads_of(r, self_train) for r in range(world)])]
-            mine = grads_of(rank, self_train)        # leaves this rank's gradients in .grad
-            assert all(torch.equal(a, b.grad) for a, b in zip(mine, net.parameters()))
+            mine = grads_of(rank, self_train, arm)   # leaves this rank's gradients in .grad (armed: the exchange under way)
+            if not arm:
+                assert all(torch.equal(a, b.grad) for a, b in zip(mine, net.parameters()))
             red.reduce()
+            assert red._early_pending is None
             for w, p in zip(want, net.parameters()):
                 scale = float(w.abs().max()) + 1e-12
                 worst = max(worst, float((p.grad - w).abs().max()) / scale)
