@@ -29,6 +29,17 @@ sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
 GOLDEN_SCENES, GOLDEN_VOXELS, GOLDEN_SEED = 2, 10000, 4242
+GRAD_SAMPLE = 4096
+
+
+def grad_sample_index(name, numel):
+    """Positions of the elementwise gradient sample of parameter `name`: a fixed multiplicative sequence
+    through the flattened tensor — reproduced by the test, so only the VALUES are stored.  Small tensors are taken whole."""
+    import zlib
+    if numel <= GRAD_SAMPLE:
+        return np.arange(numel, dtype=np.int64)
+    start = zlib.crc32(name.encode()) % numel
+    return (start + np.arange(GRAD_SAMPLE, dtype=np.int64) * 2654435761) % numel
 
 
 def import_reference_model():
@@ -72,11 +83,17 @@ def main(voxels=GOLDEN_VOXELS):
         with open(os.path.join(HERE, "unet_state_keys.json"), "w") as f:
             json.dump(keys, f, indent=0, sort_keys=True)
     names = sorted(grads)
+    params = dict(net.named_parameters())
+    # elementwise sample of every parameter gradient (a permuted or sign-flipped block inside a weight gradient keeps its norm)
+    sample = [params[n].grad.reshape(-1)[torch.from_numpy(grad_sample_index(n, params[n].numel()))].numpy() for n in names]
+    gs_off = np.cumsum([0] + [len(v) for v in sample]).astype(np.int64)
     np.savez_compressed(
         os.path.join(HERE, "unet_golden.npz" if small else "unet_golden_%dk.npz" % (GOLDEN_SCENES * voxels // 1000)),
         scores_head=scores[:4096].detach().numpy().astype(np.float32),
         scores_colsum=scores.detach().sum(0).numpy(), scores_abssum=float(scores.detach().abs().sum()),
         loss=float(loss), grad_names=np.array(names), grad_norms=np.array([grads[n] for n in names]),
+        grad_sample_offsets=gs_off, grad_sample_values=np.concatenate(sample).astype(np.float32),
+        grad_absmax=np.array([float(params[n].grad.abs().max()) for n in names]),
         n_points=batch["locs"].shape[0], n_voxels=batch["voxel_locs"].shape[0],
         voxel_checksum=int(batch["voxel_locs"].numpy().astype(np.int64).sum()),
         running_mean_l1=float(net.state_dict()["output_layer.0.running_mean"].abs().sum()))
