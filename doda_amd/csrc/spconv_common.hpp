@@ -31,7 +31,10 @@ __device__ __forceinline__ void mma_bf16_k32(f32x4 &acc, const u32x4 &w, const u
 // subtraction exact) and the unit becomes TWO v_mfma_f32_16x16x32_bf16 (32 cycles): the k = 32 of one instruction is
 // (4 channels of the lane group) x (head, tail) — A = [w_hi | w_lo] against B = [x_hi | x_hi], then against [x_lo | x_lo]:
 // all four partial products, fp32 accumulate.  The gathered bytes do not change (fp32 rows, fp32 fragment buffer).  Error of a
-// product <= ~2^-16 relative (north_star: 1e-4 on fp32 features); DODA_F32_EXACT_MFMA=1 at build time keeps the fp32 chain.
+// product <= ~2^-16 relative (north_star: 1e-4 on fp32 features).  OPT-IN per launch (DODA_F32_SPLIT_ROWS /
+// DODA_F32_WGRAD_SPLIT_ROWS, see run_gather): measured -6 % on the fp32 step, but the U-Net's gradients move from ~1e-3 to
+// ~7e-3 (elementwise, relative) away from the fp64 golden, and fp32 is the parity precision here.  DODA_F32_EXACT_MFMA=1 at
+// build time removes the split instantiations altogether.
 #ifndef DODA_F32_EXACT_MFMA
 #define DODA_F32_EXACT_MFMA 0
 #endif

@@ -856,9 +856,12 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     elem *y = (elem *)y_;
     const int NB = (nc + 15) / 16;
     EpiArgs ep = ep_arg;
-    {   // fp32 layers of at least DODA_F32_SPLIT_ROWS output rows (default 65536; 0: all, -1: none) multiply bf16 head / tail
-        // splits of both operands (spconv_common.hpp mma_f32_k16): the bench batch's levels 1-2, not the deep levels
-        static const long long min_rows = [] { const char *e = getenv("DODA_F32_SPLIT_ROWS"); return e && *e ? atoll(e) : 65536ll; }();
+    {   // OPT-IN: fp32 layers of at least DODA_F32_SPLIT_ROWS output rows (e.g. 65536; 0: all; unset / -1: none) multiply bf16
+        // head / tail splits of both operands (spconv_common.hpp mma_f32_k16).  Measured (round 5): fp32 step 11.85 -> 11.1 ms
+        // with every weight gradient and the >= 65536-row gathers split, every 1e-4 kernel test and the golden's gradient
+        // NORMS (5e-3) still green — but the elementwise distance of the U-Net's gradients from the fp64 golden grows from
+        // ~1e-3 to ~7e-3 (2^-16 products through 70 layers), and fp32 is this repository's PARITY precision: exact by default
+        static const long long min_rows = [] { const char *e = getenv("DODA_F32_SPLIT_ROWS"); return e && *e ? atoll(e) : -1ll; }();
         ep.f32_split = (sizeof(elem) == 4 && min_rows >= 0 && (long long)n_out >= min_rows) ? 1 : 0;
     }
     // all rows the table may reference must sit inside the 2 GB buffer window of the fast path

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
                     for (int s = 0; s < S; ++s) {
 #pragma unroll
                         for (int b = 0; b < NBA; ++b) {
-                            if constexpr (MODE == 2) mma_f32_k16<true>(acc[s][b], wr[u & 3][b], xa[u & 1][s]);   // (round 5: bf16 head / tail splits — tilebooks exist for >= 32768 rows only)
+                            if constexpr (MODE == 2) mma_f32_k16<false>(acc[s][b], wr[u & 3][b], xa[u & 1][s]);
                             else mma_bf16_k32(acc[s][b], wr[u & 3][b], xa[u & 1][s]);
                         }
                     }
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
                     for (int s = 0; s < S; ++s) {
 #pragma unroll
                         for (int b = 0; b < NBA; ++b) {
-                            if constexpr (MODE == 2) mma_f32_k16<true>(acc[s][b], wu[b], xo[u & 1][s]);
+                            if constexpr (MODE == 2) mma_f32_k16<false>(acc[s][b], wu[b], xo[u & 1][s]);
                             else mma_bf16_k32(acc[s][b], wu[b], xo[u & 1][s]);
                         }
                     }

@@ -457,9 +457,9 @@ bool plan_job(const doda_wgrad_job &j, JobPlan *out) {
     out->vok = ((size_t)j.ca * j.elem_bytes % 16 == 0) && ((size_t)j.cb * j.elem_bytes % 16 == 0) &&
                ((uintptr_t)j.a % 16 == 0) && ((uintptr_t)j.b % 16 == 0);
     out->p = make_plan(j.K, j.ca, j.cb, j.n_rows, j.elem_bytes, true);
-    {   // fp32 jobs of at least DODA_F32_WGRAD_SPLIT_ROWS rows (default 0: all of them — a weight gradient is a sum over
-        // thousands of rows, and one instantiation for every fp32 job keeps the layers of a step in shared launches; -1: none)
-        static const long long min_rows = [] { const char *e = getenv("DODA_F32_WGRAD_SPLIT_ROWS"); return e && *e ? atoll(e) : 0ll; }();
+    {   // OPT-IN (see spconv_gather.hip run_gather): fp32 jobs of at least DODA_F32_WGRAD_SPLIT_ROWS rows (0: all of them — one
+        // instantiation for every fp32 job keeps the layers of a step in shared launches; unset / -1: none, the exact chain)
+        static const long long min_rows = [] { const char *e = getenv("DODA_F32_WGRAD_SPLIT_ROWS"); return e && *e ? atoll(e) : -1ll; }();
         out->split = (j.elem_bytes == 4 && min_rows >= 0 && (long long)j.n_rows >= min_rows) ? 1 : 0;
     }
     out->key = ((((j.elem_bytes * 4 + out->p.TA) * 4 + out->p.TB) * 8 + out->p.OGW) * 2 + out->vok) * 2 + out->split;

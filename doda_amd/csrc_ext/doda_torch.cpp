@@ -428,6 +428,16 @@ inline bool direct_leaf(const at::Tensor &p) {
     return g_direct_grads && g_defer_wgrad && p.defined() && p.requires_grad() && p.is_leaf() &&
            p.scalar_type() == at::kFloat && p.is_contiguous();
 }
+// A backward pass that was asked for SPECIFIC gradients (torch.autograd.grad(loss, x), loss.backward(inputs=[...])) carries a
+// non-empty exec_info map; a plain loss.backward() — every leaf accumulates — an empty one.  The direct path has no edge the
+// engine could consult per parameter, so in a restricted pass the nodes neither compute nor deposit parameter gradients
+// (such passes used to mutate .grad and pay for a full weight gradient).  torch.autograd.grad(loss, params) still
+// does not see these parameters: documented in INTEGRATION.md next to set_direct_grads.
+inline bool plain_accumulating_backward() {
+    const auto *info = torch::autograd::get_current_graph_task_exec_info();
+    return info == nullptr || info->empty();
+}
+
 // what AccumulateGrad does for a fresh, contiguous gradient: bind it, or add to an existing one
 inline void deposit_grad(const at::Tensor &param, const at::Tensor &g) {
     at::Tensor &slot = const_cast<at::Tensor &>(param).mutable_grad();
@@ -676,7 +686,7 @@ struct ConvNode : public torch::autograd::Node {
             }
         }
         if (direct_w) {
-            if (!try_defer_wgrad(features, dy, fwd_tbl, n_out, weight, pl))
+            if (plain_accumulating_backward() && !try_defer_wgrad(features, dy, fwd_tbl, n_out, weight, pl))
                 deposit_grad(weight, wgrad(features, dy, fwd_tbl, n_out, pl).reshape(weight.sizes()).to(weight.scalar_type()));
         } else if (task_should_compute_output(1) && !try_defer_wgrad(features, dy, fwd_tbl, n_out, weight, pl))
             out[1] = wgrad(features, dy, fwd_tbl, n_out, pl).reshape(weight.sizes()).to(weight.scalar_type());
@@ -813,7 +823,7 @@ struct BNNode : public torch::autograd::Node {
         // whose .grad is still undefined; at most once per backward pass): AccumulateGrad then binds the alias as .grad
         auto grad_out = [&](const at::Tensor &param, int64_t c) {
             at::Tensor h;
-            if (param.is_leaf() && param.scalar_type() == at::kFloat && param.numel() == c)
+            if (param.is_leaf() && param.scalar_type() == at::kFloat && param.numel() == c && (!direct_p || plain_accumulating_backward()))
                 h = take_grad_home(param, torch::autograd::get_current_graph_task_id());
             return h.defined() ? h : at::empty({c}, x.options().dtype(at::kFloat));
         };
@@ -883,8 +893,10 @@ struct BNNode : public torch::autograd::Node {
         if (extra.defined()) dx = dx + extra;
         if (task_should_compute_output(0)) out[0] = dx;
         if (direct_p) {
-            deposit_grad(weight, dg);
-            deposit_grad(bias, db);
+            if (plain_accumulating_backward()) {
+                deposit_grad(weight, dg);
+                deposit_grad(bias, db);
+            }
         } else {
             if (task_should_compute_output(1)) out[1] = dg.scalar_type() == weight.scalar_type() ? dg : dg.to(weight.scalar_type());
             if (task_should_compute_output(2)) out[2] = db.scalar_type() == bias.scalar_type() ? db : db.to(bias.scalar_type());
@@ -1261,11 +1273,14 @@ struct CoarseNode : public torch::autograd::Node {
         B.arena.opt = g.options().dtype(at::kByte);
         const int task = torch::autograd::get_current_graph_task_id();
         std::vector<PGrad> pgrads;
+        const bool plain = plain_accumulating_backward();
         auto pgrad = [&](const at::Tensor &param, int64_t c, int &flags) -> float * {
             PGrad pg;
             pg.param = param;
             at::Tensor cur = param.grad();
-            if (cur.defined() && cur.scalar_type() == at::kFloat && cur.is_contiguous() && cur.numel() == c) {
+            if (!plain) {   // a pass restricted to specific inputs: the kernel's gamma / beta sums go to scratch
+                pg.buf = at::empty({c}, param.options().dtype(at::kFloat));
+            } else if (cur.defined() && cur.scalar_type() == at::kFloat && cur.is_contiguous() && cur.numel() == c) {
                 pg.buf = cur; pg.accum = true; flags |= DODA_CX_F_ACCUM;
             } else {
                 at::Tensor h;
@@ -1369,7 +1384,9 @@ struct CoarseNode : public torch::autograd::Node {
             }
         }
         B.run(g);
-        // parameter gradients: the weight gradients join the step's deferred launch; gamma / beta are bound now
+        // parameter gradients: the weight gradients join the step's deferred launch; gamma / beta are bound now (not in a
+        // backward pass restricted to specific inputs: see plain_accumulating_backward)
+        if (!plain) wjobs.clear();
         for (WJob &w : wjobs) {
             if (!try_defer_wgrad(w.a, w.b, w.tbl, w.n_rows, w.weight, PairLists()))
                 deposit_grad(w.weight, wgrad(w.a, w.b, w.tbl, w.n_rows).reshape(w.weight.sizes()).to(w.weight.scalar_type()));

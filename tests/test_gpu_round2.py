@@ -563,10 +563,10 @@ def test_full_size_tail_layer_properties(native_lib, dtype):
     wi = torch.zeros(27, cin, cout, device=d)
     wi[13, :cout, :] = torch.eye(cout, device=d)
     yi = ops.spconv_gather(x1, wi, tbl, m, 0, cout)
-    if dtype == torch.float32:
-        # (round 5: fp32 layers of >= 65536 rows multiply bf16 head + tail splits of both operands — x = hi + lo + e with
-        # |e| <= 2^-17 |x| — so the identity kernel copies to 2^-16 relative, per element, instead of bit for bit;
-        # DODA_F32_SPLIT_ROWS=-1 restores the exact fp32 MFMA chain)
+    import os
+    if dtype == torch.float32 and int(os.environ.get("DODA_F32_SPLIT_ROWS", "-1")) >= 0:
+        # (opt-in bf16 head + tail splits of both fp32 operands — x = hi + lo + e with |e| <= 2^-17 |x| —: the identity
+        # kernel then copies to 2^-16 relative, per element, instead of bit for bit)
         assert float(((yi - x1[:, :cout]).abs() / x1[:, :cout].abs().clamp_min(1e-30)).max()) <= 2.0 ** -16
     else:
         assert torch.equal(yi, x1[:, :cout].contiguous())

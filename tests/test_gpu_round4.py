@@ -478,3 +478,48 @@ def test_dual_pass_tile_kernel_with_four_channel_blocks_vs_oracle(native_lib, or
         assert bool(((y.float().cpu().double() - ref).abs() <= tol).all()), on
         yf = y.double().cpu()
         assert rel_err(got[on][1][0], yf.sum(0)) < 1e-5 and rel_err(got[on][1][1], (yf * yf).sum(0)) < 1e-5, on
+
+
+def test_restricted_backward_leaves_parameter_gradients_alone(native_lib):
+    """with direct parameter gradients on (set_deferred_wgrad(True)) the extension's nodes keep no autograd edge to
+    conv weights / BatchNorm vectors and deposit .grad themselves — but only in a plain accumulating backward pass.
+    torch.autograd.grad(loss, x) and loss.backward(inputs=[x]) must neither touch .grad nor queue weight-gradient jobs; a
+    plain loss.backward() afterwards still produces every gradient (incl. on the coarse-level executor)."""
+    ext = _ext_or_skip()
+    from doda_amd import model as M
+    from doda_amd import spconv
+    from doda_amd.model import SparseConvNet, default_cfg
+    from doda_amd.spconv import functional as Fsp
+    from tests.util import deterministic_init, surface_voxels
+    d = dev()
+    net = deterministic_init(SparseConvNet(default_cfg()), seed=2).to(d).train()
+    ub = net.unet.u.u.u.u                                   # level 5 subtree (ResidualBlocks, strided / inverse convs)
+    idx = torch.from_numpy(np.ascontiguousarray(surface_voxels(3, 1500, 2, [32, 32, 32]))).to(d)
+    old = (M.COARSE_EXEC, M.COARSE_EXEC_LEVEL)
+    try:
+        assert Fsp.set_deferred_wgrad(True)
+        for exec_on in (False, True):
+            M.set_coarse_exec(exec_on, 5)
+            for p in ub.parameters():
+                p.grad = None
+
+            def forward():
+                x = torch.randn(idx.shape[0], 80, device=d).to(torch.bfloat16).requires_grad_(True)
+                t = spconv.SparseConvTensor(x, idx, [32, 32, 32], 2)
+                spconv.ops.build_pyramid(t, 3, first_level=5)
+                return x, ub(t).features.float().sum()
+
+            x, loss = forward()
+            gx, = torch.autograd.grad(loss, x)
+            assert gx.shape == x.shape and float(gx.float().abs().sum()) > 0
+            assert all(p.grad is None for p in ub.parameters()) and ext.pending_wgrads() == 0
+            x, loss = forward()
+            loss.backward(inputs=[x])
+            assert x.grad is not None and all(p.grad is None for p in ub.parameters()) and ext.pending_wgrads() == 0
+            x, loss = forward()
+            loss.backward()
+            torch.cuda.synchronize()
+            assert all(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in ub.parameters())
+    finally:
+        Fsp.set_deferred_wgrad(False)
+        M.set_coarse_exec(*old)
