@@ -591,6 +591,8 @@ def main():
             if prefetch.gated:   # (A/B aid: steps whose build started without the coarse-phase event)
                 gate_info[dtype_name] = {"gate_timeouts": prefetch.gate_timeouts, "builds": steps + warmup}
                 sys.stderr.write("[bench] gated prefetch: %d of %d builds ungated (timeouts)\n" % (prefetch.gate_timeouts, steps + warmup))
+        if reducer is not None:
+            reducer.close()      # (gradient homes are process-wide: the fp32 leg builds its own reducer)
         return dt, float(loss.detach()), net
 
     elapsed, final_loss, net = run_training(args.dtype, args.steps, args.warmup)

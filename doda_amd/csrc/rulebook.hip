@@ -25,17 +25,24 @@ __device__ __forceinline__ cellkey_t cell_id(int b, int x, int y, int z, const G
     return (cellkey_t)((((long long)b * g.X + x) * g.Y + y) * g.Z + z);
 }
 
+// A row whose batch index or coordinates lie outside the declared grid is never entered into the cell map and sees no
+// neighbours: its table row is the centre only (SubM) or parent -1 (Down2).  The hash and the direct-address builders
+// apply the same test, so which one the workspace size selects does not change the table.
+__device__ __forceinline__ bool in_grid(const int4 c, int batch, const GridDesc g) {
+    return (unsigned)c.x < (unsigned)batch && (unsigned)c.y < (unsigned)g.X && (unsigned)c.z < (unsigned)g.Y && (unsigned)c.w < (unsigned)g.Z;
+}
+
 // ---- SubM ---------------------------------------------------------------------------------
 // Also pre-fills column t of the table's mirrored half (offsets first_fill .. K3-1) with -1: the
 // probe kernel only writes hits there (saves a memset launch per rulebook).
-__global__ __launch_bounds__(256) void subm_insert(const int4 *__restrict__ indices, int m,
+__global__ __launch_bounds__(256) void subm_insert(const int4 *__restrict__ indices, int m, int batch,
                                                    GridDesc g, unsigned long long *tab,
                                                    uint32_t mask, HashFmt hf, int32_t *__restrict__ nbr, int ld,
                                                    int first_fill, int k3) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const int4 c = indices[t];
-    hash_insert_min(tab, mask, hf, cell_id(c.x, c.y, c.z, c.w, g), (uint32_t)t);
+    if (in_grid(c, batch, g)) hash_insert_min(tab, mask, hf, cell_id(c.x, c.y, c.z, c.w, g), (uint32_t)t);
     for (int o = first_fill; o < k3; ++o) nbr[(long long)o * ld + t] = -1;
 }
 
@@ -47,7 +54,7 @@ __global__ __launch_bounds__(256) void subm_insert(const int4 *__restrict__ indi
 // halving the reads is what pays.  The first-slot reads are still issued together; only a
 // neighbour whose first slot holds a different key walks the probe chain.
 template <int KS>
-__global__ __launch_bounds__(256) void subm_probe(const int4 *__restrict__ indices, int m,
+__global__ __launch_bounds__(256) void subm_probe(const int4 *__restrict__ indices, int m, int batch,
                                                   GridDesc g,
                                                   const unsigned long long *__restrict__ tab,
                                                   uint32_t mask, HashFmt hf, int32_t *__restrict__ nbr,
@@ -56,7 +63,8 @@ __global__ __launch_bounds__(256) void subm_probe(const int4 *__restrict__ indic
     if (t >= m) return;
     const int4 c = indices[t];  // (b, x, y, z)
     constexpr int R = KS / 2, K3 = KS * KS * KS, NP = K3 / 2;   // offsets 0..NP-1 are probed
-    const cellkey_t own = cell_id(c.x, c.y, c.z, c.w, g);
+    const bool own_ok = in_grid(c, batch, g);
+    const cellkey_t own = own_ok ? cell_id(c.x, c.y, c.z, c.w, g) : (cellkey_t)0;
     nbr[(long long)NP * ld + t] = t;   // centre
     if (NP == 0) return;
     cellkey_t key[NP > 0 ? NP : 1];
@@ -65,7 +73,7 @@ __global__ __launch_bounds__(256) void subm_probe(const int4 *__restrict__ indic
     for (int o = 0; o < NP; ++o) {
         const int k0 = o / (KS * KS), k1 = (o / KS) % KS, k2 = o % KS;
         const int x = c.y + k0 - R, y = c.z + k1 - R, z = c.w + k2 - R;
-        const bool inb = x >= 0 && x < g.X && y >= 0 && y < g.Y && z >= 0 && z < g.Z;
+        const bool inb = own_ok && x >= 0 && x < g.X && y >= 0 && y < g.Y && z >= 0 && z < g.Z;
         // out-of-grid neighbours read the voxel's own slot chain head (a valid address) and are
         // discarded below through key == own
         key[o] = inb ? cell_id(c.x, x, y, z, g) : own;
@@ -100,10 +108,6 @@ __global__ __launch_bounds__(256) void subm_probe(const int4 *__restrict__ indic
 // opts in by handing over a workspace with room for the grid behind the hash workspace (doda_hip.h); larger grids
 // (1 cm scenes: 2^34 cells) keep the hash.  Same results: first-touch (lowest row) wins a cell, as hash_insert_min.
 constexpr long long GRID_MAX_CELLS = 1ll << 26;
-
-__device__ __forceinline__ bool in_grid(const int4 c, int batch, const GridDesc g) {
-    return (unsigned)c.x < (unsigned)batch && (unsigned)c.y < (unsigned)g.X && (unsigned)c.z < (unsigned)g.Y && (unsigned)c.w < (unsigned)g.Z;
-}
 
 __global__ __launch_bounds__(256) void subm_grid_insert(const int4 *__restrict__ indices, int m, int batch, GridDesc g,
                                                         int32_t *__restrict__ grid, int32_t *__restrict__ nbr, int ld,
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256) void down2_grid_first(const int4 *__restrict__
 }
 
 // ---- Down2 (kernel 2, stride 2, pad 0) ------------------------------------------------------
-__global__ __launch_bounds__(256) void down2_insert(const int4 *__restrict__ indices, int m,
+__global__ __launch_bounds__(256) void down2_insert(const int4 *__restrict__ indices, int m, int batch,
                                                     GridDesc go, unsigned long long *tab,
                                                     uint32_t mask, HashFmt hf, int32_t *__restrict__ off) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -172,11 +176,11 @@ __global__ __launch_bounds__(256) void down2_insert(const int4 *__restrict__ ind
     const int4 c = indices[j];
     off[j] = ((c.y & 1) * 2 + (c.z & 1)) * 2 + (c.w & 1);
     const int qx = c.y >> 1, qy = c.z >> 1, qz = c.w >> 1;
-    if (c.y < 0 || c.z < 0 || c.w < 0 || qx >= go.X || qy >= go.Y || qz >= go.Z) return;
+    if ((unsigned)c.x >= (unsigned)batch || c.y < 0 || c.z < 0 || c.w < 0 || qx >= go.X || qy >= go.Y || qz >= go.Z) return;
     hash_insert_min(tab, mask, hf, cell_id(c.x, qx, qy, qz, go), (uint32_t)j);
 }
 
-__global__ __launch_bounds__(256) void down2_first(const int4 *__restrict__ indices, int m,
+__global__ __launch_bounds__(256) void down2_first(const int4 *__restrict__ indices, int m, int batch,
                                                    GridDesc go,
                                                    const unsigned long long *__restrict__ tab,
                                                    uint32_t mask, HashFmt hf, int32_t *__restrict__ firstj,
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void down2_first(const int4 *__restrict__ indi
     const int4 c = indices[j];
     const int qx = c.y >> 1, qy = c.z >> 1, qz = c.w >> 1;
     int f = -1;
-    if (!(c.y < 0 || c.z < 0 || c.w < 0 || qx >= go.X || qy >= go.Y || qz >= go.Z))
+    if (!((unsigned)c.x >= (unsigned)batch || c.y < 0 || c.z < 0 || c.w < 0 || qx >= go.X || qy >= go.Y || qz >= go.Z))
         f = hash_find(tab, mask, hf, cell_id(c.x, qx, qy, qz, go));
     firstj[j] = f;
     flag[j] = (f == j) ? 1 : 0;
@@ -398,21 +402,23 @@ __global__ __launch_bounds__(256) void conv_tables(const int4 *__restrict__ indi
 }
 
 // SubM with a non-cubic odd kernel: plain per-offset lookups (offset = row-major kernel index)
-__global__ __launch_bounds__(256) void subm_probe_generic(const int4 *__restrict__ indices, int m,
+__global__ __launch_bounds__(256) void subm_probe_generic(const int4 *__restrict__ indices, int m, int batch,
                                                           GridDesc g, int k0, int k1, int k2,
                                                           const unsigned long long *__restrict__ tab,
                                                           uint32_t mask, HashFmt hf, int32_t *__restrict__ nbr, int ld) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const int4 c = indices[t];
+    const bool own_ok = in_grid(c, batch, g);
     int o = 0;
     for (int a = 0; a < k0; ++a)
         for (int b = 0; b < k1; ++b)
             for (int d = 0; d < k2; ++d, ++o) {
                 const int x = c.y + a - k0 / 2, y = c.z + b - k1 / 2, z = c.w + d - k2 / 2;
                 int v = -1;
-                if (x >= 0 && x < g.X && y >= 0 && y < g.Y && z >= 0 && z < g.Z)
+                if (own_ok && x >= 0 && x < g.X && y >= 0 && y < g.Y && z >= 0 && z < g.Z)
                     v = hash_find(tab, mask, hf, cell_id(c.x, x, y, z, g));
+                if (!own_ok && a == k0 / 2 && b == k1 / 2 && d == k2 / 2) v = t;   // centre only
                 nbr[(long long)o * ld + t] = v;
             }
 }
@@ -481,7 +487,7 @@ extern "C" int doda_rulebook_subm(const int32_t *indices, int32_t m, const int32
     const int grid = div_up(m, 256);
     if (ksize == 1) {
         // identity table
-        hipLaunchKernelGGL((subm_probe<1>), dim3(grid), dim3(256), 0, s, (const int4 *)indices, m,
+        hipLaunchKernelGGL((subm_probe<1>), dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, (int)batch,
                            g, w.tab, w.cap - 1, hf, nbr, ld);
         return doda_check_launch();
     }
@@ -495,9 +501,9 @@ extern "C" int doda_rulebook_subm(const int32_t *indices, int32_t m, const int32
         return doda_check_launch();
     }
     hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
-    hipLaunchKernelGGL(subm_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g,
+    hipLaunchKernelGGL(subm_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, (int)batch, g,
                        w.tab, w.cap - 1, hf, nbr, ld, 14, 27);   // + mirrored half := -1
-    hipLaunchKernelGGL((subm_probe<3>), dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g,
+    hipLaunchKernelGGL((subm_probe<3>), dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, (int)batch, g,
                        w.tab, w.cap - 1, hf, nbr, ld);
     return doda_check_launch();
 }
@@ -532,9 +538,9 @@ extern "C" int doda_rulebook_down2_assign(const int32_t *indices, int32_t m,
                            w.a /*firstj*/, w.b /*flag*/);
     } else {
         hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
-        hipLaunchKernelGGL(down2_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, go,
+        hipLaunchKernelGGL(down2_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, (int)batch, go,
                            w.tab, w.cap - 1, hf, off);
-        hipLaunchKernelGGL(down2_first, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, go,
+        hipLaunchKernelGGL(down2_first, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, (int)batch, go,
                            w.tab, w.cap - 1, hf, w.a /*firstj*/, w.b /*flag*/);
     }
     int st = exclusive_scan_i32(w.b, w.c /*rank*/, m, counts_out, w.scan, s);
@@ -706,9 +712,9 @@ extern "C" int doda_rulebook_subm_generic(const int32_t *indices, int32_t m, con
     const GridDesc g{shape_h[0], shape_h[1], shape_h[2]};
     const int grid = div_up(m, 256);
     hipMemsetAsync(w.tab, 0xFF, (size_t)w.cap * 8, s);
-    hipLaunchKernelGGL(subm_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g, w.tab, w.cap - 1, hf,
-                       nbr, ld, K, K);   // no prefill
-    hipLaunchKernelGGL(subm_probe_generic, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, g,
+    hipLaunchKernelGGL(subm_insert, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, (int)batch, g, w.tab,
+                       w.cap - 1, hf, nbr, ld, K, K);   // no prefill
+    hipLaunchKernelGGL(subm_probe_generic, dim3(grid), dim3(256), 0, s, (const int4 *)indices, m, (int)batch, g,
                        ksize_h[0], ksize_h[1], ksize_h[2], w.tab, w.cap - 1, hf, nbr, ld);
     return doda_check_launch();
 }

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
     constexpr int CAP = WIDE ? TB_CAP64 : TB_LMAX;             // distinct rows this kernel stages (LDS budget; 10-bit local indices)
     constexpr int NLJ = PPR;                                   // 16-byte list loads per thread (one per pass of 256 / PPR entries)
     constexpr int NRL = 4 * NLJ;                               // row loads per thread
-    constexpr int NLP = TB_LIDX_BYTES / 16;                    // 16-byte pieces of the index strip (576)
+    constexpr int NLP = TB_LIDX_BYTES / 16;                    // 16-byte pieces of the index strip (640)
     constexpr int NLI = (NLP + 255) / 256;                     // ... per thread
     __shared__ __attribute__((aligned(16))) unsigned char rows_s[(CAP + 1) * RB];   // slot 0: the zero row
     __shared__ __attribute__((aligned(16))) unsigned lidx_s[TB_T * TB_LW];   // ten planes of 256 words (tilebook.hpp)

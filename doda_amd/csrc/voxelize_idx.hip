@@ -230,18 +230,23 @@ __global__ __launch_bounds__(256) void vox_max(const int32_t *__restrict__ count
     if (lane_id() == 0) atomicMax(&counts_out[1], mx);
 }
 
-__global__ __launch_bounds__(256) void vox_rows_init(int m, int W, int mode,
+// n_active / max_active are the caller's (doda_voxelize_idx_fill): every kernel below bounds its reads of the workspace
+// arrays (n entries) and its writes of the outputs (n_active rows of W) by them, so a size that disagrees with what
+// doda_voxelize_idx_assign counted cannot touch memory outside the two outputs — an underestimate loses the voxels and
+// points that do not fit, an overestimate leaves trailing rows empty (count 0 / index -1, coordinates 0).
+__global__ __launch_bounds__(256) void vox_rows_init(int n, int m, int W, int mode,
                                                      const int32_t *__restrict__ count,
                                                      int32_t *__restrict__ output_map) {
     const long long total = (long long)m * W;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (long long)gridDim.x * blockDim.x) {
         const int v = (int)(e / W), c = (int)(e - (long long)v * W);
-        output_map[e] = c == 0 ? ((mode == 3 || mode == 4) ? count[v] : 1) : -1;
+        const int cnt = v < n ? count[v] : 0;   // 0 for rows past the voxels stage 1 found
+        output_map[e] = c == 0 ? ((mode == 3 || mode == 4) ? (cnt < W ? cnt : W - 1) : (cnt > 0 ? 1 : 0)) : -1;
     }
 }
 
-__global__ __launch_bounds__(256) void vox_scatter(int n, int W, int mode,
+__global__ __launch_bounds__(256) void vox_scatter(int n, int m, int W, int mode,
                                                    const int32_t *__restrict__ first,
                                                    const int32_t *__restrict__ rank,
                                                    const int32_t *__restrict__ last,
@@ -250,9 +255,11 @@ __global__ __launch_bounds__(256) void vox_scatter(int n, int W, int mode,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int v = rank[first[i]];  // voxel of point i (kept in the workspace by stage 1)
+    if (v >= m) return;
     int32_t *row = output_map + (long long)v * W;
     if (mode == 3 || mode == 4) {
-        row[1 + atomicAdd(&cursor[v], 1)] = i;  // any order; vox_finish sorts the row
+        const int slot = atomicAdd(&cursor[v], 1);
+        if (slot < W - 1) row[1 + slot] = i;  // any order; vox_finish sorts the row
     } else if (first[i] == i) {
         row[1] = (mode == 2) ? last[v] : i;
     }
@@ -275,8 +282,8 @@ __global__ __launch_bounds__(256) void vox_finish(int m, int W, int ncol, int mo
             row[b + 1] = key;
         }
     }
-    const int64_t *src = coords + (long long)row[1] * ncol;
-    for (int j = 0; j < ncol; ++j) output_coords[(long long)v * ncol + j] = src[j];
+    const int p = row[1];
+    for (int j = 0; j < ncol; ++j) output_coords[(long long)v * ncol + j] = p >= 0 ? coords[(long long)p * ncol + j] : 0;
 }
 }  // namespace
 
@@ -322,9 +329,9 @@ extern "C" int doda_voxelize_idx_fill(const int64_t *coords, int32_t n, int32_t 
     const int W = max_active + 1;
     const long long total = (long long)n_active * W;
     const int g0 = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(vox_rows_init, dim3(g0), dim3(256), 0, s, n_active, W, mode, w.count,
+    hipLaunchKernelGGL(vox_rows_init, dim3(g0), dim3(256), 0, s, n, n_active, W, mode, w.count,
                        output_map);
-    hipLaunchKernelGGL(vox_scatter, dim3(div_up(n, 256)), dim3(256), 0, s, n, W, mode, w.first,
+    hipLaunchKernelGGL(vox_scatter, dim3(div_up(n, 256)), dim3(256), 0, s, n, n_active, W, mode, w.first,
                        w.rank, w.last, w.cursor, output_map);
     hipLaunchKernelGGL(vox_finish, dim3(div_up(n_active, 256)), dim3(256), 0, s, n_active, W, ncol,
                        mode, coords, output_map, output_coords);

@@ -386,6 +386,15 @@ void set_grad_home(const at::Tensor &param, const c10::optional<at::Tensor> &vie
     g_homes.erase(key);
     g_homes.emplace(key, GradHome(param, *view));
 }
+// forget the parameter's home only if it still is `view` (a reducer built later over the same module has replaced it
+// otherwise, and the older reducer's close() / __del__ must leave that one alone).  True when a home was dropped.
+bool drop_grad_home(const at::Tensor &param, const at::Tensor &view) {
+    std::lock_guard<std::mutex> lock(g_home_mu);
+    auto it = g_homes.find(param.unsafeGetTensorImpl());
+    if (it == g_homes.end() || !view.defined() || it->second.view.data_ptr() != view.data_ptr()) return false;
+    g_homes.erase(it);
+    return true;
+}
 void clear_grad_homes() {
     std::lock_guard<std::mutex> lock(g_home_mu);
     g_homes.clear();
@@ -1741,6 +1750,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("flush_wgrads_early", &flush_wgrads_early,
           "issue the weight-gradient jobs queued so far (mid-backward) and record the event wait_wide_wgrads() waits for");
     m.def("set_grad_home", &set_grad_home, "view of a flat gradient bucket that receives the parameter's gradient in place (None: forget)");
+    m.def("drop_grad_home", &drop_grad_home, "forget the parameter's home if it is this view; returns whether it was");
     m.def("clear_grad_homes", &clear_grad_homes);
     m.def("set_wgrad_split", [](bool on) { g_wq_split = on; if (!on) g_ev_early_valid = false; },
           "issue the wide layers' weight gradients first and record an event behind them (GradAllReduce)");

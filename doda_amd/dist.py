@@ -195,11 +195,12 @@ class GradAllReduce:
         self._avg = self.active and dist.get_backend() == "nccl" and hasattr(dist.ReduceOp, "AVG")
 
     def close(self):
-        """Forget the gradient homes (the parameters' next gradients are ordinary tensors again)."""
+        """Forget the gradient homes THIS reducer registered (the parameters' next gradients are ordinary tensors again).
+        A home that a later reducer over the same parameters has replaced is left alone."""
         if self._ext is not None:
             for b in self.buckets + self.late_buckets:
-                for p in b.params:
-                    self._ext.set_grad_home(p, None)
+                for p, v in zip(b.params, b.views):
+                    self._ext.drop_grad_home(p, v)
             self._ext = None
 
     def __del__(self):

@@ -76,8 +76,11 @@ def voxelize_idx_host(coords, batch_size, mode=4):
 
 def voxelize_idx_device(coords, batch_size, mode=4, sizes=None):
     """Device version of voxelize_idx (same results); coords int64 device [N,3|4].
-    sizes = (n_voxels, max_active) known to the caller (a previous call on the same points): the D2H read-back of the
-    two output sizes between the assign and the fill kernel is skipped."""
+    sizes = (n_voxels, max_active) known to the caller — the EXACT values a previous call on the same points returned
+    (out_map.shape[0], out_map.shape[1] - 1): the D2H read-back of the two output sizes between the assign and the fill
+    kernel is skipped.  The outputs are allocated from them; the fill kernels bound every write by them, so a wrong
+    size cannot write outside the outputs, but it does not give the reference's result: too small drops the voxels /
+    points that do not fit, too large leaves trailing rows empty (count 0, index -1, coordinates 0)."""
     _need_cuda(coords)
     if coords.dtype != torch.int64 or coords.dim() != 2:
         raise RuntimeError("voxelize_idx_device: coords must be int64 [N,3|4]")

@@ -511,6 +511,8 @@ def main(argv=None):
             break
     if trainer.prefetch is not None:
         trainer.prefetch.shutdown()
+    if trainer.reducer is not None:
+        trainer.reducer.close()      # the gradient homes live in a process-wide map: drop this reducer's
     if args.timing_json and rank == 0 and trainer.step_times:
         import json
         its = sum(t[0] for t in trainer.step_times)

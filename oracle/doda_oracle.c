@@ -108,7 +108,13 @@ int orc_voxelize_idx_finish(void *handle, const int64_t *coords, int64_t *output
         else if (h->mode == 2) row[1] = i;                  /* :136-141 outputRows[i].back()     */
         else if (row[1] < 0) row[1] = i;                    /* :122-135 only point / front()     */
     }
-    for (int32_t v = 0; v < M; ++v) {                       /* :42-50 coords of rule[1]          */
+    /* :42-50 coords of rule[1].  The reference copies dimension + 1 = 4 longs per voxel with a row stride of 4 whatever the
+     * width of the tensor it was handed (voxelize.cpp:46-50): with a 3-column coords tensor it would read across rows and
+     * past the end.  DODA only calls it with (b, x, y, z) rows (lib/pointgroup_ops/functions/pointgroup_ops.py:18-44), the
+     * 4-column case below is that copy exactly; for ncol = 3 this restatement strides by 3 — the defined behaviour the
+     * reference's signature implies, NOT what its code does — and the 3-column tests pin this library to the restatement,
+     * not to the reference. */
+    for (int32_t v = 0; v < M; ++v) {
         const int64_t *src = coords + (int64_t)output_map[(int64_t)v * W + 1] * h->ncol;
         memcpy(output_coords + (int64_t)v * h->ncol, src, (size_t)h->ncol * sizeof(int64_t));
     }

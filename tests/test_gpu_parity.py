@@ -60,6 +60,35 @@ def test_voxelize_idx_mode0_and_empty(native_lib, oracle):
     assert oc.shape[0] == 0 and im.shape[0] == 0 and om.shape[0] == 0
 
 
+def test_voxelize_idx_device_caller_sizes(native_lib, oracle):
+    """sizes=(n_voxels, max_active): exact sizes give the reference result without the read-back; sizes that disagree with
+    what stage 1 counted stay inside the outputs:
+    too large leaves trailing rows empty, too small keeps a prefix of the voxels and at most max_active points of each."""
+    from doda_amd import ops
+    coords = _points(5, 6000, 3, 12)
+    ref_c, ref_im, ref_om = oracle.voxelize_idx(coords, 4)
+    m, width = ref_om.shape
+    cd = torch.from_numpy(coords).to(dev())
+    oc, im, om = ops.voxelize_idx_device(cd, 3, 4, sizes=(m, width - 1))
+    assert np.array_equal(oc.cpu().numpy(), ref_c) and np.array_equal(om.cpu().numpy(), ref_om)
+    oc, im, om = ops.voxelize_idx_device(cd, 3, 4, sizes=(m + 37, width + 2))
+    om, oc = om.cpu().numpy(), oc.cpu().numpy()
+    assert np.array_equal(om[:m, :width], ref_om) and (om[:m, width:] == -1).all()
+    assert (om[m:, 0] == 0).all() and (om[m:, 1:] == -1).all() and (oc[m:] == 0).all() and np.array_equal(oc[:m], ref_c)
+    assert np.array_equal(im.cpu().numpy(), ref_im)
+    small_m, small_a = m - 100, max(width - 3, 1)
+    torch.cuda.synchronize()
+    oc, im, om = ops.voxelize_idx_device(cd, 3, 4, sizes=(small_m, small_a))
+    torch.cuda.synchronize()
+    om, oc = om.cpu().numpy(), oc.cpu().numpy()
+    assert om.shape == (small_m, small_a + 1) and np.array_equal(om[:, 0], np.minimum(ref_om[:small_m, 0], small_a))
+    full = ref_om[:small_m, 0] <= small_a                              # rows that fit are the reference's
+    assert np.array_equal(om[full], ref_om[:small_m][full][:, :small_a + 1]) and np.array_equal(oc[full], ref_c[:small_m][full])
+    for v in np.nonzero(~full)[0][:50]:                                # the others hold small_a distinct points of the voxel
+        got = om[v, 1:]
+        assert len(set(got.tolist())) == small_a and set(got.tolist()) <= set(ref_om[v, 1:1 + ref_om[v, 0]].tolist())
+
+
 @pytest.mark.parametrize("c", [1, 3, 6, 32])
 @pytest.mark.parametrize("mode", [3, 4])
 def test_voxelize_fp_bp_bit_exact(native_lib, oracle, c, mode):

@@ -291,8 +291,27 @@ for dtype in (torch.bfloat16, torch.float32):
     for b in red.buckets + red.late_buckets:
         lo = b.flat.data_ptr(); flat[lo] = lo + b.flat.numel() * 4
     out["views_" + str(dtype)] = all(any(lo <= p.grad.data_ptr() < hi for lo, hi in flat.items()) for p in net.parameters())
+# round 5: a second reducer over the same module replaces the homes; the first one's close() / late __del__ must leave
+# them alone (it used to erase by parameter), and a step of two backward passes (gradient accumulation: the second pass
+# adds into the home through .grad) still needs no copy into the buckets
+red2 = ddist.GradAllReduce(net, bucket_mb=2.0)
+red.close(); del red
+import gc; gc.collect()
+net.zero_grad(set_to_none=True)
+for _ in range(2):
+    cross_entropy(voxelize_and_run(cfg, net, batch, dev, feature_dtype=torch.float32), batch["labels"]).backward()
+red2.reduce()
+torch.cuda.synchronize()
+out["second_moved"] = red2.last_moved
+flat = {}
+for b in red2.buckets + red2.late_buckets:
+    lo = b.flat.data_ptr(); flat[lo] = lo + b.flat.numel() * 4
+out["second_views"] = all(any(lo <= p.grad.data_ptr() < hi for lo, hi in flat.items()) for p in net.parameters())
+out["second_worst"] = max(float((p.grad - 2 * g).abs().max()) / (float(g.abs().max()) + 1e-30) for p, g in zip(net.parameters(), mine))
+red = red2
 red.sync_buffers()
 dist.barrier()
+red.close()
 dist.destroy_process_group()
 print("RESULT " + json.dumps(out))
 '''
@@ -315,6 +334,8 @@ def test_grad_allreduce_over_rccl_group_of_one(native_lib):
     for dt in ("torch.bfloat16", "torch.float32"):
         assert got_r4["views_" + dt] is True and got_r4["moved_" + dt] <= 3, got_r4
     assert all(v == 0.0 for k, v in got_r4.items() if k.startswith("torch.")), got_r4
+    # second reducer + two backward passes per step: homes intact, accumulated gradient = 2 x one pass
+    assert got_r4["second_views"] is True and got_r4["second_moved"] <= 3 and got_r4["second_worst"] < 1e-5, got_r4
 
 
 def test_bench_under_the_launcher_over_rccl(native_lib):

@@ -318,6 +318,82 @@ def test_rulebook_direct_address_grid_equals_the_hash_build(native_lib, oracle, 
     assert np.array_equal(hn.cpu().numpy(), pn) and np.array_equal(hp.cpu().numpy(), pairs)
 
 
+def test_rulebook_rows_outside_the_declared_grid_get_the_same_table_from_both_builders(native_lib, oracle):
+    """Rows whose batch index or coordinates lie outside (batch, spatial_shape) are invalid input for the reference's
+    hash too; what this library promises is that the table does not depend on which builder the workspace size selected:
+    such a row is never entered into the cell map, its SubM row holds the centre only, its k2 s2 parent is -1, and the
+    rows that ARE inside the grid get exactly the table of the input with the outside rows removed."""
+    import ctypes as C
+    from doda_amd._lib import lib, check
+    from tests.util import random_voxels
+    d = dev()
+    shape, batch = [33, 21, 47], 3
+    good = random_voxels(9, 4000, batch, shape)
+    bad = np.array([[batch, 1, 1, 1], [-1, 2, 3, 4], [0, -1, 5, 5], [1, 33, 0, 0], [2, 5, 21, 7], [0, 4, 4, 47],
+                    [1, 2, -3, 9], [2, 8, 8, -1], [7, 40, 40, 90]], dtype=np.int32)
+    rng = np.random.default_rng(4)
+    where = np.sort(rng.choice(good.shape[0] + bad.shape[0], bad.shape[0], replace=False))
+    idx = np.empty((good.shape[0] + bad.shape[0], 4), dtype=np.int32)
+    is_bad = np.zeros(idx.shape[0], dtype=bool)
+    is_bad[where] = True
+    idx[is_bad], idx[~is_bad] = bad, good
+    old_of_new = np.nonzero(~is_bad)[0]
+    new_of_old = np.full(idx.shape[0], -1, dtype=np.int64)
+    new_of_old[old_of_new] = np.arange(old_of_new.size)
+    shape_c = (C.c_int32 * 3)(*shape)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def build(rows, with_grid):
+        n = rows.shape[0]
+        ind = torch.from_numpy(np.ascontiguousarray(rows)).to(d)
+        base = lib().doda_rulebook_workspace_bytes(n)
+        out = []
+        for coarse in (False, True):
+            shp = [(v - 2) // 2 + 1 for v in shape] if coarse else shape
+            nbytes = (base + 255) // 256 * 256 + 4 * batch * shp[0] * shp[1] * shp[2] if with_grid else base
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=d)
+            if not coarse:
+                nbr = torch.empty((27, n), dtype=torch.int32, device=d)
+                check(lib().doda_rulebook_subm(ind.data_ptr(), n, shape_c, batch, 3, nbr.data_ptr(), n, ws.data_ptr(),
+                                               ws.numel(), stream), "doda_rulebook_subm")
+                out.append(nbr.cpu().numpy())
+            else:
+                parent = torch.empty(n, dtype=torch.int32, device=d)
+                off = torch.empty(n, dtype=torch.int32, device=d)
+                out_idx = torch.zeros((n, 4), dtype=torch.int32, device=d)
+                count = torch.zeros(1, dtype=torch.int32, device=d)
+                check(lib().doda_rulebook_down2_assign(ind.data_ptr(), n, shape_c, batch, parent.data_ptr(), off.data_ptr(),
+                                                       out_idx.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                      "doda_rulebook_down2_assign")
+                mo = int(count.item())
+                out += [parent.cpu().numpy(), out_idx[:mo].cpu().numpy(), mo]
+        # non-cubic SubM: hash builder only
+        k = (C.c_int32 * 3)(3, 1, 3)
+        ws = torch.empty(base, dtype=torch.uint8, device=d)
+        nbg = torch.empty((9, n), dtype=torch.int32, device=d)
+        check(lib().doda_rulebook_subm_generic(ind.data_ptr(), n, shape_c, batch, k, nbg.data_ptr(), n, ws.data_ptr(), ws.numel(),
+                                               stream), "doda_rulebook_subm_generic")
+        out.append(nbg.cpu().numpy())
+        return out
+
+    h, g = build(idx, False), build(idx, True)
+    for a, b_ in zip(h, g):
+        assert np.array_equal(a, b_)
+    nbr, parent, out_idx, mo, nbg = h
+    centre = np.full(27, -1)
+    for t in where:
+        centre[13] = t
+        assert np.array_equal(nbr[:, t], centre) and parent[t] == -1
+        assert np.array_equal(nbg[:, t], np.where(np.arange(9) == 4, t, -1))
+    assert not np.isin(nbr[:, ~is_bad], where).any() and not np.isin(nbg[:, ~is_bad], where).any()
+    ref_nbr, ref_parent, ref_out_idx, ref_mo, ref_nbg = build(good, True)
+
+    def renumber(tbl):
+        return np.where(tbl >= 0, new_of_old[np.maximum(tbl, 0)], -1)
+    assert np.array_equal(renumber(nbr[:, ~is_bad]), ref_nbr) and np.array_equal(renumber(nbg[:, ~is_bad]), ref_nbg)
+    assert mo == ref_mo and np.array_equal(out_idx, ref_out_idx) and np.array_equal(parent[~is_bad], ref_parent)
+
+
 @pytest.mark.parametrize("cin,cout,option", [(16, 16, 4), (32, 32, 5)])
 def test_pipelined_and_dual_block_tile_kernels_equal_the_plain_tile_kernel_bit_for_bit(native_lib, oracle, cin, cout, option):
     """conv_tile16 (16 -> 16, the next tile prefetched into registers: DODA_OPT_TILE_PIPELINE) and the dual-block pass of the
