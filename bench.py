@@ -45,6 +45,13 @@ def parse():
     p.add_argument("--scenes", type=int, default=4, help="scenes per GPU (BATCH_SIZE_PER_GPU)")
     p.add_argument("--voxels", type=int, default=150000, help="target active voxels per scene")
     p.add_argument("--voxel-scale", type=int, default=50)
+    p.add_argument("--voxel-order", choices=["auto", "morton", "first"], default="auto",
+                   help="numbering of a batch's voxels: the reference's first-appearance order, the loader's Z-order renumbering "
+                        "(doda_amd.collate.reorder_voxels), or what the loader decides from the batch's tile overflow "
+                        "(doda_amd.collate.choose_voxel_order: 'first' at 2 cm, 'morton' at 1 cm)")
+    p.add_argument("--config5-steps", type=int, default=12,
+                   help="timed steps of the config5 sub-record (BASELINE config 5: 1 cm voxels, ~500 k active voxels per scene, "
+                        "1 and 4 scenes; N = 1 only; 0 = skip)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-voxels", type=int, default=0, help="CPU-baseline sample: 0 = the bench batch itself (~10 s of host work at 16 threads), else one scene of this many voxels")
     p.add_argument("--kernel-reps", type=int, default=50)
@@ -369,6 +376,42 @@ def pmc_traffic(dtype):
         return None, None
 
 
+def config5_record(args, dev, run_training, ordered, make_batch):
+    """BASELINE config 5 (1 cm voxels, ~500 k active voxels per scene: the rulebook + LDS stress case) as a sub-record: the same
+    training step, same clock, one scene and four; the roofline of the same kernel on the four-scene batch.  Both arms of the
+    voxel numbering are timed on the four-scene batch: the reference's first-appearance order (74 % of the level-1 tiles above
+    the list capacity: dense-table kernels) and the loader's choice."""
+    import torch
+    from doda_amd import spconv
+    rec = {"workload": "cfgs/scannet step at voxel scale 100 (1 cm), ~500 k active voxels per scene, bf16 features, synthetic scenes",
+           "steps": args.config5_steps}
+    warm = max(4, args.config5_steps // 2)
+    for scenes in (1, 4):
+        raw = make_batch(scenes, 500000, 1000, 100)
+        b, order = ordered(raw)
+        bd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+        spconv.ops._tile_state["skip"] = 0
+        dt, loss, _ = run_training("bf16", args.config5_steps, warm, bd)
+        m = int(b["voxel_locs"].shape[0])
+        r = {"voxels": m, "voxel_order": order, "ms_per_step": dt / args.config5_steps * 1e3, "value": m * args.config5_steps / dt,
+             "unit": "voxels/s", "final_loss": loss, "tiles_state": spconv.ops._tile_state["last"]}
+        if scenes == 4:
+            roof, _ = kernel_roofline(bd, "bf16", max(5, args.kernel_reps // 5), None)
+            r["roofline"] = {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_8d", "avg_launch_us", "M", "P")}
+            if order != "first":      # the other arm: the reference's numbering on the same scenes
+                del bd
+                bd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in raw.items()}
+                spconv.ops._tile_state["skip"] = 0
+                dt1, loss1, _ = run_training("bf16", args.config5_steps, warm, bd)
+                r["first_appearance_order"] = {"ms_per_step": dt1 / args.config5_steps * 1e3, "value": m * args.config5_steps / dt1,
+                                               "final_loss": loss1, "tiles_state": spconv.ops._tile_state["last"]}
+                spconv.ops._tile_state["skip"] = 0
+        rec["B%d" % scenes] = r
+        del bd
+        torch.cuda.empty_cache()
+    return rec
+
+
 def voxelize_legs(batch, batch_dev, reps=20):
     """SURVEY 8d CPU-baseline leg (1): point -> voxel maps (`voxelize_idx`, reference voxelize.cpp:61-155 — the
     collate step the reference runs single-threaded in each DataLoader worker) on the bench batch's points.  Host:
@@ -515,7 +558,14 @@ def main():
     from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
     from doda_amd.scene import make_batch
 
-    batch = make_batch(args.scenes, args.voxels, ddist.seed_for_rank(1000, rank), args.voxel_scale)
+    from doda_amd.collate import choose_voxel_order, reorder_voxels
+
+    def ordered(b):
+        """the batch as the loader would hand it over (doda_amd.loader.DeviceFeeder): (batch, numbering used)"""
+        order = choose_voxel_order(b, dev) if args.voxel_order == "auto" else args.voxel_order
+        return reorder_voxels(b, order), order
+
+    batch, voxel_order = ordered(make_batch(args.scenes, args.voxels, ddist.seed_for_rank(1000, rank), args.voxel_scale))
     batch_dev = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
     m_local = batch["voxel_locs"].shape[0]
     n_local = batch["locs"].shape[0]
@@ -531,9 +581,10 @@ def main():
     gate_info = {}
     sync_info = {}
 
-    def run_training(dtype_name, steps, warmup):
+    def run_training(dtype_name, steps, warmup, batch_dev=batch_dev):
         """`warmup` untimed + `steps` timed training steps with a fresh network; returns
         (max-over-ranks seconds, final loss, network)."""
+        labels = batch_dev["labels"]
         torch.manual_seed(0)
         net = SparseConvNet(cfg).to(dev).train()
         # gradients: weight gradients deferred to one multi-layer launch at the end of backward, then (N > 1)
@@ -608,7 +659,7 @@ def main():
     if rank == 0:
         gate_scene = None
         if world == 1:   # the north-star gate is stated on ONE ~150k-voxel scene
-            one = make_batch(1, 150000, 1000, args.voxel_scale)
+            one = reorder_voxels(make_batch(1, 150000, 1000, args.voxel_scale), voxel_order)
             gate_scene = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in one.items()}
         roof, ppv = kernel_roofline(batch_dev, args.dtype, args.kernel_reps, gate_scene)
         step_bytes, n_layers = step_algorithmic_bytes(net, batch_dev, args.dtype)
@@ -629,6 +680,9 @@ def main():
                        "global_batch": args.scenes * world, "voxels_per_gpu": m_local,
                        "points_per_gpu": n_local, "pairs_per_voxel_subm1": round(ppv, 2),
                        "parallelism": "dp%d" % world, "n_classes": 20, "final_loss": final_loss,
+                       "voxel_order": ("Z-order renumbering by the loader (doda_amd.collate.reorder_voxels; per-point outputs unchanged)"
+                                       if voxel_order == "morton" else "first appearance (the reference's numbering)")
+                                      + (" [chosen from the batch's tile overflow]" if args.voxel_order == "auto" else ""),
                        "host_pinning": ("NUMA node %d (%d CPUs)" % (pinned["node"], pinned["cpus"])) if pinned else "none",
                        "host_priority": prio or "unchanged",
                        "grad_sync": "deferred multi-layer wgrad + bucketed all-reduce" if deferred else "torch DDP",
@@ -659,6 +713,8 @@ def main():
                 "note": "algorithmic = 2 P Cin Cout (present pairs only); dense_tile = every offset of every row, an upper "
                         "bound on what the kernel issues (it skips offsets absent from a whole 32-row wave)"}
             line["fp32"] = fp32
+        if world == 1 and args.config5_steps > 0 and args.voxel_scale != 100:
+            line["config5"] = config5_record(args, dev, run_training, ordered, make_batch)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, batch, batch_dev)
             roof["detail"]["voxelize_idx_device"] = line["cpu_baseline"]["voxelize_idx"]["device"]

@@ -540,6 +540,62 @@ inline bool narrow_weight(const at::Tensor &w) {   // [kD, kH, kW, Cin, Cout]
     return w.dim() == 5 && w.size(3) <= 32 && w.size(4) <= 32;
 }
 
+// Side flush (round 5): the weight gradients queued when the backward pass ENTERS its coarse levels — the whole decoder of
+// levels 1-3, about half of the step's weight-gradient time — are issued on a second stream, behind an event on the backward
+// pass's stream, and run under the coarse levels' chain of launch-floor kernels (few rows: most CUs idle).  The backward
+// pass's stream waits for them in flush_wgrads(), before it issues the rest; the queued tensors are kept until then (the
+// caching allocator would otherwise hand their memory to the main stream while the side stream still reads it).
+std::vector<PendingWgrad> g_side_keep;
+c10::optional<c10::hip::HIPStream> g_side_stream, g_side_main;
+hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
+int g_ev_side_dev = -1;
+bool g_side_pending = false;
+
+int64_t flush_wgrads_side() {
+    std::vector<PendingWgrad> q;
+    c10::optional<c10::hip::HIPStream> st;
+    {
+        std::lock_guard<std::mutex> lock(g_wq_mu);
+        q.swap(g_wq);
+        st = g_wq_stream;
+    }
+    if (q.empty() || !st) return 0;
+    host_timing::Scope host_scope(3);
+    const int dev = (int)st->device_index();
+    c10::hip::HIPGuard dev_guard(dev);
+    if (g_ev_side_dev != dev) {
+        if (g_ev_fork) hipEventDestroy(g_ev_fork);
+        if (g_ev_join) hipEventDestroy(g_ev_join);
+        TORCH_CHECK(hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming) == hipSuccess, "doda: hipEventCreate");
+        g_ev_side_dev = dev;
+        g_side_stream = c10::hip::getStreamFromPool(false, (c10::DeviceIndex)dev);
+    }
+    const int64_t n = (int64_t)q.size();
+    std::vector<PendingWgrad> keep(q);   // (references: issue_in_rounds consumes its argument)
+    if (g_side_pending) {                // a second side flush in one backward pass: it runs behind the first
+        g_side_keep.insert(g_side_keep.end(), keep.begin(), keep.end());
+    } else {
+        g_side_keep.swap(keep);
+    }
+    TORCH_CHECK(hipEventRecord(g_ev_fork, st->stream()) == hipSuccess &&
+                hipStreamWaitEvent(g_side_stream->stream(), g_ev_fork, 0) == hipSuccess, "doda: side flush fork");
+    issue_in_rounds(q, *g_side_stream);
+    TORCH_CHECK(hipEventRecord(g_ev_join, g_side_stream->stream()) == hipSuccess, "doda: side flush join event");
+    g_side_main = st;
+    g_side_pending = true;
+    return n;
+}
+// the backward pass's stream waits for the side flush; true when there was one
+bool join_side_wgrads(const c10::optional<c10::hip::HIPStream> &st) {
+    if (!g_side_pending) return false;
+    const c10::hip::HIPStream &main = st ? *st : *g_side_main;
+    TORCH_CHECK(hipStreamWaitEvent(main.stream(), g_ev_join, 0) == hipSuccess, "doda: side flush join");
+    g_side_pending = false;
+    g_side_keep.clear();   // (freed memory is re-used on `main`, behind the wait)
+    return true;
+}
+
 void flush_wgrads() {
     host_timing::Scope host_scope(3);
     std::vector<PendingWgrad> q;
@@ -551,6 +607,7 @@ void flush_wgrads() {
         g_wq_callback = false;
         g_wq_task = -2;
     }
+    join_side_wgrads(st);
     if (q.empty() || !st) return;   // nothing queued (or no backward pass has run yet: no stream recorded)
     if (!g_wq_split) {
         issue_in_rounds(q, *st);
@@ -587,6 +644,7 @@ int64_t flush_wgrads_early() {
     }
     if (q.empty() || !st) return 0;
     const int64_t n = (int64_t)q.size();
+    join_side_wgrads(st);
     issue_in_rounds(q, *st);
     if (g_ev_early && g_ev_early_dev != (int)st->device_index()) {
         hipEventDestroy(g_ev_early);
@@ -1747,6 +1805,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               return moved;
           }, "re-home every parameter's gradient in its bucket view (copy / zero-fill only where it is not there already)");
     m.def("flush_wgrads", &flush_wgrads);
+    m.def("flush_wgrads_side", &flush_wgrads_side,
+          "issue the weight gradients queued so far on a second stream (joined by the flush at the end of backward); returns the number of jobs");
     m.def("flush_wgrads_early", &flush_wgrads_early,
           "issue the weight-gradient jobs queued so far (mid-backward) and record the event wait_wide_wgrads() waits for");
     m.def("set_grad_home", &set_grad_home, "view of a flat gradient bucket that receives the parameter's gradient in place (None: forget)");

@@ -193,8 +193,11 @@ class DeviceFeeder:
     _END = object()
 
     def __init__(self, host_iter, device, prefetcher=None, with_pairs=False, with_tiles=None, voxel_mode=4,
-                 full_scale=(128, 512), depth=2):
+                 full_scale=(128, 512), depth=2, voxel_order="auto"):
         self.device, self.prefetcher = torch.device(device), prefetcher
+        # numbering of the voxels (collate.reorder_voxels): "first" = the reference's, "morton", or "auto" = decided from the
+        # first batch's tile overflow (collate.choose_voxel_order) and kept
+        self.voxel_order = voxel_order
         self.host_iter = host_iter
         self.kw = dict(voxel_mode=voxel_mode, full_scale=full_scale)
         self.with_pairs, self.with_tiles = with_pairs, with_tiles
@@ -208,7 +211,7 @@ class DeviceFeeder:
         self.thread.start()
 
     def _run(self):
-        from .collate import collate_device, collate_device_concat
+        from .collate import choose_voxel_order, collate_device, collate_device_concat, reorder_voxels
         try:
             import time
             torch.cuda.set_device(self.device)
@@ -226,6 +229,10 @@ class DeviceFeeder:
                         batch = collate_device_concat(items, self.device, voxel_mode=self.kw["voxel_mode"])
                     else:
                         batch = collate_device(items, self.device, **self.kw)
+                    if self.voxel_order == "auto" and batch["voxel_locs"].shape[0] > 0:
+                        self.voxel_order = choose_voxel_order(batch, self.device)
+                    if self.voxel_order == "morton":
+                        batch = reorder_voxels(batch, "morton")
                     fut = None
                     if self.prefetcher is not None and batch["voxel_locs"].shape[0] > 0:
                         # second pipeline stage: the rulebook thread builds this batch's 13 rulebooks (behind an event recorded

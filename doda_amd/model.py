@@ -256,6 +256,17 @@ def set_early_exchange(fn):
 # Level at which the forward pass turns launch-floor bound (a few thousand rows and fewer): PyramidPrefetcher starts the
 # NEXT batch's rulebook kernels there instead of next to the level-1 convolutions (see PyramidPrefetcher.submit).
 COARSE_LEVEL = 4
+# Weight gradients under the coarse levels (round 5): when the backward pass produces the gradient of level WGRAD_SIDE_LEVEL's
+# OUTPUT — the decoder of every finer level is done, the coarse levels' chain of small kernels starts — the weight gradients
+# queued so far are issued on a second stream (extension: flush_wgrads_side) and run under that chain; the flush at the end of
+# backward joins them.  0 = off.
+WGRAD_SIDE_LEVEL = int(_os.environ.get("DODA_WGRAD_SIDE_LEVEL", "4"))
+
+
+def _side_flush_hook(g):
+    if Fsp._ext is not None:
+        Fsp._ext.flush_wgrads_side()
+    return g
 _coarse_hooks = []
 
 
@@ -428,6 +439,9 @@ class UBlock(nn.Module):
                     and torch.is_tensor(st_a[1]) and torch.is_tensor(st_b[1])):
                 out._doda_stats = (out.features, (st_a[1], st_b[1]), out.features._version)
             out = self.blocks_tail(out)
+        if (self.level == WGRAD_SIDE_LEVEL and self.training and torch.is_grad_enabled() and out.features.requires_grad
+                and out.features.is_cuda):
+            out.features.register_hook(_side_flush_hook)
         return out
 
     def _down_with_skip(self, out):

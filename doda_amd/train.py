@@ -70,6 +70,9 @@ def build_parser():
                         "dataset resident in HBM with the augmentation on the device (doda_amd.loader.DeviceScenes)")
     p.add_argument("--inline_loader", action="store_true", default=False,
                    help="generate and collate every batch in the training loop's own thread (the pre-round-5 loader)")
+    p.add_argument("--voxel_order", choices=["auto", "first", "morton"], default="auto",
+                   help="numbering of a batch's voxels (doda_amd.collate.reorder_voxels): the reference's first-appearance order, a "
+                        "Z-order renumbering, or decided from the first batch's tile overflow (per-point outputs do not depend on it)")
     p.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="feature storage dtype")
     p.add_argument("--self_train", action="store_true", default=False,
                    help="tool/st.py step: a source pass and a target pass per optimizer step")
@@ -350,12 +353,14 @@ class Trainer:
             sampler.set_epoch(epoch)
             feeder = DeviceFeeder(iter(dl), self.device, prefetcher=self.prefetch, with_pairs=self.with_pairs,
                                   with_tiles=self.with_tiles, voxel_mode=self.cfg.DATA_CONFIG.DATA_PROCESSOR.voxel_mode,
-                                  full_scale=self.cfg.DATA_CONFIG.DATA_PROCESSOR.get("full_scale", [128, 512]))
+                                  full_scale=self.cfg.DATA_CONFIG.DATA_PROCESSOR.get("full_scale", [128, 512]),
+                                  voxel_order=getattr(self, "voxel_order", None) or getattr(self.args, "voxel_order", "auto"))
             try:
                 for pair in feeder:
                     yield pair
             finally:
                 feeder.close()
+                self.voxel_order = feeder.voxel_order      # ("auto" is decided once, from the first batch)
                 if feeder.batches:
                     self.feeder_ms = (1e3 * feeder.wait_host_s / feeder.batches, 1e3 * feeder.collate_s / feeder.batches)
             return

@@ -119,3 +119,87 @@ def test_hbm_resident_dataset_feeds_the_trainer_contract(cache):
         feeder.close()
         pf.shutdown()
     assert sorted(i - 24 for i in ids) == list(range(12))
+
+
+def test_reorder_voxels_renames_rows_and_keeps_every_point_in_its_voxel():
+    """collate.reorder_voxels (Z-order numbering): the two maps that name voxel rows stay consistent — every point still maps to
+    the voxel with ITS coordinates, every voxel row lists exactly its points, v2p_map_t stays the transposed table, rows are
+    sorted by (scene, Morton key) — and 'first' returns the batch untouched."""
+    from doda_amd.collate import morton_keys, reorder_voxels
+    from doda_amd.scene import make_batch
+    b = make_batch(3, 4000, 11)
+    assert reorder_voxels(b, "first") is b
+    r = reorder_voxels(b, "morton")
+    m = b["voxel_locs"].shape[0]
+    assert r["voxel_locs"].shape == b["voxel_locs"].shape and r["p2v_map"].dtype == b["p2v_map"].dtype
+    assert torch.equal(torch.sort(morton_keys(b["voxel_locs"]))[0], morton_keys(r["voxel_locs"]))   # a permutation, sorted
+    assert torch.equal(b["voxel_locs"][b["p2v_map"].long()], r["voxel_locs"][r["p2v_map"].long()])
+    cnt = r["v2p_map"][:, 0].long()
+    assert torch.equal(torch.sort(cnt)[0], torch.sort(b["v2p_map"][:, 0].long())[0]) and int(cnt.sum()) == b["p2v_map"].numel()
+    rows = torch.repeat_interleave(torch.arange(m), cnt)
+    pts = torch.cat([r["v2p_map"][j, 1:1 + int(cnt[j])] for j in range(m)]).long()
+    assert torch.equal(r["p2v_map"][pts].long(), rows)
+    assert torch.equal(r["v2p_map_t"], r["v2p_map"][:, 1:].t())
+    assert (r["voxel_locs"][1:, 0] >= r["voxel_locs"][:-1, 0]).all()        # scenes stay contiguous
+    # what the renumbering is for: the 3 x 3 x 3 neighbourhoods of 256 consecutive rows hold fewer DISTINCT voxels
+    def distinct_per_tile(v):
+        v = v.numpy().astype(np.int64)
+        key = lambda c: ((c[:, 0] * 4096 + c[:, 1] + 1) * 4096 + c[:, 2] + 1) * 4096 + c[:, 3] + 1
+        present = np.sort(key(v))
+        offs = np.array([[0, a, b_, c] for a in (-1, 0, 1) for b_ in (-1, 0, 1) for c in (-1, 0, 1)])
+        out = []
+        for t0 in range(0, v.shape[0] - 255, 256):
+            k = np.unique(key((v[t0:t0 + 256, None, :] + offs[None]).reshape(-1, 4)))
+            out.append(int(np.isin(k, present, assume_unique=True).sum()))
+        return float(np.median(out))
+    big = make_batch(1, 40000, 12)          # (a scene large enough for its scan order to show: strips against patches)
+    assert distinct_per_tile(reorder_voxels(big, "morton")["voxel_locs"]) < 0.9 * distinct_per_tile(big["voxel_locs"])
+    with pytest.raises(ValueError):
+        reorder_voxels(b, "hilbert")
+
+
+@pytest.mark.gpu
+def test_renumbered_batch_gives_the_same_points_loss_and_gradients():
+    """The U-Net step on a Z-order-renumbered batch against the same batch in the reference's numbering, fp32: per-point scores
+    (max-abs error over max-abs value 1e-4), loss, and every parameter gradient (a sum over rows in another order: 2e-3 of its
+    norm)."""
+    from doda_amd.collate import reorder_voxels
+    from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
+    from doda_amd.scene import make_batch
+    from tests.util import deterministic_init
+    d = torch.device("cuda:0")
+    cfg = default_cfg()
+    base = make_batch(2, 60000, 23)
+    got = []
+    for order in ("first", "morton"):
+        b = reorder_voxels(base, order)
+        bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in b.items()}
+        net = deterministic_init(SparseConvNet(cfg), seed=4).to(d).train()
+        scores = voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.float32)
+        loss = cross_entropy(scores, bd["labels"], ignore_index=255)
+        loss.backward()
+        torch.cuda.synchronize()
+        got.append((scores.detach().float().cpu(), float(loss), {k: p.grad.detach().float().cpu() for k, p in net.named_parameters()}))
+    (s0, l0, g0), (s1, l1, g1) = got
+    assert float((s0 - s1).abs().max()) < 1e-4 * float(s0.abs().max())
+    assert abs(l0 - l1) < 1e-5 * abs(l0)
+    for k, a in g0.items():
+        assert float((a - g1[k]).norm()) <= 2e-3 * float(a.norm()) + 1e-7, k
+
+
+@pytest.mark.gpu
+def test_choose_voxel_order_follows_the_tile_overflow():
+    """collate.choose_voxel_order: the 2 cm bench scene fits the tile lists in the reference's numbering ('first'); a 1 cm scene
+    overflows most level-1 tiles ('morton'), and after the renumbering it fits."""
+    from doda_amd.collate import choose_voxel_order, reorder_voxels
+    from doda_amd.scene import make_batch
+    from doda_amd.spconv import ops as sops
+    d = torch.device("cuda:0")
+    assert choose_voxel_order(make_batch(1, 150000, 1000), d) == "first"
+    b = make_batch(1, 400000, 1000, voxel_scale=100)       # (18 % of its level-1 tiles above the list capacity)
+    assert choose_voxel_order(b, d) == "morton"
+    r = reorder_voxels(b, "morton")
+    assert choose_voxel_order(r, d) == "first"
+    idx = r["voxel_locs"].int().to(d)
+    _, nt, _, over = sops._ext.build_pyramid_probe(idx, [int(v) for v in r["spatial_shape"]], 1, 1, -1, sops.TILE_MIN_ROWS, 1)
+    assert nt > 1000 and over == 0
