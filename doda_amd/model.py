@@ -259,8 +259,9 @@ COARSE_LEVEL = 4
 # Weight gradients under the coarse levels (round 5): when the backward pass produces the gradient of level WGRAD_SIDE_LEVEL's
 # OUTPUT — the decoder of every finer level is done, the coarse levels' chain of small kernels starts — the weight gradients
 # queued so far are issued on a second stream (extension: flush_wgrads_side) and run under that chain; the flush at the end of
-# backward joins them.  0 = off.
-WGRAD_SIDE_LEVEL = int(_os.environ.get("DODA_WGRAD_SIDE_LEVEL", "4"))
+# backward joins them.  Measured (tools/side_ab.sh, side_ab2.sh: 4 and 8 scenes, levels 2-5): no change of the step in either
+# regime — the second queue's workgroups do not run under the chain, they delay it —, so 0 = off is the default.
+WGRAD_SIDE_LEVEL = int(_os.environ.get("DODA_WGRAD_SIDE_LEVEL", "0"))
 
 
 def _side_flush_hook(g):
