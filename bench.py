@@ -229,7 +229,7 @@ def _subm16_times(idx, shape, nb, dtype, reps):
             "fwd_bwd": {"cold": gate(True), "warm": gate(False)}, "b_f": b_f}
 
 
-PROFILE_ROUND = "r04"   # in-step / PMC evidence quoted by the bench line must come from THIS round's profiles or be absent
+PROFILE_ROUND = "r05"   # in-step / PMC evidence quoted by the bench line must come from THIS round's profiles or be absent
 # the roofline kernel's instantiation as rocprofv3 prints it (template arguments up to the ones that name the epilogue),
 # shared by the live measurement's label and the look-up in the committed kernel statistics
 ROOF_KERNEL = {"bf16": "conv_tile16<false, true>", "f32": "conv_tile<2, true, true", "f32_dense": "::PF32,"}
@@ -349,7 +349,7 @@ def step_algorithmic_bytes(net, batch_dev, dtype):
 
 def pmc_traffic(dtype):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
-    of THIS round (tools/profile_round4.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of the same kernel — the
+    of THIS round (tools/profile_round5.sh: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of the same kernel — the
     statistics + residual instantiation the step launches — on the same 4 x 150k-voxel batch; no file of this round:
     null).  Counters are in KiB; FETCH_SIZE is doubled as
     MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950 (check: the doubled value,
