@@ -68,6 +68,10 @@ _SIGNATURES = {
                                        c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "doda_bn_relu_bwd_stats": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                           c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "doda_bn_relu_fwd_totals": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp,
+                                        c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "doda_bn_relu_bwd_totals": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32,
+                                        c_vp, c_vp, c_vp, c_vp]),
     "doda_bn_relu_bwd_add": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp,
                                         c_vp, c_vp, c_vp, c_sz, c_vp]),
     "doda_bn_relu_apply": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
@@ -96,7 +100,7 @@ _SIGNATURES = {
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 OPT_TILE_KERNEL, OPT_WLDS_KERNEL, OPT_WDMA_KERNEL, OPT_TILE_PIPELINE, OPT_TILE_DUAL, OPT_CONV_UP = 1, 2, 3, 4, 5, 6   # doda_set_option / doda_get_option
-ABI_VERSION = 8   # include/doda_hip.h DODA_ABI_VERSION
+ABI_VERSION = 9   # include/doda_hip.h DODA_ABI_VERSION
 
 _lib = None
 

@@ -152,20 +152,94 @@ __global__ __launch_bounds__(64) void bn_stats_final(const typename T::elem *__r
     }
 }
 
+// ---- statistics from TOTALS (ABI 9) ---------------------------------------------------------------------------------
+// The conv epilogues can add their workgroups' (sum, sum of squares) straight into DODA_STATS_SLOTS rows of fp64 totals
+// (spconv_common.hpp stats_emit: hardware fp64 atomics, no return) instead of writing one row per workgroup.  The apply
+// sweeps below then need no reduction launch in front of them: the first c threads of every workgroup add the eight slots of
+// their channel (fixed order, fp64), do the arithmetic of bn_fwd_final_stats / bn_bwd_final_stats and park the per-channel
+// vectors in LDS; workgroup 0 publishes what later kernels need.  (Round 3's form of this — the conv kernel's LAST workgroup
+// summing the rows behind a ticket — made the conv kernels 15-160 % slower: profiles/r03_stats_finish_ab.txt.)
+// ta / tb: the totals of the producers of the columns [0, ca) and [ca, c) (tb null: one producer) — a channel concatenation.
+constexpr int BN_TOT_MAX_C = 256;
+constexpr int BN_TOT_SLOTS = 8;      // = DODA_STATS_SLOTS (spconv_common.hpp)
+struct TotArgs {
+    const double *ta, *tb;
+    int ca, m;
+    float eps, momentum;
+    float *rm, *rv;           // forward: running statistics or null
+    long long *nbt;
+    float *out_a, *out_b;     // forward: save_mean, save_invstd; backward: dgamma, dbeta
+};
+__device__ __forceinline__ void tot_sums(const TotArgs &t, int c, int ch, double &s1, double &s2) {
+    const bool first = ch < t.ca;
+    const double *src = first ? t.ta : t.tb;
+    const int cw = first ? t.ca : c - t.ca, cc = first ? ch : ch - t.ca;
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < BN_TOT_SLOTS; ++k) {
+        s1 += src[(size_t)k * 2 * cw + cc];
+        s2 += src[(size_t)k * 2 * cw + cw + cc];
+    }
+}
+__device__ __forceinline__ void tot_fwd_prologue(const TotArgs &t, int c, float *v_mu, float *v_is) {
+    for (int ch = threadIdx.x; ch < c; ch += BN_BLOCK) {
+        double s1, s2;
+        tot_sums(t, c, ch, s1, s2);
+        const double d = s1 / t.m;
+        double var = s2 / t.m - d * d;
+        if (var < 0.0) var = 0.0;
+        const float mu = (float)d, is = (float)(1.0 / sqrt(var + (double)t.eps));
+        v_mu[ch] = mu;
+        v_is[ch] = is;
+        if (blockIdx.x == 0) {
+            t.out_a[ch] = mu;
+            t.out_b[ch] = is;
+            if (t.rm) {
+                const double unbiased = t.m > 1 ? var * (double)t.m / (double)(t.m - 1) : var;
+                t.rm[ch] = (float)((1.0 - t.momentum) * (double)t.rm[ch] + t.momentum * d);
+                t.rv[ch] = (float)((1.0 - t.momentum) * (double)t.rv[ch] + t.momentum * unbiased);
+            }
+            if (ch == 0 && t.nbt) *t.nbt = *t.nbt + 1;
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void tot_bwd_prologue(const TotArgs &t, int c, const float *__restrict__ invstd,
+                                                 const float *__restrict__ gamma, float *v_co /*[3][c]*/) {
+    for (int ch = threadIdx.x; ch < c; ch += BN_BLOCK) {
+        double s1, s2;
+        tot_sums(t, c, ch, s1, s2);
+        v_co[ch] = gamma[ch] * invstd[ch];          // dx = a * (dz - b - xhat * d)
+        v_co[c + ch] = (float)(s1 / t.m);
+        v_co[2 * c + ch] = (float)(s2 / t.m);
+        if (blockIdx.x == 0) {
+            t.out_b[ch] = (float)s1;                // dbeta
+            t.out_a[ch] = (float)s2;                // dgamma
+        }
+    }
+    __syncthreads();
+}
+
 // ---- pass 2: normalise + affine (+ReLU) --------------------------------------------------------
 // Round 3: the launcher picks a grid whose thread count is a multiple of the fragments per row, so a thread's channels
 // never change while it strides over the rows: the per-channel vectors are loaded ONCE into registers (they used to be
 // four extra vector loads per 8 bytes of payload — the sweep was bound by the texture path's instruction rate, 3.3 TB/s
 // at level 1, not by HBM), and bf16 rows move in 16-byte accesses (two fragments per thread).  Same arithmetic, same
 // order: results unchanged bit for bit.  FIXED = false: the general form (any grid).
-template <class T, bool FIXED>
+template <class T, bool FIXED, bool TOT = false>
 __global__ __launch_bounds__(BN_BLOCK) void bn_apply(const typename T::elem *__restrict__ x,
                                                      long long n_frag, int nf,
-                                                     const float *__restrict__ mean,
-                                                     const float *__restrict__ invstd,
+                                                     const float *mean,
+                                                     const float *invstd,
                                                      const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, int relu,
-                                                     typename T::elem *__restrict__ y) {
+                                                     typename T::elem *__restrict__ y, const TotArgs tot = TotArgs()) {
+    if constexpr (TOT) {   // mean / invstd from the totals, through LDS
+        __shared__ __attribute__((aligned(16))) float v_mu[BN_TOT_MAX_C], v_is[BN_TOT_MAX_C];
+        tot_fwd_prologue(tot, nf * 4, v_mu, v_is);
+        mean = v_mu;
+        invstd = v_is;
+    }
     if constexpr (FIXED) {
         constexpr int W = T::W;
         const long long n_w = n_frag / W, e0 = (long long)blockIdx.x * BN_BLOCK + threadIdx.x;
@@ -297,7 +371,7 @@ __global__ __launch_bounds__(64) void bn_bwd_final(const float *__restrict__ par
     coef[2 * c + ch] = (float)(s2 / m);
 }
 
-template <class T, bool FIXED>
+template <class T, bool FIXED, bool TOT = false>
 __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply(const typename T::elem *__restrict__ x,
                                                          const typename T::elem *__restrict__ dy,
                                                          long long n_frag, int nf, int c,
@@ -305,9 +379,15 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply(const typename T::elem 
                                                          const float *__restrict__ invstd,
                                                          const float *__restrict__ gamma,
                                                          const float *__restrict__ beta, int relu,
-                                                         const float *__restrict__ coef,
+                                                         const float *coef,
                                                          typename T::elem *__restrict__ dx,
-                                                         const typename T::elem *__restrict__ add, int add_ld = 0) {
+                                                         const typename T::elem *__restrict__ add, int add_ld = 0,
+                                                         const TotArgs tot = TotArgs()) {
+    if constexpr (TOT) {   // the three coefficient vectors from the totals, through LDS
+        __shared__ __attribute__((aligned(16))) float v_co[3 * BN_TOT_MAX_C];
+        tot_bwd_prologue(tot, c, invstd, gamma, v_co);
+        coef = v_co;
+    }
     if constexpr (FIXED) {   // (see bn_apply: per-thread channel vectors in registers, 16-byte accesses)
         constexpr int W = T::W;
         const int cols = nf / W;
@@ -384,6 +464,34 @@ void launch_apply(const typename T::elem *x, long long n_frag, int nf, const flo
         hipLaunchKernelGGL((bn_apply<T, true>), dim3(grid), dim3(BN_BLOCK), 0, s, x, n_frag, nf, mean, invstd, gamma, beta, relu, y);
     else
         hipLaunchKernelGGL((bn_apply<T, false>), dim3(grid), dim3(BN_BLOCK), 0, s, x, n_frag, nf, mean, invstd, gamma, beta, relu, y);
+}
+template <class T>
+void launch_apply_tot(const typename T::elem *x, long long n_frag, int nf, const float *gamma, const float *beta, int relu,
+                      typename T::elem *y, const TotArgs &tot, hipStream_t s) {
+    bool fixed;
+    int grid = apply_grid(n_frag, nf, T::W, &fixed);
+    if (fixed && !(al16(x) && al16(y))) { fixed = false; grid = plain_grid(n_frag); }
+    if (fixed)
+        hipLaunchKernelGGL((bn_apply<T, true, true>), dim3(grid), dim3(BN_BLOCK), 0, s, x, n_frag, nf, nullptr, nullptr, gamma, beta, relu, y, tot);
+    else
+        hipLaunchKernelGGL((bn_apply<T, false, true>), dim3(grid), dim3(BN_BLOCK), 0, s, x, n_frag, nf, nullptr, nullptr, gamma, beta, relu, y, tot);
+}
+template <class T>
+void launch_bwd_apply_tot(const typename T::elem *x, const typename T::elem *dy, long long n_frag, int nf, int c,
+                          const float *mean, const float *invstd, const float *gamma, const float *beta, int relu,
+                          typename T::elem *dx, const typename T::elem *add, int add_ld, const TotArgs &tot, hipStream_t s) {
+    bool fixed;
+    int grid = apply_grid(n_frag, nf, T::W, &fixed);
+    if (fixed && !(al16(x) && al16(dy) && al16(dx) && (!add || (al16(add) && add_ld % (4 * T::W) == 0)))) {
+        fixed = false;
+        grid = plain_grid(n_frag);
+    }
+    if (fixed)
+        hipLaunchKernelGGL((bn_bwd_apply<T, true, true>), dim3(grid), dim3(BN_BLOCK), 0, s, x, dy, n_frag, nf, c, mean, invstd, gamma,
+                           beta, relu, nullptr, dx, add, add_ld, tot);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply<T, false, true>), dim3(grid), dim3(BN_BLOCK), 0, s, x, dy, n_frag, nf, c, mean, invstd, gamma,
+                           beta, relu, nullptr, dx, add, add_ld, tot);
 }
 template <class T>
 void launch_bwd_apply(const typename T::elem *x, const typename T::elem *dy, long long n_frag, int nf, int c,
@@ -1129,6 +1237,55 @@ extern "C" int doda_bn_fwd_final(const float *stats, int32_t stats_rows, int32_t
     if (!stats || stats_rows <= 0 || !save_mean || !save_invstd || (!running_mean != !running_var)) return DODA_ERR_INVALID;
     hipLaunchKernelGGL(bn_fwd_final_stats, dim3(c / 4), dim3(BN_BLOCK), 0, as_stream(stream), stats, stats_rows, m, c, eps,
                        momentum, save_mean, save_invstd, running_mean, running_var, (long long *)num_batches_tracked);
+    return doda_check_launch();
+}
+
+// ABI 9: BatchNorm(+ReLU) over TOTALS that conv epilogues accumulated (doda_conv_epilogue.stats_totals): ONE launch.
+// totals_b / c_a: the columns [c_a, c) come from a second producer (a channel concatenation); totals_b null: c_a is ignored.
+extern "C" int doda_bn_relu_fwd_totals(const void *x, int32_t m, int32_t c, int32_t elem_bytes, const double *totals,
+                                       const double *totals_b, int32_t c_a, float eps, float momentum, const float *gamma,
+                                       const float *beta, float *running_mean, float *running_var,
+                                       int64_t *num_batches_tracked, int32_t relu, void *y, float *save_mean,
+                                       float *save_invstd, doda_stream_t stream) {
+    if (m == 0) return DODA_OK;
+    if (bn_args_bad(m, c, elem_bytes) || c > BN_TOT_MAX_C) return DODA_ERR_UNSUPPORTED;
+    if (!x || !y || !totals || !gamma || !beta || !save_mean || !save_invstd || (!running_mean != !running_var))
+        return DODA_ERR_INVALID;
+    if (totals_b && (c_a <= 0 || c_a >= c)) return DODA_ERR_INVALID;
+    TotArgs t;
+    t.ta = totals; t.tb = totals_b; t.ca = totals_b ? c_a : c; t.m = m; t.eps = eps; t.momentum = momentum;
+    t.rm = running_mean; t.rv = running_var; t.nbt = (long long *)num_batches_tracked;
+    t.out_a = save_mean; t.out_b = save_invstd;
+    const Geo g = make_geo(c);
+    const long long n_frag = (long long)m * g.nf;
+    if (elem_bytes == 4)
+        launch_apply_tot<F32>((const float *)x, n_frag, g.nf, gamma, beta, relu, (float *)y, t, as_stream(stream));
+    else
+        launch_apply_tot<BF16>((const unsigned short *)x, n_frag, g.nf, gamma, beta, relu, (unsigned short *)y, t, as_stream(stream));
+    return doda_check_launch();
+}
+
+extern "C" int doda_bn_relu_bwd_totals(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes,
+                                       const double *totals, const float *save_mean, const float *save_invstd,
+                                       const float *gamma, const float *beta, int32_t relu, const void *add, int32_t add_ld,
+                                       void *dx, float *dgamma, float *dbeta, doda_stream_t stream) {
+    if (add && (add_ld < c || add_ld % 4 || ((uintptr_t)add % (4 * (size_t)elem_bytes)))) return DODA_ERR_INVALID;
+    if (m == 0) return DODA_OK;
+    if (bn_args_bad(m, c, elem_bytes) || c > BN_TOT_MAX_C) return DODA_ERR_UNSUPPORTED;
+    if (!x || !dy || !dx || !totals || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta) return DODA_ERR_INVALID;
+    TotArgs t;
+    t.ta = totals; t.tb = nullptr; t.ca = c; t.m = m; t.eps = 0.f; t.momentum = 0.f;
+    t.rm = nullptr; t.rv = nullptr; t.nbt = nullptr;
+    t.out_a = dgamma; t.out_b = dbeta;
+    const Geo g = make_geo(c);
+    const long long n_frag = (long long)m * g.nf;
+    if (add_ld == c || !add) add_ld = 0;   // dense
+    if (elem_bytes == 4)
+        launch_bwd_apply_tot<F32>((const float *)x, (const float *)dy, n_frag, g.nf, c, save_mean, save_invstd, gamma, beta, relu,
+                                  (float *)dx, (const float *)add, add_ld, t, as_stream(stream));
+    else
+        launch_bwd_apply_tot<BF16>((const unsigned short *)x, (const unsigned short *)dy, n_frag, g.nf, c, save_mean, save_invstd,
+                                   gamma, beta, relu, (unsigned short *)dx, (const unsigned short *)add, add_ld, t, as_stream(stream));
     return doda_check_launch();
 }
 

@@ -100,7 +100,32 @@ struct EpiArgs {   // plain data, shared across translation units
     int bn_relu;
     int res_bcast;           // ABI 6: `res` is ONE row [nc] added to every output row (a bias): conv_fast only
     int f32_split;           // round 5: fp32 units as two bf16 MFMAs on head / tail splits (mma_f32_k16); set by run_gather
+    double *stats_tot;       // ABI 9: [DODA_STATS_SLOTS][2][nc] totals, accumulated with fp64 atomics INSTEAD of the rows, or null
 };
+#ifndef DODA_STATS_SLOTS
+#define DODA_STATS_SLOTS 8      // (include/doda_hip.h)
+#endif
+#if defined(__HIPCC__)
+// A workgroup's (sum, sum of squares) of the four columns col .. col + 3: its row of `stats`, or — ABI 9 — added to the
+// totals of slot (part mod 8).  The additions are hardware fp64 atomics without return (fire and forget: the workgroup does
+// not wait, the kernel's end does); every addend is an fp32 value, so a sum of a few thousand of them is exact in fp64 unless
+// their magnitudes span more than ~2^16, and then differs from any other order by an ulp of fp64 — the statistics derived
+// from the totals are fp32.
+__device__ __forceinline__ void stats_emit(const EpiArgs &ep, long long part, int nc, int col, const f32x4 &a1, const f32x4 &a2) {
+    if (ep.stats_tot) {
+        double *t = ep.stats_tot + (size_t)((unsigned)part & (unsigned)(DODA_STATS_SLOTS - 1)) * 2 * nc + col;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsafeAtomicAdd(t + q, (double)a1[q]);
+            unsafeAtomicAdd(t + nc + q, (double)a2[q]);
+        }
+    } else {
+        float *dst = ep.stats + part * 2 * nc + col;
+        *reinterpret_cast<f32x4 *>(dst) = a1;
+        *reinterpret_cast<f32x4 *>(dst + nc) = a2;
+    }
+}
+#endif
 
 namespace doda_tile {
 bool enabled();   // doda_set_option(DODA_OPT_TILE_KERNEL)

@@ -776,9 +776,7 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                         a1 = (a1 + sred[1][nb][0][g]) + (sred[2][nb][0][g] + sred[3][nb][0][g]);
                         a2 = (a2 + sred[1][nb][1][g]) + (sred[2][nb][1][g] + sred[3][nb][1][g]);
                     }
-                    float *dst = ep.stats + (long long)part * 2 * nc + col;
-                    *reinterpret_cast<f32x4 *>(dst) = a1;
-                    *reinterpret_cast<f32x4 *>(dst + nc) = a2;
+                    stats_emit(ep, (long long)part, nc, col, a1, a2);
                 }
             }
         }
@@ -848,7 +846,7 @@ template <class T>
 int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tbl, int ld, int K,
                int n_out, void *y_, int wl, void *ws, size_t ws_bytes, long long n_in, bool out32,
                const void *res, hipStream_t s,
-               const EpiArgs &ep_arg = EpiArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0},
+               const EpiArgs &ep_arg = EpiArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr},
                int *n_part = nullptr, const void *tilebook = nullptr, int tilebook_rows = 0) {
     typedef typename T::elem elem;
     typedef typename T::frag frag;
@@ -1086,7 +1084,7 @@ extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, in
         if (st == DODA_OK && epi && epi->stats_rows_h) *epi->stats_rows_h = 0;
         return st;
     }
-    EpiArgs ep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    EpiArgs ep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
     const void *res = nullptr;
     int n_part = 0;
     if (epi) {
@@ -1095,6 +1093,7 @@ extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, in
         if (epi->stats) {
             if (!epi->stats_rows_h) return DODA_ERR_INVALID;
             ep.stats = epi->stats;
+            ep.stats_tot = epi->stats_totals;
             if (epi->bn_x) {
                 if (!epi->bn_mean || !epi->bn_invstd || !epi->bn_gamma || !epi->bn_beta) return DODA_ERR_INVALID;
                 ep.bn_x = epi->bn_x;

@@ -166,7 +166,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][NBA], const EpiPre
 }
 
 // the workgroup's partial row of channel block nb0 from the lanes' running sums (all 256 threads call it)
-__device__ __forceinline__ void stats_flush(f32x4 (&lst)[2], int i, int g, int wid, int nb0, int nc, float *__restrict__ stats_row) {
+__device__ __forceinline__ void stats_flush(f32x4 (&lst)[2], int i, int g, int wid, int nb0, int nc, const EpiArgs &ep, long long part) {
     __shared__ f32x4 sred[4][2][4];
     f32x4 st1 = lst[0], st2 = lst[1];
 #pragma unroll
@@ -177,8 +177,7 @@ __device__ __forceinline__ void stats_flush(f32x4 (&lst)[2], int i, int g, int w
     if (wid == 0 && i == 15 && col < nc) {
         const f32x4 a1 = (sred[0][0][g] + sred[1][0][g]) + (sred[2][0][g] + sred[3][0][g]);
         const f32x4 a2 = (sred[0][1][g] + sred[1][1][g]) + (sred[2][1][g] + sred[3][1][g]);
-        *reinterpret_cast<f32x4 *>(stats_row + col) = a1;
-        *reinterpret_cast<f32x4 *>(stats_row + nc + col) = a2;
+        stats_emit(ep, part, nc, col, a1, a2);
     }
     __syncthreads();   // sred is reused by the next channel block
 }
@@ -484,11 +483,10 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
     }
     if constexpr (STATS) {   // the workgroup's partial row (zeros when it had no tile)
         const int lane = tid0 & 63, i = lane & 15, g = lane >> 4;
-        float *row = ep.stats + (long long)blockIdx.x * 2 * nc;
-        stats_flush(lst[0], i, g, wid, 0, nc, row);
+        stats_flush(lst[0], i, g, wid, 0, nc, ep, (long long)blockIdx.x);
 #pragma unroll
         for (int b = 1; b < MAXNB; ++b)
-            if (b < NB) stats_flush(lst[b], i, g, wid, b, nc, row);
+            if (b < NB) stats_flush(lst[b], i, g, wid, b, nc, ep, (long long)blockIdx.x);
     }
 }
 
@@ -714,7 +712,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile16(const void *__restrict__ x
         __syncthreads();   // the next tile overwrites the staged rows
         TILE_STAMP(5);
     }
-    if constexpr (STATS) stats_flush(lst, i, g, wid, 0, nc, ep.stats + (long long)blockIdx.x * 2 * nc);
+    if constexpr (STATS) stats_flush(lst, i, g, wid, 0, nc, ep, (long long)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -751,7 +749,6 @@ __global__ __launch_bounds__(256) void conv_up32(const void *__restrict__ x, uns
             te[o] = ok ? v : -1;
         }
     }
-    float *stats_row = STATS ? ep.stats + (long long)blockIdx.x * 2 * nc : nullptr;
     for (int nb0 = 0; nb0 < NB; ++nb0) {
         EpiPre<OUT32> pre;
         epi_prefetch<S, OUT32, STATS>(pre, row0, i, g, nb0, nc, n_out, y_bytes, res, ep);
@@ -794,7 +791,7 @@ __global__ __launch_bounds__(256) void conv_up32(const void *__restrict__ x, uns
         }
         f32x4 lst[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         tile_epilogue<S, OUT32, STATS>(acc, pre, row0, i, g, nb0, nc, n_out, rs_y, res, ep, lst);
-        if constexpr (STATS) stats_flush(lst, i, g, wid, nb0, nc, stats_row);
+        if constexpr (STATS) stats_flush(lst, i, g, wid, nb0, nc, ep, (long long)blockIdx.x);
     }
 }
 

@@ -74,9 +74,7 @@ __device__ __forceinline__ void wlds_epilogue(f32x4 (&acc)[S], const u32x2 (&pre
             f32x4 a1 = sred[0][0][g], a2 = sred[0][1][g];
 #pragma unroll
             for (int w = 1; w < 8; ++w) { a1 += sred[w][0][g]; a2 += sred[w][1][g]; }
-            float *dst = ep.stats + (long long)part * 2 * WCH + col;
-            *reinterpret_cast<f32x4 *>(dst) = a1;
-            *reinterpret_cast<f32x4 *>(dst + WCH) = a2;
+            stats_emit(ep, (long long)part, WCH, col, a1, a2);
         }
         __syncthreads();   // sred is reused by the next channel block / tile
     }

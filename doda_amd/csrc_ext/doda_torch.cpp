@@ -103,6 +103,38 @@ void build_tilebook(const at::Tensor &tbl, void *st) {
                               doda_tilebook_bytes((int32_t)tbl.size(1), (int32_t)tbl.size(0)), st), "doda_tilebook_build");
 }
 
+// BatchNorm statistics as fp64 TOTALS (ABI 9, doda_conv_epilogue.stats_totals): the conv epilogues add their workgroups' sums
+// into 8 x 2 x nc doubles and the BatchNorm that follows derives its vectors from them inside its own sweep — the `final`
+// reduction launches (52 per U-Net step) are gone.  The totals of a pass come out of ONE zeroed arena (one memset per forward
+// pass instead of one per conv): a slice per statistics-producing call, forward and backward.  A slice is handed out once:
+// the arena only grows, and a full one is replaced by a fresh zeroed buffer (one 4 MB memset every several steps; slices still
+// referenced keep the old storage alive).
+bool g_stats_totals = [] { const char *e = getenv("DODA_STATS_TOTALS"); return !(e && e[0] == '0'); }();
+constexpr int64_t TOT_ARENA_DOUBLES = 512 * 1024;      // 4 MB: ~250 slices of 64 channels
+std::mutex g_tot_mu;
+at::Tensor g_tot_buf;
+int64_t g_tot_used = 0;
+void stats_totals_begin_pass() {
+    std::lock_guard<std::mutex> lock(g_tot_mu);
+    g_tot_buf = at::Tensor();
+    g_tot_used = 0;
+}
+at::Tensor stats_totals_take(int64_t nc, const at::TensorOptions &like) {
+    const int64_t n = (int64_t)DODA_STATS_SLOTS * 2 * nc;
+    std::lock_guard<std::mutex> lock(g_tot_mu);
+    if (!g_tot_buf.defined() || g_tot_buf.device() != like.device() || g_tot_used + n > g_tot_buf.numel()) {
+        g_tot_buf = at::zeros({n > TOT_ARENA_DOUBLES ? n : TOT_ARENA_DOUBLES}, like.dtype(at::kDouble));
+        g_tot_used = 0;
+    }
+    at::Tensor t = g_tot_buf.narrow(0, g_tot_used, n).view({(int64_t)DODA_STATS_SLOTS, 2, nc});
+    g_tot_used += n;
+    return t;
+}
+inline bool is_totals(const at::Tensor &st, int64_t c) {
+    return st.defined() && st.scalar_type() == at::kDouble && st.dim() == 3 && st.size(0) == DODA_STATS_SLOTS && st.size(1) == 2 &&
+           st.size(2) == c && st.is_contiguous();
+}
+
 // y[t] = sum_o x[tbl[o][t]] . B_o   (include/doda_hip.h: doda_spconv_gather_ex)
 at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::optional<at::Tensor> &packed,
                   const at::Tensor &tbl, int64_t n_out, int64_t layout, int64_t nc, bool out_f32,
@@ -126,9 +158,16 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
     at::Tensor stats;
     ep.residual = res.defined() ? res.data_ptr() : nullptr;
     bool with_stats = epi && epi->want && n_out > 0;
+    const bool totals = with_stats && g_stats_totals && nc % 4 == 0;
     if (with_stats) {
-        stats = at::empty({(int64_t)doda_spconv_stats_capacity((int32_t)n_out), 2, nc}, x.options().dtype(at::kFloat));
-        ep.stats = (float *)stats.data_ptr();
+        if (totals) {
+            stats = stats_totals_take(nc, x.options());
+            ep.stats_totals = (double *)stats.data_ptr();
+            ep.stats = (float *)stats.data_ptr();      // (non-NULL selects the statistics epilogue; nothing is written through it)
+        } else {
+            stats = at::empty({(int64_t)doda_spconv_stats_capacity((int32_t)n_out), 2, nc}, x.options().dtype(at::kFloat));
+            ep.stats = (float *)stats.data_ptr();
+        }
         ep.stats_rows_h = &stats_rows;
         if (epi->bn_x.defined()) {
             TORCH_CHECK(epi->bn_x.scalar_type() == y.scalar_type() && epi->bn_x.is_contiguous() &&
@@ -172,6 +211,7 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
         if (status == DODA_ERR_UNSUPPORTED && with_stats) {  // generic kernel: no statistics in its epilogue
             with_stats = false;
             ep.stats = nullptr;
+            ep.stats_totals = nullptr;
             ep.stats_rows_h = nullptr;
             ep.bn_x = nullptr;
             use_packed = packed.has_value() && packed->defined();
@@ -180,7 +220,7 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
         check(status, "doda_spconv_gather");
         break;
     }
-    if (epi) epi->stats = (with_stats && stats_rows > 0) ? stats.narrow(0, 0, stats_rows) : at::Tensor();
+    if (epi) epi->stats = (with_stats && stats_rows > 0) ? (totals ? stats : stats.narrow(0, 0, stats_rows)) : at::Tensor();
     return y;
 }
 
@@ -715,7 +755,9 @@ struct BNLink {
 };
 thread_local std::shared_ptr<BNLink> g_last_bn;
 bool g_bn_fusion = true;
-constexpr int64_t BN_SMALL_ROWS = 4096;   // below: the one-launch BatchNorm kernels win (csrc/bn.hip)
+// below: the one-launch BatchNorm kernels (csrc/bn.hip bn_small_*) instead of conv-epilogue statistics (DODA_STATS_MIN_ROWS, also
+// read by spconv/functional.py: the two thresholds move together)
+const int64_t BN_SMALL_ROWS = [] { const char *e = getenv("DODA_STATS_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
 
 // features, weight [k,k,k,Cin,Cout], fwd_tbl, bwd_tbl, n_out, bwd_layout, packed fwd / data-grad,
 // optional residual (y = conv + residual; its gradient is the incoming gradient itself).
@@ -903,7 +945,21 @@ struct BNNode : public torch::autograd::Node {
             link->stats.reset();
             link->dz.reset();
         }
-        if (stats.defined()) {
+        if (stats.defined() && is_totals(stats, x.size(1)) && x.size(1) <= 256) {
+            const int64_t m = x.size(0), c = x.size(1);
+            int64_t add_ld = c;
+            const at::Tensor add = extra.defined() ? add_operand(extra, m, c, add_ld) : at::Tensor();
+            dx = at::empty_like(x);
+            dg = grad_out(weight, c);
+            db = grad_out(bias, c);
+            check(doda_bn_relu_bwd_totals(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x), (const double *)stats.data_ptr(),
+                                          (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(),
+                                          (const float *)weight.data_ptr(), (const float *)bias.data_ptr(), relu ? 1 : 0,
+                                          add.defined() ? add.data_ptr() : nullptr, (int)add_ld, dx.data_ptr(),
+                                          (float *)dg.data_ptr(), (float *)db.data_ptr(), stream_of(x)),
+                  "doda_bn_relu_bwd_totals");
+            extra = at::Tensor();
+        } else if (stats.defined() && stats.scalar_type() == at::kFloat) {
             const int64_t m = x.size(0), c = x.size(1);
             int64_t add_ld = c;
             const at::Tensor add = extra.defined() ? add_operand(extra, m, c, add_ld) : at::Tensor();
@@ -1004,7 +1060,20 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
             mean = running_mean.to(at::kFloat).contiguous();
             invstd = at::rsqrt(running_var.to(at::kFloat) + eps).contiguous();
         }
-        if (training && stats.defined() && stats_b.defined() && m > BN_SMALL_ROWS && stats.dim() == 3 &&
+        if (training && m > BN_SMALL_ROWS && c <= 256 && stats.defined() && stats.scalar_type() == at::kDouble &&
+            (stats_b.defined() ? (stats.dim() == 3 && stats_b.dim() == 3 && is_totals(stats, stats.size(2)) &&
+                                  is_totals(stats_b, c - stats.size(2)) && stats.size(2) > 0 && stats.size(2) < c)
+                               : is_totals(stats, c))) {
+            // ABI 9: statistics as totals — ONE launch, also for a channel concatenation [a | b] (two producers)
+            check(doda_bn_relu_fwd_totals(x.data_ptr(), (int)m, (int)c, esz, (const double *)stats.data_ptr(),
+                                          stats_b.defined() ? (const double *)stats_b.data_ptr() : nullptr, (int)stats.size(2),
+                                          (float)eps, (float)momentum, (const float *)weight.data_ptr(),
+                                          (const float *)bias.data_ptr(), (float *)running_mean.data_ptr(),
+                                          (float *)running_var.data_ptr(), nbt.defined() ? (int64_t *)nbt.data_ptr() : nullptr,
+                                          relu ? 1 : 0, y.data_ptr(), (float *)mean.data_ptr(), (float *)invstd.data_ptr(),
+                                          stream_of(x)),
+                  "doda_bn_relu_fwd_totals");
+        } else if (training && stats.defined() && stats_b.defined() && m > BN_SMALL_ROWS && stats.dim() == 3 &&
             stats_b.dim() == 3 && stats.size(2) + stats_b.size(2) == c && stats.scalar_type() == at::kFloat &&
             stats_b.scalar_type() == at::kFloat && stats.is_contiguous() && stats_b.is_contiguous() && stats.size(2) % 4 == 0) {
             // x is a channel concatenation [a | b] (the U-Net level's skip + upsampled features): BatchNorm statistics are
@@ -1805,6 +1874,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               return moved;
           }, "re-home every parameter's gradient in its bucket view (copy / zero-fill only where it is not there already)");
     m.def("flush_wgrads", &flush_wgrads);
+    m.def("stats_totals_begin_pass", &stats_totals_begin_pass, "a new forward pass: the next statistics totals come out of a fresh zeroed arena");
+    m.def("set_stats_totals", [](bool on) { g_stats_totals = on; return g_stats_totals; },
+          "BatchNorm statistics of the conv epilogues as fp64 totals (one-launch BatchNorm) or as per-workgroup rows + a reduction launch");
+    m.def("get_stats_totals", []() { return g_stats_totals; });
     m.def("flush_wgrads_side", &flush_wgrads_side,
           "issue the weight gradients queued so far on a second stream (joined by the flush at the end of backward); returns the number of jobs");
     m.def("flush_wgrads_early", &flush_wgrads_early,

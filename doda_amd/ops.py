@@ -287,11 +287,14 @@ def _feat_ok(x, name):
         raise RuntimeError("%s must be a contiguous [rows, channels] tensor" % name)
 
 
-class _ConvEpilogue(C.Structure):   # doda_conv_epilogue (include/doda_hip.h, ABI 7)
+STATS_SLOTS = 8     # DODA_STATS_SLOTS
+
+
+class _ConvEpilogue(C.Structure):   # doda_conv_epilogue (include/doda_hip.h, ABI 9)
     _fields_ = [("residual", C.c_void_p), ("stats", C.c_void_p), ("stats_rows_h", C.POINTER(C.c_int32)),
                 ("bn_x", C.c_void_p), ("bn_mean", C.c_void_p), ("bn_invstd", C.c_void_p), ("bn_gamma", C.c_void_p),
                 ("bn_beta", C.c_void_p), ("bn_relu", C.c_int32), ("tilebook_rows", C.c_int32),
-                ("tilebook", C.c_void_p), ("residual_bcast", C.c_int32)]
+                ("tilebook", C.c_void_p), ("residual_bcast", C.c_int32), ("stats_totals", C.c_void_p)]
 
 
 def tilebook_build(tbl, n_rows=None):
@@ -366,8 +369,15 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
         ep.tilebook = _p(tilebook)
         ep.tilebook_rows = int(getattr(tilebook, "_doda_rows", n_out))
     stats, rows = None, C.c_int32(0)
-    if want_stats:
-        stats = torch.empty((int(lib().doda_spconv_stats_capacity(n_out)), 2, nc), dtype=torch.float32, device=x.device)
+    totals = None
+    if want_stats == "totals" or torch.is_tensor(want_stats):   # ABI 9: fp64 totals [8, 2, nc] (a tensor: accumulate into it)
+        totals = want_stats if torch.is_tensor(want_stats) else torch.zeros((STATS_SLOTS, 2, nc), dtype=torch.float64, device=x.device)
+        if totals.dtype != torch.float64 or tuple(totals.shape) != (STATS_SLOTS, 2, nc) or not totals.is_contiguous():
+            raise RuntimeError("spconv_gather: totals must be a contiguous float64 [8, 2, nc] tensor")
+        ep.stats_totals = _p(totals)
+    if want_stats is not False and want_stats is not None:
+        stats = torch.empty((int(lib().doda_spconv_stats_capacity(n_out)) if totals is None else 1, 2, nc), dtype=torch.float32,
+                            device=x.device)
         ep.stats, ep.stats_rows_h = _p(stats), C.pointer(rows)
         if bn is not None:
             bx, mean, invstd, gamma, beta, relu = bn
@@ -378,7 +388,9 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
     check(lib().doda_spconv_gather_ex(*call_args), "doda_spconv_gather_ex")
     if _call is not None:   # (GatherCall: everything the native call references stays alive with the object)
         _call._args = call_args
-        _call._keep = (x, w, tbl, y, ep, rows, stats, residual, tilebook, bn, packed, ws if packed is None else None)
+        _call._keep = (x, w, tbl, y, ep, rows, stats, residual, tilebook, bn, packed, ws if packed is None else None, totals)
+    if totals is not None:
+        return y, totals
     return (y, stats[:rows.value]) if want_stats else y
 
 
@@ -660,6 +672,43 @@ def bn_relu_bwd_stats(x, dy, stats, save_mean, save_invstd, gamma, beta, relu, a
     check(lib().doda_bn_relu_bwd_stats(_p(x), _p(dy), m, c, _esz(x), _p(stats), stats.shape[0], _p(save_mean),
                                           _p(save_invstd), _p(gamma), _p(beta), int(bool(relu)), ap, ld, _p(dx), _p(dgamma),
                                           _p(dbeta), _p(coef), _stream()), "doda_bn_relu_bwd_stats")
+    return dx, dgamma, dbeta
+
+
+def bn_relu_fwd_totals(x, totals, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None,
+                       totals_b=None):
+    """Training-mode BatchNorm(+ReLU) over the fp64 totals of conv epilogues (doda_bn_relu_fwd_totals, ONE launch);
+    totals_b: totals of the producer of the trailing columns (a channel concatenation).  -> (y, save_mean, save_invstd)."""
+    _feat_ok(x, "x")
+    _need_cuda(totals)
+    m, c = x.shape
+    c_a = int(totals.shape[2])
+    y = torch.empty_like(x)
+    save_mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    save_invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(lib().doda_bn_relu_fwd_totals(_p(x), m, c, _esz(x), _p(totals), _p(totals_b) if totals_b is not None else None, c_a,
+                                        float(eps), float(momentum), _p(gamma), _p(beta),
+                                        _p(running_mean) if running_mean is not None else None,
+                                        _p(running_var) if running_var is not None else None,
+                                        _p(num_batches_tracked) if num_batches_tracked is not None else None, int(bool(relu)),
+                                        _p(y), _p(save_mean), _p(save_invstd), _stream()), "doda_bn_relu_fwd_totals")
+    return y, save_mean, save_invstd
+
+
+def bn_relu_bwd_totals(x, dy, totals, save_mean, save_invstd, gamma, beta, relu, add=None):
+    """BatchNorm(+ReLU) backward over the fp64 totals of a data-grad conv epilogue (doda_bn_relu_bwd_totals, ONE launch).
+    -> (dx [+ add], dgamma, dbeta)."""
+    _feat_ok(x, "x")
+    _feat_ok(dy, "dy")
+    _need_cuda(totals)
+    m, c = x.shape
+    ap, ld = _add_ld(add, m, c, "bn_relu_bwd_totals") if add is not None else (None, c)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(lib().doda_bn_relu_bwd_totals(_p(x), _p(dy), m, c, _esz(x), _p(totals), _p(save_mean), _p(save_invstd), _p(gamma),
+                                        _p(beta), int(bool(relu)), ap, ld, _p(dx), _p(dgamma), _p(dbeta), _stream()),
+          "doda_bn_relu_bwd_totals")
     return dx, dgamma, dbeta
 
 

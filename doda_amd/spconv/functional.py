@@ -125,7 +125,7 @@ class _IndiceConv(Function):
 BN_FUSION = os.environ.get("DODA_BN_FUSION", "1") == "1" and _ext is not None and _SERIAL
 if _ext is not None:
     _ext.set_bn_fusion(BN_FUSION)
-STATS_MIN_ROWS = 4096   # below: the one-launch BatchNorm kernels win (csrc/bn.hip BN_SMALL_ROWS)
+STATS_MIN_ROWS = int(os.environ.get("DODA_STATS_MIN_ROWS", "4096"))   # below: the one-launch BatchNorm kernels win (csrc/bn.hip BN_SMALL_ROWS)
 
 
 def set_bn_fusion(on):

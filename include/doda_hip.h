@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DODA_ABI_VERSION 8
+#define DODA_ABI_VERSION 9
 
 #define DODA_OK 0
 #define DODA_ERR_INVALID (-1)        /* bad argument (null pointer, negative size, bad mode) */
@@ -238,7 +238,15 @@ typedef struct doda_conv_epilogue {
     const void *tilebook;    /* ABI 3: doda_tilebook_build of `tbl`, or NULL */
     int32_t residual_bcast;   /* ABI 6: `residual` is ONE row [nc] (dtype of y) added to every output row — a bias (the Linear
                                * head of reference model/unet.py:64 as a gather-GEMM); dense-table kernels only */
+    double *stats_totals;     /* ABI 9: with `stats`: DODA_STATS_SLOTS x 2 x nc doubles, ZERO on entry (or holding the sums of
+                               * other calls over the same rows), to which the kernel's workgroups ADD their (sum, sum of squares)
+                               * with fp64 atomics instead of writing rows into `stats` (which must still be non-NULL: it selects
+                               * the statistics epilogue, nothing is written there).  Feed them to doda_bn_relu_fwd_totals /
+                               * doda_bn_relu_bwd_totals: BatchNorm in ONE launch, no reduction launch in front of it.  Every addend
+                               * is an fp32 value: a sum of a few thousand is exact in fp64 unless the magnitudes span more than
+                               * ~2^16, and then differs between runs by an ulp of fp64 — the statistics are rounded to fp32. */
 } doda_conv_epilogue;
+#define DODA_STATS_SLOTS 8
 /* ABI 3.  Tile-local form of a SubM gather table ("tilebook") for the LDS-staged convolution kernel:
  * per tile of doda_tilebook_tile() consecutive output rows, the sorted list of DISTINCT input rows the
  * tile's K x tile table entries reference and, per entry, its position in that list.  The kernel loads
@@ -395,6 +403,19 @@ int doda_bn_relu_bwd_stats(const void *x, const void *dy, int32_t m, int32_t c, 
                            const float *save_invstd, const float *gamma, const float *beta, int32_t relu,
                            const void *add, int32_t add_ld, void *dx, float *dgamma, float *dbeta,
                            float *coef_ws, doda_stream_t stream);   /* add / add_ld as doda_bn_relu_bwd_add; add may be NULL */
+/* ABI 9.  The same two operators over TOTALS (doda_conv_epilogue.stats_totals) — reference torch.nn.BatchNorm1d + ReLU applied by
+ * SparseSequential (model/unet_block.py:23-30,46-49), ONE launch each: every workgroup of the sweep derives the per-channel
+ * vectors from the DODA_STATS_SLOTS x 2 x c totals itself.  totals_b / c_a (forward): the columns [c_a, c) of x come from a second
+ * producer with its own totals (DODA_STATS_SLOTS x 2 x (c - c_a)) — the U-Net level's concatenation (unet_block.py:93); NULL: one
+ * producer.  c <= 256. */
+int doda_bn_relu_fwd_totals(const void *x, int32_t m, int32_t c, int32_t elem_bytes, const double *totals,
+                            const double *totals_b, int32_t c_a, float eps, float momentum, const float *gamma,
+                            const float *beta, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                            int32_t relu, void *y, float *save_mean, float *save_invstd, doda_stream_t stream);
+int doda_bn_relu_bwd_totals(const void *x, const void *dy, int32_t m, int32_t c, int32_t elem_bytes, const double *totals,
+                            const float *save_mean, const float *save_invstd, const float *gamma, const float *beta,
+                            int32_t relu, const void *add, int32_t add_ld, void *dx, float *dgamma, float *dbeta,
+                            doda_stream_t stream);
 /* ABI 6.  The apply half alone: y = relu?((x - mean) * invstd * gamma + beta) with given per-channel vectors (e.g. from two
  * doda_bn_fwd_final calls over the two halves of a channel concatenation, whose statistics rows come from the two convs
  * that produced the halves — reference model/unet_block.py:93 followed by :23). */

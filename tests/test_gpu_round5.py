@@ -1,0 +1,160 @@
+"""Round 5 / ABI 9: BatchNorm statistics of the conv epilogues as fp64 TOTALS (doda_conv_epilogue.stats_totals: hardware fp64
+atomics into 8 x 2 x nc doubles) and the one-launch BatchNorm over them (doda_bn_relu_fwd_totals / _bwd_totals), against the
+per-workgroup rows + reduction launch they replace (reference: torch.nn.BatchNorm1d + ReLU applied by SparseSequential,
+model/unet_block.py:23-30,46-49; spconv indice_conv, model/unet_block.py:26,29)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def scene(oracle):
+    from tests.test_gpu_round4 import _big_scene, _hip_rulebook
+    idx, shape, batch, pairs, pn = _big_scene(oracle)
+    tbl, tb = _hip_rulebook(idx, shape, batch, pairs, pn)
+    return idx.shape[0], tbl, tb
+
+
+@pytest.mark.parametrize("cin,cout,tiled", [(16, 16, True), (32, 32, True), (16, 16, False), (64, 32, False), (48, 48, False)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_epilogue_totals_equal_the_sum_of_the_epilogue_rows(native_lib, scene, cin, cout, tiled, dtype):
+    """Same call, statistics once as rows and once as totals: y bit-equal, and the totals (summed over their eight slots)
+    equal the fp64 sum of the rows to fp64 rounding — for the tile kernels (conv_tile16 / conv_tile with 1250 tiles, incl. tiles
+    without a list), conv_fast and conv_wlds48; forward sums and, with the BatchNorm operands, the backward sums of a
+    data-gradient call.  Also against the fp64 column sums of the stored output."""
+    from doda_amd import ops
+    if tiled and dtype != torch.bfloat16:
+        pytest.skip("tile kernels: bf16 rows")
+    n, tbl, tb = scene
+    d = dev()
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = torch.randn(n, cin, generator=g).to(dtype).to(d)
+    w = (torch.randn(27, cin, cout, generator=g) * 0.1).to(d)
+    res = torch.randn(n, cout, generator=g).to(dtype).to(d)
+    kw = dict(tilebook=tb if tiled else None, residual=res)
+    y0, rows = ops.spconv_gather(x, w, tbl, n, 0, cout, want_stats=True, **kw)
+    y1, tot = ops.spconv_gather(x, w, tbl, n, 0, cout, want_stats="totals", **kw)
+    assert torch.equal(y0, y1) and tot.dtype == torch.float64 and tuple(tot.shape) == (8, 2, cout)
+    want = rows.double().sum(0)
+    got = tot.sum(0)
+    assert float((got - want).abs().max()) <= 1e-12 * float(want.abs().max())
+    col = y1.double()
+    ref = torch.stack([col.sum(0), (col * col).sum(0)])
+    assert float((got - ref).abs().max()) <= (2e-3 if dtype == torch.bfloat16 else 2e-5) * float(ref.abs().max())
+    # accumulating into totals that already hold something: the sums add
+    y2, tot2 = ops.spconv_gather(x, w, tbl, n, 0, cout, want_stats=tot.clone(), **kw)
+    assert float((tot2.sum(0) - 2 * want).abs().max()) <= 1e-12 * float(want.abs().max())
+    # backward sums (sum dz, sum dz * xhat) of a data-gradient call
+    bx = torch.randn(n, cin, generator=g).to(dtype).to(d)
+    mean = torch.randn(cin, generator=g).to(d) * 0.1
+    invstd = (torch.rand(cin, generator=g) + 0.5).to(d)
+    gamma = (torch.rand(cin, generator=g) + 0.5).to(d)
+    beta = (torch.randn(cin, generator=g) * 0.1).to(d)
+    dy = torch.randn(n, cout, generator=g).to(dtype).to(d)
+    wb = (torch.randn(27, cout, cin, generator=g) * 0.1).to(d)
+    kwb = dict(tilebook=tb if tiled else None, bn=(bx, mean, invstd, gamma, beta, True))
+    d0, rows_b = ops.spconv_gather(dy, wb, tbl, n, 0, cin, want_stats=True, **kwb)
+    d1, tot_b = ops.spconv_gather(dy, wb, tbl, n, 0, cin, want_stats="totals", **kwb)
+    assert torch.equal(d0, d1)
+    want_b = rows_b.double().sum(0)
+    assert float((tot_b.sum(0) - want_b).abs().max()) <= 1e-12 * float(want_b.abs().max()) + 1e-300
+
+
+@pytest.mark.parametrize("c", [16, 32, 64, 96])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_batchnorm_over_totals_equals_batchnorm_over_rows(native_lib, c, dtype):
+    """doda_bn_relu_fwd_totals / _bwd_totals against doda_bn_relu_fwd_stats / _bwd_stats on statistics of the same tensor: the
+    totals are the rows' fp64 sums spread over eight slots, so mean / invstd / running statistics / dgamma / dbeta and the swept
+    tensors must be bit-equal; a channel concatenation (two producers) against the two-reductions + apply sequence; the strided
+    second-gradient operand."""
+    from doda_amd import ops
+    d = dev()
+    m = 70001
+    g = torch.Generator().manual_seed(c)
+    x = (torch.randn(m, c, generator=g) * 2 + 0.3).to(dtype).to(d)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(d)
+    beta = (torch.randn(c, generator=g) * 0.1).to(d)
+    xs = x.float()
+    parts = 37
+    edges = torch.linspace(0, m, parts + 1).long()
+    rows = torch.stack([torch.stack([xs[a:b].sum(0), (xs[a:b] * xs[a:b]).sum(0)]) for a, b in zip(edges[:-1], edges[1:])])   # [37, 2, c] fp32
+    tot = torch.zeros(8, 2, c, dtype=torch.float64, device=d)
+    for k in range(parts):
+        tot[k % 8] += rows[k].double()
+
+    def buffers():
+        return torch.zeros(c, device=d), torch.ones(c, device=d), torch.zeros((), dtype=torch.int64, device=d)
+    rm0, rv0, nb0 = buffers()
+    rm1, rv1, nb1 = buffers()
+    mu0, is0 = ops.bn_fwd_final(rows.contiguous(), m, 1e-4, 0.1, rm0, rv0, nb0)     # (the reduction launch of the rows form)
+    y1, mu1, is1 = ops.bn_relu_fwd_totals(x, tot, gamma, beta, rm1, rv1, 0.1, 1e-4, True, nb1)
+    assert torch.equal(mu0, mu1) and torch.equal(is0, is1) and torch.equal(rm0, rm1) and torch.equal(rv0, rv1) and int(nb1) == 1
+    ref = torch.relu((xs - mu1) * is1 * gamma + beta)
+    assert float((y1.float() - ref).abs().max()) <= (2e-2 if dtype == torch.bfloat16 else 1e-5) * float(ref.abs().max())
+    # a concatenation [a | b]: two producers' totals
+    ca = c // 2 if (c // 2) % 4 == 0 else 16
+    if 0 < ca < c:
+        ta = tot[:, :, :ca].contiguous()
+        tb_ = tot[:, :, ca:].contiguous()
+        rm2, rv2, nb2 = buffers()
+        y2, mu2, is2 = ops.bn_relu_fwd_totals(x, ta, gamma, beta, rm2, rv2, 0.1, 1e-4, True, nb2, totals_b=tb_)
+        assert torch.equal(mu2, mu1) and torch.equal(is2, is1) and torch.equal(y2, y1) and torch.equal(rm2, rm1)
+    # backward
+    dy = torch.randn(m, c, generator=g).to(dtype).to(d)
+    xh = (xs - mu1) * is1
+    dz = torch.where(xh * gamma + beta > 0, dy.float(), torch.zeros((), device=d))
+    rows_b = torch.stack([torch.stack([dz[a:b].sum(0), (dz[a:b] * xh[a:b]).sum(0)]) for a, b in zip(edges[:-1], edges[1:])])
+    tot_b = torch.zeros(8, 2, c, dtype=torch.float64, device=d)
+    for k in range(parts):
+        tot_b[k % 8] += rows_b[k].double()
+    wide = torch.randn(m, 2 * c, generator=g).to(dtype).to(d)
+    for add in (None, torch.randn(m, c, generator=g).to(dtype).to(d), wide[:, c:]):
+        dx0, dg0, db0 = ops.bn_relu_bwd_stats(x, dy, rows_b.contiguous(), mu1, is1, gamma, beta, True, add=add)
+        dx1, dg1, db1 = ops.bn_relu_bwd_totals(x, dy, tot_b, mu1, is1, gamma, beta, True, add=add)
+        assert torch.equal(dg0, dg1) and torch.equal(db0, db1) and torch.equal(dx0, dx1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_unet_step_with_totals_equals_the_step_with_rows(native_lib, dtype):
+    """The U-Net training step with the statistics as totals (default) against rows + reduction launches: the statistics differ
+    at most by fp64 rounding of their totals, so loss and every parameter gradient agree to fp32 accumulation noise; and the step
+    launches fewer kernels."""
+    from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
+    from doda_amd.scene import make_batch
+    from doda_amd.spconv import functional as Fsp
+    from tests.util import deterministic_init
+    ext = Fsp._ext
+    if ext is None or not hasattr(ext, "set_stats_totals"):
+        pytest.skip("extension without the totals switch")
+    d = dev()
+    cfg = default_cfg()
+    b = make_batch(2, 60000, 31)
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in b.items()}
+    got = {}
+    was = ext.get_stats_totals()
+    assert Fsp.set_deferred_wgrad(True)
+    try:
+        for on in (True, False):
+            ext.set_stats_totals(on)
+            net = deterministic_init(SparseConvNet(cfg), seed=6).to(d).train()
+            loss = cross_entropy(voxelize_and_run(cfg, net, bd, d, feature_dtype=dtype), bd["labels"], ignore_index=255)
+            loss.backward()
+            torch.cuda.synchronize()
+            got[on] = (float(loss), {k: p.grad.detach().float().clone() for k, p in net.named_parameters()},
+                       {k: v.detach().clone() for k, v in net.named_buffers()})
+    finally:
+        ext.set_stats_totals(was)
+        Fsp.set_deferred_wgrad(False)
+    (l1, g1, b1), (l0, g0, b0) = got[True], got[False]
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    assert abs(l0 - l1) <= 1e-5 * abs(l0) + (1e-3 if dtype == torch.bfloat16 else 0.0)
+    for k, a in g0.items():
+        assert float((a - g1[k]).norm()) <= tol * float(a.norm()) + 1e-7, k
+    for k, a in b0.items():
+        assert float((a.double() - b1[k].double()).abs().max()) <= 1e-5 * float(a.double().abs().max()) + 1e-6, k
