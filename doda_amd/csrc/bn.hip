@@ -176,9 +176,9 @@ __device__ __forceinline__ void tot_sums(const TotArgs &t, int c, int ch, double
     const int cw = first ? t.ca : c - t.ca, cc = first ? ch : ch - t.ca;
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < BN_TOT_SLOTS; ++k) {
-        s1 += src[(size_t)k * 2 * cw + cc];
-        s2 += src[(size_t)k * 2 * cw + cw + cc];
+    for (int k = 0; k < BN_TOT_SLOTS; ++k) {      // (layout: spconv_common.hpp stats_emit — a 128-byte line per four channels)
+        s1 += src[((size_t)(k * 2 + 0) * (cw / 4) + cc / 4) * 16 + (cc & 3)];
+        s2 += src[((size_t)(k * 2 + 1) * (cw / 4) + cc / 4) * 16 + (cc & 3)];
     }
 }
 __device__ __forceinline__ void tot_fwd_prologue(const TotArgs &t, int c, float *v_mu, float *v_is) {

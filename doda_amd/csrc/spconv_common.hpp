@@ -100,7 +100,7 @@ struct EpiArgs {   // plain data, shared across translation units
     int bn_relu;
     int res_bcast;           // ABI 6: `res` is ONE row [nc] added to every output row (a bias): conv_fast only
     int f32_split;           // round 5: fp32 units as two bf16 MFMAs on head / tail splits (mma_f32_k16); set by run_gather
-    double *stats_tot;       // ABI 9: [DODA_STATS_SLOTS][2][nc] totals, accumulated with fp64 atomics INSTEAD of the rows, or null
+    double *stats_tot;       // ABI 9: [DODA_STATS_SLOTS][2][nc / 4][16] totals (4 of 16 used), accumulated with fp64 atomics INSTEAD of the rows, or null
 };
 #ifndef DODA_STATS_SLOTS
 #define DODA_STATS_SLOTS 8      // (include/doda_hip.h)
@@ -113,11 +113,16 @@ struct EpiArgs {   // plain data, shared across translation units
 // from the totals are fp32.
 __device__ __forceinline__ void stats_emit(const EpiArgs &ep, long long part, int nc, int col, const f32x4 &a1, const f32x4 &a2) {
     if (ep.stats_tot) {
-        double *t = ep.stats_tot + (size_t)((unsigned)part & (unsigned)(DODA_STATS_SLOTS - 1)) * 2 * nc + col;
+// (layout: every group of four channels of a (slot, sum) pair owns a 128-byte line — 16 doubles, the first four used.
+        // With the 2 x nc doubles of a slot packed, the 64 workgroups of a slot sent ~1000 atomics to each line and the L2
+        // serialised them: +1.7 us at the end of conv_tile16; padded, the kernel is as fast as with rows.)
+        const size_t k = (size_t)((unsigned)part & (unsigned)(DODA_STATS_SLOTS - 1));
+        double *t1 = ep.stats_tot + ((k * 2 + 0) * (size_t)(nc / 4) + (size_t)(col / 4)) * 16;
+        double *t2 = ep.stats_tot + ((k * 2 + 1) * (size_t)(nc / 4) + (size_t)(col / 4)) * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            unsafeAtomicAdd(t + q, (double)a1[q]);
-            unsafeAtomicAdd(t + nc + q, (double)a2[q]);
+            unsafeAtomicAdd(t1 + q, (double)a1[q]);
+            unsafeAtomicAdd(t2 + q, (double)a2[q]);
         }
     } else {
         float *dst = ep.stats + part * 2 * nc + col;

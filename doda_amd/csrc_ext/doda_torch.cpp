@@ -104,13 +104,13 @@ void build_tilebook(const at::Tensor &tbl, void *st) {
 }
 
 // BatchNorm statistics as fp64 TOTALS (ABI 9, doda_conv_epilogue.stats_totals): the conv epilogues add their workgroups' sums
-// into 8 x 2 x nc doubles and the BatchNorm that follows derives its vectors from them inside its own sweep — the `final`
+// into DODA_STATS_TOTALS_DOUBLES(nc) doubles and the BatchNorm that follows derives its vectors from them inside its own sweep — the `final`
 // reduction launches (52 per U-Net step) are gone.  The totals of a pass come out of ONE zeroed arena (one memset per forward
 // pass instead of one per conv): a slice per statistics-producing call, forward and backward.  A slice is handed out once:
-// the arena only grows, and a full one is replaced by a fresh zeroed buffer (one 4 MB memset every several steps; slices still
+// the arena only grows, and a full one is replaced by a fresh zeroed buffer (one 8 MB memset every two or three steps; slices still
 // referenced keep the old storage alive).
 bool g_stats_totals = [] { const char *e = getenv("DODA_STATS_TOTALS"); return !(e && e[0] == '0'); }();
-constexpr int64_t TOT_ARENA_DOUBLES = 512 * 1024;      // 4 MB: ~250 slices of 64 channels
+constexpr int64_t TOT_ARENA_DOUBLES = 1024 * 1024;     // 8 MB: 64 x nc doubles per slice (512 slices of 32 channels)
 std::mutex g_tot_mu;
 at::Tensor g_tot_buf;
 int64_t g_tot_used = 0;
@@ -120,19 +120,19 @@ void stats_totals_begin_pass() {
     g_tot_used = 0;
 }
 at::Tensor stats_totals_take(int64_t nc, const at::TensorOptions &like) {
-    const int64_t n = (int64_t)DODA_STATS_SLOTS * 2 * nc;
+    const int64_t n = (int64_t)DODA_STATS_TOTALS_DOUBLES(nc);
     std::lock_guard<std::mutex> lock(g_tot_mu);
     if (!g_tot_buf.defined() || g_tot_buf.device() != like.device() || g_tot_used + n > g_tot_buf.numel()) {
         g_tot_buf = at::zeros({n > TOT_ARENA_DOUBLES ? n : TOT_ARENA_DOUBLES}, like.dtype(at::kDouble));
         g_tot_used = 0;
     }
-    at::Tensor t = g_tot_buf.narrow(0, g_tot_used, n).view({(int64_t)DODA_STATS_SLOTS, 2, nc});
+    at::Tensor t = g_tot_buf.narrow(0, g_tot_used, n).view({(int64_t)DODA_STATS_SLOTS, 2, nc / 4, 16});
     g_tot_used += n;
     return t;
 }
 inline bool is_totals(const at::Tensor &st, int64_t c) {
-    return st.defined() && st.scalar_type() == at::kDouble && st.dim() == 3 && st.size(0) == DODA_STATS_SLOTS && st.size(1) == 2 &&
-           st.size(2) == c && st.is_contiguous();
+    return st.defined() && st.scalar_type() == at::kDouble && st.dim() == 4 && st.size(0) == DODA_STATS_SLOTS && st.size(1) == 2 &&
+           st.size(2) * 4 == c && st.size(3) == 16 && st.is_contiguous();
 }
 
 // y[t] = sum_o x[tbl[o][t]] . B_o   (include/doda_hip.h: doda_spconv_gather_ex)
@@ -1061,12 +1061,12 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
             invstd = at::rsqrt(running_var.to(at::kFloat) + eps).contiguous();
         }
         if (training && m > BN_SMALL_ROWS && c <= 256 && stats.defined() && stats.scalar_type() == at::kDouble &&
-            (stats_b.defined() ? (stats.dim() == 3 && stats_b.dim() == 3 && is_totals(stats, stats.size(2)) &&
-                                  is_totals(stats_b, c - stats.size(2)) && stats.size(2) > 0 && stats.size(2) < c)
+            (stats_b.defined() ? (stats.dim() == 4 && stats_b.dim() == 4 && is_totals(stats, stats.size(2) * 4) &&
+                                  is_totals(stats_b, c - stats.size(2) * 4) && stats.size(2) > 0 && stats.size(2) * 4 < c)
                                : is_totals(stats, c))) {
             // ABI 9: statistics as totals — ONE launch, also for a channel concatenation [a | b] (two producers)
             check(doda_bn_relu_fwd_totals(x.data_ptr(), (int)m, (int)c, esz, (const double *)stats.data_ptr(),
-                                          stats_b.defined() ? (const double *)stats_b.data_ptr() : nullptr, (int)stats.size(2),
+                                          stats_b.defined() ? (const double *)stats_b.data_ptr() : nullptr, (int)stats.size(2) * 4,
                                           (float)eps, (float)momentum, (const float *)weight.data_ptr(),
                                           (const float *)bias.data_ptr(), (float *)running_mean.data_ptr(),
                                           (float *)running_var.data_ptr(), nbt.defined() ? (int64_t *)nbt.data_ptr() : nullptr,

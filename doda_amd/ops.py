@@ -290,6 +290,26 @@ def _feat_ok(x, name):
 STATS_SLOTS = 8     # DODA_STATS_SLOTS
 
 
+def totals_zeros(nc, device):
+    """Zeroed fp64 totals for nc channels in the library's layout (doda_conv_epilogue.stats_totals): [8 slots, 2 sums, nc / 4
+    groups, 16] — a 128-byte line per four channels, the first four doubles of a group used."""
+    return torch.zeros((STATS_SLOTS, 2, nc // 4, 16), dtype=torch.float64, device=device)
+
+
+def totals_sums(totals):
+    """[2, nc] float64: the totals summed over their slots."""
+    return totals[..., :4].sum(0).reshape(2, -1)
+
+
+def totals_from_rows(rows):
+    """The totals that epilogue rows [n, 2, nc] (fp32) add up to, row k in slot k mod 8 (tests)."""
+    n, _, nc = rows.shape
+    t = totals_zeros(nc, rows.device)
+    for k in range(n):
+        t[k % STATS_SLOTS, :, :, :4] += rows[k].double().view(2, nc // 4, 4)
+    return t
+
+
 class _ConvEpilogue(C.Structure):   # doda_conv_epilogue (include/doda_hip.h, ABI 9)
     _fields_ = [("residual", C.c_void_p), ("stats", C.c_void_p), ("stats_rows_h", C.POINTER(C.c_int32)),
                 ("bn_x", C.c_void_p), ("bn_mean", C.c_void_p), ("bn_invstd", C.c_void_p), ("bn_gamma", C.c_void_p),
@@ -371,9 +391,9 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
     stats, rows = None, C.c_int32(0)
     totals = None
     if want_stats == "totals" or torch.is_tensor(want_stats):   # ABI 9: fp64 totals [8, 2, nc] (a tensor: accumulate into it)
-        totals = want_stats if torch.is_tensor(want_stats) else torch.zeros((STATS_SLOTS, 2, nc), dtype=torch.float64, device=x.device)
-        if totals.dtype != torch.float64 or tuple(totals.shape) != (STATS_SLOTS, 2, nc) or not totals.is_contiguous():
-            raise RuntimeError("spconv_gather: totals must be a contiguous float64 [8, 2, nc] tensor")
+        totals = want_stats if torch.is_tensor(want_stats) else totals_zeros(nc, x.device)
+        if totals.dtype != torch.float64 or tuple(totals.shape) != (STATS_SLOTS, 2, nc // 4, 16) or not totals.is_contiguous():
+            raise RuntimeError("spconv_gather: totals must be a contiguous float64 [8, 2, nc / 4, 16] tensor (totals_zeros)")
         ep.stats_totals = _p(totals)
     if want_stats is not False and want_stats is not None:
         stats = torch.empty((int(lib().doda_spconv_stats_capacity(n_out)) if totals is None else 1, 2, nc), dtype=torch.float32,
@@ -682,7 +702,7 @@ def bn_relu_fwd_totals(x, totals, gamma, beta, running_mean, running_var, moment
     _feat_ok(x, "x")
     _need_cuda(totals)
     m, c = x.shape
-    c_a = int(totals.shape[2])
+    c_a = int(totals.shape[2]) * 4
     y = torch.empty_like(x)
     save_mean = torch.empty(c, dtype=torch.float32, device=x.device)
     save_invstd = torch.empty(c, dtype=torch.float32, device=x.device)

@@ -238,7 +238,8 @@ typedef struct doda_conv_epilogue {
     const void *tilebook;    /* ABI 3: doda_tilebook_build of `tbl`, or NULL */
     int32_t residual_bcast;   /* ABI 6: `residual` is ONE row [nc] (dtype of y) added to every output row — a bias (the Linear
                                * head of reference model/unet.py:64 as a gather-GEMM); dense-table kernels only */
-    double *stats_totals;     /* ABI 9: with `stats`: DODA_STATS_SLOTS x 2 x nc doubles, ZERO on entry (or holding the sums of
+    double *stats_totals;     /* ABI 9: with `stats`: DODA_STATS_TOTALS_DOUBLES(nc) doubles — DODA_STATS_SLOTS x 2 x nc / 4 groups of 16
+                               * (a 128-byte line per four channels; the first four doubles of a group are used) —, ZERO on entry (or holding the sums of
                                * other calls over the same rows), to which the kernel's workgroups ADD their (sum, sum of squares)
                                * with fp64 atomics instead of writing rows into `stats` (which must still be non-NULL: it selects
                                * the statistics epilogue, nothing is written there).  Feed them to doda_bn_relu_fwd_totals /
@@ -247,6 +248,7 @@ typedef struct doda_conv_epilogue {
                                * ~2^16, and then differs between runs by an ulp of fp64 — the statistics are rounded to fp32. */
 } doda_conv_epilogue;
 #define DODA_STATS_SLOTS 8
+#define DODA_STATS_TOTALS_DOUBLES(nc) ((size_t)DODA_STATS_SLOTS * 2 * 16 * ((size_t)(nc) / 4))
 /* ABI 3.  Tile-local form of a SubM gather table ("tilebook") for the LDS-staged convolution kernel:
  * per tile of doda_tilebook_tile() consecutive output rows, the sorted list of DISTINCT input rows the
  * tile's K x tile table entries reference and, per entry, its position in that list.  The kernel loads
@@ -405,8 +407,8 @@ int doda_bn_relu_bwd_stats(const void *x, const void *dy, int32_t m, int32_t c, 
                            float *coef_ws, doda_stream_t stream);   /* add / add_ld as doda_bn_relu_bwd_add; add may be NULL */
 /* ABI 9.  The same two operators over TOTALS (doda_conv_epilogue.stats_totals) — reference torch.nn.BatchNorm1d + ReLU applied by
  * SparseSequential (model/unet_block.py:23-30,46-49), ONE launch each: every workgroup of the sweep derives the per-channel
- * vectors from the DODA_STATS_SLOTS x 2 x c totals itself.  totals_b / c_a (forward): the columns [c_a, c) of x come from a second
- * producer with its own totals (DODA_STATS_SLOTS x 2 x (c - c_a)) — the U-Net level's concatenation (unet_block.py:93); NULL: one
+ * vectors from the DODA_STATS_TOTALS_DOUBLES(c) totals itself.  totals_b / c_a (forward): the columns [c_a, c) of x come from a second
+ * producer with its own totals (DODA_STATS_TOTALS_DOUBLES(c - c_a)) — the U-Net level's concatenation (unet_block.py:93); NULL: one
  * producer.  c <= 256. */
 int doda_bn_relu_fwd_totals(const void *x, int32_t m, int32_t c, int32_t elem_bytes, const double *totals,
                             const double *totals_b, int32_t c_a, float eps, float momentum, const float *gamma,

@@ -1,5 +1,5 @@
 """Round 5 / ABI 9: BatchNorm statistics of the conv epilogues as fp64 TOTALS (doda_conv_epilogue.stats_totals: hardware fp64
-atomics into 8 x 2 x nc doubles) and the one-launch BatchNorm over them (doda_bn_relu_fwd_totals / _bwd_totals), against the
+atomics into 8 slots x 2 sums x nc / 4 padded groups of doubles) and the one-launch BatchNorm over them (doda_bn_relu_fwd_totals / _bwd_totals), against the
 per-workgroup rows + reduction launch they replace (reference: torch.nn.BatchNorm1d + ReLU applied by SparseSequential,
 model/unet_block.py:23-30,46-49; spconv indice_conv, model/unet_block.py:26,29)."""
 import numpy as np
@@ -40,16 +40,17 @@ def test_epilogue_totals_equal_the_sum_of_the_epilogue_rows(native_lib, scene, c
     kw = dict(tilebook=tb if tiled else None, residual=res)
     y0, rows = ops.spconv_gather(x, w, tbl, n, 0, cout, want_stats=True, **kw)
     y1, tot = ops.spconv_gather(x, w, tbl, n, 0, cout, want_stats="totals", **kw)
-    assert torch.equal(y0, y1) and tot.dtype == torch.float64 and tuple(tot.shape) == (8, 2, cout)
+    assert torch.equal(y0, y1) and tot.dtype == torch.float64 and tuple(tot.shape) == (8, 2, cout // 4, 16)
+    assert float(tot[..., 4:].abs().max()) == 0.0            # (the padding of the 128-byte lines stays untouched)
     want = rows.double().sum(0)
-    got = tot.sum(0)
+    got = ops.totals_sums(tot)
     assert float((got - want).abs().max()) <= 1e-12 * float(want.abs().max())
     col = y1.double()
     ref = torch.stack([col.sum(0), (col * col).sum(0)])
     assert float((got - ref).abs().max()) <= (2e-3 if dtype == torch.bfloat16 else 2e-5) * float(ref.abs().max())
     # accumulating into totals that already hold something: the sums add
     y2, tot2 = ops.spconv_gather(x, w, tbl, n, 0, cout, want_stats=tot.clone(), **kw)
-    assert float((tot2.sum(0) - 2 * want).abs().max()) <= 1e-12 * float(want.abs().max())
+    assert float((ops.totals_sums(tot2) - 2 * want).abs().max()) <= 1e-12 * float(want.abs().max())
     # backward sums (sum dz, sum dz * xhat) of a data-gradient call
     bx = torch.randn(n, cin, generator=g).to(dtype).to(d)
     mean = torch.randn(cin, generator=g).to(d) * 0.1
@@ -63,7 +64,7 @@ def test_epilogue_totals_equal_the_sum_of_the_epilogue_rows(native_lib, scene, c
     d1, tot_b = ops.spconv_gather(dy, wb, tbl, n, 0, cin, want_stats="totals", **kwb)
     assert torch.equal(d0, d1)
     want_b = rows_b.double().sum(0)
-    assert float((tot_b.sum(0) - want_b).abs().max()) <= 1e-12 * float(want_b.abs().max()) + 1e-300
+    assert float((ops.totals_sums(tot_b) - want_b).abs().max()) <= 1e-12 * float(want_b.abs().max()) + 1e-300
 
 
 @pytest.mark.parametrize("c", [16, 32, 64, 96])
@@ -84,9 +85,7 @@ def test_batchnorm_over_totals_equals_batchnorm_over_rows(native_lib, c, dtype):
     parts = 37
     edges = torch.linspace(0, m, parts + 1).long()
     rows = torch.stack([torch.stack([xs[a:b].sum(0), (xs[a:b] * xs[a:b]).sum(0)]) for a, b in zip(edges[:-1], edges[1:])])   # [37, 2, c] fp32
-    tot = torch.zeros(8, 2, c, dtype=torch.float64, device=d)
-    for k in range(parts):
-        tot[k % 8] += rows[k].double()
+    tot = ops.totals_from_rows(rows)
 
     def buffers():
         return torch.zeros(c, device=d), torch.ones(c, device=d), torch.zeros((), dtype=torch.int64, device=d)
@@ -100,8 +99,8 @@ def test_batchnorm_over_totals_equals_batchnorm_over_rows(native_lib, c, dtype):
     # a concatenation [a | b]: two producers' totals
     ca = c // 2 if (c // 2) % 4 == 0 else 16
     if 0 < ca < c:
-        ta = tot[:, :, :ca].contiguous()
-        tb_ = tot[:, :, ca:].contiguous()
+        ta = tot[:, :, :ca // 4].contiguous()
+        tb_ = tot[:, :, ca // 4:].contiguous()
         rm2, rv2, nb2 = buffers()
         y2, mu2, is2 = ops.bn_relu_fwd_totals(x, ta, gamma, beta, rm2, rv2, 0.1, 1e-4, True, nb2, totals_b=tb_)
         assert torch.equal(mu2, mu1) and torch.equal(is2, is1) and torch.equal(y2, y1) and torch.equal(rm2, rm1)
@@ -110,9 +109,7 @@ def test_batchnorm_over_totals_equals_batchnorm_over_rows(native_lib, c, dtype):
     xh = (xs - mu1) * is1
     dz = torch.where(xh * gamma + beta > 0, dy.float(), torch.zeros((), device=d))
     rows_b = torch.stack([torch.stack([dz[a:b].sum(0), (dz[a:b] * xh[a:b]).sum(0)]) for a, b in zip(edges[:-1], edges[1:])])
-    tot_b = torch.zeros(8, 2, c, dtype=torch.float64, device=d)
-    for k in range(parts):
-        tot_b[k % 8] += rows_b[k].double()
+    tot_b = ops.totals_from_rows(rows_b)
     wide = torch.randn(m, 2 * c, generator=g).to(dtype).to(d)
     for add in (None, torch.randn(m, c, generator=g).to(dtype).to(d), wide[:, c:]):
         dx0, dg0, db0 = ops.bn_relu_bwd_stats(x, dy, rows_b.contiguous(), mu1, is1, gamma, beta, True, add=add)

@@ -205,10 +205,11 @@ def test_tile_kernel_statistics_epilogue(native_lib):
     # one statistics row per persistent workgroup (<= 768; round 2: one per tile)
     assert s1 is not None and 1 <= s1.shape[0] <= min(768, ((n + 255) // 256 + 7) // 8 * 8)
     assert (y0 != y1).float().mean().item() < 0.02
-    assert rel_err(s1.double().sum(0).cpu(), s0.double().sum(0).cpu()) < 1e-3
+    from tests.util import stats_sums
+    assert rel_err(stats_sums(s1).cpu(), stats_sums(s0).cpu()) < 1e-3
     yf = y1.detach().double()
-    assert rel_err(s1.double().sum(0)[0].cpu(), yf.sum(0).cpu()) < 1e-5
-    assert rel_err(s1.double().sum(0)[1].cpu(), (yf * yf).sum(0).cpu()) < 1e-5
+    assert rel_err(stats_sums(s1)[0].cpu(), yf.sum(0).cpu()) < 1e-5
+    assert rel_err(stats_sums(s1)[1].cpu(), (yf * yf).sum(0).cpu()) < 1e-5
     # BatchNorm -> ReLU -> conv, backward through the data-grad statistics
     bn = torch.nn.BatchNorm1d(16, eps=1e-4).to(d).train()
     with torch.no_grad():
@@ -332,7 +333,8 @@ def test_weights_in_lds_kernel_48_channels(native_lib, m, layout):
     with torch.no_grad():
         yy, st = ext.indice_conv_stats(x, wt, tbl, tbl, n, 2, None, None, res)
     # (rows of the launch, or — ABI 9, the default — the fp64 totals [8, 2, c] its workgroups added their sums to)
+    from tests.util import stats_sums
     assert st is not None and (st.shape[0] == (n + 255) // 256 or (st.dtype == torch.float64 and st.shape[0] == 8))
     yf = yy.double()
-    assert rel_err(st.double().sum(0)[0].cpu(), yf.sum(0).cpu()) < 1e-5
-    assert rel_err(st.double().sum(0)[1].cpu(), (yf * yf).sum(0).cpu()) < 1e-5
+    assert rel_err(stats_sums(st)[0].cpu(), yf.sum(0).cpu()) < 1e-5
+    assert rel_err(stats_sums(st)[1].cpu(), (yf * yf).sum(0).cpu()) < 1e-5

@@ -57,3 +57,11 @@ def deterministic_init(model, seed=0):
                 fan_in = t.shape[-2] * (t.numel() // (t.shape[-1] * t.shape[-2])) if t.dim() == 5 else t.shape[1]
                 t.copy_(torch.randn(t.shape, generator=g) * (1.5 / max(fan_in, 1)) ** 0.5)
     return model
+
+
+def stats_sums(st):
+    """[2, c] float64 sums of a conv epilogue's BatchNorm statistics in either form the extension hands out: rows
+    [n, 2, c] fp32 (one per workgroup) or — ABI 9, the default — fp64 totals [8, 2, c / 4, 16] (doda_amd.ops.totals_sums)."""
+    if st.dim() == 4:
+        return st[..., :4].sum(0).reshape(2, -1)
+    return st.double().sum(0)

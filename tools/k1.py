@@ -4,6 +4,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+if os.environ.get("K1_LIB"):      # a variant build of the library (experiments)
+    from doda_amd import _lib
+    _lib.LIB_PATH = os.environ["K1_LIB"]
 from doda_amd import ops, spconv
 from doda_amd.scene import make_batch
 dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
@@ -34,6 +37,11 @@ for _ in range(reps):
     elif which == "dgrad": ops.spconv_gather(gy, None, sub.tbl, m, 2, c, packed=plan.outputs[1], tilebook=tb)
     elif which == "fwdstep":   # the instantiation the training step launches: statistics + residual in the epilogue
         ops.spconv_gather(x, None, sub.tbl, m, 0, c, packed=plan.outputs[0], tilebook=tb, residual=res, want_stats=True)
+    elif which == "fwdtot":    # ... with the statistics as fp64 totals (ABI 9: what the step launches by default)
+        if "big_tot" not in globals():
+            big_tot = torch.zeros(4 * 8 * 2 * c, dtype=torch.float64, device=dev)      # (room for a padded-layout experiment)
+        ops.spconv_gather(x, None, sub.tbl, m, 0, c, packed=plan.outputs[0], tilebook=tb, residual=res,
+                          want_stats=big_tot[:8 * 2 * c].view(8, 2, c))
     elif which == "wgradt": ops.spconv_wgrad_multi([(x, gy, sub.tbl, m, None, None, tb)] * 8)   # LDS-staged tile kernel, 8 layers per call
     elif which == "wgradp": ops.spconv_wgrad_multi([(x, gy, sub.tbl, m, pairs)] * 8)   # pair-list kernel, 8 layers per call
     else: ops.spconv_wgrad_multi([(x, gy, sub.tbl, m)] * 8)                              # gather-table kernel
