@@ -153,6 +153,9 @@ def _subm16_times(idx, shape, nb, dtype, reps):
     # prepared calls (ops.GatherCall: one native call per launch, the host cost of the extension's call sites): the Python
     # wrapper around doda_spconv_gather_ex takes longer than the 9 us kernels of one 150k scene on a busy host
     calls = {}
+    # the statistics form the step launches: fp64 totals (ABI 9, default) or per-workgroup rows
+    _e = spconv.functional._ext
+    stats_form = "totals" if (_e is not None and hasattr(_e, "get_stats_totals") and _e.get_stats_totals()) else True
 
     def call(name, st, step):
         key = (name, id(st), step)
@@ -160,9 +163,10 @@ def _subm16_times(idx, shape, nb, dtype, reps):
         if c is None:
             if name == "fwd":
                 c = ops.GatherCall(st.x, None, st.tbl, m, 0, 16, packed=pk_f, tilebook=st.tb, out=st.y,
-                                   residual=st.res if step else None, want_stats=step)
+                                   residual=st.res if step else None, want_stats=stats_form if step else False)
             else:
-                c = ops.GatherCall(st.gy, None, st.tbl, m, 2, 16, packed=pk_d, tilebook=st.tb, out=st.y, want_stats=step,
+                c = ops.GatherCall(st.gy, None, st.tbl, m, 2, 16, packed=pk_d, tilebook=st.tb, out=st.y,
+                                   want_stats=stats_form if step else False,
                                    bn=(st.x, mean, invstd, gamma, beta, True) if step else None)
             calls[key] = c
             return

@@ -354,7 +354,9 @@ def spconv_gather(x, w, tbl, n_out, w_layout, nc, out_f32=False, packed=None, re
     float32 when out_f32); with `residual` ([n_out, nc], dtype of y) returns conv + residual.
     want_stats: returns (y, stats [rows, 2, nc] fp32): the BatchNorm partial sums of the epilogue
     (doda_conv_epilogue.stats) — (sum y, sum y^2), or with bn = (bn_x, mean, invstd, gamma, beta, relu) the
-    BatchNorm-backward sums of a data-grad call.  out: write into this tensor instead of allocating."""
+    BatchNorm-backward sums of a data-grad call.  want_stats = "totals" (or a totals tensor to accumulate into): the
+    sums as fp64 totals instead (ABI 9, doda_conv_epilogue.stats_totals; totals_zeros / totals_sums), returns (y, totals).
+    out: write into this tensor instead of allocating."""
     _feat_ok(x, "x")
     _need_cuda(tbl)
     K, ld = tbl.shape
