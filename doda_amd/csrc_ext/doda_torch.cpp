@@ -371,7 +371,12 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
         check(doda_rulebook_down2_tables((const int32_t *)parent.data_ptr(), (const int32_t *)off.data_ptr(), m, m_out,
                                          (int32_t *)child.data_ptr(), m_out, (int32_t *)par_off.data_ptr(), m, st),
               "doda_rulebook_down2_tables");
-        if (with_pairs) std::tie(dp, dn, dh) = export_pairs(par_off, m, false, st);
+        // (round 5) the strided rulebooks' lists are no longer exported by default: since the SubM layers of levels 1-2 take the
+        // tile weight gradient, the only consumers left were the six k2 s2 / inverse layers of levels 1-3, and the export (three
+        // launches per rulebook on the rulebook stream, 230 us per step) cost four times what the pair-list kernels saved over
+        // the gather-table kernel (54 us): 5.2-5.6 -> 5.0 ms per step in alternating runs (tools/pairs_ab.sh).
+        static const bool down_pairs = [] { const char *e = getenv("DODA_WGRAD_PAIRS_DOWN"); return e && e[0] == '1'; }();
+        if (with_pairs && down_pairs) std::tie(dp, dn, dh) = export_pairs(par_off, m, false, st);
         std::vector<int64_t> oshape = {(shape[0] - 2) / 2 + 1, (shape[1] - 2) / 2 + 1, (shape[2] - 2) / 2 + 1};
         at::Tensor outids = out_idx.narrow(0, 0, m_out);
         out.emplace_back(nbr, outids, child, par_off, oshape, sp, sn, sh, dp, dn, dh);

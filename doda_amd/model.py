@@ -174,10 +174,11 @@ class ResidualBlock(SparseModule):
                     return None
         n_out = data.outids.shape[0]
         w1, w2 = c1._parameters["weight"], c2._parameters["weight"]
-        if Fsp._want_pairs(feats, w1) and Fsp._want_pairs(feats, w2):
-            p = data.wgrad_lists()
+        p1, p2 = Fsp._lists(data, feats, w1), Fsp._lists(data, feats, w2)
+        if p1 is not None and p2 is not None:
+            p = p1
             rb = [data.tbl, p[0], p[1], p[2], p[3] if len(p) > 3 else None]
-        elif Fsp._want_pairs(feats, w1) or Fsp._want_pairs(feats, w2):
+        elif p1 is not None or p2 is not None:
             return None
         else:
             rb = [data.tbl, None, None, None, None]

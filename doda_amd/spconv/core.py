@@ -5,6 +5,10 @@ import torch
 from .. import ops as _ops
 
 
+import os as _os
+_TRACE_PAIRS = _os.environ.get("DODA_TRACE_PAIRS", "0") == "1"
+
+
 class IndiceData:
     """Rulebook of one indice_key.
 
@@ -43,6 +47,11 @@ class IndiceData:
         once per rulebook (doda_rulebook_pairs without the -1 fill)."""
         if self._wpairs is None:
             n_in = self.indices.shape[0]
+            if _TRACE_PAIRS:
+                import sys
+                import traceback
+                sys.stderr.write("[doda] lazy pair-list export: kind %s, %d rows, inverse %s, from %s\n" % (
+                    self.kind, n_in, inverse, " <- ".join("%s:%d" % (f.name, f.lineno) for f in reversed(traceback.extract_stack(limit=6)[:-1]))))
             if self.kind == "subm":
                 self._wpairs = _ops.rulebook_pairs(self.tbl, n_in, flip=True, pad=False, with_seg=True)
             else:

@@ -162,6 +162,10 @@ def _conv(features, weight, fwd_tbl, bwd_tbl, n_out, bwd_layout, packed, residua
 WGRAD_PAIRS = os.environ.get("DODA_WGRAD_PAIRS", "1") == "1"
 
 
+# (round 5) lists of the STRIDED rulebooks (k2 s2 conv / inverse conv): off by default — once the SubM layers of levels 1-2 took
+# the tile weight gradient, these six layers were the only consumers left and the export of their lists (pairs_count / _scan /
+# _fill per rulebook: 230 us per step on the rulebook stream) cost four times what the pair-list kernels saved (54 us)
+WGRAD_PAIRS_DOWN = os.environ.get("DODA_WGRAD_PAIRS_DOWN", "0") == "1"
 PAIRS_MIN_ROWS = 65536   # smaller rulebooks stay on the gather-table kernel: the list export (three launches
 #                          per rulebook, issued by a host that is as busy as the GPU) would cost more than it saves
 
@@ -174,6 +178,22 @@ def _want_pairs(features, weight, n_rows=None):
             and (features.shape[0] if n_rows is None else n_rows) >= PAIRS_MIN_ROWS)
 
 
+def _lists(data, features, weight, inverse=False, n_rows=None):
+    """The rulebook's pair lists for a layer's weight gradient, or None: lists that already exist are used; a SubM rulebook
+    with a tilebook needs none (its layers take the tile weight gradient or the gather table) and a strided rulebook gets none
+    unless DODA_WGRAD_PAIRS_DOWN=1 — nothing is exported just in case (round 5: four such exports per step ran on the
+    step's own stream, 230 us of kernels and twelve launches, for jobs that did not read them)."""
+    if not _want_pairs(features, weight, n_rows):
+        return None
+    if data._wpairs is None:
+        if data.kind == "subm":
+            if _ext is not None and _ext.has_tilebook(data.tbl):
+                return None
+        elif not WGRAD_PAIRS_DOWN:
+            return None
+    return data.wgrad_lists(inverse=inverse)
+
+
 def conv1x1(features, weight, ident, packed=None, want_stats=False):
     """SubMConv3d(kernel_size=1) (upstream: features @ W.view(Cin,Cout)) as a K = 1 gather-GEMM over an
     identity table: the library GEMM picked for these skinny shapes ([600k,32] @ [32,16]) runs 5-10x
@@ -183,18 +203,18 @@ def conv1x1(features, weight, ident, packed=None, want_stats=False):
 
 
 def indice_subm_conv(features, weight, data, packed=None, residual=None, want_stats=False):
-    pairs = data.wgrad_lists() if _want_pairs(features, weight) else None
+    pairs = _lists(data, features, weight)
     return _conv(features, weight, data.tbl, data.tbl, data.outids.shape[0], 2, packed, residual, pairs, want_stats)
 
 
 def indice_conv(features, weight, data, packed=None, want_stats=False):
-    pairs = data.wgrad_lists() if _want_pairs(features, weight) else None
+    pairs = _lists(data, features, weight)
     return _conv(features, weight, data.tbl, data.tbl_rev, data.outids.shape[0], 1, packed, None, pairs, want_stats)
 
 
 def indice_inverse_conv(features, weight, data, packed=None, want_stats=False):
     # roles swapped: outputs live on the saved (fine) input indices of the strided conv
-    pairs = data.wgrad_lists(inverse=True) if _want_pairs(features, weight, data.indices.shape[0]) else None
+    pairs = _lists(data, features, weight, inverse=True, n_rows=data.indices.shape[0])
     return _conv(features, weight, data.tbl_rev, data.tbl, data.indices.shape[0], 1, packed, None, pairs, want_stats)
 
 

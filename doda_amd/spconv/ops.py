@@ -14,6 +14,7 @@ from .._ext import ext as _ext
 from .core import IndiceData
 
 PAIRS_MIN_ROWS = 65536   # as doda_amd.spconv.functional.PAIRS_MIN_ROWS (pair lists only for large rulebooks)
+WGRAD_PAIRS_DOWN = os.environ.get("DODA_WGRAD_PAIRS_DOWN", "0") == "1"   # (as doda_amd.spconv.functional: strided rulebooks' lists)
 
 
 def _triple(v):
@@ -124,7 +125,8 @@ def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", firs
         key = subm_key % lvl
         if key not in tensor.indice_dict:
             tensor.indice_dict[key] = build_subm(indices, tensor.batch_size, shape, 3)
-        if with_pairs and indices.shape[0] >= PAIRS_MIN_ROWS:
+        if (with_pairs and indices.shape[0] >= PAIRS_MIN_ROWS
+                and not (_ext is not None and _ext.has_tilebook(tensor.indice_dict[key].tbl))):   # (tiled: no consumer)
             tensor.indice_dict[key].wgrad_lists()
         if lvl == first_level + n_levels - 1:
             break
@@ -133,7 +135,7 @@ def build_pyramid(tensor, n_levels, subm_key="subm%d", down_key="spconv%d", firs
         if data is None:
             data = build_down2(indices, tensor.batch_size, shape, 2, 2, 0, 1)
             tensor.indice_dict[key] = data
-        if with_pairs and indices.shape[0] >= PAIRS_MIN_ROWS:
+        if with_pairs and WGRAD_PAIRS_DOWN and indices.shape[0] >= PAIRS_MIN_ROWS:
             data.wgrad_lists()
         indices, shape = data.outids, data.out_spatial_shape
     return tensor.indice_dict
