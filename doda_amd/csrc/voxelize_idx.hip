@@ -227,7 +227,15 @@ __global__ __launch_bounds__(256) void vox_max(const int32_t *__restrict__ count
         const int o = __shfl_xor(mx, d, 64);
         mx = o > mx ? o : mx;
     }
-    if (lane_id() == 0) atomicMax(&counts_out[1], mx);
+    // one atomic per workgroup, and only when it would raise the value (2048 waves on one address took 25 us)
+    __shared__ int wmx[4];
+    if (lane_id() == 0) wmx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int a = wmx[0] > wmx[1] ? wmx[0] : wmx[1], b = wmx[2] > wmx[3] ? wmx[2] : wmx[3];
+        const int bm = a > b ? a : b;
+        if (bm > __hip_atomic_load(&counts_out[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&counts_out[1], bm);
+    }
 }
 
 // n_active / max_active are the caller's (doda_voxelize_idx_fill): every kernel below bounds its reads of the workspace
@@ -301,9 +309,7 @@ extern "C" int doda_voxelize_idx_assign(const int64_t *coords, int32_t n, int32_
     if (ws_bytes < w.total) return DODA_ERR_WORKSPACE;
     const int grid = div_up(n, 256);
     hipMemsetD32Async((hipDeviceptr_t)w.tab, VX_EMPTY, w.cap, s);
-    hipMemsetAsync(w.count, 0, (size_t)n * 4, s);
-    hipMemsetAsync(w.cursor, 0, (size_t)n * 4, s);
-    hipMemsetAsync(w.last, 0, (size_t)n * 4, s);
+    hipMemsetAsync(w.count, 0, (size_t)((char *)w.last - (char *)w.count) + (size_t)n * 4, s);   // count, cursor, last: adjacent (vox_carve)
     hipLaunchKernelGGL(vox_insert, dim3(grid), dim3(256), 0, s, coords, n, ncol, w.tab, w.cap - 1);
     hipLaunchKernelGGL(vox_first, dim3(grid), dim3(256), 0, s, coords, n, ncol, w.tab, w.cap - 1,
                        w.first, w.flag);

@@ -87,8 +87,8 @@ def voxelize_idx_device(coords, batch_size, mode=4, sizes=None):
     coords = coords.contiguous()
     n, ncol = coords.shape
     dev = coords.device
-    input_map = torch.zeros(n, dtype=torch.int32, device=dev)
-    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    input_map = torch.empty(n, dtype=torch.int32, device=dev)      # (every entry is written by the assign kernel)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)          # (zeroed by doda_voxelize_idx_assign itself)
     nbytes = lib().doda_voxelize_idx_workspace_bytes(n)
     ws = _ws(nbytes, dev)
     check(lib().doda_voxelize_idx_assign(_p(coords), n, ncol, int(mode), _p(input_map), _p(counts),
@@ -98,8 +98,11 @@ def voxelize_idx_device(coords, batch_size, mode=4, sizes=None):
     else:
         m, max_active = (int(v) for v in counts.tolist())  # one D2H sync: sizes of the outputs
     max_active = max(max_active, 1)
-    out_coords = torch.zeros((m, ncol), dtype=torch.int64, device=dev)
-    out_map = torch.zeros((m, max_active + 1), dtype=torch.int32, device=dev)
+    # (the fill kernels write every element of both outputs: rows_init all of out_map, finish all of out_coords)
+    out_coords = torch.empty((m, ncol), dtype=torch.int64, device=dev)
+    out_map = torch.empty((m, max_active + 1), dtype=torch.int32, device=dev)
+    if n == 0 or m == 0:
+        out_coords.zero_(); out_map.zero_()
     check(lib().doda_voxelize_idx_fill(_p(coords), n, ncol, int(mode), m, max_active,
                                        _p(out_coords), _p(out_map), _p(ws), ws.numel(), _stream()),
           "doda_voxelize_idx_fill")
