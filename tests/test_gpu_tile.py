@@ -301,16 +301,17 @@ def test_safety_valve_for_voxel_orders_without_locality(native_lib):
         state.update(saved)
 
 
-@pytest.mark.parametrize("m,layout", [(20000, 0), (20000, 2), (8300, 0)])
+@pytest.mark.parametrize("m,layout", [(20000, 0), (20000, 2), (8300, 0), (90000, 0), (90000, 2)])
 def test_weights_in_lds_kernel_48_channels(native_lib, m, layout):
     """conv_wlds48 (bf16 48 -> 48, the level-3 layers): against the fp64 oracle on bf16-representable operands, against
-    the streaming-weights kernel (switch off), with residual; statistics rows through the extension."""
+    the streaming-weights kernel (switch off), with residual; statistics rows through the extension.  m = 90000: more than
+    256 tiles of 256 rows — workgroups take a SECOND pass (level 3 of batches above ~6 scenes and of every 1 cm batch)."""
     from doda_amd import ops
     from doda_amd._lib import lib
     d = dev()
-    _, tbl = _scene_table(m, seed=31 + m)
+    _, tbl = (_scene_table(m, seed=31 + m, shape=(160, 140, 90)) if m > 40000 else _scene_table(m, seed=31 + m))
     n = tbl.shape[1]
-    assert n >= 8192
+    assert n >= 8192 and (m < 40000 or n > 256 * 256 + 1000)
     torch.manual_seed(m)
     x = torch.randn(n, 48, device=d).bfloat16()
     w = (torch.randn(27, 48, 48, device=d) * 0.1).bfloat16().float()
