@@ -155,3 +155,57 @@ def test_unet_step_with_totals_equals_the_step_with_rows(native_lib, dtype):
         assert float((a - g1[k]).norm()) <= tol * float(a.norm()) + 1e-7, k
     for k, a in b0.items():
         assert float((a.double() - b1[k].double()).abs().max()) <= 1e-5 * float(a.double().abs().max()) + 1e-6, k
+
+
+def test_tile_kernels_on_a_two_million_voxel_batch(native_lib):
+    """BASELINE config 5 at batch 4 in the loader's Z-order numbering: 2.0 M voxels, 7770 tiles (15 per conv_tile16 workgroup; the
+    unit tests above stop at 1250), a level-1 rulebook built by the HASH builder (4 x 362 x 318 x 186 cells > 2^26: no
+    direct-address grid), tiles whose rows span more than the tilebook builder's bitmap covers.  No CPU oracle at this size:
+    conv_tile16 against the plain conv_tile bit for bit (forward and data gradient in the step's form, statistics as totals),
+    both against the dense-table kernel to bf16 output rounding, the tile weight gradient against the gather-table kernel, and
+    everything twice (a second run must reproduce the first exactly)."""
+    from doda_amd import ops, spconv
+    from doda_amd._lib import lib
+    from doda_amd.collate import reorder_voxels
+    from doda_amd.scene import make_batch
+    d = dev()
+    b = reorder_voxels(make_batch(4, 500000, 1000, 100), "morton")
+    idx = b["voxel_locs"].int().to(d)
+    shape = [int(s) for s in b["spatial_shape"]]
+    n = idx.shape[0]
+    assert n > 1900000 and 4 * shape[0] * shape[1] * shape[2] > (1 << 26)
+    tbl = ops.rulebook_subm(idx, shape, 4, 3)
+    tb = ops.tilebook_build(tbl)
+    n_over = tb[-8:].view(torch.int32).cpu().tolist()
+    assert n_over[1] == 0                                   # (the renumbering's point: every tile keeps its list)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, 16, generator=g).bfloat16().to(d)
+    dy = torch.randn(n, 16, generator=g).bfloat16().to(d)
+    res = torch.randn(n, 16, generator=g).bfloat16().to(d)
+    w = (torch.randn(27, 16, 16, generator=g) * 0.1).to(d)
+    runs = []
+    for rep in range(2):
+        out = {}
+        for on in (1, 0):
+            assert lib().doda_set_option(4, on) == 0        # DODA_OPT_TILE_PIPELINE: conv_tile16 / plain conv_tile
+            try:
+                out[on] = [ops.spconv_gather(inp, w, tbl, n, layout, 16, tilebook=tb, residual=res, want_stats="totals")
+                           for inp, layout in ((x, 0), (dy, 2))]
+            finally:
+                lib().doda_set_option(4, 1)
+        for (y1, t1), (y0, t0) in zip(out[1], out[0]):
+            assert torch.equal(y1, y0)
+            s1, s0 = ops.totals_sums(t1), ops.totals_sums(t0)
+            assert float((s1 - s0).abs().max()) <= 1e-6 * float(s0.abs().max())      # (fp32 partials of 512 against 768 workgroups)
+        dense = ops.spconv_gather(x, w, tbl, n, 0, 16, residual=res)
+        assert (dense != out[1][0][0]).float().mean().item() < 0.02 and rel_err_t(out[1][0][0], dense) < 2.0 ** -6
+        dw_t, = ops.spconv_wgrad_multi([(x, dy, tbl, n, None, None, tb)])
+        dw_g, = ops.spconv_wgrad_multi([(x, dy, tbl, n)])
+        assert float((dw_t - dw_g).norm()) <= 2e-3 * float(dw_g.norm())
+        runs.append((out[1][0][0], out[1][1][0], ops.totals_sums(out[1][0][1]), dw_t))
+    for a, b_ in zip(runs[0], runs[1]):
+        assert torch.equal(a, b_)
+
+
+def rel_err_t(a, b):
+    return float((a.double() - b.double()).abs().max()) / max(float(b.double().abs().max()), 1e-30)
