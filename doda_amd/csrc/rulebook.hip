@@ -107,7 +107,13 @@ __global__ __launch_bounds__(256) void subm_probe(const int4 *__restrict__ indic
 // 64-byte sectors instead of ~17 — the hash probe ran at the fabric's random-sector rate.  The caller
 // opts in by handing over a workspace with room for the grid behind the hash workspace (doda_hip.h); larger grids
 // (1 cm scenes: 2^34 cells) keep the hash.  Same results: first-touch (lowest row) wins a cell, as hash_insert_min.
-constexpr long long GRID_MAX_CELLS = 1ll << 26;
+// (round 5: 2^28 cells = 1 GiB of grid — a batch of four 1 cm scenes has 8.5e7 cells; its level-1 probe took 1.1 ms on the
+// hash and the memset of the grid costs 45 us.  DODA_RULEBOOK_GRID_MAX_LOG2 moves the limit; callers size the workspace.)
+static const long long GRID_MAX_CELLS = [] {
+    const char *e = getenv("DODA_RULEBOOK_GRID_MAX_LOG2");
+    const int b = e ? atoi(e) : 28;
+    return 1ll << (b < 0 ? 0 : b > 30 ? 30 : b);
+}();
 
 __global__ __launch_bounds__(256) void subm_grid_insert(const int4 *__restrict__ indices, int m, int batch, GridDesc g,
                                                         int32_t *__restrict__ grid, int32_t *__restrict__ nbr, int ld,

@@ -336,9 +336,14 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
         const int32_t m = (int32_t)indices.size(0);
         int32_t shp[3] = {(int32_t)shape[0], (int32_t)shape[1], (int32_t)shape[2]};
         size_t wsb = doda_rulebook_workspace_bytes(m);
-        {   // room for the direct-address grid behind it (doda_hip.h: grids of <= 2^26 cells; larger ones keep the hash)
+        {   // room for the direct-address grid behind it (doda_hip.h: grids of <= 2^28 cells; larger ones keep the hash)
             const long double cells = (long double)batch * shape[0] * shape[1] * shape[2];
-            if (m > 0 && cells > 0 && cells <= (long double)(1ll << 26)) wsb = (wsb + 255) / 256 * 256 + (size_t)cells * 4;
+            static const long long grid_max = [] {      // (csrc/rulebook.hip GRID_MAX_CELLS: the same switch)
+                const char *e = getenv("DODA_RULEBOOK_GRID_MAX_LOG2");
+                const int b = e ? atoi(e) : 28;
+                return 1ll << (b < 0 ? 0 : b > 30 ? 30 : b);
+            }();
+            if (m > 0 && cells > 0 && cells <= (long double)grid_max) wsb = (wsb + 255) / 256 * 256 + (size_t)cells * 4;
         }
         at::Tensor ws = at::empty({(int64_t)(wsb > 256 ? wsb : 256)}, iopt.dtype(at::kByte));
         // tilebooks for the finest `tile_levels` levels: DODA's 16- and 32-channel bf16 layers (2) or the 16-channel

@@ -5,6 +5,7 @@ and makes exactly the native calls — no arithmetic happens in Python and there
 (device tensors are required wherever the ABI takes device pointers).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -160,7 +161,7 @@ def _check_indices(indices):
     return indices.contiguous()
 
 
-RULEBOOK_GRID_MAX_CELLS = 1 << 26
+RULEBOOK_GRID_MAX_CELLS = 1 << min(30, max(0, int(os.environ.get("DODA_RULEBOOK_GRID_MAX_LOG2", "28"))))   # csrc/rulebook.hip GRID_MAX_CELLS
 
 
 def _rulebook_ws(m, batch_size, shape3, device):

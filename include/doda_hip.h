@@ -101,9 +101,10 @@ size_t doda_rulebook_workspace_bytes(int32_t m);
 /* ABI 7 (round 4).  doda_rulebook_subm (ksize 3) and doda_rulebook_down2_assign look voxels up through a 64-bit hash table
  * inside `ws`.  A caller that hands over a LARGER workspace — align256(doda_rulebook_workspace_bytes(m)) + 4 * cells bytes,
  * cells = batch * X * Y * Z of the grid the call looks up in (the input shape for subm, the output shape (s - 2) / 2 + 1
- * for down2), cells <= 2^26 — gets a direct-address grid instead (grid[cell] = row or -1: one 4-byte read per probe, the
- * three z-neighbours adjacent; a batch of 2 cm scenes is 16.5 M cells = 66 MB).  Same tables, same first-touch numbering;
- * larger grids (1 cm scenes) and the minimum workspace keep the hash.  DODA_RULEBOOK_GRID=0 disables the grid. */
+ * for down2), cells <= 2^28 (ABI 9; 2^26 before; DODA_RULEBOOK_GRID_MAX_LOG2) — gets a direct-address grid instead (grid[cell] = row
+ * or -1: one 4-byte read per probe, the three z-neighbours adjacent; a batch of 2 cm scenes is 16.5 M cells = 66 MB, of four 1 cm
+ * scenes 85 M cells = 340 MB).  Same tables, same first-touch numbering; larger grids and the minimum workspace keep the hash.
+ * DODA_RULEBOOK_GRID=0 disables the grid. */
 
 /* SubMConv3d, odd cubic kernel `ksize` (1 or 3), stride 1, padding ksize/2, dilation 1.
  * indices: int32 [m,4] = (batch, x, y, z).  nbr: int32 [ksize^3][ld], ld >= m.
