@@ -159,8 +159,8 @@ def test_unet_step_with_totals_equals_the_step_with_rows(native_lib, dtype):
 
 def test_tile_kernels_on_a_two_million_voxel_batch(native_lib):
     """BASELINE config 5 at batch 4 in the loader's Z-order numbering: 2.0 M voxels, 7770 tiles (15 per conv_tile16 workgroup; the
-    unit tests above stop at 1250), a level-1 rulebook built by the HASH builder (4 x 362 x 318 x 186 cells > 2^26: no
-    direct-address grid), tiles whose rows span more than the tilebook builder's bitmap covers.  No CPU oracle at this size:
+    unit tests above stop at 1250), a level-1 rulebook over 8.5e7 cells (direct-address grid since the limit is 2^28; the hash
+    builder must give the same table), tiles whose rows span more than the tilebook builder's bitmap covers.  No CPU oracle at this size:
     conv_tile16 against the plain conv_tile bit for bit (forward and data gradient in the step's form, statistics as totals),
     both against the dense-table kernel to bf16 output rounding, the tile weight gradient against the gather-table kernel, and
     everything twice (a second run must reproduce the first exactly)."""
@@ -175,6 +175,14 @@ def test_tile_kernels_on_a_two_million_voxel_batch(native_lib):
     n = idx.shape[0]
     assert n > 1900000 and 4 * shape[0] * shape[1] * shape[2] > (1 << 26)
     tbl = ops.rulebook_subm(idx, shape, 4, 3)
+    import ctypes as C
+    from doda_amd._lib import check
+    ws = torch.empty(lib().doda_rulebook_workspace_bytes(n), dtype=torch.uint8, device=d)        # minimum workspace: the hash builder
+    tbl_h = torch.empty_like(tbl)
+    check(lib().doda_rulebook_subm(idx.data_ptr(), n, (C.c_int32 * 3)(*shape), 4, 3, tbl_h.data_ptr(), n, ws.data_ptr(), ws.numel(),
+                                   torch.cuda.current_stream().cuda_stream), "doda_rulebook_subm")
+    assert torch.equal(tbl, tbl_h)
+    del tbl_h, ws
     tb = ops.tilebook_build(tbl)
     n_over = tb[-8:].view(torch.int32).cpu().tolist()
     assert n_over[1] == 0                                   # (the renumbering's point: every tile keeps its list)
