@@ -25,6 +25,20 @@
 #include <chrono>
 #include <cstdlib>
 
+// Debug aid (DODA_POISON=1): every tensor this file allocates uninitialised is filled with 0xFF bytes (NaN for fp32 / bf16 /
+// fp64, -1 for int32) right after the allocation, on the current stream.  A kernel that reads something it (or a predecessor) did
+// not write then yields NaN instead of whatever the caching allocator left there — the stale values that make such a read an
+// intermittent, plausible-looking error (tools/traindet.py, tools/stepdet.py).
+static const bool g_poison = [] { const char *e = getenv("DODA_POISON"); return e && e[0] == '1'; }();
+static inline at::Tensor poisoned(at::Tensor t) {
+    if (g_poison && t.defined() && t.is_cuda() && t.numel() > 0)
+        (void)hipMemsetAsync(t.data_ptr(), 0xFF, (size_t)t.numel() * t.element_size(), c10::hip::getCurrentHIPStream(t.device().index()).stream());
+    return t;
+}
+template <class... A> static inline at::Tensor pempty(A &&...a) { return poisoned(at::empty(std::forward<A>(a)...)); }
+static inline at::Tensor pempty(at::IntArrayRef sizes, const at::TensorOptions &o) { return poisoned(at::empty(sizes, o)); }
+template <class... A> static inline at::Tensor pempty_like(A &&...a) { return poisoned(at::empty_like(std::forward<A>(a)...)); }
+
 // Host-side time of the extension's own entry points (DODA_HOST_TIMING=1; tools/hostcount.py prints it): where the issuing
 // thread spends a step — the step sits at the host / GPU crossover.
 namespace host_timing {
@@ -90,8 +104,8 @@ const void *tilebook_behind(const at::Tensor &tbl, int64_t n_out) {
 // int32 [K, m] table whose storage has room for the tilebook (written later by build_tilebook)
 at::Tensor table_with_tilebook(int64_t K, int64_t m, const at::TensorOptions &iopt) {
     const size_t tb = doda_tilebook_bytes((int32_t)m, (int32_t)K);
-    if (tb == 0) return at::empty({K, m}, iopt);
-    at::Tensor buf = at::empty({(int64_t)((tilebook_offset(K, m) + tb) / 4)}, iopt);
+    if (tb == 0) return pempty({K, m}, iopt);
+    at::Tensor buf = pempty({(int64_t)((tilebook_offset(K, m) + tb) / 4)}, iopt);
     return buf.narrow(0, 0, K * m).view({K, m});
 }
 
@@ -145,7 +159,7 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
     const int64_t K = tbl.size(0), ld = tbl.size(1), kc = x.size(1);
     void *st = stream_of(x);
     const bool f32_out = esz == 4 || out_f32;
-    at::Tensor y = at::empty({n_out, nc}, x.options().dtype(f32_out ? at::kFloat : at::kBFloat16));
+    at::Tensor y = pempty({n_out, nc}, x.options().dtype(f32_out ? at::kFloat : at::kBFloat16));
     at::Tensor res;   // y = conv + res
     if (residual.has_value() && residual->defined()) {
         res = residual->contiguous();
@@ -165,7 +179,7 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
             ep.stats_totals = (double *)stats.data_ptr();
             ep.stats = (float *)stats.data_ptr();      // (non-NULL selects the statistics epilogue; nothing is written through it)
         } else {
-            stats = at::empty({(int64_t)doda_spconv_stats_capacity((int32_t)n_out), 2, nc}, x.options().dtype(at::kFloat));
+            stats = pempty({(int64_t)doda_spconv_stats_capacity((int32_t)n_out), 2, nc}, x.options().dtype(at::kFloat));
             ep.stats = (float *)stats.data_ptr();
         }
         ep.stats_rows_h = &stats_rows;
@@ -197,7 +211,7 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
             TORCH_CHECK(wc.scalar_type() == at::kFloat && wc.numel() == K * kc * nc, "doda gather: weight shape");
             wptr = wc.data_ptr();
             ws_bytes = doda_spconv_gather_workspace_bytes((int)K, (int)kc, (int)nc, esz);
-            ws_t = at::empty({(int64_t)ws_bytes}, x.options().dtype(at::kByte));
+            ws_t = pempty({(int64_t)ws_bytes}, x.options().dtype(at::kByte));
             ws = ws_t.data_ptr();
             lay = (int)layout;
         }
@@ -243,7 +257,7 @@ at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tenso
     TORCH_CHECK(a.scalar_type() == b.scalar_type(), "doda wgrad: dtype mismatch");
     const int esz = elem_bytes(a);
     const int64_t K = tbl.size(0), ld = tbl.size(1), ca = a.size(1), cb = b.size(1);
-    at::Tensor dw = at::empty({K, ca, cb}, a.options().dtype(at::kFloat));
+    at::Tensor dw = pempty({K, ca, cb}, a.options().dtype(at::kFloat));
     // one job of the multi-layer entry point (ABI 7: the only weight-gradient entry point); the library picks the
     // kernel: LDS-staged over the tilebook, pair lists, or the gather table
     doda_wgrad_job j;
@@ -261,8 +275,8 @@ at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tenso
         j.pair_seg_nt = pl.seg.defined() ? (int32_t)pl.seg.size(1) : 0;
     }
     const size_t wsb = doda_spconv_wgrad_multi_workspace_bytes(&j, 1), dsb = doda_spconv_wgrad_multi_desc_bytes(1);
-    at::Tensor ws = at::empty({(int64_t)wsb}, a.options().dtype(at::kByte));
-    at::Tensor desc = at::empty({(int64_t)dsb}, a.options().dtype(at::kByte));
+    at::Tensor ws = pempty({(int64_t)wsb}, a.options().dtype(at::kByte));
+    at::Tensor desc = pempty({(int64_t)dsb}, a.options().dtype(at::kByte));
     check(doda_spconv_wgrad_multi(&j, 1, ws.data_ptr(), wsb, desc.data_ptr(), dsb, stream_of(a)), "doda_spconv_wgrad_multi");
     return dw;
 }
@@ -272,11 +286,11 @@ at::Tensor wgrad(const at::Tensor &a_in, const at::Tensor &b_in, const at::Tenso
 std::tuple<at::Tensor, at::Tensor, at::Tensor> export_pairs(const at::Tensor &tbl, int64_t n_rows, bool flip, void *st) {
     const int64_t K = tbl.size(0);
     const auto iopt = tbl.options();
-    at::Tensor pairs = at::empty({2, K, n_rows > 0 ? n_rows : 1}, iopt), num = at::empty({K}, iopt);
+    at::Tensor pairs = pempty({2, K, n_rows > 0 ? n_rows : 1}, iopt), num = pempty({K}, iopt);
     // the workspace is an ordinary int32 tensor: its head IS the segment prefix handed on to the weight
     // gradient, and a view of it takes part in record_stream like any other allocation
     const size_t wsb = doda_rulebook_pairs_workspace_bytes((int32_t)n_rows, (int32_t)K);
-    at::Tensor ws = at::empty({(int64_t)((wsb > 256 ? wsb : 256) / 4)}, iopt);
+    at::Tensor ws = pempty({(int64_t)((wsb > 256 ? wsb : 256) / 4)}, iopt);
     check(doda_rulebook_pairs((const int32_t *)tbl.data_ptr(), (int32_t)tbl.size(1), (int32_t)K, (int32_t)n_rows,
                               (flip ? 1 : 0) | 2, (int32_t *)pairs.data_ptr(), (int32_t)pairs.size(2),
                               (int32_t *)num.data_ptr(), ws.data_ptr(), (size_t)ws.numel() * 4, st),
@@ -345,11 +359,11 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
             }();
             if (m > 0 && cells > 0 && cells <= (long double)grid_max) wsb = (wsb + 255) / 256 * 256 + (size_t)cells * 4;
         }
-        at::Tensor ws = at::empty({(int64_t)(wsb > 256 ? wsb : 256)}, iopt.dtype(at::kByte));
+        at::Tensor ws = pempty({(int64_t)(wsb > 256 ? wsb : 256)}, iopt.dtype(at::kByte));
         // tilebooks for the finest `tile_levels` levels: DODA's 16- and 32-channel bf16 layers (2) or the 16-channel
         // fp32 layers (1) — rows of 32 or 64 bytes, what the tile kernel stages
         const bool tiled = lvl < tile_levels && tile_min_rows >= 0 && m >= tile_min_rows;
-        at::Tensor nbr = tiled ? table_with_tilebook(27, m, iopt) : at::empty({27, m}, iopt);
+        at::Tensor nbr = tiled ? table_with_tilebook(27, m, iopt) : pempty({27, m}, iopt);
         check(doda_rulebook_subm((const int32_t *)indices.data_ptr(), m, shp, (int32_t)batch, 3,
                                  (int32_t *)nbr.data_ptr(), m, ws.data_ptr(), (size_t)ws.numel(), st),
               "doda_rulebook_subm");
@@ -365,14 +379,14 @@ std::vector<PyramidLevel> build_pyramid(const at::Tensor &indices_in, std::vecto
             out.emplace_back(nbr, at::Tensor(), at::Tensor(), at::Tensor(), std::vector<int64_t>(), sp, sn, sh, dp, dn, dh);
             break;
         }
-        at::Tensor parent = at::empty({m > 0 ? m : 1}, iopt), off = at::empty({m > 0 ? m : 1}, iopt);
-        at::Tensor out_idx = at::empty({m > 0 ? m : 1, 4}, iopt), count = at::empty({1}, iopt);
+        at::Tensor parent = pempty({m > 0 ? m : 1}, iopt), off = pempty({m > 0 ? m : 1}, iopt);
+        at::Tensor out_idx = pempty({m > 0 ? m : 1, 4}, iopt), count = pempty({1}, iopt);
         check(doda_rulebook_down2_assign((const int32_t *)indices.data_ptr(), m, shp, (int32_t)batch,
                                          (int32_t *)parent.data_ptr(), (int32_t *)off.data_ptr(),
                                          (int32_t *)out_idx.data_ptr(), (int32_t *)count.data_ptr(), ws.data_ptr(),
                                          (size_t)ws.numel(), st), "doda_rulebook_down2_assign");
         const int32_t m_out = read_back_i32(count, st);   // the level's one size read-back
-        at::Tensor child = at::empty({8, m_out}, iopt), par_off = at::empty({8, m}, iopt);
+        at::Tensor child = pempty({8, m_out}, iopt), par_off = pempty({8, m}, iopt);
         check(doda_rulebook_down2_tables((const int32_t *)parent.data_ptr(), (const int32_t *)off.data_ptr(), m, m_out,
                                          (int32_t *)child.data_ptr(), m_out, (int32_t *)par_off.data_ptr(), m, st),
               "doda_rulebook_down2_tables");
@@ -525,7 +539,7 @@ void issue_wgrads(std::vector<PendingWgrad> &q, const c10::hip::HIPStream &st) {
         } else {
             TORCH_CHECK(!target.defined(), "doda deferred wgrad: existing .grad of a conv weight is not a contiguous fp32 tensor");
             target = take_grad_home(p.weight);     // the reducer's bucket view, when the weight has one
-            if (!target.defined()) target = at::empty(p.weight.sizes(), p.weight.options());
+            if (!target.defined()) target = pempty(p.weight.sizes(), p.weight.options());
             fresh[k] = target;
         }
         doda_wgrad_job j;
@@ -552,7 +566,7 @@ void issue_wgrads(std::vector<PendingWgrad> &q, const c10::hip::HIPStream &st) {
     const auto opt = q[0].a.options().dtype(at::kByte);
     const size_t wsb = doda_spconv_wgrad_multi_workspace_bytes(jobs.data(), (int32_t)jobs.size());
     const size_t dsb = doda_spconv_wgrad_multi_desc_bytes((int32_t)jobs.size());
-    at::Tensor ws = at::empty({(int64_t)wsb}, opt), desc = at::empty({(int64_t)dsb}, opt);
+    at::Tensor ws = pempty({(int64_t)wsb}, opt), desc = pempty({(int64_t)dsb}, opt);
     {
         host_timing::Scope lib_scope(4);
         check(doda_spconv_wgrad_multi(jobs.data(), (int32_t)jobs.size(), ws.data_ptr(), wsb, desc.data_ptr(), dsb,
@@ -944,7 +958,7 @@ struct BNNode : public torch::autograd::Node {
             at::Tensor h;
             if (param.is_leaf() && param.scalar_type() == at::kFloat && param.numel() == c && (!direct_p || plain_accumulating_backward()))
                 h = take_grad_home(param, torch::autograd::get_current_graph_task_id());
-            return h.defined() ? h : at::empty({c}, x.options().dtype(at::kFloat));
+            return h.defined() ? h : pempty({c}, x.options().dtype(at::kFloat));
         };
         if (link) {
             if (training && link->stats.defined() && link->dz.defined() &&
@@ -959,7 +973,7 @@ struct BNNode : public torch::autograd::Node {
             const int64_t m = x.size(0), c = x.size(1);
             int64_t add_ld = c;
             const at::Tensor add = extra.defined() ? add_operand(extra, m, c, add_ld) : at::Tensor();
-            dx = at::empty_like(x);
+            dx = pempty_like(x);
             dg = grad_out(weight, c);
             db = grad_out(bias, c);
             check(doda_bn_relu_bwd_totals(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x), (const double *)stats.data_ptr(),
@@ -973,10 +987,10 @@ struct BNNode : public torch::autograd::Node {
             const int64_t m = x.size(0), c = x.size(1);
             int64_t add_ld = c;
             const at::Tensor add = extra.defined() ? add_operand(extra, m, c, add_ld) : at::Tensor();
-            dx = at::empty_like(x);
+            dx = pempty_like(x);
             dg = grad_out(weight, c);
             db = grad_out(bias, c);
-            at::Tensor coef = at::empty({3 * c}, x.options().dtype(at::kFloat));
+            at::Tensor coef = pempty({3 * c}, x.options().dtype(at::kFloat));
             check(doda_bn_relu_bwd_stats(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
                                             (const float *)stats.data_ptr(), (int)stats.size(0),
                                             (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(),
@@ -990,11 +1004,11 @@ struct BNNode : public torch::autograd::Node {
             const int64_t m = x.size(0), c = x.size(1);
             int64_t add_ld = c;
             const at::Tensor add = add_operand(extra, m, c, add_ld);
-            dx = at::empty_like(x);
+            dx = pempty_like(x);
             dg = grad_out(weight, c);
             db = grad_out(bias, c);
             const size_t wsb = doda_bn_workspace_bytes((int)m, (int)c);
-            at::Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
+            at::Tensor ws = pempty({(int64_t)wsb}, x.options().dtype(at::kByte));
             check(doda_bn_relu_bwd_add(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
                                           (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(),
                                           (const float *)weight.data_ptr(), (const float *)bias.data_ptr(),
@@ -1004,11 +1018,11 @@ struct BNNode : public torch::autograd::Node {
             extra = at::Tensor();
         } else if (training) {
             const int64_t m = x.size(0), c = x.size(1);
-            dx = at::empty_like(x);
+            dx = pempty_like(x);
             dg = grad_out(weight, c);
             db = grad_out(bias, c);
             const size_t wsb = doda_bn_workspace_bytes((int)m, (int)c);
-            at::Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
+            at::Tensor ws = pempty({(int64_t)wsb}, x.options().dtype(at::kByte));
             check(doda_bn_relu_bwd(x.data_ptr(), dy.data_ptr(), (int)m, (int)c, elem_bytes(x),
                                    (const float *)mean.data_ptr(), (const float *)invstd.data_ptr(),
                                    (const float *)weight.data_ptr(), (const float *)bias.data_ptr(), relu ? 1 : 0,
@@ -1062,10 +1076,10 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
         if (passthrough) xp = x.alias();
         const int esz = elem_bytes(x);
         const int64_t m = x.size(0), c = x.size(1);
-        y = at::empty_like(x);
+        y = pempty_like(x);
         if (training) {
-            mean = at::empty({c}, x.options().dtype(at::kFloat));
-            invstd = at::empty({c}, x.options().dtype(at::kFloat));
+            mean = pempty({c}, x.options().dtype(at::kFloat));
+            invstd = pempty({c}, x.options().dtype(at::kFloat));
         } else {
             mean = running_mean.to(at::kFloat).contiguous();
             invstd = at::rsqrt(running_var.to(at::kFloat) + eps).contiguous();
@@ -1113,7 +1127,7 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
                   "doda_bn_relu_fwd_stats");
         } else {
         const size_t wsb = doda_bn_workspace_bytes((int)m, (int)c);
-        at::Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
+        at::Tensor ws = pempty({(int64_t)wsb}, x.options().dtype(at::kByte));
         check(doda_bn_relu_fwd(x.data_ptr(), (int)m, (int)c, esz, (float)eps, (float)momentum,
                                (const float *)weight.data_ptr(), (const float *)bias.data_ptr(),
                                training ? (float *)running_mean.data_ptr() : nullptr,
@@ -1248,7 +1262,7 @@ struct Arena {   // device scratch that is never handed out as a tensor: a few c
         bytes = (bytes + 255) & ~(size_t)255;
         if (bytes > left) {
             const size_t sz = bytes > ((size_t)2 << 20) ? bytes : ((size_t)2 << 20);
-            chunks.push_back(at::empty({(int64_t)sz}, opt));
+            chunks.push_back(pempty({(int64_t)sz}, opt));
             cur = (char *)chunks.back().data_ptr();
             left = sz;
         }
@@ -1336,7 +1350,7 @@ struct Builder {
     Val dense(int rows, int c, bool as_tensor) {
         Val v;
         v.rows = rows; v.c = c; v.ld = c;
-        if (as_tensor) { v.t = at::empty({rows, c}, bf); v.p = v.t.data_ptr(); }
+        if (as_tensor) { v.t = pempty({rows, c}, bf); v.p = v.t.data_ptr(); }
         else v.p = arena.alloc((size_t)rows * c * 2);
         return v;
     }
@@ -1359,7 +1373,7 @@ struct Builder {
     void bn_fwd(Layer &L, bool training) {
         Val &x = L.x;
         if (training && !x.stats) stats_of(x);
-        L.a = at::empty({x.rows, x.c}, bf);
+        L.a = pempty({x.rows, x.c}, bf);
         doda_cx_op &o = push(DODA_CX_BNFWD, (first ? 0 : DODA_CX_F_BARRIER) | DODA_CX_F_RELU | (training ? DODA_CX_F_TRAINING : 0));
         first = false;
         o.rows = x.rows; o.c_in = x.c; o.x_ld = x.ld; o.y_ld = x.c; o.x = x.p; o.y = L.a.data_ptr();
@@ -1425,13 +1439,13 @@ struct CoarseNode : public torch::autograd::Node {
             pg.param = param;
             at::Tensor cur = param.grad();
             if (!plain) {   // a pass restricted to specific inputs: the kernel's gamma / beta sums go to scratch
-                pg.buf = at::empty({c}, param.options().dtype(at::kFloat));
+                pg.buf = pempty({c}, param.options().dtype(at::kFloat));
             } else if (cur.defined() && cur.scalar_type() == at::kFloat && cur.is_contiguous() && cur.numel() == c) {
                 pg.buf = cur; pg.accum = true; flags |= DODA_CX_F_ACCUM;
             } else {
                 at::Tensor h;
                 if (param.is_leaf() && param.scalar_type() == at::kFloat && param.numel() == c) h = take_grad_home(param, task);
-                pg.buf = h.defined() ? h : at::empty({c}, param.options().dtype(at::kFloat));
+                pg.buf = h.defined() ? h : pempty({c}, param.options().dtype(at::kFloat));
                 pg.fresh = true;
             }
             pgrads.push_back(pg);
@@ -1464,10 +1478,10 @@ struct CoarseNode : public torch::autograd::Node {
             int flags = DODA_CX_F_BARRIER;
             const int c = L.c_in;
             const int split = (L.x.c_split > 0 && L.x.c_split < c) ? L.x.c_split : c;
-            left = at::empty({L.n_in, split}, B.bf);
+            left = pempty({L.n_in, split}, B.bf);
             keep_alive.push_back(left);   // (every tensor an op points at stays alive until the launch is queued: a freed block
             //                               could be handed out again by the next at::empty of this very pass)
-            if (split < c) { right = at::empty({L.n_in, c - split}, B.bf); keep_alive.push_back(right); }
+            if (split < c) { right = pempty({L.n_in, c - split}, B.bf); keep_alive.push_back(right); }
             float *dg = nullptr, *db = nullptr;
             {
                 int f1 = 0, f2 = 0;
@@ -1475,8 +1489,8 @@ struct CoarseNode : public torch::autograd::Node {
                 db = pgrad(L.bn.beta, c, f2);
                 if ((f1 != 0) != (f2 != 0)) {   // one accumulates, the other does not: give both fresh buffers and add afterwards
                     PGrad &pa = pgrads[pgrads.size() - 2], &pb = pgrads.back();
-                    if (pa.accum) { pa.buf = at::empty({c}, pa.param.options().dtype(at::kFloat)); pa.accum = false; pa.fresh = true; dg = (float *)pa.buf.data_ptr(); }
-                    if (pb.accum) { pb.buf = at::empty({c}, pb.param.options().dtype(at::kFloat)); pb.accum = false; pb.fresh = true; db = (float *)pb.buf.data_ptr(); }
+                    if (pa.accum) { pa.buf = pempty({c}, pa.param.options().dtype(at::kFloat)); pa.accum = false; pa.fresh = true; dg = (float *)pa.buf.data_ptr(); }
+                    if (pb.accum) { pb.buf = pempty({c}, pb.param.options().dtype(at::kFloat)); pb.accum = false; pb.fresh = true; db = (float *)pb.buf.data_ptr(); }
                 } else if (f1) flags |= DODA_CX_F_ACCUM;
             }
             doda_cx_op &o = B.push(DODA_CX_BNBWD, flags);
@@ -1499,7 +1513,7 @@ struct CoarseNode : public torch::autograd::Node {
                 void *dz2 = gemm_bwd(S.l2, g, false, st2, true);
                 at::Tensor gS;
                 if (S.has_skip) {   // data gradient of the 1x1 skip conv: no mask, no statistics; independent of dz2
-                    gS = at::empty({S.l1.n_in, S.l1.c_in}, B.bf);
+                    gS = pempty({S.l1.n_in, S.l1.c_in}, B.bf);
                     keep_alive.push_back(gS);
                     doda_cx_op &o = B.push(DODA_CX_GEMM, DODA_CX_F_IDENTITY);
                     o.rows = S.l1.n_in; o.rows_in = S.l1.n_in; o.c_in = S.l2.c_out; o.c_out = S.l1.c_in; o.K = 1; o.tbl_ld = S.l1.n_in;
@@ -1627,7 +1641,7 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
             // where the block's output goes: the left half of the concatenation when a strided conv follows
             Val y;
             if (!last && kinds[si + 1] == 1) {
-                at::Tensor cat = at::empty({n, 2 * cout}, B.bf);
+                at::Tensor cat = pempty({n, 2 * cout}, B.bf);
                 y.p = cat.data_ptr(); y.rows = n; y.c = cout; y.ld = 2 * cout;
                 skips.push_back({Val(), cat});
             } else {
@@ -1635,7 +1649,7 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
                 if (last) y_out = y.t;
             }
             if (last && training) {   // the caller may feed these rows to the next fused BatchNorm
-                y_stats = at::empty({B.G, 2, cout}, x.options().dtype(at::kFloat));
+                y_stats = pempty({B.G, 2, cout}, x.options().dtype(at::kFloat));
             }
             B.gemm_fwd(S.l2, tbl, false, y, &skipv, training, true);
             if (last && training) {   // (gemm_fwd put the partial rows into the arena: point the op at the returned tensor instead)
@@ -1729,7 +1743,7 @@ void sgd_step(const std::vector<at::Tensor> &params, const std::vector<at::Tenso
     }
     c10::DeviceGuard guard(dev);
     const size_t nb = doda_sgd_multi_desc_bytes((int32_t)n);
-    at::Tensor desc = at::empty({(int64_t)nb}, params[0].options().dtype(at::kByte));
+    at::Tensor desc = pempty({(int64_t)nb}, params[0].options().dtype(at::kByte));
     check(doda_sgd_multi(t.data(), (int32_t)n, lr, momentum, dampening, weight_decay, nesterov ? 1 : 0,
                          maximize ? 1 : 0, desc.data_ptr(), nb, stream_of(params[0])), "doda_sgd_multi");
 }
@@ -1833,10 +1847,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               char *p = (char *)const_cast<void *>(tb);
               auto o32 = tbl.options();
               // (stored in the DMA kernel's lane order, csrc/tilebook.hpp tb_upos: handed out in list order)
-              at::Tensor order = at::empty({UMAX}, at::TensorOptions().dtype(at::kLong));
+              at::Tensor order = pempty({UMAX}, at::TensorOptions().dtype(at::kLong));
               for (int64_t e = 0; e < UMAX; ++e) order.data_ptr<int64_t>()[e] = (((e >> 5) & 7) * 32 + (e & 31)) * 4 + (e >> 8);
               at::Tensor ulist = at::from_blob(p, {nt, UMAX}, o32).index_select(1, order.to(tbl.device()));
-              at::Tensor pos = at::empty({T}, at::TensorOptions().dtype(at::kLong));      // word of row t inside a plane
+              at::Tensor pos = pempty({T}, at::TensorOptions().dtype(at::kLong));      // word of row t inside a plane
               for (int64_t t = 0; t < T; ++t) pos.data_ptr<int64_t>()[t] = (t & 0xC0) | (((t & 3) | ((t & 4) << 1) | ((t & 8) >> 1)) << 2) | ((t >> 4) & 3);
               at::Tensor words = at::from_blob(p + nt * UMAX * 4, {nt, LW, T}, o32).to(at::kLong).index_select(2, pos.to(tbl.device()));
               std::vector<at::Tensor> per_offset;
