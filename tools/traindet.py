@@ -46,5 +46,8 @@ for r in range(runs):
     chk = float(sum(p.detach().double().abs().sum() for p in net.parameters()))
     res.append((ls, chk))
     first_diff = next((k for k in range(steps) if ls[k] != res[0][0][k]), None)
-    print("run %d: final loss %.6f checksum %.10e  first step whose loss differs from run 0: %s" % (r, ls[-1], chk, first_diff), flush=True)
-print("all runs identical:", all(x == res[0] for x in res))
+    if runs <= 8 or first_diff is not None:
+        print("run %d: final loss %.6f checksum %.10e  first step whose loss differs from run 0: %s" % (r, ls[-1], chk, first_diff), flush=True)
+import collections
+modes = collections.Counter(x[1] for x in res)
+print("all runs identical:", all(x == res[0] for x in res), " distinct outcomes:", len(modes), " runs off the most common one: %d of %d" % (runs - modes.most_common(1)[0][1], runs))
