@@ -98,7 +98,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_stats_partial(const typename T::e
             lds[(rl * 2 + 1) * c + f * 4 + q] = s2[q];
         }
     }
-    __syncthreads();
+    doda_sync();
     for (int e = threadIdx.x; e < 2 * c; e += BN_BLOCK) {
         float t = 0.f;
         for (int r = 0; r < g.rpb; ++r) t += lds[r * 2 * c + e];
@@ -202,7 +202,7 @@ __device__ __forceinline__ void tot_fwd_prologue(const TotArgs &t, int c, float 
             if (ch == 0 && t.nbt) *t.nbt = *t.nbt + 1;
         }
     }
-    __syncthreads();
+    doda_sync();
 }
 __device__ __forceinline__ void tot_bwd_prologue(const TotArgs &t, int c, const float *__restrict__ invstd,
                                                  const float *__restrict__ gamma, float *v_co /*[3][c]*/) {
@@ -217,7 +217,7 @@ __device__ __forceinline__ void tot_bwd_prologue(const TotArgs &t, int c, const 
             t.out_a[ch] = (float)s2;                // dgamma
         }
     }
-    __syncthreads();
+    doda_sync();
 }
 
 // ---- pass 2: normalise + affine (+ReLU) --------------------------------------------------------
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial(const typename T::ele
             lds[(rl * 2 + 1) * c + f * 4 + q] = s2[q];
         }
     }
-    __syncthreads();
+    doda_sync();
     for (int e = threadIdx.x; e < 2 * c; e += BN_BLOCK) {
         float t = 0.f;
         for (int r = 0; r < g.rpb; ++r) t += lds[r * 2 * c + e];
@@ -524,12 +524,12 @@ __device__ __forceinline__ f32x4 block_sum4(f32x4 v, float (*lds)[4]) {  // 256 
         for (int q = 0; q < 4; ++q) v[q] += __shfl_xor(v[q], d, 64);
     }
     const int wid = threadIdx.x >> 6;
-    __syncthreads();
+    doda_sync();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) lds[wid][q] = v[q];
     }
-    __syncthreads();
+    doda_sync();
     f32x4 t;
 #pragma unroll
     for (int q = 0; q < 4; ++q) t[q] = (lds[0][q] + lds[1][q]) + (lds[2][q] + lds[3][q]);
@@ -548,7 +548,7 @@ __device__ __forceinline__ void block_sum4x2(f32x4 &a, f32x4 &b, float (*lds)[8]
 #pragma unroll
         for (int q = 0; q < 4; ++q) { lds[wid][q] = a[q]; lds[wid][4 + q] = b[q]; }
     }
-    __syncthreads();
+    doda_sync();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         a[q] = (lds[0][q] + lds[1][q]) + (lds[2][q] + lds[3][q]);
@@ -696,12 +696,12 @@ __device__ __forceinline__ void block_sum_d4(double (&v)[4], double (*lds)[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = wave_sum(v[q]);
     const int wid = threadIdx.x >> 6;
-    __syncthreads();
+    doda_sync();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) lds[wid][q] = v[q];
     }
-    __syncthreads();
+    doda_sync();
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = (lds[0][q] + lds[1][q]) + (lds[2][q] + lds[3][q]);
 }
@@ -715,7 +715,7 @@ __device__ __forceinline__ void block_sum_d8(double (&a)[4], double (&b)[4], dou
 #pragma unroll
         for (int q = 0; q < 4; ++q) { lds[wid][q] = a[q]; lds[wid][4 + q] = b[q]; }
     }
-    __syncthreads();
+    doda_sync();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         a[q] = (lds[0][q] + lds[1][q]) + (lds[2][q] + lds[3][q]);
@@ -873,7 +873,7 @@ __device__ __forceinline__ void fused_reduce(const float *__restrict__ stats, in
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) { red[threadIdx.x][q] = s1[q]; red[threadIdx.x][4 + q] = s2[q]; }
-    __syncthreads();
+    doda_sync();
     if (rl == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { s1[q] = 0.0; s2[q] = 0.0; }
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_fused_fwd(const typename T::elem 
             if (f == 0 && nbt) *nbt = *nbt + 1;
         }
     }
-    __syncthreads();
+    doda_sync();
     for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < n_frag; e += (long long)gridDim.x * BN_BLOCK) {
         const int f = (int)(e % nf);
         const f32x4 v = T::load4(x + e * 4);
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_fused_bwd(const typename T::elem 
             *reinterpret_cast<f32x4 *>(dgamma + f * 4) = dg;
         }
     }
-    __syncthreads();
+    doda_sync();
     for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < n_frag; e += (long long)gridDim.x * BN_BLOCK) {
         const int f = (int)(e % nf);
         const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + f * 4);

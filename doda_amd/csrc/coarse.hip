@@ -79,7 +79,7 @@ struct CxCtl {
 // All workgroups of the call meet here.  Every wave first drains its own write-through stores.
 __device__ __forceinline__ void cx_barrier(CxCtl &c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    doda_sync();
     c.target += (unsigned)c.G;
     if (threadIdx.x == 0 && !c.dead) {
         __hip_atomic_fetch_add(c.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -93,7 +93,7 @@ __device__ __forceinline__ void cx_barrier(CxCtl &c) {
             }
         }
     }
-    __syncthreads();
+    doda_sync();
     // (one lane polled; the others learn of a time-out at the next barrier through the flag: not needed — a dead call's
     // results are discarded by the host, it only has to terminate)
 }
@@ -224,14 +224,14 @@ __device__ __forceinline__ void cx_gemm_units(const doda_cx_op &op, int me, int 
                 ev[q] = __builtin_amdgcn_raw_buffer_load_b128(bwd ? rs_a : rs_r, ok ? ((unsigned)row * (unsigned)epi_ld + (unsigned)(nb0 * 16 + ck * 8)) * 2u : OOB, 0, CX_SC1);
             }
         }
-        __syncthreads();                                       // (strip / chunk buffer of the previous unit are done with)
+        doda_sync();                                       // (strip / chunk buffer of the previous unit are done with)
         for (int e = tid; e < K * rows_u; e += CX_THREADS) {   // the unit's slice of the table
             const int o = e >> (4 + tsh), rr = e & (rows_u - 1), row = tile0 * 16 + rr;
             int v = -1;
             if (row < n_out) v = identity ? row : op.tbl[(long long)o * op.tbl_ld + row];
             strip[e] = v;
         }
-        __syncthreads();
+        doda_sync();
         cx_stamp(me, 11);
         f32x4 acc[NBU_MAX];
 #pragma unroll
@@ -251,16 +251,16 @@ __device__ __forceinline__ void cx_gemm_units(const doda_cx_op &op, int me, int 
         // first two trips only request)
         for (int c = -2; c < NCH; c += 2) {
             if (c >= 0) {
-                __syncthreads();        // every wave is done with the chunk in LDS
+                doda_sync();        // every wave is done with the chunk in LDS
                 park(Ra);
             }
             issue(c + 2, Ra);
             if (c >= 0) {
-                __syncthreads();
+                doda_sync();
                 multiply(c);
             }
             if (c + 1 >= 0 && c + 1 < NCH) {
-                __syncthreads();
+                doda_sync();
                 park(Rb);
             }
             issue(c + 3, Rb);
@@ -273,16 +273,16 @@ __device__ __forceinline__ void cx_gemm_units(const doda_cx_op &op, int me, int 
                 }
             }
             if (c + 1 >= 0 && c + 1 < NCH) {
-                __syncthreads();
+                doda_sync();
                 multiply(c + 1);
             }
         }
-        __syncthreads();                // the chunk buffer becomes the reduction / output staging area
+        doda_sync();                // the chunk buffer becomes the reduction / output staging area
         cx_stamp(me, 16);
 #pragma unroll
         for (int j = 0; j < NBU_MAX; ++j)
             if (j < NBU) red[(wave * 8 + j) * 64 + lane] = acc[j];
-        __syncthreads();
+        doda_sync();
         // epilogue: wave j finishes channel block nb0 + j of every tile of the unit
         if (wave < nbu_here) {
             const int ch = (nb0 + wave) * 16 + g * 4;
@@ -333,7 +333,7 @@ __device__ __forceinline__ void cx_gemm_units(const doda_cx_op &op, int me, int 
                 for (int q = 0; q < 4; ++q) { wgst[ch + q] += st1[q]; wgst[CX_MAXC + ch + q] += st2[q]; }
             }
         }
-        __syncthreads();
+        doda_sync();
         cx_stamp(me, 17);
         {   // the unit's rows x channel blocks in 16-byte write-through stores
             const int cpr = nbu_here * 2;
@@ -369,10 +369,10 @@ __device__ __forceinline__ void cx_gemm(const doda_cx_op &op, int me, int G, cha
         else if (c < nWf + nAf) { const int fa = c - nWf, f2 = fa / CC; d = 0x40000000 | ((f2 / pl.tpw) << 16) | ((fa % CC) << 8) | (f2 % pl.tpw); }
         reinterpret_cast<int *>(smem + CX_DEC_OFF)[c] = d;
     }
-    __syncthreads();
+    doda_sync();
     cx_stamp(me, 21);
     if (pl.nbu >= 1 && pl.nbu <= NBU_MAX) cx_gemm_units(op, me, G, smem, pl);
-    __syncthreads();
+    doda_sync();
     if (op.stats) {   // this workgroup's partial row: what it accumulated over its units, zeros elsewhere
         const rsrc_t rs_s = cx_rsrc(op.stats);
         for (int e = threadIdx.x; e < 2 * op.c_out; e += CX_THREADS) {
@@ -414,7 +414,7 @@ __device__ __forceinline__ void cx_bnfwd(const doda_cx_op &op, int me, int G, ch
         g_ = op.gamma[tid]; b_ = op.beta[tid];
         if (op.running_mean && (me == 0 || !training)) { rm_ = op.running_mean[tid]; rv_ = op.running_var[tid]; }
     }
-    __syncthreads();
+    doda_sync();
     if (tid < C) {
         float mu, is;
         if (training) {
@@ -449,7 +449,7 @@ __device__ __forceinline__ void cx_bnfwd(const doda_cx_op &op, int me, int G, ch
         vec[2 * CX_MAXC + tid] = g_;
         vec[3 * CX_MAXC + tid] = b_;
     }
-    __syncthreads();
+    doda_sync();
     int r0, r1;
     cx_own_rows(rows, me, G, r0, r1);
     const int cpr = C >> 3;
@@ -482,7 +482,7 @@ __device__ __forceinline__ void cx_bnbwd(const doda_cx_op &op, int me, int G, ch
         is_ = op.invstd[tid]; mu_ = op.mean[tid]; ga_ = op.gamma[tid];
         if (me == 0 && op.dgamma && (op.flags & DODA_CX_F_ACCUM)) { dg_ = op.dgamma[tid]; db_ = op.dbeta[tid]; }
     }
-    __syncthreads();
+    doda_sync();
     if (tid < C) {
         double s1 = 0.0, s2 = 0.0;
         for (int p = 0; p < op.n_part; ++p) {
@@ -496,7 +496,7 @@ __device__ __forceinline__ void cx_bnbwd(const doda_cx_op &op, int me, int G, ch
         vec[4 * CX_MAXC + tid] = (float)(s2 / rows);
         if (me == 0 && op.dgamma) { op.dbeta[tid] = db_ + (float)s1; op.dgamma[tid] = dg_ + (float)s2; }
     }
-    __syncthreads();
+    doda_sync();
     int r0, r1;
     cx_own_rows(rows, me, G, r0, r1);
     const int cpr = C >> 3, csp = op.c_split;
@@ -548,14 +548,14 @@ __device__ __forceinline__ void cx_stats(const doda_cx_op &op, int me, int G, ch
             sred[(rl * 2 + 1) * C + col * 8 + q] = s2[q];
         }
     }
-    __syncthreads();
+    doda_sync();
     const rsrc_t rs_s = cx_rsrc(op.stats);
     for (int e = tid; e < 2 * C; e += CX_THREADS) {
         float t = 0.f;
         for (int k = 0; k < RL; ++k) t += sred[k * 2 * C + e];
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), rs_s, ((unsigned)me * 2u * (unsigned)C + (unsigned)e) * 4u, 0, CX_SC1);
     }
-    __syncthreads();
+    doda_sync();
 }
 
 __global__ __launch_bounds__(CX_THREADS) void coarse_exec(const doda_cx_op *__restrict__ ops, int n_ops, unsigned *sync, int G, int xcds) {
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(CX_THREADS) void coarse_exec(const doda_cx_op *__re
     for (int i = 0; i < n_ops; ++i) {
         int nxt = 0;
         if (threadIdx.x < OPW && i + 1 < n_ops) nxt = reinterpret_cast<const int *>(ops + i + 1)[threadIdx.x];
-        __syncthreads();
+        doda_sync();
         struct alignas(8) { int w[OPW]; } raw;
 #pragma unroll
         for (int k = 0; k < OPW; ++k) raw.w[k] = __builtin_amdgcn_readfirstlane(opbuf[i & 1][k]);
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(CX_THREADS) void coarse_exec(const doda_cx_op *__re
     }
     // the last workgroup to leave puts the barrier counter back to zero for the next launch (every workgroup is past its
     // last barrier once it has counted itself out; a launch whose barrier timed out still ends with a clean counter)
-    __syncthreads();
+    doda_sync();
     if (threadIdx.x == 0) {
         const unsigned old = __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == (unsigned)G - 1u) {

@@ -26,7 +26,7 @@ __device__ __forceinline__ int block_exclusive_sum(int v, int *total, int *lds /
     const int lane = lane_id(), wid = threadIdx.x >> 6;
     int inc = wave_inclusive_sum(v);
     if (lane == 63) lds[wid] = inc;
-    __syncthreads();
+    doda_sync();
     int base = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
@@ -34,7 +34,7 @@ __device__ __forceinline__ int block_exclusive_sum(int v, int *total, int *lds /
         if (w < wid) base += s;
         tot += s;
     }
-    __syncthreads();
+    doda_sync();
     *total = tot;
     return base + inc - v;
 }

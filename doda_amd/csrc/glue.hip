@@ -37,7 +37,7 @@ __global__ __launch_bounds__(GL_BLOCK) void cast_colsum(const float *__restrict_
     // fixed-order reduce over the row lanes: through LDS, column by column
     __shared__ float acc[GL_BLOCK];
     acc[threadIdx.x] = rl < lanes ? s : 0.f;
-    __syncthreads();
+    doda_sync();
     if (threadIdx.x < c) {
         float t = 0.f;
         for (int k = 0; k < lanes; ++k) t += acc[k * c + threadIdx.x];

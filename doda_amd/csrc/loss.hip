@@ -40,7 +40,7 @@ __global__ __launch_bounds__(CE_BLOCK) void ce_fwd(const float *__restrict__ log
         cnt += __shfl_xor(cnt, d, 64);
     }
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = loss; red[1][threadIdx.x >> 6] = cnt; }
-    __syncthreads();
+    doda_sync();
     if (threadIdx.x == 0) {
         float a = 0.f, b = 0.f;
         for (int w = 0; w < CE_BLOCK / 64; ++w) { a += red[0][w]; b += red[1][w]; }

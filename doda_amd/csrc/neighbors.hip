@@ -27,23 +27,23 @@ __device__ __forceinline__ void sweep_candidates(const float *__restrict__ cand,
     __shared__ float tile[NQ_BLOCK * 3];
     __shared__ int range[2];
     if (threadIdx.x == 0) { range[0] = 0x7fffffff; range[1] = 0; }
-    __syncthreads();
+    doda_sync();
     if (active && end > start) {
         atomicMin(&range[0], start);
         atomicMax(&range[1], end);
     }
-    __syncthreads();
+    doda_sync();
     const int lo = range[0], hi = range[1];
     for (int t0 = lo; t0 < hi; t0 += NQ_BLOCK) {
         const int n_here = hi - t0 < NQ_BLOCK ? hi - t0 : NQ_BLOCK;
         for (int e = threadIdx.x; e < n_here * 3; e += NQ_BLOCK) tile[e] = cand[(long long)t0 * 3 + e];
-        __syncthreads();
+        doda_sync();
         if (active) {
             const int b = start > t0 ? start - t0 : 0;
             const int e = end - t0 < n_here ? end - t0 : n_here;
             for (int c = b; c < e; ++c) visit(t0 + c, tile[c * 3], tile[c * 3 + 1], tile[c * 3 + 2]);
         }
-        __syncthreads();
+        doda_sync();
     }
 }
 

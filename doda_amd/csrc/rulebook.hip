@@ -245,7 +245,7 @@ __global__ __launch_bounds__(PAIR_TILE) void pairs_count(const int32_t *__restri
     const bool valid = j < n_rows && tbl[(long long)src * ld + j] >= 0;
     const unsigned long long b = __ballot(valid);
     if (lane_id() == 0) lds[threadIdx.x >> 6] = __popcll(b);
-    __syncthreads();
+    doda_sync();
     if (threadIdx.x == 0) {
         int s = 0;
         for (int w = 0; w < PAIR_TILE / 64; ++w) s += lds[w];
@@ -263,13 +263,13 @@ __global__ __launch_bounds__(256) void pairs_scan(int32_t *counts, int nt, int32
         const int v = i < nt ? row[i] : 0;
         const int inc = wave_inclusive_sum(v);
         if (lane_id() == 63) lds[threadIdx.x >> 6] = inc;
-        __syncthreads();
+        doda_sync();
         int base = 0, tot = 0;
         for (int w = 0; w < 4; ++w) {
             if (w < (int)(threadIdx.x >> 6)) base += lds[w];
             tot += lds[w];
         }
-        __syncthreads();
+        doda_sync();
         if (i < nt) row[i] = carry + base + inc - v;
         carry += tot;
     }
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(PAIR_TILE) void pairs_fill(const int32_t *__restric
     const bool valid = v >= 0;
     const unsigned long long b = __ballot(valid);
     if (lane_id() == 0) lds[threadIdx.x >> 6] = __popcll(b);
-    __syncthreads();
+    doda_sync();
     int base = counts[(long long)o * nt + blockIdx.x];
     for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += lds[w];
     if (valid) {

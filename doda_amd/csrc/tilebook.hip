@@ -9,8 +9,12 @@
 // the dense table for that tile.  spconv has no counterpart (it keeps pair lists and gathers per offset);
 // the dense table stays the source of truth and the reference for parity (tests/test_gpu_tile.py).
 #include "common.hpp"
+#include <stdlib.h>
 #include "tilebook.hpp"
 
+#ifdef DODA_TB_DEBUG
+__device__ unsigned g_tb_dbg[8 + 2 * 2048];   // [0] hits, [1] tile, [2] U, [3] P, [4] where; then the keys before / after the sort
+#endif
 namespace {
 
 constexpr int HCAP = 4096;   // hash slots: the insert loop stops adding once TB_UMAX + 256 keys are in
@@ -53,23 +57,23 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
         }
         __shared__ int wmn[4], wmx[4];
         if ((tid & 63) == 0) { wmn[tid >> 6] = mn; wmx[tid >> 6] = mx; }
-        __syncthreads();
+        doda_sync();
         const int lo = min(min(wmn[0], wmn[1]), min(wmn[2], wmn[3])), hi = max(max(wmx[0], wmx[1]), max(wmx[2], wmx[3]));
         const long long span = (long long)hi - lo + 1;
         if (hi >= 0 && span <= (long long)BMW * 32) {
             const int W = (int)((span + 31) >> 5);              // words in use
             const int wpt = (W + 255) / 256;                    // consecutive words per thread (<= 24)
             for (int k = 0; k < wpt; ++k) { const int w = tid * wpt + k; if (w < W) htab[w] = 0u; }
-            __syncthreads();
+            doda_sync();
 #pragma unroll
             for (int o = 0; o < TB_K; ++o)
                 if (e[o] >= 0) atomicOr(&htab[(unsigned)(e[o] - lo) >> 5], 1u << ((unsigned)(e[o] - lo) & 31u));
-            __syncthreads();
+            doda_sync();
             int c = 0;
             for (int k = 0; k < wpt; ++k) { const int w = tid * wpt + k; if (w < W) c += __popc(htab[w]); }
             const int incl = wave_inclusive_sum(c);
             if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-            __syncthreads();
+            doda_sync();
             int base = incl - c;
             for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
             const int U = wsum[0] + wsum[1] + wsum[2] + wsum[3];
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
                 run += __popc(htab[w]);
             }
             for (int k = U + tid; k < TB_UMAX; k += 256) ul[tb_upos(k)] = -1;
-            __syncthreads();
+            doda_sync();
             // ... and the list: the set bits in order.  The rows come in a few dense runs (hundreds of consecutive row
             // numbers = ten consecutive FULL words), so the words are dealt out by BYTES, interleaved over the threads —
             // a thread that walked its own consecutive words emitted a whole run alone while the others idled
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
 
     for (int k = tid; k < HCAP; k += 256) htab[k] = EMPTY;
     if (tid == 0) cnt = 0;
-    __syncthreads();
+    doda_sync();
 
     // ---- 1. distinct rows ----  (loops over o stay unrolled: e[] must live in registers)
 #pragma unroll
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
             slot = (slot + 1) & (HCAP - 1);
         }
     }
-    __syncthreads();
+    doda_sync();
     const int U = cnt;
     if (tid == 0) {
         v.ucount[tile] = U;
@@ -172,27 +176,41 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
         const int incl = wave_inclusive_sum(c);
         if ((tid & 63) == 63) wsum[tid >> 6] = incl;
         for (int k = tid; k < UQ; k += 256) uq[k] = EMPTY;
-        __syncthreads();
+        doda_sync();
         int base = incl - c;
         for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
 #pragma unroll
         for (int k = 0; k < HCAP / 256; ++k)
             if (mine[k] != EMPTY) uq[base++] = mine[k];
-        __syncthreads();
+        doda_sync();
     }
     int P = 2;                    // sort only the power of two that holds the keys (EMPTY pads sort last)
     while (P < U) P <<= 1;
-    // compare-exchange p of a stage pairs idx = insert-zero-bit(p, j) with idx | j.  Thread tid takes
-    // p = tid + 256 q, so for j <= 64 both elements lie in the 128-element chunk its own wave handles and
-    // LDS operations of one wave execute in order: only stages with j >= 128 (and the first j <= 64 stage
-    // after one) need the workgroup barrier — 12 barriers instead of 55 for P = 1024.  (P = 2048: a thread's four
-    // pairs p = tid + 256 q still stay inside its wave's chunks for j <= 64.)
-    bool crossed = true;
+#ifdef DODA_TB_DEBUG
+    __shared__ unsigned uq0[2048];
+    __shared__ int wP[4], wStages[4];
+    for (int k = tid; k < 2048; k += 256) uq0[k] = uq[k];
+    if ((tid & 63) == 0) { wP[tid >> 6] = P * 10000 + U; wStages[tid >> 6] = 0; }
+    doda_sync();
+#endif
+    // compare-exchange p of a stage pairs idx = insert-zero-bit(p, j) with idx | j; a workgroup barrier in front of EVERY stage.
+    // (Round 3 elided the barriers of the stages with j <= 64 — both elements of a pair then lie in the 128-element chunk the
+    // thread's own wave handles, and LDS operations of one wave execute in order — 12 barriers instead of 55.  Round 5 found that
+    // sort WRONG about once in 50 000 tiles: a list with one key twice and its neighbour missing, the missing row's local
+    // indices then pointing at whatever rank the hash slot held — wrong neighbours, sometimes garbage — in ~1 of 400 builds of a
+    // Z-ordered 2 M-voxel table (131 of its tiles take this path; tools/rbdet.py).  The elision was not the cause (next comment),
+    // but it rested on the same unchecked assumption about what the compiler waits for, and only tiles whose rows span more than
+    // the bitmap form covers come here: the barriers cost nothing measurable.)
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            const bool cross = j >= 128;
-            if (cross || crossed) __syncthreads();
-            crossed = cross;
+            // (explicit: hipcc emitted this in-loop barrier as a bare s_barrier — the compare-exchange's ds_write_b32 pair sits in a
+            // conditionally executed block and its wait-count pass lost them across the back edge — so a wave could arrive with its
+            // stores still in flight and the next stage read the old keys: THE bug above, with or without the elision)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            doda_sync();
+#ifdef DODA_TB_DEBUG
+            if ((tid & 63) == 0) wStages[tid >> 6] += 1;
+#endif
             for (int p = tid; p < (P >> 1); p += 256) {
                 const int idx = ((p & ~(j - 1)) << 1) | (p & (j - 1)), ixj = idx | j;
                 const bool up = (idx & k) == 0;
@@ -201,7 +219,28 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
             }
         }
     }
-    __syncthreads();
+    doda_sync();
+#ifdef DODA_TB_DEBUG
+    {
+        __shared__ int viol;
+        if (tid == 0) viol = 0;
+        doda_sync();
+        for (int k = tid; k + 1 < U; k += 256)
+            if (!(uq[k] < uq[k + 1])) atomicAdd(&viol, 1);
+        doda_sync();
+        if (viol > 0) {
+            __shared__ unsigned first_hit;
+            if (tid == 0) first_hit = atomicAdd(&g_tb_dbg[0], 1u);
+            doda_sync();
+            if (first_hit == 0) {
+                if (tid == 0) { g_tb_dbg[1] = (unsigned)tile; g_tb_dbg[2] = (unsigned)U; g_tb_dbg[3] = (unsigned)P; g_tb_dbg[4] = (unsigned)viol; }
+                if (tid < 4) { g_tb_dbg[8 + 4096 - 8 + tid] = (unsigned)wP[tid]; g_tb_dbg[8 + 4096 - 4 + tid] = (unsigned)wStages[tid]; }
+                for (int k = tid; k < 2048; k += 256) { g_tb_dbg[8 + k] = uq0[k]; g_tb_dbg[8 + 2048 + k] = uq[k]; }
+            }
+        }
+        doda_sync();
+    }
+#endif
     for (int k = tid; k < TB_UMAX; k += 256) ul[tb_upos(k)] = k < U ? (int32_t)uq[k] : -1;
 
     // ---- 3. local indices ----
@@ -214,7 +253,7 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
         while (htab[slot] != key) slot = (slot + 1) & (HCAP - 1);
         hrank[slot] = (unsigned short)k;
     }
-    __syncthreads();
+    doda_sync();
     uint32_t *li = v.lidx + (size_t)tile * (TB_T * TB_LW) + tb_lpos(tid);
 #pragma unroll
     for (int w3 = 0; w3 < TB_LW; ++w3) {
@@ -237,6 +276,13 @@ __global__ __launch_bounds__(256) void tilebook_build(const int32_t *__restrict_
 
 }  // namespace
 
+#ifdef DODA_TB_DEBUG
+extern "C" int doda_tilebook_debug(unsigned *host_buf /*[8 + 4096]*/, int reset) {
+    if (hipMemcpyFromSymbol(host_buf, HIP_SYMBOL(g_tb_dbg), sizeof(unsigned) * (8 + 4096)) != hipSuccess) return -1;
+    if (reset) { unsigned z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_tb_dbg), &z, 4); }
+    return 0;
+}
+#endif
 extern "C" int32_t doda_tilebook_tile(void) { return TB_T; }
 extern "C" int32_t doda_tilebook_umax(void) { return TB_UMAX; }
 

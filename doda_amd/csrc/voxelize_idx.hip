@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void vox_max(const int32_t *__restrict__ count
     // one atomic per workgroup, and only when it would raise the value (2048 waves on one address took 25 us)
     __shared__ int wmx[4];
     if (lane_id() == 0) wmx[threadIdx.x >> 6] = mx;
-    __syncthreads();
+    doda_sync();
     if (threadIdx.x == 0) {
         const int a = wmx[0] > wmx[1] ? wmx[0] : wmx[1], b = wmx[2] > wmx[3] ? wmx[2] : wmx[3];
         const int bm = a > b ? a : b;

@@ -38,6 +38,41 @@ static inline at::Tensor poisoned(at::Tensor t) {
 template <class... A> static inline at::Tensor pempty(A &&...a) { return poisoned(at::empty(std::forward<A>(a)...)); }
 static inline at::Tensor pempty(at::IntArrayRef sizes, const at::TensorOptions &o) { return poisoned(at::empty(sizes, o)); }
 template <class... A> static inline at::Tensor pempty_like(A &&...a) { return poisoned(at::empty_like(std::forward<A>(a)...)); }
+// Debug aid (DODA_NANCHECK=1, with DODA_POISON=1): after every operator of this file its outputs are searched for NaN (a
+// synchronisation each: slow) and the first hit is reported with the operator and its shapes — where a poisoned byte was read.
+static const bool g_nancheck = [] { const char *e = getenv("DODA_NANCHECK"); return e && e[0] == '1'; }();
+static int g_nan_reports = 0;
+// Debug aid (DODA_FPLOG=1): a fingerprint (int64 sum of the raw 32-bit words) of every operator output, in call order;
+// fp_log_take() hands the list over and clears it.  Two passes over the same inputs must log the same list: the first entry that
+// differs names the operator whose output changed (tools/fwddet.py).
+static const bool g_fplog = [] { const char *e = getenv("DODA_FPLOG"); return e && e[0] == '1'; }();
+static std::vector<std::tuple<std::string, int64_t>> g_fp;
+static std::mutex g_fp_mu;
+static inline void fp_log(const at::Tensor &t, const char *what, const char *which, long long a, long long b, long long c) {
+    if (!t.defined() || t.numel() == 0 || !t.is_cuda()) return;
+    at::NoGradGuard ng;
+    at::Tensor flat = t.detach().contiguous().reshape({-1});
+    const int64_t bytes = flat.numel() * flat.element_size();
+    at::Tensor words = bytes % 4 == 0 ? flat.view(at::kInt) : flat.view(at::kByte);
+    const int64_t v = at::sum(words, at::kLong).item<int64_t>();
+    char name[160];
+    snprintf(name, sizeof(name), "%s/%s %lld %lld %lld [%lld]", what, which, a, b, c, (long long)flat.numel());
+    std::lock_guard<std::mutex> lock(g_fp_mu);
+    g_fp.emplace_back(std::string(name), v);
+}
+static inline void nan_check(const at::Tensor &t, const char *what, const char *which, long long a = 0, long long b = 0, long long c = 0) {
+    if (g_fplog) fp_log(t, what, which, a, b, c);
+    if (!g_nancheck || !t.defined() || !t.is_floating_point() || t.numel() == 0 || g_nan_reports >= 20) return;
+    at::NoGradGuard ng;
+    at::Tensor bad = at::isnan(t.detach());
+    const long long n = bad.sum().item<int64_t>();
+    if (n > 0) {
+        ++g_nan_reports;
+        at::Tensor pos = bad.reshape({-1}).nonzero().reshape({-1});
+        fprintf(stderr, "[doda nancheck] %s: %lld NaN in %s %s, first at flat index %lld (of %lld); args %lld %lld %lld\n", what, n, which,
+                c10::str(t.sizes()).c_str(), (long long)pos[0].item<int64_t>(), (long long)t.numel(), a, b, c);
+    }
+}
 
 // Host-side time of the extension's own entry points (DODA_HOST_TIMING=1; tools/hostcount.py prints it): where the issuing
 // thread spends a step — the step sits at the host / GPU crossover.
@@ -235,6 +270,11 @@ at::Tensor gather(const at::Tensor &x_in, const at::Tensor &w, const c10::option
         break;
     }
     if (epi) epi->stats = (with_stats && stats_rows > 0) ? (totals ? stats : stats.narrow(0, 0, stats_rows)) : at::Tensor();
+    if (g_nancheck || g_fplog) {
+        nan_check(x, "gather", "INPUT x", K, n_out, layout);
+        nan_check(y, "gather", "y", K, n_out, layout);
+        if (epi && epi->stats.defined()) nan_check(epi->stats, "gather", "statistics", K, n_out, stats_rows);
+    }
     return y;
 }
 
@@ -574,6 +614,12 @@ void issue_wgrads(std::vector<PendingWgrad> &q, const c10::hip::HIPStream &st) {
     }
     for (size_t k = 0; k < q.size(); ++k)
         if (fresh[k].defined()) q[k].weight.mutable_grad() = fresh[k];
+    if (g_nancheck || g_fplog)
+        for (size_t k = 0; k < q.size(); ++k) {
+            nan_check(q[k].a, "weight gradient", "INPUT a", (long long)k, q[k].n_rows, q[k].a.size(1));
+            nan_check(q[k].b, "weight gradient", "INPUT b", (long long)k, q[k].n_rows, q[k].b.size(1));
+            nan_check(q[k].weight.grad(), "weight gradient", "dw", (long long)k, q[k].n_rows, (long long)jobs[k].flags);
+        }
 }
 
 // jobs whose weight already appeared earlier in the queue wait for a follow-up call
@@ -1038,6 +1084,12 @@ struct BNNode : public torch::autograd::Node {
             db = dz.sum(0);
         }
         if (extra.defined()) dx = dx + extra;
+        if (g_nancheck || g_fplog) {
+            nan_check(dy, "bn backward", "INPUT dy", x.size(0), x.size(1));
+            nan_check(dx, "bn backward", "dx", x.size(0), x.size(1), stats.defined() ? (stats.scalar_type() == at::kDouble ? 2 : 1) : 0);
+            nan_check(dg, "bn backward", "dgamma", x.size(0), x.size(1));
+            nan_check(db, "bn backward", "dbeta", x.size(0), x.size(1));
+        }
         if (task_should_compute_output(0)) out[0] = dx;
         if (direct_p) {
             if (plain_accumulating_backward()) {
@@ -1136,6 +1188,12 @@ std::vector<at::Tensor> bn_relu_impl(const at::Tensor &x_in, const at::Tensor &w
                                relu ? 1 : 0, y.data_ptr(), (float *)mean.data_ptr(), (float *)invstd.data_ptr(),
                                ws.data_ptr(), wsb, stream_of(x)),
               "doda_bn_relu_fwd");
+        }
+        if (g_nancheck || g_fplog) {
+            nan_check(x, "bn forward", "INPUT x", x.size(0), x.size(1));
+            nan_check(y, "bn forward", "y", x.size(0), x.size(1), stats.defined() ? (stats.scalar_type() == at::kDouble ? 2 : 1) : 0);
+            nan_check(mean, "bn forward", "mean", x.size(0), x.size(1));
+            nan_check(invstd, "bn forward", "invstd", x.size(0), x.size(1));
         }
     }
     g_last_bn.reset();
@@ -1898,6 +1956,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
               return moved;
           }, "re-home every parameter's gradient in its bucket view (copy / zero-fill only where it is not there already)");
     m.def("flush_wgrads", &flush_wgrads);
+    m.def("fp_log_take", []() { std::lock_guard<std::mutex> lock(g_fp_mu); auto out = g_fp; g_fp.clear(); return out; },
+          "DODA_FPLOG=1: the (operator, fingerprint) list logged since the last call");
     m.def("stats_totals_begin_pass", &stats_totals_begin_pass, "a new forward pass: the next statistics totals come out of a fresh zeroed arena");
     m.def("set_stats_totals", [](bool on) { g_stats_totals = on; return g_stats_totals; },
           "BatchNorm statistics of the conv epilogues as fp64 totals (one-launch BatchNorm) or as per-workgroup rows + a reduction launch");

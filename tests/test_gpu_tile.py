@@ -46,25 +46,25 @@ def _scene_table(m, seed=0, batch=2, shape=(80, 70, 60)):
     return idx, ops.rulebook_subm(idx, list(shape), batch, 3)
 
 
-def _far_apart_table(n=300000):
+def _far_apart_table(n=300000, second_div=1):
     """Every tile references two clusters of rows ~200k rows apart (span above the builder's 131072-bit bitmap: the hash +
     sort form), ~570 distinct rows per tile; some entries absent."""
     t = torch.arange(n, dtype=torch.int64)
     tbl = torch.empty(27, n, dtype=torch.int64)
     for o in range(27):
-        tbl[o] = (t + o) % n if o < 13 else (t + 200000 + o) % n
+        tbl[o] = (t + o) % n if o < 13 else (t // second_div + 200000 + o) % n   # (second_div = 2: ~410 distinct rows per tile)
     g = torch.Generator().manual_seed(3)
     tbl[torch.rand(27, n, generator=g) < 0.3] = -1
     tbl[13] = t   # the centre tap is always present
     return tbl.int().to(dev())
 
 
-@pytest.mark.parametrize("m", [40000, 1000, 256, 255, -1])
+@pytest.mark.parametrize("m", [40000, 1000, 256, 255, -1, -2])
 def test_tilebook_is_a_lossless_encoding(native_lib, m):
     """m > 0: scene tables (rows of a tile within a few thousand row numbers: the builder's bitmap form); m = -1: a table
     whose tiles reference two far-apart clusters (the hash + bitonic-sort form).  Same format, same checks."""
     ext = _ext_or_skip()
-    tbl = _far_apart_table() if m < 0 else _scene_table(m, seed=m)[1]
+    tbl = _far_apart_table(second_div=2 if m == -2 else 1) if m < 0 else _scene_table(m, seed=m)[1]
     n = tbl.shape[1]
     t = ext.with_tilebook(tbl)
     assert ext.has_tilebook(t) and torch.equal(t, tbl)
@@ -85,6 +85,24 @@ def test_tilebook_is_a_lossless_encoding(native_lib, m):
         assert loc.max() <= len(uniq)
         back = np.where(absent, -1, ulist[tile][np.maximum(loc - 1, 0)])
         assert np.array_equal(back, ent)
+
+
+def test_tilebook_hash_form_is_the_same_every_time(native_lib):
+    """Round 5 regression: the hash + bitonic-sort form of the builder (tiles whose rows span more than its bitmap covers) used to
+    leave out workgroup barriers between sort stages that stay inside one wave's chunk; about once in 50 000 tiles a list came out
+    with one key twice and its neighbour missing (wrong local indices, garbage rows in the conv: the rare wrong steps of 1 cm
+    batches in Z-order numbering).  A table whose 1172 tiles ALL take that form, built 400 times: every build must
+    equal the first byte for byte, and the first is checked by test_tilebook_is_a_lossless_encoding."""
+    from doda_amd import ops
+    for div in (2, 1):          # ~410 distinct rows per tile (a 512-key sort: where the race was seen) and ~570 (1024 keys)
+        tbl = _far_apart_table(second_div=div)
+        ref = ops.tilebook_build(tbl)
+        torch.cuda.synchronize()
+        ref = ref.clone()
+        bad = 0
+        for _ in range(400):
+            bad += int(not torch.equal(ops.tilebook_build(tbl), ref))
+        assert bad == 0, "%d of 400 builds differ (second_div %d)" % (bad, div)
 
 
 def _oracle_conv(x, w, tbl, layout):

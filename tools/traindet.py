@@ -22,6 +22,9 @@ cfg = default_cfg()
 spconv.functional.set_deferred_wgrad(True)
 wp = bool(spconv.functional.WGRAD_PAIRS)
 use_pf = os.environ.get("PREFETCH", "1") == "1"
+inline = os.environ.get("INLINE", "0") == "1"      # rulebooks built in the forward pass, on the step's own stream
+if inline:
+    use_pf = False
 res = []
 for r in range(runs):
     torch.manual_seed(0)
@@ -36,8 +39,23 @@ for r in range(runs):
         if pf:
             pyr = PyramidPrefetcher.take(pend[0], dev)
             pend[0] = pf.submit(bd, wp, tile_levels_for(torch.bfloat16), resident=True)
-        loss = cross_entropy(voxelize_and_run(cfg, net, bd, dev, feature_dtype=torch.bfloat16, inputs_ready=True, pyramid=pyr), bd["labels"], ignore_index=255)
-        loss.backward(); opt.step()
+        loss = cross_entropy(voxelize_and_run(cfg, net, bd, dev, feature_dtype=torch.bfloat16, inputs_ready=not inline, pyramid=pyr), bd["labels"], ignore_index=255)
+        loss.backward()
+        if os.environ.get("GRADCHECK", "0") == "1":     # which parameter's gradient is off, and at which step
+            names = [n for n, p in net.named_parameters()]
+            norms = torch.stack(torch._foreach_norm([p.grad.float() for p in net.parameters()])).cpu()
+            if r == 0:
+                ref_norms = globals().setdefault("REF", {})
+                ref_norms[k] = norms
+            else:
+                ref = globals()["REF"].get(k)
+                if ref is not None and not torch.equal(ref, norms) and not globals().get("REPORTED_%d" % r):
+                    globals()["REPORTED_%d" % r] = True
+                    offs = [(names[j], float(ref[j]), float(norms[j])) for j in range(len(names)) if ref[j] != norms[j]]
+                    offs.sort(key=lambda t: -abs(t[2] - t[1]) / (abs(t[1]) + 1e-30))
+                    print("run %d step %d: %d gradient norms differ from run 0; largest relative deviations: %s" % (
+                        r, k, len(offs), ["%s %.6g -> %.6g" % o for o in offs[:5]]), flush=True)
+        opt.step()
         losses.append(loss.detach().clone())
     torch.cuda.synchronize()
     if pf:
