@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_gather(const typename T::elem *__res
         const int o = e / TM, r = e - o * TM;
         idx_tile[e] = (r0 + r < n_out) ? tbl[(long long)o * ld + r0 + r] : -1;
     }
-    __syncthreads();
+    doda_sync();
 
     const int wrow = wid * 16 * S;  // this wave's first row inside the tile
     if (r0 + wrow >= n_out) return;
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
             if ((rank & 3) == wid) mine |= m & (0u - m);
         active = __builtin_amdgcn_readfirstlane(mine);
     }
-    __syncthreads();
+    doda_sync();
 
     f32x4 acc[S][NBW];
 #pragma unroll
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb) part[wid - 1][s][nb][lane] = acc[s][nb];
         }
-        __syncthreads();
+        doda_sync();
         if (wid > 0) return;
 #pragma unroll
         for (int w = 0; w < 3; ++w)
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
         }
     }
     if constexpr (STATS) {
-        if constexpr (!SPLIT) __syncthreads();   // the four waves hold four row ranges of the tile
+        if constexpr (!SPLIT) doda_sync();   // the four waves hold four row ranges of the tile
         if (wid == 0 && i == 15) {
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {

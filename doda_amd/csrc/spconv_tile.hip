@@ -172,14 +172,14 @@ __device__ __forceinline__ void stats_flush(f32x4 (&lst)[2], int i, int g, int w
 #pragma unroll
     for (int q = 0; q < 4; ++q) { st1[q] = row_sum16(st1[q]); st2[q] = row_sum16(st2[q]); }
     if (i == 15) { sred[wid][0][g] = st1; sred[wid][1][g] = st2; }
-    __syncthreads();
+    doda_sync();
     const int col = nb0 * 16 + 4 * g;
     if (wid == 0 && i == 15 && col < nc) {
         const f32x4 a1 = (sred[0][0][g] + sred[1][0][g]) + (sred[2][0][g] + sred[3][0][g]);
         const f32x4 a2 = (sred[0][1][g] + sred[1][1][g]) + (sred[2][1][g] + sred[3][1][g]);
         stats_emit(ep, part, nc, col, a1, a2);
     }
-    __syncthreads();   // sred is reused by the next channel block
+    doda_sync();   // sred is reused by the next channel block
 }
 
 // PERSISTENT: 3 workgroups per CU (LDS footprint), XCD (blockIdx & 7) walks its own contiguous range of
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
             for (int o = 0; o < TB_K; ++o) tab_s[o * TB_T + tid] = (unsigned)(t0 + tid) < (unsigned)n_out ? te[o] : -1;
         }
         TILE_STAMP(1);
-        __syncthreads();
+        doda_sync();
         TILE_STAMP(2);
 
         for (int nb0 = 0; nb0 < NB; nb0 += NBA) {
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void conv_tile(const void *
             }
         }
         TILE_STAMP(4);
-        __syncthreads();   // the next tile overwrites the staged rows
+        doda_sync();   // the next tile overwrites the staged rows
         TILE_STAMP(5);
     }
     if constexpr (STATS) {   // the workgroup's partial row (zeros when it had no tile)
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile16(const void *__restrict__ x
             for (int o = 0; o < TB_K; ++o) tab_s[o * TB_T + tid] = (unsigned)(t0 + tid) < (unsigned)n_out ? te[o] : -1;
         }
         TILE_STAMP(1);
-        __syncthreads();
+        doda_sync();
         TILE_STAMP(2);
 
         // ---- requests, in the order their data is needed (vmcnt retires in order): this tile's epilogue operands, the NEXT
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile16(const void *__restrict__ x
         tile_epilogue<S, OUT32, STATS, true>(acc, pre, row0, i, g, 0, nc, n_out, rs_y, res, ep, lst, bnv_s);
         U = Unext;
         TILE_STAMP(4);
-        __syncthreads();   // the next tile overwrites the staged rows
+        doda_sync();   // the next tile overwrites the staged rows
         TILE_STAMP(5);
     }
     if constexpr (STATS) stats_flush(lst, i, g, wid, 0, nc, ep, (long long)blockIdx.x);

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(512) void wgrad_dma_reduce(const WdRJobs jobs) {
     }
     for (int q = 0; b < n_part; b += 16, ++q) a[q & 7] += d.part[(size_t)b * (TB_K * 256) + e];
     red[p][jx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    __syncthreads();
+    doda_sync();
     if (p == 0) {
         float v = 0.f;
 #pragma unroll

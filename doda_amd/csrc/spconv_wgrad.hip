@@ -224,7 +224,7 @@ __device__ __forceinline__ void wgrad_body(const typename T::elem *__restrict__ 
     }
     for (long long r0 = r_begin; r0 < r_end; r0 += RT) {
         // ---- dY tile (already in registers) -> shared LDS ----
-        __syncthreads();
+        doda_sync();
 #pragma unroll
         for (int k = 0; k < NDY; ++k) {
             const int e = threadIdx.x + k * 256;
@@ -243,7 +243,7 @@ __device__ __forceinline__ void wgrad_body(const typename T::elem *__restrict__ 
             load_dy(r0 + RT);
             load_idx(r0 + RT);
         }
-        __syncthreads();
+        doda_sync();
         kfrag bf[TB][T::KSTEPS];
 #pragma unroll
         for (int y_ = 0; y_ < TB; ++y_) T::template frags<SB>(b_tile, g, i, y_ * 16, bf[y_]);
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi(const RJob *__restrict
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     part[rl][el] = s;
-    __syncthreads();
+    doda_sync();
     if (rl == 0 && q < d.n_quad) {
         float4 t = part[0][el];
 #pragma unroll 4
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float *__restrict__ pa
     if (e < n_elem)
         for (int r = rl; r < R; r += 16) s += partial[(long long)r * n_elem + e];
     part[rl][el] = s;
-    __syncthreads();
+    doda_sync();
     if (rl == 0 && e < n_elem) {
         float t = 0.f;
 #pragma unroll

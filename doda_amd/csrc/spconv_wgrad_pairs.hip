@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void wgrad_pairs_reduce(const RJob *__restrict
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     part[rl][el] = s;
-    __syncthreads();
+    doda_sync();
     if (rl == 0 && q < d.n_quad) {
         float4 t = part[0][el];
 #pragma unroll 4

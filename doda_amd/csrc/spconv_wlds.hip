@@ -69,14 +69,14 @@ __device__ __forceinline__ void wlds_epilogue(f32x4 (&acc)[S], const u32x2 (&pre
 #pragma unroll
         for (int q = 0; q < 4; ++q) { st1[q] = row_sum16(st1[q]); st2[q] = row_sum16(st2[q]); }
         if (i == 15) { sred[wid][0][g] = st1; sred[wid][1][g] = st2; }
-        __syncthreads();
+        doda_sync();
         if (wid == 0 && i == 15) {
             f32x4 a1 = sred[0][0][g], a2 = sred[0][1][g];
 #pragma unroll
             for (int w = 1; w < 8; ++w) { a1 += sred[w][0][g]; a2 += sred[w][1][g]; }
             stats_emit(ep, (long long)part, WCH, col, a1, a2);
         }
-        __syncthreads();   // sred is reused by the next channel block / tile
+        doda_sync();   // sred is reused by the next channel block / tile
     }
 }
 
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(512) void conv_wlds48(const unsigned short *__restr
             if (e < WK * WNB * W_SLOTS) wl[e] = tmp[k];
         }
     }
-    __syncthreads();
+    doda_sync();
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int row0 = tile * TM + wid * RW;
