@@ -7,6 +7,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from doda_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, "tools", "_tbdbg", "libdoda_hip.so")
+if not os.path.exists(_lib.LIB_PATH) or "--build" in sys.argv:      # (build it in the container: hipcc cross-compiles; the .so travels)
+    import subprocess
+    from doda_amd import build as B
+    B.build_native(verbose=False)
+    os.makedirs(os.path.dirname(_lib.LIB_PATH), exist_ok=True)
+    obj = os.path.join(os.path.dirname(_lib.LIB_PATH), "tilebook.o")
+    subprocess.check_call([B.HIPCC, *B.FLAGS, "-DDODA_TB_DEBUG", "-c", os.path.join(B.HERE, "csrc", "tilebook.hip"), "-o", obj])
+    objs = [os.path.join(B.OBJ, f) for f in sorted(os.listdir(B.OBJ)) if f.endswith(".o") and f != "tilebook.o"]
+    subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", obj, *objs, "-o", _lib.LIB_PATH])
+    if "--build" in sys.argv:
+        sys.exit(0)
 import numpy as np, torch
 from doda_amd import ops, spconv
 from doda_amd.collate import reorder_voxels
