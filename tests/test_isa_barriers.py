@@ -61,3 +61,28 @@ def test_library_kernels_reach_no_barrier_with_a_pending_lds_store():
     tool = _tool()
     for name in ("tilebook", "rulebook", "voxelize_idx", "core", "glue", "loss"):
         assert tool.check_file(os.path.join(ROOT, "doda_amd", "csrc", name + ".hip")) == 0, name
+
+
+def test_the_analysis_tracks_lds_dma_by_vmcnt():
+    """`buffer_load ... lds` writes LDS under vmcnt: lgkmcnt(0) in front of the barrier does not publish it, vmcnt(0) does."""
+    tool = _tool()
+    k = """_Z3dmav:
+	s_mov_b32 m0, s4
+	buffer_load_dwordx4 v1, s[8:11], 0 offen lds
+	s_waitcnt lgkmcnt(0)
+	s_barrier
+	s_waitcnt vmcnt(0)
+	s_barrier
+	s_endpgm""".splitlines()
+    assert list(tool.check_kernel(k[0], k, "dma")) == [4]
+    assert tool.check_kernel(k[0], k, "store") == {}
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_wgrad_dma16_publishes_its_staged_buffers_behind_vmcnt0():
+    """The LDS-DMA weight-gradient kernel (spconv_wdma.hip) is double-buffered: of its eleven barriers exactly the eight of the two
+    inlined flush() sites run with the next item's DMA in flight (they exchange through the buffer that DMA does not target); the three
+    that publish a staged buffer -- prologue and the two loop tops -- are behind s_waitcnt vmcnt(0)."""
+    tool = _tool()
+    assert tool.check_file(os.path.join(ROOT, "doda_amd", "csrc", "spconv_wdma.hip"), verbose=False) == 0
+    assert tool.check_file.last_dma_barriers == 8

@@ -4,7 +4,11 @@
 For every kernel of the given csrc/*.hip files (all by default; cross-compiled to gfx950 ISA with the library's flags, no GPU needed)
 the control-flow graph is rebuilt from the assembly text and a forward may-analysis runs over it: a ds_write* / ds_* update without
 a following `s_waitcnt ... lgkmcnt(0)` leaves the state "LDS store pending"; states are OR-ed at joins (back edges included) until
-nothing changes; an s_barrier reached in the pending state is reported.  This is the hazard of DESIGN.md §9 (round 5): hipcc's
+nothing changes; an s_barrier reached in the pending state is reported.  The same analysis runs a second time for LDS-DMA
+(`buffer_load_* ... lds`: the LDS write is counted by vmcnt, so the state clears at `s_waitcnt vmcnt(0)` only -- every wait of the one
+kernel that uses it, spconv_wdma, is vmcnt(0)).  That count is informational: a double-buffered kernel holds barriers with the NEXT
+buffer's DMA in flight by design (wgrad_dma16: the eight barriers of its two inlined flush() sites, which exchange through the buffer
+the DMA does not target; the barriers that publish a staged buffer -- prologue and the two loop tops -- must NOT be in the list).  This is the hazard of DESIGN.md §9 (round 5): hipcc's
 wait-count pass lost the stores of a conditionally executed block across a loop back edge and emitted a bare s_barrier in the tilebook
 builder's sort.  Since then every barrier of the library is doda_sync() (explicit wait): the expected result is zero reports;
 `--source <file.hip>` checks any other source (e.g. an old revision: `git show <rev>:doda_amd/csrc/tilebook.hip > /tmp/old.hip`).
@@ -31,7 +35,24 @@ def waits_lgkm0(rest):
     return False
 
 
-def check_kernel(name, lines):
+def waits_vm0(rest):
+    m = re.search(r"vmcnt\((\d+)\)", rest)
+    if m:
+        return int(m.group(1)) == 0
+    m = re.search(r"^\s*(0x[0-9a-fA-F]+|\d+)\s*$", rest)      # raw immediate: vmcnt = bits 15:14 | 3:0
+    if m:
+        v = int(m.group(1), 0)
+        return ((v & 0xF) | ((v >> 14) & 3) << 4) == 0
+    return False
+
+
+# LDS-DMA (`buffer_load_* ... lds`, `global_load_lds_*`): the LDS write is counted by vmcnt, not lgkmcnt
+LDS_DMA = re.compile(r"^\s*(buffer_load_\w+\s.*\blds\b|global_load_lds_\w+)")
+HAZARDS = {"store": (LDS_WRITE, waits_lgkm0), "dma": (LDS_DMA, waits_vm0)}
+
+
+def check_kernel(name, lines, hazard="store"):
+    SET, cleared = HAZARDS[hazard]
     # basic blocks
     leaders = {0}
     for i, l in enumerate(lines):
@@ -73,11 +94,11 @@ def check_kernel(name, lines):
         a, b = blocks[bi]
         for i in range(a, b):
             l = lines[i]
-            if LDS_WRITE.match(l):
+            if SET.match(l):
                 pending = i
             else:
                 m = WAIT.match(l)
-                if m and waits_lgkm0(m.group(1)):
+                if m and cleared(m.group(1)):
                     pending = False
                 elif re.match(r"^\s*s_barrier\b", l) and pending is not False:
                     reports[i] = pending if pending is not True else None
@@ -88,7 +109,7 @@ def check_kernel(name, lines):
     return reports
 
 
-def check_file(src, extra=()):
+def check_file(src, extra=(), verbose=True):
     out = "/tmp/_isa_check.s"
     r = subprocess.run([HIPCC, *FLAGS, *extra, "--cuda-device-only", "-S", src, "-o", out], capture_output=True, text=True)
     if r.returncode:
@@ -96,19 +117,28 @@ def check_file(src, extra=()):
         return -1
     text = open(out).read().splitlines()
     starts = [i for i, l in enumerate(text) if KERNEL.match(l)]
-    n_bar = n_rep = 0
+    n_bar = n_rep = n_dma = n_dma_bar = 0
     for k, a in enumerate(starts):
         b = starts[k + 1] if k + 1 < len(starts) else len(text)
         body = text[a:b]
         n_bar += sum(1 for l in body if re.match(r"^\s*s_barrier\b", l))
-        rep = check_kernel(text[a], body)
-        if rep:
-            dem = subprocess.run(["c++filt", text[a].rstrip(":")], capture_output=True, text=True).stdout.strip()
-            for line, w in sorted(rep.items())[:6]:
-                n_rep += 1
-                print("   %s: s_barrier at line %d reachable with a pending LDS store (e.g. `%s`, line %s)" % (
-                    dem[:90], a + line, body[w].strip() if isinstance(w, int) else "?", a + w if isinstance(w, int) else "?"))
-    print("%-28s kernels %3d  barriers %4d  reachable with a pending LDS store: %d" % (os.path.basename(src), len(starts), n_bar, n_rep), flush=True)
+        n_dma += sum(1 for l in body if LDS_DMA.match(l))
+        for hazard, what in (("store", "LDS store"), ("dma", "LDS-DMA load")):
+            rep = check_kernel(text[a], body, hazard)
+            if hazard == "dma":     # informational: a double-buffered kernel holds barriers with the NEXT buffer's DMA in flight by design
+                n_dma_bar += len(rep)
+                if rep and verbose:
+                    print("   note: %d barrier(s) with an LDS-DMA load in flight, asm lines %s" % (len(rep), [a + x for x in sorted(rep)]))
+                continue
+            if rep:
+                dem = subprocess.run(["c++filt", text[a].rstrip(":")], capture_output=True, text=True).stdout.strip()
+                for line, w in sorted(rep.items())[:6]:
+                    n_rep += 1
+                    print("   %s: s_barrier at line %d reachable with a pending %s (e.g. `%s`, line %s)" % (
+                        dem[:90], a + line, what, body[w].strip() if isinstance(w, int) else "?", a + w if isinstance(w, int) else "?"))
+    print("%-24s kernels %3d  barriers %4d  reachable with a pending LDS store: %d   (LDS-DMA loads %2d, barriers with one in flight %d)" % (
+        os.path.basename(src), len(starts), n_bar, n_rep, n_dma, n_dma_bar), flush=True)
+    check_file.last_dma_barriers = n_dma_bar
     return n_rep
 
 
