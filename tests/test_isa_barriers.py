@@ -86,3 +86,20 @@ def test_wgrad_dma16_publishes_its_staged_buffers_behind_vmcnt0():
     tool = _tool()
     assert tool.check_file(os.path.join(ROOT, "doda_amd", "csrc", "spconv_wdma.hip"), verbose=False) == 0
     assert tool.check_file.last_dma_barriers == 8
+
+
+def test_every_source_barrier_is_doda_sync():
+    """No kernel source calls __syncthreads() itself: common.hpp's doda_sync() (explicit s_waitcnt lgkmcnt(0) + barrier) is the only
+    spelling, so the compiler's wait-count pass is never what an LDS exchange depends on.  (Hand-written `s_barrier` in inline asm
+    carries its own wait on the same asm statement.)"""
+    import glob
+    import re
+    bad = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "doda_amd", "csrc", "*.h*"))):
+        for n, line in enumerate(open(f), 1):
+            code = line.split("//")[0]
+            if "__syncthreads" in code and not (f.endswith("common.hpp") and "doda_sync" not in code):
+                bad.append("%s:%d" % (os.path.basename(f), n))
+            if re.search(r"s_barrier", code) and "s_waitcnt" not in code and "asm" in code:
+                bad.append("%s:%d (bare s_barrier in inline asm)" % (os.path.basename(f), n))
+    assert not bad, bad
