@@ -26,6 +26,7 @@ _SIGNATURES = {
                                        c_sz, c_vp]),
     "doda_voxelize_fp": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "doda_voxelize_bp": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "doda_voxelize_fp_rows": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
     "doda_point_recover_fp": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "doda_point_recover_bp": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "doda_rulebook_workspace_bytes": (c_sz, [c_i32]),
@@ -100,7 +101,7 @@ _SIGNATURES = {
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 OPT_TILE_KERNEL, OPT_WLDS_KERNEL, OPT_WDMA_KERNEL, OPT_TILE_PIPELINE, OPT_TILE_DUAL, OPT_CONV_UP = 1, 2, 3, 4, 5, 6   # doda_set_option / doda_get_option
-ABI_VERSION = 9   # include/doda_hip.h DODA_ABI_VERSION
+ABI_VERSION = 10  # include/doda_hip.h DODA_ABI_VERSION
 
 _lib = None
 

@@ -755,6 +755,31 @@ class PyramidPrefetcher:
             _coarse_hooks.remove(self._open_gate)
 
 
+INPUT_ROWS = _os.environ.get("DODA_INPUT_ROWS", "1") == "1"
+
+
+def _input_rows(net, feats, xyz, v2p, mode, feature_dtype):
+    """The input layer's rows in one launch (ops.voxelize_fp_rows: cat + voxel pooling + cast + the layer's channel padding,
+    reference model/unet.py:89-94), or None when that form does not apply (CPU, features with a gradient, another input layer)."""
+    if not (INPUT_ROWS and feats.is_cuda and v2p.is_cuda and not feats.requires_grad and (xyz is None or not xyz.requires_grad)
+            and feats.dtype == torch.float32 and (xyz is None or xyz.dtype == torch.float32) and v2p.dtype == torch.int32
+            and v2p.dim() == 2 and v2p.shape[0] > 0 and feature_dtype in (torch.float32, torch.bfloat16) and mode in (3, 4)):
+        return None
+    conv = getattr(net, "input_conv", None)
+    conv = conv[0] if conv is not None and len(conv) == 1 else None
+    if not isinstance(conv, spconv.SubMConv3d):
+        return None
+    c_in = feats.shape[1] + (0 if xyz is None else xyz.shape[1])
+    c_out = _cv.padded_in_channels(conv, feature_dtype)
+    if conv.in_channels != c_in:
+        return None
+    rows = _ops.voxelize_fp_rows(feats.contiguous(), None if xyz is None else xyz.contiguous(), v2p.contiguous(), mode,
+                                  c_out or c_in, feature_dtype)
+    if c_out:
+        rows._doda_padded_from = c_in
+    return rows
+
+
 def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fused_head=True,
                      inputs_ready=False, pyramid=None):
     """reference model/unet.py:72-99 (test_model_feat): H2D, voxel mean-pooling, network.
@@ -765,11 +790,14 @@ def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fus
     p2v = batch["p2v_map"].to(device, non_blocking=True)
     v2p = batch["v2p_map"].to(device, non_blocking=True)
     feats = batch["feats"].to(device, non_blocking=True)
-    if cfg.MODEL.BACKBONE.use_xyz:
-        feats = torch.cat((feats, batch["locs_float"].to(device, non_blocking=True)), 1)
-    voxel_feats = pointgroup_ops.voxelization(feats, v2p, cfg.DATA_CONFIG.DATA_PROCESSOR.voxel_mode)
+    xyz = batch["locs_float"].to(device, non_blocking=True) if cfg.MODEL.BACKBONE.use_xyz else None
     batch_size = batch["offsets"].numel() - 1
     net = model.module if hasattr(model, "module") else model
+    voxel_feats = _input_rows(net, feats, xyz, v2p, cfg.DATA_CONFIG.DATA_PROCESSOR.voxel_mode, feature_dtype)
+    if voxel_feats is None:
+        if xyz is not None:
+            feats = torch.cat((feats, xyz), 1)
+        voxel_feats = pointgroup_ops.voxelization(feats, v2p, cfg.DATA_CONFIG.DATA_PROCESSOR.voxel_mode)
     if pyramid is not None:
         idx32, book = pyramid
         inp = spconv.SparseConvTensor(voxel_feats.to(feature_dtype), idx32, batch["spatial_shape"], batch_size)

@@ -124,6 +124,27 @@ def voxelize_fp(feats, out, rules, mode, n_active, max_active, n_plane):
                                  int(max_active), int(n_plane), _stream()), "doda_voxelize_fp")
 
 
+def voxelize_fp_rows(feats_a, feats_b, rules, mode, c_out, dtype):
+    """The network's input rows in ONE launch (doda_voxelize_fp_rows): voxelization(cat(feats_a, feats_b), rules, mode) cast to
+    `dtype` (float32 / bfloat16) and zero-padded to c_out channels.  feats_b may be None.  No gradient."""
+    cb = 0 if feats_b is None else feats_b.shape[1]
+    for t in (feats_a, feats_b):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 2 or t.device != rules.device):
+            raise RuntimeError("voxelize_fp_rows: point features must be contiguous float32 [N, C] on the rules' device")
+    if feats_b is not None and feats_b.shape[0] != feats_a.shape[0]:
+        raise RuntimeError("voxelize_fp_rows: the two feature matrices differ in rows")
+    if rules.dtype != torch.int32 or not rules.is_contiguous() or rules.dim() != 2:
+        raise RuntimeError("voxelize_fp_rows: rules must be contiguous int32 [M, 1 + maxActive]")
+    if dtype not in (torch.float32, torch.bfloat16) or c_out < feats_a.shape[1] + cb:
+        raise RuntimeError("voxelize_fp_rows: dtype float32 / bfloat16, c_out >= the pooled channels")
+    m = rules.shape[0]
+    out = torch.empty((m, c_out), dtype=dtype, device=rules.device)
+    check(lib().doda_voxelize_fp_rows(_p(feats_a), int(feats_a.shape[1]), _p(feats_b) if feats_b is not None else None, int(cb),
+                                      _p(rules), int(mode), int(m), int(rules.shape[1] - 1), _p(out), int(c_out),
+                                      out.element_size(), _stream()), "doda_voxelize_fp_rows")
+    return out
+
+
 def voxelize_bp(d_out, d_feats, rules, mode, n_active, max_active, n_plane):
     _pool_args(d_out, d_feats, rules)
     check(lib().doda_voxelize_bp(_p(d_out), _p(d_feats), _p(rules), int(mode), int(n_active),

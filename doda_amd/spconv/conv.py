@@ -45,6 +45,16 @@ _GEN = [1]    # current weight generation
 _PAD_INPUT_16 = _os.environ.get("DODA_PAD_INPUT16", "1") == "1"
 
 
+def padded_in_channels(conv, dtype):
+    """Channels the rows of `conv`'s input are zero-padded to on the GPU (forward below), or None when it takes them as they are."""
+    if conv.in_channels % 4 == 0:
+        return None
+    extra = (-conv.in_channels) % 4
+    if _PAD_INPUT_16 and dtype == torch.bfloat16 and conv.in_channels < 16 and conv.subm and conv.kernel_size == [3, 3, 3]:
+        extra = 16 - conv.in_channels
+    return conv.in_channels + extra
+
+
 def set_prepack(on):
     """Switch the one-launch pre-pack on or off at run time (off: every conv call packs its own
     weights inside the call — the reference behaviour for the parity tests)."""
@@ -296,7 +306,9 @@ class SparseConvolution(SparseModule):
                 # rulebook's tilebook (forward 69 -> 34 us, weight gradient 85 -> ~31 us at 600k voxels) instead of the
                 # 8-byte-row generic paths, for one extra 19 MB tensor
                 extra = 16 - self.in_channels
-            if features.is_cuda and not features.requires_grad and features.is_contiguous() and features.shape[0] > 0:
+            if getattr(features, "_doda_padded_from", None) == self.in_channels and features.shape[1] == self.in_channels + extra:
+                pass        # already this layer's padded rows (model.voxelize_and_run: doda_voxelize_fp_rows wrote them)
+            elif features.is_cuda and not features.requires_grad and features.is_contiguous() and features.shape[0] > 0:
                 features = _nops.pad_channels(features, self.in_channels + extra)   # one kernel (torch: fill + strided copy)
             else:
                 features = nn.functional.pad(features, (0, extra))

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DODA_ABI_VERSION 9
+#define DODA_ABI_VERSION 10
 
 #define DODA_OK 0
 #define DODA_ERR_INVALID (-1)        /* bad argument (null pointer, negative size, bad mode) */
@@ -80,6 +80,15 @@ int doda_voxelize_fp(const float *feats, float *out, const int32_t *rules, int32
                      int32_t n_active, int32_t max_active, int32_t n_plane, doda_stream_t stream);
 int doda_voxelize_bp(const float *d_out, float *d_feats, const int32_t *rules, int32_t mode,
                      int32_t n_active, int32_t max_active, int32_t n_plane, doda_stream_t stream);
+/* The network's input rows in one launch (round 5): what model/unet.py:89-94 builds with torch.cat + PG_OP.voxelize_fp
+ * (pointgroup_ops.py:44-64) + the cast to the network's feature type, plus the zero channels this library's input layer appends
+ * (32-byte rows for the tile kernels).  out[r, 0:c_a+c_b] = pooled row of (feats_a | feats_b) in voxelize_fp's arithmetic (fp32,
+ * products rounded before the add, point order), written as fp32 (out_elem_bytes 4) or bf16 round-to-nearest-even (2);
+ * out[r, c_a+c_b : c_out] = 0.  `out` [n_active, c_out] is overwritten (no zero-initialisation needed); feats_b may be NULL
+ * with c_b = 0.  Not differentiable (the reference's input features carry no gradient). */
+int doda_voxelize_fp_rows(const float *feats_a, int32_t c_a, const float *feats_b, int32_t c_b, const int32_t *rules, int32_t mode,
+                          int32_t n_active, int32_t max_active, void *out, int32_t c_out, int32_t out_elem_bytes,
+                          doda_stream_t stream);
 /* PG_OP.point_recover_fp / _bp (pointgroup_ops_api.cpp:10-11 -> voxelize.cpp:184-205): the two
  * kernels above with roles swapped and no averaging. */
 int doda_point_recover_fp(const float *feats, float *out, const int32_t *rules, int32_t n_active,

@@ -223,3 +223,66 @@ def test_tile_kernels_on_a_two_million_voxel_batch(native_lib):
 
 def rel_err_t(a, b):
     return float((a.double() - b.double()).abs().max()) / max(float(b.double().abs().max()), 1e-30)
+
+
+@pytest.mark.parametrize("mode", [3, 4])
+@pytest.mark.parametrize("ca,cb,c_out", [(3, 3, 16), (3, 3, 8), (3, 0, 4), (6, 0, 6), (1, 2, 3)])
+def test_input_rows_in_one_launch_equal_pool_cast_pad(native_lib, oracle, mode, ca, cb, c_out):
+    """doda_voxelize_fp_rows (cat + voxel pooling + cast + channel padding in ONE launch, reference model/unet.py:89-94): the
+    fp32 form bit for bit the oracle's voxelize_fp of the concatenated features (restated from voxelize.cu:10-31) with zero
+    channels behind it; the bf16 form that result rounded to nearest even (torch's cast)."""
+    from doda_amd import ops
+    from tests.test_gpu_parity import _points
+    coords = _points(22, 30000, 3, 24)
+    _, _, om = oracle.voxelize_idx(coords, mode)
+    rng = np.random.default_rng(ca * 10 + cb)
+    fa = rng.standard_normal((coords.shape[0], ca)).astype(np.float32) * 3
+    fb = rng.standard_normal((coords.shape[0], cb)).astype(np.float32) if cb else None
+    ref = oracle.voxelize_fp(np.ascontiguousarray(np.concatenate([fa, fb], 1)) if cb else fa, om, average=(mode == 4))
+    want = np.zeros((om.shape[0], c_out), np.float32)
+    want[:, :ca + cb] = ref
+    d = dev()
+    rules = torch.from_numpy(om).to(d)
+    ta, tb = torch.from_numpy(fa).to(d), (torch.from_numpy(fb).to(d) if cb else None)
+    got = ops.voxelize_fp_rows(ta, tb, rules, mode, c_out, torch.float32)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    got16 = ops.voxelize_fp_rows(ta, tb, rules, mode, c_out, torch.bfloat16)
+    assert torch.equal(got16.cpu().view(torch.int16), torch.from_numpy(want).to(torch.bfloat16).view(torch.int16))
+    with pytest.raises(RuntimeError):
+        ops.voxelize_fp_rows(ta, tb, rules, mode, ca + cb - 1, torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_unet_step_with_the_one_launch_input_equals_the_four_launch_input(native_lib, dtype):
+    """voxelize_and_run with the input layer's rows written by doda_voxelize_fp_rows against torch.cat + voxelization + cast +
+    pad_channels: the same rows, so the same loss and the same gradients, bit for bit."""
+    from doda_amd import model as M
+    from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
+    from doda_amd.scene import make_batch
+    from tests.util import deterministic_init
+    d = dev()
+    cfg = default_cfg()
+    b = make_batch(2, 40000, 37)
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in b.items()}
+    got = {}
+    was = M.INPUT_ROWS
+    try:
+        for on in (True, False):
+            M.INPUT_ROWS = on
+            net = deterministic_init(SparseConvNet(cfg), seed=8).to(d).train()
+            use_xyz = bool(cfg.MODEL.BACKBONE.use_xyz)
+            c_in = 6 if use_xyz else 3
+            rows = M._input_rows(net, bd["feats"], bd["locs_float"] if use_xyz else None, bd["v2p_map"], 4, dtype)
+            assert (rows is not None) == on
+            if on:
+                assert rows.shape[1] == (16 if dtype == torch.bfloat16 else c_in + (-c_in) % 4) and rows._doda_padded_from == c_in
+                assert M._input_rows(net, bd["feats"], bd["locs_float"] if not use_xyz else None, bd["v2p_map"], 4, dtype) is None
+            loss = cross_entropy(voxelize_and_run(cfg, net, bd, d, feature_dtype=dtype), bd["labels"], ignore_index=255)
+            loss.backward()
+            torch.cuda.synchronize()
+            got[on] = (float(loss), {k: p.grad.detach().float().clone() for k, p in net.named_parameters()})
+    finally:
+        M.INPUT_ROWS = was
+    assert got[True][0] == got[False][0]
+    for k, a in got[False][1].items():
+        assert torch.equal(a, got[True][1][k]), k
