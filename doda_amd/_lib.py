@@ -97,11 +97,13 @@ _SIGNATURES = {
     "doda_coarse_debug_stamps": (c_i32, [c_vp]),
     "doda_coarse_desc_bytes": (c_sz, [c_i32]),
     "doda_coarse_run": (c_i32, [c_vp, c_i32, c_vp, c_sz, c_vp, c_vp]),
+    "doda_layers_run": (c_i32, [c_vp, c_i32, c_i32, C.POINTER(c_i32), c_vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 OPT_TILE_KERNEL, OPT_WLDS_KERNEL, OPT_WDMA_KERNEL, OPT_TILE_PIPELINE, OPT_TILE_DUAL, OPT_CONV_UP = 1, 2, 3, 4, 5, 6   # doda_set_option / doda_get_option
-ABI_VERSION = 10  # include/doda_hip.h DODA_ABI_VERSION
+OPT_PRE_FWD_ROWS, OPT_PRE_BWD_ROWS = 7, 8   # (row thresholds of doda_layers_run's BatchNorm folding)
+ABI_VERSION = 11  # include/doda_hip.h DODA_ABI_VERSION
 
 _lib = None
 

@@ -20,7 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # kernels use 40-150 VGPRs, so the unified register file has room.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-value"] + os.environ.get("DODA_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _sources():

@@ -16,6 +16,7 @@
 // fragments, so every access is a contiguous wave-wide burst.  All reductions are fixed-order:
 // results are run-to-run deterministic.  Algorithmic bytes: fwd 3 passes, bwd 5 passes of M*C*s.
 #include "common.hpp"
+#include "bn_totals.hpp"
 #include <stdlib.h>
 #include <utility>
 
@@ -160,62 +161,24 @@ __global__ __launch_bounds__(64) void bn_stats_final(const typename T::elem *__r
 // vectors in LDS; workgroup 0 publishes what later kernels need.  (Round 3's form of this — the conv kernel's LAST workgroup
 // summing the rows behind a ticket — made the conv kernels 15-160 % slower: profiles/r03_stats_finish_ab.txt.)
 // ta / tb: the totals of the producers of the columns [0, ca) and [ca, c) (tb null: one producer) — a channel concatenation.
-constexpr int BN_TOT_MAX_C = 256;
-constexpr int BN_TOT_SLOTS = 8;      // = DODA_STATS_SLOTS (spconv_common.hpp)
-struct TotArgs {
-    const double *ta, *tb;
-    int ca, m;
-    float eps, momentum;
-    float *rm, *rv;           // forward: running statistics or null
-    long long *nbt;
-    float *out_a, *out_b;     // forward: save_mean, save_invstd; backward: dgamma, dbeta
-};
-__device__ __forceinline__ void tot_sums(const TotArgs &t, int c, int ch, double &s1, double &s2) {
-    const bool first = ch < t.ca;
-    const double *src = first ? t.ta : t.tb;
-    const int cw = first ? t.ca : c - t.ca, cc = first ? ch : ch - t.ca;
-    s1 = 0.0; s2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < BN_TOT_SLOTS; ++k) {      // (layout: spconv_common.hpp stats_emit — a 128-byte line per four channels)
-        s1 += src[((size_t)(k * 2 + 0) * (cw / 4) + cc / 4) * 16 + (cc & 3)];
-        s2 += src[((size_t)(k * 2 + 1) * (cw / 4) + cc / 4) * 16 + (cc & 3)];
-    }
-}
+// (TotArgs, tot_sums and the per-channel arithmetic: bn_totals.hpp — shared with the conv kernels that fold a BatchNorm into their gather)
 __device__ __forceinline__ void tot_fwd_prologue(const TotArgs &t, int c, float *v_mu, float *v_is) {
     for (int ch = threadIdx.x; ch < c; ch += BN_BLOCK) {
-        double s1, s2;
-        tot_sums(t, c, ch, s1, s2);
-        const double d = s1 / t.m;
-        double var = s2 / t.m - d * d;
-        if (var < 0.0) var = 0.0;
-        const float mu = (float)d, is = (float)(1.0 / sqrt(var + (double)t.eps));
+        float mu, is;
+        tot_fwd_channel(t, c, ch, blockIdx.x == 0, mu, is);
         v_mu[ch] = mu;
         v_is[ch] = is;
-        if (blockIdx.x == 0) {
-            t.out_a[ch] = mu;
-            t.out_b[ch] = is;
-            if (t.rm) {
-                const double unbiased = t.m > 1 ? var * (double)t.m / (double)(t.m - 1) : var;
-                t.rm[ch] = (float)((1.0 - t.momentum) * (double)t.rm[ch] + t.momentum * d);
-                t.rv[ch] = (float)((1.0 - t.momentum) * (double)t.rv[ch] + t.momentum * unbiased);
-            }
-            if (ch == 0 && t.nbt) *t.nbt = *t.nbt + 1;
-        }
     }
     doda_sync();
 }
 __device__ __forceinline__ void tot_bwd_prologue(const TotArgs &t, int c, const float *__restrict__ invstd,
                                                  const float *__restrict__ gamma, float *v_co /*[3][c]*/) {
     for (int ch = threadIdx.x; ch < c; ch += BN_BLOCK) {
-        double s1, s2;
-        tot_sums(t, c, ch, s1, s2);
-        v_co[ch] = gamma[ch] * invstd[ch];          // dx = a * (dz - b - xhat * d)
-        v_co[c + ch] = (float)(s1 / t.m);
-        v_co[2 * c + ch] = (float)(s2 / t.m);
-        if (blockIdx.x == 0) {
-            t.out_b[ch] = (float)s1;                // dbeta
-            t.out_a[ch] = (float)s2;                // dgamma
-        }
+        float ca, cb, cd;
+        tot_bwd_channel(t, c, ch, blockIdx.x == 0, invstd[ch], gamma[ch], ca, cb, cd);   // dx = a * (dz - b - xhat * d)
+        v_co[ch] = ca;
+        v_co[c + ch] = cb;
+        v_co[2 * c + ch] = cd;
     }
     doda_sync();
 }

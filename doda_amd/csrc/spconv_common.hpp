@@ -2,6 +2,7 @@
 // the C ABI; spconv_tile.hip: the LDS-staged kernels over a tilebook).  gfx950 only.
 #pragma once
 #include "common.hpp"
+#include "bn_totals.hpp"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -101,6 +102,29 @@ struct EpiArgs {   // plain data, shared across translation units
     int res_bcast;           // ABI 6: `res` is ONE row [nc] added to every output row (a bias): conv_fast only
     int f32_split;           // round 5: fp32 units as two bf16 MFMAs on head / tail splits (mma_f32_k16); set by run_gather
     double *stats_tot;       // ABI 9: [DODA_STATS_SLOTS][2][nc / 4][16] totals (4 of 16 used), accumulated with fp64 atomics INSTEAD of the rows, or null
+    // ABI 11: row strides in ELEMENTS of x / y / res / bn_x (0: dense — kc, nc, nc, nc): a column slice of a wider matrix, e.g. one
+    // half of a U-Net level's concatenation (reference model/unet_block.py:89-93), is read / written in place.  conv_fast only.
+    unsigned x_ld, y_ld, res_ld, bnx_ld;
+};
+// ABI 11: a BatchNorm folded into the gather of the convolution that consumes it (conv_fast<..., PRE>; reference
+// model/unet_block.py:23-30,46-49,67-79: BatchNorm1d -> ReLU -> conv, and the backward of that chain).
+//   kind 1 (forward): the gathered rows of x are normalised on their way into the MFMA — xn = [relu]((x - mean) * invstd * gamma +
+//          beta), rounded to the storage type — with mean / invstd derived by every workgroup from the producer's fp64 totals
+//          (tot.ta / tb; null: running statistics = evaluation mode); workgroup 0 publishes save_mean / save_invstd and the
+//          running statistics; the launch also writes xn once per row to `side` (the weight gradient's operand).
+//   kind 2 (backward): the gathered rows are du = ca * ([yv > 0] dz - cb - xhat * cd) (+ add, kind 3) computed from the rows of
+//          x = dz, `aux` = the BatchNorm's input and `add`; the coefficient vectors come from the totals (sum dz, sum dz xhat)
+//          the producing data-grad call accumulated; workgroup 0 writes dgamma / dbeta; `side` receives du once per row.
+struct PreArgs {
+    int kind, relu;
+    int rows;                       // rows of x (= of side / aux / add)
+    TotArgs tot;                    // (bn_totals.hpp)
+    const float *gamma, *beta;
+    const float *mean, *invstd;     // kind >= 2: the BatchNorm's saved vectors
+    void *side;
+    unsigned side_ld;
+    const void *aux, *add;
+    unsigned aux_ld, add_ld;
 };
 #ifndef DODA_STATS_SLOTS
 #define DODA_STATS_SLOTS 8      // (include/doda_hip.h)
@@ -132,6 +156,194 @@ __device__ __forceinline__ void stats_emit(const EpiArgs &ep, long long part, in
 }
 #endif
 
+#if defined(__HIPCC__)
+namespace {
+// ---- ABI 11: BatchNorm folded into the gather (PreArgs above) ---------------------------------------------------------------
+// A gathered 16-byte piece (8 bf16 / 4 fp32 values of one row) is transformed in registers between its load and its MFMA.
+// `pm` = all ones for a present neighbour, zero for an absent one (an absent row contributes zeros, not relu(beta - mean ...)).
+// Two forms of the arithmetic, chosen by the storage type, used by EVERY kernel of the per-layer backend that applies a BatchNorm
+// below its row threshold — the folded gathers, their once-per-row side output and the standalone lay_bn sweeps (layers.hip) — so
+// that folding an op never changes a bit:
+//   fp32 rows: the standalone sweeps' order (bn_totals.hpp bn_fwd_elem / bn_bwd_elem: every operation rounds) — fp32 is the parity
+//              precision (reference lib/pointgroup_ops/src/cuda.cu:11-13), and (x - mean) first is the well-conditioned order;
+//   bf16 rows: ONE fused multiply-add per value on per-channel products — forward y = x sc + sh (sc = invstd gamma,
+//              sh = beta - mean sc), backward du = [u G + H > 0] (A dz) + (E - C u) — a quarter of the vector instructions; the
+//              result is rounded to bf16 (2^-9) anyway, and the kernels are paced by exactly these instructions (every gathered
+//              row is transformed once per kernel offset that reads it).
+constexpr int PRE_MAX_C = BN_TOT_MAX_C;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+template <int ESZ, int KIND> struct PreForm {
+    static constexpr bool FMA = ESZ == 2;
+    static constexpr int NV = 16 / ESZ;                                                    // values per piece
+    static constexpr int NVEC = FMA ? (KIND == 1 ? 2 : 5) : (KIND == 1 ? 4 : 7);           // per-channel vectors
+};
+template <int ESZ, int KIND> struct PreCo { float v[PreForm<ESZ, KIND>::NVEC][PreForm<ESZ, KIND>::NV]; };   // a lane's channels, in registers
+
+// What a thread (= channel) reads for the vectors, requested BEFORE anything is waited for (one memory round trip for the
+// statistics, the gather table and the side output's rows together: at the coarse levels a kernel IS its chain of round trips)
+struct PreRaw { double d[2 * BN_TOT_SLOTS]; float ga, be, mu, is; };
+template <int KIND>
+__device__ __forceinline__ PreRaw pre_request(const PreArgs &pre, int kc) {
+    // NO control flow around the loads — neither per lane (threads past kc re-read channel 0 and are zeroed in pre_finish) nor
+    // uniform (evaluation mode reads gamma's first bytes in place of totals, training mode in place of running statistics):
+    // with a branch here hipcc waits for the whole batch at the merge point, before the table and side-output loads are issued
+    PreRaw r;
+    const int ch = (int)threadIdx.x < kc ? (int)threadIdx.x : 0;
+    r.ga = pre.gamma[ch];
+    r.be = pre.beta[ch];
+    const bool totals = pre.tot.ta != nullptr;
+    const float *pa = KIND == 1 ? (totals || !pre.tot.rm ? pre.gamma : (const float *)pre.tot.rm) : pre.mean;
+    const float *pb = KIND == 1 ? (totals || !pre.tot.rv ? pre.gamma : (const float *)pre.tot.rv) : pre.invstd;
+    r.mu = pa[ch];
+    r.is = pb[ch];
+    const bool first = ch < pre.tot.ca;
+    const double *src = totals ? (first ? pre.tot.ta : pre.tot.tb) : (const double *)pre.gamma;   // (gamma: >= 16 floats, 16-byte aligned)
+    const int cw = first ? pre.tot.ca : kc - pre.tot.ca, cc = first ? ch : ch - pre.tot.ca;
+    const size_t g = totals ? (size_t)(cw / 4) : 0, base = totals ? (size_t)(cc / 4) * 16 + (size_t)(cc & 3) : 0;
+#pragma unroll
+    for (int k = 0; k < BN_TOT_SLOTS; ++k) {      // (layout: stats_emit — a 128-byte line per four channels)
+        r.d[2 * k] = src[(size_t)(k * 2 + 0) * g * 16 + base];
+        r.d[2 * k + 1] = src[(size_t)(k * 2 + 1) * g * 16 + base];
+    }
+    return r;
+}
+// The vectors of channel threadIdx.x into LDS (zero past kc); workgroup 0 publishes what later kernels need — the arithmetic of
+// tot_fwd_channel / tot_bwd_channel (bn_totals.hpp) on the sums in their order.
+template <int ESZ, int KIND>
+__device__ __forceinline__ void pre_finish(const PreArgs &pre, int kc, const PreRaw &r, float (*co)[PRE_MAX_C]) {
+    typedef PreForm<ESZ, KIND> F;
+    const int ch = threadIdx.x;
+    if (ch >= PRE_MAX_C) return;
+    float mu = 0.f, is = 0.f, ga = r.ga, be = r.be, ca = 0.f, cb = 0.f, cd = 0.f;
+    if (ch < kc) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < BN_TOT_SLOTS; ++k) { s1 += r.d[2 * k]; s2 += r.d[2 * k + 1]; }
+        const bool publish = blockIdx.x == 0;
+        const TotArgs &t = pre.tot;
+        if constexpr (KIND == 1) {
+            if (t.ta) {
+                const double d = s1 / t.m;
+                double var = s2 / t.m - d * d;
+                if (var < 0.0) var = 0.0;
+                mu = (float)d;
+                is = (float)(1.0 / sqrt(var + (double)t.eps));
+                if (publish) {
+                    t.out_a[ch] = mu;
+                    t.out_b[ch] = is;
+                    if (t.rm) {
+                        const double unbiased = t.m > 1 ? var * (double)t.m / (double)(t.m - 1) : var;
+                        t.rm[ch] = (float)((1.0 - t.momentum) * (double)t.rm[ch] + t.momentum * d);
+                        t.rv[ch] = (float)((1.0 - t.momentum) * (double)t.rv[ch] + t.momentum * unbiased);
+                    }
+                    if (ch == 0 && t.nbt) *t.nbt = *t.nbt + 1;
+                }
+            } else {
+                mu = r.mu;
+                is = 1.0f / sqrtf(r.is + t.eps);
+            }
+        } else {
+            mu = r.mu;
+            is = r.is;
+            ca = ga * is;
+            cb = (float)(s1 / t.m);
+            cd = (float)(s2 / t.m);
+            if (publish) {
+                if (t.accum) { t.out_b[ch] += (float)s1; t.out_a[ch] += (float)s2; }
+                else { t.out_b[ch] = (float)s1; t.out_a[ch] = (float)s2; }      // dbeta, dgamma
+            }
+        }
+    } else {
+        ga = 0.f; be = 0.f;
+    }
+    if constexpr (!F::FMA) {
+        co[0][ch] = mu; co[1][ch] = is; co[2][ch] = ga; co[3][ch] = be;
+        if constexpr (KIND >= 2) { co[4][ch] = ca; co[5][ch] = cb; co[6][ch] = cd; }
+    } else if constexpr (KIND == 1) {
+        const float sc = is * ga;
+        co[0][ch] = sc;
+        co[1][ch] = be - mu * sc;
+    } else {
+        const float G = is * ga, C = ca * cd * is;
+        co[0][ch] = G;                          // mask: u G + H > 0
+        co[1][ch] = be - mu * G;
+        co[2][ch] = ca;                         // A
+        co[3][ch] = C;
+        co[4][ch] = ca * (cd * is * mu - cb);   // E
+    }
+}
+// a lane's NV consecutive channels from c0 on: LDS -> registers
+template <int ESZ, int KIND>
+__device__ __forceinline__ void pre_load_co(const float (*co)[PRE_MAX_C], int c0, PreCo<ESZ, KIND> &cv) {
+    typedef PreForm<ESZ, KIND> F;
+#pragma unroll
+    for (int v = 0; v < F::NVEC; ++v)
+#pragma unroll
+        for (int q = 0; q < F::NV; q += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(&co[v][c0 + q]);
+            cv.v[v][q] = t[0]; cv.v[v][q + 1] = t[1]; cv.v[v][q + 2] = t[2]; cv.v[v][q + 3] = t[3];
+        }
+}
+// one 16-byte piece: x (forward: the BatchNorm's input; backward: dz), u (backward: the BatchNorm's input), a (kind 3: the skip gradient)
+template <int ESZ, int KIND>
+__device__ __forceinline__ u32x4 pre_piece(const u32x4 &x, const u32x4 &u, const u32x4 &a, const PreCo<ESZ, KIND> &cv, int relu, unsigned pm) {
+    u32x4 o;
+    if constexpr (ESZ == 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float t;
+            if constexpr (KIND == 1) {
+                t = bn_fwd_elem(__uint_as_float(x[q]), cv.v[0][q], cv.v[1][q], cv.v[2][q], cv.v[3][q]);
+                if (relu) t = t > 0.f ? t : 0.f;
+            } else {
+                t = bn_bwd_elem(__uint_as_float(u[q]), __uint_as_float(x[q]), cv.v[0][q], cv.v[1][q], cv.v[2][q], cv.v[3][q], cv.v[4][q],
+                                cv.v[5][q], cv.v[6][q], relu);
+                if constexpr (KIND == 3) t += __uint_as_float(a[q]);
+            }
+            o[q] = __float_as_uint(t) & pm;
+        }
+    } else {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {     // two bf16 values per 32-bit word: packed fp32 math (v_pk_fma_f32)
+            const f32x2 xv = {__uint_as_float(x[j] << 16), __uint_as_float(x[j] & 0xffff0000u)};
+            f32x2 r;
+            if constexpr (KIND == 1) {
+                const f32x2 sc = {cv.v[0][2 * j], cv.v[0][2 * j + 1]}, sh = {cv.v[1][2 * j], cv.v[1][2 * j + 1]};
+                r = __builtin_elementwise_fma(xv, sc, sh);
+            } else {
+                const f32x2 uv = {__uint_as_float(u[j] << 16), __uint_as_float(u[j] & 0xffff0000u)};
+                const f32x2 G = {cv.v[0][2 * j], cv.v[0][2 * j + 1]}, H = {cv.v[1][2 * j], cv.v[1][2 * j + 1]};
+                const f32x2 A = {cv.v[2][2 * j], cv.v[2][2 * j + 1]}, C = {cv.v[3][2 * j], cv.v[3][2 * j + 1]};
+                const f32x2 E = {cv.v[4][2 * j], cv.v[4][2 * j + 1]};
+                const f32x2 t = __builtin_elementwise_fma(-C, uv, E);
+                const f32x2 full = __builtin_elementwise_fma(A, xv, t);
+                r = full;
+                if (relu) {
+                    const f32x2 yv = __builtin_elementwise_fma(uv, G, H);
+                    r[0] = yv[0] > 0.f ? full[0] : t[0];
+                    r[1] = yv[1] > 0.f ? full[1] : t[1];
+                }
+                if constexpr (KIND == 3) {
+                    const f32x2 av = {__uint_as_float(a[j] << 16), __uint_as_float(a[j] & 0xffff0000u)};
+                    r = r + av;
+                }
+            }
+            unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+            if constexpr (KIND == 1) {
+                // ReLU AFTER the rounding, on the packed pair: max(int16, 0) zeroes every negative bf16 (and -0) — the same bits as
+                // relu-then-round (rounding is monotonic and keeps 0)
+                if (relu) w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), (s16x2){0, 0}));
+            }
+            o[j] = w & pm;
+        }
+    }
+    return o;
+}
+}  // namespace
+#endif
+
 namespace doda_tile {
 bool enabled();   // doda_set_option(DODA_OPT_TILE_KERNEL)
 void set_enabled(bool on);
@@ -152,6 +364,15 @@ int launch_conv_up32(bool out32, const void *x, unsigned x_bytes, const void *wp
                      const int32_t *tbl, int ld, int n_out, void *y, unsigned y_bytes, const void *res, const EpiArgs &ep,
                      int *n_part, hipStream_t s);
 }  // namespace doda_tile
+
+namespace doda_layers {
+// doda_set_option(DODA_OPT_PRE_FWD_ROWS / DODA_OPT_PRE_BWD_ROWS): a BatchNorm op of doda_layers_run with at most this many rows is
+// folded into the next convolution's gather (0: never); defaults from DODA_PRE_FWD_ROWS / DODA_PRE_BWD_ROWS (16384 / 0)
+long long fwd_rows();
+long long bwd_rows();
+void set_fwd_rows(long long v);
+void set_bwd_rows(long long v);
+}  // namespace doda_layers
 
 namespace doda_wlds {
 bool enabled();

@@ -468,7 +468,7 @@ __device__ __forceinline__ float bf16_rounded(float f) {
 // series (27 offsets x 3..7 chunks, ~70 ns each) while the chip is nearly empty.
 // STATS: the BatchNorm-statistics epilogue is a compile-time variant, so the plain kernels keep their
 // register allocation and instruction stream.
-template <class P, int NBW, int S, int D, bool OUT32, bool SPLIT = false, bool STATS = false>
+template <class P, int NBW, int S, int D, bool OUT32, bool SPLIT = false, bool STATS = false, int PRE = 0>
 __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restrict__ x,
                                                  unsigned x_bytes, int kc,
                                                  const void *__restrict__ wp,
@@ -476,18 +476,49 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                                                  const int32_t *__restrict__ tbl,
                                                  unsigned tbl_bytes, int ld, int K, int n_out,
                                                  void *__restrict__ y, unsigned y_bytes,
-                                                 const void *__restrict__ res, const EpiArgs ep) {
+                                                 const void *__restrict__ res, const EpiArgs ep, const PreArgs pre) {
     typedef typename P::elem elem;
     typedef typename P::raw raw;
     constexpr unsigned OSZ = OUT32 ? 4u : (unsigned)sizeof(elem);   // output element size
     constexpr int RW = 16 * S;                 // rows per wave
     constexpr int OPI = 256 / RW;              // table offsets fetched per (16-byte) load instruction
     constexpr int NLD = (MAX_K + 1 + OPI - 1) / OPI;  // strips 0..MAX_K; strip MAX_K is all-OOB
-    constexpr int L = S + NBW;                 // asm loads per unit
+    constexpr int NOP = PRE >= 3 ? 3 : PRE == 2 ? 2 : 1;   // gathered operands per row (PRE >= 2: dz, the BatchNorm's input, the skip gradient)
+    constexpr int L = S * NOP + NBW;           // asm loads per unit
     constexpr unsigned ESZ = sizeof(elem), FSZ = sizeof(raw);
     constexpr int CH = P::CH;
     static_assert((D - 1) * L <= 63, "vmcnt field");
+    static_assert(PRE == 0 || (FSZ == 16 && !P::PAIR && !OUT32), "the folded BatchNorm works on 16-byte pieces of same-dtype rows");
     __shared__ __attribute__((aligned(16))) unsigned off_tile[4][(MAX_K + 1) * RW];
+    // PRE: per-channel vectors of the folded BatchNorm (spconv_common.hpp pre_finish), zero past kc.  Everything the kernel's
+    // prologue reads — the statistics totals, the gather table below, the first rows of the side output — is REQUESTED before
+    // anything is waited for: one exposed round trip instead of three (a coarse-level kernel is its chain of round trips).
+    constexpr int PESZ = PRE == 0 ? 2 : (int)ESZ, PKIND = PRE == 0 ? 1 : PRE;
+    typedef PreForm<PESZ, PKIND> PF;
+    __shared__ __attribute__((aligned(16))) float pre_co[PRE == 0 ? 1 : PF::NVEC][PRE == 0 ? 4 : PRE_MAX_C];
+    PreRaw pre_raw;
+    u32x4 sw_x = {0u, 0u, 0u, 0u}, sw_u = sw_x, sw_a = sw_x;     // side-output sweep, first piece of this thread
+    unsigned sw_e = 0, sw_n = 0, sw_ppr = 1;                    // (piece numbers fit 32 bits: rows x row bytes < 2^31 on the fast path)
+#ifdef DODA_PRE_ABLATE
+    const int ablate = pre.kind >> 8;
+#endif
+    if constexpr (PRE != 0) {
+#ifdef DODA_PRE_ABLATE
+        if (ablate & 4) { pre_raw = PreRaw{}; } else
+#endif
+        pre_raw = pre_request<PRE>(pre, kc);
+        constexpr unsigned NV = 16 / ESZ;
+        sw_ppr = (unsigned)kc / NV;     // 16-byte pieces per row (kc % NV == 0 on this path)
+        sw_n = (unsigned)pre.rows * sw_ppr;
+        sw_e = blockIdx.x * 256u + threadIdx.x;
+        {   // requested unconditionally (a thread without a piece re-reads piece 0): no branch, no wait before the table loads
+            const unsigned e = sw_e < sw_n ? sw_e : 0u;
+            const unsigned r = e / sw_ppr, c0 = (e - r * sw_ppr) * NV;
+            sw_x = *reinterpret_cast<const u32x4 *>(x + (size_t)r * (ep.x_ld ? ep.x_ld : (unsigned)kc) + c0);
+            if constexpr (PRE >= 2) sw_u = *reinterpret_cast<const u32x4 *>((const elem *)pre.aux + (size_t)r * pre.aux_ld + c0);
+            if constexpr (PRE >= 3) sw_a = *reinterpret_cast<const u32x4 *>((const elem *)pre.add + (size_t)r * pre.add_ld + c0);
+        }
+    }
 
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, g = lane >> 4;
@@ -504,7 +535,7 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
     // 16-byte table loads: a lane takes 4 consecutive rows of one offset, so one instruction covers
     // OPI = 256 / RW offsets (the kernel is paced by the NUMBER of vector-memory instructions; this
     // is 4 instead of 14 per 32-row wave).  Strip MAX_K stays all-out-of-range (the dummy unit).
-    const unsigned row_bytes = (unsigned)kc * ESZ;
+    const unsigned row_bytes = (ep.x_ld ? ep.x_ld : (unsigned)kc) * ESZ;
     unsigned active = 0;
     {
         constexpr int LPO = RW / 4;            // lanes per offset
@@ -520,7 +551,7 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const bool present = ok && row0 + rq + k < n_out && (int)t[k] >= 0;
-                off[k] = present ? t[k] * row_bytes : OOB;
+                off[k] = present ? (PRE >= 2 ? t[k] : t[k] * row_bytes) : OOB;   // (PRE >= 2: the row INDEX — three operands, three row strides)
                 any |= present;
             }
             if (o <= MAX_K) *reinterpret_cast<u32x4 *>(&off_tile[wid][o * RW + rq]) = off;
@@ -533,6 +564,14 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
         }
     }
     active = __builtin_amdgcn_readfirstlane(active);
+#ifdef DODA_PRE_ABLATE
+    if constexpr (PRE != 0) {
+        if (ablate & 4) { for (int v = 0; v < PF::NVEC; ++v) pre_co[v][threadIdx.x] = 0.5f; }
+        else pre_finish<(int)ESZ, PRE>(pre, kc, pre_raw, pre_co);
+    }
+#else
+    if constexpr (PRE != 0) pre_finish<(int)ESZ, PRE>(pre, kc, pre_raw, pre_co);
+#endif
     if (SPLIT) {  // keep the offsets whose rank among the active ones is wid (mod 4)
         unsigned mine = 0;
         int rank = 0;
@@ -541,6 +580,27 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
         active = __builtin_amdgcn_readfirstlane(mine);
     }
     doda_sync();
+
+    if constexpr (PRE != 0) {
+        // the transformed rows ONCE per row, for the weight gradient (forward: the BatchNorm's output; backward: the gradient of
+        // its input): the launch's workgroups share the rows of x evenly, each piece goes through the same pre_piece as the gathers
+        constexpr unsigned NV = 16 / ESZ;
+        const unsigned xl = ep.x_ld ? ep.x_ld : (unsigned)kc;
+#ifdef DODA_PRE_ABLATE
+        if (!(ablate & 1))
+#endif
+        for (unsigned e = sw_e; e < sw_n; e += gridDim.x * 256u) {
+            const unsigned r = e / sw_ppr, c0 = (e - r * sw_ppr) * NV;
+            if (e != sw_e) {     // (the first piece was requested in the prologue)
+                sw_x = *reinterpret_cast<const u32x4 *>(x + (size_t)r * xl + c0);
+                if constexpr (PRE >= 2) sw_u = *reinterpret_cast<const u32x4 *>((const elem *)pre.aux + (size_t)r * pre.aux_ld + c0);
+                if constexpr (PRE >= 3) sw_a = *reinterpret_cast<const u32x4 *>((const elem *)pre.add + (size_t)r * pre.add_ld + c0);
+            }
+            PreCo<(int)ESZ, PRE> cv;
+            pre_load_co<(int)ESZ, PRE>(pre_co, (int)c0, cv);
+            *reinterpret_cast<u32x4 *>((elem *)pre.side + (size_t)r * pre.side_ld + c0) = pre_piece<(int)ESZ, PRE>(sw_x, sw_u, sw_a, cv, pre.relu, ~0u);
+        }
+    }
 
     f32x4 acc[S][NBW];
 #pragma unroll
@@ -561,17 +621,37 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
     const int n_units = PAIR ? (__builtin_popcount(active) + 1) / 2 : __builtin_popcount(active) * n_chunk;
     if (n_units > 0) {
         raw xa[D][S], wb[D][NBW];
+        // PRE: the second / third gathered operand of a row, its presence mask and the unit's channel chunk, per ring slot
+        raw ua[D][PRE >= 2 ? S : 1], aa[D][PRE >= 3 ? S : 1];
+        unsigned pm[D][S];
+        int ccs[D];
+        const u32x4 rs_u = make_rsrc(PRE >= 2 ? pre.aux : nullptr,
+                                     PRE >= 2 ? (unsigned)(((size_t)(pre.rows - 1) * pre.aux_ld + kc) * ESZ) : 0u);
+        const u32x4 rs_a = make_rsrc(PRE >= 3 ? pre.add : nullptr,
+                                     PRE >= 3 ? (unsigned)(((size_t)(pre.rows - 1) * pre.add_ld + kc) * ESZ) : 0u);
+        const unsigned aux_rb = PRE >= 2 ? pre.aux_ld * ESZ : 0u, add_rb = PRE >= 3 ? pre.add_ld * ESZ : 0u;
         // (o, cc, have): the next unit to issue.  Every asm load below is UNCONDITIONAL (a slot with
         // nothing left to fetch gets the all-out-of-range dummy unit, strip MAX_K): conditional
         // definitions of ring registers make the register allocator resolve phis with moves of
         // registers whose loads are still in flight (observed as a nondeterministic race).
+        // PRE_CC_OUTER: the chunk as the OUTER loop (all active offsets of chunk 0, then of chunk 1, ...): a lane's channels — and with
+        // them its registers of per-channel vectors — change n_chunk times per wave instead of once per unit
+#ifdef DODA_PRE_CC_OUTER
+        constexpr bool PRE_CC_OUTER = true;
+#else
+        constexpr bool PRE_CC_OUTER = false;
+#endif
+        const unsigned active_all = active;
+        PreCo<PESZ, PKIND> pre_cv;
+        int pre_cc = -1;
         int o = __builtin_ctz(active), cc = 0, o2 = MAX_K;
         active &= active - 1;
         if (PAIR && active != 0) { o2 = __builtin_ctz(active); active &= active - 1; }
         bool have = true;
         int to_issue = n_units;
 
-        auto issue = [&](raw (&xr)[S], raw (&wr)[NBW]) {
+        auto issue = [&](raw (&xr)[S], raw (&wr)[NBW], raw (&ur)[PRE >= 2 ? S : 1], raw (&ar)[PRE >= 3 ? S : 1], unsigned (&pmr)[S],
+                         int &ccr) {
             if constexpr (PAIR) {
                 // offset of this lane's half of the unit; strip MAX_K / a W offset past the packed
                 // buffer are the all-zero dummies (odd offset count, ring top-up)
@@ -604,26 +684,71 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
             unsigned off[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) off[s] = p[s * 16];
+            if constexpr (PRE != 0) {
+                ccr = cc;
 #pragma unroll
-            for (int s = 0; s < S; ++s) P::gather(xr[s], off[s] + lane_x, rs_x, soff_x);
-            const unsigned soff_w = (unsigned)((o * n_chunk + cc) * NB + nb0) * 64u * FSZ;
+                for (int s = 0; s < S; ++s) pmr[s] = (int)off[s] >= 0 ? ~0u : 0u;
+            }
+            if constexpr (PRE >= 2) {   // the strip holds row indices: one multiply per operand
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const bool pr = (int)off[s] >= 0;
+                    P::gather(xr[s], pr ? off[s] * row_bytes + lane_x : OOB, rs_x, soff_x);
+                    P::gather(ur[s], pr ? off[s] * aux_rb + lane_x : OOB, rs_u, soff_x);
+                    if constexpr (PRE >= 3) P::gather(ar[s], pr ? off[s] * add_rb + lane_x : OOB, rs_a, soff_x);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < S; ++s) P::gather(xr[s], off[s] + lane_x, rs_x, soff_x);
+            }
+            unsigned soff_w = (unsigned)((o * n_chunk + cc) * NB + nb0) * 64u * FSZ;
+            // (PRE >= 2: hipcc computes this uniform value on the vector side — the asm's "s" operand then fails to assemble)
+            if constexpr (PRE >= 2) soff_w = (unsigned)__builtin_amdgcn_readfirstlane((int)soff_w);
             const unsigned voff_w = have ? lane_w : OOB;
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) P::load(wr[nb], voff_w, rs_w, soff_w + nb * 64u * FSZ);
             if (have) {
                 --to_issue;
-                if (++cc == n_chunk) {
+                if constexpr (PRE != 0 && PRE_CC_OUTER) {
+                    if (active == 0) {
+                        if (++cc == n_chunk) have = false;
+                        else { active = active_all; o = __builtin_ctz(active); active &= active - 1; }
+                    } else { o = __builtin_ctz(active); active &= active - 1; }
+                } else if (++cc == n_chunk) {
                     cc = 0;
                     if (active == 0) have = false;
                     else { o = __builtin_ctz(active); active &= active - 1; }
                 }
             }
         };
-        auto consume = [&](raw (&xr)[S], raw (&wr)[NBW]) {
+        auto consume = [&](raw (&xr)[S], raw (&wr)[NBW], raw (&ur)[PRE >= 2 ? S : 1], raw (&ar)[PRE >= 3 ? S : 1], unsigned (&pmr)[S],
+                           int ccr) {
 #pragma unroll
             for (int s = 1; s < S; ++s) touch(xr[s]);
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) touch(wr[nb]);
+            if constexpr (PRE != 0) {
+                if constexpr (PRE >= 2) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) touch(ur[s]);
+                }
+                if constexpr (PRE >= 3) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) touch(ar[s]);
+                }
+#ifdef DODA_PRE_ABLATE
+                if (!(ablate & 2))
+#endif
+                {
+                if (ccr != pre_cc) {                // (wave-uniform: a new chunk = this lane's next 16 / ESZ channels)
+                    pre_cc = ccr;
+                    pre_load_co<PESZ, PKIND>(pre_co, ccr * CH + lane_c, pre_cv);
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    xr[s] = pre_piece<PESZ, PKIND>(xr[s], ur[PRE >= 2 ? s : 0], ar[PRE >= 3 ? s : 0], pre_cv, pre.relu, pmr[s]);
+                }
+            }
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
@@ -632,15 +757,15 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
         };
 
 #pragma unroll
-        for (int k = 0; k < D; ++k) issue(xa[k], wb[k]);
+        for (int k = 0; k < D; ++k) issue(xa[k], wb[k], ua[k], aa[k], pm[k], ccs[k]);
         int consumed = 0;
         // steady state: D-1 units (L loads each) stay in flight behind the one being consumed
         while (to_issue > 0) {
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 wait_vm<(D - 1) * L>(xa[k][0]);
-                consume(xa[k], wb[k]);
-                issue(xa[k], wb[k]);
+                consume(xa[k], wb[k], ua[k], aa[k], pm[k], ccs[k]);
+                issue(xa[k], wb[k], ua[k], aa[k], pm[k], ccs[k]);
             }
             consumed += D;
         }
@@ -649,12 +774,20 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             if (k > 0) touch(xa[k][0]);
-            if (consumed + k < n_units) consume(xa[k], wb[k]);
+            if (consumed + k < n_units) consume(xa[k], wb[k], ua[k], aa[k], pm[k], ccs[k]);
             else {
 #pragma unroll
                 for (int s = 1; s < S; ++s) touch(xa[k][s]);
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb) touch(wb[k][nb]);
+                if constexpr (PRE >= 2) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) touch(ua[k][s]);
+                }
+                if constexpr (PRE >= 3) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) touch(aa[k][s]);
+                }
             }
         }
     }
@@ -687,6 +820,12 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
     // occupancy: 46 -> 92 VGPRs on the 48-channel tile).
     __shared__ f32x4 sred[STATS ? (SPLIT ? 1 : 4) : 1][STATS ? NBW : 1][2][4];
     const int part = item / n_nbg;   // the workgroup's row tile
+    // row strides (ABI 11; 0 = dense): y, the residual and the BatchNorm input of the data-gradient statistics may be column
+    // slices of wider matrices
+    const unsigned y_ld = ep.y_ld ? ep.y_ld : (unsigned)nc, res_ld = ep.res_ld ? ep.res_ld : (unsigned)nc,
+                   bnx_ld = ep.bnx_ld ? ep.bnx_ld : (unsigned)nc;
+    const unsigned res_bytes = ep.res_ld ? (unsigned)(((size_t)(n_out - 1) * res_ld + nc) * OSZ) : (ep.y_ld ? (unsigned)((size_t)n_out * nc * OSZ) : y_bytes);
+    const unsigned bnx_bytes = ep.bnx_ld ? (unsigned)(((size_t)(n_out - 1) * bnx_ld + nc) * OSZ) : (ep.y_ld ? (unsigned)((size_t)n_out * nc * OSZ) : y_bytes);
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const unsigned col = (unsigned)((nb0 + nb) * 16 + 4 * g);
@@ -694,11 +833,14 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const unsigned t = (unsigned)(row0 + s * 16 + i);
-            const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * (unsigned)nc + col) * OSZ : OOB;
+            const bool in_range = t < (unsigned)n_out && col < (unsigned)nc;
+            const unsigned voff = in_range ? (t * y_ld + col) * OSZ : OOB;
+            const unsigned voff_res = in_range ? (t * res_ld + col) * OSZ : OOB;
+            const unsigned voff_bnx = in_range ? (t * bnx_ld + col) * OSZ : OOB;
             if (res) {   // y = conv + res (residual add of the block fused into the store; res has y's dtype)
-                const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, y_bytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, res_bytes, 0x00020000);
                 // (res_bcast: one row for every output row — the Linear head's bias, reference model/unet.py:64)
-                const unsigned voff_r = ep.res_bcast ? (voff != OOB ? col * OSZ : OOB) : voff;
+                const unsigned voff_r = ep.res_bcast ? (in_range ? col * OSZ : OOB) : voff_res;
                 if (OUT32 || sizeof(elem) == 4) {
                     const f32x4 r4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, voff_r, 0, 0));
 #pragma unroll
@@ -724,12 +866,12 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                                 __uint_as_float(packed_out[1] << 16), __uint_as_float(packed_out[1] & 0xffff0000u)};
                 }
                 if (ep.bn_x) {
-                    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)ep.bn_x, 0, y_bytes, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)ep.bn_x, 0, bnx_bytes, 0x00020000);
                     f32x4 xr;
                     if (OUT32 || sizeof(elem) == 4) {
-                        xr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff, 0, 0));
+                        xr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff_bnx, 0, 0));
                     } else {
-                        const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rs_x, voff, 0, 0);
+                        const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rs_x, voff_bnx, 0, 0);
                         xr = (f32x4){__uint_as_float(r2[0] << 16), __uint_as_float(r2[0] & 0xffff0000u),
                                      __uint_as_float(r2[1] << 16), __uint_as_float(r2[1] & 0xffff0000u)};
                     }
@@ -783,12 +925,20 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
     }
 }
 
+// kernel shapes that carry the folded BatchNorm (PreArgs): 16-byte pieces of same-dtype rows, split blocks — the shapes of the
+// coarse U-Net levels, where a BatchNorm sweep of its own is a launch-floor kernel
+template <class P, int NBW, int S, bool SPLIT>
+constexpr bool pre_shape() {
+    return SPLIT && ((NBW == 1 && S == 1) || (NBW == 4 && S == 2)) && (std::is_same<P, PBF16W>::value || std::is_same<P, PF32>::value);
+}
+
 template <class P, int NBW, int S, bool SPLIT = false>
 int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_bytes, int nc, int NB,
                 const int32_t *tbl, int ld, int K, int n_out, long long n_in, void *y, bool out32,
-                const void *res, const EpiArgs &ep_in, int *n_part, hipStream_t s) {
+                const void *res, const EpiArgs &ep_in, int *n_part, hipStream_t s, const PreArgs *pre = nullptr) {
     if constexpr (std::is_same<P, PF32>::value) {   // fp32 layers of many rows: the bf16 head / tail instantiation
-        if (ep_in.f32_split) return launch_fast<PF32S, NBW, S, SPLIT>(x, kc, wp, wp_bytes, nc, NB, tbl, ld, K, n_out, n_in, y, out32, res, ep_in, n_part, s);
+        if (ep_in.f32_split && !(pre && pre->kind))
+            return launch_fast<PF32S, NBW, S, SPLIT>(x, kc, wp, wp_bytes, nc, NB, tbl, ld, K, n_out, n_in, y, out32, res, ep_in, n_part, s);
     }
     const dim3 grid(div_up(n_out, (SPLIT ? 1 : 4) * 16 * S) * div_up(NB, NBW)), block(256);
     if (n_part) *n_part = div_up(n_out, (SPLIT ? 1 : 4) * 16 * S);
@@ -798,24 +948,49 @@ int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_byt
     // instruction issue and by how many waves a SIMD can interleave, not by memory latency.  Depth 8
     // cost 124 VGPRs (4 waves per SIMD); depth 3: level-1 16->16 52 -> 38 us, level-2 32->32 37 -> 32 us.
     constexpr int D = 3;
-    const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(typename P::elem));
+    const size_t esz = sizeof(typename P::elem);
+    const unsigned xb = (unsigned)(ep.x_ld ? ((size_t)(n_in - 1) * ep.x_ld + kc) * esz : (size_t)n_in * kc * esz);
     const unsigned tb = (unsigned)((size_t)K * ld * 4);
+    const PreArgs none{};
+    if (pre && pre->kind) {
+        if constexpr (pre_shape<P, NBW, S, SPLIT>()) {
+            if (out32 && esz != 4) return DODA_ERR_UNSUPPORTED;
+            const unsigned yb = (unsigned)(ep.y_ld ? ((size_t)(n_out - 1) * ep.y_ld + nc) * esz : (size_t)n_out * nc * esz);
+#define DODA_PRE_GO(KIND)                                                                                            \
+            do {                                                                                                     \
+                if (ep.stats)                                                                                        \
+                    hipLaunchKernelGGL((conv_fast<P, NBW, S, D, false, SPLIT, true, KIND>), grid, block, 0, s, x, xb, kc, wp,  \
+                                       (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep, *pre);     \
+                else                                                                                                 \
+                    hipLaunchKernelGGL((conv_fast<P, NBW, S, D, false, SPLIT, false, KIND>), grid, block, 0, s, x, xb, kc, wp, \
+                                       (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep, *pre);     \
+            } while (0)
+            if ((pre->kind & 0xff) == 1) DODA_PRE_GO(1);
+            else if ((pre->kind & 0xff) == 2) DODA_PRE_GO(2);
+            else if ((pre->kind & 0xff) == 3) DODA_PRE_GO(3);
+            else return DODA_ERR_INVALID;
+#undef DODA_PRE_GO
+            return doda_check_launch();
+        } else {
+            return DODA_ERR_UNSUPPORTED;
+        }
+    }
     if (out32 && sizeof(typename P::elem) != 4) {
-        const unsigned yb = (unsigned)((size_t)n_out * nc * 4);
+        const unsigned yb = (unsigned)(ep.y_ld ? ((size_t)(n_out - 1) * ep.y_ld + nc) * 4 : (size_t)n_out * nc * 4);
         if (ep.stats)
             hipLaunchKernelGGL((conv_fast<P, NBW, S, D, true, SPLIT, true>), grid, block, 0, s, x, xb, kc, wp,
-                               (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep);
+                               (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep, none);
         else
             hipLaunchKernelGGL((conv_fast<P, NBW, S, D, true, SPLIT, false>), grid, block, 0, s, x, xb, kc, wp,
-                               (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep);
+                               (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep, none);
     } else {
-        const unsigned yb = (unsigned)((size_t)n_out * nc * sizeof(typename P::elem));
+        const unsigned yb = (unsigned)(ep.y_ld ? ((size_t)(n_out - 1) * ep.y_ld + nc) * esz : (size_t)n_out * nc * esz);
         if (ep.stats)
             hipLaunchKernelGGL((conv_fast<P, NBW, S, D, false, SPLIT, true>), grid, block, 0, s, x, xb, kc, wp,
-                               (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep);
+                               (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep, none);
         else
             hipLaunchKernelGGL((conv_fast<P, NBW, S, D, false, SPLIT, false>), grid, block, 0, s, x, xb, kc, wp,
-                               (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep);
+                               (unsigned)wp_bytes, nc, NB, tbl, tb, ld, K, n_out, y, yb, res, ep, none);
     }
     return doda_check_launch();
 }
@@ -847,7 +1022,7 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
                int n_out, void *y_, int wl, void *ws, size_t ws_bytes, long long n_in, bool out32,
                const void *res, hipStream_t s,
                const EpiArgs &ep_arg = EpiArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr},
-               int *n_part = nullptr, const void *tilebook = nullptr, int tilebook_rows = 0) {
+               int *n_part = nullptr, const void *tilebook = nullptr, int tilebook_rows = 0, const PreArgs *pre = nullptr) {
     typedef typename T::elem elem;
     typedef typename T::frag frag;
     const elem *x = (const elem *)x_;
@@ -867,9 +1042,18 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     const size_t va = 4 * sizeof(elem);  // vector access granule
     const int vec_ok = (kc % 4 == 0) && (nc % 4 == 0) && ((uintptr_t)x % va == 0) &&
                        ((uintptr_t)y % va == 0);
+    // ABI 11: row strides (column slices of wider matrices) and the folded BatchNorm exist in conv_fast only
+    const bool strided = ep.x_ld || ep.y_ld || ep.res_ld || ep.bnx_ld;
+    const bool folded = pre && pre->kind != 0;
+    const size_t x_ld = ep.x_ld ? ep.x_ld : (size_t)kc, y_ld = ep.y_ld ? ep.y_ld : (size_t)nc;
+    const bool ld_ok = x_ld % 4 == 0 && y_ld % 4 == 0 && ep.res_ld % 4 == 0 && ep.bnx_ld % 4 == 0 &&
+                       (size_t)n_in * x_ld * sizeof(elem) < 0x7ffffff0ull && (size_t)n_out * y_ld * 4 < 0x7fffffffull &&
+                       (size_t)n_out * (ep.res_ld ? ep.res_ld : (size_t)nc) * 4 < 0x7fffffffull &&
+                       (size_t)n_out * (ep.bnx_ld ? ep.bnx_ld : (size_t)nc) * 4 < 0x7fffffffull;
     const bool fast = (kc % 4 == 0) && (nc % 4 == 0) && ((uintptr_t)x % 16 == 0) &&
                       ((uintptr_t)y % 16 == 0) && ((size_t)n_out * nc * 4 < 0x7fffffffull) &&
-                      ((size_t)K * ld * 4 < 0xffffffffull) && x_rows_bytes_ok;
+                      ((size_t)K * ld * 4 < 0xffffffffull) && x_rows_bytes_ok && ld_ok;
+    if ((strided || folded) && !fast) return DODA_ERR_UNSUPPORTED;
     if (out32 && sizeof(elem) != 4 && !fast) return DODA_ERR_UNSUPPORTED;
     if (ep.stats && !fast) return DODA_ERR_UNSUPPORTED;   // the statistics ride in the fast kernel's epilogue only
     const int mode = pack_mode(K, kc, (int)sizeof(elem));
@@ -899,18 +1083,43 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
                                nc, n_chunk, NB, wl & 3, (frag *)ws);
     }
     if (ep.res_bcast && !fast) return DODA_ERR_UNSUPPORTED;   // (the broadcast residual lives in conv_fast's epilogue)
+    if (folded) {
+        // the folded BatchNorm: 16-byte pieces of rows in the output's dtype (bf16 >= 32 channels, fp32), at most PRE_MAX_C
+        // channels, every operand 16-byte aligned; split blocks — 16 rows x one channel block while the grid stays small,
+        // 32 rows x four channel blocks above (the shapes the unfolded call would take at the coarse levels)
+        const size_t va16 = 16 / sizeof(elem);
+        const int pk = pre->kind & 0xff;     // (the high bits carry the DODA_PRE_ABLATE mask of debug builds)
+        if (out32 || pair || (sizeof(elem) == 2 && !wide) || kc > PRE_MAX_C || kc % (int)va16 != 0 || x_ld % va16 != 0 ||
+            !pre->side || pre->side_ld % va16 != 0 || ((uintptr_t)pre->side % 16) != 0 || pre->rows != (int)n_in ||
+            (pk >= 2 && (!pre->aux || pre->aux_ld % va16 != 0 || ((uintptr_t)pre->aux % 16) != 0 || !pre->mean || !pre->invstd ||
+                                !pre->tot.ta || (size_t)n_in * pre->aux_ld * sizeof(elem) >= 0x7ffffff0ull)) ||
+            (pk >= 3 && (!pre->add || pre->add_ld % va16 != 0 || ((uintptr_t)pre->add % 16) != 0 ||
+                                (size_t)n_in * pre->add_ld * sizeof(elem) >= 0x7ffffff0ull)) ||
+            (pk == 1 && !pre->tot.ta && (!pre->tot.rm || !pre->tot.rv)) || !pre->gamma || !pre->beta)
+            return DODA_ERR_UNSUPPORTED;
+        typedef typename FastPolicy<T>::wide PWp;
+        typedef typename FastPolicy<T>::narrow PNp;
+        const long long wf = ((long long)n_out + 15) / 16;
+        static const long long small_max = [] { const char *e = getenv("DODA_PRE_SMALL_BLOCKS"); return e && *e ? atoll(e) : 2048ll; }();
+        if (wf * NB <= small_max) {
+            if (wide) return launch_fast<PWp, 1, 1, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, ep, n_part, s, pre);
+            return launch_fast<PNp, 1, 1, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, ep, n_part, s, pre);
+        }
+        if (wide) return launch_fast<PWp, 4, 2, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, ep, n_part, s, pre);
+        return launch_fast<PNp, 4, 2, true>(x, kc, wp, need, nc, NB, tbl, ld, K, n_out, n_in, y_, out32, res, ep, n_part, s, pre);
+    }
     // K <= 8, 32 input channels, fewer input rows than output rows (the k2 s2 rulebook read from the fine side: one source row
     // per output row): conv_up32 (spconv_tile.hip).  DODA_CONV_UP=0 / doda_set_option(DODA_OPT_CONV_UP, 0): conv_fast as before.
     {
         if (doda_tile::up_enabled() && wide && sizeof(elem) == 2 && kc == 32 && K <= 8 && K > 1 && n_in < (long long)n_out && nc % 16 == 0 &&
-            !ep.res_bcast && doda_tile::enabled()) {
+            !ep.res_bcast && !strided && doda_tile::enabled()) {
             const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
             const unsigned yb = (unsigned)((size_t)n_out * nc * (out32 ? 4 : sizeof(elem)));
             return doda_tile::launch_conv_up32(out32, x_, xb, wp, (unsigned)need, nc, NB, K, tbl, ld, n_out, y_, yb, res, ep, n_part, s);
         }
     }
     // A tilebook of this table and rows of 32 / 64 bytes: the LDS-staged tile kernel (spconv_tile.hip)
-    if (!ep.res_bcast) {
+    if (!ep.res_bcast && !strided) {
         // (fp32 rows: the tile kernel's fp32 mode is bound by the fp32 matrix rate like the dense-table kernel and measured
         // within a few percent of it; DODA_F32_CONV_TILE=0 keeps fp32 forward / data-grad calls on conv_fast even when the
         // table carries a tilebook — the fp32 weight gradient uses the tilebook either way)
@@ -926,7 +1135,7 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
         }
     }
     // 48 -> 48 channels on a mid-size level: the layer's fragments in LDS, one workgroup per CU (spconv_wlds.hip)
-    if (!ep.res_bcast && wide && kc == 48 && nc == 48 && K == 27 && !out32 && n_out >= 8192 && n_out <= 262144 && doda_wlds::enabled()) {
+    if (!ep.res_bcast && !strided && wide && kc == 48 && nc == 48 && K == 27 && !out32 && n_out >= 8192 && n_out <= 262144 && doda_wlds::enabled()) {
         const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
         const unsigned yb = (unsigned)((size_t)n_out * nc * sizeof(elem));
         return doda_wlds::launch_conv48(x_, xb, wp, tbl, (unsigned)((size_t)K * ld * 4), ld, n_out, y_, yb, res, ep, n_part, s);
@@ -1057,6 +1266,8 @@ extern "C" int doda_set_option(int32_t option, int32_t value) {
     case DODA_OPT_TILE_PIPELINE: doda_tile::set_pipeline(value != 0); return DODA_OK;
     case DODA_OPT_TILE_DUAL: doda_tile::set_dual(value != 0); return DODA_OK;
     case DODA_OPT_CONV_UP: doda_tile::set_up(value != 0); return DODA_OK;
+    case DODA_OPT_PRE_FWD_ROWS: doda_layers::set_fwd_rows(value); return DODA_OK;
+    case DODA_OPT_PRE_BWD_ROWS: doda_layers::set_bwd_rows(value); return DODA_OK;
     default: return DODA_ERR_INVALID;
     }
 }
@@ -1068,6 +1279,8 @@ extern "C" int32_t doda_get_option(int32_t option) {
     case DODA_OPT_TILE_PIPELINE: return doda_tile::pipeline_enabled() ? 1 : 0;
     case DODA_OPT_TILE_DUAL: return doda_tile::dual_enabled() ? 1 : 0;
     case DODA_OPT_CONV_UP: return doda_tile::up_enabled() ? 1 : 0;
+    case DODA_OPT_PRE_FWD_ROWS: return (int32_t)doda_layers::fwd_rows();
+    case DODA_OPT_PRE_BWD_ROWS: return (int32_t)doda_layers::bwd_rows();
     default: return -1;
     }
 }
@@ -1103,13 +1316,49 @@ extern "C" int doda_spconv_gather_ex(const void *x, int32_t n_in, int32_t kc, in
             }
         }
     }
+    PreArgs pre{};
+    const PreArgs *prep = nullptr;
+    if (epi) {
+        if (epi->x_ld < 0 || epi->y_ld < 0 || epi->residual_ld < 0 || epi->bn_x_ld < 0) return DODA_ERR_INVALID;
+        ep.x_ld = (unsigned)epi->x_ld; ep.y_ld = (unsigned)epi->y_ld;
+        ep.res_ld = res ? (unsigned)epi->residual_ld : 0u; ep.bnx_ld = ep.bn_x ? (unsigned)epi->bn_x_ld : 0u;
+        if ((ep.x_ld && ep.x_ld < (unsigned)kc) || (ep.y_ld && ep.y_ld < (unsigned)nc) || (ep.res_ld && ep.res_ld < (unsigned)nc) ||
+            (ep.bnx_ld && ep.bnx_ld < (unsigned)nc))
+            return DODA_ERR_INVALID;
+        if (ep.x_ld == (unsigned)kc) ep.x_ld = 0;      // dense
+        if (ep.y_ld == (unsigned)nc) ep.y_ld = 0;
+        if (ep.res_ld == (unsigned)nc) ep.res_ld = 0;
+        if (ep.bnx_ld == (unsigned)nc) ep.bnx_ld = 0;
+        if (ep.res_bcast) ep.res_ld = 0;
+        if (const doda_conv_prologue *q = epi->prologue) {
+            if (q->kind < 1 || q->kind > 3 || q->rows != n_in || q->side_ld < kc || (q->kind >= 2 && q->aux_ld < kc) ||
+                (q->kind >= 3 && q->add_ld < kc) || (q->kind >= 2 && (!q->dgamma || !q->dbeta || !q->totals)) ||
+                (q->kind == 1 && q->totals && (!q->mean || !q->invstd || (!q->running_mean != !q->running_var))) ||
+                (q->kind == 1 && q->totals_b && (q->c_a <= 0 || q->c_a >= kc || q->c_a % 4 || !q->totals)))
+                return DODA_ERR_INVALID;
+            pre.kind = q->kind; pre.relu = q->relu ? 1 : 0; pre.rows = q->rows;
+#ifdef DODA_PRE_ABLATE
+            { static const int ab = getenv("DODA_PRE_ABLATE") ? atoi(getenv("DODA_PRE_ABLATE")) : 0; pre.kind |= ab << 8; }
+#endif
+            pre.tot.ta = q->totals; pre.tot.tb = q->kind == 1 ? q->totals_b : nullptr;
+            pre.tot.ca = (q->kind == 1 && q->totals_b) ? q->c_a : kc;
+            pre.tot.m = q->rows; pre.tot.eps = q->eps; pre.tot.momentum = q->momentum;
+            pre.tot.rm = q->running_mean; pre.tot.rv = q->running_var; pre.tot.nbt = (long long *)q->num_batches_tracked;
+            if (q->kind == 1) { pre.tot.out_a = q->mean; pre.tot.out_b = q->invstd; }
+            else { pre.tot.out_a = q->dgamma; pre.tot.out_b = q->dbeta; pre.tot.accum = q->accumulate ? 1 : 0; pre.tot.rm = nullptr; pre.tot.rv = nullptr; pre.tot.nbt = nullptr; }
+            pre.gamma = q->gamma; pre.beta = q->beta; pre.mean = q->mean; pre.invstd = q->invstd;
+            pre.side = q->side; pre.side_ld = (unsigned)q->side_ld;
+            pre.aux = q->aux; pre.add = q->add; pre.aux_ld = (unsigned)q->aux_ld; pre.add_ld = (unsigned)q->add_ld;
+            prep = &pre;
+        }
+    }
     if (elem_bytes == 4)
         st = run_gather<F32>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, false, res,
-                             as_stream(stream), ep, &n_part, epi ? epi->tilebook : nullptr, epi ? epi->tilebook_rows : 0);
+                             as_stream(stream), ep, &n_part, epi ? epi->tilebook : nullptr, epi ? epi->tilebook_rows : 0, prep);
     else
         st = run_gather<BF16>(x, kc, w, nc, tbl, ld, K, n_out, y, w_layout, ws, ws_bytes, n_in, y_is_f32 != 0, res,
                               as_stream(stream), ep, &n_part, epi ? epi->tilebook : nullptr,
-                              epi ? epi->tilebook_rows : 0);
+                              epi ? epi->tilebook_rows : 0, prep);
     if (st == DODA_OK && epi && epi->stats_rows_h) *epi->stats_rows_h = n_part;
     return st;
 }

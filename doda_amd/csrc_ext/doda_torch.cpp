@@ -1389,12 +1389,19 @@ uint32_t *sync_words(const at::Tensor &like) {
     return (uint32_t *)s.words.data_ptr();
 }
 
+// Two backends walk the same op list (include/doda_hip.h): the persistent executor (doda_coarse_run: ONE launch on one XCD, fp32
+// partial rows as statistics) and — ABI 11, `layers` — whole-chip per-layer launches issued from inside the library
+// (doda_layers_run: fp64 totals as statistics, BatchNorm ops folded into the consuming convolution's gather).
 struct Builder {
     std::vector<doda_cx_op> ops;
     Arena arena;
     int G = 0;
     at::TensorOptions bf;
     bool first = true;
+    bool layers = false;
+    int esz = 2;
+    std::vector<at::Tensor> tot_keep;   // totals slices of this pass (zeroed arena of stats_totals_take)
+    int launches = 0;
 
     doda_cx_op &push(int kind, int flags) {
         ops.emplace_back();
@@ -1402,18 +1409,31 @@ struct Builder {
         memset(&o, 0, sizeof(o));
         o.kind = kind;
         o.flags = flags;
-        o.n_part = G;
+        o.n_part = layers ? 0 : G;
         return o;
+    }
+    // statistics of a c-channel tensor: G partial rows (executor) or zeroed fp64 totals (layers), as the op field's float *
+    float *stat_buf(int c) {
+        if (!layers) return arena.floats((size_t)G * 2 * c);
+        at::Tensor t = stats_totals_take(c, bf);
+        tot_keep.push_back(t);
+        return (float *)t.data_ptr();
     }
     Val dense(int rows, int c, bool as_tensor) {
         Val v;
         v.rows = rows; v.c = c; v.ld = c;
         if (as_tensor) { v.t = pempty({rows, c}, bf); v.p = v.t.data_ptr(); }
-        else v.p = arena.alloc((size_t)rows * c * 2);
+        else v.p = arena.alloc((size_t)rows * c * esz);
         return v;
     }
     void run(const at::Tensor &like) {
         if (ops.empty()) return;
+        if (layers) {
+            int32_t n = 0;
+            check(doda_layers_run(ops.data(), (int32_t)ops.size(), esz, &n, stream_of(like)), "doda_layers_run");
+            launches = n;
+            return;
+        }
         const size_t nb = doda_coarse_desc_bytes((int32_t)ops.size());
         void *desc = arena.alloc(nb);
         check(doda_coarse_run(ops.data(), (int32_t)ops.size(), desc, nb, sync_words(like), stream_of(like)), "doda_coarse_run");
@@ -1421,7 +1441,7 @@ struct Builder {
 
     // ---- forward ----
     void stats_of(Val &x) {   // a tensor that arrives without statistics (the executor's input)
-        x.stats = arena.floats((size_t)G * 2 * x.c);
+        x.stats = stat_buf(x.c);
         x.stats_b = nullptr;
         x.c_split = x.c;
         doda_cx_op &o = push(DODA_CX_STATS, first ? 0 : DODA_CX_F_BARRIER);
@@ -1449,19 +1469,20 @@ struct Builder {
         }
     }
     // y = conv(L.a) (+ res), statistics of y when `want_stats`; `out` preset (p / ld) = where y goes
+    // (identity: the 1x1 convolution — the executor needs no table; the per-layer kernels read the identity table `tbl`)
     void gemm_fwd(Layer &L, const at::Tensor &tbl, bool identity, Val &out, const Val *res, bool want_stats, bool barrier) {
         doda_cx_op &o = push(DODA_CX_GEMM, (barrier ? DODA_CX_F_BARRIER : 0) | (identity ? DODA_CX_F_IDENTITY : 0));
         first = false;
         o.rows = out.rows; o.rows_in = (int32_t)L.a.size(0); o.c_in = (int32_t)L.a.size(1); o.c_out = out.c;
         o.K = identity ? 1 : (int32_t)tbl.size(0);
-        o.tbl = identity ? nullptr : (const int32_t *)tbl.data_ptr();
+        o.tbl = (identity && !layers) ? nullptr : (const int32_t *)tbl.data_ptr();
         o.tbl_ld = identity ? out.rows : (int32_t)tbl.size(1);
         o.x = L.a.data_ptr(); o.x_ld = (int32_t)L.a.size(1);
         o.w = L.cv.pk_fwd.data_ptr();
         o.y = out.p; o.y_ld = out.ld;
         if (res) { o.res = res->p; o.res_ld = res->ld; }
         if (want_stats) {
-            out.stats = arena.floats((size_t)G * 2 * out.c);
+            out.stats = stat_buf(out.c);
             out.stats_b = nullptr;
             out.c_split = out.c;
             o.stats = out.stats;
@@ -1469,11 +1490,14 @@ struct Builder {
     }
 };
 
+int g_coarse_launches_fwd = 0, g_coarse_launches_bwd = 0;   // launches of the last per-layer forward / backward list (tests, tools)
+
 struct CoarseNode : public torch::autograd::Node {
     std::vector<Step> steps;
     std::vector<at::Tensor> keep;      // arena chunks and tensors the saved pointers refer to
     at::Tensor x_in;                   // (kept for its size / options)
     int G = 0;
+    bool layers = false;
 
     // gamma / beta gradient targets: the reducer's bucket views when the parameters have homes, existing .grad tensors
     // (accumulate) or fresh tensors deposited afterwards
@@ -1484,9 +1508,11 @@ struct CoarseNode : public torch::autograd::Node {
         variable_list out(1);
         if (!grads[0].defined()) return out;
         at::Tensor g = grads[0].contiguous();
-        TORCH_CHECK(g.scalar_type() == at::kBFloat16, "doda coarse: gradient dtype");
+        TORCH_CHECK(g.scalar_type() == x_in.scalar_type(), "doda coarse: gradient dtype");
         Builder B;
         B.G = G;
+        B.layers = layers;
+        B.esz = elem_bytes(g);
         B.bf = g.options();
         B.arena.opt = g.options().dtype(at::kByte);
         const int task = torch::autograd::get_current_graph_task_id();
@@ -1514,8 +1540,8 @@ struct CoarseNode : public torch::autograd::Node {
         bool first = true;
         // dz = data gradient of L's conv applied to `dy`, masked by L's ReLU; statistics for L's BatchNorm backward
         auto gemm_bwd = [&](const Layer &L, const at::Tensor &dy, bool identity, float *&st, bool barrier) -> void * {
-            void *dz = B.arena.alloc((size_t)L.n_in * L.c_in * 2);
-            st = B.arena.floats((size_t)G * 2 * L.c_in);
+            void *dz = B.arena.alloc((size_t)L.n_in * L.c_in * B.esz);
+            st = B.stat_buf(L.c_in);
             doda_cx_op &o = B.push(DODA_CX_GEMM, (barrier && !first ? DODA_CX_F_BARRIER : 0) | DODA_CX_F_RELU | (identity ? DODA_CX_F_IDENTITY : 0));
             first = false;
             o.rows = L.n_in; o.rows_in = L.n_out; o.c_in = L.c_out; o.c_out = L.c_in;
@@ -1551,7 +1577,9 @@ struct CoarseNode : public torch::autograd::Node {
                     if (pb.accum) { pb.buf = pempty({c}, pb.param.options().dtype(at::kFloat)); pb.accum = false; pb.fresh = true; db = (float *)pb.buf.data_ptr(); }
                 } else if (f1) flags |= DODA_CX_F_ACCUM;
             }
+            if (layers) flags |= DODA_CX_F_RELU;   // (the per-layer data-grad kernels store dz unmasked: the op masks, and needs beta)
             doda_cx_op &o = B.push(DODA_CX_BNBWD, flags);
+            o.beta = (const float *)L.bn.beta.data_ptr();
             o.rows = L.n_in; o.c_in = c; o.c_split = split;
             o.x = dz; o.x_ld = c;
             o.aux = L.x.p; o.aux_ld = L.x.ld;
@@ -1574,6 +1602,7 @@ struct CoarseNode : public torch::autograd::Node {
                     gS = pempty({S.l1.n_in, S.l1.c_in}, B.bf);
                     keep_alive.push_back(gS);
                     doda_cx_op &o = B.push(DODA_CX_GEMM, DODA_CX_F_IDENTITY);
+                    if (layers) o.tbl = (const int32_t *)S.ident.data_ptr();
                     o.rows = S.l1.n_in; o.rows_in = S.l1.n_in; o.c_in = S.l2.c_out; o.c_out = S.l1.c_in; o.K = 1; o.tbl_ld = S.l1.n_in;
                     o.x = g.data_ptr(); o.x_ld = S.l2.c_out; o.w = S.skip.pk_bwd.data_ptr(); o.y = gS.data_ptr(); o.y_ld = S.l1.c_in;
                 }
@@ -1614,6 +1643,7 @@ struct CoarseNode : public torch::autograd::Node {
         // (the arena of this pass must outlive the launch: the caching allocator re-uses a freed block only for work queued
         // LATER on this stream, which is ordered behind the launch)
         keep_alive.clear();
+        g_coarse_launches_bwd = B.launches;
         if (task_should_compute_output(0)) out[0] = g;
         return out;
     }
@@ -1627,11 +1657,14 @@ struct CoarseNode : public torch::autograd::Node {
 };
 
 // Returns {y [n, c] bf16, statistics partial rows of y [G, 2, c] (training) or undefined}.
+// layers: the per-layer backend (doda_layers_run; bf16 or fp32 features, statistics as fp64 totals) instead of the executor.
 std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optional<at::Tensor> &stats_in, const std::vector<int64_t> &kinds,
-                                      const std::vector<TList> &tensors, const std::vector<std::vector<double>> &scalars, bool training) {
+                                      const std::vector<TList> &tensors, const std::vector<std::vector<double>> &scalars, bool training,
+                                      bool layers) {
     host_timing::Scope host_scope(6);
-    TORCH_CHECK(x_in.is_cuda() && x_in.dim() == 2 && x_in.scalar_type() == at::kBFloat16 && x_in.size(0) >= 2,
-                "doda coarse_ublock: bf16 device features");
+    TORCH_CHECK(x_in.is_cuda() && x_in.dim() == 2 && x_in.size(0) >= 2 &&
+                (x_in.scalar_type() == at::kBFloat16 || (layers && x_in.scalar_type() == at::kFloat)),
+                "doda coarse_ublock: bf16 device features (the per-layer backend also takes fp32)");
     TORCH_CHECK(kinds.size() == tensors.size() && kinds.size() == scalars.size() && !kinds.empty(), "doda coarse_ublock: step lists");
     const bool need_grad = at::GradMode::is_enabled() && x_in.requires_grad();
     TORCH_CHECK(!need_grad || (training && g_direct_grads && g_defer_wgrad),
@@ -1640,14 +1673,18 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
     const at::Tensor x = x_in.contiguous();
     Builder B;
     B.G = doda_coarse_workgroups();
+    B.layers = layers;
+    B.esz = elem_bytes(x);
     B.bf = x.options();
     B.arena.opt = x.options().dtype(at::kByte);
     std::vector<Step> steps(kinds.size());
     Val cur;
     cur.p = x.data_ptr(); cur.rows = (int)x.size(0); cur.c = (int)x.size(1); cur.ld = cur.c; cur.t = x;
     at::Tensor stats_keep;
-    if (training && stats_in.has_value() && stats_in->defined() && stats_in->dim() == 3 && stats_in->size(0) == B.G &&
-        stats_in->size(2) == cur.c && stats_in->scalar_type() == at::kFloat && stats_in->is_contiguous()) {
+    if (training && stats_in.has_value() && stats_in->defined() &&
+        (layers ? is_totals(*stats_in, cur.c)
+                : (stats_in->dim() == 3 && stats_in->size(0) == B.G && stats_in->size(2) == cur.c && stats_in->scalar_type() == at::kFloat &&
+                   stats_in->is_contiguous()))) {
         stats_keep = *stats_in;
         cur.stats = (float *)stats_keep.data_ptr();
         cur.c_split = cur.c;
@@ -1692,7 +1729,7 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
                 Layer sk;
                 sk.a = cur.t;
                 sk.cv = S.skip;
-                B.gemm_fwd(sk, at::Tensor(), true, skipv, nullptr, false, false);
+                B.gemm_fwd(sk, S.ident, true, skipv, nullptr, false, false);
             }
             S.l2.x = y1;
             B.bn_fwd(S.l2, training);
@@ -1706,8 +1743,8 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
                 y = B.dense(n, cout, last);
                 if (last) y_out = y.t;
             }
-            if (last && training) {   // the caller may feed these rows to the next fused BatchNorm
-                y_stats = pempty({B.G, 2, cout}, x.options().dtype(at::kFloat));
+            if (last && training) {   // the caller may feed these rows (layers: totals) to the next fused BatchNorm
+                y_stats = layers ? stats_totals_take(cout, x.options()) : pempty({B.G, 2, cout}, x.options().dtype(at::kFloat));
             }
             B.gemm_fwd(S.l2, tbl, false, y, &skipv, training, true);
             if (last && training) {   // (gemm_fwd put the partial rows into the arena: point the op at the returned tensor instead)
@@ -1739,7 +1776,7 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
                 skips.pop_back();
                 TORCH_CHECK(sk.left.rows == n_out && sk.left.c == cout, "doda coarse_ublock: the inverse conv must restore the skipped level");
                 Val u;
-                u.p = (char *)sk.cat.data_ptr() + (size_t)cout * 2; u.rows = n_out; u.c = cout; u.ld = 2 * cout;
+                u.p = (char *)sk.cat.data_ptr() + (size_t)cout * B.esz; u.rows = n_out; u.c = cout; u.ld = 2 * cout;
                 B.gemm_fwd(S.l1, S.l1.fwd_tbl, false, u, nullptr, training, true);
                 Val cat;
                 cat.p = sk.cat.data_ptr(); cat.rows = n_out; cat.c = 2 * cout; cat.ld = 2 * cout; cat.t = sk.cat;
@@ -1752,11 +1789,13 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
     }
     TORCH_CHECK(y_out.defined() && skips.empty(), "doda coarse_ublock: the last step must be a residual block at the input's level");
     B.run(x);
+    g_coarse_launches_fwd = B.launches;
     g_last_bn.reset();
     if (need_grad) {
         auto node = std::shared_ptr<CoarseNode>(new CoarseNode(), torch::autograd::deleteNode);
         node->set_next_edges(torch::autograd::collect_next_edges(x_in));
         node->steps = std::move(steps);
+        node->layers = layers;
         node->keep = B.arena.chunks;
         if (stats_keep.defined()) node->keep.push_back(stats_keep);
         node->keep.push_back(x);
@@ -1993,11 +2032,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::call_guard<py::gil_scoped_release>());
     m.def("coarse_ublock", [](const at::Tensor &x, const c10::optional<at::Tensor> &stats_in, const std::vector<int64_t> &kinds,
                               const std::vector<std::vector<c10::optional<at::Tensor>>> &tensors,
-                              const std::vector<std::vector<double>> &scalars, bool training) {
-        auto r = coarse::coarse_ublock(x, stats_in, kinds, tensors, scalars, training);
+                              const std::vector<std::vector<double>> &scalars, bool training, bool layers) {
+        auto r = coarse::coarse_ublock(x, stats_in, kinds, tensors, scalars, training, layers);
         return std::make_pair(r[0], r[1].defined() ? c10::optional<at::Tensor>(r[1]) : c10::nullopt);
-    }, "a U-Net subtree of coarse levels as one persistent launch per direction (doda_coarse_run)",
-          py::arg("x"), py::arg("stats_in"), py::arg("kinds"), py::arg("tensors"), py::arg("scalars"), py::arg("training"));
+    }, "a U-Net subtree of coarse levels as one op list per direction: one persistent launch (doda_coarse_run) or, layers = True, "
+       "per-layer launches issued inside the library with the BatchNorm ops folded into the convolutions (doda_layers_run)",
+          py::arg("x"), py::arg("stats_in"), py::arg("kinds"), py::arg("tensors"), py::arg("scalars"), py::arg("training"),
+          py::arg("layers") = false);
+    m.def("coarse_launches", []() { return std::make_pair((int64_t)coarse::g_coarse_launches_fwd, (int64_t)coarse::g_coarse_launches_bwd); },
+          "kernel launches of the last per-layer forward / backward op list");
     m.def("coarse_workgroups", []() { return (int64_t)doda_coarse_workgroups(); });
     m.def("coarse_error", [](int64_t device) {   // a grid barrier of an earlier executor launch on `device` timed out (synchronises)
         std::lock_guard<std::mutex> lock(coarse::g_sync_mu);

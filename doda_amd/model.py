@@ -208,23 +208,50 @@ class VGGBlock(SparseModule):
         return self.conv_layers(input)
 
 
-# Coarse-level executor (csrc/coarse.hip): the UBlock subtree from level COARSE_EXEC_LEVEL down runs as ONE
-# persistent launch forward and ONE backward (bf16 features, compiled extension, training with deferred weight gradients and
-# direct parameter gradients, or any no-grad pass).  Built, parity-tested against the per-layer path and fp32
-# (tests/test_gpu_coarse.py) and MEASURED SLOWER on MI355X (2 x ~1.1 ms per step for levels 5-7 against
-# ~1.0 ms for the ~110 launches it replaces — one XCD has 1/8 of the chip's loads in flight, and a grid barrier over more XCDs
-# costs more than the kernel boundary it saves), so it is OPT-IN: DODA_COARSE_EXEC=1 / set_coarse_exec(True).
-COARSE_EXEC = _os.environ.get("DODA_COARSE_EXEC", "0") == "1"
-COARSE_EXEC_LEVEL = int(_os.environ.get("DODA_COARSE_LEVEL", "5"))
-COARSE_MAX_ROWS = int(_os.environ.get("DODA_COARSE_MAX_ROWS", "16384"))   # above: the whole-chip per-layer kernels win
+# Coarse levels as ONE extension call per direction (csrc_ext coarse_ublock: a UBlock subtree compiled into an op list, one autograd
+# node, gradients of every layer incl. the deferred weight-gradient jobs).  Two backends walk the list (include/doda_hip.h):
+#   "layers" (round 6, default): whole-chip per-layer launches issued inside the library (doda_layers_run) with every BatchNorm
+#            whose rows are few folded into the gather of the convolution behind it, forward and backward, and the level
+#            concatenations written in place by their two producers — ~55 launches, ~100 autograd nodes and the interpreter
+#            between them less per step; bf16 and fp32;
+#   "exec"   (round 5): ONE persistent launch on one XCD (doda_coarse_run).  Wins where the step is host-bound (<= 2 scenes),
+#            loses at the bench size (one XCD has 1/8 of the chip's matrix rate);
+#   "auto":  "exec" when the subtree's input has at most COARSE_EXEC_MAX_ROWS rows, else "layers";   "off": module by module.
+# DODA_COARSE_MODE picks; the legacy switch DODA_COARSE_EXEC=1 means "exec".
+COARSE_MODE = _os.environ.get("DODA_COARSE_MODE", "exec" if _os.environ.get("DODA_COARSE_EXEC", "0") == "1" else "layers")
+COARSE_EXEC = COARSE_MODE == "exec"                                              # (kept: tools and tests read it)
+COARSE_EXEC_LEVEL = int(_os.environ.get("DODA_COARSE_LEVEL", "5" if COARSE_MODE == "exec" else "4"))
+COARSE_MAX_ROWS = int(_os.environ.get("DODA_COARSE_MAX_ROWS", "16384"))          # executor: above, the whole-chip kernels win
+COARSE_LAYERS_MAX_ROWS = int(_os.environ.get("DODA_COARSE_LAYERS_MAX_ROWS", "262144"))
+COARSE_EXEC_MAX_ROWS = int(_os.environ.get("DODA_COARSE_EXEC_MAX_ROWS", "1200"))  # "auto": rows of the subtree's input
 
 
 def set_coarse_exec(on, level=None):
-    global COARSE_EXEC, COARSE_EXEC_LEVEL
-    COARSE_EXEC = bool(on)
+    """Legacy switch of the round-5 tests: the persistent executor on / off (off = module by module)."""
+    return set_coarse_mode("exec" if on else "off", level)
+
+
+def set_coarse_mode(mode, level=None):
+    """mode: "layers" | "exec" | "auto" | "off"; level: the U-Net level whose UBlock subtree becomes one extension call."""
+    global COARSE_MODE, COARSE_EXEC, COARSE_EXEC_LEVEL
+    assert mode in ("layers", "exec", "auto", "off"), mode
+    COARSE_MODE = mode
+    COARSE_EXEC = mode == "exec"
     if level is not None:
         COARSE_EXEC_LEVEL = int(level)
-    return COARSE_EXEC
+    return mode
+
+
+def choose_coarse_backend(rows, dtype):
+    """Which backend runs a subtree whose input has `rows` rows: "layers", "exec" or None (module by module)."""
+    if COARSE_MODE == "off":
+        return None
+    if COARSE_MODE == "exec" or (COARSE_MODE == "auto" and rows <= COARSE_EXEC_MAX_ROWS):
+        if dtype == torch.bfloat16 and 2 <= rows <= COARSE_MAX_ROWS:
+            return "exec"
+        if COARSE_MODE == "exec":
+            return None
+    return "layers" if 2 <= rows <= COARSE_LAYERS_MAX_ROWS else None
 
 
 def _bn_list(bn):
@@ -339,9 +366,12 @@ class UBlock(nn.Module):
         ext = Fsp._ext
         feats = input.features
         if (ext is None or not Fsp._SERIAL or not hasattr(ext, "coarse_ublock") or not feats.is_cuda
-                or feats.dtype != torch.bfloat16 or feats.dim() != 2 or not (2 <= feats.shape[0] <= COARSE_MAX_ROWS)
+                or feats.dtype not in (torch.bfloat16, torch.float32) or feats.dim() != 2
                 or _torch_module._global_forward_hooks or _torch_module._global_forward_pre_hooks
                 or _torch_module._global_backward_hooks or _torch_module._global_backward_pre_hooks):
+            return None
+        backend = choose_coarse_backend(feats.shape[0], feats.dtype)
+        if backend is None:
             return None
         plan = self._coarse_modules()
         if plan is False:
@@ -398,7 +428,7 @@ class UBlock(nn.Module):
                     scalars.append([bn.eps, bn.momentum, rows[lvl]])
         st = input.__dict__.get("_doda_stats")
         stats_in = st[1] if (st is not None and st[0] is feats and st[2] == feats._version and torch.is_tensor(st[1])) else None
-        y, stats = ext.coarse_ublock(feats, stats_in, kinds, tensors, scalars, training)
+        y, stats = ext.coarse_ublock(feats, stats_in, kinds, tensors, scalars, training, backend == "layers")
         out = spconv.SparseConvTensor(y, input.indices, input.spatial_shape, input.batch_size)
         out.indice_dict = idict
         out.grid = input.grid
@@ -416,7 +446,7 @@ class UBlock(nn.Module):
                 fn()
                 return g
             input.features.register_hook(_fire)
-        if COARSE_EXEC and self.level == COARSE_EXEC_LEVEL:
+        if COARSE_MODE != "off" and self.level == COARSE_EXEC_LEVEL:
             out = self._forward_coarse(input)
             if out is not None:
                 return out

@@ -335,11 +335,13 @@ def totals_from_rows(rows):
     return t
 
 
-class _ConvEpilogue(C.Structure):   # doda_conv_epilogue (include/doda_hip.h, ABI 9)
+class _ConvEpilogue(C.Structure):   # doda_conv_epilogue (include/doda_hip.h, ABI 11)
     _fields_ = [("residual", C.c_void_p), ("stats", C.c_void_p), ("stats_rows_h", C.POINTER(C.c_int32)),
                 ("bn_x", C.c_void_p), ("bn_mean", C.c_void_p), ("bn_invstd", C.c_void_p), ("bn_gamma", C.c_void_p),
                 ("bn_beta", C.c_void_p), ("bn_relu", C.c_int32), ("tilebook_rows", C.c_int32),
-                ("tilebook", C.c_void_p), ("residual_bcast", C.c_int32), ("stats_totals", C.c_void_p)]
+                ("tilebook", C.c_void_p), ("residual_bcast", C.c_int32), ("stats_totals", C.c_void_p),
+                ("x_ld", C.c_int32), ("y_ld", C.c_int32), ("residual_ld", C.c_int32), ("bn_x_ld", C.c_int32),   # ABI 11: row strides
+                ("prologue", C.c_void_p)]                                                                         # ABI 11: doda_conv_prologue *
 
 
 def tilebook_build(tbl, n_rows=None):
@@ -922,3 +924,48 @@ def coarse_run(ops, device):
     nbytes = lib().doda_coarse_desc_bytes(n)
     desc = _ws(nbytes, device)
     check(lib().doda_coarse_run(C.cast(arr, C.c_void_p), n, _p(desc), nbytes, _p(st), _stream()), "doda_coarse_run")
+
+
+def _cx_array(ops, n_part):
+    n = len(ops)
+    arr = (_CxOp * n)()
+    ptr_fields = {"x", "w", "tbl", "y", "y2", "res", "aux", "stats", "stats_b", "gamma", "beta", "mean", "invstd",
+                  "running_mean", "running_var", "nbt", "dgamma", "dbeta"}
+    for k, o in enumerate(ops):
+        for name, v in o.items():
+            if name in ptr_fields:
+                if v is not None:
+                    _need_cuda(v)
+                setattr(arr[k], name, v.data_ptr() if v is not None else None)
+            else:
+                setattr(arr[k], name, v)
+        arr[k].n_part = n_part
+    return arr
+
+
+def stats_totals(c, device):
+    """Zeroed fp64 totals for the statistics of a c-channel tensor (the `stats` of an op of layers_run) = totals_zeros."""
+    return totals_zeros(c, device)
+
+
+def layers_run(ops, device, elem_bytes=2):
+    """Run a list of ops (dicts as for coarse_run) through the per-layer backend (doda_layers_run, ABI 11): one whole-chip launch
+    per op, BatchNorm ops folded into the next convolution's gather where their rows are few (set_pre_rows).  `stats` /
+    `stats_b` are fp64 totals (stats_totals).  Returns the number of launches issued."""
+    n = len(ops)
+    arr = _cx_array(ops, 0)
+    launches = C.c_int32(0)
+    check(lib().doda_layers_run(C.cast(arr, C.c_void_p), n, int(elem_bytes), C.byref(launches), _stream()), "doda_layers_run")
+    return int(launches.value)
+
+
+def set_pre_rows(fwd=None, bwd=None):
+    """Row thresholds of layers_run's BatchNorm folding (doda_set_option DODA_OPT_PRE_FWD_ROWS / _BWD_ROWS; 0: never fold).
+    Returns the previous pair."""
+    from ._lib import OPT_PRE_BWD_ROWS, OPT_PRE_FWD_ROWS
+    old = (int(lib().doda_get_option(OPT_PRE_FWD_ROWS)), int(lib().doda_get_option(OPT_PRE_BWD_ROWS)))
+    if fwd is not None:
+        check(lib().doda_set_option(OPT_PRE_FWD_ROWS, int(fwd)), "doda_set_option")
+    if bwd is not None:
+        check(lib().doda_set_option(OPT_PRE_BWD_ROWS, int(bwd)), "doda_set_option")
+    return old

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DODA_ABI_VERSION 10
+#define DODA_ABI_VERSION 11
 
 #define DODA_OK 0
 #define DODA_ERR_INVALID (-1)        /* bad argument (null pointer, negative size, bad mode) */
@@ -256,7 +256,47 @@ typedef struct doda_conv_epilogue {
                                * doda_bn_relu_bwd_totals: BatchNorm in ONE launch, no reduction launch in front of it.  Every addend
                                * is an fp32 value: a sum of a few thousand is exact in fp64 unless the magnitudes span more than
                                * ~2^16, and then differs between runs by an ulp of fp64 — the statistics are rounded to fp32. */
+    int32_t x_ld, y_ld, residual_ld, bn_x_ld;   /* ABI 11: row strides in ELEMENTS of x / y / residual / bn_x (0 = dense: kc, nc, nc, nc;
+                               * multiples of 4): a column slice of a wider matrix — one half of a U-Net level's concatenation
+                               * (reference model/unet_block.py:89-93: the two producing convs write the halves, no torch.cat
+                               * launch) — is read / written in place.  Dense-table fast kernel only (else DODA_ERR_UNSUPPORTED) */
+    const struct doda_conv_prologue *prologue;   /* ABI 11: a BatchNorm folded into the gather (below), or NULL */
 } doda_conv_epilogue;
+/* ABI 11.  The BatchNorm1d(+ReLU) in FRONT of a convolution folded into that convolution's gather — the BatchNorm launch of
+ * reference model/unet_block.py:23-30,46-49,67-79 (BatchNorm1d -> ReLU -> conv, 65 pairs per forward pass of model/unet.py:42-45)
+ * disappears, forward and backward.  Where it pays: layers of a few thousand rows and fewer (U-Net levels 4-7), where a BatchNorm
+ * sweep is a launch-floor kernel; every gathered row is transformed once per kernel offset that reads it.
+ *   kind 1, forward: y = sum_o xn[tbl[o][t]] . B_o with xn = [relu]((x - mean) * invstd * gamma + beta) rounded to the storage
+ *       type.  Training: mean / invstd come from `totals` (the fp64 sums the conv that PRODUCED x accumulated:
+ *       doda_conv_epilogue.stats_totals; `totals_b` / `c_a`: x is a channel concatenation [a | b] of two producers), every
+ *       workgroup derives them itself; the launch writes mean / invstd, updates running_mean / running_var (momentum, unbiased
+ *       variance) and num_batches_tracked once.  totals == NULL: evaluation mode, the running statistics are used as they are.
+ *       `side` [rows, kc] (row stride side_ld) receives xn — the operand of the layer's weight gradient.
+ *   kind 2, backward: x = dz, the data gradient a later conv produced for the BatchNorm's OUTPUT with the sums (sum dz', sum dz' xhat)
+ *       in `totals` (its data-grad statistics epilogue, bn_x = aux); the gathered rows are
+ *       du = gamma invstd ([gamma xhat + beta > 0] dz - mean(dz') - xhat mean(dz' xhat)), xhat = (aux - mean) invstd — the gradient of the
+ *       BatchNorm's INPUT — and feed the data gradient of the conv in front of that BatchNorm; kind 3: du + add (the skip
+ *       connection's gradient, reference model/unet_block.py:36).  `side` receives du; dgamma / dbeta are written (accumulate:
+ *       added to).  aux / add: [rows, kc] with row strides aux_ld / add_ld.
+ * Arithmetic per element = doda_bn_relu_fwd_totals / doda_bn_relu_bwd_totals (same operations, same order: same bits).  Needs
+ * 16-byte rows pieces: bf16 with kc >= 32, kc % 8 == 0, or fp32; kc <= 256; same dtype in and out. */
+typedef struct doda_conv_prologue {
+    int32_t kind, relu;
+    int32_t rows;            /* rows of x, aux, add, side (= n_in of the call) */
+    int32_t c_a;             /* kind 1: channels covered by `totals` when totals_b != NULL */
+    const double *totals, *totals_b;
+    float eps, momentum;
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    int64_t *num_batches_tracked;
+    float *mean, *invstd;    /* kind 1: written in training mode (unused in evaluation mode); kind >= 2: read */
+    void *side;
+    int32_t side_ld;
+    int32_t aux_ld, add_ld;
+    int32_t accumulate;
+    const void *aux, *add;
+    float *dgamma, *dbeta;
+} doda_conv_prologue;
 #define DODA_STATS_SLOTS 8
 #define DODA_STATS_TOTALS_DOUBLES(nc) ((size_t)DODA_STATS_SLOTS * 2 * 16 * ((size_t)(nc) / 4))
 /* ABI 3.  Tile-local form of a SubM gather table ("tilebook") for the LDS-staged convolution kernel:
@@ -295,6 +335,9 @@ int doda_tilebook_build(const int32_t *tbl, int32_t ld, int32_t K, int32_t n_row
 #define DODA_OPT_CONV_UP 6       /* 0: K <= 8 gathers with 32 input channels and fewer input than output rows (inverse convolution
                                   * forward, strided convolution data gradient) stay on the offset-by-offset kernel (default 1:
                                   * conv_up32, one gather per output row) */
+#define DODA_OPT_PRE_FWD_ROWS 7  /* ABI 11, not a 0 / 1 switch: doda_layers_run folds a BNFWD op of at most this many rows into the next
+                                  * convolution's gather (0: never; default 16384 or DODA_PRE_FWD_ROWS) */
+#define DODA_OPT_PRE_BWD_ROWS 8  /* ABI 11: the same for BNBWD ops (default 0 or DODA_PRE_BWD_ROWS) */
 int doda_set_option(int32_t option, int32_t value);
 int32_t doda_get_option(int32_t option);
 size_t doda_spconv_stats_capacity(int32_t n_out);
@@ -596,6 +639,23 @@ int doda_coarse_debug_stamps(void *buf_dev);   /* debug aid (tools/cxstamps.py):
 size_t doda_coarse_desc_bytes(int32_t n_ops);
 int doda_coarse_run(const doda_cx_op *ops_h, int32_t n_ops, void *desc_dev, size_t desc_bytes, uint32_t *sync_dev,
                     doda_stream_t stream);
+
+/* ABI 11: the same op list as WHOLE-CHIP launches, one per op, issued back to back from inside the library (csrc/layers.hip) — the
+ * per-layer kernels of doda_spconv_gather_ex and the BatchNorm sweeps over totals, without the caller's interpreter, autograd
+ * nodes and allocations between them — with every BatchNorm op whose output only feeds the NEXT op's gather folded into that
+ * convolution (doda_conv_prologue): BNFWD ; GEMM -> one launch, BNBWD ; GEMM -> one launch, where the BatchNorm has at most
+ * DODA_PRE_FWD_ROWS (16384) / DODA_PRE_BWD_ROWS (0: the backward fold is built and tested but measured slower on the GPU) rows (environment; doda_set_option).  Same reference scope as doda_coarse_run
+ * (model/unet_block.py:9-37,55-100); the folded and unfolded forms of a list give the same bits.  Differences to doda_coarse_run's
+ * reading of an op:
+ *   - n_part must be 0 and every statistics array (`stats`, `stats_b`) is DODA_STATS_TOTALS_DOUBLES(c) doubles of fp64 TOTALS
+ *     (doda_conv_epilogue.stats_totals), zero before the op that accumulates into them;
+ *   - DODA_CX_F_BARRIER is ignored (stream order); DODA_CX_F_IDENTITY still needs `tbl` (an identity table, K = 1);
+ *   - a data-gradient GEMM (aux != NULL) stores y UNMASKED — the statistics are those of the masked values — and DODA_CX_BNBWD
+ *     applies the mask itself: it needs `beta` and DODA_CX_F_RELU like the forward op;
+ *   - `w` are the fragment-packed weights of doda_spconv_pack_multi for (K, c_in, c_out, elem_bytes) in the op's direction;
+ *   - elem_bytes 2 (bf16) or 4 (fp32) for every feature matrix of the list.
+ * *n_launches_h (optional, HOST) receives the number of kernel launches issued. */
+int doda_layers_run(const doda_cx_op *ops_h, int32_t n_ops, int32_t elem_bytes, int32_t *n_launches_h, doda_stream_t stream);
 
 #ifdef __cplusplus
 }

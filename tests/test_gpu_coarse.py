@@ -297,8 +297,8 @@ def _unet_step(exec_on, level, dtype=torch.bfloat16, voxels=60000, seed=11, two_
     batch = make_batch(2, voxels, seed)
     bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
     net = deterministic_init(SparseConvNet(cfg), seed=3).to(d).train()
-    old = (M.COARSE_EXEC, M.COARSE_EXEC_LEVEL)
-    M.set_coarse_exec(exec_on, level)
+    old = (M.COARSE_MODE, M.COARSE_EXEC_LEVEL)
+    (M.set_coarse_mode(exec_on, level) if isinstance(exec_on, str) else M.set_coarse_exec(exec_on, level))
     try:
         assert Fsp.set_deferred_wgrad(True)
         net.zero_grad(set_to_none=True)
@@ -311,7 +311,7 @@ def _unet_step(exec_on, level, dtype=torch.bfloat16, voxels=60000, seed=11, two_
         torch.cuda.synchronize()
     finally:
         Fsp.set_deferred_wgrad(False)
-        M.set_coarse_exec(*old)
+        M.set_coarse_mode(*old)
     from doda_amd._ext import ext
     assert not ext.coarse_error(0)
     grads = {n: p.grad.detach().float().clone() for n, p in net.named_parameters()}
@@ -339,8 +339,8 @@ def _run_subtree(ub, ind, shape, batch, level, x0, gout, exec_on):
     from doda_amd import model as M
     from doda_amd import spconv
     from doda_amd.spconv import functional as Fsp
-    old = (M.COARSE_EXEC, M.COARSE_EXEC_LEVEL)
-    M.set_coarse_exec(exec_on, level)
+    old = (M.COARSE_MODE, M.COARSE_EXEC_LEVEL)
+    (M.set_coarse_mode(exec_on, level) if isinstance(exec_on, str) else M.set_coarse_exec(exec_on, level))
     try:
         assert Fsp.set_deferred_wgrad(True)
         for p in ub.parameters():
@@ -353,7 +353,7 @@ def _run_subtree(ub, ind, shape, batch, level, x0, gout, exec_on):
         torch.cuda.synchronize()
     finally:
         Fsp.set_deferred_wgrad(False)
-        M.set_coarse_exec(*old)
+        M.set_coarse_mode(*old)
     return (y.detach().float(), x.grad.detach().float(), {n: p.grad.detach().float().clone() for n, p in ub.named_parameters()},
             {n: b.detach().clone() for n, b in ub.named_buffers()})
 
@@ -458,7 +458,7 @@ def test_unet_executor_eval_and_no_grad(native_lib):
     batch = make_batch(2, 40000, 5)
     bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
     net = deterministic_init(SparseConvNet(cfg), seed=4).to(d)
-    old = (M.COARSE_EXEC, M.COARSE_EXEC_LEVEL)
+    old = (M.COARSE_MODE, M.COARSE_EXEC_LEVEL)
     out = {}
     try:
         for mode in ("eval", "train"):
@@ -470,7 +470,7 @@ def test_unet_executor_eval_and_no_grad(native_lib):
                     out[(mode, on)] = voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.bfloat16).float()
                 net.load_state_dict(state)   # (training-mode passes move the running statistics)
     finally:
-        M.set_coarse_exec(*old)
+        M.set_coarse_mode(*old)
     torch.cuda.synchronize()
     assert not ext.coarse_error(0)
     for mode in ("eval", "train"):

@@ -1,0 +1,410 @@
+"""Per-layer backend of the coarse-level op list (csrc/layers.hip, ABI 11: doda_layers_run) and the BatchNorm folded into the
+convolution's gather (doda_conv_prologue; reference model/unet_block.py:23-30,46-49,67-79: BatchNorm1d -> ReLU -> conv, 65
+pairs per forward pass of model/unet.py:42-45), at the row / channel counts of the U-Net's levels 4-7.
+
+Checked against: torch.nn.functional.batch_norm (+ autograd for the backward), the oracle's indice_conv on the normalised rows
+(bf16 tolerance: 2^-7 of the tensor's scale), and the UNFOLDED form of the same op list, whose BatchNorm outputs must be
+bit-equal (the folded transform is the standalone sweep's arithmetic, operation for operation: csrc/bn_totals.hpp).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_coarse import LEVELS, _bf, _level, _pack, _run_subtree, _scale_err, _subtree, _unet_step, dev
+
+pytestmark = pytest.mark.gpu
+
+BIG = 1 << 30
+
+
+def _tables(ops, idx, shape, batch, d):
+    return ops.rulebook_subm(torch.from_numpy(idx).to(d), shape, batch, 3)
+
+
+def _cast(t, dtype):
+    return t.to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("n,c", LEVELS)
+def test_forward_fold_vs_torch_oracle_and_unfolded(native_lib, oracle, n, c, dtype):
+    """BNFWD ; GEMM as one launch: statistics from totals, normalised rows (side output), running statistics, conv output."""
+    from doda_amd import ops
+    d = dev()
+    esz = 2 if dtype == torch.bfloat16 else 4
+    idx, shape, batch = _level(n, n)
+    n = idx.shape[0]
+    pairs, pn = oracle.indice_pairs_subm(idx, batch, shape, 3)
+    tbl = _tables(ops, idx, shape, batch, d)
+    g = torch.Generator().manual_seed(n + esz)
+    for cin, cout in ((c, c), (2 * c, c)):
+        x = _cast(torch.randn(n, cin, generator=g) * 1.7 + 0.3, dtype).to(d)
+        res = _cast(torch.randn(n, cout, generator=g), dtype).to(d)
+        w = (torch.randn(27, cin, cout, generator=g) * (1.0 / (cin * 9)) ** 0.5).to(d)
+        wp = ops.PackPlan([(w, 27, cin, cout, 0, esz)], d)
+        wp.run()
+        wp = wp.outputs[0]
+        gamma = (torch.rand(cin, generator=g) + 0.5).to(d)
+        beta = (torch.randn(cin, generator=g) * 0.3).to(d)
+        ca = cin // 2 if cin == 2 * c else cin      # the concatenation case: two producers' totals
+        out = {}
+        for fold in (True, False):
+            old = ops.set_pre_rows(BIG if fold else 0, BIG if fold else 0)
+            try:
+                ta, tb = ops.stats_totals(ca, d), (ops.stats_totals(cin - ca, d) if ca < cin else None)
+                a = torch.full((n, cin), float("nan"), dtype=dtype, device=d)
+                y = torch.full((n, cout), float("nan"), dtype=dtype, device=d)
+                ty = ops.stats_totals(cout, d)
+                mean, invstd = torch.zeros(cin, device=d), torch.zeros(cin, device=d)
+                rm, rv = torch.zeros(cin, device=d), torch.ones(cin, device=d)
+                nbt = torch.zeros(1, dtype=torch.int64, device=d)
+                lst = [dict(kind=ops.CX_STATS, flags=0, rows=n, c_in=ca, x_ld=cin, x=x, stats=ta)]
+                if tb is not None:
+                    lst.append(dict(kind=ops.CX_STATS, flags=0, rows=n, c_in=cin - ca, x_ld=cin, x=x[:, ca:], stats=tb))
+                lst += [dict(kind=ops.CX_BNFWD, flags=ops.CX_F_RELU | ops.CX_F_TRAINING, rows=n, c_in=cin, x_ld=cin, y_ld=cin, x=x, y=a,
+                             eps=1e-4, momentum=0.1, gamma=gamma, beta=beta, running_mean=rm, running_var=rv, nbt=nbt, mean=mean,
+                             invstd=invstd, stats=ta, stats_b=tb, c_split=ca),
+                        dict(kind=ops.CX_GEMM, flags=0, rows=n, rows_in=n, c_in=cin, c_out=cout, K=27, tbl_ld=n, x_ld=cin, y_ld=cout,
+                             res_ld=cout, x=a, w=wp, tbl=tbl, y=y, res=res, stats=ty)]
+                launches = ops.layers_run(lst, d, esz)
+                torch.cuda.synchronize()
+            finally:
+                ops.set_pre_rows(*old)
+            assert launches == len(lst) - (1 if fold else 0), (launches, fold)
+            out[fold] = (a, y, mean, invstd, rm, rv, int(nbt), ops.totals_sums(ty), ops.totals_sums(ta))
+        (a1, y1, m1, i1, rm1, rv1, nb1, ty1, tx1), (a0, y0, m0, i0, rm0, rv0, nb0, ty0, _) = out[True], out[False]
+        # the folded BatchNorm is the unfolded one, bit for bit; the conv differs only in the summation order over offsets
+        assert torch.equal(a1.view(torch.int16 if esz == 2 else torch.int32), a0.view(torch.int16 if esz == 2 else torch.int32))
+        assert torch.equal(m1, m0) and torch.equal(i1, i0) and torch.equal(rm1, rm0) and torch.equal(rv1, rv0) and nb1 == nb0 == 1
+        tol = 2.0 ** -7 if esz == 2 else 1e-5
+        assert _scale_err(y1.float(), y0.float()) < tol
+        # statistics op: column sums of x
+        xd = x.double()
+        assert torch.allclose(tx1[0], xd[:, :ca].sum(0), rtol=1e-6, atol=1e-6 * n)
+        assert torch.allclose(tx1[1], (xd[:, :ca] ** 2).sum(0), rtol=1e-6, atol=1e-6 * n)
+        # torch: BatchNorm1d(training) + ReLU on the same x
+        rm_t, rv_t = torch.zeros(cin, device=d), torch.ones(cin, device=d)
+        ref_a = torch.relu(torch.nn.functional.batch_norm(x.float(), rm_t, rv_t, gamma, beta, True, 0.1, 1e-4))
+        assert _scale_err(a1.float(), ref_a) < (2.0 ** -7 if esz == 2 else 2e-5)
+        assert torch.allclose(rm1, rm_t, rtol=1e-4, atol=1e-5) and torch.allclose(rv1, rv_t, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(m1, x.float().mean(0), rtol=1e-4, atol=1e-5)
+        # oracle conv on the stored normalised rows
+        wq = w.to(dtype).float() if esz == 2 else w
+        ref = oracle.indice_conv(a1.float().cpu().numpy(), wq.cpu().numpy().reshape(3, 3, 3, cin, cout), pairs, pn, n, subm=True)
+        ref = torch.as_tensor(ref) + res.float().cpu()
+        assert _scale_err(y1.float().cpu(), ref) < (2.0 ** -7 if esz == 2 else 1e-4), (cin, cout)
+        yd = y1.double()
+        assert torch.allclose(ty1[0], yd.sum(0), rtol=1e-5, atol=1e-4 * float(yd.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("n,c", LEVELS[1:])
+def test_backward_fold_vs_autograd_and_unfolded(native_lib, oracle, n, c, dtype):
+    """GEMM(data gradient + BatchNorm-backward totals) ; BNBWD(+ skip gradient) ; GEMM as two launches instead of three: the
+    gradient of the BatchNorm's input (side output), dgamma / dbeta and the next data gradient."""
+    from doda_amd import ops
+    d = dev()
+    esz = 2 if dtype == torch.bfloat16 else 4
+    idx, shape, batch = _level(n + 5, n)
+    n = idx.shape[0]
+    pairs, pn = oracle.indice_pairs_subm(idx, batch, shape, 3)
+    tbl = _tables(ops, idx, shape, batch, d)
+    g = torch.Generator().manual_seed(3 * n + esz)
+    u = _cast(torch.randn(n, c, generator=g) * 1.3 - 0.2, dtype).to(d)            # the BatchNorm's input
+    dy = _cast(torch.randn(n, c, generator=g), dtype).to(d)                         # gradient of the conv behind the BatchNorm
+    add_full = _cast(torch.randn(n, 2 * c, generator=g), dtype).to(d)               # the skip gradient: a column slice (ld = 2c)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(d)
+    beta = (torch.randn(c, generator=g) * 0.3).to(d)
+    w2 = (torch.randn(27, c, c, generator=g) * (1.0 / (c * 9)) ** 0.5).to(d)       # conv behind the BatchNorm (its data gradient)
+    w1 = (torch.randn(27, c, c, generator=g) * (1.0 / (c * 9)) ** 0.5).to(d)       # conv in front of it
+    plan = ops.PackPlan([(w2, 27, c, c, 2, esz), (w1, 27, c, c, 2, esz)], d)
+    plan.run()
+    wp2, wp1 = plan.outputs
+    xf = u.float()
+    mean = xf.mean(0)
+    invstd = 1.0 / torch.sqrt(xf.var(0, unbiased=False) + 1e-4)
+    zero = torch.zeros(c, device=d)
+    for with_add in (False, True):
+        out = {}
+        for fold in (True, False):
+            old = ops.set_pre_rows(BIG if fold else 0, BIG if fold else 0)
+            try:
+                t_bn, t_prev = ops.stats_totals(c, d), ops.stats_totals(c, d)
+                da = torch.full((n, c), float("nan"), dtype=dtype, device=d)
+                du = torch.full((n, c), float("nan"), dtype=dtype, device=d)
+                dx = torch.full((n, c), float("nan"), dtype=dtype, device=d)
+                dg, db = torch.full((c,), float("nan"), device=d), torch.full((c,), float("nan"), device=d)
+                lst = [dict(kind=ops.CX_GEMM, flags=ops.CX_F_RELU, rows=n, rows_in=n, c_in=c, c_out=c, K=27, tbl_ld=n, x_ld=c, y_ld=c,
+                            x=dy, w=wp2, tbl=tbl, y=da, aux=u, aux_ld=c, mean=mean, invstd=invstd, gamma=gamma, beta=beta, stats=t_bn),
+                       dict(kind=ops.CX_BNBWD, flags=ops.CX_F_RELU, rows=n, c_in=c, c_split=c, x_ld=c, y_ld=c, aux_ld=c, x=da, aux=u, y=du,
+                            res=(add_full[:, c:] if with_add else None), res_ld=2 * c, stats=t_bn, mean=mean, invstd=invstd,
+                            gamma=gamma, beta=beta, dgamma=dg, dbeta=db),
+                       # the previous layer's data gradient (no BatchNorm in front of it here: plain statistics of the output)
+                       dict(kind=ops.CX_GEMM, flags=0, rows=n, rows_in=n, c_in=c, c_out=c, K=27, tbl_ld=n, x_ld=c, y_ld=c,
+                            x=du, w=wp1, tbl=tbl, y=dx, stats=t_prev)]
+                launches = ops.layers_run(lst, d, esz)
+                torch.cuda.synchronize()
+            finally:
+                ops.set_pre_rows(*old)
+            assert launches == (2 if fold else 3)
+            out[fold] = (da, du, dx, dg, db)
+        (da1, du1, dx1, dg1, db1), (da0, du0, dx0, dg0, db0) = out[True], out[False]
+        it = torch.int16 if esz == 2 else torch.int32
+        assert torch.equal(da1.view(it), da0.view(it))
+        assert torch.equal(du1.view(it), du0.view(it)), with_add
+        assert torch.equal(dg1, dg0) and torch.equal(db1, db0)
+        assert _scale_err(dx1.float(), dx0.float()) < (2.0 ** -7 if esz == 2 else 1e-5)
+        # autograd of relu(batch_norm(u)) under the upstream gradient da (as stored), fp64
+        ud = u.double().requires_grad_(True)
+        a = torch.relu(torch.nn.functional.batch_norm(ud, None, None, gamma.double(), beta.double(), True, 0.1, 1e-4))
+        gd = gamma.double().requires_grad_(True)
+        bd = beta.double().requires_grad_(True)
+        a2 = torch.relu(torch.nn.functional.batch_norm(ud, None, None, gd, bd, True, 0.1, 1e-4))
+        gu, gg, gb = torch.autograd.grad(a2, (ud, gd, bd), da1.double())
+        ref_du = gu + (add_full[:, c:].double() if with_add else 0.0)
+        assert _scale_err(du1.double(), ref_du) < (2.0 ** -6 if esz == 2 else 2e-4), with_add
+        assert torch.allclose(dg1.double(), gg, rtol=2e-3, atol=2e-3 * float(gg.abs().max()))
+        assert torch.allclose(db1.double(), gb, rtol=2e-3, atol=2e-3 * float(gb.abs().max()))
+        # the data gradient in front: oracle on the stored du with mirrored, transposed weights = indice_conv_backward's dx
+        wq = (w1.to(dtype).float() if esz == 2 else w1).cpu().double().reshape(3, 3, 3, c, c)
+        ref_dx, _ = oracle.indice_conv_backward(torch.zeros(n, c, dtype=torch.float64), wq, du1.cpu().double(), pairs, pn, False, True)
+        assert _scale_err(dx1.cpu().double(), torch.as_tensor(ref_dx)) < (2.0 ** -7 if esz == 2 else 1e-4)
+
+
+def test_fold_accumulates_parameter_gradients_and_takes_strided_operands(native_lib):
+    """DODA_CX_F_ACCUM through the folded kernel (second backward pass of tool/st.py:136-198) and a BatchNorm input that is the
+    left half of a concatenation (row stride 2c: the strided conv's BatchNorm reads the level's skip features in place)."""
+    from doda_amd import ops
+    d = dev()
+    n, c = 1900, 80
+    idx, shape, batch = _level(n + 11, n)
+    n = idx.shape[0]
+    tbl = _tables(ops, idx, shape, batch, d)
+    g = torch.Generator().manual_seed(77)
+    cat = _bf(torch.randn(n, 2 * c, generator=g)).to(d)
+    u = cat[:, :c]                                                                   # ld = 2c
+    da = _bf(torch.randn(n, c, generator=g)).to(d)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(d), (torch.randn(c, generator=g) * 0.3).to(d)
+    w1 = (torch.randn(27, c, c, generator=g) * (1.0 / (c * 9)) ** 0.5).to(d)
+    wp1 = _pack(w1, 27, c, c, 2, d)
+    uf = u.float()
+    mean, invstd = uf.mean(0), 1.0 / torch.sqrt(uf.var(0, unbiased=False) + 1e-4)
+    # totals of (sum dz, sum dz xhat) as a data-grad epilogue would have left them
+    xh = (uf - mean) * invstd
+    dz = da.float() * ((xh * gamma + beta) > 0)
+    res = {}
+    for fold in (True, False):
+        old = ops.set_pre_rows(BIG if fold else 0, BIG if fold else 0)
+        try:
+            t = ops.stats_totals(c, d)
+            t[0, 0, :, :4] = dz.double().sum(0).reshape(-1, 4)
+            t[0, 1, :, :4] = (dz.double() * xh.double()).sum(0).reshape(-1, 4)
+            du = torch.zeros((n, c), dtype=torch.bfloat16, device=d)
+            dx = torch.zeros((n, c), dtype=torch.bfloat16, device=d)
+            dg, db = torch.full((c,), 2.0, device=d), torch.full((c,), -1.0, device=d)
+            lst = [dict(kind=ops.CX_BNBWD, flags=ops.CX_F_RELU | ops.CX_F_ACCUM, rows=n, c_in=c, c_split=c, x_ld=c, y_ld=c, aux_ld=2 * c,
+                        x=da, aux=u, y=du, stats=t, mean=mean, invstd=invstd, gamma=gamma, beta=beta, dgamma=dg, dbeta=db),
+                   dict(kind=ops.CX_GEMM, flags=0, rows=n, rows_in=n, c_in=c, c_out=c, K=27, tbl_ld=n, x_ld=c, y_ld=c, x=du, w=wp1,
+                        tbl=tbl, y=dx)]
+            assert ops.layers_run(lst, d, 2) == (1 if fold else 2)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_pre_rows(*old)
+        res[fold] = (du, dx, dg, db)
+    assert torch.equal(res[True][0].view(torch.int16), res[False][0].view(torch.int16))
+    assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
+    assert torch.allclose(res[True][2], 2.0 + (dz * xh).sum(0), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(res[True][3], -1.0 + dz.sum(0), rtol=1e-4, atol=1e-3)
+    assert _scale_err(res[True][1].float(), res[False][1].float()) < 2.0 ** -7
+    ref = 1.0 * (gamma * invstd) * (dz - dz.mean(0) - xh * (dz * xh).mean(0))
+    assert _scale_err(res[True][0].float(), ref) < 2.0 ** -6
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("level,n", [(4, 8400), (5, 1900), (5, 700), (6, 420), (7, 83)])
+def test_subtree_layers_vs_module_path(native_lib, level, n, dtype):
+    """UBlock(level) forward + backward as ONE extension call over the per-layer backend against the same modules run one by
+    one (autograd node per op) — same kernels up to the tile shapes, so fp32 agrees to 1e-4 of scale and bf16 sits as close to the
+    fp32 run as the module path does."""
+    from doda_amd._ext import ext
+    if ext is None or not hasattr(ext, "coarse_ublock"):
+        pytest.skip("compiled extension not built")
+    net, ub, ind, shape, batch = _subtree(level, n, 23)
+    g = torch.Generator().manual_seed(level * 100 + n)
+    c = 16 * level
+    x0 = _bf(torch.randn(ind.shape[0], c, generator=g)).to(dev())
+    gout = _bf(torch.randn(ind.shape[0], c, generator=g)).to(dev())
+    state = {k: v.clone() for k, v in ub.state_dict().items()}
+    yf, dxf, gf, bf_ = _run_subtree(ub, ind, shape, batch, level, x0.float(), gout.float(), "off")
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp(min=1e-20))
+    if dtype == torch.float32:
+        ub.load_state_dict(state)
+        y1, dx1, g1, b1 = _run_subtree(ub, ind, shape, batch, level, x0.float(), gout.float(), "layers")
+        fwd, bwd = ext.coarse_launches()
+        assert fwd > 0 and bwd > 0
+        # (gradients: the two paths derive a small level's BatchNorm statistics differently — fp64 totals here, a shifted two-pass
+        # sweep there —, mean / invstd differ in their last bits and a handful of ReLU masks at |pre-activation| ~ 1e-7 flip: each
+        # flip moves one element of a gradient by O(1).  The folded-vs-unfolded test below, where the masks agree, is the tight one.)
+        assert rel(y1, yf) < 1e-4 and rel(dx1, dxf) < 2e-2, (rel(y1, yf), rel(dx1, dxf))
+        for k in gf:
+            assert rel(g1[k], gf[k]) < 3e-2, (k, rel(g1[k], gf[k]))
+        for k in bf_:
+            if k.endswith("num_batches_tracked"):
+                assert int(b1[k]) == int(bf_[k]) == 1
+            else:
+                assert torch.allclose(b1[k], bf_[k], rtol=1e-4, atol=1e-5), k
+        return
+    ub.load_state_dict(state)
+    y0, dx0, g0, b0 = _run_subtree(ub, ind, shape, batch, level, x0, gout, "off")
+    ub.load_state_dict(state)
+    y1, dx1, g1, b1 = _run_subtree(ub, ind, shape, batch, level, x0, gout, "layers")
+
+    def same_distance(name, e, l, f):
+        e_l, l_f, e_f = rel(e, l), rel(l, f), rel(e, f)
+        assert e_f < 1.5 * l_f + 2e-2, (name, e_f, l_f)
+        assert e_l < 1.5 * l_f + 2e-2, (name, e_l, l_f)
+
+    same_distance("y", y1, y0, yf)
+    assert rel(y1, yf) < 2e-2
+    same_distance("dx", dx1, dx0, dxf)
+    for k in g0:
+        same_distance(k, g1[k], g0[k], gf[k])
+        assert float(g1[k].abs().max()) > 0, k
+    for k in b0:
+        if k.endswith("num_batches_tracked"):
+            assert int(b0[k]) == int(b1[k]) == 1, k
+        else:
+            assert torch.allclose(b1[k], b0[k], rtol=1e-2, atol=1e-3), k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_subtree_folded_equals_unfolded_and_launch_counts(native_lib, dtype):
+    """The same subtree with the folding switched off: every BatchNorm then runs as its own launch.  Forward outputs agree to the
+    summation order of the convs; the launch counts are those of DESIGN.md (per residual block 2 instead of 4 forward, 3 instead
+    of 4 backward)."""
+    from doda_amd import ops
+    from doda_amd._ext import ext
+    if ext is None or not hasattr(ext, "coarse_ublock"):
+        pytest.skip("compiled extension not built")
+    level, n = 5, 1900
+    net, ub, ind, shape, batch = _subtree(level, n, 29)
+    g = torch.Generator().manual_seed(5)
+    c = 16 * level
+    x0 = _bf(torch.randn(ind.shape[0], c, generator=g)).to(dev())
+    gout = _bf(torch.randn(ind.shape[0], c, generator=g)).to(dev())
+    state = {k: v.clone() for k, v in ub.state_dict().items()}
+    res, counts = {}, {}
+    for fold in (True, False):
+        ub.load_state_dict(state)
+        old = ops.set_pre_rows(BIG if fold else 0, BIG if fold else 0)
+        try:
+            res[fold] = _run_subtree(ub, ind, shape, batch, level, x0.to(dtype), gout.to(dtype), "layers")
+        finally:
+            ops.set_pre_rows(*old)
+        counts[fold] = ext.coarse_launches()
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp(min=1e-20))
+    if dtype == torch.float32:   # same statistics, same masks: only the convs' summation order over offsets differs
+        assert rel(res[True][0], res[False][0]) < 1e-5 and rel(res[True][1], res[False][1]) < 2e-3, (rel(res[True][0], res[False][0]), rel(res[True][1], res[False][1]))
+        for k in res[True][2]:
+            assert rel(res[True][2][k], res[False][2][k]) < 5e-3, k
+    else:
+        assert rel(res[True][0], res[False][0]) < 2e-2 and rel(res[True][1], res[False][1]) < 0.3
+    # levels 5-7: 10 residual blocks (two with a 1x1 skip conv), 2 strided + 2 inverse convs; one statistics op for the input
+    n_rb, n_skip, n_updown = 10, 2, 4
+    assert counts[False][0] == 1 + 4 * n_rb + n_skip + 2 * n_updown, counts
+    assert counts[True][0] == 1 + 2 * n_rb + n_skip + n_updown, counts
+    assert counts[False][1] == 4 * n_rb + n_skip + 2 * n_updown, counts
+    # backward: every BNBWD folds but the two with two outputs (the concatenations' gradients) and the last (nothing follows it)
+    assert counts[True][1] == counts[False][1] - (2 * n_rb + n_updown - 3), counts
+
+
+def test_unet_step_layers_vs_module_path_and_fp32(native_lib):
+    """The whole training step with levels 4-7 as one extension call (default) against the module-by-module step and fp32."""
+    from doda_amd._ext import ext
+    if ext is None or not hasattr(ext, "coarse_ublock"):
+        pytest.skip("compiled extension not built")
+    sf, lf, gf, _ = _unet_step("off", 4, dtype=torch.float32)
+    sl, ll, gl, _ = _unet_step("layers", 4, dtype=torch.float32)
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp(min=1e-20))
+    assert abs(ll - lf) / lf < 1e-5, (ll, lf)
+    assert _scale_err(sl, sf) < 1e-4
+    for k in gf:
+        assert rel(gl[k], gf[k]) < 1e-2, (k, rel(gl[k], gf[k]))
+    s0, l0, g0, b0 = _unet_step("off", 4)
+    s1, l1, g1, b1 = _unet_step("layers", 4)
+    assert abs(l1 - l0) / abs(l0) < 2e-3 and abs(l1 - lf) / lf < 2e-2, (lf, l0, l1)
+    assert _scale_err(s1, s0) < 3e-2
+    for k in g0:
+        e_mod, e_lay = rel(g0[k], gf[k]), rel(g1[k], gf[k])
+        assert e_lay < 1.3 * e_mod + 0.05, (k, e_lay, e_mod)
+    for k in b0:
+        if k.endswith("num_batches_tracked"):
+            assert int(b0[k]) == int(b1[k]) == 1, k
+        else:
+            assert torch.allclose(b1[k], b0[k], rtol=5e-2, atol=5e-3), k
+
+
+def test_unet_layers_two_backward_passes_accumulate(native_lib):
+    """Two forward / backward passes into the same .grad tensors (tool/st.py:136-198)."""
+    from doda_amd._ext import ext
+    if ext is None or not hasattr(ext, "coarse_ublock"):
+        pytest.skip("compiled extension not built")
+    _, _, g1, _ = _unet_step("layers", 4, voxels=30000)
+    _, _, g2, _ = _unet_step("layers", 4, voxels=30000, two_pass=True)
+    for k in g1:
+        if k.startswith("unet.u.u.u."):
+            assert torch.allclose(g2[k], 2.0 * g1[k], rtol=2e-2, atol=2e-2 * float(g1[k].abs().max())), k
+
+
+def test_unet_layers_eval_and_no_grad(native_lib):
+    """Evaluation mode (running statistics folded into the gathers) and torch.no_grad() in training mode."""
+    from doda_amd import model as M
+    from doda_amd.model import SparseConvNet, default_cfg, voxelize_and_run
+    from doda_amd.scene import make_batch
+    from tests.util import deterministic_init
+    from doda_amd._ext import ext
+    if ext is None or not hasattr(ext, "coarse_ublock"):
+        pytest.skip("compiled extension not built")
+    d = dev()
+    cfg = default_cfg()
+    batch = make_batch(2, 40000, 5)
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    net = deterministic_init(SparseConvNet(cfg), seed=4).to(d)
+    old = (M.COARSE_MODE, M.COARSE_EXEC_LEVEL)
+    out = {}
+    try:
+        for mode in ("eval", "train"):
+            net.train(mode == "train")
+            for cm in ("off", "layers"):
+                M.set_coarse_mode(cm, 4)
+                state = {k: v.clone() for k, v in net.state_dict().items()}
+                for dt in (torch.bfloat16, torch.float32):
+                    with torch.no_grad():
+                        out[(mode, cm, dt)] = voxelize_and_run(cfg, net, bd, d, feature_dtype=dt).float()
+                    net.load_state_dict(state)
+    finally:
+        M.set_coarse_mode(*old)
+    torch.cuda.synchronize()
+    for mode in ("eval", "train"):
+        assert _scale_err(out[(mode, "layers", torch.bfloat16)], out[(mode, "off", torch.bfloat16)]) < 3e-2, mode
+        assert _scale_err(out[(mode, "layers", torch.float32)], out[(mode, "off", torch.float32)]) < 2e-4, mode
+
+
+def test_backend_selection():
+    """choose_coarse_backend: the rule that picks executor / per-layer launches / module path (no GPU work)."""
+    from doda_amd import model as M
+    old = (M.COARSE_MODE, M.COARSE_EXEC_LEVEL)
+    try:
+        M.set_coarse_mode("layers")
+        assert M.choose_coarse_backend(8400, torch.bfloat16) == "layers" and M.choose_coarse_backend(8400, torch.float32) == "layers"
+        assert M.choose_coarse_backend(1, torch.bfloat16) is None
+        M.set_coarse_mode("auto")
+        assert M.choose_coarse_backend(M.COARSE_EXEC_MAX_ROWS, torch.bfloat16) == "exec"
+        assert M.choose_coarse_backend(M.COARSE_EXEC_MAX_ROWS, torch.float32) == "layers"
+        assert M.choose_coarse_backend(M.COARSE_EXEC_MAX_ROWS + 1, torch.bfloat16) == "layers"
+        M.set_coarse_mode("exec")
+        assert M.choose_coarse_backend(2000, torch.bfloat16) == "exec" and M.choose_coarse_backend(2000, torch.float32) is None
+        M.set_coarse_mode("off")
+        assert M.choose_coarse_backend(2000, torch.bfloat16) is None
+    finally:
+        M.set_coarse_mode(*old)

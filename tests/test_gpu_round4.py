@@ -571,7 +571,7 @@ def test_restricted_backward_leaves_parameter_gradients_alone(native_lib):
     net = deterministic_init(SparseConvNet(default_cfg()), seed=2).to(d).train()
     ub = net.unet.u.u.u.u                                   # level 5 subtree (ResidualBlocks, strided / inverse convs)
     idx = torch.from_numpy(np.ascontiguousarray(surface_voxels(3, 1500, 2, [32, 32, 32]))).to(d)
-    old = (M.COARSE_EXEC, M.COARSE_EXEC_LEVEL)
+    old = (M.COARSE_MODE, M.COARSE_EXEC_LEVEL)
     try:
         assert Fsp.set_deferred_wgrad(True)
         for exec_on in (False, True):
@@ -598,4 +598,4 @@ def test_restricted_backward_leaves_parameter_gradients_alone(native_lib):
             assert all(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in ub.parameters())
     finally:
         Fsp.set_deferred_wgrad(False)
-        M.set_coarse_exec(*old)
+        M.set_coarse_mode(*old)

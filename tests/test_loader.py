@@ -159,32 +159,44 @@ def test_reorder_voxels_renames_rows_and_keeps_every_point_in_its_voxel():
 
 
 @pytest.mark.gpu
-def test_renumbered_batch_gives_the_same_points_loss_and_gradients():
+@pytest.mark.parametrize("deferred", [False, True])
+def test_renumbered_batch_gives_the_same_points_loss_and_gradients(deferred):
     """The U-Net step on a Z-order-renumbered batch against the same batch in the reference's numbering, fp32: per-point scores
     (max-abs error over max-abs value 1e-4), loss, and every parameter gradient (a sum over rows in another order: 2e-3 of its
-    norm)."""
+    norm on the module-by-module path; 5e-3 with the deferred weight gradients on, where levels 4-7 run as one extension call
+    whose BatchNorm statistics are fp64 totals of per-workgroup fp32 sums — the workgroups' rows change with the numbering —
+    and the gradient of a BatchNorm weight is a cancelling sum over 30 k rows)."""
     from doda_amd.collate import reorder_voxels
     from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
     from doda_amd.scene import make_batch
+    from doda_amd.spconv import functional as Fsp
     from tests.util import deterministic_init
     d = torch.device("cuda:0")
     cfg = default_cfg()
     base = make_batch(2, 60000, 23)
     got = []
-    for order in ("first", "morton"):
-        b = reorder_voxels(base, order)
-        bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in b.items()}
-        net = deterministic_init(SparseConvNet(cfg), seed=4).to(d).train()
-        scores = voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.float32)
-        loss = cross_entropy(scores, bd["labels"], ignore_index=255)
-        loss.backward()
-        torch.cuda.synchronize()
-        got.append((scores.detach().float().cpu(), float(loss), {k: p.grad.detach().float().cpu() for k, p in net.named_parameters()}))
+    if deferred and not Fsp.set_deferred_wgrad(True):
+        pytest.skip("compiled extension not built")
+    if not deferred:
+        Fsp.set_deferred_wgrad(False)
+    try:
+        for order in ("first", "morton"):
+            b = reorder_voxels(base, order)
+            bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in b.items()}
+            net = deterministic_init(SparseConvNet(cfg), seed=4).to(d).train()
+            scores = voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.float32)
+            loss = cross_entropy(scores, bd["labels"], ignore_index=255)
+            loss.backward()
+            torch.cuda.synchronize()
+            got.append((scores.detach().float().cpu(), float(loss), {k: p.grad.detach().float().cpu() for k, p in net.named_parameters()}))
+    finally:
+        Fsp.set_deferred_wgrad(False)
     (s0, l0, g0), (s1, l1, g1) = got
     assert float((s0 - s1).abs().max()) < 1e-4 * float(s0.abs().max())
     assert abs(l0 - l1) < 1e-5 * abs(l0)
+    tol = 5e-3 if deferred else 2e-3
     for k, a in g0.items():
-        assert float((a - g1[k]).norm()) <= 2e-3 * float(a.norm()) + 1e-7, k
+        assert float((a - g1[k]).norm()) <= tol * float(a.norm()) + 1e-7, k
 
 
 @pytest.mark.gpu
