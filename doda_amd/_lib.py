@@ -93,10 +93,6 @@ _SIGNATURES = {
     "doda_ballquery_workspace_bytes": (c_sz, [c_i32]),
     "doda_ballquery_batch_p": (c_i32, [c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                        C.POINTER(c_i32), c_vp, c_sz, c_vp]),
-    "doda_coarse_workgroups": (c_i32, []),
-    "doda_coarse_debug_stamps": (c_i32, [c_vp]),
-    "doda_coarse_desc_bytes": (c_sz, [c_i32]),
-    "doda_coarse_run": (c_i32, [c_vp, c_i32, c_vp, c_sz, c_vp, c_vp]),
     "doda_layers_run": (c_i32, [c_vp, c_i32, c_i32, C.POINTER(c_i32), c_vp]),
 }
 

@@ -2,8 +2,7 @@
 //
 // The deep levels of DODA's U-Net (reference model/unet_block.py:55-100 UBlock: blocks -> strided conv -> UBlock -> inverse conv ->
 // concatenation -> blocks_tail, ResidualBlocks of model/unet_block.py:9-37 inside) are described by the caller as a list of
-// doda_cx_op — the same list doda_coarse_run walks inside ONE persistent launch on one XCD.  Here every op is a WHOLE-CHIP launch of
-// the kernels the per-layer path uses anyway (doda_spconv_gather_ex, the BatchNorm sweeps over fp64 totals), issued back to back
+// doda_cx_op (include/doda_hip.h).  Every op is a WHOLE-CHIP launch of the kernels the module-by-module path uses anyway (doda_spconv_gather_ex, the BatchNorm sweeps over fp64 totals), issued back to back
 // from C++ with nothing in between — and a BatchNorm whose consumer is the next convolution of the list is folded into that
 // convolution's gather (doda_conv_prologue):
 //     BNFWD ; GEMM(x = its output)                 -> one launch   (forward:  BatchNorm1d -> ReLU -> conv)
@@ -12,8 +11,8 @@
 // wherever the BatchNorm's rows are few enough for its own sweep to be a launch-floor kernel (DODA_PRE_FWD_ROWS, default 16384 /
 // DODA_PRE_BWD_ROWS, default 0 = the backward BatchNorm keeps its own 3.3 us launch: measured, see g_bwd_rows below).
 // The folded and the unfolded form of an op give the same bits (bn_totals.hpp), so the fusion is a schedule, not a numerics change.
-// Measured against the executor: one XCD has 1/8 of the chip's matrix rate and loads in flight; the per-layer
-// kernels keep the whole chip and pay one ~1.7 us kernel boundary each, which the folding then halves.
+// (Round 5 walked the same list inside ONE persistent launch on one XCD: 1/8 of the chip's matrix rate and loads in flight lost to
+// the whole-chip kernels at the bench size and, once those were issued from here, at the host floor too — removed in ABI 11.)
 #include "common.hpp"
 #include "spconv_common.hpp"
 #include <stdlib.h>

@@ -1296,12 +1296,13 @@ std::vector<at::Tensor> residual_block(const at::Tensor &x, const c10::optional<
 }
 
 
-// ---- coarse-level executor glue (csrc/coarse.hip, doda_coarse_run) --------------------------------------------
+// ---- coarse levels as one call: op-list glue (csrc/layers.hip, doda_layers_run) -------------------------------------------
 // reference model/unet_block.py:55-100: one UBlock subtree (blocks -> strided conv -> UBlock -> inverse conv ->
 // concatenation -> blocks_tail, ResidualBlocks of model/unet_block.py:9-37 inside) whose levels hold a few thousand rows
-// and fewer, as ONE persistent launch forward and ONE backward.  The Python side (doda_amd/model.py: UBlock._coarse_steps)
-// flattens the subtree into STEPS; this file expands them into executor ops, owns the intermediate tensors and the
-// autograd node.  No arithmetic here: every op is a kernel phase of libdoda_hip.so.
+// and fewer, as ONE extension call forward and ONE autograd node backward.  The Python side (doda_amd/model.py:
+// UBlock._forward_coarse) flattens the subtree into STEPS; this file expands them into ops (include/doda_hip.h doda_cx_op), owns
+// the intermediate tensors and the autograd node, and hands each list to doda_layers_run, which issues the per-layer kernels back
+// to back.  No arithmetic here: every op is a kernel of libdoda_hip.so.
 //   step RB   (kind 0): tensors {subm table, bn1 x5, conv1 x3, bn2 x5, conv2 x3, skip conv x3 | None x3, identity table | None}
 //                       scalars {eps1, momentum1, eps2, momentum2}
 //   step DOWN (kind 1): tensors {child [8, m], par_off [8, n], bn x5, conv x3}        scalars {eps, momentum, m}
@@ -1379,26 +1380,14 @@ inline CVP cv_of(const TList &t, size_t at_) {
     return c;
 }
 
-struct SyncState { at::Tensor words; };
-std::mutex g_sync_mu;
-std::unordered_map<int, SyncState> g_sync;
-uint32_t *sync_words(const at::Tensor &like) {
-    std::lock_guard<std::mutex> lock(g_sync_mu);
-    SyncState &s = g_sync[(int)like.device().index()];
-    if (!s.words.defined()) s.words = at::zeros({4}, like.options().dtype(at::kInt));
-    return (uint32_t *)s.words.data_ptr();
-}
-
-// Two backends walk the same op list (include/doda_hip.h): the persistent executor (doda_coarse_run: ONE launch on one XCD, fp32
-// partial rows as statistics) and — ABI 11, `layers` — whole-chip per-layer launches issued from inside the library
-// (doda_layers_run: fp64 totals as statistics, BatchNorm ops folded into the consuming convolution's gather).
+// The op list of a pass (include/doda_hip.h doda_cx_op), issued by doda_layers_run as whole-chip per-layer launches: fp64 totals as
+// statistics, BatchNorm ops folded into the consuming convolution's gather.  (ABI 8-10 had a second backend, a persistent
+// single-XCD executor; removed in ABI 11.)
 struct Builder {
     std::vector<doda_cx_op> ops;
     Arena arena;
-    int G = 0;
     at::TensorOptions bf;
     bool first = true;
-    bool layers = false;
     int esz = 2;
     std::vector<at::Tensor> tot_keep;   // totals slices of this pass (zeroed arena of stats_totals_take)
     int launches = 0;
@@ -1409,12 +1398,10 @@ struct Builder {
         memset(&o, 0, sizeof(o));
         o.kind = kind;
         o.flags = flags;
-        o.n_part = layers ? 0 : G;
         return o;
     }
-    // statistics of a c-channel tensor: G partial rows (executor) or zeroed fp64 totals (layers), as the op field's float *
+    // statistics of a c-channel tensor: zeroed fp64 totals, as the op field's float *
     float *stat_buf(int c) {
-        if (!layers) return arena.floats((size_t)G * 2 * c);
         at::Tensor t = stats_totals_take(c, bf);
         tot_keep.push_back(t);
         return (float *)t.data_ptr();
@@ -1428,15 +1415,9 @@ struct Builder {
     }
     void run(const at::Tensor &like) {
         if (ops.empty()) return;
-        if (layers) {
-            int32_t n = 0;
-            check(doda_layers_run(ops.data(), (int32_t)ops.size(), esz, &n, stream_of(like)), "doda_layers_run");
-            launches = n;
-            return;
-        }
-        const size_t nb = doda_coarse_desc_bytes((int32_t)ops.size());
-        void *desc = arena.alloc(nb);
-        check(doda_coarse_run(ops.data(), (int32_t)ops.size(), desc, nb, sync_words(like), stream_of(like)), "doda_coarse_run");
+        int32_t n = 0;
+        check(doda_layers_run(ops.data(), (int32_t)ops.size(), esz, &n, stream_of(like)), "doda_layers_run");
+        launches = n;
     }
 
     // ---- forward ----
@@ -1469,13 +1450,13 @@ struct Builder {
         }
     }
     // y = conv(L.a) (+ res), statistics of y when `want_stats`; `out` preset (p / ld) = where y goes
-    // (identity: the 1x1 convolution — the executor needs no table; the per-layer kernels read the identity table `tbl`)
+    // (identity: the 1x1 convolution = K = 1 over the identity table `tbl`)
     void gemm_fwd(Layer &L, const at::Tensor &tbl, bool identity, Val &out, const Val *res, bool want_stats, bool barrier) {
         doda_cx_op &o = push(DODA_CX_GEMM, (barrier ? DODA_CX_F_BARRIER : 0) | (identity ? DODA_CX_F_IDENTITY : 0));
         first = false;
         o.rows = out.rows; o.rows_in = (int32_t)L.a.size(0); o.c_in = (int32_t)L.a.size(1); o.c_out = out.c;
         o.K = identity ? 1 : (int32_t)tbl.size(0);
-        o.tbl = (identity && !layers) ? nullptr : (const int32_t *)tbl.data_ptr();
+        o.tbl = (const int32_t *)tbl.data_ptr();
         o.tbl_ld = identity ? out.rows : (int32_t)tbl.size(1);
         o.x = L.a.data_ptr(); o.x_ld = (int32_t)L.a.size(1);
         o.w = L.cv.pk_fwd.data_ptr();
@@ -1496,8 +1477,6 @@ struct CoarseNode : public torch::autograd::Node {
     std::vector<Step> steps;
     std::vector<at::Tensor> keep;      // arena chunks and tensors the saved pointers refer to
     at::Tensor x_in;                   // (kept for its size / options)
-    int G = 0;
-    bool layers = false;
 
     // gamma / beta gradient targets: the reducer's bucket views when the parameters have homes, existing .grad tensors
     // (accumulate) or fresh tensors deposited afterwards
@@ -1510,8 +1489,6 @@ struct CoarseNode : public torch::autograd::Node {
         at::Tensor g = grads[0].contiguous();
         TORCH_CHECK(g.scalar_type() == x_in.scalar_type(), "doda coarse: gradient dtype");
         Builder B;
-        B.G = G;
-        B.layers = layers;
         B.esz = elem_bytes(g);
         B.bf = g.options();
         B.arena.opt = g.options().dtype(at::kByte);
@@ -1577,7 +1554,7 @@ struct CoarseNode : public torch::autograd::Node {
                     if (pb.accum) { pb.buf = pempty({c}, pb.param.options().dtype(at::kFloat)); pb.accum = false; pb.fresh = true; db = (float *)pb.buf.data_ptr(); }
                 } else if (f1) flags |= DODA_CX_F_ACCUM;
             }
-            if (layers) flags |= DODA_CX_F_RELU;   // (the per-layer data-grad kernels store dz unmasked: the op masks, and needs beta)
+            flags |= DODA_CX_F_RELU;   // (the data-grad kernels store dz unmasked: the op masks, and needs beta)
             doda_cx_op &o = B.push(DODA_CX_BNBWD, flags);
             o.beta = (const float *)L.bn.beta.data_ptr();
             o.rows = L.n_in; o.c_in = c; o.c_split = split;
@@ -1602,7 +1579,7 @@ struct CoarseNode : public torch::autograd::Node {
                     gS = pempty({S.l1.n_in, S.l1.c_in}, B.bf);
                     keep_alive.push_back(gS);
                     doda_cx_op &o = B.push(DODA_CX_GEMM, DODA_CX_F_IDENTITY);
-                    if (layers) o.tbl = (const int32_t *)S.ident.data_ptr();
+                    o.tbl = (const int32_t *)S.ident.data_ptr();
                     o.rows = S.l1.n_in; o.rows_in = S.l1.n_in; o.c_in = S.l2.c_out; o.c_out = S.l1.c_in; o.K = 1; o.tbl_ld = S.l1.n_in;
                     o.x = g.data_ptr(); o.x_ld = S.l2.c_out; o.w = S.skip.pk_bwd.data_ptr(); o.y = gS.data_ptr(); o.y_ld = S.l1.c_in;
                 }
@@ -1656,15 +1633,13 @@ struct CoarseNode : public torch::autograd::Node {
     std::string name() const override { return "DodaCoarseUBlockBackward"; }
 };
 
-// Returns {y [n, c] bf16, statistics partial rows of y [G, 2, c] (training) or undefined}.
-// layers: the per-layer backend (doda_layers_run; bf16 or fp32 features, statistics as fp64 totals) instead of the executor.
+// Returns {y [n, c] in the dtype of x, fp64 totals of y (training) or undefined}.
 std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optional<at::Tensor> &stats_in, const std::vector<int64_t> &kinds,
-                                      const std::vector<TList> &tensors, const std::vector<std::vector<double>> &scalars, bool training,
-                                      bool layers) {
+                                      const std::vector<TList> &tensors, const std::vector<std::vector<double>> &scalars, bool training) {
     host_timing::Scope host_scope(6);
     TORCH_CHECK(x_in.is_cuda() && x_in.dim() == 2 && x_in.size(0) >= 2 &&
-                (x_in.scalar_type() == at::kBFloat16 || (layers && x_in.scalar_type() == at::kFloat)),
-                "doda coarse_ublock: bf16 device features (the per-layer backend also takes fp32)");
+                (x_in.scalar_type() == at::kBFloat16 || x_in.scalar_type() == at::kFloat),
+                "doda coarse_ublock: bf16 or fp32 device features");
     TORCH_CHECK(kinds.size() == tensors.size() && kinds.size() == scalars.size() && !kinds.empty(), "doda coarse_ublock: step lists");
     const bool need_grad = at::GradMode::is_enabled() && x_in.requires_grad();
     TORCH_CHECK(!need_grad || (training && g_direct_grads && g_defer_wgrad),
@@ -1672,8 +1647,6 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
     at::AutoDispatchBelowADInplaceOrView guard;
     const at::Tensor x = x_in.contiguous();
     Builder B;
-    B.G = doda_coarse_workgroups();
-    B.layers = layers;
     B.esz = elem_bytes(x);
     B.bf = x.options();
     B.arena.opt = x.options().dtype(at::kByte);
@@ -1681,10 +1654,7 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
     Val cur;
     cur.p = x.data_ptr(); cur.rows = (int)x.size(0); cur.c = (int)x.size(1); cur.ld = cur.c; cur.t = x;
     at::Tensor stats_keep;
-    if (training && stats_in.has_value() && stats_in->defined() &&
-        (layers ? is_totals(*stats_in, cur.c)
-                : (stats_in->dim() == 3 && stats_in->size(0) == B.G && stats_in->size(2) == cur.c && stats_in->scalar_type() == at::kFloat &&
-                   stats_in->is_contiguous()))) {
+    if (training && stats_in.has_value() && stats_in->defined() && is_totals(*stats_in, cur.c)) {
         stats_keep = *stats_in;
         cur.stats = (float *)stats_keep.data_ptr();
         cur.c_split = cur.c;
@@ -1743,9 +1713,7 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
                 y = B.dense(n, cout, last);
                 if (last) y_out = y.t;
             }
-            if (last && training) {   // the caller may feed these rows (layers: totals) to the next fused BatchNorm
-                y_stats = layers ? stats_totals_take(cout, x.options()) : pempty({B.G, 2, cout}, x.options().dtype(at::kFloat));
-            }
+            if (last && training) y_stats = stats_totals_take(cout, x.options());   // (the caller may feed these totals to the next fused BatchNorm)
             B.gemm_fwd(S.l2, tbl, false, y, &skipv, training, true);
             if (last && training) {   // (gemm_fwd put the partial rows into the arena: point the op at the returned tensor instead)
                 B.ops.back().stats = (float *)y_stats.data_ptr();
@@ -1795,12 +1763,10 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
         auto node = std::shared_ptr<CoarseNode>(new CoarseNode(), torch::autograd::deleteNode);
         node->set_next_edges(torch::autograd::collect_next_edges(x_in));
         node->steps = std::move(steps);
-        node->layers = layers;
         node->keep = B.arena.chunks;
         if (stats_keep.defined()) node->keep.push_back(stats_keep);
         node->keep.push_back(x);
         node->x_in = x;
-        node->G = B.G;
         torch::autograd::set_history(y_out, node);
     }
     return {y_out, y_stats};
@@ -2032,22 +1998,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::call_guard<py::gil_scoped_release>());
     m.def("coarse_ublock", [](const at::Tensor &x, const c10::optional<at::Tensor> &stats_in, const std::vector<int64_t> &kinds,
                               const std::vector<std::vector<c10::optional<at::Tensor>>> &tensors,
-                              const std::vector<std::vector<double>> &scalars, bool training, bool layers) {
-        auto r = coarse::coarse_ublock(x, stats_in, kinds, tensors, scalars, training, layers);
+                              const std::vector<std::vector<double>> &scalars, bool training) {
+        auto r = coarse::coarse_ublock(x, stats_in, kinds, tensors, scalars, training);
         return std::make_pair(r[0], r[1].defined() ? c10::optional<at::Tensor>(r[1]) : c10::nullopt);
-    }, "a U-Net subtree of coarse levels as one op list per direction: one persistent launch (doda_coarse_run) or, layers = True, "
-       "per-layer launches issued inside the library with the BatchNorm ops folded into the convolutions (doda_layers_run)",
-          py::arg("x"), py::arg("stats_in"), py::arg("kinds"), py::arg("tensors"), py::arg("scalars"), py::arg("training"),
-          py::arg("layers") = false);
+    }, "a U-Net subtree of coarse levels as one op list per direction: per-layer launches issued inside the library with the "
+       "BatchNorm ops folded into the convolutions (doda_layers_run)",
+          py::arg("x"), py::arg("stats_in"), py::arg("kinds"), py::arg("tensors"), py::arg("scalars"), py::arg("training"));
     m.def("coarse_launches", []() { return std::make_pair((int64_t)coarse::g_coarse_launches_fwd, (int64_t)coarse::g_coarse_launches_bwd); },
           "kernel launches of the last per-layer forward / backward op list");
-    m.def("coarse_workgroups", []() { return (int64_t)doda_coarse_workgroups(); });
-    m.def("coarse_error", [](int64_t device) {   // a grid barrier of an earlier executor launch on `device` timed out (synchronises)
-        std::lock_guard<std::mutex> lock(coarse::g_sync_mu);
-        auto it = coarse::g_sync.find((int)device);
-        if (it == coarse::g_sync.end() || !it->second.words.defined()) return false;
-        return it->second.words.cpu()[1].item<int32_t>() != 0;
-    });
     m.def("abi_version", []() { return doda_abi_version(); });
     m.def("built_for_abi", []() { return (int)DODA_ABI_VERSION; });
 }

@@ -209,48 +209,32 @@ class VGGBlock(SparseModule):
 
 
 # Coarse levels as ONE extension call per direction (csrc_ext coarse_ublock: a UBlock subtree compiled into an op list, one autograd
-# node, gradients of every layer incl. the deferred weight-gradient jobs).  Two backends walk the list (include/doda_hip.h):
-#   "layers" (round 6, default): whole-chip per-layer launches issued inside the library (doda_layers_run) with every BatchNorm
-#            whose rows are few folded into the gather of the convolution behind it, forward and backward, and the level
-#            concatenations written in place by their two producers — ~55 launches, ~100 autograd nodes and the interpreter
-#            between them less per step; bf16 and fp32;
-#   "exec"   (round 5): ONE persistent launch on one XCD (doda_coarse_run).  Wins where the step is host-bound (<= 2 scenes),
-#            loses at the bench size (one XCD has 1/8 of the chip's matrix rate);
-#   "auto":  "exec" when the subtree's input has at most COARSE_EXEC_MAX_ROWS rows, else "layers";   "off": module by module.
-# DODA_COARSE_MODE picks; the legacy switch DODA_COARSE_EXEC=1 means "exec".
-COARSE_MODE = _os.environ.get("DODA_COARSE_MODE", "exec" if _os.environ.get("DODA_COARSE_EXEC", "0") == "1" else "layers")
-COARSE_EXEC = COARSE_MODE == "exec"                                              # (kept: tools and tests read it)
-COARSE_EXEC_LEVEL = int(_os.environ.get("DODA_COARSE_LEVEL", "5" if COARSE_MODE == "exec" else "4"))
-COARSE_MAX_ROWS = int(_os.environ.get("DODA_COARSE_MAX_ROWS", "16384"))          # executor: above, the whole-chip kernels win
+# node, gradients of every layer incl. the deferred weight-gradient jobs), issued by the library as whole-chip per-layer launches
+# (doda_layers_run, csrc/layers.hip) with every BatchNorm whose rows are few folded into the gather of the convolution behind it
+# and the level concatenations written in place by their two producers: ~60 launches, ~100 autograd nodes and the interpreter
+# between them less per step; bf16 and fp32.  Bench step 5.05 -> 4.81 ms, host floor 5.0 -> 4.1 ms (tools/layers_ab.py).
+# DODA_COARSE_MODE: "layers" (default) | "off" (module by module).  Round 5's persistent single-XCD executor ("exec") is gone:
+# with the per-layer launches issued from inside the library it lost at every batch size (4.30 against 4.05-4.28 ms at the host
+# floor, 7.35 against 4.81 at the bench size).
+COARSE_MODE = _os.environ.get("DODA_COARSE_MODE", "layers")
+COARSE_EXEC_LEVEL = int(_os.environ.get("DODA_COARSE_LEVEL", "4"))
 COARSE_LAYERS_MAX_ROWS = int(_os.environ.get("DODA_COARSE_LAYERS_MAX_ROWS", "262144"))
-COARSE_EXEC_MAX_ROWS = int(_os.environ.get("DODA_COARSE_EXEC_MAX_ROWS", "1200"))  # "auto": rows of the subtree's input
-
-
-def set_coarse_exec(on, level=None):
-    """Legacy switch of the round-5 tests: the persistent executor on / off (off = module by module)."""
-    return set_coarse_mode("exec" if on else "off", level)
 
 
 def set_coarse_mode(mode, level=None):
-    """mode: "layers" | "exec" | "auto" | "off"; level: the U-Net level whose UBlock subtree becomes one extension call."""
-    global COARSE_MODE, COARSE_EXEC, COARSE_EXEC_LEVEL
-    assert mode in ("layers", "exec", "auto", "off"), mode
+    """mode: "layers" | "off"; level: the U-Net level whose UBlock subtree becomes one extension call."""
+    global COARSE_MODE, COARSE_EXEC_LEVEL
+    assert mode in ("layers", "off"), mode
     COARSE_MODE = mode
-    COARSE_EXEC = mode == "exec"
     if level is not None:
         COARSE_EXEC_LEVEL = int(level)
     return mode
 
 
 def choose_coarse_backend(rows, dtype):
-    """Which backend runs a subtree whose input has `rows` rows: "layers", "exec" or None (module by module)."""
-    if COARSE_MODE == "off":
+    """"layers" when a subtree whose input has `rows` rows runs as one extension call, None for module by module."""
+    if COARSE_MODE == "off" or dtype not in (torch.bfloat16, torch.float32):
         return None
-    if COARSE_MODE == "exec" or (COARSE_MODE == "auto" and rows <= COARSE_EXEC_MAX_ROWS):
-        if dtype == torch.bfloat16 and 2 <= rows <= COARSE_MAX_ROWS:
-            return "exec"
-        if COARSE_MODE == "exec":
-            return None
     return "layers" if 2 <= rows <= COARSE_LAYERS_MAX_ROWS else None
 
 
@@ -428,7 +412,7 @@ class UBlock(nn.Module):
                     scalars.append([bn.eps, bn.momentum, rows[lvl]])
         st = input.__dict__.get("_doda_stats")
         stats_in = st[1] if (st is not None and st[0] is feats and st[2] == feats._version and torch.is_tensor(st[1])) else None
-        y, stats = ext.coarse_ublock(feats, stats_in, kinds, tensors, scalars, training, backend == "layers")
+        y, stats = ext.coarse_ublock(feats, stats_in, kinds, tensors, scalars, training)
         out = spconv.SparseConvTensor(y, input.indices, input.spatial_shape, input.batch_size)
         out.indice_dict = idict
         out.grid = input.grid

@@ -868,7 +868,7 @@ def sgd_multi(params, grads, bufs, first, lr, momentum=0.0, dampening=0.0, weigh
                                _stream()), "doda_sgd_multi")
 
 
-# ---- coarse-level executor (ABI 8, csrc/coarse.hip) ----------------------------------------------------
+# ---- coarse-level op lists (ABI 11, csrc/layers.hip: doda_layers_run) --------------------------------------
 CX_GEMM, CX_BNFWD, CX_BNBWD, CX_STATS = 1, 2, 3, 4
 CX_F_BARRIER, CX_F_IDENTITY, CX_F_RELU, CX_F_TRAINING, CX_F_ACCUM = 1, 2, 4, 8, 16
 
@@ -884,46 +884,6 @@ class _CxOp(C.Structure):   # doda_cx_op
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("nbt", C.c_void_p),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
-
-
-_CX_SYNC = {}   # device -> uint32 [4] tensor (barrier counter, time-out flag, exit counter)
-
-
-def coarse_workgroups():
-    return int(lib().doda_coarse_workgroups())
-
-
-def coarse_error(device):
-    """True when a grid barrier of an earlier coarse_run on `device` timed out (synchronises)."""
-    st = _CX_SYNC.get(torch.device(device))
-    return bool(st is not None and int(st[1].item()) != 0)
-
-
-def coarse_run(ops, device):
-    """Run a list of executor ops (dicts keyed by the doda_cx_op field names; tensors for the pointer fields) in ONE
-    persistent launch (doda_coarse_run).  Tensor operands: bf16 feature matrices (row strides given by the caller in
-    `*_ld`), fp32 statistics / BatchNorm vectors, int32 tables.  The caller keeps every tensor alive until the stream has
-    passed the launch.  Used by the tests and tools; the training path builds its op lists in the C++ extension."""
-    device = torch.device(device)
-    n = len(ops)
-    arr = (_CxOp * n)()
-    ptr_fields = {"x", "w", "tbl", "y", "y2", "res", "aux", "stats", "stats_b", "gamma", "beta", "mean", "invstd",
-                  "running_mean", "running_var", "nbt", "dgamma", "dbeta"}
-    for k, o in enumerate(ops):
-        for name, v in o.items():
-            if name in ptr_fields:
-                if v is not None:
-                    _need_cuda(v)
-                setattr(arr[k], name, v.data_ptr() if v is not None else None)
-            else:
-                setattr(arr[k], name, v)
-        arr[k].n_part = coarse_workgroups()
-    st = _CX_SYNC.get(device)
-    if st is None:
-        st = _CX_SYNC[device] = torch.zeros(4, dtype=torch.int32, device=device)
-    nbytes = lib().doda_coarse_desc_bytes(n)
-    desc = _ws(nbytes, device)
-    check(lib().doda_coarse_run(C.cast(arr, C.c_void_p), n, _p(desc), nbytes, _p(st), _stream()), "doda_coarse_run")
 
 
 def _cx_array(ops, n_part):
@@ -949,7 +909,7 @@ def stats_totals(c, device):
 
 
 def layers_run(ops, device, elem_bytes=2):
-    """Run a list of ops (dicts as for coarse_run) through the per-layer backend (doda_layers_run, ABI 11): one whole-chip launch
+    """Run a list of ops (dicts keyed by the doda_cx_op field names; tensors for the pointer fields) through the per-layer backend (doda_layers_run, ABI 11): one whole-chip launch
     per op, BatchNorm ops folded into the next convolution's gather where their rows are few (set_pre_rows).  `stats` /
     `stats_b` are fp64 totals (stats_totals).  Returns the number of launches issued."""
     n = len(ops)

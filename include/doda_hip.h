@@ -563,41 +563,39 @@ int doda_sgd_multi(const doda_sgd_tensor *tensors_h, int32_t n_tensors, double l
                    double dampening, double weight_decay, int32_t nesterov, int32_t maximize, void *desc_dev,
                    size_t desc_bytes, doda_stream_t stream);
 
-/* ---- ABI 8: coarse-level executor -----------------------------------------------------------------------
- * The deep levels of DODA's U-Net in ONE persistent launch per direction (csrc/coarse.hip).  Replaces, for levels of a
- * few thousand rows and fewer, the per-layer launches of reference model/unet_block.py:55-100 (UBlock: blocks -> strided
- * conv -> UBlock -> inverse conv -> concatenation -> blocks_tail) with model/unet_block.py:9-37 inside (ResidualBlock:
- * BatchNorm1d -> ReLU -> SubMConv3d, twice, + skip); the arithmetic per layer is that of doda_spconv_gather_ex (bf16
- * features, fp32 accumulate, one rounding at the store) and doda_bn_relu_fwd / _bwd.
+/* ---- ABI 11: coarse U-Net levels as an op list of per-layer launches (csrc/layers.hip) ----------------------------------------
+ * The deep levels of DODA's U-Net — reference model/unet_block.py:55-100 (UBlock: blocks -> strided conv -> UBlock -> inverse conv
+ * -> concatenation -> blocks_tail) with model/unet_block.py:9-37 inside (ResidualBlock: BatchNorm1d -> ReLU -> SubMConv3d, twice,
+ * + skip) — are described by the caller as a HOST array of ops and issued by doda_layers_run as whole-chip launches, back to back,
+ * with nothing of the caller's (interpreter, autograd nodes, allocations) in between; the arithmetic per layer is that of
+ * doda_spconv_gather_ex (fp32 accumulate, one rounding at the store) and of the BatchNorm sweeps over fp64 totals.  (ABI 8-10 also
+ * had a persistent single-XCD executor walking the same list, doda_coarse_run: removed in ABI 11 — it lost to the per-layer
+ * kernels at every batch size once those were issued from inside the library; DESIGN.md.)
  *
- * The caller describes the work as a HOST array of ops; doda_coarse_workgroups() persistent workgroups on one XCD walk
- * it in order, with a grid barrier in front of every op flagged DODA_CX_F_BARRIER (an op whose inputs an EARLIER op of
- * the same call wrote needs the flag; independent neighbours may omit it).  All feature tensors are bf16 [rows, c] with a
- * row stride in elements (`*_ld`: a column slice of a wider matrix — the halves of a concatenation — is addressed in
- * place); channel counts are multiples of 8 (GEMM outputs: of 16), at most 256.  Statistics arrays hold
- * doda_coarse_workgroups() rows of [2][c] floats (`n_part` must say so).
+ * All feature tensors are [rows, c] in ONE storage type per call (bf16 or fp32) with a row stride in elements (`*_ld`: a column
+ * slice of a wider matrix — the halves of a concatenation — is addressed in place); channel counts are multiples of 8 (bf16) / 4
+ * (fp32), at most 256.  Every statistics array (`stats`, `stats_b`) is DODA_STATS_TOTALS_DOUBLES(c) doubles of fp64 TOTALS
+ * (doda_conv_epilogue.stats_totals), zero before the op that accumulates into them.  `n_part` must be 0.
  *
  * DODA_CX_GEMM   y[t, :] = sum_o x[tbl[o][t], :] . B_o (+ res[t, :])   t < rows; `w` = the fragment-packed weights of
- *                doda_spconv_pack_multi for (K, c_in, c_out, bf16) — "wide" order, c_in >= 32; tbl int32 [K][tbl_ld]
- *                (or DODA_CX_F_IDENTITY: K = 1, row t reads row t: the 1x1 convolution).
- *                aux == NULL (forward): stats[p] = (sum y, sum y^2) over the rows workgroup p stored, y as stored.
- *                aux != NULL (data gradient; aux = input of the BatchNorm in FRONT of the conv, mean / invstd / gamma /
- *                beta its vectors): y = dz = (sum ...) * [gamma * xhat + beta > 0] (the mask only with DODA_CX_F_RELU),
- *                stats[p] = (sum dz, sum dz * xhat), xhat = (aux - mean) * invstd.   stats may be NULL.
- * DODA_CX_BNFWD  y = [relu]((x - mean) * invstd * gamma + beta) over c_in channels.  DODA_CX_F_TRAINING: mean / invstd
- *                from the partial rows `stats` (first c_split channels) and `stats_b` (the rest: x is a concatenation),
- *                written to mean / invstd; running_mean / running_var / nbt updated when given.  Otherwise the running
- *                statistics are used.
- * DODA_CX_BNBWD  dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) (+ res): x = dz (masked), aux = the
- *                BatchNorm's input, stats = the GEMM's backward statistics; columns < c_split go to y, the rest to y2
- *                (the two halves of a concatenation's gradient as two dense tensors); dgamma / dbeta written (or, with
- *                DODA_CX_F_ACCUM, added to) when given.
- * DODA_CX_STATS  stats[p] = (sum x, sum x^2) over the rows workgroup p owns.
- *
- * sync: uint32 [4] device words owned by the caller across calls, zeroed once before the first: [0] the barrier counter and
- * [2] the exit counter (both back at zero when a launch has ended), [1] set to 1 by a barrier that timed out (a workgroup
- * never arrived: the results are garbage, the launch still terminates and leaves the counters clean).  Calls sharing
- * `sync` must be stream ordered.  desc_dev: doda_coarse_desc_bytes(n_ops) bytes of device scratch for the uploaded ops. */
+ *                doda_spconv_pack_multi for (K, c_in, c_out, elem_bytes) in the op's direction; tbl int32 [K][tbl_ld]
+ *                (DODA_CX_F_IDENTITY: K = 1 over an identity table — the 1x1 convolution).
+ *                aux == NULL (forward): stats += (sum y, sum y^2), y as stored.
+ *                aux != NULL (data gradient; aux = input of the BatchNorm in FRONT of the conv, mean / invstd / gamma / beta its
+ *                vectors): stats += (sum dz, sum dz * xhat), dz = y * [gamma * xhat + beta > 0] (the mask only with
+ *                DODA_CX_F_RELU), xhat = (aux - mean) * invstd; y itself is stored UNMASKED.   stats may be NULL.
+ * DODA_CX_BNFWD  y = [relu]((x - mean) * invstd * gamma + beta) over c_in channels.  DODA_CX_F_TRAINING: mean / invstd from the
+ *                totals `stats` (first c_split channels) and `stats_b` (the rest: x is a concatenation), written to mean /
+ *                invstd; running_mean / running_var / nbt updated when given.  Otherwise the running statistics are used.
+ * DODA_CX_BNBWD  dx = gamma * invstd * ([gamma * xhat + beta > 0] dz - mean(dz') - xhat * mean(dz' * xhat)) (+ res): x = dz (unmasked; the
+ *                op masks with DODA_CX_F_RELU and needs `beta`), aux = the BatchNorm's input, stats = the GEMM's backward totals;
+ *                columns < c_split go to y, the rest to y2 (the two halves of a concatenation's gradient as two dense tensors);
+ *                dgamma / dbeta written (or, with DODA_CX_F_ACCUM, added to).
+ * DODA_CX_STATS  stats += (sum x, sum x^2).
+ * A BatchNorm op whose output only feeds the NEXT op's gather is folded into that convolution (doda_conv_prologue): BNFWD ; GEMM ->
+ * one launch, BNBWD ; GEMM -> one launch, where the BatchNorm has at most DODA_PRE_FWD_ROWS (16384) / DODA_PRE_BWD_ROWS (0: the backward
+ * fold is built and tested but measured slower on the GPU) rows (environment; doda_set_option).  The folded and unfolded forms of a
+ * list give the same bits.  DODA_CX_F_BARRIER is accepted and ignored (stream order). */
 #define DODA_CX_GEMM 1
 #define DODA_CX_BNFWD 2
 #define DODA_CX_BNBWD 3
@@ -614,7 +612,7 @@ typedef struct doda_cx_op {
     int32_t c_in, c_out;     /* GEMM: channels of x / y; other kinds: c_in = channels */
     int32_t K, tbl_ld;
     int32_t x_ld, y_ld, res_ld, aux_ld, y2_ld;
-    int32_t n_part;          /* rows of every statistics array = doda_coarse_workgroups() */
+    int32_t n_part;          /* must be 0 (ABI 8-10: the executor's partial-row count) */
     int32_t c_split;
     int32_t reserved;
     float eps, momentum;
@@ -625,7 +623,7 @@ typedef struct doda_cx_op {
     void *y2;
     const void *res;
     const void *aux;
-    float *stats;
+    float *stats;            /* fp64 totals (doda_conv_epilogue.stats_totals), typed float * for ABI 8 compatibility */
     const float *stats_b;
     const float *gamma, *beta;
     float *mean, *invstd;
@@ -633,28 +631,7 @@ typedef struct doda_cx_op {
     int64_t *nbt;
     float *dgamma, *dbeta;
 } doda_cx_op;
-int32_t doda_coarse_workgroups(void);
-int doda_coarse_debug_stamps(void *buf_dev);   /* debug aid (tools/cxstamps.py): uint64 [4001] device words that workgroup 0 fills with
-                                                * (label << 56 | 100 MHz clock) at the phase boundaries of later launches; NULL: off */
-size_t doda_coarse_desc_bytes(int32_t n_ops);
-int doda_coarse_run(const doda_cx_op *ops_h, int32_t n_ops, void *desc_dev, size_t desc_bytes, uint32_t *sync_dev,
-                    doda_stream_t stream);
-
-/* ABI 11: the same op list as WHOLE-CHIP launches, one per op, issued back to back from inside the library (csrc/layers.hip) — the
- * per-layer kernels of doda_spconv_gather_ex and the BatchNorm sweeps over totals, without the caller's interpreter, autograd
- * nodes and allocations between them — with every BatchNorm op whose output only feeds the NEXT op's gather folded into that
- * convolution (doda_conv_prologue): BNFWD ; GEMM -> one launch, BNBWD ; GEMM -> one launch, where the BatchNorm has at most
- * DODA_PRE_FWD_ROWS (16384) / DODA_PRE_BWD_ROWS (0: the backward fold is built and tested but measured slower on the GPU) rows (environment; doda_set_option).  Same reference scope as doda_coarse_run
- * (model/unet_block.py:9-37,55-100); the folded and unfolded forms of a list give the same bits.  Differences to doda_coarse_run's
- * reading of an op:
- *   - n_part must be 0 and every statistics array (`stats`, `stats_b`) is DODA_STATS_TOTALS_DOUBLES(c) doubles of fp64 TOTALS
- *     (doda_conv_epilogue.stats_totals), zero before the op that accumulates into them;
- *   - DODA_CX_F_BARRIER is ignored (stream order); DODA_CX_F_IDENTITY still needs `tbl` (an identity table, K = 1);
- *   - a data-gradient GEMM (aux != NULL) stores y UNMASKED — the statistics are those of the masked values — and DODA_CX_BNBWD
- *     applies the mask itself: it needs `beta` and DODA_CX_F_RELU like the forward op;
- *   - `w` are the fragment-packed weights of doda_spconv_pack_multi for (K, c_in, c_out, elem_bytes) in the op's direction;
- *   - elem_bytes 2 (bf16) or 4 (fp32) for every feature matrix of the list.
- * *n_launches_h (optional, HOST) receives the number of kernel launches issued. */
+/* *n_launches_h (optional, HOST) receives the number of kernel launches issued. */
 int doda_layers_run(const doda_cx_op *ops_h, int32_t n_ops, int32_t elem_bytes, int32_t *n_launches_h, doda_stream_t stream);
 
 #ifdef __cplusplus

@@ -10,11 +10,116 @@ import numpy as np
 import pytest
 import torch
 
-from tests.test_gpu_coarse import LEVELS, _bf, _level, _pack, _run_subtree, _scale_err, _subtree, _unet_step, dev
+from tests.util import surface_voxels
 
 pytestmark = pytest.mark.gpu
 
 BIG = 1 << 30
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _pack(w, K, kc, nc, layout, d):
+    from doda_amd import ops
+    plan = ops.PackPlan([(w, K, kc, nc, layout, 2)], d)
+    plan.run()
+    return plan.outputs[0]
+
+
+def _scale_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+LEVELS = [(8400, 64), (1900, 80), (420, 96), (83, 112)]
+
+
+def _level(seed, n, batch=4):
+    side = max(16, int(round((n / batch / 0.08) ** (1 / 3))))   # ~8 % occupancy: 10-14 neighbours per voxel
+    shape = [side, side, side]
+    idx = surface_voxels(seed, n, batch, shape)
+    return np.ascontiguousarray(idx[:n]), shape, batch
+
+
+
+def _unet_step(mode, level, dtype=torch.bfloat16, voxels=60000, seed=11, two_pass=False):
+    """One training step of the U-Net on a seeded batch with the executor on / off: (logits, loss, {name: grad}, running stats)."""
+    from doda_amd import model as M
+    from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
+    from doda_amd.scene import make_batch
+    from doda_amd.spconv import functional as Fsp
+    from tests.util import deterministic_init
+    d = dev()
+    cfg = default_cfg()
+    batch = make_batch(2, voxels, seed)
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    net = deterministic_init(SparseConvNet(cfg), seed=3).to(d).train()
+    old = (M.COARSE_MODE, M.COARSE_EXEC_LEVEL)
+    M.set_coarse_mode(mode, level)
+    try:
+        assert Fsp.set_deferred_wgrad(True)
+        net.zero_grad(set_to_none=True)
+        scores = voxelize_and_run(cfg, net, bd, d, feature_dtype=dtype)
+        loss = cross_entropy(scores, bd["labels"])
+        loss.backward()
+        if two_pass:   # a second backward pass into the same .grad tensors (tool/st.py:136-198 runs two per optimizer step)
+            scores2 = voxelize_and_run(cfg, net, bd, d, feature_dtype=dtype)
+            cross_entropy(scores2, bd["labels"]).backward()
+        torch.cuda.synchronize()
+    finally:
+        Fsp.set_deferred_wgrad(False)
+        M.set_coarse_mode(*old)
+    grads = {n: p.grad.detach().float().clone() for n, p in net.named_parameters()}
+    bufs = {n: b.detach().clone() for n, b in net.named_buffers()}
+    return scores.detach().float(), float(loss.detach()), grads, bufs
+
+
+def _subtree(level, n, seed):
+    """UBlock(level) of a freshly initialised U-Net plus a level-`level` input of n voxels."""
+    from doda_amd.model import SparseConvNet, default_cfg
+    from tests.util import deterministic_init
+    d = dev()
+    net = deterministic_init(SparseConvNet(default_cfg()), seed=seed).to(d).train()
+    ub = net.unet
+    for _ in range(level - 1):
+        ub = ub.u
+    idx, shape, batch = _level(seed + n, n)
+    q = 2 ** (8 - level)
+    shape = [max(q, s + (-s) % q) for s in shape]   # every deeper level keeps >= 2 cells per axis
+    ind = torch.from_numpy(idx).to(d)
+    return net, ub, ind, shape, batch
+
+
+def _run_subtree(ub, ind, shape, batch, level, x0, gout, mode):
+    from doda_amd import model as M
+    from doda_amd import spconv
+    from doda_amd.spconv import functional as Fsp
+    old = (M.COARSE_MODE, M.COARSE_EXEC_LEVEL)
+    M.set_coarse_mode(mode, level)
+    try:
+        assert Fsp.set_deferred_wgrad(True)
+        for p in ub.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        t = spconv.SparseConvTensor(x, ind, shape, batch)
+        spconv.ops.build_pyramid(t, 8 - level, first_level=level)
+        y = ub(t).features
+        (y.float() * gout.float()).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        Fsp.set_deferred_wgrad(False)
+        M.set_coarse_mode(*old)
+    return (y.detach().float(), x.grad.detach().float(), {n: p.grad.detach().float().clone() for n, p in ub.named_parameters()},
+            {n: b.detach().clone() for n, b in ub.named_buffers()})
+
+
 
 
 def _tables(ops, idx, shape, batch, d):
@@ -220,6 +325,147 @@ def test_fold_accumulates_parameter_gradients_and_takes_strided_operands(native_
     assert _scale_err(res[True][0].float(), ref) < 2.0 ** -6
 
 
+@pytest.mark.parametrize("n,c", LEVELS[1:])
+def test_gemm_down_up_and_1x1_with_strided_operands(native_lib, oracle, n, c):
+    """k2 s2 convolution (K = 8 tables, both directions) and the 1x1 skip convolution (identity table) with operands that are
+    column slices of a wider matrix — the level's concatenation read and written in place (reference model/unet_block.py:89-93)."""
+    from doda_amd import ops
+    d = dev()
+    idx, shape, batch = _level(7 * n, n)
+    n = idx.shape[0]
+    outids, child, par_off = ops.rulebook_down2(torch.from_numpy(idx).to(d), shape, batch)[:3]
+    m = outids.shape[0]
+    g = torch.Generator().manual_seed(n + 1)
+    c2 = c + 16
+    # strided conv fine -> coarse, reading x as the left half of a [n, 2c] matrix
+    cat = _bf(torch.randn(n, 2 * c, generator=g)).to(d)
+    w = (torch.randn(8, c, c2, generator=g) * (1.0 / (c * 4)) ** 0.5).to(d)
+    wp = _pack(w, 8, c, c2, 0, d)
+    y = torch.zeros((m, c2), dtype=torch.bfloat16, device=d)
+    st = ops.stats_totals(c2, d)
+    ops.layers_run([dict(kind=ops.CX_GEMM, flags=0, rows=m, rows_in=n, c_in=c, c_out=c2, K=8, tbl_ld=child.shape[1], x_ld=2 * c, y_ld=c2,
+                         x=cat, w=wp, tbl=child, y=y, stats=st)], d)
+    lay = ops.spconv_gather(cat[:, :c].contiguous(), w, child, m, 0, c2, packed=wp)
+    assert _scale_err(y.float(), lay.float()) < 2.0 ** -7
+    yd = y.double()
+    assert torch.allclose(ops.totals_sums(st)[0], yd.sum(0), rtol=1e-5, atol=1e-4 * float(yd.abs().max()))
+    # inverse conv coarse -> fine, writing the right half of a [n, 2c] matrix
+    z = _bf(torch.randn(m, c2, generator=g)).to(d)
+    wi = (torch.randn(8, c2, c, generator=g) * (1.0 / c2) ** 0.5).to(d)
+    wpi = _pack(wi, 8, c2, c, 0, d)
+    out = torch.zeros((n, 2 * c), dtype=torch.bfloat16, device=d)
+    ops.layers_run([dict(kind=ops.CX_GEMM, flags=0, rows=n, rows_in=m, c_in=c2, c_out=c, K=8, tbl_ld=par_off.shape[1], x_ld=c2, y_ld=2 * c,
+                         x=z, w=wpi, tbl=par_off, y=out[:, c:], stats=None)], d)
+    lay = ops.spconv_gather(z, wi, par_off, n, 0, c, packed=wpi)
+    assert _scale_err(out[:, c:].float(), lay.float()) < 2.0 ** -7
+    assert float(out[:, :c].abs().max()) == 0.0
+    # 1x1 convolution over the concatenation, with a residual that is itself a column slice
+    w1 = (torch.randn(1, 2 * c, c, generator=g) * (1.0 / (2 * c)) ** 0.5).to(d)
+    wp1 = _pack(w1, 1, 2 * c, c, 0, d)
+    s = torch.zeros((n, c), dtype=torch.bfloat16, device=d)
+    ident = torch.arange(n, dtype=torch.int32, device=d).view(1, n)
+    ops.layers_run([dict(kind=ops.CX_GEMM, flags=ops.CX_F_IDENTITY, rows=n, rows_in=n, c_in=2 * c, c_out=c, K=1, tbl_ld=n, x_ld=2 * c, y_ld=c,
+                         res_ld=2 * c, x=cat, w=wp1, tbl=ident, y=s, res=out[:, c:], stats=None)], d)
+    ref = cat.float() @ w1[0].to(torch.bfloat16).float() + out[:, c:].float()
+    assert _scale_err(s.float(), ref) < 2.0 ** -7
+
+
+@pytest.mark.parametrize("n,c", LEVELS[1:3])
+def test_gemm_backward_epilogue_vs_definition(native_lib, oracle, n, c):
+    """Data-gradient call: y = dy gathered through W[26-o]^T, stored UNMASKED; totals (sum dz, sum dz * xhat) of the values masked by
+    the ReLU of the BatchNorm in front of the conv; also the 2c-channel output (several channel blocks)."""
+    from doda_amd import ops
+    d = dev()
+    idx, shape, batch = _level(3 * n, n)
+    n = idx.shape[0]
+    pairs, pn = oracle.indice_pairs_subm(idx, batch, shape, 3)
+    tbl = ops.rulebook_subm(torch.from_numpy(idx).to(d), shape, batch, 3)
+    g = torch.Generator().manual_seed(n + 2)
+    for cin, cout in ((c, c), (2 * c, c)):
+        x_bn = _bf(torch.randn(n, cin, generator=g)).to(d)            # input of the BatchNorm in front of the conv
+        mean = (0.1 * torch.randn(cin, generator=g)).to(d)
+        invstd = (1.0 + 0.2 * torch.rand(cin, generator=g)).to(d)
+        gamma = (1.0 + 0.1 * torch.randn(cin, generator=g)).to(d)
+        beta = (0.1 * torch.randn(cin, generator=g)).to(d)
+        dy = _bf(torch.randn(n, cout, generator=g)).to(d)
+        w = (torch.randn(27, cin, cout, generator=g) * (1.0 / (cin * 9)) ** 0.5).to(d)
+        wpb = _pack(w, 27, cout, cin, 2, d)                           # data-grad layout of a SubM conv
+        dz = torch.zeros((n, cin), dtype=torch.bfloat16, device=d)
+        st = ops.stats_totals(cin, d)
+        ops.layers_run([dict(kind=ops.CX_GEMM, flags=ops.CX_F_RELU, rows=n, rows_in=n, c_in=cout, c_out=cin, K=27, tbl_ld=n, x_ld=cout, y_ld=cin,
+                             aux_ld=cin, x=dy, w=wpb, tbl=tbl, y=dz, aux=x_bn, stats=st, mean=mean, invstd=invstd, gamma=gamma, beta=beta)], d)
+        torch.cuda.synchronize()
+        xn = torch.relu((x_bn.float() - mean) * invstd * gamma + beta)
+        din, _ = oracle.indice_conv_backward(xn.cpu().numpy(), w.to(torch.bfloat16).float().cpu().numpy().reshape(3, 3, 3, cin, cout),
+                                             dy.float().cpu().numpy(), pairs, pn, subm=True)
+        assert _scale_err(dz.float(), torch.as_tensor(din).to(d)) < 2.0 ** -7, (cin, cout)
+        xh = (x_bn.float() - mean) * invstd
+        zf = dz.double() * ((xh * gamma + beta) > 0).double()
+        sums = ops.totals_sums(st)
+        assert torch.allclose(sums[0], zf.sum(0), rtol=1e-4, atol=1e-3 * float(zf.abs().max()))
+        assert torch.allclose(sums[1], (zf * xh.double()).sum(0), rtol=1e-4, atol=1e-3 * float(zf.abs().max()))
+
+
+@pytest.mark.parametrize("n,c", LEVELS[1:])
+def test_batchnorm_ops_vs_torch(native_lib, n, c):
+    """STATS -> BNFWD (training, incl. the two-segment form of a concatenation, running statistics) and BNBWD (with the added skip
+    gradient and the split output) as launches of their own against torch.nn.functional.batch_norm + autograd in fp32."""
+    from doda_amd import ops
+    import torch.nn.functional as F
+    d = dev()
+    g = torch.Generator().manual_seed(n + 3)
+    C2 = 2 * c
+    x = _bf(torch.randn(n, C2, generator=g) * 1.5 + 0.3).to(d)
+    gamma = (1.0 + 0.1 * torch.randn(C2, generator=g)).to(d)
+    beta = (0.1 * torch.randn(C2, generator=g)).to(d)
+    rm, rv = torch.zeros(C2, device=d), torch.ones(C2, device=d)
+    nbt = torch.zeros((), dtype=torch.int64, device=d)
+    sa, sb = ops.stats_totals(c, d), ops.stats_totals(c, d)
+    mean, invstd = torch.zeros(C2, device=d), torch.zeros(C2, device=d)
+    y = torch.zeros((n, C2), dtype=torch.bfloat16, device=d)
+    assert ops.layers_run([
+        dict(kind=ops.CX_STATS, flags=0, rows=n, c_in=c, x_ld=C2, x=x, stats=sa),
+        dict(kind=ops.CX_STATS, flags=0, rows=n, c_in=c, x_ld=C2, x=x[:, c:], stats=sb),
+        dict(kind=ops.CX_BNFWD, flags=ops.CX_F_RELU | ops.CX_F_TRAINING, rows=n, c_in=C2, x_ld=C2, y_ld=C2, c_split=c, eps=1e-4, momentum=0.1,
+             x=x, y=y, stats=sa, stats_b=sb, gamma=gamma, beta=beta, mean=mean, invstd=invstd, running_mean=rm, running_var=rv, nbt=nbt),
+    ], d) == 3
+    xf = x.float().requires_grad_(True)
+    rm_ref, rv_ref = torch.zeros(C2, device=d), torch.ones(C2, device=d)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = torch.relu(F.batch_norm(xf, rm_ref, rv_ref, gr, br, True, 0.1, 1e-4))
+    torch.cuda.synchronize()
+    assert _scale_err(y.float(), y_ref.detach()) < 2.0 ** -7
+    assert torch.allclose(rm, rm_ref, rtol=1e-4, atol=1e-5) and torch.allclose(rv, rv_ref, rtol=1e-4, atol=1e-5)
+    assert int(nbt) == 1
+    assert torch.allclose(mean, xf.detach().mean(0), rtol=1e-4, atol=1e-5)
+    # backward: the unmasked gradient as the data-grad GEMM stores it, the totals of its masked values as that GEMM's epilogue leaves them
+    dy = _bf(torch.randn(n, C2, generator=g)).to(d)
+    add = _bf(torch.randn(n, C2, generator=g)).to(d)
+    (y_ref * dy.float()).sum().backward()
+    xh = (x.float() - mean) * invstd
+    dz = dy.float() * ((xh * gamma + beta) > 0).float()
+    st = ops.stats_totals(C2, d)
+    st[0, 0, :, :4] = dz.double().sum(0).reshape(-1, 4)
+    st[0, 1, :, :4] = (dz.double() * xh.double()).sum(0).reshape(-1, 4)
+    dxa = torch.zeros((n, c), dtype=torch.bfloat16, device=d)
+    dxb = torch.zeros((n, c), dtype=torch.bfloat16, device=d)
+    dg, db = torch.zeros(C2, device=d), torch.zeros(C2, device=d)
+    ops.layers_run([dict(kind=ops.CX_BNBWD, flags=ops.CX_F_RELU, rows=n, c_in=C2, x_ld=C2, aux_ld=C2, res_ld=C2, y_ld=c, y2_ld=c, c_split=c,
+                         x=dy, aux=x, res=add, y=dxa, y2=dxb, stats=st, mean=mean, invstd=invstd, gamma=gamma, beta=beta, dgamma=dg, dbeta=db)], d)
+    torch.cuda.synchronize()
+    ref = xf.grad + add.float()
+    got = torch.cat((dxa, dxb), 1).float()
+    assert _scale_err(got, ref) < 2.0 ** -6
+    assert torch.allclose(dg, gr.grad, rtol=2e-2, atol=2e-2 * float(gr.grad.abs().max()))
+    assert torch.allclose(db, br.grad, rtol=2e-2, atol=2e-2 * float(br.grad.abs().max()))
+    # evaluation mode: running statistics
+    ye = torch.zeros((n, C2), dtype=torch.bfloat16, device=d)
+    ops.layers_run([dict(kind=ops.CX_BNFWD, flags=ops.CX_F_RELU, rows=n, c_in=C2, x_ld=C2, y_ld=C2, c_split=C2, eps=1e-4, momentum=0.1,
+                         x=x, y=ye, gamma=gamma, beta=beta, running_mean=rm, running_var=rv)], d)
+    ye_ref = torch.relu(F.batch_norm(x.float(), rm, rv, gamma, beta, False, 0.1, 1e-4))
+    assert _scale_err(ye.float(), ye_ref) < 2.0 ** -7
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("level,n", [(4, 8400), (5, 1900), (5, 700), (6, 420), (7, 83)])
 def test_subtree_layers_vs_module_path(native_lib, level, n, dtype):
@@ -391,19 +637,13 @@ def test_unet_layers_eval_and_no_grad(native_lib):
 
 
 def test_backend_selection():
-    """choose_coarse_backend: the rule that picks executor / per-layer launches / module path (no GPU work)."""
+    """choose_coarse_backend: one extension call over the per-layer launches, or module by module (no GPU work)."""
     from doda_amd import model as M
     old = (M.COARSE_MODE, M.COARSE_EXEC_LEVEL)
     try:
         M.set_coarse_mode("layers")
         assert M.choose_coarse_backend(8400, torch.bfloat16) == "layers" and M.choose_coarse_backend(8400, torch.float32) == "layers"
-        assert M.choose_coarse_backend(1, torch.bfloat16) is None
-        M.set_coarse_mode("auto")
-        assert M.choose_coarse_backend(M.COARSE_EXEC_MAX_ROWS, torch.bfloat16) == "exec"
-        assert M.choose_coarse_backend(M.COARSE_EXEC_MAX_ROWS, torch.float32) == "layers"
-        assert M.choose_coarse_backend(M.COARSE_EXEC_MAX_ROWS + 1, torch.bfloat16) == "layers"
-        M.set_coarse_mode("exec")
-        assert M.choose_coarse_backend(2000, torch.bfloat16) == "exec" and M.choose_coarse_backend(2000, torch.float32) is None
+        assert M.choose_coarse_backend(1, torch.bfloat16) is None and M.choose_coarse_backend(8400, torch.float16) is None
         M.set_coarse_mode("off")
         assert M.choose_coarse_backend(2000, torch.bfloat16) is None
     finally:

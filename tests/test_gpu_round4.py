@@ -560,7 +560,7 @@ def test_restricted_backward_leaves_parameter_gradients_alone(native_lib):
     """with direct parameter gradients on (set_deferred_wgrad(True)) the extension's nodes keep no autograd edge to
     conv weights / BatchNorm vectors and deposit .grad themselves — but only in a plain accumulating backward pass.
     torch.autograd.grad(loss, x) and loss.backward(inputs=[x]) must neither touch .grad nor queue weight-gradient jobs; a
-    plain loss.backward() afterwards still produces every gradient (incl. on the coarse-level executor)."""
+    plain loss.backward() afterwards still produces every gradient (incl. with the coarse levels as one extension call)."""
     ext = _ext_or_skip()
     from doda_amd import model as M
     from doda_amd import spconv
@@ -574,8 +574,8 @@ def test_restricted_backward_leaves_parameter_gradients_alone(native_lib):
     old = (M.COARSE_MODE, M.COARSE_EXEC_LEVEL)
     try:
         assert Fsp.set_deferred_wgrad(True)
-        for exec_on in (False, True):
-            M.set_coarse_exec(exec_on, 5)
+        for coarse_mode in ("off", "layers"):
+            M.set_coarse_mode(coarse_mode, 5)
             for p in ub.parameters():
                 p.grad = None
 
