@@ -197,6 +197,16 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply(const typename T::elem *__r
                                                      const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, int relu,
                                                      typename T::elem *__restrict__ y, const TotArgs tot = TotArgs()) {
+    // (round 6) FIXED: this thread's first rows are REQUESTED before the totals prologue (its fp64 arithmetic and barrier are a
+    // dependent round trip of their own): with the whole grid resident at once (launch_apply_tot caps it) every workgroup used to sit
+    // through the prologue with no row in flight — 12-16 us per level-1 sweep of 38 MB in the step, 7.5 us without the prologue
+    f32x4 pre_v[T::W];
+    [[maybe_unused]] bool pre_have = false;
+    if constexpr (FIXED && TOT) {
+        const long long n_w0 = n_frag / T::W, e00 = (long long)blockIdx.x * BN_BLOCK + threadIdx.x;
+        pre_have = e00 < n_w0;
+        T::loadw(x + (pre_have ? e00 : 0) * (4 * T::W), pre_v);
+    }
     if constexpr (TOT) {   // mean / invstd from the totals, through LDS
         __shared__ __attribute__((aligned(16))) float v_mu[BN_TOT_MAX_C], v_is[BN_TOT_MAX_C];
         tot_fwd_prologue(tot, nf * 4, v_mu, v_is);
@@ -217,7 +227,10 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply(const typename T::elem *__r
         }
         for (long long e = e0; e < n_w; e += (long long)gridDim.x * BN_BLOCK) {
             f32x4 v[W];
-            T::loadw(x + e * (4 * W), v);
+            if (TOT && e == e0) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) v[w] = pre_v[w];
+            } else T::loadw(x + e * (4 * W), v);
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 f32x4 o = (v[w] - mu[w]) * is[w] * ga[w] + be[w];
@@ -250,11 +263,11 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply(const typename T::elem *__r
 
 // grid of an apply sweep: as many workgroups as fragments need (<= 4096), rounded DOWN so that the thread count is a
 // multiple of the 16-byte columns per row (then FIXED applies); *fixed = false when no such grid exists
-inline int apply_grid(long long n_frag, int nf, int W, bool *fixed) {
+inline int apply_grid(long long n_frag, int nf, int W, bool *fixed, int cap = 4096) {
     const long long n_w = n_frag / W;
     const int cols = nf / W;
     long long grid = (n_w + BN_BLOCK - 1) / BN_BLOCK;
-    if (grid > 4096) grid = 4096;
+    if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     *fixed = false;
     if (nf % W != 0 || n_frag % W != 0) return (int)((n_frag + BN_BLOCK - 1) / BN_BLOCK < 4096 ? (n_frag + BN_BLOCK - 1) / BN_BLOCK : 4096);
@@ -346,6 +359,15 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply(const typename T::elem 
                                                          typename T::elem *__restrict__ dx,
                                                          const typename T::elem *__restrict__ add, int add_ld = 0,
                                                          const TotArgs tot = TotArgs()) {
+    f32x4 pre_x[T::W], pre_dz[T::W], pre_av[T::W];   // (round 6: first rows requested before the totals prologue, see bn_apply)
+    if constexpr (FIXED && TOT) {
+        const int cols0 = nf / T::W;
+        const long long n_w0 = n_frag / T::W, e00 = (long long)blockIdx.x * BN_BLOCK + threadIdx.x;
+        const long long ee = e00 < n_w0 ? e00 : 0;
+        T::loadw(x + ee * (4 * T::W), pre_x);
+        T::loadw(dy + ee * (4 * T::W), pre_dz);
+        if (add) T::loadw(add_ld ? add + (ee / cols0) * add_ld + (int)(ee % cols0) * T::W * 4 : add + ee * (4 * T::W), pre_av);
+    }
     if constexpr (TOT) {   // the three coefficient vectors from the totals, through LDS
         __shared__ __attribute__((aligned(16))) float v_co[3 * BN_TOT_MAX_C];
         tot_bwd_prologue(tot, c, invstd, gamma, v_co);
@@ -369,9 +391,14 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply(const typename T::elem 
         }
         for (long long e = e0; e < n_w; e += (long long)gridDim.x * BN_BLOCK) {
             f32x4 xv[W], dz[W], av[W];
-            T::loadw(x + e * (4 * W), xv);
-            T::loadw(dy + e * (4 * W), dz);
-            if (add) T::loadw(add_ld ? add + (e / cols) * add_ld + f * 4 : add + e * (4 * W), av);
+            if (TOT && e == e0) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) { xv[w] = pre_x[w]; dz[w] = pre_dz[w]; av[w] = pre_av[w]; }
+            } else {
+                T::loadw(x + e * (4 * W), xv);
+                T::loadw(dy + e * (4 * W), dz);
+                if (add) T::loadw(add_ld ? add + (e / cols) * add_ld + f * 4 : add + e * (4 * W), av);
+            }
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 const f32x4 xh = (xv[w] - mu[w]) * is[w];
@@ -431,8 +458,13 @@ void launch_apply(const typename T::elem *x, long long n_frag, int nf, const flo
 template <class T>
 void launch_apply_tot(const typename T::elem *x, long long n_frag, int nf, const float *gamma, const float *beta, int relu,
                       typename T::elem *y, const TotArgs &tot, hipStream_t s) {
+    // (round 6) at most 1024 workgroups (4 per CU, all resident at once): every workgroup pays the totals prologue — 16 doubles per
+    // channel out of padded 128-byte lines, fp64 division / square root, a barrier — once per ~5 x 16 bytes per thread at level 1
+    // instead of once per 16 bytes.  In-step sums of bn_apply + bn_bwd_apply (tools/layers_prof.sh, DODA_BN_TOT_GRID): 4096
+    // workgroups 613 us, 2048 573, 1024 518, 768 518, 512 531, 256 667
+    static const int cap = [] { const char *e = getenv("DODA_BN_TOT_GRID"); const int v = e ? atoi(e) : 1024; return v < 64 ? 64 : v > 4096 ? 4096 : v; }();
     bool fixed;
-    int grid = apply_grid(n_frag, nf, T::W, &fixed);
+    int grid = apply_grid(n_frag, nf, T::W, &fixed, cap);
     if (fixed && !(al16(x) && al16(y))) { fixed = false; grid = plain_grid(n_frag); }
     if (fixed)
         hipLaunchKernelGGL((bn_apply<T, true, true>), dim3(grid), dim3(BN_BLOCK), 0, s, x, n_frag, nf, nullptr, nullptr, gamma, beta, relu, y, tot);
@@ -443,8 +475,9 @@ template <class T>
 void launch_bwd_apply_tot(const typename T::elem *x, const typename T::elem *dy, long long n_frag, int nf, int c,
                           const float *mean, const float *invstd, const float *gamma, const float *beta, int relu,
                           typename T::elem *dx, const typename T::elem *add, int add_ld, const TotArgs &tot, hipStream_t s) {
+    static const int cap = [] { const char *e = getenv("DODA_BN_TOT_GRID"); const int v = e ? atoi(e) : 1024; return v < 64 ? 64 : v > 4096 ? 4096 : v; }();
     bool fixed;
-    int grid = apply_grid(n_frag, nf, T::W, &fixed);
+    int grid = apply_grid(n_frag, nf, T::W, &fixed, cap);
     if (fixed && !(al16(x) && al16(dy) && al16(dx) && (!add || (al16(add) && add_ld % (4 * T::W) == 0)))) {
         fixed = false;
         grid = plain_grid(n_frag);

@@ -80,6 +80,9 @@ def build_parser():
     p.add_argument("--max_iters", type=int, default=None, help="stop after this many iterations (smoke runs)")
     p.add_argument("--timing_warmup", type=int, default=10, help="iterations of an epoch before its steady-state clock starts")
     p.add_argument("--timing_json", type=str, default=None, help="write {iterations, seconds, ms_per_iter, voxels_per_s} here at exit")
+    p.add_argument("--curve_json", type=str, default=None,
+                   help="write the run's curve here at exit: per epoch the mean training loss and, when evaluated, the held-out "
+                        "loss / mIoU / per-class IoU (tools/trajectory.sh: bf16 against fp32 on the same data and seed)")
     p.add_argument("--set", dest="set_cfgs", default=None, nargs=argparse.REMAINDER,
                    help="set extra config keys if needed")
     return p
@@ -291,6 +294,7 @@ class Trainer:
         self.model = model.to(device)
         self.fdt = torch.float32 if args.dtype == "f32" else torch.bfloat16
         self.optimizer = build_optimizer(cfg.OPTIMIZATION, self.model)
+        self.curve = []      # per epoch: mean training loss (+ the held-out metrics when evaluated): --curve_json
         self.deferred = Fsp.set_deferred_wgrad(True)
         self.reducer = None
         if world > 1:
@@ -384,8 +388,12 @@ class Trainer:
         t_steady = None
         for i, (batch, pyramid) in enumerate(self._batches(epoch, "train")):
             if i == warm:   # steady-state clock: from here to the end of the epoch, device drained on both sides
-                torch.cuda.synchronize(self.device)
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
                 t_steady = (time.time(), i)
+                vox_steady = 0
+            if t_steady is not None:
+                vox_steady += int(batch["voxel_locs"].shape[0])
             lr = adjust_lr(cfg.OPTIMIZATION, self.optimizer, None, total_epochs, n_iter, epoch, i)
             self.optimizer.zero_grad(set_to_none=True)
             if args.self_train:   # tool/st.py:136-198: source pass, then target pass, ONE optimizer step
@@ -414,14 +422,16 @@ class Trainer:
             if args.max_iters is not None and self.iters_done >= args.max_iters:
                 break
         if t_steady is not None:
-            torch.cuda.synchronize(self.device)
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
             done = i + 1 - t_steady[1]
             if done > 0:
-                self.step_times.append((done, time.time() - t_steady[0]))
+                self.step_times.append((done, time.time() - t_steady[0], vox_steady))
                 self.log("Steady state: %d iterations, %.3f ms per iteration" % (done, 1e3 * self.step_times[-1][1] / done))
         meters.all_reduce()
         l, miou, macc, allacc, _ = meters.read()
         self.log("Train result at epoch [%d/%d]: mIoU/mAcc/allAcc %.4f/%.4f/%.4f." % (epoch + 1, total_epochs, miou, macc, allacc))
+        self.curve.append({"epoch": epoch + 1, "iterations": self.iters_done, "train_loss": l, "train_miou": miou})
         return l
 
     @torch.no_grad()
@@ -443,6 +453,9 @@ class Trainer:
         meters.all_reduce()
         l, miou, macc, allacc, iou = meters.read()
         self.log("Val result: mIoU/mAcc/allAcc %.4f/%.4f/%.4f." % (miou, macc, allacc))
+        self.log("Val IoU per class: " + " ".join("%.4f" % v for v in iou))
+        if self.curve and self.curve[-1]["epoch"] == epoch + 1:
+            self.curve[-1].update({"val_loss": l, "val_miou": miou, "val_allacc": allacc, "val_iou": [float(v) for v in iou]})
         return miou
 
 
@@ -522,12 +535,19 @@ def main(argv=None):
         import json
         its = sum(t[0] for t in trainer.step_times)
         sec = sum(t[1] for t in trainer.step_times)
+        vox = sum(t[2] for t in trainer.step_times)
         with open(args.timing_json, "w") as f:
             json.dump({"iterations": its, "seconds": sec, "ms_per_iter": 1e3 * sec / its, "world": world,
+                       "voxels_per_s": vox * world / sec if sec > 0 else None,   # (this rank's voxels x ranks: weak scaling)
                        "batch_size_per_gpu": args.batch_size, "workers": args.workers, "dtype": args.dtype,
                        "voxels_per_scene": args.synthetic_voxels,
                        "feeder_wait_for_workers_ms": getattr(trainer, "feeder_ms", (None, None))[0],
                        "feeder_collate_and_rulebooks_ms": getattr(trainer, "feeder_ms", (None, None))[1]}, f)
+    if args.curve_json and rank == 0:
+        import json
+        with open(args.curve_json, "w") as f:
+            json.dump({"dtype": args.dtype, "seed": args.manual_seed, "batch_size_per_gpu": args.batch_size, "world": world,
+                       "scenes_per_epoch": args.synthetic_scenes, "voxels_per_scene": args.synthetic_voxels, "curve": trainer.curve}, f)
     ddist.barrier()
 
 
