@@ -172,14 +172,18 @@ class EpochSampler(torch.utils.data.Sampler):
         return iter([base + i for i in self._mine()])
 
 
-def host_loader(dataset, batch_size, rank, world, workers, shuffle=True, seed=0):
+def host_loader(dataset, batch_size, rank, world, workers, shuffle=True, seed=0, full_scale0=128):
     """(DataLoader of lists of `batch_size` dataset items for this rank, its EpochSampler) — reference
     dataset/__init__.py:62-75 with the collate left to the device."""
     sampler = EpochSampler(len(dataset), batch_size, rank, world, shuffle, seed)
     kw = {}
     if workers > 0:
         kw = dict(num_workers=workers, multiprocessing_context="forkserver", prefetch_factor=4, persistent_workers=True)
-    return torch.utils.data.DataLoader(dataset, batch_size=batch_size, sampler=sampler, collate_fn=host_collate, drop_last=True,
+    import functools
+    # (full_scale0: cfg DATA_PROCESSOR.full_scale[0] — the clip of spatial_shape, reference dataset/dataset.py:176 — as DeviceScenes
+    # and collate_device take it: the two loaders must agree for any config)
+    collate = host_collate if int(full_scale0) == 128 else functools.partial(host_collate, full_scale0=int(full_scale0))
+    return torch.utils.data.DataLoader(dataset, batch_size=batch_size, sampler=sampler, collate_fn=collate, drop_last=True,
                                        pin_memory=torch.cuda.is_available(), **kw), sampler
 
 
@@ -353,23 +357,40 @@ class DeviceScenes:
                 "spatial_shape": np.clip(top, self.full_scale0, None), "id": [int(i) for i in ids]}
 
 
-_CACHES = []
+_OWN_CACHES = []      # cache directories this PROCESS created privately (DODA_PRIVATE_SCENES=1): the only ones it may delete
 
 
 def synthetic_dataset(cfg, args, split):
     """The synthetic stand-in for the reference's dataset objects: `--synthetic_scenes` items per epoch over a pool of
-    min(--synthetic_base, items) base scenes per split."""
+    min(--synthetic_base, items) base scenes per split.
+
+    The default cache (/dev/shm/doda_amd_scenes_<uid>) is SHARED by every job of the user on the node — files are keyed by
+    (seed, voxels, scale) and written atomically, so concurrent jobs and later runs reuse them — and is therefore never deleted
+    by a job (an exiting job used to remove it under a running one; `python -m doda_amd.loader --clean` or
+    remove_cache() empties it).  DODA_PRIVATE_SCENES=1: a per-process directory instead, removed at exit by local rank 0."""
     base_seed = {"train": 1000, "target": 501000, "val": 901000}[split]
     n_base = max(1, min(int(getattr(args, "synthetic_base", 16)), int(args.synthetic_scenes)))
     voxel_scale = cfg.DATA_CONFIG.DATA_PROCESSOR.voxel_scale
-    cache_dir, paths = prepare_cache(n_base, args.synthetic_voxels, voxel_scale, base_seed, getattr(args, "scene_cache", None))
-    if getattr(args, "scene_cache", None) is None and cache_dir not in _CACHES and not os.environ.get("DODA_KEEP_SCENES"):
-        _CACHES.append(cache_dir)
+    cache = getattr(args, "scene_cache", None)
+    if cache is None and os.environ.get("DODA_PRIVATE_SCENES") == "1":
+        if not _OWN_CACHES:
+            root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+            # (one directory per job: every rank of a torchrun job sees the same MASTER_PORT; a single process its own pid)
+            _OWN_CACHES.append(os.path.join(root, "doda_amd_scenes_%d_%s" % (os.getuid(), os.environ.get("MASTER_PORT", os.getpid()))))
+        cache = _OWN_CACHES[0]
+    cache_dir, paths = prepare_cache(n_base, args.synthetic_voxels, voxel_scale, base_seed, cache)
     return SyntheticScenes(paths, args.synthetic_scenes, voxel_scale, seed=base_seed, augment=split != "val")
 
 
 @atexit.register
-def _cleanup():   # (rank 0 of a local run owns the default cache; shared explicit caches are left alone)
-    if int(os.environ.get("RANK", "0")) == 0:
-        for d in _CACHES:
+def _cleanup():   # (only a private per-job cache, by the node's first rank; the shared default cache and explicit ones are left alone)
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        for d in _OWN_CACHES:
             remove_cache(d)
+
+
+if __name__ == "__main__":   # python -m doda_amd.loader --clean : empty the shared default scene cache of this user on this node
+    import sys
+    if "--clean" in sys.argv:
+        root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+        remove_cache(os.path.join(root, "doda_amd_scenes_%d" % os.getuid()))

@@ -47,7 +47,9 @@ _PAD_INPUT_16 = _os.environ.get("DODA_PAD_INPUT16", "1") == "1"
 
 def padded_in_channels(conv, dtype):
     """Channels the rows of `conv`'s input are zero-padded to on the GPU (forward below), or None when it takes them as they are."""
-    if conv.in_channels % 4 == 0:
+    # (only where forward below pads: a 3x3x3 SubM / strided layer — the 1x1 shortcut multiplies [N, c_in] x [c_in, c_out] with
+    # torch.mm and would meet pre-padded rows with a shape mismatch, ADVICE r5)
+    if conv.in_channels % 4 == 0 or getattr(conv, "conv1x1", False) or list(conv.kernel_size) != [3, 3, 3]:
         return None
     extra = (-conv.in_channels) % 4
     if _PAD_INPUT_16 and dtype == torch.bfloat16 and conv.in_channels < 16 and conv.subm and conv.kernel_size == [3, 3, 3]:

@@ -337,13 +337,14 @@ class Trainer:
             if self.rank != 0:
                 ds = synthetic_dataset(self.cfg, self.args, split)
             seed = self.args.manual_seed or 0
-            if self.args.host_loader:
+            fs0 = self.cfg.DATA_CONFIG.DATA_PROCESSOR.get("full_scale", [128, 512])[0]
+            if self.args.host_loader:   # (same sampler seed and the same spatial-shape clip as the HBM-resident loader below)
                 self._loaders[split] = host_loader(ds, self.args.batch_size, self.rank, self.world, self.args.workers,
-                                                   shuffle=split != "val", seed=seed)
+                                                   shuffle=split != "val", seed=ds.seed + seed, full_scale0=fs0)
             else:
                 dsc = DeviceScenes(ds.paths, ds.length, ds.voxel_scale, ds.seed + seed, self.args.batch_size, self.rank, self.world,
                                    self.device, augment=ds.augment, shuffle=split != "val",
-                                   full_scale0=self.cfg.DATA_CONFIG.DATA_PROCESSOR.get("full_scale", [128, 512])[0])
+                                   full_scale0=fs0)
                 self._loaders[split] = (dsc, dsc)
         return self._loaders[split]
 
