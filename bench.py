@@ -57,6 +57,8 @@ def parse():
     p.add_argument("--kernel-reps", type=int, default=50)
     p.add_argument("--fp32-steps", type=int, default=40,
                    help="timed steps of the fp32 sub-record (reference precision); 0 = skip")
+    p.add_argument("--refgraph-steps", dest="refgraph_steps", type=int, default=15,
+                   help="timed steps of the reference_graph sub-record (the zero-change route: doda_amd.refgraph; 0: skip)")
     p.add_argument("--no-train-entry", action="store_true",
                    help="skip the train_entry sub-record (python -m doda_amd.train on fresh batches, 1 rank and 2 gloo ranks on this GPU)")
     p.add_argument("--train-entry-scenes", type=int, default=640, help="scenes per run of the train_entry sub-record (4 per iteration)")
@@ -650,6 +652,39 @@ def main():
             reducer.close()      # (gradient homes are process-wide: the fp32 leg builds its own reducer)
         return dt, float(loss.detach()), net
 
+    def run_reference_graph(dtype_name, steps, warmup):
+        """The ZERO-CHANGE route: the module tree and glue a DODA checkout runs over the shims —
+        doda_amd.refgraph: plain SparseSequential, `output.features += identity.features`, torch.cat, features[p2v] + nn.Linear,
+        rulebooks built inside the convs' first use, nn.CrossEntropyLoss and torch.optim.SGD as tool/train.py builds them —
+        on the same batch, timed by the same clock.  Nothing of doda_amd.model's extensions (fused residual, one-call
+        residual blocks / coarse levels, fused loss, deferred weight gradients, prefetched rulebooks, one-launch SGD)."""
+        from doda_amd.refgraph import RefSparseConvNet, run_reference_route
+        Fsp.set_deferred_wgrad(False)
+        try:
+            torch.manual_seed(0)
+            rnet = RefSparseConvNet(cfg).to(dev).train()
+            ropt = torch.optim.SGD(rnet.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+            crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+            fdt = torch.float32 if dtype_name == "f32" else torch.bfloat16
+
+            def rstep():
+                ropt.zero_grad()
+                loss = crit(run_reference_route(cfg, rnet, batch_dev, dev, feature_dtype=fdt).float(), batch_dev["labels"])
+                loss.backward()
+                ropt.step()
+                return loss
+
+            for _ in range(warmup):
+                rstep()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = rstep()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, float(loss.detach())
+        finally:
+            Fsp.set_deferred_wgrad(deferred)
+
     elapsed, final_loss, net = run_training(args.dtype, args.steps, args.warmup)
     elapsed, (m_total, n_total) = ddist.reduce_step_stats(elapsed, [m_local, n_local], dev)
     # the reference computes in fp32 end to end (lib/pointgroup_ops/src/cuda.cu:11-13): the same step in
@@ -701,7 +736,18 @@ def main():
                                           "spconv is not vendored by the reference: orderings unpinned"},
             "roofline": roof,
         }
+        if world == 1 and args.refgraph_steps > 0:
+            er, lr_ = run_reference_graph(args.dtype, args.refgraph_steps, max(3, args.warmup // 3))
+            line["reference_graph"] = {
+                "ms_per_step": er / args.refgraph_steps * 1e3, "value": m_local * args.refgraph_steps / er, "unit": "voxels/s",
+                "steps": args.refgraph_steps, "final_loss": lr_, "vs_headline_step": (er / args.refgraph_steps) / (elapsed / args.steps),
+                "note": "doda_amd.refgraph: the reference's module tree and call pattern (model/unet.py:15-99, model/unet_block.py:9-100) "
+                        "over the drop-in spconv / pointgroup_ops surface, torch CrossEntropyLoss + torch.optim.SGD — what a DODA "
+                        "checkout runs with zero changes; the headline runs doda_amd.model.SparseConvNet (same parameters, same "
+                        "graph) with the fused residual, one-call blocks / coarse levels, deferred weight gradients, prefetched "
+                        "rulebooks, fused loss and one-launch SGD"}
         if fp32 is not None:
+            line["fp32_ms_per_step"] = fp32["ms_per_step"]      # (top level too: the driver's parser keeps flat keys)
             r32, _ = kernel_roofline(batch_dev, "f32", max(10, args.kernel_reps // 2), gate_scene)
             b32, _ = step_algorithmic_bytes(net, batch_dev, "f32")
             fp32["roofline"] = {"kernel": r32["kernel"], "achieved": r32["achieved"], "frac": r32["frac"],

@@ -106,3 +106,53 @@ def test_bf16_training_trajectory_tracks_fp32(native_lib, tmp_path):
     assert t["held_out"]["per_class_iou_max_abs_diff"] < t["fp32_other_seed"]["per_class_iou_max_abs_diff"], (t["held_out"], t["fp32_other_seed"])
     # and training did happen: the loss fell by a factor of five from its first epoch
     assert t["train_loss_curve"]["bf16"][-1] < 0.2 * t["train_loss_curve"]["bf16"][0]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_reference_call_pattern_equals_the_extended_model(native_lib, dtype):
+    """The zero-change route (doda_amd.refgraph: the reference's module tree and call pattern — plain SparseSequential, in-place
+    `output.features += identity.features`, torch.cat, features[p2v] + nn.Linear; model/unet.py:15-99, model/unet_block.py:9-100)
+    against doda_amd.model.SparseConvNet on the SAME state dict (the parameter names are the reference's in both): loss, per-point
+    scores and every parameter gradient.  fp32: 1e-4 / 1e-2; bf16: the two evaluation orders of a bf16 step."""
+    from doda_amd import model as M
+    from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
+    from doda_amd.refgraph import RefSparseConvNet, run_reference_route
+    from doda_amd.scene import make_batch
+    from doda_amd.spconv import functional as Fsp
+    from tests.util import deterministic_init
+    d = dev()
+    cfg = default_cfg()
+    b = make_batch(2, 60000, 41)
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in b.items()}
+    net = deterministic_init(SparseConvNet(cfg), seed=8).to(d).train()
+    ref = RefSparseConvNet(cfg).to(d).train()
+    assert list(ref.state_dict().keys()) == list(net.state_dict().keys())
+    ref.load_state_dict(net.state_dict())
+    Fsp.set_deferred_wgrad(False)
+    old = (M.COARSE_MODE, M.COARSE_EXEC_LEVEL)
+    M.set_coarse_mode("off")
+    try:
+        s0 = voxelize_and_run(cfg, net, bd, d, feature_dtype=dtype)
+        l0 = cross_entropy(s0, bd["labels"])
+        l0.backward()
+        s1 = run_reference_route(cfg, ref, bd, d, feature_dtype=dtype)
+        l1 = torch.nn.functional.cross_entropy(s1.float(), bd["labels"], ignore_index=255)
+        l1.backward()
+        torch.cuda.synchronize()
+    finally:
+        M.set_coarse_mode(*old)
+    rel = lambda a, c: float((a.double() - c.double()).norm() / c.double().norm().clamp(min=1e-30))
+    g0 = dict(net.named_parameters())
+    if dtype == torch.float32:
+        assert abs(float(l1) - float(l0)) < 1e-5 * abs(float(l0))
+        assert float((s1.float() - s0.float()).abs().max()) < 1e-4 * float(s0.float().abs().max())
+        for k, p in ref.named_parameters():
+            assert rel(p.grad, g0[k].grad) < 1e-2, (k, rel(p.grad, g0[k].grad))
+    else:
+        assert abs(float(l1) - float(l0)) < 2e-2 * abs(float(l0))
+        assert float((s1.float() - s0.float()).abs().max()) < 6e-2 * float(s0.float().abs().max())
+        worst = max(rel(p.grad, g0[k].grad) for k, p in ref.named_parameters())
+        assert worst < 1.0, worst      # (bf16: deep-level gradients of two evaluation orders sit 0.4-0.9 apart, DESIGN.md §5)
+    tol = (2e-3, 2e-4) if dtype == torch.float32 else (1e-1, 2e-2)   # (running statistics of bf16 activations: two rounding histories)
+    for (k, v), (_, v0) in zip(ref.named_buffers(), net.named_buffers()):
+        assert torch.allclose(v.float(), v0.float(), rtol=tol[0], atol=tol[1]), k
