@@ -57,6 +57,8 @@ def parse():
     p.add_argument("--kernel-reps", type=int, default=50)
     p.add_argument("--fp32-steps", type=int, default=40,
                    help="timed steps of the fp32 sub-record (reference precision); 0 = skip")
+    p.add_argument("--matrix-head", dest="matrix_head", action="store_true", default=False,
+                   help="the head as a [points, classes] score matrix + cross-entropy (round 5) instead of the voxel-level fused head + loss")
     p.add_argument("--refgraph-steps", dest="refgraph_steps", type=int, default=15,
                    help="timed steps of the reference_graph sub-record (the zero-change route: doda_amd.refgraph; 0: skip)")
     p.add_argument("--no-train-entry", action="store_true",
@@ -616,9 +618,14 @@ def main():
             if prefetch is not None:
                 pyramid = PyramidPrefetcher.take(pending[0], dev)
                 pending[0] = prefetch.submit(batch_dev, with_pairs, with_tiles, resident=True)
-            scores = voxelize_and_run(cfg, model, batch_dev, dev, feature_dtype=fdt, inputs_ready=True,
-                                      pyramid=pyramid)
-            loss = cross_entropy(scores, labels, ignore_index=255)
+            # head + CrossEntropyLoss at voxel level (reference model/unet.py:62-64,107-108,196; csrc/head.hip): same loss and
+            # gradients, no [points, classes] score matrix (--matrix-head: the round-5 form, scores then cross_entropy)
+            if args.matrix_head:
+                scores = voxelize_and_run(cfg, model, batch_dev, dev, feature_dtype=fdt, inputs_ready=True, pyramid=pyramid)
+                loss = cross_entropy(scores, labels, ignore_index=255)
+            else:
+                loss = voxelize_and_run(cfg, model, batch_dev, dev, feature_dtype=fdt, inputs_ready=True, pyramid=pyramid,
+                                        labels=labels, ignore_index=255)
             loss.backward()
             if reducer is not None:
                 reducer.reduce()
@@ -724,6 +731,8 @@ def main():
                                       + (" [chosen from the batch's tile overflow]" if args.voxel_order == "auto" else ""),
                        "host_pinning": ("NUMA node %d (%d CPUs)" % (pinned["node"], pinned["cpus"])) if pinned else "none",
                        "host_priority": prio or "unchanged",
+                       "head": ("[points, classes] score matrix + fused cross-entropy" if args.matrix_head else
+                                "Linear head + CrossEntropyLoss at voxel level (csrc/head.hip): no score matrix; same loss and gradients"),
                        "grad_sync": "deferred multi-layer wgrad + bucketed all-reduce" if deferred else "torch DDP",
                        "collectives": ("none (single process)" if not dist.is_initialized() else
                                        "%s (forced, 1 rank)" % dist.get_backend() if world == 1 else

@@ -94,6 +94,12 @@ _SIGNATURES = {
     "doda_ballquery_batch_p": (c_i32, [c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                        C.POINTER(c_i32), c_vp, c_sz, c_vp]),
     "doda_layers_run": (c_i32, [c_vp, c_i32, c_i32, C.POINTER(c_i32), c_vp]),
+    "doda_head_ce_blocks": (c_i32, [c_i32]),
+    "doda_head_dw_blocks": (c_i32, [c_i32]),
+    "doda_head_dw_bf16": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
+    "doda_head_ce_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, C.c_int64, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "doda_head_ce_bwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, C.c_int64, c_vp, c_vp, c_vp, c_vp,
+                                 c_vp, c_i32, c_vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -555,6 +555,35 @@ class _FusedCE(Function):
         return _ops.cross_entropy_bwd(scores, labels, lse, out, g, ctx.ignore_index), None, None
 
 
+class _VoxelHeadCE(Function):
+    """loss = CrossEntropyLoss(ignore_index)(Linear(feats[p2v]), labels) (reference model/unet.py:62-64,107-108,196) computed at
+    VOXEL level: every point of a voxel reads the same feature row, so the [points, classes] score matrix — written and re-read
+    five times by the matrix path, ~210 us of the bench step — never exists (csrc/head.hip).  Second output: the per-voxel
+    argmax class (the meters' prediction: pred_point = pred_voxel[p2v])."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, bias, v2p, labels, ignore_index):
+        out, pred = _ops.head_ce_fwd(feats, weight, bias, v2p, labels, ignore_index)
+        ctx.save_for_backward(feats, weight, bias, v2p, labels, out)
+        ctx.ignore_index = ignore_index
+        ctx.mark_non_differentiable(pred)
+        return out[0], pred
+
+    @staticmethod
+    def backward(ctx, grad, _grad_pred):
+        feats, weight, bias, v2p, labels, out = ctx.saved_tensors
+        g = grad.reshape(1).to(torch.float32)
+        d_feats, dz, d_b = _ops.head_ce_bwd(feats, weight, bias, v2p, labels, ctx.ignore_index, out, g)
+        d_w = None
+        if ctx.needs_input_grad[1]:   # dW = dz^T feats (voxels as the MFMA k dimension: doda_head_dw_bf16; fp32: identity-table wgrad)
+            d_w = _ops.head_dw(feats, dz).to(weight.dtype)
+        return (d_feats if ctx.needs_input_grad[0] else None), d_w, (d_b if bias is not None and ctx.needs_input_grad[2] else None), \
+            None, None, None
+
+
+FUSED_HEAD_LOSS = _os.environ.get("DODA_FUSED_HEAD_LOSS", "1") == "1"
+
+
 def cross_entropy(scores, labels, ignore_index=255):
     """nn.CrossEntropyLoss(ignore_index) (reference model/unet.py:108,196).  Device fp32 logits with at
     most 64 classes go through the fused native pair (doda_cross_entropy_fwd/_bwd: 3 launches instead
@@ -589,7 +618,21 @@ class SparseConvNet(nn.Module):
                 mod.weight.data.fill_(1.0)
                 mod.bias.data.fill_(0.0)
 
-    def forward(self, input, input_map, return_mid_feat=False, v2p_map=None, v2p_map_t=None):
+    def head_loss(self, feats, v2p_map, labels, ignore_index=255):
+        """Linear head + CrossEntropyLoss on the voxel features without the point-level score matrix (_VoxelHeadCE), or None
+        when that form does not apply (then: scores = forward(...), cross_entropy(scores, labels)).  Sets self.voxel_pred."""
+        if not (FUSED_HEAD_LOSS and feats.is_cuda and feats.dim() == 2 and feats.shape[1] == 16 and feats.shape[0] > 0
+                and feats.dtype in (torch.float32, torch.bfloat16) and self.linear.out_features <= 32
+                and self.linear.weight.dtype == torch.float32 and v2p_map is not None and v2p_map.is_cuda
+                and v2p_map.dtype == torch.int32 and v2p_map.dim() == 2 and v2p_map.shape[0] == feats.shape[0]
+                and labels.is_cuda and labels.dtype == torch.int64
+                and not (self.linear._forward_hooks or self.linear._forward_pre_hooks or self.linear._backward_hooks)):
+            return None
+        loss, pred = _VoxelHeadCE.apply(feats, self.linear.weight, self.linear.bias, v2p_map, labels, int(ignore_index))
+        self.voxel_pred = pred
+        return loss
+
+    def forward(self, input, input_map, return_mid_feat=False, v2p_map=None, v2p_map_t=None, labels=None, ignore_index=255):
         if input.features.is_cuda and input.indices.shape[0] > 0:
             # all 13 rulebooks up front (+ their pair lists when a bf16 backward pass will follow)
             spconv.ops.build_pyramid(input, len(self.unet.nPlanes), with_pairs=(
@@ -598,15 +641,28 @@ class SparseConvNet(nn.Module):
                 with_tiles=tile_levels_for(input.features.dtype))   # tilebooks serve inference as well
         out = self.output_layer(self.unet(self.input_conv(input)))
         feats = out.features
+        if labels is not None and not return_mid_feat:      # the caller wants the loss: head + loss at voxel level
+            loss = self.head_loss(feats, v2p_map, labels, ignore_index)
+            if loss is not None:
+                return loss
         fused = (v2p_map is not None and not return_mid_feat and feats.is_cuda
                  and input_map.dtype == torch.int32 and 0 < v2p_map.shape[1] - 1 <= 27
                  and feats.shape[1] % 4 == 0 and self.linear.out_features % 4 == 0)
         if fused:  # voxel->point gather + Linear as one gather-GEMM over the p2v table
             v2p_t = v2p_map_t if (v2p_map_t is not None and v2p_map_t.shape == (v2p_map.shape[1] - 1, v2p_map.shape[0])
                                   and v2p_map_t.is_contiguous()) else v2p_map[:, 1:].t().contiguous()
-            return _PointLinear.apply(feats, self.linear.weight, self.linear.bias, input_map, v2p_t)
+            scores = _PointLinear.apply(feats, self.linear.weight, self.linear.bias, input_map, v2p_t)
+            if labels is not None:
+                self.voxel_pred = None
+                self.point_scores = scores
+                return cross_entropy(scores, labels, ignore_index)
+            return scores
         point_feats = feats[input_map.long()]  # voxel -> point
         scores = self.linear(point_feats.to(self.linear.weight.dtype))
+        if labels is not None and not return_mid_feat:
+            self.voxel_pred = None
+            self.point_scores = scores
+            return cross_entropy(scores, labels, ignore_index)
         return (point_feats, scores) if return_mid_feat else scores
 
 
@@ -794,9 +850,22 @@ def _input_rows(net, feats, xyz, v2p, mode, feature_dtype):
     return rows
 
 
+def point_predictions(model, p2v):
+    """argmax class per POINT after a `labels=` call of voxelize_and_run: the per-voxel argmax of the fused head gathered through
+    p2v, or the argmax of the score matrix when the matrix path ran."""
+    net = model.module if hasattr(model, "module") else model
+    vp = getattr(net, "voxel_pred", None)
+    if vp is not None:
+        return vp[p2v.long()].long()
+    return net.point_scores.detach().argmax(1)
+
+
 def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fused_head=True,
-                     inputs_ready=False, pyramid=None):
+                     inputs_ready=False, pyramid=None, labels=None, ignore_index=255):
     """reference model/unet.py:72-99 (test_model_feat): H2D, voxel mean-pooling, network.
+    labels: return the training LOSS instead of the per-point scores (reference model/unet.py:107-108,196: CrossEntropyLoss on the
+    head's scores) — computed at voxel level without the score matrix when the head allows it; point_predictions() afterwards
+    gives the argmax per point for the meters.
     inputs_ready: the batch is resident on `device` with no copy or kernel still producing it, so the
     rulebooks may be built on a side stream ahead of the main stream's queue (_prebuild_pyramid).
     pyramid: (indices int32, indice_dict) of this batch from PyramidPrefetcher.take."""
@@ -830,5 +899,10 @@ def voxelize_and_run(cfg, model, batch, device, feature_dtype=torch.float32, fus
                                       batch["spatial_shape"], batch_size)
     if fused_head:
         v2p_t = batch.get("v2p_map_t")
+        if labels is not None:   # -> the LOSS (head + CrossEntropyLoss at voxel level when the fused form applies)
+            return model(inp, p2v, v2p_map=v2p, v2p_map_t=v2p_t.to(device, non_blocking=True) if v2p_t is not None else None,
+                         labels=labels, ignore_index=ignore_index)
         return model(inp, p2v, v2p_map=v2p, v2p_map_t=v2p_t.to(device, non_blocking=True) if v2p_t is not None else None)
+    if labels is not None:
+        return cross_entropy(model(inp, p2v), labels, ignore_index)
     return model(inp, p2v)

@@ -838,6 +838,56 @@ def cross_entropy_bwd(logits, labels, lse, out, grad, ignore_index):
     return d
 
 
+# ---- point head + loss at voxel level (ABI 11, csrc/head.hip) -----------------------------------------------------
+def head_ce_fwd(feats, weight, bias, v2p, labels, ignore_index, want_pred=True):
+    """Linear head + cross-entropy over the voxel -> point lists without the [points, classes] matrix (doda_head_ce_fwd).
+    -> (out float32 [2] = {mean loss over the valid points, n_valid}, pred int32 [m] = argmax class per voxel or None)."""
+    _feat_ok(feats, "feats")
+    for t in (weight, v2p, labels):
+        _need_cuda(t)
+    if weight.dtype != torch.float32 or v2p.dtype != torch.int32 or labels.dtype != torch.int64 or v2p.dim() != 2:
+        raise RuntimeError("head_ce: weight float32 [n_cls, c], v2p int32 [m, 1 + max_active], labels int64 [points]")
+    feats, weight, v2p, labels = feats.contiguous(), weight.contiguous(), v2p.contiguous(), labels.contiguous()
+    m, c = feats.shape
+    nb = int(lib().doda_head_ce_blocks(m))
+    out = torch.empty(2, dtype=torch.float32, device=feats.device)
+    pred = torch.empty(m, dtype=torch.int32, device=feats.device) if want_pred else None
+    ws = torch.empty(2 * nb, dtype=torch.float32, device=feats.device)
+    check(lib().doda_head_ce_fwd(_p(feats), m, c, feats.element_size(), _p(weight), _p(bias.contiguous()) if bias is not None else None,
+                                 weight.shape[0], _p(v2p), v2p.shape[1], _p(labels), int(ignore_index), _p(out),
+                                 _p(pred) if pred is not None else None, _p(ws), nb, _stream()), "doda_head_ce_fwd")
+    return out, pred
+
+
+def head_ce_bwd(feats, weight, bias, v2p, labels, ignore_index, out, grad):
+    """-> (d_feats [m, c], dz [m, n_cls] — both in the features' dtype —, d_bias float32 [n_cls])."""
+    feats, weight, v2p, labels = feats.contiguous(), weight.contiguous(), v2p.contiguous(), labels.contiguous()
+    m, c = feats.shape
+    n_cls = weight.shape[0]
+    nb = int(lib().doda_head_ce_blocks(m))
+    d_feats = torch.empty_like(feats)
+    dz = torch.empty((m, n_cls), dtype=feats.dtype, device=feats.device)
+    dbp = torch.empty((nb, n_cls), dtype=torch.float32, device=feats.device)
+    check(lib().doda_head_ce_bwd(_p(feats), m, c, feats.element_size(), _p(weight), _p(bias.contiguous()) if bias is not None else None,
+                                 n_cls, _p(v2p), v2p.shape[1], _p(labels), int(ignore_index), _p(out), _p(grad.contiguous()),
+                                 _p(d_feats), _p(dz), _p(dbp), nb, _stream()), "doda_head_ce_bwd")
+    return d_feats, dz, dbp.sum(0)
+
+
+def head_dw(feats, dz):
+    """d weight [n_cls, c] of the voxel-level head from feats [m, c] and dz [m, n_cls]: the bf16 MFMA kernel (doda_head_dw_bf16) or,
+    fp32, the library's weight gradient over an identity table."""
+    m, c = feats.shape
+    n_cls = dz.shape[1]
+    if feats.dtype == torch.bfloat16 and c == 16 and n_cls <= 32:
+        nb = int(lib().doda_head_dw_blocks(m))
+        part = torch.empty((nb, 32, 16), dtype=torch.float32, device=feats.device)
+        check(lib().doda_head_dw_bf16(_p(feats.contiguous()), _p(dz.contiguous()), m, c, n_cls, _p(part), nb, _stream()), "doda_head_dw_bf16")
+        return part.sum(0)[:n_cls]
+    ident = torch.arange(m, dtype=torch.int32, device=feats.device).view(1, m)
+    return spconv_wgrad(feats.contiguous(), dz, ident, m)[0].t()
+
+
 # ---- optimizer step -------------------------------------------------------------------------------
 class _SgdTensor(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("buf", C.c_void_p), ("n", C.c_int64),

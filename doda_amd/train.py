@@ -315,15 +315,15 @@ class Trainer:
     # one forward + backward of one batch; `domain`: None | "source" | "target" (DSNorm statistics)
     def _pass(self, batch, pyramid, domain, weight=1.0):
         from .dsnorm import set_ds_source, set_ds_target
-        from .model import cross_entropy, voxelize_and_run
+        from .model import point_predictions, voxelize_and_run
         if self.cfg.MODEL.get("dsnorm", False) and domain is not None:
             self.model.apply(set_ds_source if domain == "source" else set_ds_target)
-        scores = voxelize_and_run(self.cfg, self.model, batch, self.device, feature_dtype=self.fdt,
-                                  inputs_ready=True, pyramid=pyramid)
         labels = batch["labels"]
-        loss = cross_entropy(scores, labels, ignore_index=self.cfg.DATA_CONFIG.DATA_CLASS.ignore_label)
+        # head + CrossEntropyLoss at voxel level (no [points, classes] matrix); the meters' prediction = the voxel's argmax
+        loss = voxelize_and_run(self.cfg, self.model, batch, self.device, feature_dtype=self.fdt, inputs_ready=True, pyramid=pyramid,
+                                labels=labels, ignore_index=self.cfg.DATA_CONFIG.DATA_CLASS.ignore_label)
         (loss * weight if weight != 1.0 else loss).backward()
-        return loss, scores.detach().argmax(1), labels
+        return loss, point_predictions(self.model, batch["p2v_map"]), labels
 
     def _loader(self, split):
         """(iterable of host / device batches, object with set_epoch) per split, made once: the dataset resident in HBM

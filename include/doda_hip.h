@@ -528,6 +528,32 @@ int doda_cross_entropy_bwd(const float *logits, const int64_t *labels, const flo
                            const float *grad, int32_t n, int32_t c, int64_t ignore_index, float *dlogits,
                            doda_stream_t stream);
 
+/* ABI 11.  The point head and its loss without the point-level score matrix (csrc/head.hip) — reference model/unet.py:62-64
+ * (feats_pt = out.features[p2v]; scores = Linear(feats_pt)) + :107-108,196 (CrossEntropyLoss(ignore_index)).  Every point of a
+ * voxel reads the same feature row, so its logits are its voxel's: loss = (1 / n_valid) sum_v [cnt_v lse(z_v) - sum_{p in v} z_v[y_p]],
+ * z_v = W f_v + b — two sweeps over the VOXEL rows and their point lists instead of five over a [points, classes] fp32 matrix.
+ *   feats [m, c] bf16 / fp32 (c == 16), weight fp32 [n_cls, c] (rounded to bf16 for bf16 features, as the gather-GEMM's pre-pack
+ *   does), bias fp32 [n_cls] or NULL, v2p int32 [m, v2p_ld] = (count, point ids ...) per voxel (doda_voxelize_idx's output_map:
+ *   every point in exactly one row), labels int64 [points].
+ *   fwd: out float [2] = {mean loss over the valid points, n_valid}; pred int32 [m] = argmax class per voxel (or NULL);
+ *        partial_ws: float [2 * doda_head_ce_blocks(m)] scratch.
+ *   bwd: d_feats [m, c] and dz [m, n_cls] in the features' storage type (dz = d loss / d z_v summed over the voxel's points: the
+ *        operand of the weight gradient dW = dz^T feats through doda_spconv_wgrad_multi over an identity table);
+ *        db_partial float [doda_head_ce_blocks(m)][n_cls]: the caller adds the rows (fixed order) for d bias.  grad float [1]. */
+/*   doda_head_dw_bf16: the weight gradient of that head from bf16 feats [m, 16] and dz [m, n_cls] (voxels as the MFMA k dimension):
+ *        partial float [doda_head_dw_blocks(m)][32][16] — rows = classes (zero past n_cls), the caller adds the blocks (fixed order);
+ *        fp32 features take doda_spconv_wgrad_multi over an identity table instead. */
+int32_t doda_head_dw_blocks(int32_t m);
+int doda_head_dw_bf16(const void *feats, const void *dz, int32_t m, int32_t c, int32_t n_cls, float *partial, int32_t n_blocks,
+                      doda_stream_t stream);
+int32_t doda_head_ce_blocks(int32_t m);
+int doda_head_ce_fwd(const void *feats, int32_t m, int32_t c, int32_t elem_bytes, const float *weight, const float *bias,
+                     int32_t n_cls, const int32_t *v2p, int32_t v2p_ld, const int64_t *labels, int64_t ignore_index, float *out,
+                     int32_t *pred, float *partial_ws, int32_t n_blocks, doda_stream_t stream);
+int doda_head_ce_bwd(const void *feats, int32_t m, int32_t c, int32_t elem_bytes, const float *weight, const float *bias,
+                     int32_t n_cls, const int32_t *v2p, int32_t v2p_ld, const int64_t *labels, int64_t ignore_index, const float *out,
+                     const float *grad, void *d_feats, void *dz, float *db_partial, int32_t n_blocks, doda_stream_t stream);
+
 /* ABI 6.  Glue of the head and the input layer (csrc/glue.hip).
  * doda_cast_colsum_f32_bf16: y = bf16(x) (round to nearest even, as torch's cast) and partial[b][c] = sum of the rows
  *   workgroup b swept — the Linear head's backward (reference model/unet.py:64) needs the score gradient as a bf16 GEMM

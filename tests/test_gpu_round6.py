@@ -156,3 +156,76 @@ def test_reference_call_pattern_equals_the_extended_model(native_lib, dtype):
     tol = (2e-3, 2e-4) if dtype == torch.float32 else (1e-1, 2e-2)   # (running statistics of bf16 activations: two rounding histories)
     for (k, v), (_, v0) in zip(ref.named_buffers(), net.named_buffers()):
         assert torch.allclose(v.float(), v0.float(), rtol=tol[0], atol=tol[1]), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_voxel_level_head_and_loss_equals_the_score_matrix_path(native_lib, dtype):
+    """doda_head_ce_fwd / _bwd (reference model/unet.py:62-64,107-108,196 without the [points, classes] matrix) against torch on the
+    definition — Linear on the gathered rows, F.cross_entropy with ignore_index, autograd — and against the matrix path of the
+    model (_PointLinear + fused cross-entropy): loss, d feats, dW, db, the per-point predictions; ignored and out-of-voxel-order
+    labels included."""
+    import torch.nn.functional as F
+    from doda_amd import ops
+    from doda_amd.model import _VoxelHeadCE
+    from doda_amd.scene import make_batch
+    d = dev()
+    b = make_batch(2, 60000, 51)
+    v2p, p2v = b["v2p_map"].to(d), b["p2v_map"].to(d)
+    labels = b["labels"].to(d).clone()
+    g = torch.Generator().manual_seed(9)
+    labels[torch.randperm(labels.numel(), generator=g)[:5000].to(d)] = 255              # ignored points
+    m = v2p.shape[0]
+    feats = (torch.randn(m, 16, generator=g) * 1.5).to(d).to(dtype).requires_grad_(True)
+    W = (torch.randn(20, 16, generator=g) * 0.4).to(d).requires_grad_(True)
+    bias = (torch.randn(20, generator=g) * 0.2).to(d).requires_grad_(True)
+    loss, pred = _VoxelHeadCE.apply(feats, W, bias, v2p, labels, 255)
+    loss.backward()
+    got = (loss.detach().clone(), feats.grad.clone(), W.grad.clone(), bias.grad.clone())
+    # definition in fp64 on the same (rounded) operands; bf16: the weights rounded as the kernels round them
+    fd = feats.detach().double().requires_grad_(True)
+    Wd = (W.detach().to(dtype).double() if dtype == torch.bfloat16 else W.detach().double()).requires_grad_(True)
+    bd_ = bias.detach().double().requires_grad_(True)
+    scores = fd[p2v.long()] @ Wd.t() + bd_
+    ref = F.cross_entropy(scores, labels, ignore_index=255)
+    ref.backward()
+    assert abs(float(got[0]) - float(ref)) < 1e-5 * abs(float(ref))
+    tol = 1e-4 if dtype == torch.float32 else 2.0 ** -7
+    rel = lambda a, c: float((a.double() - c).abs().max() / c.abs().max())
+    assert rel(got[1], fd.grad) < tol, rel(got[1], fd.grad)
+    assert rel(got[3], bd_.grad) < 1e-4
+    assert rel(got[2], Wd.grad) < (1e-4 if dtype == torch.float32 else 3e-3), rel(got[2], Wd.grad)   # (bf16: dz rounded for the weight-gradient GEMM)
+    assert float((pred[p2v.long()].long() != scores.detach().argmax(1)).float().mean()) < 1e-4           # (ties at fp32 rounding)
+    # an all-ignored batch: zero loss, zero gradients, no NaN
+    feats2 = feats.detach().clone().requires_grad_(True)
+    l0, _ = _VoxelHeadCE.apply(feats2, W, bias, v2p, torch.full_like(labels, 255), 255)
+    l0.backward()
+    assert float(l0) == 0.0 and float(feats2.grad.abs().max()) == 0.0
+
+
+def test_training_step_with_voxel_level_head_equals_matrix_head(native_lib):
+    """The whole step with `labels=` (head + loss at voxel level) against scores + cross_entropy: loss and every gradient, fp32."""
+    from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, point_predictions, voxelize_and_run
+    from doda_amd.scene import make_batch
+    from tests.util import deterministic_init
+    d = dev()
+    cfg = default_cfg()
+    b = make_batch(2, 40000, 61)
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in b.items()}
+    out = []
+    for fused in (True, False):
+        net = deterministic_init(SparseConvNet(cfg), seed=5).to(d).train()
+        if fused:
+            loss = voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.float32, labels=bd["labels"])
+            preds = point_predictions(net, bd["p2v_map"])
+        else:
+            scores = voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.float32)
+            loss = cross_entropy(scores, bd["labels"])
+            preds = scores.detach().argmax(1)
+        loss.backward()
+        torch.cuda.synchronize()
+        out.append((float(loss), preds, {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+    (l1, p1, g1), (l0, p0, g0) = out
+    assert abs(l1 - l0) < 1e-5 * abs(l0)
+    assert float((p1 != p0).float().mean()) < 1e-4
+    for k in g0:
+        assert float((g1[k] - g0[k]).norm()) <= 2e-3 * float(g0[k].norm()) + 1e-9, k

@@ -18,6 +18,7 @@ ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--modes", default="off,layers")
 ap.add_argument("--level", type=int, default=4)
+ap.add_argument("--heads", default="fused", help="comma list of head forms to alternate: fused (voxel-level head + loss), matrix")
 args = ap.parse_args()
 
 from doda_amd import model as M
@@ -42,12 +43,18 @@ pre = PyramidPrefetcher(dev, len(net.unet.nPlanes))
 with_pairs = Fsp.WGRAD_PAIRS and dtype == torch.bfloat16
 
 
+HEAD = ["fused"]
+
+
 def step(fut):
     pyr = PyramidPrefetcher.take(fut, dev)
     nxt = pre.submit(bd, with_pairs=with_pairs, with_tiles=tile_levels_for(dtype), resident=True)
     opt.zero_grad(set_to_none=True)
-    scores = voxelize_and_run(cfg, net, bd, dev, feature_dtype=dtype, pyramid=pyr)
-    loss = cross_entropy(scores, bd["labels"])
+    if HEAD[0] == "fused":
+        loss = voxelize_and_run(cfg, net, bd, dev, feature_dtype=dtype, pyramid=pyr, labels=bd["labels"])
+    else:
+        scores = voxelize_and_run(cfg, net, bd, dev, feature_dtype=dtype, pyramid=pyr)
+        loss = cross_entropy(scores, bd["labels"])
     loss.backward()
     opt.step()
     return nxt, loss
@@ -61,15 +68,18 @@ for m in modes:          # warm-up of every mode
         fut, loss = step(fut)
 torch.cuda.synchronize()
 for r in range(args.rounds):
+  for head in args.heads.split(","):
+    HEAD[0] = head
     for m in modes:
         M.set_coarse_mode(m, args.level)
-        fut, loss = step(fut)
+        for _ in range(3):
+            fut, loss = step(fut)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             fut, loss = step(fut)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps * 1e3
-        print("round %d mode %-7s level %d: %.3f ms/step  loss %.5f  launches (fwd, bwd) of the op lists: %s" %
-              (r, m, args.level, dt, float(loss), ext.coarse_launches() if m == "layers" else "-"), flush=True)
+        print("round %d mode %-7s head %-6s level %d: %.3f ms/step  loss %.5f  launches (fwd, bwd) of the op lists: %s" %
+              (r, m, head, args.level, dt, float(loss), ext.coarse_launches() if m == "layers" else "-"), flush=True)
 pre.shutdown()
