@@ -105,7 +105,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 OPT_TILE_KERNEL, OPT_WLDS_KERNEL, OPT_WDMA_KERNEL, OPT_TILE_PIPELINE, OPT_TILE_DUAL, OPT_CONV_UP = 1, 2, 3, 4, 5, 6   # doda_set_option / doda_get_option
 OPT_PRE_FWD_ROWS, OPT_PRE_BWD_ROWS = 7, 8   # (row thresholds of doda_layers_run's BatchNorm folding)
-ABI_VERSION = 11  # include/doda_hip.h DODA_ABI_VERSION
+ABI_VERSION = 12  # include/doda_hip.h DODA_ABI_VERSION
 
 _lib = None
 

@@ -36,22 +36,35 @@ __global__ __launch_bounds__(256) void lay_bn(const void *__restrict__ x_, unsig
     const PreRaw raw = pre_request<KIND>(pre, c);
     pre_finish<ESZ, KIND>(pre, c, raw, co);
     doda_sync();
-    constexpr int NV = 16 / ESZ;
-    const int ppr = c / NV;
-    const long long n_pieces = (long long)pre.rows * ppr;
+    // a thread keeps ONE 16-byte column piece for the whole sweep (the block uses the largest multiple of the pieces per row among
+    // its 256 threads): the per-channel coefficients are read from LDS once, no division per piece, four rows in flight per thread
+    constexpr int NV = 16 / ESZ, U = 4;
+    const int ppr = c / NV, rpb = 256 / ppr;
+    const int tr = (int)threadIdx.x / ppr, c0 = ((int)threadIdx.x - tr * ppr) * NV;
+    if (tr >= rpb) return;
+    PreCo<ESZ, KIND> cv;
+    pre_load_co<ESZ, KIND>(co, c0, cv);
     const elem *x = (const elem *)x_;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n_pieces; e += (long long)gridDim.x * 256) {
-        const long long r = e / ppr;
-        const int c0 = (int)(e - r * ppr) * NV;
-        const u32x4 xv = *reinterpret_cast<const u32x4 *>(x + r * x_ld + c0);
-        u32x4 uv = xv, av = xv;
-        if constexpr (KIND >= 2) uv = *reinterpret_cast<const u32x4 *>((const elem *)pre.aux + r * pre.aux_ld + c0);
-        if constexpr (KIND >= 3) av = *reinterpret_cast<const u32x4 *>((const elem *)pre.add + r * pre.add_ld + c0);
-        PreCo<ESZ, KIND> cv;
-        pre_load_co<ESZ, KIND>(co, c0, cv);
-        const u32x4 o = pre_piece<ESZ, KIND>(xv, uv, av, cv, pre.relu, ~0u);
-        if (c0 < c_split) *reinterpret_cast<u32x4 *>((elem *)y_ + r * y_ld + c0) = o;
-        else *reinterpret_cast<u32x4 *>((elem *)y2_ + r * y2_ld + (c0 - c_split)) = o;
+    const bool left = c0 < c_split;
+    elem *const yo = left ? (elem *)y_ + c0 : (elem *)y2_ + (c0 - c_split);
+    const size_t yl = left ? y_ld : y2_ld;
+    const long long rows = pre.rows, step = (long long)gridDim.x * rpb;
+    for (long long r0 = (long long)blockIdx.x * rpb + tr; r0 < rows; r0 += step * U) {
+        u32x4 xv[U], uv[U], av[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const long long r = r0 + k * step < rows ? r0 + k * step : r0;   // (past the end: the first row again, not stored)
+            xv[k] = *reinterpret_cast<const u32x4 *>(x + r * x_ld + c0);
+            uv[k] = av[k] = xv[k];
+            if constexpr (KIND >= 2) uv[k] = *reinterpret_cast<const u32x4 *>((const elem *)pre.aux + r * pre.aux_ld + c0);
+            if constexpr (KIND >= 3) av[k] = *reinterpret_cast<const u32x4 *>((const elem *)pre.add + r * pre.add_ld + c0);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const long long r = r0 + k * step;
+            const u32x4 o = pre_piece<ESZ, KIND>(xv[k], uv[k], av[k], cv, pre.relu, ~0u);
+            if (r < rows) *reinterpret_cast<u32x4 *>(yo + r * yl) = o;
+        }
     }
 }
 
@@ -141,9 +154,10 @@ bool pre_of(const doda_cx_op &o, int esz, PreArgs *p) {
 template <int KIND>
 int launch_bn(const doda_cx_op &o, int esz, const PreArgs &p, hipStream_t s) {
     const int c = o.c_in;
-    const long long pieces = (long long)o.rows * (c / (16 / esz));
-    long long grid = (pieces + 255) / 256;
-    if (grid > 2048) grid = 2048;
+    const int ppr = c / (16 / esz), rpb = 256 / ppr;            // (c <= PRE_MAX_C = 256: ppr <= 64)
+    long long grid = ((long long)o.rows + rpb - 1) / rpb;       // one row per thread, then four
+    static const long long cap = env_ll("DODA_LAY_BN_GRID", 2048);
+    if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     const int split = (o.kind == DODA_CX_BNBWD && o.c_split > 0 && o.c_split < c) ? o.c_split : c;
     if (esz == 2)
@@ -155,6 +169,12 @@ int launch_bn(const doda_cx_op &o, int esz, const PreArgs &p, hipStream_t s) {
     return doda_check_launch();
 }
 
+// rows from which a dense BatchNorm op takes the register-resident sweeps of bn.hip instead of lay_bn
+inline long long tuned_rows(int esz) {
+    static const long long bf = env_ll("DODA_LAY_TUNED_ROWS", 32768);
+    return esz == 4 ? 4096 : bf;
+}
+
 int run_bn(const doda_cx_op &o, int esz, hipStream_t s) {
     PreArgs p;
     if (!pre_of(o, esz, &p)) return DODA_ERR_INVALID;
@@ -164,7 +184,8 @@ int run_bn(const doda_cx_op &o, int esz, hipStream_t s) {
         if (o.y_ld < o.c_in || o.x_ld < o.c_in) return DODA_ERR_INVALID;
         // dense training-mode sweeps of many rows take the tuned kernels of bn.hip (registers hold the channel vectors)
         // (fp32 only: the bf16 sweeps of this backend use the fused-multiply-add form whether folded or not, see pre_piece)
-        if (esz == 4 && (o.flags & DODA_CX_F_TRAINING) && o.x_ld == o.c_in && o.y_ld == o.c_in && o.rows >= 4096)
+        // (ABI 12, bf16: above the rows any fold limit reaches — the finest levels, where the sweep is an HBM-bound kernel)
+        if ((o.flags & DODA_CX_F_TRAINING) && o.x_ld == o.c_in && o.y_ld == o.c_in && o.rows >= tuned_rows(esz))
             return doda_bn_relu_fwd_totals(o.x, o.rows, o.c_in, esz, p.tot.ta, p.tot.tb, p.tot.ca, o.eps, o.momentum, o.gamma, o.beta,
                                            o.running_mean, o.running_var, o.nbt, p.relu, o.y, o.mean, o.invstd, (doda_stream_t)s);
         return launch_bn<1>(o, esz, p, s);
@@ -173,7 +194,7 @@ int run_bn(const doda_cx_op &o, int esz, hipStream_t s) {
     if (split % va || (split < o.c_in && (!o.y2 || o.y2_ld % va || !al16(o.y2))) || o.aux_ld % va || !al16(o.aux) ||
         (o.res && (o.res_ld % va || !al16(o.res))))
         return DODA_ERR_UNSUPPORTED;
-    if (esz == 4 && split == o.c_in && o.x_ld == o.c_in && o.y_ld == o.c_in && o.aux_ld == o.c_in && !(o.flags & DODA_CX_F_ACCUM) && o.rows >= 4096)
+    if (split == o.c_in && o.x_ld == o.c_in && o.y_ld == o.c_in && o.aux_ld == o.c_in && !(o.flags & DODA_CX_F_ACCUM) && o.rows >= tuned_rows(esz))
         return doda_bn_relu_bwd_totals(o.aux, o.x, o.rows, o.c_in, esz, p.tot.ta, o.mean, o.invstd, o.gamma, o.beta, p.relu, o.res,
                                        o.res ? o.res_ld : 0, o.y, o.dgamma, o.dbeta, (doda_stream_t)s);
     return p.kind == 3 ? launch_bn<3>(o, esz, p, s) : launch_bn<2>(o, esz, p, s);
@@ -201,6 +222,8 @@ int run_gemm(const doda_cx_op &o, int esz, const doda_cx_op *bn, hipStream_t s) 
     ep.residual_ld = o.res ? o.res_ld : 0;
     ep.x_ld = o.x_ld;
     ep.y_ld = o.y_ld;
+    ep.tilebook = o.tilebook;
+    ep.tilebook_rows = o.tilebook ? o.rows : 0;
     if (o.stats) {
         ep.stats = (float *)o.stats;             // (non-NULL selects the statistics epilogue; the sums go to the totals)
         ep.stats_totals = (double *)o.stats;

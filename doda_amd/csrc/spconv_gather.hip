@@ -1092,8 +1092,10 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     const size_t va = 4 * sizeof(elem);  // vector access granule
     const int vec_ok = (kc % 4 == 0) && (nc % 4 == 0) && ((uintptr_t)x % va == 0) &&
                        ((uintptr_t)y % va == 0);
-    // ABI 11: row strides (column slices of wider matrices) and the folded BatchNorm exist in conv_fast only
-    const bool strided = ep.x_ld || ep.y_ld || ep.res_ld || ep.bnx_ld;
+    // ABI 11: row strides (column slices of wider matrices) and the folded BatchNorm in conv_fast; ABI 12: the LDS-staged kernels
+    // (conv_tile*, conv_up32, conv_wlds48) take strided OUTPUT-side operands (y, residual, BatchNorm input) — their gathered x stays dense
+    const bool strided = (ep.x_ld && ep.x_ld != (unsigned)kc) || ep.y_ld || ep.res_ld || ep.bnx_ld;
+    const bool x_dense = !ep.x_ld || ep.x_ld == (unsigned)kc;
     const bool folded = pre && pre->kind != 0;
     const size_t x_ld = ep.x_ld ? ep.x_ld : (size_t)kc, y_ld = ep.y_ld ? ep.y_ld : (size_t)nc;
     const bool ld_ok = x_ld % 4 == 0 && y_ld % 4 == 0 && ep.res_ld % 4 == 0 && ep.bnx_ld % 4 == 0 &&
@@ -1162,14 +1164,14 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
     // per output row): conv_up32 (spconv_tile.hip).  DODA_CONV_UP=0 / doda_set_option(DODA_OPT_CONV_UP, 0): conv_fast as before.
     {
         if (doda_tile::up_enabled() && wide && sizeof(elem) == 2 && kc == 32 && K <= 8 && K > 1 && n_in < (long long)n_out && nc % 16 == 0 &&
-            !ep.res_bcast && !strided && doda_tile::enabled()) {
+            !ep.res_bcast && x_dense && doda_tile::enabled()) {
             const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
-            const unsigned yb = (unsigned)((size_t)n_out * nc * (out32 ? 4 : sizeof(elem)));
+            const unsigned yb = (unsigned)((((size_t)n_out - 1) * y_ld + nc) * (out32 ? 4 : sizeof(elem)));
             return doda_tile::launch_conv_up32(out32, x_, xb, wp, (unsigned)need, nc, NB, K, tbl, ld, n_out, y_, yb, res, ep, n_part, s);
         }
     }
     // A tilebook of this table and rows of 32 / 64 bytes: the LDS-staged tile kernel (spconv_tile.hip)
-    if (!ep.res_bcast && !strided) {
+    if (!ep.res_bcast && x_dense) {
         // (fp32 rows: the tile kernel's fp32 mode is bound by the fp32 matrix rate like the dense-table kernel and measured
         // within a few percent of it; DODA_F32_CONV_TILE=0 keeps fp32 forward / data-grad calls on conv_fast even when the
         // table carries a tilebook — the fp32 weight gradient uses the tilebook either way)
@@ -1179,15 +1181,15 @@ int run_gather(const void *x_, int kc, const float *w, int nc, const int32_t *tb
         const bool stats_fit = !ep.stats || NB <= 2 || (tmode == 1 && NB == 4 && doda_tile::dual_enabled());
         if (tmode >= 0 && tilebook && K == TB_K && tilebook_rows == n_out && doda_tile::enabled() && stats_fit) {
             const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
-            const unsigned yb = (unsigned)((size_t)n_out * nc * (out32 ? 4 : sizeof(elem)));
+            const unsigned yb = (unsigned)((((size_t)n_out - 1) * y_ld + nc) * (out32 ? 4 : sizeof(elem)));
             return doda_tile::launch_conv_tile(tmode, out32 || sizeof(elem) == 4, x_, xb, wp, (unsigned)need, nc, NB, tbl, ld,
                                                n_out, tilebook, y_, yb, res, ep, n_part, s);
         }
     }
     // 48 -> 48 channels on a mid-size level: the layer's fragments in LDS, one workgroup per CU (spconv_wlds.hip)
-    if (!ep.res_bcast && !strided && wide && kc == 48 && nc == 48 && K == 27 && !out32 && n_out >= 8192 && n_out <= 262144 && doda_wlds::enabled()) {
+    if (!ep.res_bcast && x_dense && wide && kc == 48 && nc == 48 && K == 27 && !out32 && n_out >= 8192 && n_out <= 262144 && doda_wlds::enabled()) {
         const unsigned xb = (unsigned)((size_t)n_in * kc * sizeof(elem));
-        const unsigned yb = (unsigned)((size_t)n_out * nc * sizeof(elem));
+        const unsigned yb = (unsigned)((((size_t)n_out - 1) * y_ld + nc) * sizeof(elem));
         return doda_wlds::launch_conv48(x_, xb, wp, tbl, (unsigned)((size_t)K * ld * 4), ld, n_out, y_, yb, res, ep, n_part, s);
     }
     // Tile choice: many rows -> more subtiles per wave and all channel blocks in one wave (x is

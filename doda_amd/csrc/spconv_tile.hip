@@ -60,14 +60,22 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<OUT32> &pre, int row0, int i
                                              unsigned y_bytes, const void *__restrict__ res, const EpiArgs &ep) {
     constexpr unsigned OSZ = OUT32 ? 4u : 2u;
     const unsigned col = (unsigned)(nb0 * 16 + 4 * g);
-    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)ep.bn_x, 0, y_bytes, 0x00020000);
+    // (ABI 12: the residual and the BatchNorm input may be column slices of wider matrices — row strides res_ld / bnx_ld, 0 = dense;
+    // a dense operand keeps the caller's y_bytes bound)
+    const unsigned rl = ep.res_ld ? ep.res_ld : (unsigned)nc, bl = ep.bnx_ld ? ep.bnx_ld : (unsigned)nc;
+    const unsigned dense_bytes = (unsigned)n_out * (unsigned)nc * OSZ;
+    const unsigned r_bytes = ep.res_ld ? ((unsigned)(n_out - 1) * rl + (unsigned)nc) * OSZ : (ep.y_ld ? dense_bytes : y_bytes);
+    const unsigned b_bytes = ep.bnx_ld ? ((unsigned)(n_out - 1) * bl + (unsigned)nc) * OSZ : (ep.y_ld ? dense_bytes : y_bytes);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, r_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)ep.bn_x, 0, b_bytes, 0x00020000);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const unsigned t = (unsigned)(row0 + s * 16 + i);
-        const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * (unsigned)nc + col) * OSZ : OOB;
+        const bool in_range = t < (unsigned)n_out && col < (unsigned)nc;
+        const unsigned voff = in_range ? (t * rl + col) * OSZ : OOB;
+        const unsigned voff_b = in_range ? (t * bl + col) * OSZ : OOB;
         if constexpr (ALWAYS) {
-            const unsigned vr = res ? voff : OOB, vb = ep.bn_x ? voff : OOB;
+            const unsigned vr = res ? voff : OOB, vb = ep.bn_x ? voff_b : OOB;
             if constexpr (OUT32) pre.res[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, vr, 0, 0);
             else pre.res[s] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, vr, 0, 0);
             if constexpr (STATS) {
@@ -81,8 +89,8 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<OUT32> &pre, int row0, int i
             else pre.res[s] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, voff, 0, 0);
         }
         if (STATS && ep.bn_x) {
-            if constexpr (OUT32) pre.bnx[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff, 0, 0);
-            else pre.bnx[s] = __builtin_amdgcn_raw_buffer_load_b64(rs_b, voff, 0, 0);
+            if constexpr (OUT32) pre.bnx[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, 0, 0);
+            else pre.bnx[s] = __builtin_amdgcn_raw_buffer_load_b64(rs_b, voff_b, 0, 0);
         }
     }
 }
@@ -125,10 +133,11 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[S][NBA], const EpiPre
             }
         }
     }
+    const unsigned yl = ep.y_ld ? ep.y_ld : (unsigned)nc;   // (ABI 12: y may be a column slice of a wider matrix)
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const unsigned t = (unsigned)(row0 + s * 16 + i);
-        const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * (unsigned)nc + col) * OSZ : OOB;
+        const unsigned voff = (t < (unsigned)n_out && col < (unsigned)nc) ? (t * yl + col) * OSZ : OOB;
         f32x4 a = acc[s][B];
         if (res) a += epi_unpack(pre.res[s]);
         u32x2 packed_out = {0u, 0u};

@@ -36,7 +36,7 @@ __device__ __forceinline__ void wlds_epilogue(f32x4 (&acc)[S], const u32x2 (&pre
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const unsigned t = (unsigned)(row0 + s * 16 + i);
-        const unsigned voff = t < (unsigned)n_out ? (t * (unsigned)WCH + col) * 2u : OOB;
+        const unsigned voff = t < (unsigned)n_out ? (t * (ep.y_ld ? ep.y_ld : (unsigned)WCH) + col) * 2u : OOB;   // (ABI 12: row stride of y)
         f32x4 a = acc[s];
         if (res) a += unpack(pre_res[s]);
         u32x2 packed_out;
@@ -145,16 +145,23 @@ __global__ __launch_bounds__(512) void conv_wlds48(const unsigned short *__restr
         // the epilogue's operands of all three channel blocks: requested now, consumed at the end of the tile
         u32x2 pre_res[WNB][S], pre_bnx[WNB][S];
         {
-            const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, y_bytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)ep.bn_x, 0, y_bytes, 0x00020000);
+            // (ABI 12: the residual and the BatchNorm input may be column slices of wider matrices)
+            const unsigned rl = ep.res_ld ? ep.res_ld : (unsigned)WCH, bl = ep.bnx_ld ? ep.bnx_ld : (unsigned)WCH;
+            const unsigned dense_bytes = (unsigned)n_out * (unsigned)WCH * 2u;
+            const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)res, 0, ep.res_ld ? ((unsigned)(n_out - 1) * rl + (unsigned)WCH) * 2u : dense_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)ep.bn_x, 0, ep.bnx_ld ? ((unsigned)(n_out - 1) * bl + (unsigned)WCH) * 2u : dense_bytes, 0x00020000);
 #pragma unroll
             for (int nb = 0; nb < WNB; ++nb)
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     const unsigned t = (unsigned)(row0 + s * 16 + i);
-                    const unsigned voff = t < (unsigned)n_out ? (t * (unsigned)WCH + (unsigned)(nb * 16 + 4 * g)) * 2u : OOB;
+                    const unsigned cc = (unsigned)(nb * 16 + 4 * g);
+                    const unsigned voff = t < (unsigned)n_out ? (t * rl + cc) * 2u : OOB;
+                    const unsigned voff_b = t < (unsigned)n_out ? (t * bl + cc) * 2u : OOB;
                     pre_res[nb][s] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, res ? voff : OOB, 0, 0);
-                    if constexpr (STATS) pre_bnx[nb][s] = __builtin_amdgcn_raw_buffer_load_b64(rs_b, ep.bn_x ? voff : OOB, 0, 0);
+                    if constexpr (STATS) pre_bnx[nb][s] = __builtin_amdgcn_raw_buffer_load_b64(rs_b, ep.bn_x ? voff_b : OOB, 0, 0);
                     else pre_bnx[nb][s] = (u32x2){0u, 0u};
                 }
         }

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <vector>
 
@@ -1361,6 +1362,7 @@ struct Step {
     bool has_skip = false;
     CVP skip;
     at::Tensor ident;           // identity table of the 1x1 skip conv (weight-gradient job)
+    bool skip_pairs = false;    // ... which doubles as both pair lists of the pair-list weight-gradient kernel (large bf16 levels)
 };
 
 inline BNP bn_of(const TList &t, size_t at_, double eps, double mom) {
@@ -1413,11 +1415,19 @@ struct Builder {
         else v.p = arena.alloc((size_t)rows * c * esz);
         return v;
     }
-    void run(const at::Tensor &like) {
+    // `cut` > 0: the ops in front of it are issued, `between` runs on the host (the rulebook prefetcher's gate: an event recorded
+    // where the forward pass enters its launch-floor levels), then the rest
+    void run(const at::Tensor &like, size_t cut = 0, const std::function<void()> &between = nullptr) {
         if (ops.empty()) return;
-        int32_t n = 0;
-        check(doda_layers_run(ops.data(), (int32_t)ops.size(), esz, &n, stream_of(like)), "doda_layers_run");
-        launches = n;
+        int32_t n = 0, n2 = 0;
+        if (cut > 0 && cut < ops.size() && between) {
+            check(doda_layers_run(ops.data(), (int32_t)cut, esz, &n, stream_of(like)), "doda_layers_run");
+            between();
+            check(doda_layers_run(ops.data() + cut, (int32_t)(ops.size() - cut), esz, &n2, stream_of(like)), "doda_layers_run");
+        } else {
+            check(doda_layers_run(ops.data(), (int32_t)ops.size(), esz, &n, stream_of(like)), "doda_layers_run");
+        }
+        launches = n + n2;
     }
 
     // ---- forward ----
@@ -1461,6 +1471,7 @@ struct Builder {
         o.x = L.a.data_ptr(); o.x_ld = (int32_t)L.a.size(1);
         o.w = L.cv.pk_fwd.data_ptr();
         o.y = out.p; o.y_ld = out.ld;
+        if (!identity) o.tilebook = tilebook_behind(tbl, out.rows);   // (levels 1-2: the LDS-staged kernels)
         if (res) { o.res = res->p; o.res_ld = res->ld; }
         if (want_stats) {
             out.stats = stat_buf(out.c);
@@ -1512,7 +1523,7 @@ struct CoarseNode : public torch::autograd::Node {
             pgrads.push_back(pg);
             return (float *)pg.buf.data_ptr();
         };
-        struct WJob { at::Tensor a, b, tbl, weight; int64_t n_rows; };
+        struct WJob { at::Tensor a, b, tbl, weight; int64_t n_rows; PairLists pl; };
         std::vector<WJob> wjobs;
         bool first = true;
         // dz = data gradient of L's conv applied to `dy`, masked by L's ReLU; statistics for L's BatchNorm backward
@@ -1525,6 +1536,7 @@ struct CoarseNode : public torch::autograd::Node {
             o.K = identity ? 1 : (int32_t)L.bwd_tbl.size(0);
             o.tbl = identity ? nullptr : (const int32_t *)L.bwd_tbl.data_ptr();
             o.tbl_ld = identity ? L.n_in : (int32_t)L.bwd_tbl.size(1);
+            if (!identity) o.tilebook = tilebook_behind(L.bwd_tbl, L.n_in);
             o.x = dy.data_ptr(); o.x_ld = L.c_out;
             o.w = L.cv.pk_bwd.data_ptr();
             o.y = dz; o.y_ld = L.c_in;
@@ -1588,9 +1600,13 @@ struct CoarseNode : public torch::autograd::Node {
                 void *dz1 = gemm_bwd(S.l1, g1, false, st1, true);
                 at::Tensor left, right;
                 bn_bwd(S.l1, dz1, st1, S.has_skip ? gS : g, left, right);
-                wjobs.push_back({S.l2.a, g, S.l2.fwd_tbl, S.l2.cv.weight, S.l2.n_out});
-                wjobs.push_back({S.l1.a, g1, S.l1.fwd_tbl, S.l1.cv.weight, S.l1.n_out});
-                if (S.has_skip) wjobs.push_back({S.l1.x.t, g, S.ident, S.skip.weight, S.l1.n_in});
+                wjobs.push_back({S.l2.a, g, S.l2.fwd_tbl, S.l2.cv.weight, S.l2.n_out, PairLists()});
+                wjobs.push_back({S.l1.a, g1, S.l1.fwd_tbl, S.l1.cv.weight, S.l1.n_out, PairLists()});
+                if (S.has_skip) {
+                    PairLists pl;
+                    if (S.skip_pairs) { pl.in = S.ident; pl.out = S.ident; }
+                    wjobs.push_back({S.l1.x.t, g, S.ident, S.skip.weight, S.l1.n_in, pl});
+                }
                 if (right.defined()) { skip_grads.push_back(left); g = right; }
                 else g = left;
             } else {
@@ -1603,7 +1619,7 @@ struct CoarseNode : public torch::autograd::Node {
                     skip_grads.pop_back();
                 }
                 bn_bwd(S.l1, dz, st, add, left, none);
-                wjobs.push_back({S.l1.a, g, S.l1.fwd_tbl, S.l1.cv.weight, S.l1.n_out});
+                wjobs.push_back({S.l1.a, g, S.l1.fwd_tbl, S.l1.cv.weight, S.l1.n_out, PairLists()});
                 g = left;
             }
         }
@@ -1612,8 +1628,8 @@ struct CoarseNode : public torch::autograd::Node {
         // backward pass restricted to specific inputs: see plain_accumulating_backward)
         if (!plain) wjobs.clear();
         for (WJob &w : wjobs) {
-            if (!try_defer_wgrad(w.a, w.b, w.tbl, w.n_rows, w.weight, PairLists()))
-                deposit_grad(w.weight, wgrad(w.a, w.b, w.tbl, w.n_rows).reshape(w.weight.sizes()).to(w.weight.scalar_type()));
+            if (!try_defer_wgrad(w.a, w.b, w.tbl, w.n_rows, w.weight, w.pl))
+                deposit_grad(w.weight, wgrad(w.a, w.b, w.tbl, w.n_rows, w.pl).reshape(w.weight.sizes()).to(w.weight.scalar_type()));
         }
         for (PGrad &pg : pgrads)
             if (pg.fresh) deposit_grad(pg.param, pg.buf);
@@ -1634,8 +1650,10 @@ struct CoarseNode : public torch::autograd::Node {
 };
 
 // Returns {y [n, c] in the dtype of x, fp64 totals of y (training) or undefined}.
+// gate_step >= 0 with `gate`: the host callback runs when the ops of steps [0, gate_step) have been issued.
 std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optional<at::Tensor> &stats_in, const std::vector<int64_t> &kinds,
-                                      const std::vector<TList> &tensors, const std::vector<std::vector<double>> &scalars, bool training) {
+                                      const std::vector<TList> &tensors, const std::vector<std::vector<double>> &scalars, bool training,
+                                      int64_t gate_step = -1, const std::function<void()> &gate = nullptr) {
     host_timing::Scope host_scope(6);
     TORCH_CHECK(x_in.is_cuda() && x_in.dim() == 2 && x_in.size(0) >= 2 &&
                 (x_in.scalar_type() == at::kBFloat16 || x_in.scalar_type() == at::kFloat),
@@ -1662,14 +1680,16 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
     struct Skip { Val left; at::Tensor cat; };
     std::vector<Skip> skips;
     at::Tensor y_out, y_stats;
+    size_t cut = 0;
     for (size_t si = 0; si < kinds.size(); ++si) {
+        if ((int64_t)si == gate_step) cut = B.ops.size();
         Step &S = steps[si];
         const TList &t = tensors[si];
         const std::vector<double> &sc = scalars[si];
         S.kind = (int)kinds[si];
         const bool last = si + 1 == kinds.size();
         if (S.kind == 0) {
-            TORCH_CHECK(t.size() == 21 && sc.size() == 4 && t[0].has_value(), "doda coarse_ublock: RB step");
+            TORCH_CHECK((t.size() == 21 || t.size() == 22) && sc.size() == 4 && t[0].has_value(), "doda coarse_ublock: RB step");
             const at::Tensor &tbl = *t[0];
             const int n = cur.rows;
             TORCH_CHECK(tbl.dim() == 2 && tbl.size(0) == 27 && tbl.size(1) == n && tbl.scalar_type() == at::kInt, "doda coarse_ublock: SubM table");
@@ -1694,6 +1714,7 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
                 S.skip = cv_of(t, 17);
                 TORCH_CHECK(t[20].has_value(), "doda coarse_ublock: identity table of the skip conv");
                 S.ident = *t[20];
+                S.skip_pairs = t.size() > 21 && t[21].has_value() && t[21]->defined();
                 TORCH_CHECK(cur.t.defined() && cur.ld == cur.c, "doda coarse_ublock: the skip conv's input must be dense");
                 skipv = B.dense(n, cout, false);
                 Layer sk;
@@ -1756,7 +1777,7 @@ std::vector<at::Tensor> coarse_ublock(const at::Tensor &x_in, const c10::optiona
         }
     }
     TORCH_CHECK(y_out.defined() && skips.empty(), "doda coarse_ublock: the last step must be a residual block at the input's level");
-    B.run(x);
+    B.run(x, cut, gate);
     g_coarse_launches_fwd = B.launches;
     g_last_bn.reset();
     if (need_grad) {
@@ -1998,12 +2019,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::call_guard<py::gil_scoped_release>());
     m.def("coarse_ublock", [](const at::Tensor &x, const c10::optional<at::Tensor> &stats_in, const std::vector<int64_t> &kinds,
                               const std::vector<std::vector<c10::optional<at::Tensor>>> &tensors,
-                              const std::vector<std::vector<double>> &scalars, bool training) {
-        auto r = coarse::coarse_ublock(x, stats_in, kinds, tensors, scalars, training);
+                              const std::vector<std::vector<double>> &scalars, bool training, int64_t gate_step, py::object gate) {
+        std::function<void()> between;
+        if (gate_step >= 0 && !gate.is_none()) between = [gate]() { gate(); };   // (the GIL is held throughout this call)
+        auto r = coarse::coarse_ublock(x, stats_in, kinds, tensors, scalars, training, gate_step, between);
         return std::make_pair(r[0], r[1].defined() ? c10::optional<at::Tensor>(r[1]) : c10::nullopt);
     }, "a U-Net subtree of coarse levels as one op list per direction: per-layer launches issued inside the library with the "
        "BatchNorm ops folded into the convolutions (doda_layers_run)",
-          py::arg("x"), py::arg("stats_in"), py::arg("kinds"), py::arg("tensors"), py::arg("scalars"), py::arg("training"));
+          py::arg("x"), py::arg("stats_in"), py::arg("kinds"), py::arg("tensors"), py::arg("scalars"), py::arg("training"),
+          py::arg("gate_step") = -1, py::arg("gate") = py::none());
     m.def("coarse_launches", []() { return std::make_pair((int64_t)coarse::g_coarse_launches_fwd, (int64_t)coarse::g_coarse_launches_bwd); },
           "kernel launches of the last per-layer forward / backward op list");
     m.def("abi_version", []() { return doda_abi_version(); });

@@ -216,9 +216,12 @@ class VGGBlock(SparseModule):
 # DODA_COARSE_MODE: "layers" (default) | "off" (module by module).  Round 5's persistent single-XCD executor ("exec") is gone:
 # with the per-layer launches issued from inside the library it lost at every batch size (4.30 against 4.05-4.28 ms at the host
 # floor, 7.35 against 4.81 at the bench size).
+# ABI 12: the op list takes ANY level (a GEMM op carries its table's tilebook, the LDS-staged kernels write column slices), so the
+# default subtree is the whole U-Net: one extension call forward, one autograd node backward, no interpreter between the ~110 + ~170
+# launches of a step's convolutions and BatchNorms, the three remaining torch.cat and their gradient slices gone.
 COARSE_MODE = _os.environ.get("DODA_COARSE_MODE", "layers")
-COARSE_EXEC_LEVEL = int(_os.environ.get("DODA_COARSE_LEVEL", "4"))
-COARSE_LAYERS_MAX_ROWS = int(_os.environ.get("DODA_COARSE_LAYERS_MAX_ROWS", "262144"))
+COARSE_EXEC_LEVEL = int(_os.environ.get("DODA_COARSE_LEVEL", "1"))
+COARSE_LAYERS_MAX_ROWS = int(_os.environ.get("DODA_COARSE_LAYERS_MAX_ROWS", str(1 << 23)))
 
 
 def set_coarse_mode(mode, level=None):
@@ -238,6 +241,17 @@ def choose_coarse_backend(rows, dtype):
     return "layers" if 2 <= rows <= COARSE_LAYERS_MAX_ROWS else None
 
 
+def _coarse_entry_level():
+    """The level whose UBlock becomes one call: COARSE_EXEC_LEVEL, but not above the levels whose inputs carry tensor hooks (the early
+    gradient exchange at EARLY_LEVEL, the side-stream weight gradients at WGRAD_SIDE_LEVEL: both opt-in)."""
+    lvl = COARSE_EXEC_LEVEL
+    if _early_exchange[0] is not None:
+        lvl = max(lvl, EARLY_LEVEL + 1)
+    if WGRAD_SIDE_LEVEL:
+        lvl = max(lvl, WGRAD_SIDE_LEVEL + 1)
+    return lvl
+
+
 def _bn_list(bn):
     return [bn._parameters["weight"], bn._parameters["bias"], bn._buffers["running_mean"], bn._buffers["running_var"],
             bn._buffers["num_batches_tracked"]]
@@ -251,7 +265,7 @@ def _plain_bn(m):
 
 def _plain_conv(m, cls, ksize):
     return (type(m) is cls and m.bias is None and m.kernel_size == ksize and m._parameters["weight"].dtype == torch.float32
-            and m.in_channels % 16 == 0 and m.out_channels % 16 == 0 and m.in_channels >= 32
+            and m.in_channels % 16 == 0 and m.out_channels % 16 == 0 and m.in_channels >= 16
             and not (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks))
 
 
@@ -366,6 +380,7 @@ class UBlock(nn.Module):
             return None
         idict = input.indice_dict
         kinds, tensors, scalars = [], [], []
+        gate_step = -1          # first step of level COARSE_LEVEL: where the rulebook prefetcher's gate opens (see forward)
         rows = {self.level: feats.shape[0]}
         for kind, m, lvl in plan:
             if kind == "rb":
@@ -380,12 +395,17 @@ class UBlock(nn.Module):
                     return None
                 sk = m.i_branch[0]
                 if type(sk) is nn.Identity:
-                    skt = [None, None, None, None]
+                    skt = [None, None, None, None, None]
                 else:
                     pks = sk._packed(feats, idict)
                     if pks is None:
                         return None
-                    skt = [sk._parameters["weight"], pks[0], pks[1], _cv._identity_table(rows[lvl], feats.device)]
+                    ident = _cv._identity_table(rows[lvl], feats.device)
+                    # (t[21]: the identity table doubles as both pair lists of the skip conv's weight gradient at the large levels)
+                    skt = [sk._parameters["weight"], pks[0], pks[1], ident,
+                           ident if (grad and Fsp._want_pairs(feats, sk._parameters["weight"], rows[lvl])) else None]
+                if kind == "rb" and lvl == COARSE_LEVEL and gate_step < 0:
+                    gate_step = len(kinds)
                 kinds.append(0)
                 tensors.append([data.tbl] + _bn_list(bn1) + [c1._parameters["weight"], pk1[0], pk1[1]] + _bn_list(bn2)
                                + [c2._parameters["weight"], pk2[0], pk2[1]] + skt)
@@ -412,7 +432,14 @@ class UBlock(nn.Module):
                     scalars.append([bn.eps, bn.momentum, rows[lvl]])
         st = input.__dict__.get("_doda_stats")
         stats_in = st[1] if (st is not None and st[0] is feats and st[2] == feats._version and torch.is_tensor(st[1])) else None
-        y, stats = ext.coarse_ublock(feats, stats_in, kinds, tensors, scalars, training)
+        gate = None
+        if self.level < COARSE_LEVEL and gate_step >= 0 and _coarse_hooks and training and torch.is_grad_enabled():
+            hooks = list(_coarse_hooks)
+
+            def gate():
+                for hook in hooks:
+                    hook()
+        y, stats = ext.coarse_ublock(feats, stats_in, kinds, tensors, scalars, training, gate_step if gate is not None else -1, gate)
         out = spconv.SparseConvTensor(y, input.indices, input.spatial_shape, input.batch_size)
         out.indice_dict = idict
         out.grid = input.grid
@@ -430,7 +457,7 @@ class UBlock(nn.Module):
                 fn()
                 return g
             input.features.register_hook(_fire)
-        if COARSE_MODE != "off" and self.level == COARSE_EXEC_LEVEL:
+        if COARSE_MODE != "off" and self.level == _coarse_entry_level():
             out = self._forward_coarse(input)
             if out is not None:
                 return out

@@ -933,7 +933,7 @@ class _CxOp(C.Structure):   # doda_cx_op
                 ("res", C.c_void_p), ("aux", C.c_void_p), ("stats", C.c_void_p), ("stats_b", C.c_void_p),
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("nbt", C.c_void_p),
-                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("tilebook", C.c_void_p)]
 
 
 def _cx_array(ops, n_part):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DODA_ABI_VERSION 11
+#define DODA_ABI_VERSION 12
 
 #define DODA_OK 0
 #define DODA_ERR_INVALID (-1)        /* bad argument (null pointer, negative size, bad mode) */
@@ -589,7 +589,7 @@ int doda_sgd_multi(const doda_sgd_tensor *tensors_h, int32_t n_tensors, double l
                    double dampening, double weight_decay, int32_t nesterov, int32_t maximize, void *desc_dev,
                    size_t desc_bytes, doda_stream_t stream);
 
-/* ---- ABI 11: coarse U-Net levels as an op list of per-layer launches (csrc/layers.hip) ----------------------------------------
+/* ---- ABI 11 (ABI 12: any level — a GEMM op may carry its table's tilebook): U-Net levels as an op list of per-layer launches (csrc/layers.hip) ----------------------------------------
  * The deep levels of DODA's U-Net — reference model/unet_block.py:55-100 (UBlock: blocks -> strided conv -> UBlock -> inverse conv
  * -> concatenation -> blocks_tail) with model/unet_block.py:9-37 inside (ResidualBlock: BatchNorm1d -> ReLU -> SubMConv3d, twice,
  * + skip) — are described by the caller as a HOST array of ops and issued by doda_layers_run as whole-chip launches, back to back,
@@ -656,6 +656,7 @@ typedef struct doda_cx_op {
     float *running_mean, *running_var;
     int64_t *nbt;
     float *dgamma, *dbeta;
+    const void *tilebook;    /* ABI 12, GEMM: the tilebook of `tbl` (doda_tilebook_build over rows == this op's `rows`), or NULL */
 } doda_cx_op;
 /* *n_launches_h (optional, HOST) receives the number of kernel launches issued. */
 int doda_layers_run(const doda_cx_op *ops_h, int32_t n_ops, int32_t elem_bytes, int32_t *n_launches_h, doda_stream_t stream);

@@ -564,20 +564,24 @@ def test_subtree_folded_equals_unfolded_and_launch_counts(native_lib, dtype):
     assert counts[True][1] == counts[False][1] - (2 * n_rb + n_updown - 3), counts
 
 
-def test_unet_step_layers_vs_module_path_and_fp32(native_lib):
-    """The whole training step with levels 4-7 as one extension call (default) against the module-by-module step and fp32."""
+@pytest.mark.parametrize("level", [4, 2, 1])
+def test_unet_step_layers_vs_module_path_and_fp32(native_lib, level):
+    """The whole training step with levels `level`-7 as one extension call (1 = the whole U-Net, the default: tile kernels over
+    tilebooks, the weights-in-LDS kernel and the k2 s2 kernels inside the op list, every concatenation written in place) against
+    the module-by-module step and fp32."""
     from doda_amd._ext import ext
     if ext is None or not hasattr(ext, "coarse_ublock"):
         pytest.skip("compiled extension not built")
     sf, lf, gf, _ = _unet_step("off", 4, dtype=torch.float32)
-    sl, ll, gl, _ = _unet_step("layers", 4, dtype=torch.float32)
+    sl, ll, gl, _ = _unet_step("layers", level, dtype=torch.float32)
+    assert ext.coarse_launches()[0] > (60 if level == 1 else 20), ext.coarse_launches()   # (the op list did run)
     rel = lambda a, b: float((a - b).norm() / b.norm().clamp(min=1e-20))
     assert abs(ll - lf) / lf < 1e-5, (ll, lf)
     assert _scale_err(sl, sf) < 1e-4
     for k in gf:
         assert rel(gl[k], gf[k]) < 1e-2, (k, rel(gl[k], gf[k]))
     s0, l0, g0, b0 = _unet_step("off", 4)
-    s1, l1, g1, b1 = _unet_step("layers", 4)
+    s1, l1, g1, b1 = _unet_step("layers", level)
     assert abs(l1 - l0) / abs(l0) < 2e-3 and abs(l1 - lf) / lf < 2e-2, (lf, l0, l1)
     assert _scale_err(s1, s0) < 3e-2
     for k in g0:
@@ -590,19 +594,21 @@ def test_unet_step_layers_vs_module_path_and_fp32(native_lib):
             assert torch.allclose(b1[k], b0[k], rtol=5e-2, atol=5e-3), k
 
 
-def test_unet_layers_two_backward_passes_accumulate(native_lib):
+@pytest.mark.parametrize("level", [4, 1])
+def test_unet_layers_two_backward_passes_accumulate(native_lib, level):
     """Two forward / backward passes into the same .grad tensors (tool/st.py:136-198)."""
     from doda_amd._ext import ext
     if ext is None or not hasattr(ext, "coarse_ublock"):
         pytest.skip("compiled extension not built")
-    _, _, g1, _ = _unet_step("layers", 4, voxels=30000)
-    _, _, g2, _ = _unet_step("layers", 4, voxels=30000, two_pass=True)
+    _, _, g1, _ = _unet_step("layers", level, voxels=30000)
+    _, _, g2, _ = _unet_step("layers", level, voxels=30000, two_pass=True)
     for k in g1:
-        if k.startswith("unet.u.u.u."):
+        if k.startswith("unet.u.u.u." if level == 4 else "unet."):
             assert torch.allclose(g2[k], 2.0 * g1[k], rtol=2e-2, atol=2e-2 * float(g1[k].abs().max())), k
 
 
-def test_unet_layers_eval_and_no_grad(native_lib):
+@pytest.mark.parametrize("level", [4, 1])
+def test_unet_layers_eval_and_no_grad(native_lib, level):
     """Evaluation mode (running statistics folded into the gathers) and torch.no_grad() in training mode."""
     from doda_amd import model as M
     from doda_amd.model import SparseConvNet, default_cfg, voxelize_and_run
@@ -622,7 +628,7 @@ def test_unet_layers_eval_and_no_grad(native_lib):
         for mode in ("eval", "train"):
             net.train(mode == "train")
             for cm in ("off", "layers"):
-                M.set_coarse_mode(cm, 4)
+                M.set_coarse_mode(cm, level)
                 state = {k: v.clone() for k, v in net.state_dict().items()}
                 for dt in (torch.bfloat16, torch.float32):
                     with torch.no_grad():

@@ -19,7 +19,7 @@ def test_header_symbols_all_exported(native_lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(native_lib, name), name
-    assert native_lib.doda_abi_version() == 11
+    assert native_lib.doda_abi_version() == 12
     assert len(declared) <= 70      # (the boundary a maintainer carries; ABI 8: four executor entry points, ABI 9: BatchNorm over totals, ABI 11: doda_layers_run)
     assert native_lib.doda_strerror(-3).decode().startswith("cell id")
 

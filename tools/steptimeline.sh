@@ -27,6 +27,10 @@ for e, g in zip(step, gaps):
 print("per kernel: count, busy us, idle us in front")
 for k, v in sorted(fam.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))[:45]:
     print("  %3d x  busy %7.1f  idle %6.1f  %s" % (v[0], v[1], v[2], k))
+t0, t1 = mainev[a][1], step[-1][1]
+print("glue launches inside the step window, per queue (main = %s):" % main)
+gl = collections.Counter((e[3], short(e[2])) for e in ev if t0 <= e[0] <= t1 and re.search("fillBuffer|copyBuffer|at::native", e[2]))
+for (q, n), c in sorted(gl.items()): print("  queue %s  %3d x %s" % (q, c, n))
 print("timeline (duration us / gap in front us):")
 for e, g in zip(step, gaps):
     print("  %7.1f  gap %6.2f  %s" % ((e[1] - e[0]) / 1e3, g, short(e[2])))
