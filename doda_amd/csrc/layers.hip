@@ -1,4 +1,4 @@
-// Per-layer backend of the coarse-level op list (ABI 11: doda_layers_run).
+// Per-layer backend of the U-Net op list (ABI 11: doda_layers_run; ABI 12: every level — GEMM ops carry their table's tilebook).
 //
 // The deep levels of DODA's U-Net (reference model/unet_block.py:55-100 UBlock: blocks -> strided conv -> UBlock -> inverse conv ->
 // concatenation -> blocks_tail, ResidualBlocks of model/unet_block.py:9-37 inside) are described by the caller as a list of
@@ -182,8 +182,9 @@ int run_bn(const doda_cx_op &o, int esz, hipStream_t s) {
     if (!chan_ok(o.c_in, esz) || !o.x || o.x_ld % va || o.y_ld % va || !al16(o.x) || !al16(o.y)) return DODA_ERR_UNSUPPORTED;
     if (o.kind == DODA_CX_BNFWD) {
         if (o.y_ld < o.c_in || o.x_ld < o.c_in) return DODA_ERR_INVALID;
-        // dense training-mode sweeps of many rows take the tuned kernels of bn.hip (registers hold the channel vectors)
-        // (fp32 only: the bf16 sweeps of this backend use the fused-multiply-add form whether folded or not, see pre_piece)
+        // dense training-mode sweeps of many rows take the tuned kernels of bn.hip (registers hold the channel vectors).  fp32: the
+        // same operation order as lay_bn / the folded gather, so from 4096 rows; bf16: bn.hip rounds in a different order than the
+        // fused-multiply-add form of pre_piece, so only above any fold limit, where "folded == unfolded" has nothing to compare
         // (ABI 12, bf16: above the rows any fold limit reaches — the finest levels, where the sweep is an HBM-bound kernel)
         if ((o.flags & DODA_CX_F_TRAINING) && o.x_ld == o.c_in && o.y_ld == o.c_in && o.rows >= tuned_rows(esz))
             return doda_bn_relu_fwd_totals(o.x, o.rows, o.c_in, esz, p.tot.ta, p.tot.tb, p.tot.ca, o.eps, o.momentum, o.gamma, o.beta,

@@ -997,6 +997,8 @@ int launch_fast(const typename P::elem *x, int kc, const void *wp, size_t wp_byt
     // every load hitting L1 (ablation) the kernel time did not move, i.e. the unit loop is paced by
     // instruction issue and by how many waves a SIMD can interleave, not by memory latency.  Depth 8
     // cost 124 VGPRs (4 waves per SIMD); depth 3: level-1 16->16 52 -> 38 us, level-2 32->32 37 -> 32 us.
+    // (round 6: depth 6 for the 16-row split blocks of the coarse levels — ~20 units per wave, one wave per SIMD — measured the same
+    // 8.1-8.2 us per launch: those kernels are not paced by the ring either)
     constexpr int D = 3;
     const size_t esz = sizeof(typename P::elem);
     const unsigned xb = (unsigned)(ep.x_ld ? ((size_t)(n_in - 1) * ep.x_ld + kc) * esz : (size_t)n_in * kc * esz);

@@ -590,7 +590,7 @@ int doda_sgd_multi(const doda_sgd_tensor *tensors_h, int32_t n_tensors, double l
                    size_t desc_bytes, doda_stream_t stream);
 
 /* ---- ABI 11 (ABI 12: any level — a GEMM op may carry its table's tilebook): U-Net levels as an op list of per-layer launches (csrc/layers.hip) ----------------------------------------
- * The deep levels of DODA's U-Net — reference model/unet_block.py:55-100 (UBlock: blocks -> strided conv -> UBlock -> inverse conv
+ * The levels of DODA's U-Net (ABI 11: the deep ones; ABI 12: any, from the root UBlock down) — reference model/unet_block.py:55-100 (UBlock: blocks -> strided conv -> UBlock -> inverse conv
  * -> concatenation -> blocks_tail) with model/unet_block.py:9-37 inside (ResidualBlock: BatchNorm1d -> ReLU -> SubMConv3d, twice,
  * + skip) — are described by the caller as a HOST array of ops and issued by doda_layers_run as whole-chip launches, back to back,
  * with nothing of the caller's (interpreter, autograd nodes, allocations) in between; the arithmetic per layer is that of

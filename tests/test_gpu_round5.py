@@ -135,6 +135,9 @@ def test_unet_step_with_totals_equals_the_step_with_rows(native_lib, dtype):
     bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in b.items()}
     got = {}
     was = ext.get_stats_totals()
+    from doda_amd import model as M
+    old_mode = (M.COARSE_MODE, M.COARSE_EXEC_LEVEL)
+    M.set_coarse_mode("off")       # (the op list of the default path keeps its statistics as totals whatever the switch says)
     assert Fsp.set_deferred_wgrad(True)
     try:
         for on in (True, False):
@@ -148,6 +151,7 @@ def test_unet_step_with_totals_equals_the_step_with_rows(native_lib, dtype):
     finally:
         ext.set_stats_totals(was)
         Fsp.set_deferred_wgrad(False)
+        M.set_coarse_mode(*old_mode)
     (l1, g1, b1), (l0, g0, b0) = got[True], got[False]
     tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
     assert abs(l0 - l1) <= 1e-5 * abs(l0) + (1e-3 if dtype == torch.bfloat16 else 0.0)
