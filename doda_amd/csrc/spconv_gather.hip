@@ -618,41 +618,11 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
     const bool second = PAIR && g >= 2;
     const unsigned *my_off = &off_tile[wid][i];
 
-    // (round 6) 16-row split blocks — the coarse U-Net levels, where a kernel IS its chain of memory round trips: the epilogue's
-    // operands (the residual row, the BatchNorm input of the data-grad statistics and its four per-channel vectors) are REQUESTED
-    // here, before the unit loop, by the wave that will run the epilogue; they used to be one more exposed round trip (~1.5 us of an
-    // 8 us kernel) behind the cross-wave reduction.  Older than every ring load, so the ring's counted waits still hold.
-    constexpr bool EPI_PRE = SPLIT && NBW == 1 && S == 1 && !OUT32;
-    u32x4 epi_res = {0u, 0u, 0u, 0u}, epi_bnx = {0u, 0u, 0u, 0u};
-    f32x4 epi_mu = {0.f, 0.f, 0.f, 0.f}, epi_is = epi_mu, epi_ga = epi_mu, epi_be = epi_mu;
-    if constexpr (EPI_PRE) {
-        if (wid == 0) {
-            const unsigned col = (unsigned)(nb0 * 16 + 4 * g), t = (unsigned)(row0 + i);
-            const bool in_range = t < (unsigned)n_out && col < (unsigned)nc;
-            const unsigned rl = ep.res_ld ? ep.res_ld : (unsigned)nc, bl = ep.bnx_ld ? ep.bnx_ld : (unsigned)nc;
-            const unsigned dense_bytes = (unsigned)((size_t)n_out * nc * OSZ);
-            if (res) {
-                const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
-                    (void *)res, 0, ep.res_ld ? (unsigned)(((size_t)(n_out - 1) * rl + nc) * OSZ) : (ep.y_ld ? dense_bytes : y_bytes), 0x00020000);
-                const unsigned vo = ep.res_bcast ? (in_range ? col * OSZ : OOB) : (in_range ? (t * rl + col) * OSZ : OOB);
-                if constexpr (sizeof(elem) == 4) epi_res = __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo, 0, 0);
-                else { const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rs_r, vo, 0, 0); epi_res[0] = r2[0]; epi_res[1] = r2[1]; }
-            }
-            if (STATS && ep.bn_x) {
-                const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-                    (void *)ep.bn_x, 0, ep.bnx_ld ? (unsigned)(((size_t)(n_out - 1) * bl + nc) * OSZ) : (ep.y_ld ? dense_bytes : y_bytes), 0x00020000);
-                const unsigned vo = in_range ? (t * bl + col) * OSZ : OOB;
-                if constexpr (sizeof(elem) == 4) epi_bnx = __builtin_amdgcn_raw_buffer_load_b128(rs_b, vo, 0, 0);
-                else { const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rs_b, vo, 0, 0); epi_bnx[0] = r2[0]; epi_bnx[1] = r2[1]; }
-                const unsigned cc = col < (unsigned)nc ? col : 0u;
-                epi_mu = *reinterpret_cast<const f32x4 *>(ep.bn_mean + cc);
-                epi_is = *reinterpret_cast<const f32x4 *>(ep.bn_invstd + cc);
-                epi_ga = *reinterpret_cast<const f32x4 *>(ep.bn_gamma + cc);
-                epi_be = *reinterpret_cast<const f32x4 *>(ep.bn_beta + cc);
-            }
-        }
-    }
-
+    // (round 6, tried and REMOVED: requesting the epilogue's operands — residual row, BatchNorm input and vectors — here, in front of
+    // the unit loop of the 16-row split blocks.  8.4 -> 8.2 us per launch, and unsafe: the ring below is inline asm whose loads hipcc
+    // does not see; it sank the compiler-visible requests BETWEEN ring loads in one instantiation (PBF16P, statistics), which breaks the
+    // hand-counted vmcnt waits — a two-rank gradient test caught the resulting race once in three runs.  Every compiler-visible vector
+    // load of this kernel must be consumed before the first asm load or issued after the ring has drained.)
     const int n_units = PAIR ? (__builtin_popcount(active) + 1) / 2 : __builtin_popcount(active) * n_chunk;
     if (n_units > 0) {
         raw xa[D][S], wb[D][NBW];
@@ -876,18 +846,7 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                 const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)res, 0, res_bytes, 0x00020000);
                 // (res_bcast: one row for every output row — the Linear head's bias, reference model/unet.py:64)
                 const unsigned voff_r = ep.res_bcast ? (in_range ? col * OSZ : OOB) : voff_res;
-                if constexpr (EPI_PRE) {
-                    if constexpr (sizeof(elem) == 4) {
-                        const f32x4 r4 = __builtin_bit_cast(f32x4, epi_res);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[s][nb][q] += r4[q];
-                    } else {
-                        acc[s][nb][0] += __uint_as_float(epi_res[0] << 16);
-                        acc[s][nb][1] += __uint_as_float(epi_res[0] & 0xffff0000u);
-                        acc[s][nb][2] += __uint_as_float(epi_res[1] << 16);
-                        acc[s][nb][3] += __uint_as_float(epi_res[1] & 0xffff0000u);
-                    }
-                } else if (OUT32 || sizeof(elem) == 4) {
+                if (OUT32 || sizeof(elem) == 4) {
                     const f32x4 r4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, voff_r, 0, 0));
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[s][nb][q] += r4[q];
@@ -914,11 +873,7 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                 if (ep.bn_x) {
                     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)ep.bn_x, 0, bnx_bytes, 0x00020000);
                     f32x4 xr;
-                    if constexpr (EPI_PRE) {
-                        if constexpr (sizeof(elem) == 4) xr = __builtin_bit_cast(f32x4, epi_bnx);
-                        else xr = (f32x4){__uint_as_float(epi_bnx[0] << 16), __uint_as_float(epi_bnx[0] & 0xffff0000u),
-                                          __uint_as_float(epi_bnx[1] << 16), __uint_as_float(epi_bnx[1] & 0xffff0000u)};
-                    } else if (OUT32 || sizeof(elem) == 4) {
+                    if (OUT32 || sizeof(elem) == 4) {
                         xr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff_bnx, 0, 0));
                     } else {
                         const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rs_x, voff_bnx, 0, 0);
@@ -926,12 +881,12 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
                                      __uint_as_float(r2[1] << 16), __uint_as_float(r2[1] & 0xffff0000u)};
                     }
                     const unsigned cc = col < (unsigned)nc ? col : 0u;
-                    const f32x4 mu = EPI_PRE ? epi_mu : *reinterpret_cast<const f32x4 *>(ep.bn_mean + cc);
-                    const f32x4 is = EPI_PRE ? epi_is : *reinterpret_cast<const f32x4 *>(ep.bn_invstd + cc);
+                    const f32x4 mu = *reinterpret_cast<const f32x4 *>(ep.bn_mean + cc);
+                    const f32x4 is = *reinterpret_cast<const f32x4 *>(ep.bn_invstd + cc);
                     const f32x4 xh = (xr - mu) * is;
                     if (ep.bn_relu) {
-                        const f32x4 ga = EPI_PRE ? epi_ga : *reinterpret_cast<const f32x4 *>(ep.bn_gamma + cc);
-                        const f32x4 be = EPI_PRE ? epi_be : *reinterpret_cast<const f32x4 *>(ep.bn_beta + cc);
+                        const f32x4 ga = *reinterpret_cast<const f32x4 *>(ep.bn_gamma + cc);
+                        const f32x4 be = *reinterpret_cast<const f32x4 *>(ep.bn_beta + cc);
                         const f32x4 yv = xh * ga + be;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = yv[q] > 0.f ? v[q] : 0.f;

@@ -103,3 +103,33 @@ def test_every_source_barrier_is_doda_sync():
             if re.search(r"s_barrier", code) and "s_waitcnt" not in code and "asm" in code:
                 bad.append("%s:%d (bare s_barrier in inline asm)" % (os.path.basename(f), n))
     assert not bad, bad
+
+
+def _ring_tool():
+    spec = importlib.util.spec_from_file_location("isa_ring_check", os.path.join(ROOT, "tools", "isa_ring_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_ring_analysis_sees_a_compiler_load_between_ring_loads():
+    """conv_fast's unit ring: inline-asm loads with hand-counted vmcnt waits.  A compiler-visible load sunk between two of them (round
+    6: the epilogue's operands requested in front of the loop) makes the count wrong; in front of the first / behind the last it is fine."""
+    tool = _ring_tool()
+    ring = "\tbuffer_load_dwordx4 v[22:25], v26, s[16:19], s4 offen"
+    ok = ["\tbuffer_load_dwordx2 v[46:47], v4, s[4:7], 0 offen", ring, "\tv_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[0:3]", ring,
+          "\ts_waitcnt vmcnt(0)", "\tglobal_load_dwordx4 v[14:17], v[6:7], off", "\tbuffer_store_dwordx2 v[4:5], v10, s[12:15], 0 offen"]
+    assert tool.check_kernel(ok) == []
+    bad = [ring, "\tbuffer_load_dwordx2 v[46:47], v4, s[4:7], 0 offen", ring, "\tglobal_load_dwordx4 v[14:17], v[6:7], off", ring]
+    assert [k for k, _ in tool.check_kernel(bad)] == [1, 3]
+
+
+def test_conv_fast_rings_hold_only_ring_loads():
+    """Every conv_fast instantiation of the BUILT library object (264 kernels): zero foreign vector-memory instructions inside a ring."""
+    tool = _ring_tool()
+    obj = os.path.join(ROOT, "doda_amd", "csrc", "_obj", "spconv_gather.o")
+    if not (os.path.exists(obj) and os.path.exists(tool.OBJDUMP)):
+        pytest.skip("no built object / llvm-objdump")
+    n, report = tool.check_object(obj)
+    assert n >= 100, n
+    assert report == {}, {k: v[:3] for k, v in report.items()}
