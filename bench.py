@@ -237,7 +237,7 @@ def _subm16_times(idx, shape, nb, dtype, reps):
             "fwd_bwd": {"cold": gate(True), "warm": gate(False)}, "b_f": b_f}
 
 
-PROFILE_ROUND = "r05"   # in-step / PMC evidence quoted by the bench line must come from THIS round's profiles or be absent
+PROFILE_ROUND = "r06"   # in-step / PMC evidence quoted by the bench line must come from THIS round's profiles or be absent
 # the roofline kernel's instantiation as rocprofv3 prints it (template arguments up to the ones that name the epilogue),
 # shared by the live measurement's label and the look-up in the committed kernel statistics
 ROOF_KERNEL = {"bf16": "conv_tile16<false, true>", "f32": "conv_tile<2, true, true", "f32_dense": "::PF32,"}
