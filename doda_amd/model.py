@@ -376,6 +376,18 @@ class UBlock(nn.Module):
             return None
         training = self.training
         grad = torch.is_grad_enabled() and feats.requires_grad
+        # per call (the plan is cached): a hook registered on ANY module of the subtree since then (feature taps, profilers) must
+        # fire, and a frozen parameter must not receive a gradient — both mean module by module
+        flat = self.__dict__.get("_doda_coarse_flat")
+        if flat is None:
+            flat = self.__dict__["_doda_coarse_flat"] = (list(self.modules()), list(self.parameters()))
+        for m in flat[0]:
+            if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+                return None
+        if grad:
+            for q in flat[1]:
+                if not q.requires_grad:
+                    return None
         if grad and not (training and ext.get_defer_wgrad() and ext.get_direct_grads()):
             return None
         idict = input.indice_dict

@@ -654,3 +654,47 @@ def test_backend_selection():
         assert M.choose_coarse_backend(2000, torch.bfloat16) is None
     finally:
         M.set_coarse_mode(*old)
+
+
+def test_unet_layers_yield_to_hooks_and_frozen_parameters(native_lib):
+    """The one-call subtree must step aside for a forward hook registered on any of its modules (the hook has to fire) and for a
+    frozen parameter (no gradient may be deposited): both fall back to the module-by-module path, per call — the plan is cached."""
+    from doda_amd import model as M
+    from doda_amd.model import SparseConvNet, cross_entropy, default_cfg, voxelize_and_run
+    from doda_amd.scene import make_batch
+    from doda_amd.spconv import functional as Fsp
+    from tests.util import deterministic_init
+    from doda_amd._ext import ext
+    if ext is None or not hasattr(ext, "coarse_ublock"):
+        pytest.skip("compiled extension not built")
+    d = dev()
+    cfg = default_cfg()
+    bd = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in make_batch(2, 30000, 9).items()}
+    net = deterministic_init(SparseConvNet(cfg), seed=5).to(d).train()
+    old = (M.COARSE_MODE, M.COARSE_EXEC_LEVEL)
+    M.set_coarse_mode("layers", 1)
+    try:
+        assert Fsp.set_deferred_wgrad(True)
+
+        def step():
+            net.zero_grad(set_to_none=True)
+            cross_entropy(voxelize_and_run(cfg, net, bd, d, feature_dtype=torch.bfloat16), bd["labels"]).backward()
+            torch.cuda.synchronize()
+
+        step()                                              # plan made, one call
+        seen = []
+        deep = net.unet.u.u.blocks.block0
+        h = deep.register_forward_hook(lambda m, i, o: seen.append(o.features.shape[0]))
+        step()
+        assert len(seen) == 1, seen                         # the hook fired: the subtree ran module by module
+        h.remove()
+        w = net.unet.u.blocks.block1.conv_branch[2].weight
+        w.requires_grad_(False)
+        step()
+        assert w.grad is None                               # nothing deposited into the frozen weight
+        w.requires_grad_(True)
+        step()
+        assert w.grad is not None and float(w.grad.abs().sum()) > 0
+    finally:
+        Fsp.set_deferred_wgrad(False)
+        M.set_coarse_mode(*old)

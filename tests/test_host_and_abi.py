@@ -156,3 +156,24 @@ def test_numa_pinning_helper_is_safe_without_a_gpu():
     res = host.pin_to_device_numa(0)
     assert res is None or (isinstance(res, dict) and res["cpus"] >= 1)
     assert os.sched_getaffinity(0) <= before
+
+
+def test_every_environment_switch_is_documented():
+    """dozens of DODA_* switches, the default path one point among them.  INTEGRATION.md §2c lists every variable the
+    code reads (default, class, meaning); a new getenv / os.environ read without a row fails here."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r'(?:getenv\(|env_ll\(|environ(?:\.get)?[\(\[])\s*"(DODA_[A-Z0-9_]+)"')
+    read = set()
+    files = [os.path.join(root, "bench.py")]
+    for ext in ("py", "hip", "hpp", "cpp"):
+        files += glob.glob(os.path.join(root, "doda_amd", "**", "*." + ext), recursive=True)
+    for f in files:
+        with open(f, errors="replace") as fh:
+            read.update(pat.findall(fh.read()))
+    assert len(read) > 40, sorted(read)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    section = doc[doc.index("## 2c. Environment switches"):doc.index("## 2d. Training entry point")]
+    missing = sorted(v for v in read if "`" + v + "`" not in section)
+    assert not missing, missing
