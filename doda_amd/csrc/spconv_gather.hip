@@ -105,9 +105,9 @@ __device__ __forceinline__ u32x4_t pack_wide_frag(const float *__restrict__ w, i
     for (int q = 0; q < 8; ++q) {
         const int c = cc * 32 + 8 * g + q;
         float f = 0.f;
-        if (c < kc && col < nc) {
-            if (wl == 0) f = w[((long long)o * kc + c) * nc + col];
-            else f = w[((long long)(wl == 2 ? K - 1 - o : o) * nc + col) * kc + c];
+        if (c < kc && col < nc) {   // (a weight tensor has far fewer than 2^31 elements: 32-bit indices)
+            if (wl == 0) f = w[((unsigned)o * (unsigned)kc + (unsigned)c) * (unsigned)nc + (unsigned)col];
+            else f = w[((unsigned)(wl == 2 ? K - 1 - o : o) * (unsigned)nc + (unsigned)col) * (unsigned)kc + (unsigned)c];
         }
         h[q] = f2bf(f);
     }
@@ -148,10 +148,9 @@ struct PackDesc {
 template <class T>
 __device__ __forceinline__ void pack_one(const PackDesc &d, long long e) {
     const int lane = (int)(e & 63);
-    long long r = e >> 6;
-    const int nb = (int)(r % d.NB); r /= d.NB;
-    const int cc = (int)(r % d.n_chunk);
-    const int o = (int)(r / d.n_chunk);
+    const unsigned r = (unsigned)(e >> 6), r1 = r / (unsigned)d.NB;
+    const int nb = (int)(r - r1 * (unsigned)d.NB);
+    const int o = (int)(r1 / (unsigned)d.n_chunk), cc = (int)(r1 - (unsigned)o * (unsigned)d.n_chunk);
     const int i = lane & 15, g = lane >> 4;
     const int col = nb * 16 + i;
     typename T::frag v;
@@ -177,22 +176,23 @@ __global__ __launch_bounds__(256) void pack_weights_multi(const PackDesc *__rest
     }
     const PackDesc d = descs[lo];
     const int first = lo == 0 ? 0 : blk_end[lo - 1];
-    const long long e = (long long)(blockIdx.x - first) * 256 + threadIdx.x;
+    // (32-bit index arithmetic: a tensor's fragment count is far below 2^31, and the three 64-bit divisions per thread of the first
+    // form — ~100 instructions each — were most of this kernel's 47 us for 16 bytes of output per thread)
+    const unsigned e = (unsigned)(blockIdx.x - first) * 256u + threadIdx.x;
     if (d.layout & 0x20) {  // pair packing (kc == 16): [o][nb][32 slots] = lanes 0..31 of a wide fragment
-        if (e >= (long long)d.K * d.NB * 32) return;
-        const long long r = e >> 5;
+        if (e >= (unsigned)d.K * (unsigned)d.NB * 32u) return;
+        const unsigned r = e >> 5, o = r / (unsigned)d.NB;
         reinterpret_cast<u32x4_t *>(d.out)[e] =
-            pack_wide_frag(d.w, d.K, d.kc, d.nc, d.layout & 3, (int)(r / d.NB), 0, (int)(r % d.NB), (int)(e & 31));
+            pack_wide_frag(d.w, d.K, d.kc, d.nc, d.layout & 3, (int)o, 0, (int)(r - o * (unsigned)d.NB), (int)(e & 31));
         return;
     }
-    const long long total = (long long)d.K * d.n_chunk * d.NB * 64;
+    const unsigned total = (unsigned)d.K * (unsigned)d.n_chunk * (unsigned)d.NB * 64u;
     if (e >= total) return;
     if (d.layout & 0x10) {  // wide bf16 fragments
-        long long r = e >> 6;
-        const int nb = (int)(r % d.NB); r /= d.NB;
-        const int cc = (int)(r % d.n_chunk);
+        const unsigned r = e >> 6, r1 = r / (unsigned)d.NB, nb = r - r1 * (unsigned)d.NB;
+        const unsigned o = r1 / (unsigned)d.n_chunk, cc = r1 - o * (unsigned)d.n_chunk;
         reinterpret_cast<u32x4_t *>(d.out)[e] =
-            pack_wide_frag(d.w, d.K, d.kc, d.nc, d.layout & 3, (int)(r / d.n_chunk), cc, nb, (int)(e & 63));
+            pack_wide_frag(d.w, d.K, d.kc, d.nc, d.layout & 3, (int)o, (int)cc, (int)nb, (int)(e & 63));
     } else if (d.elem_bytes == 4) pack_one<F32>(d, e);
     else pack_one<BF16>(d, e);
 }

@@ -26,5 +26,5 @@ for key in ("subm1", "subm2"):
         v = tc[:, k * 256:(k + 1) * 256].ravel()
         cnt[k] = np.unique(v[v >= 0]).size
     q = np.percentile(cnt, [50, 90, 99, 100])
-    print("%s: %d rows, %d tiles, %.1f pairs/row; distinct rows per tile p50 %d p90 %d p99 %d max %d; tiles > 960: %.2f %%, > 1023: %.2f %%, > 1216: %.2f %%" % (
-        key, m, nt, present, q[0], q[1], q[2], q[3], 100.0 * (cnt > 960).mean(), 100.0 * (cnt > 1023).mean(), 100.0 * (cnt > 1216).mean()), flush=True)
+    print("%s: %d rows, %d tiles, %.1f pairs/row; distinct rows per tile p50 %d p90 %d p99 %d max %d; tiles > 640: %.2f %%, > 704: %.2f %%, > 960: %.2f %%, > 1023: %.2f %%, > 1216: %.2f %%" % (
+        key, m, nt, present, q[0], q[1], q[2], q[3], 100.0 * (cnt > 640).mean(), 100.0 * (cnt > 704).mean(), 100.0 * (cnt > 960).mean(), 100.0 * (cnt > 1023).mean(), 100.0 * (cnt > 1216).mean()), flush=True)
