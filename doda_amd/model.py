@@ -217,8 +217,9 @@ class VGGBlock(SparseModule):
 # with the per-layer launches issued from inside the library it lost at every batch size (4.30 against 4.05-4.28 ms at the host
 # floor, 7.35 against 4.81 at the bench size).
 # ABI 12: the op list takes ANY level (a GEMM op carries its table's tilebook, the LDS-staged kernels write column slices), so the
-# default subtree is the whole U-Net: one extension call forward, one autograd node backward, no interpreter between the ~110 + ~170
-# launches of a step's convolutions and BatchNorms, the three remaining torch.cat and their gradient slices gone.
+# default subtree is the whole U-Net: one extension call forward, one autograd node backward, no interpreter between the 99 + 134
+# launches of a step's convolutions and BatchNorms, the three remaining torch.cat and their gradient slices gone (4.61 -> 4.53 ms,
+# host floor 4.1 -> 2.1 ms per step).
 COARSE_MODE = _os.environ.get("DODA_COARSE_MODE", "layers")
 COARSE_EXEC_LEVEL = int(_os.environ.get("DODA_COARSE_LEVEL", "1"))
 COARSE_LAYERS_MAX_ROWS = int(_os.environ.get("DODA_COARSE_LAYERS_MAX_ROWS", str(1 << 23)))
