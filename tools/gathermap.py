@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 env = dict(os.environ, DODA_TRACE_GATHER="1")
 steps, warm = 4, 2
 r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warm), "--fp32-steps", "0",
-                    "--no-cpu-baseline", "--kernel-reps", "0"], env=env, capture_output=True, text=True)
+                    "--no-cpu-baseline", "--kernel-reps", "0", "--no-train-entry", "--config5-steps", "0", "--refgraph-steps", "0"], env=env, capture_output=True, text=True)
 c = collections.Counter(l for l in r.stderr.split("\n") if l.startswith("doda_gather"))
 tot = steps + warm
 for line, n in sorted(c.items(), key=lambda kv: (-int(kv[0].split("n_out=")[1].split()[0]), kv[0])):
