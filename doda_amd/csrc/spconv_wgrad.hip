@@ -338,27 +338,30 @@ __global__ __launch_bounds__(256) void wgrad_multi_kernel(const WJob *__restrict
                                     d.out, (int)blockIdx.x - first);
 }
 
-// 16 element quads x 16 chunk lanes per block, fixed order (as wgrad_reduce4<16>)
+// (256 / RL) element quads x RL chunk lanes per block, fixed order (as wgrad_reduce4<16>): lane r sums chunks r, r + RL, ..., the
+// lane sums are added in ascending r.  RL = d.pad = the smallest power of two >= min(R, 16) (round 6; it was 16 for every job: the
+// coarse levels' jobs have 1 .. 4 chunks, so 3/4 .. 15/16 of a block's threads had nothing to read and a 7.5 M-parameter network
+// took 117 k blocks of 256 bytes each).  For R <= 16 every lane holds at most one chunk either way: the same sums, bit for bit.
 __global__ __launch_bounds__(256) void wgrad_reduce_multi(const RJob *__restrict__ jobs, int n_jobs) {
-    __shared__ float4 part[16][16];
+    __shared__ float4 part[256];
     const int j = find_job(jobs, n_jobs, (int)blockIdx.x);
     const RJob d = jobs[j];
     const int first = j == 0 ? 0 : jobs[j - 1].blk_end;
-    const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const long long q = (long long)((int)blockIdx.x - first) * 16 + el;
+    const int RL = d.pad, EL = 256 / RL;                 // RL in {1, 2, 4, 8, 16}
+    const int el = (int)threadIdx.x % EL, rl = (int)threadIdx.x / EL;
+    const long long q = (long long)((int)blockIdx.x - first) * EL + el;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < d.n_quad)
-        for (int r = rl; r < d.R; r += 16) {
+        for (int r = rl; r < d.R; r += RL) {
             const float4 v = d.partial[(long long)r * d.n_quad + q];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-    part[rl][el] = s;
+    part[rl * EL + el] = s;
     doda_sync();
     if (rl == 0 && q < d.n_quad) {
-        float4 t = part[0][el];
-#pragma unroll 4
-        for (int r = 1; r < 16; ++r) {
-            const float4 v = part[r][el];
+        float4 t = part[el];
+        for (int r = 1; r < RL; ++r) {
+            const float4 v = part[r * EL + el];
             t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
         }
         if (d.accumulate) {
@@ -656,7 +659,10 @@ extern "C" int doda_spconv_wgrad_multi(const doda_wgrad_job *jobs_h, int32_t n_j
         d.R = plans[k].p.R;
         d.accumulate = (jobs_h[k].flags & DODA_WGRAD_ACCUMULATE) ? 1 : 0;
         d.pad = 0;
-        r_blocks += (int)div_up(d.n_quad, 16);
+        int rl = 1;
+        while (rl < 16 && rl < d.R) rl *= 2;
+        d.pad = rl;                                        // chunk lanes per block (wgrad_reduce_multi)
+        r_blocks += (int)div_up(d.n_quad, 256 / rl);
         d.blk_end = r_blocks;
         rj.push_back(d);
     }
