@@ -698,3 +698,80 @@ def test_unet_layers_yield_to_hooks_and_frozen_parameters(native_lib):
     finally:
         Fsp.set_deferred_wgrad(False)
         M.set_coarse_mode(*old)
+
+
+@pytest.mark.parametrize("kernel", ["conv_tile16", "conv_tile", "conv_tile_dual", "conv_wlds48", "conv_up32"])
+@pytest.mark.parametrize("form", ["forward", "data_grad"])
+def test_lds_staged_kernels_take_strided_output_operands(native_lib, kernel, form):
+    """ABI 12: the LDS-staged kernels write y, read the residual and read the BatchNorm input of the data-gradient statistics through
+    row strides (the halves of a level's concatenation, in place: reference model/unet_block.py:89-93).  Every kernel, forward form
+    (residual + statistics of y) and data-gradient form (ReLU mask and statistics against a BatchNorm input): the strided call must
+    give the dense call's bits in the slice, the same totals, and must not touch the other columns of the wide matrices."""
+    from doda_amd import ops
+    d = dev()
+    spec = {"conv_tile16": (27, 16, 16, 200000), "conv_tile": (27, 16, 16, 60000), "conv_tile_dual": (27, 32, 32, 60000),
+            "conv_wlds48": (27, 48, 48, 20000), "conv_up32": (8, 32, 16, 60000)}[kernel]
+    K, cin, cout, n_req = spec
+    idx, shape, batch = _level(1234 + n_req + cin, n_req)
+    n = idx.shape[0]
+    g = torch.Generator().manual_seed(n + cout)
+    tb = None
+    if K == 27:
+        tbl = _tables(ops, idx, shape, batch, d)
+        tbl = tbl[0] if isinstance(tbl, (tuple, list)) else tbl
+        rows_in = n
+        if kernel != "conv_wlds48":
+            tb = ops.tilebook_build(tbl)
+            assert tb is not None
+    else:
+        outids, child, par_off = ops.rulebook_down2(torch.from_numpy(idx).to(d), shape, batch)[:3]
+        tbl, rows_in = par_off, outids.shape[0]          # coarse -> fine: one source row per output row
+        assert rows_in < n
+    assert tbl.shape == (K, n)
+    x = _bf(torch.randn(rows_in, cin, generator=g)).to(d)
+    w = (torch.randn(K, cin, cout, generator=g) * (1.0 / (cin * 6)) ** 0.5).to(d)
+    wp = _pack(w, K, cin, cout, 0, d)
+    wide = 2 * cout + 16
+    res_d = _bf(torch.randn(n, cout, generator=g)).to(d)
+    aux_d = _bf(torch.randn(n, cout, generator=g)).to(d)
+    mean, invstd = torch.randn(cout, generator=g).to(d) * 0.1, (torch.rand(cout, generator=g) + 0.5).to(d)
+    gamma, beta = (torch.rand(cout, generator=g) + 0.5).to(d), torch.randn(cout, generator=g).to(d) * 0.2
+
+    def run(strided):
+        if strided:
+            ybuf = torch.full((n, wide), 7.0, dtype=torch.bfloat16, device=d)
+            rbuf = torch.full((n, wide), -3.0, dtype=torch.bfloat16, device=d)
+            abuf = torch.full((n, wide), 5.0, dtype=torch.bfloat16, device=d)
+            y, res, aux = ybuf[:, cout:2 * cout], rbuf[:, 16:16 + cout], abuf[:, wide - cout:]
+            res.copy_(res_d); aux.copy_(aux_d)
+        else:
+            ybuf = torch.zeros((n, cout), dtype=torch.bfloat16, device=d)
+            y, res, aux, rbuf, abuf = ybuf, res_d, aux_d, None, None
+        st = ops.stats_totals(cout, d)
+        op = dict(kind=ops.CX_GEMM, flags=0, rows=n, rows_in=rows_in, c_in=cin, c_out=cout, K=K, tbl_ld=tbl.shape[1], x_ld=cin,
+                  y_ld=ybuf.shape[1], x=x, w=wp, tbl=tbl, y=y, stats=st)
+        if tb is not None:
+            op["tilebook"] = tb.data_ptr()
+        if form == "forward":
+            op.update(res=res, res_ld=res.stride(0))
+        else:
+            op.update(flags=ops.CX_F_RELU, aux=aux, aux_ld=aux.stride(0), mean=mean, invstd=invstd, gamma=gamma, beta=beta)
+        assert ops.layers_run([op], d) == 1
+        torch.cuda.synchronize()
+        return y.clone(), ops.totals_sums(st).clone(), ybuf, rbuf, abuf
+
+    y0, s0, _, _, _ = run(False)
+    y1, s1, ybuf, rbuf, abuf = run(True)
+    assert float(y0.float().abs().max()) > 0.1
+    assert torch.equal(y0, y1)
+    assert torch.allclose(s0, s1, rtol=1e-12, atol=1e-9)
+    assert float(s0.abs().max()) > 0
+    keep = torch.ones(wide, dtype=torch.bool, device=d)
+    keep[cout:2 * cout] = False
+    assert bool((ybuf[:, keep] == 7.0).all())
+    assert bool((rbuf[:, :16] == -3.0).all()) and bool((rbuf[:, 16 + cout:] == -3.0).all())
+    assert bool((abuf[:, :wide - cout] == 5.0).all())
+    # and the dense call is the module path's kernel: against ops.spconv_gather on the same operands
+    ref = ops.spconv_gather(x, w, tbl, n, 0, cout, packed=wp, tilebook=tb, residual=res_d if form == "forward" else None)
+    ref = ref[0] if isinstance(ref, (tuple, list)) else ref
+    assert torch.equal(ref, y0)
