@@ -406,7 +406,7 @@ def test_gemm_backward_epilogue_vs_definition(native_lib, oracle, n, c):
         assert torch.allclose(sums[1], (zf * xh.double()).sum(0), rtol=1e-4, atol=1e-3 * float(zf.abs().max()))
 
 
-@pytest.mark.parametrize("n,c", LEVELS[1:])
+@pytest.mark.parametrize("n,c", LEVELS[1:] + [(300007, 8), (150001, 16), (70001, 24)])
 def test_batchnorm_ops_vs_torch(native_lib, n, c):
     """STATS -> BNFWD (training, incl. the two-segment form of a concatenation, running statistics) and BNBWD (with the added skip
     gradient and the split output) as launches of their own against torch.nn.functional.batch_norm + autograd in fp32."""
@@ -438,6 +438,16 @@ def test_batchnorm_ops_vs_torch(native_lib, n, c):
     assert torch.allclose(rm, rm_ref, rtol=1e-4, atol=1e-5) and torch.allclose(rv, rv_ref, rtol=1e-4, atol=1e-5)
     assert int(nbt) == 1
     assert torch.allclose(mean, xf.detach().mean(0), rtol=1e-4, atol=1e-5)
+    # the same op writing a column slice of a wider matrix (ABI 12: the fine levels take this form too — lay_bn's strided sweep,
+    # where the dense form of many rows goes to bn.hip's kernels)
+    wide = torch.full((n, C2 + 16), 9.0, dtype=torch.bfloat16, device=d)
+    m2, i2 = torch.zeros(C2, device=d), torch.zeros(C2, device=d)
+    ops.layers_run([dict(kind=ops.CX_BNFWD, flags=ops.CX_F_RELU | ops.CX_F_TRAINING, rows=n, c_in=C2, x_ld=C2, y_ld=C2 + 16, c_split=c, eps=1e-4,
+                         momentum=0.1, x=x, y=wide[:, 16:], stats=sa, stats_b=sb, gamma=gamma, beta=beta, mean=m2, invstd=i2,
+                         running_mean=torch.zeros(C2, device=d), running_var=torch.ones(C2, device=d))], d)
+    torch.cuda.synchronize()
+    assert _scale_err(wide[:, 16:].float(), y_ref.detach()) < 2.0 ** -7 and bool((wide[:, :16] == 9.0).all())
+    assert torch.equal(m2, mean) and torch.equal(i2, invstd)
     # backward: the unmasked gradient as the data-grad GEMM stores it, the totals of its masked values as that GEMM's epilogue leaves them
     dy = _bf(torch.randn(n, C2, generator=g)).to(d)
     add = _bf(torch.randn(n, C2, generator=g)).to(d)
