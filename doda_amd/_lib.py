@@ -54,6 +54,7 @@ _SIGNATURES = {
     "doda_maxpool_fwd_f32": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "doda_maxpool_bwd_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "doda_cross_entropy_workspace_bytes": (c_sz, [c_i32]),
+    "doda_seg_meters": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, C.c_int64, c_vp, c_vp]),
     "doda_cross_entropy_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, C.c_int64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "doda_cross_entropy_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, C.c_int64, c_vp, c_vp]),
     "doda_tilebook_tile": (c_i32, []),

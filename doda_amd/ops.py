@@ -814,6 +814,26 @@ def ballquery_batch_p(xyz, batch_idxs, batch_offsets, idx, start_len, n, mean_ac
 # ------------------------------------------------------------------------------------------
 # loss
 # ------------------------------------------------------------------------------------------
+def seg_meters(hist, preds, labels, n_classes, ignore_index, p2v=None):
+    """hist int64 [3, k] += (intersection, prediction area, target area) of the points (doda_seg_meters; reference
+    util/common_utils.py:233-246).  preds: int32 / int64 class per point, or per VOXEL with p2v (int32 [N]) mapping points to voxels."""
+    _need_cuda(preds)
+    _need_cuda(labels)
+    if (hist.dtype != torch.int64 or not hist.is_contiguous() or tuple(hist.shape) != (3, int(n_classes)) or labels.dtype != torch.int64
+            or preds.dtype not in (torch.int32, torch.int64) or (p2v is not None and p2v.dtype != torch.int32)):
+        raise RuntimeError("seg_meters: hist int64 [3,k], labels int64 [N], preds int32|int64, p2v int32")
+    preds, labels = preds.contiguous(), labels.contiguous()
+    if p2v is not None:
+        _need_cuda(p2v)
+        p2v = p2v.contiguous()
+    n = labels.shape[0]
+    if (p2v.shape[0] if p2v is not None else preds.shape[0]) != n:
+        raise RuntimeError("seg_meters: one prediction (or one p2v entry) per label")
+    check(lib().doda_seg_meters(_p(preds), 1 if preds.dtype == torch.int64 else 0, _p(p2v) if p2v is not None else None, _p(labels),
+                                n, int(n_classes), int(ignore_index), _p(hist), _stream()), "doda_seg_meters")
+    return hist
+
+
 def cross_entropy_fwd(logits, labels, ignore_index):
     """-> (out float32 [2] = {mean loss over valid points, n_valid}, lse float32 [N])."""
     _need_cuda(logits)

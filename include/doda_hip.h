@@ -589,6 +589,14 @@ int doda_sgd_multi(const doda_sgd_tensor *tensors_h, int32_t n_tensors, double l
                    double dampening, double weight_decay, int32_t nesterov, int32_t maximize, void *desc_dev,
                    size_t desc_bytes, doda_stream_t stream);
 
+/* ABI 12.  Segmentation meters — reference util/common_utils.py:233-246 intersectionAndUnionGPU (per iteration through update_meter,
+ * :249; tool/test.py:82): hist[0][c] += valid points with pred == label == c, hist[1][c] += valid points predicted c, hist[2][c] +=
+ * valid points labelled c (union = hist[1] + hist[2] - hist[0]); valid: label != ignore_index and 0 <= label < k; a point's
+ * prediction is preds[p2v ? p2v[p] : p] (int32, or int64 with preds_are_int64) clamped to [0, k - 1].  hist: int64 [3][k],
+ * ACCUMULATED (zero it once); k <= 256.  One launch, integer atomics: exact and order-independent. */
+int doda_seg_meters(const void *preds, int32_t preds_are_int64, const int32_t *p2v, const int64_t *labels, int32_t n, int32_t k,
+                    int64_t ignore_index, int64_t *hist, doda_stream_t stream);
+
 /* ---- ABI 11 (ABI 12: any level — a GEMM op may carry its table's tilebook): U-Net levels as an op list of per-layer launches (csrc/layers.hip) ----------------------------------------
  * The levels of DODA's U-Net (ABI 11: the deep ones; ABI 12: any, from the root UBlock down) — reference model/unet_block.py:55-100 (UBlock: blocks -> strided conv -> UBlock -> inverse conv
  * -> concatenation -> blocks_tail) with model/unet_block.py:9-37 inside (ResidualBlock: BatchNorm1d -> ReLU -> SubMConv3d, twice,

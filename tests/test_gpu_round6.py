@@ -233,3 +233,29 @@ def test_training_step_with_voxel_level_head_equals_matrix_head(native_lib):
     assert float((p1 != p0).float().mean()) < 1e-4
     for k in g0:
         assert float((g1[k] - g0[k]).norm()) <= 2e-3 * float(g0[k].norm()) + 1e-9, k
+
+
+@pytest.mark.parametrize("voxel_level", [False, True])
+def test_segmentation_meters_kernel_equals_the_torch_form(native_lib, voxel_level):
+    """doda_seg_meters (reference util/common_utils.py:233-246 intersectionAndUnionGPU's three histograms, one launch) against the
+    fixed-shape torch form of doda_amd.train.DeviceMeters on CPU copies: ignored labels, labels and predictions out of range, int32
+    per-voxel predictions through p2v and int64 per-point predictions; accumulation over two calls; mIoU read-back equal."""
+    from doda_amd.train import DeviceMeters
+    d = dev()
+    k, n, m = 20, 200003, 150001
+    g = torch.Generator().manual_seed(5 + voxel_level)
+    labels = torch.randint(-2, k + 2, (n,), generator=g)
+    labels[::13] = 255
+    if voxel_level:
+        preds = torch.randint(-1, k + 1, (m,), generator=g, dtype=torch.int32)
+        p2v = torch.randint(0, m, (n,), generator=g, dtype=torch.int32)
+    else:
+        preds, p2v = torch.randint(-1, k + 1, (n,), generator=g), None
+    loss = torch.tensor(0.5)
+    ref, got = DeviceMeters(k, 255, torch.device("cpu")), DeviceMeters(k, 255, d)
+    for _ in range(2):
+        ref.update(loss, preds, labels, p2v=p2v)
+        got.update(loss.to(d), preds.to(d), labels.to(d), p2v=p2v.to(d) if p2v is not None else None)
+    torch.cuda.synchronize()
+    assert int(ref.cnt.sum()) > 0 and torch.equal(ref.cnt, got.cnt.cpu())
+    assert ref.read()[:4] == got.read()[:4]
