@@ -15,6 +15,7 @@
 #include <c10/hip/HIPGuard.h>
 #include <unordered_map>
 #include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPCachingAllocator.h>
 #include <hip/hip_runtime_api.h>
 
 #include <cstring>
@@ -1974,7 +1975,17 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                   at::Tensor &slot = const_cast<at::Tensor &>(params[k]).mutable_grad();
                   const at::Tensor &v = views[k];
                   if (!slot.defined()) const_cast<at::Tensor &>(v).zero_();
-                  else if (slot.data_ptr() != v.data_ptr() || slot.strides() != v.strides()) const_cast<at::Tensor &>(v).copy_(slot);
+                  else if (slot.data_ptr() != v.data_ptr() || slot.strides() != v.strides()) {
+                      const_cast<at::Tensor &>(v).copy_(slot);
+                      // (round 6) the copy runs on the CURRENT stream — the reducer's side stream — while the stray gradient was
+                      // allocated on the backward pass's stream: dropping it below hands its block back to THAT stream's pool at
+                      // once, and the backward pass still running there (the early exchange) or the next step could overwrite it
+                      // before the copy has read it.  Seen as a two-rank test failing once in ~30 runs: linear.bias (a gradient
+                      // torch's AccumulateGrad makes, not one deposited in its bucket) off by half.
+                      // (the allocator's own entry point: Tensor::record_stream wants a stream of the tensor's masqueraded device type)
+                      if (slot.is_cuda() && slot.has_storage())
+                          c10::hip::HIPCachingAllocator::recordStream(slot.storage().data_ptr(), c10::hip::getCurrentHIPStream(slot.device().index()));
+                  }
                   else continue;
                   slot = v;
                   ++moved;

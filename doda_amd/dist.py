@@ -106,6 +106,8 @@ class _Bucket:
                 v.zero_()
             elif g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
                 v.copy_(g)
+                if g.is_cuda:      # (the copy may run on a side stream: the block must not go back to its own stream's pool before it)
+                    g.record_stream(torch.cuda.current_stream(g.device))
             else:
                 continue
             p.grad = v
