@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void conv_fast(const typename P::elem *__restr
     // (round 6, tried and REMOVED: requesting the epilogue's operands — residual row, BatchNorm input and vectors — here, in front of
     // the unit loop of the 16-row split blocks.  8.4 -> 8.2 us per launch, and unsafe: the ring below is inline asm whose loads hipcc
     // does not see; it sank the compiler-visible requests BETWEEN ring loads in one instantiation (PBF16P, statistics), which breaks the
-    // hand-counted vmcnt waits — a two-rank gradient test caught the resulting race once in three runs.  Every compiler-visible vector
+    // hand-counted vmcnt waits (found in the ISA while chasing a flaky two-rank test whose cause turned out to be elsewhere).  Every compiler-visible vector
     // load of this kernel must be consumed before the first asm load or issued after the ring has drained.)
     const int n_units = PAIR ? (__builtin_popcount(active) + 1) / 2 : __builtin_popcount(active) * n_chunk;
     if (n_units > 0) {

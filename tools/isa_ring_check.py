@@ -7,7 +7,7 @@ outstanding vector-memory instruction IS a ring load.  hipcc may move an ordinar
 pointer dereference) across `asm volatile` statements — they carry no memory clobber — so a request placed in front of the loop and
 consumed behind it can be sunk between ring loads: the count is then off by one and a unit is consumed before it has arrived.  Round 6
 did exactly that (the epilogue's operands requested early: one instantiation, PBF16P with statistics, got them between ring loads; a
-two-rank gradient test failed once in three runs) and removed it again.
+found in the disassembly while a flaky two-rank test was being chased — its cause was elsewhere) and removed it again.
 
 The check works on the built object (doda_amd/csrc/_obj/spconv_gather.o, no GPU needed): per conv_fast kernel, ring loads are the
 buffer loads with a scalar-register soffset (every compiler-visible buffer access of that file passes the literal 0), and between the
