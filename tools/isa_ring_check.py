@@ -6,7 +6,7 @@ hand-placed `s_waitcnt vmcnt((D-1) L)`: "at most (D-1) L loads outstanding" mean
 outstanding vector-memory instruction IS a ring load.  hipcc may move an ordinary load (a `__builtin_amdgcn_raw_buffer_load_*`, a
 pointer dereference) across `asm volatile` statements — they carry no memory clobber — so a request placed in front of the loop and
 consumed behind it can be sunk between ring loads: the count is then off by one and a unit is consumed before it has arrived.  Round 6
-did exactly that (the epilogue's operands requested early: one instantiation, PBF16P with statistics, got them between ring loads; a
+did exactly that (the epilogue's operands requested early: one instantiation, PBF16P with statistics, got them between ring loads —
 found in the disassembly while a flaky two-rank test was being chased — its cause was elsewhere) and removed it again.
 
 The check works on the built object (doda_amd/csrc/_obj/spconv_gather.o, no GPU needed): per conv_fast kernel, ring loads are the
